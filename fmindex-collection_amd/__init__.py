@@ -1,0 +1,319 @@
+"""fmindex-collection_amd — MI355X-native backward-search engine (host-side Python mirror over the C-ABI).
+
+The product is libfmgpu.so (hand-written HIP for gfx950, include/fmgpu.h); this package is the thin Python
+host layer used by the tests and bench.py.  It mirrors the reference's names for the hot path:
+FMIndex / BiFMIndex (fmindex/FMIndex.h, fmindex/BiFMIndex.h), search_no_errors.search (search/SearchNoErrors.h),
+search_backtracking.search (search/Backtracking.h), search_ng26.search (search/SearchNg26.h), LocateLinear
+(locate.h), search_scheme.* (search_scheme/).  The C++ mirror of the template API is include/fmc_gpu.hpp.
+
+There is no CPU fallback anywhere in this package: without libfmgpu.so and a GPU every compute call raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import FmgpuError, DeviceBuffer, LAYOUTS, UINT64_MAX, HIT_DTYPE
+from . import search_scheme  # noqa: F401
+
+__all__ = ["FMIndex", "BiFMIndex", "search_no_errors", "search_backtracking", "search_ng26", "search", "LocateLinear",
+           "search_scheme", "FmgpuError", "DeviceBuffer", "flatten", "device_count"]
+
+
+def device_count():
+    n = C.c_int()
+    capi.check(capi.lib().fmgpu_device_count(C.byref(n)))
+    return n.value
+
+
+def flatten(sequences):
+    """Sequences (list of byte sequences) -> (qbuf uint8[total], qoff uint64[nq+1]) — the ABI's query format"""
+    lens = np.fromiter((len(q) for q in sequences), dtype=np.uint64, count=len(sequences))
+    qoff = np.zeros(len(sequences) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=qoff[1:])
+    total = int(qoff[-1])
+    qbuf = np.zeros(max(total, 1), dtype=np.uint8)
+    if total:
+        qbuf[:total] = np.concatenate([np.asarray(q, dtype=np.uint8) for q in sequences if len(q)])
+    return qbuf, qoff
+
+
+def _u64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+class _StringArrays:
+    """host arrays of one reference String object, kept alive while the descriptor is in use"""
+
+    def __init__(self, layout, sigma, n, blocks=None, super_blocks=None, nodes=None):
+        self.layout, self.sigma, self.n = layout, sigma, n
+        self.blocks = None if blocks is None else np.ascontiguousarray(blocks).view(np.uint8)
+        self.super_blocks = None if super_blocks is None else _u64(super_blocks).reshape(-1)
+        self.nodes = nodes  # list of (superblocks u64, blocks u8, bits u64, total_length)
+        self._node_arr = None
+
+    def desc(self):
+        d = capi.StringDesc()
+        d.layout = LAYOUTS[self.layout]
+        d.sigma = self.sigma
+        d.n = self.n
+        if self.blocks is not None:
+            d.blocks = self.blocks.ctypes.data
+            d.blocks_bytes = self.blocks.nbytes
+            d.super_blocks = self.super_blocks.ctypes.data_as(capi.u64p)
+            d.n_super_blocks = self.super_blocks.size // self.sigma
+        if self.nodes is not None:
+            arr = (capi.WaveletNode * len(self.nodes))()
+            keep = []
+            for k, (sb, bl, bits, total) in enumerate(self.nodes):
+                sb, bl, bits = _u64(sb), np.ascontiguousarray(bl, dtype=np.uint8), _u64(bits)
+                keep.append((sb, bl, bits))
+                arr[k].superblocks = sb.ctypes.data_as(capi.u64p); arr[k].n_superblocks = sb.size
+                arr[k].blocks = bl.ctypes.data_as(capi.u8p); arr[k].n_blocks = bl.size
+                arr[k].bits = bits.ctypes.data_as(capi.u64p); arr[k].n_bits = bits.size
+                arr[k].total_length = int(total)
+            self._node_arr, self._keep = arr, keep
+            d.nodes = arr
+            d.n_nodes = len(self.nodes)
+        return d
+
+
+class FMIndex:
+    """fmindex/FMIndex.h:14-134 (bidirectional=False) / fmindex/BiFMIndex.h:17-216 (BiFMIndex subclass), resident in HBM.
+
+    Construct from the arrays a reference index object holds (`from_reference_arrays`) or from sequences with the
+    GPU builder (`from_sequences`, replaces the libsais-based constructor fmindex/FMIndex.h:58-104)."""
+
+    bidirectional = False
+
+    def __init__(self, handle, keep=None, built=None):
+        self._h = handle
+        self._keep = keep
+        self._built = built
+        n, sigma, layout, bidir, dbytes = C.c_uint64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()
+        capi.check(capi.lib().fmgpu_index_info(self._h, C.byref(n), C.byref(sigma), C.byref(layout), C.byref(bidir), C.byref(dbytes)))
+        self.n, self.Sigma, self.layout, self.device_bytes = n.value, sigma.value, capi.LAYOUT_NAMES[layout.value], dbytes.value
+        self.bidirectional = bool(bidir.value)
+
+    # -------------------------------------------------------------- construction
+    @classmethod
+    def from_reference_arrays(cls, bwt, C_array, bwt_rev=None, sparse=None):
+        """bwt / bwt_rev: dict(layout, sigma, n, blocks, super_blocks | nodes); sparse: dict(n, l0, l1, bits, fields[2])"""
+        sa = _StringArrays(**bwt)
+        desc = capi.IndexDesc()
+        desc.bwt = sa.desc()
+        keep = [sa]
+        if bwt_rev is not None:
+            sr = _StringArrays(**bwt_rev)
+            rdesc = sr.desc()
+            desc.bwt_rev = C.pointer(rdesc)
+            keep += [sr, rdesc]
+        Carr = _u64(C_array)
+        desc.C = Carr.ctypes.data_as(capi.u64p)
+        keep.append(Carr)
+        if sparse is not None:
+            sd = capi.SparseArrayDesc()
+            l0, l1, bits = _u64(sparse["l0"]), np.ascontiguousarray(sparse["l1"], dtype=np.uint16), _u64(sparse["bits"])
+            sd.n = sparse["n"]
+            sd.l0 = l0.ctypes.data_as(capi.u64p); sd.n_l0 = l0.size
+            sd.l1 = l1.ctypes.data_as(capi.u16p); sd.n_l1 = l1.size
+            sd.bits = bits.ctypes.data_as(capi.u64p); sd.n_bit_words = bits.size
+            keep += [l0, l1, bits]
+            for f in range(2):
+                fd = sparse["fields"][f]
+                data = _u64(fd["data"])
+                keep.append(data)
+                sd.field[f].data = data.ctypes.data_as(capi.u64p); sd.field[f].n_words = data.size
+                sd.field[f].bit_count = int(fd["bitCount"]); sd.field[f].bits = int(fd["bits"])
+                sd.field[f].largest_value = int(fd["largestValue"]); sd.field[f].common_divisor = int(fd["commonDivisor"])
+            desc.annotated_array = C.pointer(sd)
+            keep.append(sd)
+        h = C.c_void_p()
+        capi.check(capi.lib().fmgpu_index_create(C.byref(desc), C.byref(h)))
+        return cls(h, keep=None)   # the library copied everything; host arrays may go
+
+    @classmethod
+    def from_sequences(cls, sequences, sigma, layout="IB16", sampling_rate=16, bidirectional=None, keep_host=False):
+        """GPU construction from Sequences (list of rank sequences, or (qbuf, qoff) already flattened / resident in HBM)"""
+        if bidirectional is None:
+            bidirectional = cls.bidirectional
+        if isinstance(sequences, tuple):
+            sbuf, soff = sequences
+            nseq = (len(soff) if not isinstance(soff, DeviceBuffer) else soff.nbytes // 8) - 1
+        else:
+            sbuf, soff = flatten(sequences)
+            nseq = len(sequences)
+        h, b = C.c_void_p(), C.c_void_p()
+        capi.check(capi.lib().fmgpu_build_index(capi.ptr(sbuf), capi.ptr(soff), nseq, sigma, LAYOUTS[layout], sampling_rate,
+                                                1 if bidirectional else 0, 1 if keep_host else 0, C.byref(h),
+                                                C.byref(b) if keep_host else None))
+        return cls(h, built=b if keep_host else None)
+
+    def built_array(self, part, dtype=np.uint8):
+        """host copy of a construction by-product (keep_host=True): 0 = BWT bytes, 1 = BWT of the reversed text, 2 = C"""
+        if not self._built:
+            raise ValueError("index was not built with keep_host=True")
+        p, nb = C.c_void_p(), C.c_uint64()
+        capi.check(capi.lib().fmgpu_built_get(self._built, part, C.byref(p), C.byref(nb)))
+        if nb.value == 0:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_uint8 * nb.value).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype)
+
+    def close(self):
+        if getattr(self, "_built", None):
+            capi.lib().fmgpu_built_free(self._built)
+            self._built = None
+        if getattr(self, "_h", None):
+            capi.lib().fmgpu_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return self.n
+
+    # -------------------------------------------------------------- String_c batch (string/concepts.h:25-87)
+    def _string_query(self, which, idx, symb, what):
+        idx = _u64(idx)
+        symb = np.ascontiguousarray(np.broadcast_to(np.asarray(symb, dtype=np.uint8), idx.shape))
+        what = np.ascontiguousarray(np.broadcast_to(np.asarray(what, dtype=np.uint8), idx.shape))
+        out = np.empty(idx.shape, dtype=np.uint64)
+        capi.check(capi.lib().fmgpu_string_query(self._h, which, capi.ptr(idx), capi.ptr(symb), capi.ptr(what), idx.size,
+                                                 capi.ptr(out), None))
+        return out
+
+    def rank(self, idx, symb, rev=False):
+        return self._string_query(1 if rev else 0, idx, symb, 0)
+
+    def prefix_rank(self, idx, symb, rev=False):
+        return self._string_query(1 if rev else 0, idx, symb, 1)
+
+    def symbol(self, idx, rev=False):
+        return self._string_query(1 if rev else 0, idx, 0, 2)
+
+    # -------------------------------------------------------------- locate (fmindex/FMIndex.h:113-124)
+    def locate(self, rows, want_stats=False):
+        rows = _u64(rows)
+        seq, pos, steps = (np.empty(rows.shape, dtype=np.uint64) for _ in range(3))
+        st = capi.Stats()
+        capi.check(capi.lib().fmgpu_locate(self._h, capi.ptr(rows), rows.size, capi.ptr(seq), capi.ptr(pos), capi.ptr(steps),
+                                           C.byref(st) if want_stats else None, None))
+        return (seq, pos, steps, st) if want_stats else (seq, pos, steps)
+
+
+class BiFMIndex(FMIndex):
+    bidirectional = True
+
+
+def _queries(queries):
+    if isinstance(queries, tuple):
+        qbuf, qoff = queries
+        nq = (qoff.nbytes // 8 if isinstance(qoff, DeviceBuffer) else len(qoff)) - 1
+        return qbuf, qoff, nq
+    qbuf, qoff = flatten(queries)
+    return qbuf, qoff, len(queries)
+
+
+class search_no_errors:
+    """search/SearchNoErrors.h"""
+
+    @staticmethod
+    def search(index, queries, out=None, want_stats=False):
+        """returns (lb, len) arrays — cursor_t{lb, len} per query (len == 0: the reference reports nothing).
+        `queries` = list of sequences or (qbuf, qoff); numpy arrays or DeviceBuffers.  `out` = (lb, len) DeviceBuffers
+        to keep results in HBM."""
+        qbuf, qoff, nq = _queries(queries)
+        if out is None:
+            lb, ln = np.empty(nq, dtype=np.uint64), np.empty(nq, dtype=np.uint64)
+        else:
+            lb, ln = out
+        st = capi.Stats()
+        capi.check(capi.lib().fmgpu_search_exact(index._h, capi.ptr(qbuf), capi.ptr(qoff), nq, capi.ptr(lb), capi.ptr(ln),
+                                                 C.byref(st) if want_stats else None, None))
+        return (lb, ln, st) if want_stats else (lb, ln)
+
+
+def _run_hits(call, capacity):
+    while True:
+        out = np.zeros(max(capacity, 1), dtype=HIT_DTYPE)
+        cnt = C.c_uint64()
+        st = capi.Stats()
+        rc = call(out, capacity, cnt, st)
+        if rc == capi.FMGPU_ERR_CAPACITY:
+            capacity = int(cnt.value)
+            continue
+        capi.check(rc)
+        hits = out[: cnt.value]
+        # the reference invokes the delegate in ascending qidx, inside a query in DFS order: (qidx, seq) restores it
+        order = np.lexsort((hits["seq"], hits["qidx"]))
+        return hits[order], st
+
+
+class search_backtracking:
+    """search/Backtracking.h"""
+
+    @staticmethod
+    def search(index, queries, max_errors, capacity=None, want_stats=False):
+        qbuf, qoff, nq = _queries(queries)
+        cap = capacity if capacity is not None else max(1024, 4 * nq)
+        hits, st = _run_hits(lambda out, c, cnt, st: capi.lib().fmgpu_search_backtracking(
+            index._h, capi.ptr(qbuf), capi.ptr(qoff), nq, max_errors, capi.ptr(out), c, C.byref(cnt), C.byref(st), None), cap)
+        return (hits, st) if want_stats else hits
+
+
+class search_ng26:
+    """search/SearchNg26.h with Edit = false (Hamming distance)"""
+
+    @staticmethod
+    def search(index, queries, scheme, partition=None, n=UINT64_MAX, capacity=None, want_stats=False):
+        """scheme = (pi, l, u) arrays [searches][parts]; partition = explicit part lengths or None (uniform per query)"""
+        qbuf, qoff, nq = _queries(queries)
+        pi, l, u = (_u64(x) for x in scheme)
+        sc = capi.Scheme()
+        sc.n_searches, sc.n_parts = pi.shape
+        sc.pi, sc.l, sc.u = (x.ctypes.data_as(capi.u64p) for x in (pi, l, u))
+        part = _u64(partition) if partition is not None else None
+        sc.partition = part.ctypes.data_as(capi.u64p) if part is not None else None
+        cap = capacity if capacity is not None else max(1024, 4 * nq)
+        hits, st = _run_hits(lambda out, c, cnt, st: capi.lib().fmgpu_search_scheme(
+            index._h, capi.ptr(qbuf), capi.ptr(qoff), nq, C.byref(sc), n, capi.ptr(out), c, C.byref(cnt), C.byref(st), None), cap)
+        return (hits, st) if want_stats else hits
+
+
+def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False):
+    """fmc::search<EditDistance=false> (search/search.h:26-35): errors == 0 -> search_no_errors, else search_ng26 with
+    h2(errors+2, 0, errors) and a uniform partition.  The reference's convenience overload additionally applies
+    limitToHamming to the un-expanded scheme (search/CachedSearchScheme.h:26-30), which loses hits;
+    compat_auto_scheme=True reproduces exactly that."""
+    if errors == 0:
+        lb, ln = search_no_errors.search(index, queries)
+        keep = np.nonzero(ln)[0]
+        hits = np.zeros(keep.size, dtype=HIT_DTYPE)
+        hits["qidx"], hits["lb"], hits["len"] = keep, lb[keep], ln[keep]
+        return hits
+    qbuf, qoff, nq = _queries(queries)
+    scheme = search_scheme.h2(errors + 2, 0, errors)
+    if compat_auto_scheme:
+        scheme = search_scheme.limitToHamming(scheme)
+    return search_ng26.search(index, (qbuf, qoff), scheme, None, n)
+
+
+class LocateLinear:
+    """locate.h:14-57: iterate a cursor's rows -> (seqId, pos, offset); batched over many cursors here"""
+
+    def __init__(self, index, lb, length):
+        self.index = index
+        lb, length = _u64(lb).reshape(-1), _u64(length).reshape(-1)
+        self.owner = np.repeat(np.arange(lb.size, dtype=np.uint64), length.astype(np.int64))
+        starts = np.repeat(lb, length.astype(np.int64))
+        first = np.repeat(np.cumsum(length) - length, length.astype(np.int64))
+        self.rows = starts + (np.arange(self.owner.size, dtype=np.uint64) - first)
+
+    def __call__(self):
+        seq, pos, steps = self.index.locate(self.rows)
+        return self.owner, seq, pos, steps

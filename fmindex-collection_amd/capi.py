@@ -1,0 +1,176 @@
+"""ctypes binding of libfmgpu.so (include/fmgpu.h).  No fallback: if the HIP library is missing, importing fails loudly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfmgpu.so")
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u64p = C.POINTER(C.c_uint64)
+
+LAYOUTS = {
+    "IB8": 0, "IB16": 1, "IB32": 2, "IB16A": 3, "IBP16": 4,
+    "EPR8": 5, "EPR16": 6, "EPR32": 7,
+    "EPRV2_8": 8, "EPRV2_16": 9, "EPRV2_32": 10, "WAVELET": 11,
+}
+LAYOUT_NAMES = {v: k for k, v in LAYOUTS.items()}
+UINT64_MAX = (1 << 64) - 1
+
+FMGPU_OK = 0
+FMGPU_ERR_INVALID = -1
+FMGPU_ERR_UNSUPPORTED = -2
+FMGPU_ERR_HIP = -3
+FMGPU_ERR_NO_DEVICE = -4
+FMGPU_ERR_CAPACITY = -5
+FMGPU_ERR_NOMEM = -6
+
+
+class FmgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fmgpu error {code}: {msg}")
+        self.code = code
+
+
+class WaveletNode(C.Structure):
+    _fields_ = [("superblocks", u64p), ("n_superblocks", C.c_uint64), ("blocks", u8p), ("n_blocks", C.c_uint64),
+                ("bits", u64p), ("n_bits", C.c_uint64), ("total_length", C.c_uint64)]
+
+
+class StringDesc(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("sigma", C.c_int32), ("n", C.c_uint64),
+                ("blocks", C.c_void_p), ("blocks_bytes", C.c_uint64),
+                ("super_blocks", u64p), ("n_super_blocks", C.c_uint64),
+                ("nodes", C.POINTER(WaveletNode)), ("n_nodes", C.c_uint64)]
+
+
+class DenseVectorDesc(C.Structure):
+    _fields_ = [("data", u64p), ("n_words", C.c_uint64), ("bit_count", C.c_uint64), ("bits", C.c_uint32),
+                ("largest_value", C.c_uint64), ("common_divisor", C.c_uint64)]
+
+
+class SparseArrayDesc(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("l0", u64p), ("n_l0", C.c_uint64), ("l1", u16p), ("n_l1", C.c_uint64),
+                ("bits", u64p), ("n_bit_words", C.c_uint64), ("field", DenseVectorDesc * 2)]
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("bwt", StringDesc), ("bwt_rev", C.POINTER(StringDesc)), ("C", u64p),
+                ("annotated_array", C.POINTER(SparseArrayDesc))]
+
+
+class Hit(C.Structure):
+    _fields_ = [("qidx", C.c_uint64), ("lb", C.c_uint64), ("lb_rev", C.c_uint64), ("len", C.c_uint64),
+                ("errors", C.c_uint32), ("seq", C.c_uint32)]
+
+
+HIT_DTYPE = np.dtype([("qidx", "<u8"), ("lb", "<u8"), ("lb_rev", "<u8"), ("len", "<u8"), ("errors", "<u4"), ("seq", "<u4")])
+assert HIT_DTYPE.itemsize == C.sizeof(Hit) == 40
+
+
+class Scheme(C.Structure):
+    _fields_ = [("n_searches", C.c_int32), ("n_parts", C.c_int32), ("pi", u64p), ("l", u64p), ("u", u64p),
+                ("partition", u64p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("lf_steps", C.c_uint64), ("hits", C.c_uint64), ("kernel_ms", C.c_float)]
+
+
+# every symbol include/fmgpu.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "fmgpu_abi_version", "fmgpu_last_error", "fmgpu_device_count", "fmgpu_set_device",
+    "fmgpu_index_create", "fmgpu_index_destroy", "fmgpu_index_info", "fmgpu_string_query",
+    "fmgpu_search_exact", "fmgpu_search_scheme", "fmgpu_search_backtracking", "fmgpu_locate",
+    "fmgpu_malloc", "fmgpu_free", "fmgpu_memcpy_h2d", "fmgpu_memcpy_d2h", "fmgpu_synchronize",
+    "fmgpu_build_index", "fmgpu_built_free", "fmgpu_built_get",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing — build it with __graft_entry__.build() "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.fmgpu_last_error.restype = C.c_char_p
+    L.fmgpu_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.fmgpu_set_device.argtypes = [C.c_int]
+    L.fmgpu_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(C.c_void_p)]
+    L.fmgpu_index_destroy.argtypes = [C.c_void_p]
+    L.fmgpu_index_info.argtypes = [C.c_void_p, u64p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p]
+    L.fmgpu_string_query.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.fmgpu_search_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.POINTER(Stats), C.c_void_p]
+    L.fmgpu_search_scheme.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Scheme), C.c_uint64,
+                                      C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats), C.c_void_p]
+    L.fmgpu_search_backtracking.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                            C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats), C.c_void_p]
+    L.fmgpu_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(Stats), C.c_void_p]
+    L.fmgpu_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
+    L.fmgpu_free.argtypes = [C.c_void_p]
+    L.fmgpu_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.fmgpu_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.fmgpu_synchronize.argtypes = [C.c_void_p]
+    if hasattr(L, "fmgpu_build_index"):
+        L.fmgpu_build_index.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, C.c_int32,
+                                        C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.fmgpu_built_free.argtypes = [C.c_void_p]
+        L.fmgpu_built_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), u64p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise FmgpuError(rc, lib().fmgpu_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    """numpy array / int device pointer / None -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    if isinstance(a, DeviceBuffer):
+        return C.c_void_p(a.ptr)
+    return C.c_void_p(a.ctypes.data)
+
+
+class DeviceBuffer:
+    """a chunk of HBM owned by the caller (queries / results that stay resident)"""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib().fmgpu_malloc(C.byref(p), nbytes))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    @classmethod
+    def from_array(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(max(a.nbytes, 8))
+        check(lib().fmgpu_memcpy_h2d(C.c_void_p(b.ptr), C.c_void_p(a.ctypes.data), a.nbytes))
+        return b
+
+    def to_array(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        check(lib().fmgpu_memcpy_d2h(C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr), out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().fmgpu_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,380 @@
+// fmgpu_index.hip — error handling, staging helpers, index upload / re-layout, String_c batch queries.
+#include "fmgpu_common.h"
+
+#include <algorithm>
+#include <memory>
+#include <new>
+
+namespace fmgpu {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+int hip_fail(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return FMGPU_ERR_HIP;
+}
+
+bool is_device_pointer(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof a);
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+int Staged::in(const void* p, size_t nbytes, hipStream_t s) {
+    stream = s; bytes = nbytes;
+    if (nbytes == 0) { dev = nullptr; return 0; }
+    if (is_device_pointer(p)) { dev = const_cast<void*>(p); return 0; }
+    FM_HIP(hipMalloc(&dev, nbytes));
+    owned = true;
+    FM_HIP(hipMemcpyAsync(dev, p, nbytes, hipMemcpyHostToDevice, s));
+    return 0;
+}
+int Staged::out(void* p, size_t nbytes, hipStream_t s) {
+    stream = s; bytes = nbytes;
+    if (nbytes == 0) { dev = nullptr; return 0; }
+    if (is_device_pointer(p)) { dev = p; return 0; }
+    FM_HIP(hipMalloc(&dev, nbytes));
+    owned = true; writeback = true; host = p;
+    return 0;
+}
+int Staged::finish() {
+    if (writeback && bytes) {
+        FM_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
+        FM_HIP(hipStreamSynchronize(stream));
+        writeback = false;
+    }
+    return 0;
+}
+Staged::~Staged() {
+    if (owned && dev) { (void)hipStreamSynchronize(stream); (void)hipFree(dev); }
+}
+
+// ------------------------------------------------------------------ layout parameters (mirror of the reference's struct layouts)
+struct RefLayout {
+    int family;      // reference family: 0 IB, 1 IBP, 2 EPR, 3 EPRV2, 4 wavelet
+    uint32_t bt, K, bits_off, stride, rows, bitct;
+    uint64_t period;
+};
+
+static int bit_width_u(uint64_t v) { int r = 0; while (v) { ++r; v >>= 1; } return r; }
+
+static int ref_layout(int layout, int sigma, RefLayout& L) {
+    uint32_t align = 8;
+    L.bitct = (uint32_t)bit_width_u((uint64_t)sigma - 1);
+    switch (layout) {
+    case FMGPU_IB8:      L.family = 0; L.bt = 1; break;
+    case FMGPU_IB16:     L.family = 0; L.bt = 2; break;
+    case FMGPU_IB32:     L.family = 0; L.bt = 4; break;
+    case FMGPU_IB16A:    L.family = 0; L.bt = 2; align = 64; break;
+    case FMGPU_IBP16:    L.family = 1; L.bt = 2; break;
+    case FMGPU_EPR8:     L.family = 2; L.bt = 1; break;
+    case FMGPU_EPR16:    L.family = 2; L.bt = 2; break;
+    case FMGPU_EPR32:    L.family = 2; L.bt = 4; break;
+    case FMGPU_EPRV2_8:  L.family = 3; L.bt = 1; break;
+    case FMGPU_EPRV2_16: L.family = 3; L.bt = 2; break;
+    case FMGPU_EPRV2_32: L.family = 3; L.bt = 4; break;
+    case FMGPU_WAVELET:  L.family = 4; L.bt = 0; return 0;
+    default: return -1;
+    }
+    uint64_t full = 1ull << (8 * L.bt);
+    L.rows = 64; L.period = full;
+    if (L.family <= 1) L.K = (uint32_t)sigma;
+    else if (L.family == 3) L.K = L.bitct;
+    else { L.K = 1; L.rows = 64 / L.bitct; L.period = (full / L.rows) * L.rows; }
+    L.bits_off = (uint32_t)(((uint64_t)sigma * L.bt + 7) / 8 * 8);
+    L.stride = (uint32_t)(((uint64_t)L.bits_off + 8ull * L.K + align - 1) / align * align);
+    return 0;
+}
+
+// ------------------------------------------------------------------ Format A conversion kernel
+// thread = (device block B, symbol c).  Reference row p lives at bit (p+1)&63 of block (p+1)>>6
+// (string/InterleavedBitvector.h:64-94); prefix layout stores s[j] <= c (InterleavedBitvectorPrefix.h:86-100).
+__global__ __launch_bounds__(256) void k_convert_ib(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ super,
+                                                    const idx_t* __restrict__ C, uint8_t* __restrict__ out,
+                                                    uint64_t nblocks, uint32_t sigma, uint32_t bt, uint32_t bits_off,
+                                                    uint32_t stride, uint64_t period, uint32_t bstride, int prefix) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblocks * sigma) return;
+    uint64_t B = t / sigma;
+    uint32_t c = (uint32_t)(t % sigma);
+    auto count_of = [&](uint64_t b, uint32_t s) -> uint64_t {
+        const uint8_t* p = raw + b * stride + (uint64_t)s * bt;
+        if (bt == 2) return *reinterpret_cast<const uint16_t*>(p);
+        if (bt == 1) return *p;
+        return *reinterpret_cast<const uint32_t*>(p);
+    };
+    auto word_of = [&](uint64_t b, uint32_t s) -> uint64_t {
+        return *reinterpret_cast<const uint64_t*>(raw + b * stride + bits_off + 8ull * s);
+    };
+    uint64_t sb = (64ull * B) / period;
+    uint64_t w = word_of(B, c), cnt = count_of(B, c) + super[sb * sigma + c];
+    uint64_t wn = B + 1 < nblocks ? word_of(B + 1, c) : 0;
+    if (prefix && c > 0) {   // cumulative planes -> exclusive planes
+        uint64_t wl = word_of(B, c - 1);
+        uint64_t wln = B + 1 < nblocks ? word_of(B + 1, c - 1) : 0;
+        uint64_t bmask = bt == 2 ? 0xffffull : (bt == 1 ? 0xffull : 0xffffffffull);
+        cnt = ((count_of(B, c) - count_of(B, c - 1)) & bmask) + super[sb * sigma + c] - super[sb * sigma + c - 1];
+        w &= ~wl; wn &= ~wln;
+    }
+    uint64_t bits = (w >> 1) | ((wn & 1ull) << 63);
+    uint32_t total = (uint32_t)(cnt + (w & 1ull)) + C[c];
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + B * bstride + 12ull * c);
+    o[0] = total; o[1] = (uint32_t)bits; o[2] = (uint32_t)(bits >> 32);
+}
+
+static int upload(const void* host, size_t bytes, void** dev) {
+    *dev = nullptr;
+    if (bytes == 0) bytes = 8;
+    FM_HIP(hipMalloc(dev, bytes));
+    if (host) FM_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyDefault));
+    return 0;
+}
+
+static void free_string(DevString& s) {
+    if (s.blk) (void)hipFree(s.blk);
+    if (s.aux) (void)hipFree(s.aux);
+    s.blk = s.aux = nullptr;
+}
+
+static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
+    if (d.sigma < 2 || d.sigma > 256) return fail(FMGPU_ERR_INVALID, "sigma must be in [2, 256]");
+    if (d.n >= 0xffffffffull - 64) return fail(FMGPU_ERR_UNSUPPORTED, "this build indexes fewer than 2^32 - 64 rows per string");
+    RefLayout L{};
+    if (ref_layout(d.layout, d.sigma, L) != 0) return fail(FMGPU_ERR_INVALID, "unknown layout id");
+    s.layout = d.layout; s.sigma = d.sigma; s.n = d.n; s.bitct = (int)L.bitct;
+    const uint32_t sigma = (uint32_t)d.sigma;
+
+    if (L.family <= 1) {   // InterleavedBitvector* / InterleavedBitvectorPrefix* -> Format A
+        uint64_t nblocks = d.n / 64 + 1, nsuper = d.n / L.period + 1;
+        if (!d.blocks || !d.super_blocks) return fail(FMGPU_ERR_INVALID, "blocks / super_blocks missing");
+        if (d.blocks_bytes != nblocks * L.stride) return fail(FMGPU_ERR_INVALID, "blocks_bytes does not match n / layout (expected " + std::to_string(nblocks * L.stride) + ")");
+        if (d.n_super_blocks != nsuper) return fail(FMGPU_ERR_INVALID, "n_super_blocks does not match n / layout");
+        void *raw = nullptr, *sup = nullptr;
+        int rc = upload(d.blocks, d.blocks_bytes, &raw); if (rc) return rc;
+        rc = upload(d.super_blocks, nsuper * sigma * 8, &sup); if (rc) { (void)hipFree(raw); return rc; }
+        uint32_t bstride = sigma <= 5 ? 64u : 12u * sigma;
+        s.blk_bytes = nblocks * bstride + 64;
+        hipError_t e = hipMalloc(&s.blk, s.blk_bytes);
+        if (e != hipSuccess) { (void)hipFree(raw); (void)hipFree(sup); return hip_fail(e, "hipMalloc(format A)"); }
+        (void)hipMemset(s.blk, 0, s.blk_bytes);
+        uint64_t threads = nblocks * sigma;
+        k_convert_ib<<<dim3((unsigned)((threads + 255) / 256)), dim3(256)>>>(
+            (const uint8_t*)raw, (const uint64_t*)sup, dC, (uint8_t*)s.blk, nblocks, sigma, L.bt, L.bits_off, L.stride,
+            L.period, bstride, L.family == 1 ? 1 : 0);
+        e = hipDeviceSynchronize();
+        (void)hipFree(raw); (void)hipFree(sup);
+        if (e != hipSuccess) return hip_fail(e, "k_convert_ib");
+        s.family = FAM_A;
+        s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC};
+        return 0;
+    }
+    if (L.family == 2 || L.family == 3) {   // EPR / EPRV2: reference layout verbatim
+        if (!d.blocks || !d.super_blocks) return fail(FMGPU_ERR_INVALID, "blocks / super_blocks missing");
+        if (d.blocks_bytes % L.stride != 0) return fail(FMGPU_ERR_INVALID, "blocks_bytes is not a multiple of sizeof(Block)");
+        uint64_t need_blocks = d.n / L.rows + 1;
+        if (d.blocks_bytes / L.stride < need_blocks) return fail(FMGPU_ERR_INVALID, "too few blocks for n rows");
+        if (d.n_super_blocks < d.n / L.period + 1) return fail(FMGPU_ERR_INVALID, "too few super blocks for n rows");
+        int rc = upload(d.blocks, d.blocks_bytes, &s.blk); if (rc) return rc;
+        rc = upload(d.super_blocks, d.n_super_blocks * sigma * 8, &s.aux); if (rc) return rc;
+        s.blk_bytes = d.blocks_bytes; s.aux_bytes = d.n_super_blocks * sigma * 8;
+        s.family = L.family == 2 ? FAM_EPR : FAM_EPRV2;
+        ViewR v{};
+        v.blk = (const uint8_t*)s.blk; v.super = (const uint64_t*)s.aux; v.C = dC;
+        v.stride = L.stride; v.bits_off = L.bits_off; v.bt = L.bt; v.sigma = sigma; v.bitct = L.bitct;
+        v.rows = L.rows; v.period_shift = 8 * L.bt; v.period = (uint32_t)std::min<uint64_t>(L.period, 0xffffffffull);
+        // InterleavedEPR.h:28-47
+        uint64_t entries = 64 / L.bitct, cm = (1ull << L.bitct) - 1, mk = 1ull << L.bitct;
+        for (uint64_t i = 0; i < entries; i += 2) { v.maskEven = (v.maskEven << (2 * L.bitct)) | cm; v.bitMask = (v.bitMask << (2 * L.bitct)) | mk; }
+        s.vr = v;
+        return 0;
+    }
+    // wavelet -> Format W
+    uint64_t nnodes = 1; while (nnodes < sigma) nnodes <<= 1;
+    if (!d.nodes || d.n_nodes != nnodes) return fail(FMGPU_ERR_INVALID, "wavelet needs bit_ceil(sigma) node descriptors");
+    std::vector<uint32_t> base(nnodes, 0);
+    uint64_t total_lines = 0;
+    for (uint64_t k = 0; k < nnodes; ++k) {
+        base[k] = (uint32_t)total_lines;
+        total_lines += d.nodes[k].total_length / 448 + 1;
+        if (d.nodes[k].n_bits < d.nodes[k].total_length / 64 + 1) return fail(FMGPU_ERR_INVALID, "wavelet node bits array too short");
+        if (total_lines >= 0xffffffffull) return fail(FMGPU_ERR_UNSUPPORTED, "wavelet too large for 32-bit line offsets");
+    }
+    std::unique_ptr<uint64_t[]> lines(new (std::nothrow) uint64_t[total_lines * 8]());
+    if (!lines) return fail(FMGPU_ERR_NOMEM, "host staging for wavelet lines");
+    for (uint64_t k = 0; k < nnodes; ++k) {
+        const fmgpu_wavelet_node& nd = d.nodes[k];
+        uint64_t nl = nd.total_length / 448 + 1, nwords = nd.total_length / 64 + 1, ones = 0;
+        for (uint64_t li = 0; li < nl; ++li) {
+            uint64_t* Lp = lines.get() + (base[k] + li) * 8;
+            Lp[0] = ones;
+            for (uint64_t j = 0; j < 7; ++j) {
+                uint64_t wi = li * 7 + j;
+                uint64_t w = wi < nwords ? nd.bits[wi] : 0;
+                Lp[1 + j] = w;
+                ones += (uint64_t)__builtin_popcountll(w);
+            }
+        }
+    }
+    int rc = upload(lines.get(), total_lines * 64, &s.blk); if (rc) return rc;
+    rc = upload(base.data(), nnodes * 4, &s.aux); if (rc) return rc;
+    s.blk_bytes = total_lines * 64; s.aux_bytes = nnodes * 4;
+    s.family = FAM_WAVELET;
+    s.vw = ViewW{(const uint64_t*)s.blk, (const uint32_t*)s.aux, dC, sigma, L.bitct};
+    return 0;
+}
+
+// ------------------------------------------------------------------ String_c batch kernel
+template <class Occ>
+__global__ __launch_bounds__(256) void k_string_query(Occ occ, const uint64_t* __restrict__ idx, const uint8_t* __restrict__ symb,
+                                                      const uint8_t* __restrict__ what, uint64_t count, uint64_t* __restrict__ out) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    idx_t i = (idx_t)idx[t];
+    uint32_t c = symb ? symb[t] : 0;
+    uint32_t w = what ? what[t] : 0;
+    uint64_t r;
+    if (w == 0) r = occ.rank(i, c);
+    else if (w == 1) r = occ.prefix_rank(i, c);
+    else r = occ.symbol(i);
+    out[t] = r;
+}
+
+}  // namespace fmgpu
+
+using namespace fmgpu;
+
+extern "C" {
+
+int fmgpu_abi_version(void) { return FMGPU_ABI_VERSION; }
+const char* fmgpu_last_error(void) { return g_last_error.c_str(); }
+
+int fmgpu_device_count(int* count) {
+    if (!count) return fail(FMGPU_ERR_INVALID, "count is null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { (void)hipGetLastError(); *count = 0; return fail(FMGPU_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = c;
+    return 0;
+}
+int fmgpu_set_device(int device) { FM_HIP(hipSetDevice(device)); return 0; }
+
+int fmgpu_index_destroy(fmgpu_index_t h) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return 0;
+    free_string(x->bwt); free_string(x->rev);
+    for (void* p : {(void*)x->dC, x->sa_l0, x->sa_l1, x->sa_bits, x->sa_f0, x->sa_f1}) if (p) (void)hipFree(p);
+    delete x;
+    return 0;
+}
+
+int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
+    if (!desc || !out) return fail(FMGPU_ERR_INVALID, "desc / out is null");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); return fail(FMGPU_ERR_NO_DEVICE, "no HIP device visible — the product path has no CPU fallback"); }
+    if (!desc->C) return fail(FMGPU_ERR_INVALID, "C is null");
+    if (desc->bwt_rev && (desc->bwt_rev->n != desc->bwt.n || desc->bwt_rev->sigma != desc->bwt.sigma))
+        return fail(FMGPU_ERR_INVALID, "bwt don't have the same size: " + std::to_string(desc->bwt.n) + " " + std::to_string(desc->bwt_rev->n));   // fmindex/BiFMIndex.h:48-50
+    std::unique_ptr<Index> x(new (std::nothrow) Index());
+    if (!x) return fail(FMGPU_ERR_NOMEM, "host allocation");
+    (void)hipGetDevice(&x->device);
+    const int sigma = desc->bwt.sigma;
+    if (sigma < 2 || sigma > 256) return fail(FMGPU_ERR_INVALID, "sigma must be in [2, 256]");
+    std::vector<idx_t> c32(sigma + 1);
+    for (int i = 0; i <= sigma; ++i) {
+        if (desc->C[i] > desc->bwt.n) return fail(FMGPU_ERR_INVALID, "C[] entry exceeds n");
+        x->hC[i] = desc->C[i]; c32[i] = (idx_t)desc->C[i];
+    }
+    int rc = upload(c32.data(), (sigma + 1) * sizeof(idx_t), (void**)&x->dC);
+    auto bail = [&](int code) { fmgpu_index_destroy(reinterpret_cast<fmgpu_index_t>(x.release())); return code; };
+    if (rc) return bail(rc);
+    rc = create_string(desc->bwt, x->dC, x->bwt); if (rc) return bail(rc);
+    if (desc->bwt_rev) { rc = create_string(*desc->bwt_rev, x->dC, x->rev); if (rc) return bail(rc); x->bidirectional = true; }
+    x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->rev.blk_bytes + x->rev.aux_bytes;
+    if (const fmgpu_sparse_array_desc* sa = desc->annotated_array) {
+        if (sa->n != desc->bwt.n) return bail(fail(FMGPU_ERR_INVALID, "annotated_array.n != bwt.n"));
+        if (sa->n_l0 < sa->n / 65536 + 1 || sa->n_l1 < sa->n / 512 + 1 || sa->n_bit_words < (sa->n / 512 + 1) * 8)
+            return bail(fail(FMGPU_ERR_INVALID, "annotated_array presence bitvector arrays too short"));
+        for (int f = 0; f < 2; ++f)
+            if (sa->field[f].bits == 0 || sa->field[f].bits > 64 || sa->field[f].common_divisor == 0)
+                return bail(fail(FMGPU_ERR_INVALID, "annotated_array dense vector has bits == 0 or > 64"));
+        rc = upload(sa->l0, sa->n_l0 * 8, &x->sa_l0); if (rc) return bail(rc);
+        rc = upload(sa->l1, sa->n_l1 * 2, &x->sa_l1); if (rc) return bail(rc);
+        rc = upload(sa->bits, sa->n_bit_words * 8, &x->sa_bits); if (rc) return bail(rc);
+        // one spare word so that the two-word read of dense_access never leaves the buffer
+        for (int f = 0; f < 2; ++f) {
+            void** dst = f == 0 ? &x->sa_f0 : &x->sa_f1;
+            size_t bytes = (sa->field[f].n_words + 1) * 8;
+            hipError_t e = hipMalloc(dst, bytes);
+            if (e != hipSuccess) return bail(hip_fail(e, "hipMalloc(sa field)"));
+            (void)hipMemset(*dst, 0, bytes);
+            if (sa->field[f].n_words) {
+                e = hipMemcpy(*dst, sa->field[f].data, sa->field[f].n_words * 8, hipMemcpyDefault);
+                if (e != hipSuccess) return bail(hip_fail(e, "hipMemcpy(sa field)"));
+            }
+            x->device_bytes += bytes;
+        }
+        x->device_bytes += sa->n_l0 * 8 + sa->n_l1 * 2 + sa->n_bit_words * 8;
+        x->vsa = ViewSA{(const uint64_t*)x->sa_l0, (const uint16_t*)x->sa_l1, (const uint64_t*)x->sa_bits,
+                        (const uint64_t*)x->sa_f0, (const uint64_t*)x->sa_f1,
+                        sa->field[0].bits, sa->field[1].bits, sa->field[0].common_divisor, sa->field[1].common_divisor};
+        x->has_sa = true;
+    }
+    *out = reinterpret_cast<fmgpu_index_t>(x.release());
+    return 0;
+}
+
+int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (n) *n = x->bwt.n;
+    if (sigma) *sigma = x->bwt.sigma;
+    if (layout) *layout = x->bwt.layout;
+    if (bidirectional) *bidirectional = x->bidirectional ? 1 : 0;
+    if (device_bytes) *device_bytes = x->device_bytes;
+    return 0;
+}
+
+int fmgpu_string_query(fmgpu_index_t h, int which, const uint64_t* idx, const uint8_t* symb, const uint8_t* what,
+                       uint64_t count, uint64_t* out, void* stream_) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (which != 0 && !(which == 1 && x->bidirectional)) return fail(FMGPU_ERR_INVALID, "which must be 0 (bwt) or 1 (bwtRev of a BiFMIndex)");
+    if (count == 0) return 0;
+    if (!idx || !out) return fail(FMGPU_ERR_INVALID, "idx / out is null");
+    hipStream_t stream = (hipStream_t)stream_;
+    const DevString& s = which ? x->rev : x->bwt;
+    Staged sidx, ssym, swhat, sout;
+    int rc;
+    if ((rc = sidx.in(idx, count * 8, stream))) return rc;
+    if ((rc = ssym.in(symb, symb ? count : 0, stream))) return rc;
+    if ((rc = swhat.in(what, what ? count : 0, stream))) return rc;
+    if ((rc = sout.out(out, count * 8, stream))) return rc;
+    dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    auto a = (const uint64_t*)sidx.dev; auto b = (const uint8_t*)ssym.dev; auto c = (const uint8_t*)swhat.dev; auto o = (uint64_t*)sout.dev;
+    switch (s.family) {
+    case FAM_A:
+        if (s.sigma == 5) k_string_query<OccA<5>><<<grid, block, 0, stream>>>(OccA<5>{s.va}, a, b, c, count, o);
+        else k_string_query<OccA<0>><<<grid, block, 0, stream>>>(OccA<0>{s.va}, a, b, c, count, o);
+        break;
+    case FAM_EPR:     k_string_query<OccR<false>><<<grid, block, 0, stream>>>(OccR<false>{s.vr}, a, b, c, count, o); break;
+    case FAM_EPRV2:   k_string_query<OccR<true>><<<grid, block, 0, stream>>>(OccR<true>{s.vr}, a, b, c, count, o); break;
+    default:          k_string_query<OccW><<<grid, block, 0, stream>>>(OccW{s.vw}, a, b, c, count, o); break;
+    }
+    FM_HIP(hipGetLastError());
+    return sout.finish();
+}
+
+int fmgpu_malloc(void** ptr, uint64_t bytes) { if (!ptr) return fail(FMGPU_ERR_INVALID, "ptr is null"); FM_HIP(hipMalloc(ptr, bytes ? bytes : 8)); return 0; }
+int fmgpu_free(void* ptr) { if (ptr) FM_HIP(hipFree(ptr)); return 0; }
+int fmgpu_memcpy_h2d(void* dst, const void* src, uint64_t bytes) { if (bytes) FM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+int fmgpu_memcpy_d2h(void* dst, const void* src, uint64_t bytes) { if (bytes) FM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
+int fmgpu_synchronize(void* stream) { FM_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+/* fmgpu.h — C-ABI of libfmgpu.so, the MI355X (gfx950) backward-search engine.
+ *
+ * This is the drop-in boundary for the reference's batched search path.  The reference
+ * (SGSSGene/fmindex-collection, header-only C++23) has no FFI; the interface this ABI replaces is
+ * the set of free function templates and member functions cited at each entry point below
+ * (paths relative to src/fmindex-collection/ in the reference).  The C++ mirror of the reference's
+ * template API that calls this ABI lives in include/fmc_gpu.hpp; INTEGRATION.md shows the binding
+ * a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative fmgpu_status; fmgpu_last_error() returns a
+ *     thread-local message for the last failure on the calling thread; no C++ exception crosses
+ *     the ABI.
+ *   - data pointers may be host or device pointers (detected per pointer with
+ *     hipPointerGetAttributes); host buffers are staged through HBM by the library, device buffers
+ *     are used in place.  `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     Calls that receive host output buffers return after the results have landed; calls that
+ *     only touch device buffers are asynchronous on `stream`.
+ *   - an index handle is immutable after creation and may be used concurrently from several host
+ *     threads (each call brings its own stream / buffers).
+ *   - symbols are ranks in [0, sigma) exactly as in the reference (0 = sequence delimiter);
+ *     row indices, interval bounds and counts are uint64_t like the reference's size_t.
+ */
+#ifndef FMGPU_H
+#define FMGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMGPU_ABI_VERSION 1
+
+typedef enum fmgpu_status {
+    FMGPU_OK = 0,
+    FMGPU_ERR_INVALID = -1,      /* bad argument (null pointer, sigma out of range, sizes that do not match the layout) */
+    FMGPU_ERR_UNSUPPORTED = -2,  /* valid request this build cannot serve (e.g. n >= 2^32 rows) */
+    FMGPU_ERR_HIP = -3,          /* a HIP runtime call failed; message holds hipGetErrorString */
+    FMGPU_ERR_NO_DEVICE = -4,    /* no gfx950 device visible */
+    FMGPU_ERR_CAPACITY = -5,     /* result buffer too small; *out_count holds the required record count */
+    FMGPU_ERR_NOMEM = -6
+} fmgpu_status;
+
+/* occurrence-table ("string with rank support") layouts of the reference, string/<file>.h */
+typedef enum fmgpu_layout {
+    FMGPU_IB8 = 0, FMGPU_IB16 = 1, FMGPU_IB32 = 2, FMGPU_IB16A = 3, /* InterleavedBitvector.h:168-173 */
+    FMGPU_IBP16 = 4,                                                 /* InterleavedBitvectorPrefix.h:204-209 */
+    FMGPU_EPR8 = 5, FMGPU_EPR16 = 6, FMGPU_EPR32 = 7,                /* InterleavedEPR.h:222-227 */
+    FMGPU_EPRV2_8 = 8, FMGPU_EPRV2_16 = 9, FMGPU_EPRV2_32 = 10,      /* InterleavedEPRV2.h:289-309 */
+    FMGPU_WAVELET = 11                                               /* Wavelet.h:27-28 over bitvector::Bitvector */
+} fmgpu_layout;
+
+/* One reference String object, described by the arrays it already holds in host memory.
+ * Blocked layouts: `blocks` = String::blocks.data() (sizeof(Block) stride),
+ *                  `super_blocks` = String::superBlocks.data() ([k][sigma] uint64).
+ * Wavelet:         `nodes` = bit_ceil(sigma) node descriptors = Wavelet::bitvector[i].{superblocks,blocks,bits,totalLength}. */
+typedef struct fmgpu_wavelet_node {
+    const uint64_t* superblocks; uint64_t n_superblocks;   /* bitvector/Bitvector.h:31 */
+    const uint8_t*  blocks;      uint64_t n_blocks;        /* :32 */
+    const uint64_t* bits;        uint64_t n_bits;          /* :33 */
+    uint64_t total_length;                                 /* :34 */
+} fmgpu_wavelet_node;
+
+typedef struct fmgpu_string_desc {
+    int32_t  layout;              /* fmgpu_layout */
+    int32_t  sigma;               /* String::Sigma, 2..256 */
+    uint64_t n;                   /* String::size() */
+    const void*     blocks;       uint64_t blocks_bytes;
+    const uint64_t* super_blocks; uint64_t n_super_blocks;
+    const fmgpu_wavelet_node* nodes; uint64_t n_nodes;
+} fmgpu_string_desc;
+
+/* suffixarray::SparseArray<std::tuple<uint32_t,uint32_t>, Bitvector2L<512,65536>> (suffixarray/SparseArray.h:31-76):
+ * presence bitvector (bitvector/Bitvector2L.h:30-33) + two bit-packed DenseVectors (DenseVector.h:26-34). */
+typedef struct fmgpu_dense_vector_desc {
+    const uint64_t* data; uint64_t n_words;
+    uint64_t bit_count; uint32_t bits; uint64_t largest_value; uint64_t common_divisor;
+} fmgpu_dense_vector_desc;
+
+typedef struct fmgpu_sparse_array_desc {
+    uint64_t n;                                   /* rows (== string n) */
+    const uint64_t* l0;   uint64_t n_l0;
+    const uint16_t* l1;   uint64_t n_l1;
+    const uint64_t* bits; uint64_t n_bit_words;   /* 8 words per 512-bit block */
+    fmgpu_dense_vector_desc field[2];             /* documents.data[0] = seqId, data[1] = pos */
+} fmgpu_sparse_array_desc;
+
+/* FMIndex (fmindex/FMIndex.h:21-23) or BiFMIndex (fmindex/BiFMIndex.h:31-35) */
+typedef struct fmgpu_index_desc {
+    fmgpu_string_desc bwt;
+    const fmgpu_string_desc* bwt_rev;             /* NULL => unidirectional FMIndex */
+    const uint64_t* C;                            /* sigma+1 entries */
+    const fmgpu_sparse_array_desc* annotated_array; /* NULL => locate unavailable */
+} fmgpu_index_desc;
+
+typedef struct fmgpu_index* fmgpu_index_t;
+
+/* one reported cursor: search/SearchNg26.h:398-403 delegate(qidx, cursor, errors); `seq` = position
+ * of this report within its query in the reference's callback order */
+typedef struct fmgpu_hit {
+    uint64_t qidx, lb, lb_rev, len;
+    uint32_t errors, seq;
+} fmgpu_hit;
+
+/* search_scheme::Scheme flattened [search][part] (search_scheme/Search.h:19-27) */
+typedef struct fmgpu_scheme {
+    int32_t n_searches, n_parts;
+    const uint64_t* pi; const uint64_t* l; const uint64_t* u;
+    const uint64_t* partition;   /* n_parts entries, or NULL = createUniformPartition per query length (expand.h:324-343) */
+} fmgpu_scheme;
+
+typedef struct fmgpu_stats {
+    uint64_t lf_steps;       /* exact search: executed extensions;  k-mismatch: visited nodes (cursor extensions) */
+    uint64_t hits;           /* records produced */
+    float    kernel_ms;      /* duration of the dominant kernel, measured with hipEvents on `stream` (0 if not requested) */
+} fmgpu_stats;
+
+int         fmgpu_abi_version(void);
+const char* fmgpu_last_error(void);
+int         fmgpu_device_count(int* count);
+int         fmgpu_set_device(int device);
+
+/* index upload: copies (and re-lays out for HBM) the arrays; the caller keeps ownership of host memory.
+ * replaces: FMIndex(span bwt, SparseArray) fmindex/FMIndex.h:30-34, BiFMIndex(...) fmindex/BiFMIndex.h:40-51 */
+int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out);
+int fmgpu_index_destroy(fmgpu_index_t h);
+int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes);
+
+/* String_c batch evaluation (string/concepts.h:25-87): what[i] selects 0 = rank(idx,symb), 1 = prefix_rank(idx,symb),
+ * 2 = symbol(idx); which = 0 -> bwt, 1 -> bwtRev */
+int fmgpu_string_query(fmgpu_index_t h, int which, const uint64_t* idx, const uint8_t* symb, const uint8_t* what,
+                       uint64_t count, uint64_t* out, void* stream);
+
+/* search_no_errors::search (search/SearchNoErrors.h:12-26 per query / :28-86 batched): out_lb/out_len = cursor after the
+ * last executed extension (len == 0: no occurrence) */
+int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                       uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats, void* stream);
+
+/* search_ng26::search<Edit=false>(index, queries, scheme, partition, delegate, n) (search/SearchNg26.h:426-433);
+ * BiFMIndex only.  max_hits_per_query = n (UINT64_MAX = unlimited).  Records are appended in no particular order across
+ * queries; (qidx, seq) restores the reference's callback order.  *out_count = records produced (also when > capacity). */
+int fmgpu_search_scheme(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                        const fmgpu_scheme* scheme, uint64_t max_hits_per_query,
+                        fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, void* stream);
+
+/* search_backtracking::search(index, queries, maxErrors, delegate) (search/Backtracking.h:85-89); FMIndex or BiFMIndex */
+int fmgpu_search_backtracking(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                              uint64_t max_errors, fmgpu_hit* out, uint64_t capacity, uint64_t* out_count,
+                              fmgpu_stats* stats, void* stream);
+
+/* FMIndex::locate / BiFMIndex::locate (fmindex/FMIndex.h:113-124, fmindex/BiFMIndex.h:176-202), one SA row per entry:
+ * out_seq/out_pos = sampled entry reached, out_steps = LF steps walked (text position = pos + steps, locate.h:46-56) */
+int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count,
+                 uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps, fmgpu_stats* stats, void* stream);
+
+/* device memory helpers for callers that keep queries / results resident in HBM */
+int fmgpu_malloc(void** ptr, uint64_t bytes);
+int fmgpu_free(void* ptr);
+int fmgpu_memcpy_h2d(void* dst, const void* src, uint64_t bytes);
+int fmgpu_memcpy_d2h(void* dst, const void* src, uint64_t bytes);
+int fmgpu_synchronize(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
