@@ -155,6 +155,20 @@ int fmgpu_search_backtracking(fmgpu_index_t h, const uint8_t* qbuf, const uint64
 int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count,
                  uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps, fmgpu_stats* stats, void* stream);
 
+/* GPU index construction from sequences — replaces FMIndex(Sequences, samplingRate, threads) (fmindex/FMIndex.h:58-104) and
+ * BiFMIndex(Sequences, samplingRate, threads) (fmindex/BiFMIndex.h:107-167), i.e. libsais (utils.h:97-129) + the String /
+ * SparseArray constructors.  Sequence i = seqs[seq_off[i] .. seq_off[i+1]); a 0 delimiter follows every sequence
+ * (utils.h:382-411).  `layout` must be an InterleavedBitvector* layout (others: build the String from the returned BWT).
+ * keep_host != 0 additionally returns host copies of the by-products through fmgpu_built_get:
+ *   part 0 BWT bytes, 1 BWT of the reversed text (BiFMIndex), 2 C (sigma+1 u64), 3 l0, 4 l1, 5 presence bits,
+ *   6 / 7 DenseVector words of seqId / pos, 8 {bitCount, bits, largestValue, commonDivisor} x 2 (u64). */
+typedef struct fmgpu_built* fmgpu_built_t;
+int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nseq, int32_t sigma, int32_t layout,
+                      uint64_t sampling_rate, int32_t bidirectional, int32_t keep_host,
+                      fmgpu_index_t* out, fmgpu_built_t* built);
+int fmgpu_built_get(fmgpu_built_t b, int32_t part, const void** ptr, uint64_t* bytes);
+int fmgpu_built_free(fmgpu_built_t b);
+
 /* device memory helpers for callers that keep queries / results resident in HBM */
 int fmgpu_malloc(void** ptr, uint64_t bytes);
 int fmgpu_free(void* ptr);
