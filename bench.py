@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the backward-search hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic reads that are already resident in HBM.
+Default workload = BASELINE.json configs[1]: GRCh38-sized FMIndex (25 sequences with the GRCh38 chromosome
+lengths, 3.09 Gbp, sigma = 5, uniform random bases — the real assembly is not available offline), 10 M x 101 bp
+exact search.  `--workload k2` runs configs[2] (BiFMIndex, h2(4,0,2) search scheme, Hamming distance).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: launched by torch.distributed.run, one rank per GPU; the index is replicated, every rank searches its own
+batch (weak scaling: per-GPU work fixed), and the resulting SA intervals are gathered to rank 0 over RCCL inside
+the timed region — the path's only exchange step.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (executed LF steps x
+2 x sizeof(InterleavedBitvector16<5>::Block) = 112 B) / the search kernel's launch duration, measured with HIP
+events on the launch stream inside the C-ABI.  `cpu_baseline` = the CPU restatement (oracle/, parity-pinned) on
+the host cores over a bounded sample of the same reads.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+                  133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
+                  58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569]
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BLOCK_BYTES_IB16_S5 = 56       # sizeof(InterleavedBitvector16<5>::Block), SURVEY.md appendix B
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="exact", choices=["exact", "k2"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the text (dev runs only; the judged run uses 1.0)")
+    ap.add_argument("--nq", type=int, default=10_000_000)
+    ap.add_argument("--read-len", type=int, default=101)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+    import fmindex_collection_amd as fm
+    from fmindex_collection_amd import capi
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    capi.check(capi.lib().fmgpu_set_device(local_rank))
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---------------------------------------------------------------- synthetic inputs, generated in HBM
+    lengths = [max(1, int(l * args.scale)) for l in GRCH38_LENGTHS]
+    total = sum(lengths)
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    text = torch.empty(total, dtype=torch.uint8, device=dev)
+    chunk = 1 << 28
+    for lo in range(0, total, chunk):                         # bases uniform in {1..4}; 0 is the delimiter
+        hi = min(total, lo + chunk)
+        text[lo:hi] = torch.randint(1, 5, (hi - lo,), generator=g, device=dev, dtype=torch.uint8)
+    seq_off = torch.tensor([0] + list(np.cumsum(lengths)), dtype=torch.int64, device=dev)
+    L, nq = args.read_len, args.nq
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(1000 + rank)                               # every rank searches its own batch
+    # reads = substrings of a random chromosome-internal position (so every unmutated read has >= 1 hit)
+    starts = torch.randint(0, total - L, (nq,), generator=gq, device=dev, dtype=torch.int64)
+    reads = torch.empty((nq, L), dtype=torch.uint8, device=dev)
+    ar = torch.arange(L, device=dev, dtype=torch.int64)
+    for lo in range(0, nq, 1 << 20):
+        hi = min(nq, lo + (1 << 20))
+        reads[lo:hi] = text[starts[lo:hi, None] + ar[None, :]]
+    if args.workload == "exact":                              # 10 % of the reads carry one substitution (early exits)
+        rows = torch.arange(0, nq, 10, device=dev)
+        nsub = torch.ones_like(rows)
+    else:                                                     # 0 / 1 / 2 substitutions in ratio 1:1:1
+        rows = torch.arange(0, nq, device=dev)
+        nsub = rows % 3
+    for k in range(2):
+        sel = rows[nsub > k]
+        pos = torch.randint(0, L, (sel.numel(),), generator=gq, device=dev)
+        shift = torch.randint(1, 4, (sel.numel(),), generator=gq, device=dev, dtype=torch.uint8)
+        reads[sel, pos] = (reads[sel, pos] - 1 + shift) % 4 + 1
+    qbuf = reads.reshape(-1)
+    qoff = (torch.arange(nq + 1, device=dev, dtype=torch.int64) * L)
+    torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- index construction on the GPU (not timed as a step)
+    bidir = args.workload == "k2"
+    want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    t0 = time.time()
+    cls = fm.BiFMIndex if bidir else fm.FMIndex
+    index = cls.from_sequences((_Dev(text), _Dev(seq_off)), 5, "IB16", 16, keep_host=want_cpu)
+    build_s = time.time() - t0
+    if not want_cpu:
+        del text
+    torch.cuda.empty_cache()
+
+    out = torch.empty(2 * nq, dtype=torch.int64, device=dev)     # [lb | len], one buffer so that the gather sends it as is
+    out_lb, out_len = out[:nq], out[nq:]
+    scheme = fm.search_scheme.h2(4, 0, 2)
+    hit_cap = 4 * nq
+    hits_buf = torch.empty(hit_cap * 40, dtype=torch.uint8, device=dev) if bidir else None
+    payload = out if not bidir else hits_buf[: 2 * nq * 40]      # k=2: the first 2*nq hit records (fixed-size message)
+    gathered = None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty_like(payload) for _ in range(world)]
+
+    import ctypes as C
+    stats = capi.Stats()
+    kernel_ms, units = [], []
+
+    def step():
+        if not bidir:
+            capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
+                                                     C.c_void_p(out_lb.data_ptr()), C.c_void_p(out_len.data_ptr()),
+                                                     C.byref(stats), None))
+        else:
+            sc = _scheme_struct(capi, scheme)
+            cnt = C.c_uint64()
+            capi.check(capi.lib().fmgpu_search_scheme(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
+                                                      C.byref(sc[0]), capi.UINT64_MAX, C.c_void_p(hits_buf.data_ptr()), hit_cap,
+                                                      C.byref(cnt), C.byref(stats), None))
+        kernel_ms.append(stats.kernel_ms)
+        units.append(stats.lf_steps)
+        if world > 1:                                          # the path's one exchange: SA intervals to rank 0 over RCCL/xGMI
+            dist.gather(payload, gathered, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear(); units.clear()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = world * nq * args.steps / elapsed
+    k_ms = sum(kernel_ms) / len(kernel_ms)
+    steps_per_launch = sum(units) / len(units)
+    alg_bytes = steps_per_launch * 2 * BLOCK_BYTES_IB16_S5
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    hits = int((out_len > 0).sum().item()) if not bidir else int(stats.hits)
+    result = {
+        "metric": "queries/sec (GRCh38-sized index, 10M x 101bp, %s)" % ("exact" if not bidir else "k=2 Hamming, h2(4,0,2)"),
+        "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "grch38_%s" % ("exact" if not bidir else "k2"), "text_symbols": total, "sequences": len(lengths),
+                   "sigma": 5, "layout": "InterleavedBitvector16", "queries_per_gpu": nq, "read_len": L,
+                   "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale,
+                   "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
+        "gbp_per_s": qps * L / 1e9,
+        "hits": hits,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_exact_a" if not bidir else "k_scheme", "kernel_ms": k_ms,
+                     "units_per_launch": steps_per_launch, "bytes_per_unit": 2 * BLOCK_BYTES_IB16_S5},
+    }
+    if want_cpu:
+        result["cpu_baseline"] = cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, args.cpu_sample, out_lb, out_len)
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+class _Dev:
+    """a torch tensor seen as a device buffer by the package (ptr + nbytes)"""
+
+    def __init__(self, t):
+        self.t = t
+        self.ptr = t.data_ptr()
+        self.nbytes = t.numel() * t.element_size()
+
+
+def _scheme_struct(capi, scheme):
+    import numpy as np
+    pi, l, u = (np.ascontiguousarray(x, dtype=np.uint64) for x in scheme)
+    sc = capi.Scheme()
+    sc.n_searches, sc.n_parts = pi.shape
+    sc.pi, sc.l, sc.u = (x.ctypes.data_as(capi.u64p) for x in (pi, l, u))
+    sc.partition = None
+    return sc, (pi, l, u)
+
+
+def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_len):
+    """the CPU restatement (oracle/) on the host cores, bounded sample of the same reads; also a parity spot-check"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fmoracle as fo
+    cores = len(os.sched_getaffinity(0))
+    t0 = time.time()
+    bwt = index.built_array(0)
+    bwt_rev = index.built_array(1) if bidir else None
+    ox = fo.OraIndex.from_bwt("IB16", 5, bwt, bwt_rev, None, None, None)
+    build = time.time() - t0
+    if sample <= 0:
+        sample = 400_000 if not bidir else 100_000
+    sample = min(sample, nq)
+    hq = qbuf[: sample * L].cpu().numpy()
+    ho = qoff[: sample + 1].cpu().numpy().astype(np.uint64)
+    if not bidir:
+        ox.search_exact(hq[: 1000 * L], ho[:1001], nthreads=cores)         # touch
+        t0 = time.time()
+        lb, ln = ox.search_exact(hq, ho, nthreads=cores)
+        dt = time.time() - t0
+        ok = bool(np.array_equal(lb, out_lb[:sample].cpu().numpy().astype(np.uint64)) and
+                  np.array_equal(ln, out_len[:sample].cpu().numpy().astype(np.uint64)))
+    else:
+        t0 = time.time()
+        _, qc, nodes = ox.search_ng26(hq, ho, scheme, nthreads=cores)
+        dt = time.time() - t0
+        ok = None
+    return {"value": sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": "%d of the same reads, OpenMP over queries, index rebuilt from the GPU-built BWT in %.0f s" % (sample, build),
+            "seconds": dt, "gpu_results_match_on_sample": ok}
+
+
+if __name__ == "__main__":
+    main()

@@ -139,7 +139,7 @@ class FMIndex:
             bidirectional = cls.bidirectional
         if isinstance(sequences, tuple):
             sbuf, soff = sequences
-            nseq = (len(soff) if not isinstance(soff, DeviceBuffer) else soff.nbytes // 8) - 1
+            nseq = (soff.nbytes // 8 if not hasattr(soff, "__len__") else len(soff)) - 1
         else:
             sbuf, soff = flatten(sequences)
             nseq = len(sequences)
@@ -213,7 +213,7 @@ class BiFMIndex(FMIndex):
 def _queries(queries):
     if isinstance(queries, tuple):
         qbuf, qoff = queries
-        nq = (qoff.nbytes // 8 if isinstance(qoff, DeviceBuffer) else len(qoff)) - 1
+        nq = (qoff.nbytes // 8 if not hasattr(qoff, "__len__") else len(qoff)) - 1
         return qbuf, qoff, nq
     qbuf, qoff = flatten(queries)
     return qbuf, qoff, len(queries)

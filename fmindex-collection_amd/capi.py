@@ -139,7 +139,7 @@ def ptr(a):
         return None
     if isinstance(a, (int, np.integer)):
         return C.c_void_p(int(a))
-    if isinstance(a, DeviceBuffer):
+    if hasattr(a, "ptr") and hasattr(a, "nbytes") and not hasattr(a, "ctypes"):   # DeviceBuffer or any (ptr, nbytes) device view
         return C.c_void_p(a.ptr)
     return C.c_void_p(a.ctypes.data)
 

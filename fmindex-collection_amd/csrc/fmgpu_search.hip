@@ -14,6 +14,7 @@
 #include "fmgpu_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace fmgpu {
 
@@ -46,6 +47,113 @@ __global__ __launch_bounds__(256) void k_exact(Occ occ, const uint8_t* __restric
             if (len == 0) break;
         }
         out_lb[q] = lb; out_len[q] = len;
+    }
+    uint32_t tot = wave_sum(steps);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
+}
+
+// ---- exact search, tuned variants (Format A only) ---------------------------------------------------------------
+// The query symbols are fetched as aligned 64-bit words one word ahead of use, so that the only load on the
+// dependent chain of an LF step is the occurrence-table entry; the second interval end re-uses the first end's
+// entry when both fall into the same 64-row block (the common case once the interval is short).
+struct QueryReader {
+    const uint64_t* base;   // 8-byte aligned
+    uint64_t pos;           // absolute byte position (relative to base) of the next symbol to hand out (moving down)
+    uint64_t cw, nw;        // current word, next (lower) word
+    __device__ __forceinline__ void init(const uint8_t* qbuf, uint64_t off, uint32_t m) {
+        uint64_t mis = (uint64_t)qbuf & 7ull;
+        base = reinterpret_cast<const uint64_t*>((uint64_t)qbuf - mis);
+        pos = off + mis + m - 1;                       // m >= 1
+        uint64_t w = pos >> 3;
+        cw = base[w];
+        nw = w ? base[w - 1] : 0;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        uint32_t c = (uint32_t)(cw >> ((pos & 7ull) * 8ull)) & 0xffu;
+        if ((pos & 7ull) == 0) {                       // crossing into the lower word: rotate and prefetch
+            uint64_t w = pos >> 3;
+            cw = nw;
+            nw = w >= 2 ? base[w - 2] : 0;
+        }
+        --pos;
+        return c;
+    }
+};
+
+template <int SIGMA, int VARIANT>
+__global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
+                                                 uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
+                                                 unsigned long long* __restrict__ steps_total) {
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t steps = 0;
+    if (q < nq) {
+        uint64_t o = qoff[q];
+        uint32_t m = (uint32_t)(qoff[q + 1] - o);
+        const uint32_t sigma = occ.sigma();
+        idx_t lb = 0, len = n;
+        if (m) {
+            QueryReader qr; qr.init(qbuf, o, m);
+            for (uint32_t i = 0; i < m; ++i) {
+                uint32_t c = qr.next();
+                ++steps;
+                if (c >= sigma) { lb = 0; len = 0; break; }
+                const idx_t a = lb, b = lb + len;
+                EntryA ea = load_entry_a(occ.v.blk, occ.v.bstride, a, c);
+                EntryA eb = ea;
+                if (VARIANT < 2 || (a >> 6) != (b >> 6)) eb = load_entry_a(occ.v.blk, occ.v.bstride, b, c);
+                idx_t ra = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
+                idx_t rb = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
+                lb = ra; len = rb - ra;
+                if (len == 0) break;
+            }
+        }
+        out_lb[q] = lb; out_len[q] = len;
+    }
+    uint32_t tot = wave_sum(steps);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
+}
+
+// two queries per lane, interleaved: twice the loads in flight per wave
+template <int SIGMA>
+__global__ __launch_bounds__(256) void k_exact_a2(OccA<SIGMA> occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
+                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
+                                                  unsigned long long* __restrict__ steps_total) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t half = (nq + 1) / 2;
+    uint32_t steps = 0;
+    if (t < half) {
+        const uint64_t q0 = t, q1 = t + half;
+        const bool has1 = q1 < nq;
+        const uint32_t sigma = occ.sigma();
+        uint64_t o0 = qoff[q0], o1 = has1 ? qoff[q1] : 0;
+        uint32_t m0 = (uint32_t)(qoff[q0 + 1] - o0), m1 = has1 ? (uint32_t)(qoff[q1 + 1] - o1) : 0;
+        idx_t lb0 = 0, len0 = n, lb1 = 0, len1 = n;
+        QueryReader r0, r1;
+        if (m0) r0.init(qbuf, o0, m0);
+        if (m1) r1.init(qbuf, o1, m1);
+        bool live0 = m0 != 0, live1 = m1 != 0;
+        uint32_t i0 = 0, i1 = 0;
+        while (live0 || live1) {
+            uint32_t c0 = 0, c1 = 0;
+            if (live0) { c0 = r0.next(); ++steps; if (c0 >= sigma) { lb0 = 0; len0 = 0; live0 = false; } }
+            if (live1) { c1 = r1.next(); ++steps; if (c1 >= sigma) { lb1 = 0; len1 = 0; live1 = false; } }
+            EntryA ea0{}, eb0{}, ea1{}, eb1{};
+            const idx_t a0 = lb0, b0 = lb0 + len0, a1 = lb1, b1 = lb1 + len1;
+            if (live0) { ea0 = load_entry_a(occ.v.blk, occ.v.bstride, a0, c0); eb0 = ea0; if ((a0 >> 6) != (b0 >> 6)) eb0 = load_entry_a(occ.v.blk, occ.v.bstride, b0, c0); }
+            if (live1) { ea1 = load_entry_a(occ.v.blk, occ.v.bstride, a1, c1); eb1 = ea1; if ((a1 >> 6) != (b1 >> 6)) eb1 = load_entry_a(occ.v.blk, occ.v.bstride, b1, c1); }
+            if (live0) {
+                idx_t ra = ea0.cnt + popc64(ea0.bits & lowmask(a0 & 63u)), rb = eb0.cnt + popc64(eb0.bits & lowmask(b0 & 63u));
+                lb0 = ra; len0 = rb - ra; ++i0;
+                if (len0 == 0 || i0 == m0) live0 = false;
+            }
+            if (live1) {
+                idx_t ra = ea1.cnt + popc64(ea1.bits & lowmask(a1 & 63u)), rb = eb1.cnt + popc64(eb1.bits & lowmask(b1 & 63u));
+                lb1 = ra; len1 = rb - ra; ++i1;
+                if (len1 == 0 || i1 == m1) live1 = false;
+            }
+        }
+        out_lb[q0] = lb0; out_len[q0] = len0;
+        if (has1) { out_lb[q1] = lb1; out_len[q1] = len1; }
     }
     uint32_t tot = wave_sum(steps);
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
@@ -456,12 +564,25 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     EventTimer timer(stream, stats != nullptr);
     dim3 grid((unsigned)((nq + 255) / 256)), block(256);
     const idx_t n = (idx_t)x->bwt.n;
+    const int variant = [] { const char* e = getenv("FMGPU_EXACT_VARIANT"); return e ? atoi(e) : 2; }();   // dev knob
     timer.start();
-    rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
-        k_exact<decltype(occ)><<<grid, block, 0, stream>>>(occ, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
-                                                          (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps);
-        return 0;
-    });
+    if (x->bwt.family == FAM_A && variant >= 1) {
+        auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
+        auto launch = [&](auto occ) {
+            using O = decltype(occ);
+            constexpr int SG = std::is_same_v<O, OccA<5>> ? 5 : 0;
+            if (variant == 1) k_exact_a<SG, 1><<<grid, block, 0, stream>>>(occ, qb, qo, nq, n, ol, on, dsteps);
+            else if (variant == 2) k_exact_a<SG, 2><<<grid, block, 0, stream>>>(occ, qb, qo, nq, n, ol, on, dsteps);
+            else k_exact_a2<SG><<<dim3((unsigned)(((nq + 1) / 2 + 255) / 256)), block, 0, stream>>>(occ, qb, qo, nq, n, ol, on, dsteps);
+        };
+        if (x->bwt.sigma == 5) launch(OccA<5>{x->bwt.va}); else launch(OccA<0>{x->bwt.va});
+    } else {
+        rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
+            k_exact<decltype(occ)><<<grid, block, 0, stream>>>(occ, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
+                                                              (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps);
+            return 0;
+        });
+    }
     timer.stop();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { (void)hipFree(dsteps); return hip_fail(e, "k_exact launch"); }
