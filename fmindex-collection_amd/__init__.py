@@ -297,10 +297,33 @@ def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False):
         hits["qidx"], hits["lb"], hits["len"] = keep, lb[keep], ln[keep]
         return hits
     qbuf, qoff, nq = _queries(queries)
-    scheme = search_scheme.h2(errors + 2, 0, errors)
-    if compat_auto_scheme:
-        scheme = search_scheme.limitToHamming(scheme)
-    return search_ng26.search(index, (qbuf, qoff), scheme, None, n)
+    if not isinstance(qoff, np.ndarray):                      # the facade splits the batch by length on the host
+        qoff = qoff.to_array(np.uint64, nq + 1) if isinstance(qoff, DeviceBuffer) else np.asarray(qoff)
+    if not isinstance(qbuf, np.ndarray):
+        qbuf = qbuf.to_array(np.uint8, int(qoff[-1]))
+    lens = np.diff(qoff.astype(np.int64))
+
+    def scheme_for(short):
+        # getCachedSearchScheme<false>(0, k, shortLen = (length == 2)): search/SearchNg26.h:436-444, CachedSearchScheme.h:16-36
+        sc = search_scheme.h2(errors + (1 if short else 2), 0, errors)
+        return search_scheme.limitToHamming(sc) if compat_auto_scheme else sc
+
+    parts = []
+    for short in (False, True):
+        sel = np.nonzero((lens == 2) == short)[0]
+        if sel.size == 0:
+            continue
+        sub = [qbuf[int(qoff[i]): int(qoff[i + 1])] for i in sel] if sel.size != nq else None
+        qb, qo = (qbuf, qoff) if sub is None else flatten(sub)
+        hits = search_ng26.search(index, (qb, qo), scheme_for(short), None, n)
+        if sub is not None:
+            hits = hits.copy()
+            hits["qidx"] = sel.astype(np.uint64)[hits["qidx"].astype(np.int64)]
+        parts.append(hits)
+    if not parts:
+        return np.zeros(0, dtype=HIT_DTYPE)
+    hits = np.concatenate(parts)
+    return hits[np.lexsort((hits["seq"], hits["qidx"]))]
 
 
 class LocateLinear:

@@ -129,9 +129,18 @@ struct OccA {
     template <int MS>
     __device__ __forceinline__ void all2(idx_t a, idx_t b, idx_t* lfa, idx_t* lfb) const {
         const uint32_t s = sigma();
+        if (MS <= 32) {
 #pragma unroll
-        for (uint32_t c = 0; c < (uint32_t)MS; ++c) {
-            if (c < s) {
+            for (uint32_t c = 0; c < (uint32_t)MS; ++c) {
+                if (c < s) {
+                    EntryA ea = load_entry_a(v.blk, v.bstride, a, c);
+                    EntryA eb = load_entry_a(v.blk, v.bstride, b, c);
+                    lfa[c] = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
+                    lfb[c] = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
+                }
+            }
+        } else {
+            for (uint32_t c = 0; c < s; ++c) {
                 EntryA ea = load_entry_a(v.blk, v.bstride, a, c);
                 EntryA eb = load_entry_a(v.blk, v.bstride, b, c);
                 lfa[c] = ea.cnt + popc64(ea.bits & lowmask(a & 63u));

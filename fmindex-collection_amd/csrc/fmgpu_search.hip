@@ -187,28 +187,86 @@ __device__ __forceinline__ void emit_hit(fmgpu_hit* out, uint64_t cap, Counters*
     }
 }
 
+// ---- symbol sets and children ----------------------------------------------------------------------------------
+// MAXSIG <= 32: one register word, arrays stay in registers (fully unrolled selects).  MAXSIG = 256: eight words, the
+// LF arrays live in scratch and are indexed dynamically (the reference itself does O(sigma) work per extend-all).
+template <int MAXSIG>
+struct SymSet {
+    static constexpr int W = (MAXSIG + 31) / 32;
+    uint32_t w[W];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < W; ++i) w[i] = 0;
+    }
+    __device__ __forceinline__ bool test(uint32_t s) const {
+        if (s >= (uint32_t)MAXSIG) return false;
+        if (W == 1) return (w[0] >> s) & 1u;
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) r = w[i];
+        return (r >> (s & 31u)) & 1u;
+    }
+    __device__ __forceinline__ void remove(uint32_t s) {
+        if (s >= (uint32_t)MAXSIG) return;
+#pragma unroll
+        for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) w[i] &= ~(1u << (s & 31u));
+    }
+    __device__ __forceinline__ bool any() const {
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) r |= w[i];
+        return r != 0;
+    }
+    __device__ __forceinline__ uint32_t first() const {     // lowest member; caller checks any()
+        uint32_t r = 0xffffffffu;
+#pragma unroll
+        for (int i = W - 1; i >= 0; --i) if (w[i]) r = (uint32_t)i * 32u + (uint32_t)__ffs((int)w[i]) - 1u;
+        return r;
+    }
+    __device__ __forceinline__ void clear_below(uint32_t s) {   // drop members < s
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            uint32_t lo = (uint32_t)i * 32u;
+            if (s >= lo + 32u) w[i] = 0;
+            else if (s > lo) w[i] &= ~((1u << (s - lo)) - 1u);
+        }
+    }
+};
+
+template <int MAXSIG>
+__device__ __forceinline__ SymSet<MAXSIG> alive_set(const idx_t* lfa, const idx_t* lfb, uint32_t sigma) {
+    SymSet<MAXSIG> m; m.clear();
+    if (MAXSIG <= 32) {
+#pragma unroll
+        for (uint32_t d = 0; d < (uint32_t)MAXSIG; ++d) if (d < sigma && lfb[d] != lfa[d]) m.w[0] |= 1u << d;
+    } else {
+        for (uint32_t d = 0; d < sigma; ++d) if (lfb[d] != lfa[d]) m.w[d >> 5] |= 1u << (d & 31u);
+    }
+    return m;
+}
+
 // kid cursor of symbol s from the LF values at both ends; `right` mirrors the roles (fmindex/BiFMIndexCursor.h:58-82)
 template <int MAXSIG>
 __device__ __forceinline__ Cur kid_of(const idx_t* lfa, const idx_t* lfb, Cur cur, uint32_t s, bool right, uint32_t sigma) {
-    idx_t pre = 0;
+    idx_t pre = 0, la = 0, lb = 0;
+    if (MAXSIG <= 32) {
 #pragma unroll
-    for (uint32_t d = 0; d < (uint32_t)MAXSIG; ++d) if (d < s && d < sigma) pre += lfb[d] - lfa[d];
-    idx_t la = 0, lb = 0;
-#pragma unroll
-    for (uint32_t d = 0; d < (uint32_t)MAXSIG; ++d) if (d == s) { la = lfa[d]; lb = lfb[d]; }
+        for (uint32_t d = 0; d < (uint32_t)MAXSIG; ++d) {
+            if (d < s && d < sigma) pre += lfb[d] - lfa[d];
+            if (d == s) { la = lfa[d]; lb = lfb[d]; }
+        }
+    } else {
+        for (uint32_t d = 0; d < s; ++d) pre += lfb[d] - lfa[d];
+        la = lfa[s]; lb = lfb[s];
+    }
     Cur k;
     k.len = lb - la;
     if (right) { k.lbRev = la; k.lb = cur.lb + pre; }
     else       { k.lb = la; k.lbRev = cur.lbRev + pre; }
     return k;
 }
-template <int MAXSIG>
-__device__ __forceinline__ uint32_t alive_mask(const idx_t* lfa, const idx_t* lfb, uint32_t sigma) {
-    uint32_t m = 0;
-#pragma unroll
-    for (uint32_t d = 0; d < (uint32_t)MAXSIG; ++d) if (d < sigma && lfb[d] != lfa[d]) m |= 1u << d;
-    return m;
-}
+
+constexpr uint32_t kNoResume = 0xffffffffu;
 
 // ---- search_ng26 Hamming --------------------------------------------------------------------------------------
 template <class Occ, int MAXSIG>
@@ -242,34 +300,24 @@ __global__ __launch_bounds__(256) void k_scheme(Occ fw, Occ rv, SchemeDev sch, c
             const uint8_t* pi = s_pi + si * kMaxParts; const uint8_t* L = s_l + si * kMaxParts; const uint8_t* U = s_u + si * kMaxParts;
             // run(): SearchNg26.h:62-79
             Cur cur{0, 0, n};
-            uint32_t e = 0, part = 0, qL = 0, qR = 0, pev, tail = 0, sp = 0, popmask = 0;
+            uint32_t e = 0, part = 0, qL = 0, qR = 0, pev, tail = 0, sp = 0, resume = kNoResume;
             for (uint32_t i = 0; i < pi[0]; ++i) { qL += part_len(i); qR += part_len(i); }
             qL -= 1;                                               // may wrap; not read until it is valid again
             pev = part_len(pi[0]);
             bool right = true;                                     // part == 0 -> Right
             bool running = cur.len != 0;
-            // `running` invariant at loop head: state is a STEP state (cur.len > 0, part < P, right set) or a resumed frame
+            // invariant at the loop head: a STEP state (cur.len > 0, part < P, `right` set), possibly a resumed frame
             while (running) {
                 const Occ& occ = right ? rv : fw;
                 const idx_t a = right ? cur.lbRev : cur.lb;
                 idx_t lfa[MAXSIG], lfb[MAXSIG];
                 occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);   // the memory phase
                 const uint32_t c = qs[right ? qR : qL];
-                const uint32_t alive = alive_mask<MAXSIG>(lfa, lfb, sigma);
+                const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
                 bool back = false, advance = false, to_next = false;
-                if (popmask) {                                     // resumed branching node: next pending substitution child
-                    uint32_t s = (uint32_t)__ffs((int)popmask) - 1u;
-                    popmask &= popmask - 1u;
-                    if (popmask) {                                 // keep the frame for the remaining siblings
-                        stk.p2[(uint64_t)sp * stk.nlanes + gid] = (stk.p2[(uint64_t)sp * stk.nlanes + gid] & ~0xffffffffull) | popmask;
-                        ++sp;
-                        popmask = 0;
-                    }
-                    cur = kid_of<MAXSIG>(lfa, lfb, cur, s, right, sigma);
-                    e += 1; advance = true;
-                } else if (tail) {                                 // search_next_dir_no_errors, :225-250 (one extension per iteration)
+                if (tail) {                                        // search_next_dir_no_errors, :225-250 (one extension per iteration)
                     ++nodes;
-                    if (c >= sigma || !((alive >> c) & 1u)) back = true;
+                    if (!alive.test(c)) back = true;
                     else {
                         cur = kid_of<MAXSIG>(lfa, lfb, cur, c, right, sigma);
                         if (right) ++qR; else --qL;
@@ -282,30 +330,32 @@ __global__ __launch_bounds__(256) void k_scheme(Occ fw, Occ rv, SchemeDev sch, c
                     // node accounting mirrors the reference's work: one per extend-all / extend; the single-row path
                     // extends once before it decides (:267-277) and once more per exact-tail step
                     if (cur.len > 1) {                             // search_next_dir, :143-224
-                        if (xOK || mOK) ++nodes;
+                        if (resume == kNoResume && (xOK || mOK)) ++nodes;
                         if (xOK) {
-                            uint32_t subs = sOK ? (alive & ~1u) : 0u;      // FirstSymb = 1 (fmindex/BiFMIndex.h:26)
-                            if (c < 32) subs &= ~(1u << c);
-                            const bool match = mOK && c < sigma && ((alive >> c) & 1u);
-                            if (!match && !subs) back = true;
+                            SymSet<MAXSIG> subs = alive;           // substitution children: FirstSymb = 1 (fmindex/BiFMIndex.h:26), != c
+                            if (!sOK) subs.clear();
+                            subs.remove(0); subs.remove(c);
+                            bool match = mOK && alive.test(c);
+                            if (resume != kNoResume) { subs.clear_below(resume); match = false; }
+                            if (!match && !subs.any()) back = true;
                             else {
-                                uint32_t first_sub = 0; bool take_sub = false;
-                                if (!match) { first_sub = (uint32_t)__ffs((int)subs) - 1u; subs &= subs - 1u; take_sub = true; }
-                                if (subs) {                        // push the parent with its pending substitution children
+                                uint32_t take = c;
+                                if (!match) { take = subs.first(); subs.remove(take); }
+                                if (subs.any()) {                  // (re-)push the parent: its remaining siblings start at subs.first()
                                     uint64_t w0 = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
                                     uint64_t w1 = (uint64_t)cur.len | ((uint64_t)(pev & 0xffffu) << 32) | ((uint64_t)(qR & 0xffffu) << 48);
-                                    uint64_t w2 = (uint64_t)subs | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
+                                    uint64_t w2 = (uint64_t)subs.first() | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
                                                   ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
                                     uint64_t o = (uint64_t)sp * stk.nlanes + gid;
                                     stk.p0[o] = w0; stk.p1[o] = w1; stk.p2[o] = w2;
                                     ++sp;
                                 }
-                                if (take_sub) { cur = kid_of<MAXSIG>(lfa, lfb, cur, first_sub, right, sigma); e += 1; }
-                                else cur = kid_of<MAXSIG>(lfa, lfb, cur, c, right, sigma);
+                                cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+                                if (!match) e += 1;
                                 advance = true;
                             }
                         } else if (mOK) {                          // exact tail; this iteration's blocks serve its first extension
-                            if (c >= sigma || !((alive >> c) & 1u)) back = true;
+                            if (!alive.test(c)) back = true;
                             else {
                                 cur = kid_of<MAXSIG>(lfa, lfb, cur, c, right, sigma);
                                 if (right) ++qR; else --qL;
@@ -314,9 +364,9 @@ __global__ __launch_bounds__(256) void k_scheme(Occ fw, Occ rv, SchemeDev sch, c
                             }
                         } else back = true;
                     } else {                                       // search_next_dir_single, :251-365: the one alive kid is the BWT symbol
-                        const uint32_t b = (uint32_t)__ffs((int)alive) - 1u;
+                        const uint32_t b = alive.first();
                         ++nodes;
-                        if (alive == 0 || b < 1) back = true;
+                        if (!alive.any() || b < 1) back = true;
                         else if (b == c) {
                             if (!mOK) back = true;
                             else if (!xOK) {                       // exact tail from here
@@ -330,6 +380,7 @@ __global__ __launch_bounds__(256) void k_scheme(Occ fw, Occ rv, SchemeDev sch, c
                         else back = true;
                     }
                 }
+                resume = kNoResume;
                 if (advance) {                                     // search_next_pos, :119-141 (children are never empty here)
                     if (right) ++qR; else --qL;
                     if (--pev == 0) { ++part; if (part != (uint32_t)P) pev = part_len(pi[part]); to_next = true; }
@@ -355,7 +406,7 @@ __global__ __launch_bounds__(256) void k_scheme(Occ fw, Occ rv, SchemeDev sch, c
                     uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o];
                     cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32);
                     cur.len = (idx_t)w1; pev = (uint32_t)(w1 >> 32) & 0xffffu; qR = (uint32_t)(w1 >> 48) & 0xffffu;
-                    popmask = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
+                    resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
                     right = (w2 >> 47) & 1u;
                     qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
                     tail = 0;
@@ -381,31 +432,31 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
         const uint8_t* qs = qbuf + qo;
         if (m > stk.depth) continue;
         Cur cur{0, 0, n};
-        uint32_t e = 0, i = 0, sp = 0, seq = 0;
-        uint32_t popmask = 0; bool resume = false;
-        bool running = true;
-        if (n == 0) running = false;                                 // Backtracking.h:43: empty cursor
+        uint32_t e = 0, i = 0, sp = 0, seq = 0, resume = kNoResume;
+        bool running = n != 0;                                       // Backtracking.h:43: empty cursor
         while (running) {
-            if (i == m && !resume) {                                 // :63 / :76 report
+            if (i == m && resume == kNoResume) {                     // :63 / :76 report
                 emit_hit(out, cap, ctr, q, cur, e, seq++);
             } else {
                 idx_t lfa[MAXSIG], lfb[MAXSIG];
                 fw.template all2<MAXSIG>(cur.lb, cur.lb + cur.len, lfa, lfb);
-                if (!resume) ++nodes;
+                if (resume == kNoResume) ++nodes;
                 const uint32_t r = qs[m - i - 1];
-                const uint32_t alive = alive_mask<MAXSIG>(lfa, lfb, sigma);
-                uint32_t subs;
-                if (resume) { subs = popmask; resume = false; }
-                else subs = e < K ? ((alive & ~1u) & ~(r < 32 ? (1u << r) : 0u)) : 0u;       // :52-56: s in [1, sigma), s != r
-                const bool match = r < sigma && ((alive >> r) & 1u);
-                if (subs) {
-                    uint32_t s = (uint32_t)__ffs((int)subs) - 1u;
-                    subs &= subs - 1u;
-                    if (subs || match) {                             // something is still pending at this node
+                const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+                SymSet<MAXSIG> subs = alive;                         // :52-56: s in [1, sigma), s != r, while e < K
+                if (e >= K) subs.clear();
+                subs.remove(0); subs.remove(r);
+                if (resume != kNoResume) subs.clear_below(resume);
+                resume = kNoResume;
+                const bool match = alive.test(r);
+                if (subs.any()) {
+                    uint32_t s = subs.first();
+                    subs.remove(s);
+                    if (subs.any() || match) {                       // something is still pending at this node
                         uint64_t o = (uint64_t)sp * stk.nlanes + gid;
                         stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
                         stk.p1[o] = (uint64_t)cur.len | ((uint64_t)i << 32);
-                        stk.p2[o] = (uint64_t)subs | ((uint64_t)e << 32) | (1ull << 63);
+                        stk.p2[o] = (uint64_t)(subs.any() ? subs.first() : 256u) | ((uint64_t)e << 32);
                         ++sp;
                     }
                     cur = kid_of<MAXSIG>(lfa, lfb, cur, s, false, sigma);
@@ -426,8 +477,7 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
             uint64_t o = (uint64_t)sp * stk.nlanes + gid;
             uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o];
             cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32); cur.len = (idx_t)w1; i = (uint32_t)(w1 >> 32);
-            popmask = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0x7fffffffu;
-            resume = true;
+            resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32);
         }
     }
     uint32_t tot = wave_sum(nodes);
@@ -483,10 +533,17 @@ static int dispatch_occ(const DevString& s, F&& f) {
     switch (s.family) {
     case FAM_A:
         if (s.sigma == 5) return f(OccA<5>{s.va}, std::integral_constant<int, 5>{});
-        return f(OccA<0>{s.va}, std::integral_constant<int, 32>{});
-    case FAM_EPR:   return f(OccR<false>{s.vr}, std::integral_constant<int, 32>{});
-    case FAM_EPRV2: return f(OccR<true>{s.vr}, std::integral_constant<int, 32>{});
-    default:        return f(OccW{s.vw}, std::integral_constant<int, 32>{});
+        if (s.sigma <= 32) return f(OccA<0>{s.va}, std::integral_constant<int, 32>{});
+        return f(OccA<0>{s.va}, std::integral_constant<int, 256>{});
+    case FAM_EPR:
+        if (s.sigma <= 32) return f(OccR<false>{s.vr}, std::integral_constant<int, 32>{});
+        return f(OccR<false>{s.vr}, std::integral_constant<int, 256>{});
+    case FAM_EPRV2:
+        if (s.sigma <= 32) return f(OccR<true>{s.vr}, std::integral_constant<int, 32>{});
+        return f(OccR<true>{s.vr}, std::integral_constant<int, 256>{});
+    default:
+        if (s.sigma <= 32) return f(OccW{s.vw}, std::integral_constant<int, 32>{});
+        return f(OccW{s.vw}, std::integral_constant<int, 256>{});
     }
 }
 
@@ -606,7 +663,6 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (out_count) *out_count = 0;
     if (nq == 0) return 0;
     if (!qbuf || !qoff || (!out && capacity) || !out_count) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out / out_count is null");
-    if (x->bwt.sigma > 32) return fail(FMGPU_ERR_UNSUPPORTED, "k-mismatch search kernels support sigma <= 32 in this build");
     SchemeDev sd{};
     if (scheme_mode) {
         if (!x->bidirectional) return fail(FMGPU_ERR_INVALID, "search_ng26 needs a BiFMIndex (bwt_rev)");

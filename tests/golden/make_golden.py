@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Generates the committed fixtures under tests/golden/ (run in the build container, where /root/reference exists).
+
+  reference_tests.json   DATA of the reference's own tests for this path — literal input vectors and expected values
+                         picked out of src/test_fmindex-collection/*.cpp (file:line recorded per entry).  No source
+                         text is kept, only numbers.
+  ref_strings.json       vectors produced by the REAL reference headers (oracle/_ref/libfmref.so): rank / prefix_rank /
+                         symbol tables and layout checksums of the occurrence-table types on seeded texts.
+  ref_schemes.json       search-scheme tables produced by the real reference (h2, pigeon_opt, backtracking, expand,
+                         limitToHamming, isValid, isComplete, nodeCount, createUniformPartition).
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import re
+import sys
+import zlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+TESTS = "/root/reference/src/test_fmindex-collection"
+
+
+# ----------------------------------------------------------------------------------------------- reference test data
+def _tok(t):
+    t = t.strip()
+    if not t:
+        return None
+    if t.startswith("'"):
+        body = t[1:-1]
+        if body == "\\0":
+            return 0
+        if body.startswith("\\"):
+            return {"n": 10, "t": 9, "\\": 92, "'": 39}[body[1]]
+        return ord(body)
+    t = re.sub(r"(ull|ul|u|l)$", "", t)
+    return int(t, 0)
+
+
+def _list_after(src, marker, start=0):
+    """numbers of the first brace-enclosed initialiser list after `marker`"""
+    i = src.index(marker, start)
+    i = src.index("{", i + len(marker) - 1) if not marker.endswith("{") else i + len(marker) - 1
+    depth, j = 0, i
+    while True:
+        if src[j] == "{":
+            depth += 1
+        elif src[j] == "}":
+            depth -= 1
+            if depth == 0:
+                break
+        j += 1
+    body = src[i + 1: j]
+    # split on commas that are not inside a char literal
+    toks = re.findall(r"'(?:\\.|[^'])'|[^,\s{}]+", body)
+    return [v for v in (_tok(t) for t in toks) if v is not None], j
+
+
+def _line_of(src, pos):
+    return src.count("\n", 0, pos) + 1
+
+
+def reference_tests():
+    out = {"_provenance": "values transcribed by tests/golden/make_golden.py from the reference's test sources (data only)"}
+    # --- string/unittest.cpp: hand counted "Hallo Welt" (sigma 255) and the 310-symbol text
+    src = open(f"{TESTS}/string/unittest.cpp").read()
+    text, _ = _list_after(src, "auto text = std::vector<uint8_t>{'H', 'a', 'l', 'l', 'o', ' ', 'W', 'e', 'l', 't'};".split("{")[0] + "{")
+    rank, prank = [], []
+    for m in re.finditer(r"CHECK\(vec\.(rank|prefix_rank)\(\s*(\d+),\s*('(?:\\.|[^'])')\)\s*==\s*(\d+)\);", src):
+        (rank if m.group(1) == "rank" else prank).append([int(m.group(2)), _tok(m.group(3)), int(m.group(4))])
+    out["hallo_welt"] = {"source": "string/unittest.cpp:52-312", "sigma": 255, "text": text[:10], "rank": rank, "prefix_rank": prank}
+    i = src.index("check symbol vectors construction on text longer than 255 characters")
+    long_text, _ = _list_after(src, "auto text = std::vector<uint8_t>{", i)
+    out["long_text"] = {"source": "string/unittest.cpp:314-398", "sigma": 255, "text": long_text,
+                        "expect": "rank/prefix_rank/symbol/all_ranks_and_prefix_ranks equal naive counts for every idx and symbol"}
+    # --- fmindex/checkFMIndex.cpp, checkBiFMIndex.cpp: literal BWT / SA
+    src = open(f"{TESTS}/fmindex/checkFMIndex.cpp").read()
+    bwt, _ = _list_after(src, "auto bwt    = std::vector<uint8_t>{")
+    sa, _ = _list_after(src, "auto sa     = std::vector<uint64_t>{")
+    out["fmindex_hallo"] = {"source": "fmindex/checkFMIndex.cpp:15-110", "sigma": 255, "bwt": bwt, "sa": sa,
+                            "expect": "locate(i): seqId == 0 and pos + offset == sa[i] for full, every-2nd-row(+sa==0), odd-row and every-2nd-text sampling"}
+    src = open(f"{TESTS}/fmindex/checkBiFMIndex.cpp").read()
+    bwt, p = _list_after(src, "auto bwt    = std::vector<uint8_t>{")
+    bwtr, p = _list_after(src, "auto bwtRev = std::vector<uint8_t>{", p)
+    sa, p = _list_after(src, "auto sa     = std::vector<uint64_t>{", p)
+    out["bifmindex_hallo"] = {"source": "fmindex/checkBiFMIndex.cpp:13-105", "sigma": 255, "bwt": bwt, "bwtRev": bwtr, "sa": sa}
+    j = src.index("checking bidirectional fm index on longer text")
+    bwt, p = _list_after(src, "auto bwt    = std::vector<uint8_t>{", j)
+    bwtr, p = _list_after(src, "auto bwtRev = std::vector<uint8_t>{", p)
+    sa, p = _list_after(src, "auto sa     = std::vector<uint64_t>{", p)
+    out["bifmindex_long"] = {"source": "fmindex/checkBiFMIndex.cpp:136-222", "sigma": 255, "bwt": bwt, "bwtRev": bwtr, "sa": sa}
+    # --- cursors
+    out["cursor"] = {"source": "fmindex/checkFMIndexCursor.cpp:13-66, fmindex/checkBiFMIndexCursor.cpp:12-103", "sigma": 256,
+                     "data": [[1, 1, 1, 1, 2, 2, 2]], "sampling_rate": 1,
+                     "extend": [[0, 1, 0], [1, 4, 1], [2, 3, 5], [3, 0, 8]],     # symbol, count, lb (left and right)
+                     "rows": [0, 1, 2, 3, 4, 5, 6, 7]}
+    # --- searches
+    src = open(f"{TESTS}/search/checkSearches.cpp").read()
+    A, B, Cc, D = ord("A"), ord("B"), ord("C"), ord("D")
+    inp = [[A, A, A, Cc, A, A, A, B, A, A, A], [A, A, A, B, A, A, A, Cc, A, A, A]]
+    i = src.index('SECTION("backtracking, all search")')
+    exp, _ = _list_after(src, "auto expected = std::vector<std::tuple<size_t, size_t, size_t>> {", i)
+    exp8 = [exp[k: k + 3] for k in range(0, len(exp), 3)]
+    i = src.index('SECTION("search, hamming distance, all search, no search scheme")')
+    exp, _ = _list_after(src, "auto expected = std::vector<std::tuple<size_t, size_t, size_t>> {", i)
+    exph = [exp[k: k + 3] for k in range(0, len(exp), 3)]
+    i = src.index('SECTION("search no errors, all search")')
+    exp, _ = _list_after(src, "auto expected = std::vector<std::tuple<size_t, size_t, size_t>> {", i)
+    out["searches"] = {"source": "search/checkSearches.cpp:14-72, :104-117, :1173-1199, :1482-1505", "sigma": 256, "sampling_rate": 1,
+                       "input": inp, "queries": [[Cc, Cc], [B, B]],
+                       "backtracking_k1": exp8, "hamming_k1_facade": exph, "no_errors": [exp[k: k + 3] for k in range(0, len(exp), 3)]}
+    src = open(f"{TESTS}/search/checkSearchBacktracking.cpp").read()
+    i = src.index("searching with collection and backtracking")
+    bexp, p = _list_after(src, "auto expected = std::vector<uint8_t>{", i)
+    j = src.index("auto expected = std::vector<std::tuple<uint32_t, uint32_t>> {", p)
+    nums = [int(x) for x in re.findall(r"make_tuple\((\d+)ull,\s*(\d+)ull\)", src[j: src.index("};", j)]) for x in x]
+    out["collection"] = {"source": "search/checkSearchBacktracking.cpp:42-102", "sigma": 255, "sampling_rate": 1,
+                         "input": [[A, A, A, Cc, A, A, A, Cc, A, A, A], [A, A, A, B, A, A, A, B, A, A, A]],
+                         "bwt": bexp, "query_A": {"lb": 2, "count": 18},
+                         "locate": [nums[k: k + 2] for k in range(0, len(nums), 2)]}
+    out["single"] = {"source": "search/checkSearchBacktracking.cpp:12-40", "sigma": 255, "sampling_rate": 1,
+                     "input": [[A, A, A, Cc, A, A, A, Cc, A, A, A]],
+                     "bwt": [A, A, A, Cc, Cc, 0, A, A, A, A, A, A], "query_A": {"lb": 1, "count": 9}}
+    out["fmindex_backtracking"] = {"source": "search/checkSearchBacktracking.cpp:295-327", "sigma": 256, "sampling_rate": 1,
+                                   "input": inp, "queries": [[Cc, Cc], [B, B]], "k": 1, "expected": exp8}
+    # --- search_scheme/expand.cpp
+    out["expand"] = {"source": "search_scheme/expand.cpp:11-60", "cases": [
+        {"in": [[0, 1], [0, 0], [0, 0]], "len": 10, "out": [list(range(10)), [0] * 10, [0] * 10]},
+        {"in": [[0, 1], [0, 0], [0, 1]], "len": 4, "out": [[0, 1, 2, 3], [0, 0, 0, 0], [0, 0, 1, 1]]},
+        {"in": [[0, 1], [0, 0], [0, 1]], "len": 3, "out": [[0, 1, 2], [0, 0, 0], [0, 0, 1]]}]}
+    out["h2_complete"] = {"source": "search_scheme/checkGeneratorsIsComplete.cpp:48-60",
+                          "expect": "isComplete(h2(N, minK, maxK), minK, maxK) for N in 1..9, minK <= maxK < min(N, 5)"}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- vectors from the real reference
+def ref_vectors():
+    import fmoracle as fo
+    from tests.util import make_text
+    if not fo.ref_available():
+        raise SystemExit("oracle/_ref/libfmref.so missing: run `make -C oracle ref` first")
+    strings = []
+    cases = [("IB16", 5, 300), ("IB16", 5, 4100), ("IB8", 5, 600), ("IB32", 5, 200), ("IB16A", 5, 300), ("IBP16", 5, 700),
+             ("EPR16", 5, 500), ("EPR8", 5, 504), ("EPR8", 5, 700), ("EPRV2_16", 5, 600), ("EPRV2_8", 5, 512), ("EPRV2_8", 5, 700),
+             ("WAVELET", 5, 900), ("WAVELET", 28, 1200), ("IB16", 28, 400), ("EPR16", 28, 300), ("EPRV2_16", 28, 300),
+             ("IB16", 255, 310), ("WAVELET", 255, 310), ("IB16", 4, 257), ("EPRV2_16", 6, 129), ("IB16", 21, 200)]
+    for layout, sigma, n in cases:
+        text = make_text(n, sigma, seed=n + sigma, lo=0)
+        r = fo.RefString(layout, sigma, text)
+        rk, pr = r.rank_table()
+        sym = [r.symbol(i) for i in range(n)]
+        entry = {"layout": layout, "sigma": sigma, "n": n, "seed": n + sigma, "block_stride": r.block_stride(),
+                 "rank_crc": zlib.crc32(rk.tobytes()), "prefix_rank_crc": zlib.crc32(pr.tobytes()),
+                 "symbol_crc": zlib.crc32(np.array(sym, dtype=np.uint8).tobytes()),
+                 "rank_last_row": rk[-1].tolist(), "prefix_last_row": pr[-1].tolist()}
+        if layout != "WAVELET":
+            cnt, words, sup = r.block_fields()
+            entry.update({"n_blocks": int(cnt.shape[0]), "n_super": int(sup.shape[0]),
+                          "counts_crc": zlib.crc32(cnt.tobytes()), "words_crc": zlib.crc32(words.tobytes()), "super_crc": zlib.crc32(sup.tobytes())})
+        else:
+            nn = 1 << max(1, (sigma - 1).bit_length())
+            entry["node_crc"] = [zlib.crc32(b"".join(r.raw(4 * k + j).tobytes() for j in range(4))) for k in range(nn)]
+        if n <= 310:
+            entry["rank_table"] = rk.tolist() if sigma <= 6 else None
+        strings.append(entry)
+    schemes = {"h2": [], "pigeon_opt": [], "pigeon_trivial": [], "backtracking": [], "expand": [], "limitToHamming": [], "partition": []}
+    for K in range(0, 5):
+        for minK in range(0, K + 1):
+            for N in range(K + 1, K + 4):
+                s = fo.ref_scheme_h2(N, minK, K)
+                schemes["h2"].append({"N": N, "minK": minK, "K": K, "pi": s[0].tolist(), "l": s[1].tolist(), "u": s[2].tolist(),
+                                      "valid": fo.ref_scheme_is_valid(s), "complete": fo.ref_scheme_is_complete(s, minK, K),
+                                      "nodeCount_sigma5": fo.ref_scheme_node_count_hamming(s, 5)})
+                if minK == 0:
+                    for L in (N, N + 3, 31, 101):
+                        e = fo.ref_scheme_expand(s, L)
+                        h = fo.ref_scheme_limit_to_hamming(e)
+                        schemes["expand"].append({"gen": "h2", "N": N, "K": K, "len": L, "searches": int(e[0].shape[0]),
+                                                  "crc": zlib.crc32(b"".join(x.tobytes() for x in e)),
+                                                  "hamming_crc": zlib.crc32(b"".join(x.tobytes() for x in h))})
+                    h = fo.ref_scheme_limit_to_hamming(s)
+                    schemes["limitToHamming"].append({"N": N, "K": K, "l": h[1].tolist(), "u": h[2].tolist()})
+            for name, fn in (("pigeon_opt", fo.ref_scheme_pigeon_opt), ("pigeon_trivial", fo.ref_scheme_pigeon_trivial)):
+                s = fn(minK, K)
+                schemes[name].append({"minK": minK, "K": K, "pi": s[0].tolist(), "l": s[1].tolist(), "u": s[2].tolist(),
+                                      "complete": fo.ref_scheme_is_complete(s, minK, K)})
+            s = fo.ref_scheme_backtracking(4, minK, K)
+            schemes["backtracking"].append({"N": 4, "minK": minK, "K": K, "pi": s[0].tolist(), "l": s[1].tolist(), "u": s[2].tolist()})
+    for parts, total in ((4, 101), (4, 151), (3, 31), (2, 2), (5, 7), (1, 9)):
+        schemes["partition"].append({"parts": parts, "total": total, "out": fo.ref_uniform_partition(parts, total).tolist()})
+    return strings, schemes
+
+
+def main():
+    with open(os.path.join(HERE, "reference_tests.json"), "w") as f:
+        json.dump(reference_tests(), f, separators=(",", ":"))
+    strings, schemes = ref_vectors()
+    with open(os.path.join(HERE, "ref_strings.json"), "w") as f:
+        json.dump({"_provenance": "produced by the real reference headers via oracle/_ref/libfmref.so (tests/golden/make_golden.py); "
+                                  "texts = tests.util.make_text(n, sigma, seed, lo=0)", "cases": strings}, f, separators=(",", ":"))
+    with open(os.path.join(HERE, "ref_schemes.json"), "w") as f:
+        json.dump({"_provenance": "produced by the real reference's search_scheme headers via oracle/_ref/libfmref.so", **schemes}, f, separators=(",", ":"))
+    print("wrote", os.listdir(HERE))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""Host-side logic of the product (search-scheme tables, query flattening, locate expansion, sharding) and the C-ABI surface.
+CPU only: no compute call is made — without a GPU the library must refuse loudly."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+import fmindex_collection_amd as fm
+from fmindex_collection_amd import capi, search_scheme as ss
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REFSCH = json.load(open(os.path.join(GOLD, "ref_schemes.json")))
+REF = json.load(open(os.path.join(GOLD, "reference_tests.json")))
+
+
+def _eq(a, b):
+    return all(np.asarray(x).shape == np.asarray(y).shape and np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built_library():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "fmindex-collection_amd", "csrc"), "-j4", "-s"], check=True)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "fmgpu.h")).read()
+    declared = set(re.findall(r"\b(fmgpu_[a-z0-9_]+)\s*\(", header))
+    assert declared and declared == set(capi.EXPORTS)
+    L = capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert L.fmgpu_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    n = C.c_int(-1)
+    rc = capi.lib().fmgpu_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(fm.FmgpuError) as e:
+        fm.FMIndex.from_sequences([[1, 2, 3]], 5)
+    assert e.value.code == capi.FMGPU_ERR_NO_DEVICE
+    d = capi.IndexDesc()
+    h = C.c_void_p()
+    assert capi.lib().fmgpu_index_create(C.byref(d), C.byref(h)) == capi.FMGPU_ERR_NO_DEVICE
+    assert b"no CPU fallback" in capi.lib().fmgpu_last_error()
+
+
+def test_argument_errors():
+    L = capi.lib()
+    assert L.fmgpu_index_create(None, None) == capi.FMGPU_ERR_INVALID
+    assert L.fmgpu_search_exact(None, None, None, 1, None, None, None, None) == capi.FMGPU_ERR_INVALID
+    assert L.fmgpu_index_destroy(None) == 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "fmindex-collection_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "fmoracle" not in src and "oracle/" not in src, f
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "fmoracle" not in open(os.path.join(ROOT, "include", f)).read()
+
+
+# ------------------------------------------------------------------------------------------------ search schemes (host tables)
+def test_scheme_generators_match_the_real_reference():
+    for g in REFSCH["h2"]:
+        s = ss.h2(g["N"], g["minK"], g["K"])
+        assert _eq(s, (g["pi"], g["l"], g["u"])), g
+        assert ss.isValid(s) == g["valid"] and ss.isComplete(s, g["minK"], g["K"]) == g["complete"]
+        assert ss.nodeCount(s, 5) == pytest.approx(g["nodeCount_sigma5"], rel=1e-9)
+    for name, fn in (("pigeon_opt", ss.pigeon_opt), ("pigeon_trivial", ss.pigeon_trivial)):
+        for g in REFSCH[name]:
+            s = fn(g["minK"], g["K"])
+            assert _eq(s, (g["pi"], g["l"], g["u"])) and ss.isComplete(s, g["minK"], g["K"]) == g["complete"]
+    for g in REFSCH["backtracking"]:
+        assert _eq(ss.backtracking(g["N"], g["minK"], g["K"]), (g["pi"], g["l"], g["u"]))
+    for g in REFSCH["expand"]:
+        e = ss.expand(ss.h2(g["N"], 0, g["K"]), g["len"])
+        assert e[0].shape[0] == g["searches"] and zlib.crc32(b"".join(np.ascontiguousarray(x).tobytes() for x in e)) == g["crc"], g
+        assert zlib.crc32(b"".join(np.ascontiguousarray(x).tobytes() for x in ss.limitToHamming(e))) == g["hamming_crc"]
+    for g in REFSCH["limitToHamming"]:
+        h = ss.limitToHamming(ss.h2(g["N"], 0, g["K"]))
+        assert h[1].tolist() == g["l"] and h[2].tolist() == g["u"]
+    for g in REFSCH["partition"]:
+        assert ss.createUniformPartition(g["parts"], g["total"]).tolist() == g["out"]
+
+
+def test_scheme_reference_test_cases():
+    """search_scheme/expand.cpp:11-60, checkGeneratorsIsComplete.cpp:48-60"""
+    for c in REF["expand"]["cases"]:
+        e = ss.expand(tuple(np.array([x], dtype=np.uint64) for x in c["in"]), c["len"])
+        assert ss.isValid(e) and _eq(e, tuple(np.array([x]) for x in c["out"]))
+    for N in range(1, 10):
+        for minK in range(0, min(N, 5)):
+            for maxK in range(minK, min(N, 5)):
+                assert ss.isComplete(ss.h2(N, minK, maxK), minK, maxK)
+    assert not ss.isValid((np.array([[0, 2, 1]]), np.zeros((1, 3), dtype=int), np.ones((1, 3), dtype=int)))
+    assert not ss.isComplete((np.array([[0, 1, 2]]), np.zeros((1, 3), dtype=int), np.array([[0, 1, 1]])), 0, 2)
+    with pytest.raises(ValueError):
+        ss.h2(2, 0, 2)
+    with pytest.raises(ValueError):
+        ss.createUniformPartition(4, 3)
+    assert ss.createUniformPartition(ss.h2(4, 0, 2), 101).tolist() == [26, 25, 25, 25]
+    assert ss.createUniformPartition(4, 151).tolist() == [38, 38, 38, 37]
+
+
+def test_flatten_and_locate_expansion():
+    qbuf, qoff = fm.flatten([[1, 2, 3], [], [4]])
+    assert qoff.tolist() == [0, 3, 3, 4] and qbuf[:4].tolist() == [1, 2, 3, 4]
+    qbuf, qoff = fm.flatten([])
+    assert qoff.tolist() == [0]
+    ll = fm.LocateLinear(None, [10, 3, 7], [2, 0, 3])
+    assert ll.rows.tolist() == [10, 11, 7, 8, 9] and ll.owner.tolist() == [0, 0, 2, 2, 2]
+
+
+def test_shard_ranges_cover_the_batch():
+    from fmindex_collection_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 100, 10_000_001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1

@@ -1,0 +1,337 @@
+"""The oracle (oracle/fmoracle.c) against every golden vector of the reference for this path, against vectors produced by
+the real reference headers, and against brute force.  CPU only."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import fmoracle as fo
+from tests.util import make_text, occurrences
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REF = json.load(open(os.path.join(GOLD, "reference_tests.json")))
+REFSTR = json.load(open(os.path.join(GOLD, "ref_strings.json")))
+REFSCH = json.load(open(os.path.join(GOLD, "ref_schemes.json")))
+
+ALL_LAYOUTS = list(fo.LAYOUTS)
+
+
+def naive_rank(text, idx, c):
+    return int(np.count_nonzero(np.asarray(text[:idx]) == c))
+
+
+def naive_prefix(text, idx, c):
+    return int(np.count_nonzero(np.asarray(text[:idx]) < c))
+
+
+# ------------------------------------------------------------------------------------------------ strings
+@pytest.mark.parametrize("layout", ALL_LAYOUTS)
+def test_hallo_welt_hand_counted(layout):
+    """string/unittest.cpp:52-312 — every hand counted rank / prefix_rank value"""
+    g = REF["hallo_welt"]
+    s = fo.OraString(layout, g["sigma"], g["text"])
+    assert s.size() == 10
+    for i, c in enumerate(g["text"]):
+        assert s.symbol(i) == c
+    for idx, sym, val in g["rank"]:
+        assert s.rank(idx, sym) == val, (idx, sym)
+    for idx, sym, val in g["prefix_rank"]:
+        assert s.prefix_rank(idx, sym) == val, (idx, sym)
+    for idx in range(10):
+        rs, prs = s.all_ranks_and_prefix_ranks(idx)
+        for sym in (32, 72, 87, 97, 101, 108, 111, 116, 122):
+            assert rs[sym] == s.rank(idx, sym) and prs[sym] == s.prefix_rank(idx, sym)
+
+
+@pytest.mark.parametrize("layout", ALL_LAYOUTS)
+def test_long_text_crossing_255(layout):
+    """string/unittest.cpp:314-398 — 310 symbols, naive counts for every idx and symbol"""
+    g = REF["long_text"]
+    text = np.array(g["text"], dtype=np.uint8)
+    s = fo.OraString(layout, g["sigma"], text)
+    assert s.size() == len(text) == 310
+    for i in range(len(text)):
+        assert s.symbol(i) == text[i]
+    present = sorted(set(text.tolist())) + [1, 200]
+    for idx in range(0, len(text) + 1):
+        rs, prs = s.all_ranks_and_prefix_ranks(idx)
+        for sym in present:
+            assert s.rank(idx, sym) == naive_rank(text, idx, sym) == rs[sym]
+            assert s.prefix_rank(idx, sym) == naive_prefix(text, idx, sym) == prs[sym]
+
+
+@pytest.mark.parametrize("case", REFSTR["cases"], ids=lambda c: f"{c['layout']}-s{c['sigma']}-n{c['n']}")
+def test_strings_against_real_reference_vectors(case):
+    """tables and layout bytes produced by the REAL reference headers (tests/golden/ref_strings.json)"""
+    text = make_text(case["n"], case["sigma"], seed=case["seed"], lo=0)
+    s = fo.OraString(case["layout"], case["sigma"], text)
+    rk, pr = s.rank_table()
+    assert zlib.crc32(rk.tobytes()) == case["rank_crc"]
+    assert zlib.crc32(pr.tobytes()) == case["prefix_rank_crc"]
+    assert rk[-1].tolist() == case["rank_last_row"] and pr[-1].tolist() == case["prefix_last_row"]
+    sym = np.array([s.symbol(i) for i in range(case["n"])], dtype=np.uint8)
+    assert zlib.crc32(sym.tobytes()) == case["symbol_crc"] and np.array_equal(sym, text)
+    if case["layout"] != "WAVELET":
+        assert s.block_stride() == case["block_stride"]
+        cnt, words, sup = s.block_fields()
+        assert (cnt.shape[0], sup.shape[0]) == (case["n_blocks"], case["n_super"])
+        assert zlib.crc32(cnt.tobytes()) == case["counts_crc"]
+        assert zlib.crc32(words.tobytes()) == case["words_crc"]
+        assert zlib.crc32(sup.tobytes()) == case["super_crc"]
+    else:
+        nn = 1 << max(1, (case["sigma"] - 1).bit_length())
+        crc = [zlib.crc32(b"".join(s.raw(4 * k + j).tobytes() for j in range(4))) for k in range(nn)]
+        assert crc == case["node_crc"]
+    if case.get("rank_table"):
+        assert rk.tolist() == case["rank_table"]
+
+
+@pytest.mark.skipif(not fo.ref_available(), reason="oracle/_ref/libfmref.so not built (needs /root/reference)")
+@pytest.mark.parametrize("layout", ALL_LAYOUTS)
+def test_strings_live_against_real_reference(layout):
+    """direct comparison with the reference headers compiled in place, incl. the 16-bit super-block boundaries"""
+    rng = np.random.default_rng(11)
+    sizes = [0, 1, 63, 64, 65, 255, 256, 257, 1000]
+    if "16" in layout or layout == "WAVELET":
+        sizes += [65519, 65520, 65536, 65537]
+    for sigma in (4, 5, 28):
+        for n in sizes:
+            if n > 10000 and sigma != 5:
+                continue
+            text = rng.integers(0, sigma, size=n, dtype=np.uint8)
+            o, r = fo.OraString(layout, sigma, text), fo.RefString(layout, sigma, text)
+            if layout != "WAVELET":
+                for a, b in zip(o.block_fields(), r.block_fields()):
+                    assert a.shape == b.shape and np.array_equal(a, b), (layout, sigma, n)
+            idxs = range(n + 1) if n <= 1000 else list(range(0, n + 1, 997)) + [n - 1, n, 65535, 65536][: 2 + 2 * (n >= 65536)]
+            for i in idxs:
+                for c in range(sigma):
+                    assert o.rank(i, c) == r.rank(i, c), (layout, sigma, n, i, c)
+                    assert o.prefix_rank(i, c) == r.prefix_rank(i, c), (layout, sigma, n, i, c)
+                if i < n:
+                    assert o.symbol(i) == r.symbol(i)
+
+
+# ------------------------------------------------------------------------------------------------ search schemes
+def _eq(a, b):
+    return all(np.asarray(x).shape == np.asarray(y).shape and np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_schemes_against_real_reference_vectors():
+    for g in REFSCH["h2"]:
+        s = fo.scheme_h2(g["N"], g["minK"], g["K"])
+        assert _eq(s, (g["pi"], g["l"], g["u"])), g
+        assert fo.scheme_is_valid(s) == g["valid"] and fo.scheme_is_complete(s, g["minK"], g["K"]) == g["complete"]
+        assert fo.scheme_node_count_hamming(s, 5) == pytest.approx(g["nodeCount_sigma5"], rel=1e-12)
+    for name, fn in (("pigeon_opt", fo.scheme_pigeon_opt), ("pigeon_trivial", fo.scheme_pigeon_trivial)):
+        for g in REFSCH[name]:
+            s = fn(g["minK"], g["K"])
+            assert _eq(s, (g["pi"], g["l"], g["u"])) and fo.scheme_is_complete(s, g["minK"], g["K"]) == g["complete"]
+    for g in REFSCH["backtracking"]:
+        assert _eq(fo.scheme_backtracking(g["N"], g["minK"], g["K"]), (g["pi"], g["l"], g["u"]))
+    for g in REFSCH["expand"]:
+        e = fo.scheme_expand(fo.scheme_h2(g["N"], 0, g["K"]), g["len"])
+        assert e[0].shape[0] == g["searches"] and zlib.crc32(b"".join(x.tobytes() for x in e)) == g["crc"], g
+        h = fo.scheme_limit_to_hamming(e)
+        assert zlib.crc32(b"".join(x.tobytes() for x in h)) == g["hamming_crc"]
+    for g in REFSCH["limitToHamming"]:
+        h = fo.scheme_limit_to_hamming(fo.scheme_h2(g["N"], 0, g["K"]))
+        assert h[1].tolist() == g["l"] and h[2].tolist() == g["u"]
+    for g in REFSCH["partition"]:
+        assert fo.uniform_partition(g["parts"], g["total"]).tolist() == g["out"]
+
+
+def test_scheme_reference_test_cases():
+    """search_scheme/expand.cpp:11-60 and checkGeneratorsIsComplete.cpp:48-60"""
+    for c in REF["expand"]["cases"]:
+        sch = tuple(np.array([x], dtype=np.uint64) for x in c["in"])
+        e = fo.scheme_expand(sch, c["len"])
+        assert fo.scheme_is_valid(e) and _eq(e, tuple(np.array([x], dtype=np.uint64) for x in c["out"]))
+    for N in range(1, 10):
+        for minK in range(0, min(N, 5)):
+            for maxK in range(minK, min(N, 5)):
+                assert fo.scheme_is_complete(fo.scheme_h2(N, minK, maxK), minK, maxK), (N, minK, maxK)
+
+
+# ------------------------------------------------------------------------------------------------ index fixtures
+def _sampled_index(layout, g, rule, bidir):
+    bwt, sa = np.array(g["bwt"], dtype=np.uint8), np.array(g["sa"], dtype=np.uint64)
+    has = np.array([rule(i, int(sa[i])) for i in range(len(sa))], dtype=np.uint8)
+    rev = np.array(g["bwtRev"], dtype=np.uint8) if bidir else None
+    return fo.OraIndex.from_bwt(layout, g["sigma"], bwt, rev, has, np.zeros(len(sa), dtype=np.uint64), sa), has, sa
+
+
+SAMPLINGS = {"full": lambda i, s: True, "every2nd_row": lambda i, s: i % 2 == 0 or s == 0, "odd_rows": lambda i, s: i % 2 == 1,
+             "every2nd_text": lambda i, s: s % 2 == 0}
+
+
+@pytest.mark.parametrize("layout", ["IB16", "IBP16", "EPR16", "EPRV2_16", "WAVELET"])
+@pytest.mark.parametrize("fixture,bidir", [("fmindex_hallo", False), ("bifmindex_hallo", True), ("bifmindex_long", True)])
+def test_index_locate_fixtures(layout, fixture, bidir):
+    """fmindex/checkFMIndex.cpp:15-110, fmindex/checkBiFMIndex.cpp:13-105, :136-222"""
+    g = REF[fixture]
+    for name, rule in SAMPLINGS.items():
+        if fixture == "bifmindex_long" and name == "odd_rows":
+            continue
+        x, has, sa = _sampled_index(layout, g, rule, bidir)
+        assert x.n == len(sa)
+        for i in range(len(sa)):
+            seq, pos, off = x.locate(i)
+            assert seq == 0 and pos + off == sa[i], (name, i)
+            step = x.single_locate_step(i)
+            assert (step == (0, int(sa[i]))) if has[i] else (step is None)
+            if name == "full":
+                assert off == 0
+
+
+@pytest.mark.parametrize("bidir", [False, True])
+def test_cursor_fixture(bidir):
+    """fmindex/checkFMIndexCursor.cpp:13-66, fmindex/checkBiFMIndexCursor.cpp:12-103"""
+    g = REF["cursor"]
+    x = fo.OraIndex.build("IB16", g["sigma"], g["data"], g["sampling_rate"], bidir)
+    cur = x.cursor()
+    assert (cur.lb, cur.len) == (0, x.n) and x.n == 8
+    left_all = x.extend_left_all(cur)
+    for sym, count, lb in g["extend"]:
+        c = x.extend_left(cur, sym)
+        assert (c.len, c.lb) == (count, lb)
+        if bidir:
+            c = x.extend_right(cur, sym)
+            assert (c.len, c.lb) == (count, lb)
+    for sym in range(g["sigma"]):
+        c = x.extend_left(cur, sym)
+        assert (c.lb, c.len) == (left_all[sym].lb, left_all[sym].len)
+    if bidir:
+        right_all = x.extend_right_all(cur)
+        for sym in range(g["sigma"]):
+            c = x.extend_right(cur, sym)
+            assert (c.lb, c.len) == (right_all[sym].lb, right_all[sym].len)
+
+
+def _located(x, hits):
+    out = []
+    for h in hits:
+        for r in range(int(h["lb"]), int(h["lb"] + h["len"])):
+            s, p, o = x.locate(r)
+            out.append([int(h["qidx"]), s, p + o])
+    return sorted(out)
+
+
+def test_search_fixtures():
+    """search/checkSearches.cpp:23-72, :104-117, :1482-1505; search/checkSearchBacktracking.cpp:295-327"""
+    g = REF["searches"]
+    qbuf, qoff = fo.flatten_queries(g["queries"])
+    for bidir in (False, True):
+        x = fo.OraIndex.build("IB16", g["sigma"], g["input"], g["sampling_rate"], bidir)
+        hits, _ = x.search_backtracking(qbuf, qoff, 1)
+        assert _located(x, hits) == g["backtracking_k1"]
+        lb, ln = x.search_exact(qbuf, qoff)
+        assert ln.tolist() == [0, 0] and g["no_errors"] == []
+    x = fo.OraIndex.build("IB16", g["sigma"], g["input"], g["sampling_rate"], True)
+    # fmc::search<false>(index, queries, 1, ...): h2(2, 0, 1) for length-2 queries + limitToHamming (CachedSearchScheme.h:26-30)
+    sch = fo.scheme_limit_to_hamming(fo.scheme_h2(2, 0, 1))
+    hits, _, _ = x.search_ng26(qbuf, qoff, sch)
+    assert _located(x, hits) == g["hamming_k1_facade"]
+    hits, _, _ = x.search_ng26(qbuf, qoff, fo.scheme_pigeon_opt(0, 1))
+    assert _located(x, hits) == g["backtracking_k1"]
+
+
+def test_collection_fixture():
+    """search/checkSearchBacktracking.cpp:12-40, :42-102 — BWT rows, 'A' interval and the locate table"""
+    for key in ("collection", "single"):
+        g = REF[key]
+        x = fo.OraIndex.build("IB16", g["sigma"], g["input"], g["sampling_rate"], True)
+        assert [x.bwt_string().symbol(i) for i in range(x.n)] == g["bwt"]
+        qbuf, qoff = fo.flatten_queries([[ord("A")]])
+        hits, _ = x.search_backtracking(qbuf, qoff, 0)
+        assert len(hits) == 1 and (hits[0]["lb"], hits[0]["len"], hits[0]["errors"]) == (g["query_A"]["lb"], g["query_A"]["count"], 0)
+        if "locate" in g:
+            for i, (seq, pos) in enumerate(g["locate"]):
+                s, p, o = x.locate(i)
+                assert (s, p + o) == (seq, pos)
+
+
+# ------------------------------------------------------------------------------------------------ brute force
+def _concat(seqs):
+    t = []
+    for s in seqs:
+        t += list(s) + [0]
+    return np.array(t, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("layout", ["IB16", "EPR16", "EPRV2_16", "WAVELET", "IBP16"])
+def test_exact_intervals_match_text_scan(layout):
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(1, 5, size=n, dtype=np.uint8) for n in (700, 45, 1300)]
+    seqs[1][:20] = seqs[0][100:120]                       # shared substrings -> multi-occurrence intervals
+    x = fo.OraIndex.build(layout, 5, seqs, 4, True)
+    text = _concat(seqs)
+    queries = [text[s: s + m] for s, m in ((3, 5), (100, 20), (100, 12), (742, 3), (800, 40))] + [np.array([1, 2, 3, 4, 1, 1, 1, 2, 2], dtype=np.uint8)]
+    qbuf, qoff = fo.flatten_queries(queries)
+    lb, ln = x.search_exact(qbuf, qoff)
+    for q, query in enumerate(queries):
+        pos, _ = occurrences(text, query)
+        pos = [p for p in pos if 0 not in text[p: p + len(query)]]
+        assert ln[q] == len(pos)
+        found = sorted(x.locate(int(r))[1] + x.locate(int(r))[2] + int(np.cumsum([0] + [len(s) + 1 for s in seqs])[x.locate(int(r))[0]]) for r in range(int(lb[q]), int(lb[q] + ln[q])))
+        assert found == sorted(int(p) for p in pos)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_ng26_equals_backtracking_equals_text_scan(k):
+    """h2(k+2, 0, k) with a uniform partition is complete and non-redundant: same multiset as naive backtracking and as a
+    scan of the text (the explicit-scheme overload is the k-mismatch contract)"""
+    rng = np.random.default_rng(100 + k)
+    base = rng.integers(1, 5, size=400, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[50:250], rng.integers(1, 5, size=300, dtype=np.uint8)]), base[::-1].copy()]
+    text = _concat(seqs)
+    x = fo.OraIndex.build("IB16", 5, seqs, 1, True)
+    queries = []
+    for i in range(60):
+        m = int(rng.integers(k + 2, 40))
+        s = int(rng.integers(0, len(seqs[0]) - m))
+        q = seqs[0][s: s + m].copy()
+        for _ in range(int(rng.integers(0, k + 2))):
+            q[int(rng.integers(0, m))] = rng.integers(1, 5)
+        queries.append(q)
+    qbuf, qoff = fo.flatten_queries(queries)
+    sch = fo.scheme_h2(k + 2, 0, k)
+    nh, qc, _ = x.search_ng26(qbuf, qoff, sch)
+    bh, _ = x.search_backtracking(qbuf, qoff, k)
+    key = lambda h: sorted(zip(h["qidx"].tolist(), h["lb"].tolist(), h["len"].tolist(), h["errors"].tolist()))
+    assert key(nh) == key(bh)
+    assert qc.sum() == len(nh)
+    starts = np.cumsum([0] + [len(s) + 1 for s in seqs])
+    for q, query in enumerate(queries):
+        pos, mism = occurrences(text, query, k)
+        ok = [(int(p), int(e)) for p, e in zip(pos, mism) if 0 not in text[p: p + len(query)]]
+        got = []
+        for h in nh[nh["qidx"] == q]:
+            for r in range(int(h["lb"]), int(h["lb"] + h["len"])):
+                s, p, o = x.locate(r)
+                got.append((int(starts[s]) + p + o, int(h["errors"])))
+        assert sorted(got) == sorted(ok), q
+
+
+def test_search_n_clips_like_the_reference():
+    """search_ng26 search_n semantics (SearchNg26.h:407-423): stop after exactly n rows, clip the last cursor"""
+    seqs = [np.array([1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 3], dtype=np.uint8)]
+    x = fo.OraIndex.build("IB16", 5, seqs, 1, True)
+    qbuf, qoff = fo.flatten_queries([[1, 2], [2, 1, 2]])
+    sch = fo.scheme_pigeon_opt(0, 1)
+    full, _, _ = x.search_ng26(qbuf, qoff, sch)
+    for n in (1, 2, 3, 5, 100):
+        hits, qc, _ = x.search_ng26(qbuf, qoff, sch, max_hits=n)
+        for q in range(2):
+            tot_full = int(full[full["qidx"] == q]["len"].sum())
+            assert int(hits[hits["qidx"] == q]["len"].sum()) == min(n, tot_full)
+
+
+def test_suffix_array_and_bwt_small():
+    text = np.array([2, 1, 3, 1, 2, 1, 0, 2, 1, 0], dtype=np.uint8)
+    sa = np.zeros(len(text), dtype=np.uint64)
+    assert fo.lib().ora_suffix_array(fo._p8(text), len(text), fo._p64(sa)) == 0
+    naive = sorted(range(len(text)), key=lambda i: bytes(text[i:].tolist()))
+    assert sa.tolist() == naive
