@@ -464,7 +464,10 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
     }
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return bail(hip_fail(e, "index construction"));
-    x->device_bytes += x->bwt.blk_bytes + x->rev.blk_bytes;
+    text.release(); sa.release(); bwt.release();
+    if ((rc = build_lf_table(x->bwt, stream))) return bail(rc);
+    if (x->bidirectional && (rc = build_lf_table(x->rev, stream))) return bail(rc);
+    x->device_bytes += x->bwt.blk_bytes + x->rev.blk_bytes + (x->bwt.lf_table ? n * sizeof(idx_t) : 0) + (x->rev.lf_table ? n * sizeof(idx_t) : 0);
     *out = reinterpret_cast<fmgpu_index_t>(x.release());
     if (built_out) *built_out = reinterpret_cast<fmgpu_built_t>(built.release());
     return 0;

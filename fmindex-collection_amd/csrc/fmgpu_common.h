@@ -129,6 +129,26 @@ struct OccA {
     template <int MS>
     __device__ __forceinline__ void all2(idx_t a, idx_t b, idx_t* lfa, idx_t* lfb) const {
         const uint32_t s = sigma();
+        if (SIGMA > 0 && SIGMA <= 5) {
+            // 64-byte block = one line: fetch it whole (4 x dwordx4); both ends usually share the block once the
+            // interval is short, then the second fetch is skipped
+            // both ends' loads are issued back to back (one round trip); a wave holds 64 out-of-phase lanes, so "rare"
+            // second fetches would otherwise be paid by the whole wave in nearly every iteration
+            uint32_t da[16], db[16];
+            const uint4* pa = reinterpret_cast<const uint4*>(v.blk + (size_t)(a >> 6) * 64u);
+            const uint4* pb = reinterpret_cast<const uint4*>(v.blk + (size_t)(b >> 6) * 64u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { uint4 t = pa[k]; da[4 * k] = t.x; da[4 * k + 1] = t.y; da[4 * k + 2] = t.z; da[4 * k + 3] = t.w; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { uint4 t = pb[k]; db[4 * k] = t.x; db[4 * k + 1] = t.y; db[4 * k + 2] = t.z; db[4 * k + 3] = t.w; }
+            const uint64_t ma = lowmask(a & 63u), mb = lowmask(b & 63u);
+#pragma unroll
+            for (uint32_t c = 0; c < (uint32_t)SIGMA; ++c) {
+                lfa[c] = da[3 * c] + popc64(((uint64_t)da[3 * c + 1] | ((uint64_t)da[3 * c + 2] << 32)) & ma);
+                lfb[c] = db[3 * c] + popc64(((uint64_t)db[3 * c + 1] | ((uint64_t)db[3 * c + 2] << 32)) & mb);
+            }
+            return;
+        }
         if (MS <= 32) {
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)MS; ++c) {
@@ -340,7 +360,14 @@ struct DevString {
     void* aux = nullptr;       // Format R superBlocks / Format W node_base
     size_t blk_bytes = 0, aux_bytes = 0;
     ViewA va{}; ViewR vr{}; ViewW vw{};
+    // explicit LF mapping: lf_table[i] = C[s[i]] + rank(i, s[i])  (n entries; the symbol is recovered from C).
+    // 4 bytes per row buy one-load single-row DFS nodes and one-load locate steps; skipped with FMGPU_LF_TABLE=0.
+    idx_t* lf_table = nullptr;
 };
+
+// fills s.lf_table from the device string (all layouts); defined in fmgpu_index.hip
+int build_lf_table(DevString& s, hipStream_t stream);
+void free_string(DevString& s);
 
 struct Index {
     DevString bwt, rev;

@@ -2,6 +2,7 @@
 #include "fmgpu_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
 #include <new>
 
@@ -136,10 +137,39 @@ static int upload(const void* host, size_t bytes, void** dev) {
     return 0;
 }
 
-static void free_string(DevString& s) {
+void free_string(DevString& s) {
     if (s.blk) (void)hipFree(s.blk);
     if (s.aux) (void)hipFree(s.aux);
-    s.blk = s.aux = nullptr;
+    if (s.lf_table) (void)hipFree(s.lf_table);
+    s.blk = s.aux = nullptr; s.lf_table = nullptr;
+}
+
+template <class Occ>
+__global__ __launch_bounds__(256) void k_lf_table(Occ occ, uint64_t n, idx_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c;
+    out[i] = occ.lf_symbol((idx_t)i, c);
+}
+
+int build_lf_table(DevString& s, hipStream_t stream) {
+    const char* e = getenv("FMGPU_LF_TABLE");
+    if (e && atoi(e) == 0) return 0;
+    if (s.n == 0) return 0;
+    FM_HIP(hipMalloc((void**)&s.lf_table, s.n * sizeof(idx_t)));
+    dim3 grid((unsigned)((s.n + 255) / 256)), block(256);
+    switch (s.family) {
+    case FAM_A:
+        if (s.sigma == 5) k_lf_table<OccA<5>><<<grid, block, 0, stream>>>(OccA<5>{s.va}, s.n, s.lf_table);
+        else k_lf_table<OccA<0>><<<grid, block, 0, stream>>>(OccA<0>{s.va}, s.n, s.lf_table);
+        break;
+    case FAM_EPR:   k_lf_table<OccR<false>><<<grid, block, 0, stream>>>(OccR<false>{s.vr}, s.n, s.lf_table); break;
+    case FAM_EPRV2: k_lf_table<OccR<true>><<<grid, block, 0, stream>>>(OccR<true>{s.vr}, s.n, s.lf_table); break;
+    default:        k_lf_table<OccW><<<grid, block, 0, stream>>>(OccW{s.vw}, s.n, s.lf_table); break;
+    }
+    FM_HIP(hipGetLastError());
+    FM_HIP(hipStreamSynchronize(stream));
+    return 0;
 }
 
 static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
@@ -296,7 +326,10 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
     if (rc) return bail(rc);
     rc = create_string(desc->bwt, x->dC, x->bwt); if (rc) return bail(rc);
     if (desc->bwt_rev) { rc = create_string(*desc->bwt_rev, x->dC, x->rev); if (rc) return bail(rc); x->bidirectional = true; }
-    x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->rev.blk_bytes + x->rev.aux_bytes;
+    rc = build_lf_table(x->bwt, nullptr); if (rc) return bail(rc);
+    if (x->bidirectional) { rc = build_lf_table(x->rev, nullptr); if (rc) return bail(rc); }
+    x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->rev.blk_bytes + x->rev.aux_bytes +
+                      (x->bwt.lf_table ? x->bwt.n * sizeof(idx_t) : 0) + (x->rev.lf_table ? x->rev.n * sizeof(idx_t) : 0);
     if (const fmgpu_sparse_array_desc* sa = desc->annotated_array) {
         if (sa->n != desc->bwt.n) return bail(fail(FMGPU_ERR_INVALID, "annotated_array.n != bwt.n"));
         if (sa->n_l0 < sa->n / 65536 + 1 || sa->n_l1 < sa->n / 512 + 1 || sa->n_bit_words < (sa->n / 512 + 1) * 8)

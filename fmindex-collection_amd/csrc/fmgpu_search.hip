@@ -15,6 +15,10 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 namespace fmgpu {
 
@@ -169,6 +173,7 @@ struct SchemeDev {             // flattened [search][part]; values fit a byte (e
     uint32_t partition[kMaxParts];   // used when uniform == 0
     uint32_t psum;                   // sum of partition[] (queries of another length are skipped)
     int uniform;
+    int dev_flags;                   // dev knobs: 1 = count hits per lane only (no records)
 };
 
 struct Counters { unsigned long long hits, nodes, next; };
@@ -268,11 +273,54 @@ __device__ __forceinline__ Cur kid_of(const idx_t* lfa, const idx_t* lfb, Cur cu
 
 constexpr uint32_t kNoResume = 0xffffffffu;
 
+// ---- per-lane query staging in LDS ------------------------------------------------------------------------------
+// A DFS visits a few hundred nodes per query; reading the query symbol of every node from global memory costs a
+// second random line per node (half a million lanes' query lines do not survive in L2).  Each lane therefore copies
+// its query once into LDS: word w of lane t at  lds[w * 256 + t]  (bank = t mod 32/64: conflict-free), 8 symbols per
+// word as nibbles (sigma <= 15; 15 = "not a symbol") or 4 symbols per word as bytes.
+struct QStage {
+    uint32_t* lds;          // this block's staging area
+    uint32_t words;         // words per query (0 = staging disabled: read global memory)
+    uint32_t nib;           // 1 = 4-bit symbols
+};
+__device__ __forceinline__ void qstage_load(const QStage& st, const uint8_t* qbuf, uint64_t off, uint32_t m, uint32_t sigma) {
+    if (!st.words) return;
+    const uint64_t addr = (uint64_t)qbuf + off;
+    const uint32_t mis = (uint32_t)(addr & 7ull);
+    const uint64_t* base = reinterpret_cast<const uint64_t*>(addr - mis);
+    const uint32_t last = (mis + m - 1u) >> 3;                     // last aligned word that holds query bytes (m >= 1)
+    uint64_t lo = base[0];
+    const uint32_t per = st.nib ? 8u : 4u;
+    uint32_t wi = 0;
+    for (uint32_t k = 0; k * 8u < m; ++k) {
+        uint64_t hi = (k + 1 <= last) ? base[k + 1] : 0ull;
+        uint64_t x = mis ? ((lo >> (8u * mis)) | (hi << (64u - 8u * mis))) : lo;   // query bytes 8k .. 8k+7
+        lo = hi;
+        if (st.nib) {
+            uint32_t w = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) { uint32_t b = (uint32_t)(x >> (8u * j)) & 0xffu; w |= (b >= sigma || b > 14u ? 15u : b) << (4u * j); }
+            st.lds[wi * 256u + threadIdx.x] = w; ++wi;
+        } else {
+            st.lds[wi * 256u + threadIdx.x] = (uint32_t)x; ++wi;
+            if ((k * 8u + 4u) < m) { st.lds[wi * 256u + threadIdx.x] = (uint32_t)(x >> 32); ++wi; }
+        }
+    }
+    (void)per;
+}
+__device__ __forceinline__ uint32_t qstage_get(const QStage& st, const uint8_t* qs, uint32_t p) {
+    if (!st.words) return qs[p];
+    if (st.nib) { uint32_t v = (st.lds[(p >> 3) * 256u + threadIdx.x] >> ((p & 7u) * 4u)) & 15u; return v == 15u ? 255u : v; }
+    return (st.lds[(p >> 2) * 256u + threadIdx.x] >> ((p & 3u) * 8u)) & 255u;
+}
+
 // ---- search_ng26 Hamming --------------------------------------------------------------------------------------
 template <class Occ, int MAXSIG>
-__global__ __launch_bounds__(256) void k_scheme(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
+__global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
                                                 const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
-                                                fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk) {
+                                                fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib) {
+    extern __shared__ uint32_t s_query[];
+    const QStage qst{s_query, qwords, qnib};
     __shared__ uint8_t s_pi[kMaxSearches * kMaxParts], s_l[kMaxSearches * kMaxParts], s_u[kMaxSearches * kMaxParts];
     __shared__ uint32_t s_part[kMaxParts];
     for (int i = threadIdx.x; i < kMaxSearches * kMaxParts; i += blockDim.x) { s_pi[i] = sch.pi[i]; s_l[i] = sch.l[i]; s_u[i] = sch.u[i]; }
@@ -281,138 +329,368 @@ __global__ __launch_bounds__(256) void k_scheme(Occ fw, Occ rv, SchemeDev sch, c
 
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t sigma = fw.sigma();
-    const int P = sch.P, S = sch.S;
+    const uint32_t P = (uint32_t)sch.P, S = (uint32_t)sch.S;
     uint32_t nodes = 0;
 
-    for (uint64_t q = gid; q < nq; q += stk.nlanes) {
-        const uint64_t qo = qoff[q];
-        const uint32_t m = (uint32_t)(qoff[q + 1] - qo);
-        const uint8_t* qs = qbuf + qo;
-        if (m < (uint32_t)P || m > stk.depth) continue;          // expand.h:325-327 precondition (the reference asserts)
-        if (!sch.uniform && m != sch.psum) continue;             // an explicit partition must cover the query exactly
-        uint64_t quota = max_hits;
-        uint32_t seq = 0;
-        bool query_done = false;
-        auto part_len = [&](uint32_t p) -> uint32_t {             // createUniformPartition, expand.h:324-335
-            return sch.uniform ? (m / (uint32_t)P + (p < m % (uint32_t)P ? 1u : 0u)) : s_part[p];
-        };
-        for (int si = 0; si < S && !query_done; ++si) {
-            const uint8_t* pi = s_pi + si * kMaxParts; const uint8_t* L = s_l + si * kMaxParts; const uint8_t* U = s_u + si * kMaxParts;
+    // One flat loop over (query, search, node): a lane that finishes a search starts its next search — or its next
+    // query — in the same iteration the other lanes of the wave spend on a node, so the wave never waits for its
+    // slowest search.  The node logic is written branch-light: the reference's case analysis (exact tail / extend-all
+    // node / single-row fast path / resumed sibling) is folded into a few predicates that pick ONE child symbol
+    // `take`; the child cursor is then computed once for all cases.
+    // Queries are handed out in batches of kBatch through a global counter (the first batch of every lane is static);
+    // the atomicAdd for the NEXT batch is issued when a batch is started, so its latency never sits on the critical
+    // path, and the grid needs no assumption about how many blocks are resident.
+    constexpr uint64_t kBatch = 4;
+    uint64_t q = gid * kBatch, q_end = q + kBatch;            // current query / end of the current batch
+    uint64_t next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
+    uint32_t si = S;                        // current search; si == S: fetch the next query first
+    bool first = true;
+    const uint8_t* qs = qbuf; uint32_t m = 0, pbase = 0, prem = 0;
+    uint64_t quota = 0; uint32_t seq = 0;
+    Cur cur{0, 0, 0};
+    uint32_t e = 0, part = 0, qL = 0, qR = 0, pev = 0, tail = 0, sp = 0, resume = kNoResume;
+    bool right = true;
+    const uint8_t *pi = s_pi, *L = s_l, *U = s_u;
+    auto part_len = [&](uint32_t p) -> uint32_t {                  // createUniformPartition, expand.h:324-335
+        return sch.uniform ? pbase + (p < prem ? 1u : 0u) : s_part[p];
+    };
+    bool need_search = true;
+    for (;;) {
+        if (need_search) {
+            // search_impl / search_n_impl driver (SearchNg26.h:369-391, :407-423)
+            if (si + 1 < S && !first && quota != 0) ++si;
+            else {
+                if (!first) ++q;
+                first = false;
+                bool found = false;
+                for (;;) {
+                    if (q >= q_end) {                             // batch exhausted: switch to the prefetched one, prefetch another
+                        q = next_batch; q_end = q + kBatch;
+                        if (q >= nq) break;
+                        next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
+                    }
+                    if (q >= nq) break;
+                    const uint64_t qo = qoff[q];
+                    m = (uint32_t)(qoff[q + 1] - qo);
+                    qs = qbuf + qo;
+                    // expand.h:325-327 precondition (the reference asserts); an explicit partition must cover the query exactly
+                    if (m >= P && m <= stk.depth && (sch.uniform || m == sch.psum) && n != 0) { found = true; break; }
+                    ++q;
+                }
+                if (!found) break;
+                si = 0; quota = max_hits; seq = 0;
+                pbase = m / P; prem = m - pbase * P;
+                qstage_load(qst, qbuf, qoff[q], m, sigma);
+            }
+            pi = s_pi + si * kMaxParts; L = s_l + si * kMaxParts; U = s_u + si * kMaxParts;
             // run(): SearchNg26.h:62-79
-            Cur cur{0, 0, n};
-            uint32_t e = 0, part = 0, qL = 0, qR = 0, pev, tail = 0, sp = 0, resume = kNoResume;
-            for (uint32_t i = 0; i < pi[0]; ++i) { qL += part_len(i); qR += part_len(i); }
+            cur = Cur{0, 0, n};
+            e = 0; part = 0; qL = 0; qR = 0; tail = 0; sp = 0; resume = kNoResume;
+            for (uint32_t i = 0; i < pi[0]; ++i) { uint32_t pl = part_len(i); qL += pl; qR += pl; }
             qL -= 1;                                               // may wrap; not read until it is valid again
             pev = part_len(pi[0]);
-            bool right = true;                                     // part == 0 -> Right
-            bool running = cur.len != 0;
-            // invariant at the loop head: a STEP state (cur.len > 0, part < P, `right` set), possibly a resumed frame
-            while (running) {
-                const Occ& occ = right ? rv : fw;
-                const idx_t a = right ? cur.lbRev : cur.lb;
-                idx_t lfa[MAXSIG], lfb[MAXSIG];
-                occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);   // the memory phase
-                const uint32_t c = qs[right ? qR : qL];
-                const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
-                bool back = false, advance = false, to_next = false;
-                if (tail) {                                        // search_next_dir_no_errors, :225-250 (one extension per iteration)
-                    ++nodes;
-                    if (!alive.test(c)) back = true;
-                    else {
-                        cur = kid_of<MAXSIG>(lfa, lfb, cur, c, right, sigma);
-                        if (right) ++qR; else --qL;
-                        if (--tail == 0) { ++part; pev = part != (uint32_t)P ? part_len(pi[part]) : 0; to_next = true; }
-                    }
+            right = true;                                          // part == 0 -> Right
+            need_search = false;
+        }
+        // invariant here: a STEP state (cur.len > 0, part < P, `right` set), possibly a resumed frame
+        const Occ& occ = right ? rv : fw;
+        const idx_t a = right ? cur.lbRev : cur.lb;
+        idx_t lfa[MAXSIG], lfb[MAXSIG];
+        occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);       // the memory phase
+        const uint32_t c = qstage_get(qst, qs, right ? qR : qL);
+        const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+        const bool c_alive = alive.test(c);
+
+        // ---- case analysis -> (ok, take, is_sub, start_tail, push) ------------------------------------------------
+        const bool in_tail = tail != 0;                            // search_next_dir_no_errors, :225-250
+        const bool multi = cur.len > 1;                            // search_next_dir (:143-224) vs search_next_dir_single (:251-365)
+        const bool resuming = resume != kNoResume;
+        const uint32_t Lp = L[part], Up = U[part];
+        const bool mOK = (pev > 1 || Lp <= e) && e <= Up;
+        const bool sOK = (pev > 1 || Lp <= e + 1) && e + 1 <= Up;
+        const bool xOK = e + 1 <= Up;
+        SymSet<MAXSIG> subs = alive;                               // substitution children of an extend-all node:
+        subs.remove(0); subs.remove(c);                            //   FirstSymb = 1 (fmindex/BiFMIndex.h:26), != query symbol
+        if (in_tail || !multi || !xOK || !sOK) subs.clear();
+        if (resuming) subs.clear_below(resume);
+        const uint32_t b = alive.first();                          // single row: the one alive child is the BWT symbol
+        const bool single_ok = !in_tail && !multi && alive.any() && b >= 1;
+        const bool take_match = in_tail ? c_alive
+                              : multi   ? (!resuming && mOK && c_alive)                   // match child first (also the exact-tail start when !xOK)
+                                        : (single_ok && b == c && mOK);
+        const bool take_sub = !take_match && (multi ? subs.any() : (single_ok && b != c && xOK && sOK));
+        const bool ok = take_match || take_sub;
+        uint32_t take = c;
+        if (take_sub) { take = multi ? subs.first() : b; }
+        if (take_sub && multi) subs.remove(take);
+        if (take_match && multi && !xOK) subs.clear();
+        const bool start_tail = !in_tail && take_match && !xOK;    // :225 from dir (:222) or from single (:310-314)
+        // node accounting mirrors the reference's work (one per extend-all / extend; the single-row path extends once
+        // before deciding, :267-277, and once more per exact-tail step)
+        nodes += in_tail ? 1u : multi ? ((!resuming && (xOK || mOK)) ? 1u : 0u) : (1u + ((take_match && !xOK) ? 1u : 0u));
+        if (ok && multi && !in_tail && subs.any()) {               // (re-)push the parent: its remaining siblings start at subs.first()
+            uint64_t w0 = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
+            uint64_t w1 = (uint64_t)cur.len | ((uint64_t)(pev & 0xffffu) << 32) | ((uint64_t)(qR & 0xffffu) << 48);
+            uint64_t w2 = (uint64_t)subs.first() | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
+                          ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
+            uint64_t o = (uint64_t)sp * stk.nlanes + gid;
+            stk.p0[o] = w0; stk.p1[o] = w1; stk.p2[o] = w2;
+            ++sp;
+        }
+        resume = kNoResume;
+        bool back = !ok, to_next = false;
+        if (ok) {
+            cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+            if (take_sub) e += 1;
+            if (right) ++qR; else --qL;                            // one query symbol consumed (search_next_pos :122-124 / tail)
+            if (in_tail) { to_next = --tail == 0; if (to_next) { ++part; pev = part != P ? part_len(pi[part]) : 0; } }
+            else if (start_tail) { tail = pev - 1; to_next = tail == 0; if (to_next) { ++part; pev = part != P ? part_len(pi[part]) : 0; } }
+            else { to_next = --pev == 0; if (to_next) { ++part; if (part != P) pev = part_len(pi[part]); } }
+        }
+        if (to_next) {                                             // search_next, :98-117
+            if (part == P) {
+                if (L[P - 1] <= e && e <= U[P - 1]) {              // delegate with search_n clipping, :412-420
+                    Cur r = cur;
+                    if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
+                    quota -= r.len;
+                    if (sch.dev_flags & 1) ++seq; else emit_hit(out, cap, ctr, q, r, e, seq++);
+                    if (quota == 0) { need_search = true; continue; }     // delegate returned true: skip the remaining searches
+                }
+                back = true;
+            } else {
+                right = pi[part - 1] < pi[part];
+            }
+        }
+        if (back) {
+            if (sp == 0) { need_search = true; continue; }
+            --sp;
+            uint64_t o = (uint64_t)sp * stk.nlanes + gid;
+            uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o];
+            cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32);
+            cur.len = (idx_t)w1; pev = (uint32_t)(w1 >> 32) & 0xffffu; qR = (uint32_t)(w1 >> 48) & 0xffffu;
+            resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
+            right = (w2 >> 47) & 1u;
+            qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
+            tail = 0;
+        }
+    }
+    uint32_t tot = wave_sum(nodes);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
+}
+
+// ---- search_ng26 Hamming, fast path ------------------------------------------------------------------------------
+// For a batch of equal-length queries on a Format-A BiFMIndex the host expands the scheme once into a per-step table
+// (query position, direction, error window [minE, maxE] of the step, "last character of its part"; SearchNg26.h:160-168:
+// match allowed <=> minE <= e <= maxE, substitution allowed <=> minE <= e+1 <= maxE, where minE = l[part] on a part's
+// last character and 0 before it, maxE = u[part]) — the same thing search_scheme::expand() does for the reference's
+// per-character searches (search_scheme/expand.h:146-165).  The kernel then carries only (cursor, e, step) per lane.
+// A single-row cursor (the common case after ~log4(n) characters) takes its one child from the explicit LF table with
+// ONE 4-byte load; the symbol is recovered from C.  Multi-row cursors use the 64-byte blocks as before.
+struct FastArgs {
+    const idx_t* lf_fw; const idx_t* lf_rv;     // LF tables of bwt / bwtRev
+    const uint32_t* steps;                      // [S][m + 1]: pos:16 | right:1 | lastOfPart:1 | minE:6 | maxE:8; entry m = final window
+    uint32_t S, m;
+    idx_t C1[8];                                // C[1..] for sigma <= 8 (symbol of an LF value), unused otherwise
+};
+
+template <int SIGMA>
+__device__ __forceinline__ uint32_t symbol_of_lf(const FastArgs& fa, const idx_t* C, uint32_t sigma, idx_t t) {
+    uint32_t b = 0;
+    if (SIGMA > 0 && SIGMA <= 8) {
+#pragma unroll
+        for (int k = 1; k < SIGMA; ++k) b += t >= fa.C1[k - 1] ? 1u : 0u;
+    } else {
+        for (uint32_t k = 1; k < sigma; ++k) b += t >= C[k] ? 1u : 0u;
+    }
+    return b;
+}
+
+// wave-synchronous staging of one query per lane: all loads of a chunk are issued before the first is consumed
+__device__ __forceinline__ void qstage_load_sync(const QStage& st, const uint8_t* qbuf, uint64_t off, uint32_t m, uint32_t sigma, bool active) {
+    const uint64_t addr = (uint64_t)qbuf + off;
+    const uint32_t mis = (uint32_t)(addr & 7ull);
+    const uint64_t* base = reinterpret_cast<const uint64_t*>(addr - mis);
+    const uint32_t nw = active ? ((mis + m + 7u) >> 3) : 0u;        // aligned 64-bit words that hold query bytes
+    uint64_t carry = 0;
+    uint32_t wi = 0;
+    for (uint32_t k0 = 0; k0 <= ((m + 14u) >> 3); k0 += 8) {        // wave-uniform trip count (m is uniform); word nw flushes the last bytes
+        uint64_t r[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) r[k] = (k0 + k < nw) ? base[k0 + k] : 0ull;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            // query bytes 8(k0+k-1) .. +7 are completed by word k0+k:  x = (carry >> 8mis) | (r[k] << (64 - 8mis))
+            const uint32_t widx = k0 + k;
+            if (widx == 0) { carry = r[k]; continue; }
+            uint64_t x = mis ? ((carry >> (8u * mis)) | (r[k] << (64u - 8u * mis))) : carry;
+            carry = r[k];
+            const uint32_t p0 = (widx - 1u) * 8u;                   // first query position in x
+            if (active && p0 < m) {
+                if (st.nib) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) { uint32_t bb = (uint32_t)(x >> (8u * j)) & 0xffu; w |= (bb >= sigma || bb > 14u ? 15u : bb) << (4u * j); }
+                    st.lds[wi * 256u + threadIdx.x] = w; ++wi;
                 } else {
-                    const bool mOK = (pev > 1 || L[part] <= e) && e <= U[part];
-                    const bool sOK = (pev > 1 || L[part] <= e + 1) && e + 1 <= U[part];
-                    const bool xOK = e + 1 <= U[part];
-                    // node accounting mirrors the reference's work: one per extend-all / extend; the single-row path
-                    // extends once before it decides (:267-277) and once more per exact-tail step
-                    if (cur.len > 1) {                             // search_next_dir, :143-224
-                        if (resume == kNoResume && (xOK || mOK)) ++nodes;
-                        if (xOK) {
-                            SymSet<MAXSIG> subs = alive;           // substitution children: FirstSymb = 1 (fmindex/BiFMIndex.h:26), != c
-                            if (!sOK) subs.clear();
-                            subs.remove(0); subs.remove(c);
-                            bool match = mOK && alive.test(c);
-                            if (resume != kNoResume) { subs.clear_below(resume); match = false; }
-                            if (!match && !subs.any()) back = true;
-                            else {
-                                uint32_t take = c;
-                                if (!match) { take = subs.first(); subs.remove(take); }
-                                if (subs.any()) {                  // (re-)push the parent: its remaining siblings start at subs.first()
-                                    uint64_t w0 = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
-                                    uint64_t w1 = (uint64_t)cur.len | ((uint64_t)(pev & 0xffffu) << 32) | ((uint64_t)(qR & 0xffffu) << 48);
-                                    uint64_t w2 = (uint64_t)subs.first() | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
-                                                  ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
-                                    uint64_t o = (uint64_t)sp * stk.nlanes + gid;
-                                    stk.p0[o] = w0; stk.p1[o] = w1; stk.p2[o] = w2;
-                                    ++sp;
-                                }
-                                cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
-                                if (!match) e += 1;
-                                advance = true;
-                            }
-                        } else if (mOK) {                          // exact tail; this iteration's blocks serve its first extension
-                            if (!alive.test(c)) back = true;
-                            else {
-                                cur = kid_of<MAXSIG>(lfa, lfb, cur, c, right, sigma);
-                                if (right) ++qR; else --qL;
-                                tail = pev - 1;
-                                if (tail == 0) { ++part; pev = part != (uint32_t)P ? part_len(pi[part]) : 0; to_next = true; }
-                            }
-                        } else back = true;
-                    } else {                                       // search_next_dir_single, :251-365: the one alive kid is the BWT symbol
-                        const uint32_t b = alive.first();
-                        ++nodes;
-                        if (!alive.any() || b < 1) back = true;
-                        else if (b == c) {
-                            if (!mOK) back = true;
-                            else if (!xOK) {                       // exact tail from here
-                                ++nodes;
-                                cur = kid_of<MAXSIG>(lfa, lfb, cur, c, right, sigma);
-                                if (right) ++qR; else --qL;
-                                tail = pev - 1;
-                                if (tail == 0) { ++part; pev = part != (uint32_t)P ? part_len(pi[part]) : 0; to_next = true; }
-                            } else { cur = kid_of<MAXSIG>(lfa, lfb, cur, b, right, sigma); advance = true; }
-                        } else if (xOK && sOK) { cur = kid_of<MAXSIG>(lfa, lfb, cur, b, right, sigma); e += 1; advance = true; }
-                        else back = true;
-                    }
-                }
-                resume = kNoResume;
-                if (advance) {                                     // search_next_pos, :119-141 (children are never empty here)
-                    if (right) ++qR; else --qL;
-                    if (--pev == 0) { ++part; if (part != (uint32_t)P) pev = part_len(pi[part]); to_next = true; }
-                }
-                if (to_next) {                                     // search_next, :98-117
-                    if (part == (uint32_t)P) {
-                        if (L[P - 1] <= e && e <= U[P - 1]) {      // delegate with search_n clipping, :412-420
-                            Cur r = cur;
-                            if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
-                            quota -= r.len;
-                            emit_hit(out, cap, ctr, q, r, e, seq++);
-                            if (quota == 0) { query_done = true; break; }
-                        }
-                        back = true;
-                    } else {
-                        right = pi[part - 1] < pi[part];
-                    }
-                }
-                if (back) {
-                    if (sp == 0) break;
-                    --sp;
-                    uint64_t o = (uint64_t)sp * stk.nlanes + gid;
-                    uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o];
-                    cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32);
-                    cur.len = (idx_t)w1; pev = (uint32_t)(w1 >> 32) & 0xffffu; qR = (uint32_t)(w1 >> 48) & 0xffffu;
-                    resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
-                    right = (w2 >> 47) & 1u;
-                    qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
-                    tail = 0;
+                    st.lds[wi * 256u + threadIdx.x] = (uint32_t)x; ++wi;
+                    if (p0 + 4u < m) { st.lds[wi * 256u + threadIdx.x] = (uint32_t)(x >> 32); ++wi; }
                 }
             }
         }
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off, 64); if (lane >= (uint32_t)off) x += y; }
+    return x - v;
+}
+
+constexpr uint32_t kHitBuf = 2;      // hits buffered per lane and round in LDS; further hits of the same query are emitted directly
+
+template <int SIGMA, int MAXSIG>
+__global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
+                                                                          const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
+                                                                          fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
+                                                                          uint32_t qwords, uint32_t qnib, int dev_flags) {
+    // Wave-synchronous rounds.  A wave pays for every slow path any of its 64 lanes takes, so nothing with a dependent
+    // memory round trip is lane-private: the 64 lanes fetch and stage their next queries TOGETHER (one atomicAdd per wave,
+    // query words issued back to back), walk the searches in a flat loop that performs exactly one memory phase per
+    // iteration, keep their hits in LDS, and flush them together (one atomicAdd per wave).
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
+    const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
+    uint32_t* s_hits = s_steps + S * stride;                        // [kHitBuf][5][256]: lb, lbRev, len, e, seq
+    const QStage qst{s_dyn, qwords, qnib};
+    for (uint32_t i = threadIdx.x; i < S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
+    __syncthreads();
+
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sigma = fw.sigma();
+    uint32_t nodes = 0;
+    for (;;) {
+        // ---- round start: 64 consecutive queries for this wave
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->next, 64ull);
+        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+        if (base >= nq) break;
+        const uint64_t q = base + lane;
+        const bool active = q < nq;
+        const uint64_t qo = active ? qoff[q] : 0;
+        const uint8_t* qs = qbuf + qo;
+        qstage_load_sync(qst, qbuf, qo, m, sigma, active);
+
+        uint64_t quota = max_hits; uint32_t seq = 0, nh = 0;
+        uint32_t si = 0, e = 0, j = 0, sp = 0, resume = kNoResume;
+        bool in_tail = false, done = !active || n == 0;
+        Cur cur{0, 0, n};                                           // run(): SearchNg26.h:62-79
+        const uint32_t* tab = s_steps;
+        while (__ballot(!done) != 0ull) {
+            if (!done) {
+                const uint32_t ent = tab[j];
+                const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x3fu, maxE = ent >> 24;
+                const bool right = (ent >> 16) & 1u, lastp = (ent >> 17) & 1u;
+                const bool multi = cur.len > 1;
+                const idx_t a = right ? cur.lbRev : cur.lb;
+                idx_t lfa[MAXSIG], lfb[MAXSIG];
+                idx_t t = 0;
+                SymSet<MAXSIG> alive; alive.clear();
+                if (multi) {                                       // extend-all on the blocks (fmindex/BiFMIndexCursor.h:58-82)
+                    const OccA<SIGMA>& occ = right ? rv : fw;
+                    occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
+                    alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+                } else {                                           // symbolLeft/Right + extend by that symbol (:267-277): one LF-table load
+                    t = (right ? fa.lf_rv : fa.lf_fw)[a];
+                    const uint32_t b1 = symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, t);
+                    if (b1 >= 1) { if (MAXSIG <= 32) alive.w[0] = 1u << b1; else alive.w[b1 >> 5] = 1u << (b1 & 31u); }   // :295-297: a delimiter row ends the walk
+                }
+                const uint32_t c = qstage_get(qst, qs, pos);
+                const bool c_alive = alive.test(c);
+                const bool resuming = resume != kNoResume;
+                const bool mOK = minE <= e && e <= maxE;
+                const bool sOK = minE <= e + 1 && e + 1 <= maxE;
+                const bool xOK = e + 1 <= maxE;
+                SymSet<MAXSIG> subs = alive;                       // substitution children: FirstSymb = 1 (fmindex/BiFMIndex.h:26), != query symbol
+                subs.remove(0); subs.remove(c);
+                if (!sOK) subs.clear();
+                if (resuming) subs.clear_below(resume);
+                const bool take_match = !resuming && mOK && c_alive;   // match child first (:171-181); in a single row it is the only candidate
+                const bool take_sub = !take_match && subs.any();
+                const bool ok = take_match || take_sub;
+                uint32_t take = c;
+                if (take_sub) { take = subs.first(); subs.remove(take); }
+                // node accounting as the reference works (see k_scheme)
+                nodes += multi ? ((!resuming && (in_tail || xOK || mOK)) ? 1u : 0u) : (1u + ((!in_tail && take_match && !xOK) ? 1u : 0u));
+                if (ok && multi && subs.any()) {                   // (re-)push the parent: remaining siblings start at subs.first()
+                    uint64_t o = (uint64_t)sp * stk.nlanes + gid;
+                    stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
+                    stk.p1[o] = (uint64_t)cur.len | ((uint64_t)(j & 0xffffu) << 32) | ((uint64_t)(e & 0xffu) << 48) | ((uint64_t)(subs.first() & 0xffu) << 56);
+                    ++sp;
+                }
+                resume = kNoResume;
+                bool back = !ok, search_over = false;
+                if (ok) {
+                    if (multi) cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+                    else { if (right) cur.lbRev = t; else cur.lb = t; }   // single row: the other side's prefix count is 0
+                    if (take_sub) e += 1;
+                    in_tail = !lastp && (in_tail || (take_match && !xOK));
+                    ++j;
+                    if (j == m) {                                  // search_next at part == P (:101-108)
+                        const uint32_t fin = tab[m];
+                        if (((fin >> 18) & 0x3fu) <= e && e <= (fin >> 24)) {
+                            Cur r = cur;
+                            if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
+                            quota -= r.len;
+                            if (!(dev_flags & 1)) {
+                                if (nh < kHitBuf) {                // buffered; written out at the end of the round
+                                    uint32_t* h = s_hits + (size_t)nh * 5u * 256u + threadIdx.x;
+                                    h[0] = r.lb; h[256] = r.lbRev; h[512] = r.len; h[768] = e; h[1024] = seq;
+                                } else emit_hit(out, cap, ctr, q, r, e, seq);
+                            }
+                            ++nh; ++seq;
+                            if (quota == 0) { search_over = true; si = S; }   // delegate returned true: no further searches (:372-383)
+                        }
+                        back = !search_over;
+                    }
+                }
+                if (back) {
+                    if (sp == 0) search_over = true;
+                    else {
+                        --sp;
+                        uint64_t o = (uint64_t)sp * stk.nlanes + gid;
+                        uint64_t w0 = stk.p0[o], w1 = stk.p1[o];
+                        cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32); cur.len = (idx_t)w1;
+                        j = (uint32_t)(w1 >> 32) & 0xffffu; e = (uint32_t)(w1 >> 48) & 0xffu; resume = (uint32_t)(w1 >> 56) & 0xffu;
+                        in_tail = false;
+                    }
+                }
+                if (search_over) {                                 // search_impl: next search of the scheme (:385-390) or the query is finished
+                    ++si;
+                    if (si >= S) done = true;
+                    else { tab = s_steps + si * stride; cur = Cur{0, 0, n}; e = 0; j = 0; sp = 0; resume = kNoResume; in_tail = false; }
+                }
+            }
+        }
+        // ---- round end: flush the buffered hits of the wave with one reservation
+        if (!(dev_flags & 1)) {
+            const uint32_t mine = nh < kHitBuf ? nh : kHitBuf;
+            const uint32_t before = wave_excl_scan(mine, lane);
+            const uint32_t total = __shfl(before + mine, 63, 64);
+            unsigned long long slot = 0;
+            if (lane == 0 && total) slot = atomicAdd(&ctr->hits, (unsigned long long)total);
+            slot = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(slot >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)slot);
+            for (uint32_t k = 0; k < mine; ++k) {
+                const uint32_t* h = s_hits + (size_t)k * 5u * 256u + threadIdx.x;
+                const unsigned long long at = slot + before + k;
+                if (at < cap) {
+                    fmgpu_hit rec;
+                    rec.qidx = q; rec.lb = h[0]; rec.lb_rev = h[256]; rec.len = h[512]; rec.errors = h[768]; rec.seq = h[1024];
+                    out[at] = rec;
+                }
+            }
+        } else if (nh) atomicAdd(&ctr->hits, (unsigned long long)nh);
     }
     uint32_t tot = wave_sum(nodes);
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
@@ -422,7 +700,9 @@ __global__ __launch_bounds__(256) void k_scheme(Occ fw, Occ rv, SchemeDev sch, c
 template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
                                                       uint64_t nq, idx_t n, uint32_t K, fmgpu_hit* __restrict__ out, uint64_t cap,
-                                                      Counters* ctr, StackView stk) {
+                                                      Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib) {
+    extern __shared__ uint32_t s_query[];
+    const QStage qst{s_query, qwords, qnib};
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t sigma = fw.sigma();
     uint32_t nodes = 0;
@@ -431,6 +711,7 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
         const uint32_t m = (uint32_t)(qoff[q + 1] - qo);
         const uint8_t* qs = qbuf + qo;
         if (m > stk.depth) continue;
+        if (m) qstage_load(qst, qbuf, qo, m, sigma);
         Cur cur{0, 0, n};
         uint32_t e = 0, i = 0, sp = 0, seq = 0, resume = kNoResume;
         bool running = n != 0;                                       // Backtracking.h:43: empty cursor
@@ -441,7 +722,7 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
                 idx_t lfa[MAXSIG], lfb[MAXSIG];
                 fw.template all2<MAXSIG>(cur.lb, cur.lb + cur.len, lfa, lfb);
                 if (resume == kNoResume) ++nodes;
-                const uint32_t r = qs[m - i - 1];
+                const uint32_t r = qstage_get(qst, qs, m - i - 1);
                 const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
                 SymSet<MAXSIG> subs = alive;                         // :52-56: s in [1, sigma), s != r, while e < K
                 if (e >= K) subs.clear();
@@ -488,7 +769,7 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
 constexpr uint32_t kLocateStepCap = 1u << 24;   // a valid index reaches a sampled row long before; bounds a corrupt one
 
 template <class Occ>
-__global__ __launch_bounds__(256) void k_locate(Occ occ, ViewSA sa, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
+__global__ __launch_bounds__(256) void k_locate(Occ occ, const idx_t* __restrict__ lf_table, ViewSA sa, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
                                                 uint64_t* __restrict__ out_seq, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_steps,
                                                 unsigned long long* __restrict__ steps_total) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -499,8 +780,8 @@ __global__ __launch_bounds__(256) void k_locate(Occ occ, ViewSA sa, const uint64
         if (r64 < n) {
             idx_t row = (idx_t)r64;
             while (!sa_present(sa, row) && steps < kLocateStepCap) {    // fmindex/FMIndex.h:116-121
-                uint32_t c;
-                row = occ.lf_symbol(row, c);
+                if (lf_table) row = lf_table[row];                      // one load per LF step when the explicit table exists
+                else { uint32_t c; row = occ.lf_symbol(row, c); }
                 ++steps;
             }
             if (sa_present(sa, row)) {
@@ -526,7 +807,6 @@ struct EventTimer {
     ~EventTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 };
 
-static int query_max_len(const uint64_t* qoff_host_or_dev, uint64_t nq, hipStream_t stream, uint32_t* out);
 
 template <class F>
 static int dispatch_occ(const DevString& s, F&& f) {
@@ -547,46 +827,85 @@ static int dispatch_occ(const DevString& s, F&& f) {
     }
 }
 
-// max query length: a tiny reduction kernel (queries may live in HBM)
-__global__ __launch_bounds__(256) void k_max_len(const uint64_t* __restrict__ qoff, uint64_t nq, unsigned long long* __restrict__ out) {
+// longest and shortest query: a tiny reduction kernel (queries may live in HBM)
+__global__ __launch_bounds__(256) void k_len_range(const uint64_t* __restrict__ qoff, uint64_t nq, unsigned long long* __restrict__ out) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long v = 0;
-    for (uint64_t q = t; q < nq; q += (uint64_t)gridDim.x * blockDim.x) { unsigned long long l = qoff[q + 1] - qoff[q]; v = l > v ? l : v; }
+    unsigned long long v = 0, w = ~0ull;
+    for (uint64_t q = t; q < nq; q += (uint64_t)gridDim.x * blockDim.x) { unsigned long long l = qoff[q + 1] - qoff[q]; v = l > v ? l : v; w = l < w ? l : w; }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
-    if ((threadIdx.x & 63u) == 0) atomicMax(out, v);
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v;
+        unsigned long long p = __shfl_xor(w, off, 64); w = p < w ? p : w;
+    }
+    if ((threadIdx.x & 63u) == 0) { atomicMax(out, v); atomicMin(out + 1, w); }
 }
 
-static int query_max_len(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out) {
+static int query_len_range(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out_max, uint32_t* out_min) {
     unsigned long long* d = nullptr;
-    FM_HIP(hipMalloc((void**)&d, 8));
-    FM_HIP(hipMemsetAsync(d, 0, 8, stream));
+    FM_HIP(hipMalloc((void**)&d, 16));
+    unsigned long long init[2] = {0ull, ~0ull};
+    FM_HIP(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, stream));
     unsigned blocks = (unsigned)std::min<uint64_t>((nq + 255) / 256, 1024);
-    k_max_len<<<dim3(blocks), dim3(256), 0, stream>>>(dqoff, nq, d);
-    unsigned long long h = 0;
-    hipError_t e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream);
+    k_len_range<<<dim3(blocks), dim3(256), 0, stream>>>(dqoff, nq, d);
+    unsigned long long h[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d);
-    if (e != hipSuccess) return hip_fail(e, "k_max_len");
-    *out = (uint32_t)std::min<unsigned long long>(h, 0xffffffffull);
+    if (e != hipSuccess) return hip_fail(e, "k_len_range");
+    *out_max = (uint32_t)std::min<unsigned long long>(h[0], 0xffffffffull);
+    *out_min = (uint32_t)std::min<unsigned long long>(h[1], 0xffffffffull);
     return 0;
+}
+
+// expands a scheme for queries of length m into the fast kernel's per-step table (see k_scheme_fast); false if it does not fit
+static bool build_step_table(const SchemeDev& sd, uint32_t m, std::vector<uint32_t>& tab) {
+    const uint32_t S = (uint32_t)sd.S, P = (uint32_t)sd.P;
+    if (m < P || m > 0xfffeu || (uint64_t)S * (m + 1) > 4096) return false;
+    std::vector<uint32_t> plen(P);
+    uint32_t sum = 0;
+    for (uint32_t p = 0; p < P; ++p) { plen[p] = sd.uniform ? m / P + (p < m % P ? 1u : 0u) : sd.partition[p]; sum += plen[p]; }
+    if (sum != m) return false;
+    tab.assign((size_t)S * (m + 1), 0);
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint8_t* pi = sd.pi + s * kMaxParts; const uint8_t* L = sd.l + s * kMaxParts; const uint8_t* U = sd.u + s * kMaxParts;
+        uint32_t start = 0;
+        for (uint32_t i = 0; i < pi[0]; ++i) start += plen[i];
+        uint32_t qR = start, qL = start - 1, j = 0;              // SearchNg26.h:62-79
+        for (uint32_t p = 0; p < P; ++p) {
+            if (L[p] > U[p] || L[p] > 63) return false;          // the table form relies on l <= u (search_scheme/isValid.h:87-91)
+            const bool right = p == 0 || pi[p - 1] < pi[p];      // :111
+            const uint32_t len = plen[pi[p]];
+            for (uint32_t k = 0; k < len; ++k, ++j) {
+                const uint32_t pos = right ? qR++ : qL--;
+                const bool last = k + 1 == len;
+                tab[(size_t)s * (m + 1) + j] = (pos & 0xffffu) | ((right ? 1u : 0u) << 16) | ((last ? 1u : 0u) << 17) |
+                                               ((last ? (uint32_t)L[p] : 0u) << 18) | ((uint32_t)U[p] << 24);
+            }
+        }
+        tab[(size_t)s * (m + 1) + m] = ((uint32_t)L[P - 1] << 18) | ((uint32_t)U[P - 1] << 24);
+    }
+    return true;
 }
 
 struct DfsWorkspace {
     uint64_t* planes = nullptr; Counters* ctr = nullptr; StackView view{};
     unsigned grid = 0;
-    int init(uint32_t depth, uint64_t nq, hipStream_t stream) {
+    // blocks_per_cu: resident 256-lane blocks of the kernel that will run (the lanes walk the batch with a static stride, so
+    // every block must be resident from the start or the late ones form a tail)
+    int init(uint32_t depth, uint64_t nq, int blocks_per_cu, hipStream_t stream) {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        uint64_t want = (uint64_t)cus * 8;                                  // 8 blocks of 256 lanes per CU = full occupancy
+        uint64_t want = (uint64_t)cus * (uint64_t)std::max(1, std::min(8, blocks_per_cu));
         grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (nq + 255) / 256));
         view.nlanes = (uint64_t)grid * 256; view.depth = depth;
         uint64_t words = view.nlanes * ((uint64_t)depth + 1);
         FM_HIP(hipMalloc((void**)&planes, words * 8 * 3));
         view.p0 = planes; view.p1 = planes + words; view.p2 = planes + 2 * words;
         FM_HIP(hipMalloc((void**)&ctr, sizeof(Counters)));
-        FM_HIP(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));
+        Counters init{0, 0, view.nlanes * 4ull};                            // next: the first batch of every lane is static (kBatch = 4)
+        FM_HIP(hipMemcpyAsync(ctr, &init, sizeof(Counters), hipMemcpyHostToDevice, stream));
+        FM_HIP(hipStreamSynchronize(stream));
         return 0;
     }
     ~DfsWorkspace() { if (planes) (void)hipFree(planes); if (ctr) (void)hipFree(ctr); }
@@ -671,6 +990,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             return fail(FMGPU_ERR_UNSUPPORTED, "scheme larger than 16 searches x 16 parts");
         if (max_hits == 0 || scheme->n_searches == 0) return 0;                       // SearchNg26.h:408-409
         sd.S = scheme->n_searches; sd.P = scheme->n_parts; sd.uniform = scheme->partition ? 0 : 1;
+        { const char* e = getenv("FMGPU_DEV_FLAGS"); sd.dev_flags = e ? atoi(e) : 0; }
         for (int s = 0; s < sd.S; ++s) {
             uint32_t seen = 0;
             for (int p = 0; p < sd.P; ++p) {
@@ -701,16 +1021,57 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     else total = qoff[nq];
     if ((rc = sbuf.in(qbuf, total, stream))) return rc;
     if ((rc = sout.out(out, capacity * sizeof(fmgpu_hit), stream))) return rc;
-    uint32_t maxlen = 0;
-    if ((rc = query_max_len((const uint64_t*)soff.dev, nq, stream, &maxlen))) return rc;
+    uint32_t maxlen = 0, minlen = 0;
+    if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &maxlen, &minlen))) return rc;
     if (maxlen > 0xfffeu) return fail(FMGPU_ERR_UNSUPPORTED, "queries longer than 65534 symbols");
+    static std::mutex occ_mu; static std::map<std::tuple<int, int, int, size_t>, int> occ_cache;
+    int bpc = 8;
+    const size_t occ_lds = (size_t)((x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4)) * 1024 > 48 * 1024 ? 0 : (size_t)((x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4)) * 1024;
+    const auto occ_key = std::make_tuple(x->bwt.family, x->bwt.sigma, (int)scheme_mode, occ_lds);
+    bool occ_known = false;
+    { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(occ_key); if (it != occ_cache.end()) { bpc = it->second; occ_known = true; } }
+    if (!occ_known) {   // residency of the kernel instantiation that will run (queried once: the call is slow)
+        auto occ_of = [&](auto kernel) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, occ_lds) == hipSuccess && nb > 0) bpc = nb; else (void)hipGetLastError(); };
+        dispatch_occ(x->bwt, [&](auto occ, auto ms) {
+            using O = decltype(occ);
+            if (scheme_mode) occ_of(k_scheme<O, decltype(ms)::value>); else occ_of(k_backtracking<O, decltype(ms)::value>);
+            return 0;
+        });
+        std::lock_guard<std::mutex> g(occ_mu); occ_cache[occ_key] = bpc;
+    }
+    // query staging: 8 (nibbles) or 4 (bytes) symbols per LDS word, 256 lanes per block; above 48 KB the kernels read global memory
+    const uint32_t qnib = x->bwt.sigma <= 15 ? 1u : 0u;
+    uint32_t qwords = qnib ? (maxlen + 7) / 8 : (maxlen + 3) / 4;
+    if ((size_t)qwords * 1024 > 48 * 1024) qwords = 0;
+    const size_t lds_bytes = (size_t)qwords * 1024;
     DfsWorkspace ws;
-    if ((rc = ws.init(maxlen, nq, stream))) return rc;
+    if ((rc = ws.init(maxlen, nq, bpc, stream))) return rc;
     EventTimer timer(stream, stats != nullptr);
     const idx_t n = (idx_t)x->bwt.n;
     dim3 grid(ws.grid), block(256);
+    // fast path: equal-length batch on a Format-A BiFMIndex with LF tables
+    std::vector<uint32_t> step_tab;
+    const bool fast = scheme_mode && x->bwt.family == FAM_A && x->bwt.lf_table && x->rev.lf_table && minlen == maxlen &&
+                      x->bwt.sigma <= 32 && !(sd.dev_flags & 2) && build_step_table(sd, maxlen, step_tab);
+    uint32_t* d_steps = nullptr;
+    if (fast) {
+        FM_HIP(hipMalloc((void**)&d_steps, step_tab.size() * 4));
+        FM_HIP(hipMemcpyAsync(d_steps, step_tab.data(), step_tab.size() * 4, hipMemcpyHostToDevice, stream));
+    }
     timer.start();
-    if (scheme_mode) {
+    if (fast) {
+        FastArgs fa{};
+        fa.lf_fw = x->bwt.lf_table; fa.lf_rv = x->rev.lf_table; fa.steps = d_steps; fa.S = (uint32_t)sd.S; fa.m = maxlen;
+        for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
+        const size_t lds_fast = lds_bytes + step_tab.size() * 4 + (size_t)kHitBuf * 5 * 256 * 4;
+        FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));       // the fast kernel hands out 64-query rounds from 0
+        if (x->bwt.sigma == 5)
+            k_scheme_fast<5, 5><<<grid, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                   nq, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags);
+        else
+            k_scheme_fast<0, 32><<<grid, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                    nq, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags);
+    } else if (scheme_mode) {
         const DevString& rv = x->rev;
         rc = dispatch_occ(x->bwt, [&](auto occ, auto ms) {
             using O = decltype(occ);
@@ -718,23 +1079,25 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             if constexpr (std::is_same_v<O, OccA<5>> || std::is_same_v<O, OccA<0>>) r = O{rv.va};
             else if constexpr (std::is_same_v<O, OccW>) r = O{rv.vw};
             else r = O{rv.vr};
-            k_scheme<O, decltype(ms)::value><<<grid, block, 0, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
-                                                                         max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view);
+            k_scheme<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
+                                                                         max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib);
             return 0;
         });
     } else {
         rc = dispatch_occ(x->bwt, [&](auto occ, auto ms) {
-            k_backtracking<decltype(occ), decltype(ms)::value><<<grid, block, 0, stream>>>(occ, x->bidirectional, (const uint8_t*)sbuf.dev,
+            k_backtracking<decltype(occ), decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, x->bidirectional, (const uint8_t*)sbuf.dev,
                                                                                            (const uint64_t*)soff.dev, nq, n, K, (fmgpu_hit*)sout.dev,
-                                                                                           capacity, ws.ctr, ws.view);
+                                                                                           capacity, ws.ctr, ws.view, qwords, qnib);
             return 0;
         });
     }
     timer.stop();
-    FM_HIP(hipGetLastError());
+    hipError_t le = hipGetLastError();
     Counters hc{};
-    FM_HIP(hipMemcpyAsync(&hc, ws.ctr, sizeof hc, hipMemcpyDeviceToHost, stream));
-    FM_HIP(hipStreamSynchronize(stream));
+    if (le == hipSuccess) le = hipMemcpyAsync(&hc, ws.ctr, sizeof hc, hipMemcpyDeviceToHost, stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(stream);
+    if (d_steps) (void)hipFree(d_steps);
+    if (le != hipSuccess) return hip_fail(le, "search kernel");
     *out_count = hc.hits;
     if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); }
     if (hc.hits > capacity) {
@@ -783,7 +1146,7 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
     const idx_t n = (idx_t)x->bwt.n;
     timer.start();
     rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
-        k_locate<decltype(occ)><<<grid, block, 0, stream>>>(occ, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev,
+        k_locate<decltype(occ)><<<grid, block, 0, stream>>>(occ, x->bwt.lf_table, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev,
                                                            (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
         return 0;
     });

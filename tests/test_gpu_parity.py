@@ -176,6 +176,27 @@ def test_scheme_search_matches_reference_order(k):
         assert hits[hits["qidx"] == q]["seq"].tolist() == list(range(int(qc[q])))
 
 
+@pytest.mark.parametrize("k,length", [(1, 20), (2, 31), (2, 101), (3, 64)])
+def test_scheme_search_equal_length_fast_path(k, length):
+    """equal-length batches take the table-driven kernel (k_scheme_fast): same hits, order and node count as the reference walk"""
+    seqs = repeat_text(40 + k, n=6000)
+    ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
+    gx = gpu_index(ox)
+    queries = mutated_queries(seqs, 1500, length, length + 1, k + 1, seed=11 + k)
+    assert len({len(q) for q in queries}) == 1
+    qbuf, qoff = fm.flatten(queries)
+    for sch in (fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k)):
+        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True)
+        ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes
+    os.environ["FMGPU_DEV_FLAGS"] = "2"                       # force the generic kernel: both kernels agree
+    try:
+        hits2 = fm.search_ng26.search(gx, (qbuf, qoff), fm.search_scheme.h2(k + 2, 0, k))
+    finally:
+        del os.environ["FMGPU_DEV_FLAGS"]
+    assert same_hits(hits2, ox.search_ng26(qbuf, qoff, fm.search_scheme.h2(k + 2, 0, k))[0])
+
+
 def test_scheme_search_variants():
     seqs = repeat_text(20)
     ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
