@@ -1,0 +1,407 @@
+// fmc_gpu.hpp — C++ host mirror of the reference's template API for the backward-search path, on top of the C-ABI
+// (include/fmgpu.h, libfmgpu.so).  Header-only, C++17.  Same names, argument meaning and error behaviour as
+// SGSSGene/fmindex-collection for: FMIndex / BiFMIndex (fmindex/FMIndex.h:14-134, fmindex/BiFMIndex.h:17-216), their cursors
+// (fmindex/FMIndexCursor.h, fmindex/BiFMIndexCursor.h: lb, lbRev, len, steps, count(), empty(), begin/end),
+// search_no_errors::search (search/SearchNoErrors.h), search_backtracking::search (search/Backtracking.h),
+// search_ng26::search (search/SearchNg26.h:426-444), fmc::search<Edit> (search/search.h:26-35), LocateLinear (locate.h:14-57),
+// search_scheme::{Search, Scheme, generator::{h2, pigeon_opt, pigeon_trivial, backtracking}, createUniformPartition, expand,
+// limitToHamming, isValid, isComplete} (search_scheme/).
+//
+// Differences that follow from batching on a GPU: searches run over the whole `queries` range in one call and the delegates
+// are invoked on the host afterwards — in ascending qidx and, inside a query, in the reference's callback order.  Edit
+// distance (Edit = true) is outside the accelerated path and throws std::runtime_error.
+#pragma once
+
+#include "fmgpu.h"
+
+#include <algorithm>
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <limits>
+#include <numeric>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+namespace fmc {
+
+namespace detail {
+inline void check(int rc) {
+    if (rc != 0) throw std::runtime_error(std::string("fmindex-collection (gpu): ") + fmgpu_last_error());
+}
+template <typename Seqs>
+inline void flatten(Seqs const& seqs, std::vector<uint8_t>& buf, std::vector<uint64_t>& off) {
+    off.assign(1, 0);
+    for (auto const& s : seqs) {
+        for (auto c : s) buf.push_back(static_cast<uint8_t>(c));
+        off.push_back(buf.size());
+    }
+    if (buf.empty()) buf.push_back(0);
+}
+}  // namespace detail
+
+// ------------------------------------------------------------------------------------------------ occurrence-table tags
+namespace string {
+#define FMC_GPU_STRING_TAG(NAME, ID) \
+    template <size_t TSigma> struct NAME { static constexpr size_t Sigma = TSigma; static constexpr int layout = ID; };
+FMC_GPU_STRING_TAG(InterleavedBitvector8, FMGPU_IB8)
+FMC_GPU_STRING_TAG(InterleavedBitvector16, FMGPU_IB16)
+FMC_GPU_STRING_TAG(InterleavedBitvector32, FMGPU_IB32)
+FMC_GPU_STRING_TAG(InterleavedBitvector16Aligned, FMGPU_IB16A)
+FMC_GPU_STRING_TAG(InterleavedBitvectorPrefix16, FMGPU_IBP16)
+#undef FMC_GPU_STRING_TAG
+}  // namespace string
+
+// ------------------------------------------------------------------------------------------------ indices
+template <size_t TSigma, template <size_t> class String, bool Bidirectional>
+struct GpuIndexBase {
+    static constexpr size_t Sigma = TSigma;
+    static constexpr size_t FirstSymb = 1;
+    using LEntry = std::tuple<uint32_t, uint32_t, size_t>;   // (seqId, pos, steps): decltype(tuple_cat(ADEntry{}, tuple<size_t>{}))
+
+    fmgpu_index_t handle{};
+    uint64_t n{};
+
+    GpuIndexBase() = default;
+    GpuIndexBase(GpuIndexBase const&) = delete;
+    GpuIndexBase(GpuIndexBase&& o) noexcept : handle{o.handle}, n{o.n} { o.handle = nullptr; }
+    auto operator=(GpuIndexBase&& o) noexcept -> GpuIndexBase& { std::swap(handle, o.handle); std::swap(n, o.n); return *this; }
+    ~GpuIndexBase() { if (handle) fmgpu_index_destroy(handle); }
+
+    // FMIndex(Sequences, samplingRate, threadNbr) / BiFMIndex(Sequences, samplingRate, threadNbr): built on the GPU
+    template <typename Seqs>
+    GpuIndexBase(Seqs const& input, size_t samplingRate, size_t /*threadNbr*/) {
+        std::vector<uint8_t> buf; std::vector<uint64_t> off;
+        detail::flatten(input, buf, off);
+        detail::check(fmgpu_build_index(buf.data(), off.data(), off.size() - 1, static_cast<int32_t>(Sigma), String<Sigma>::layout, samplingRate,
+                                        Bidirectional ? 1 : 0, 0, &handle, nullptr));
+        detail::check(fmgpu_index_info(handle, &n, nullptr, nullptr, nullptr, nullptr));
+    }
+
+    size_t size() const { return n; }
+
+    auto locate(size_t idx) const -> LEntry {
+        uint64_t row = idx, seq{}, pos{}, steps{};
+        detail::check(fmgpu_locate(handle, &row, 1, &seq, &pos, &steps, nullptr, nullptr));
+        return {static_cast<uint32_t>(seq), static_cast<uint32_t>(pos), static_cast<size_t>(steps)};
+    }
+    auto locate(std::vector<uint64_t> const& rows) const -> std::vector<LEntry> {
+        std::vector<uint64_t> seq(rows.size()), pos(rows.size()), steps(rows.size());
+        detail::check(fmgpu_locate(handle, rows.data(), rows.size(), seq.data(), pos.data(), steps.data(), nullptr, nullptr));
+        std::vector<LEntry> out(rows.size());
+        for (size_t i = 0; i < rows.size(); ++i) out[i] = {static_cast<uint32_t>(seq[i]), static_cast<uint32_t>(pos[i]), static_cast<size_t>(steps[i])};
+        return out;
+    }
+};
+
+template <size_t TSigma, template <size_t> class String = string::InterleavedBitvector16>
+struct FMIndex : GpuIndexBase<TSigma, String, false> {
+    using GpuIndexBase<TSigma, String, false>::GpuIndexBase;
+};
+template <size_t TSigma, template <size_t> class String = string::InterleavedBitvector16>
+struct BiFMIndex : GpuIndexBase<TSigma, String, true> {
+    using GpuIndexBase<TSigma, String, true>::GpuIndexBase;
+};
+
+// ------------------------------------------------------------------------------------------------ cursors
+struct IntIterator {   // utils.h:656-669
+    size_t i;
+    auto operator*() const -> size_t { return i; }
+    auto operator++() -> IntIterator& { ++i; return *this; }
+    bool operator!=(IntIterator const& o) const { return i != o.i; }
+};
+template <typename Index>
+struct FMIndexCursor {
+    static constexpr size_t Sigma = Index::Sigma;
+    Index const* index{};
+    size_t lb{}, len{};
+    bool empty() const { return len == 0; }
+    size_t count() const { return len; }
+};
+template <typename Index>
+struct BiFMIndexCursor {
+    static constexpr size_t Sigma = Index::Sigma;
+    Index const* index{};
+    size_t lb{}, lbRev{}, len{}, steps{};
+    bool empty() const { return len == 0; }
+    size_t count() const { return len; }
+    bool operator==(BiFMIndexCursor const& o) const noexcept { return lb == o.lb && len == o.len; }
+};
+template <typename C> auto begin(C const& c) -> decltype(IntIterator{c.lb}) { return IntIterator{c.lb}; }
+template <typename C> auto end(C const& c) -> decltype(IntIterator{c.lb + c.len}) { return IntIterator{c.lb + c.len}; }
+
+template <typename Index> struct select_cursor { using type = FMIndexCursor<Index>; };
+template <size_t S, template <size_t> class Str> struct select_cursor<BiFMIndex<S, Str>> { using type = BiFMIndexCursor<BiFMIndex<S, Str>>; };
+template <typename Index> using select_cursor_t = typename select_cursor<Index>::type;
+
+// ------------------------------------------------------------------------------------------------ search schemes
+namespace search_scheme {
+struct Search {
+    std::vector<size_t> pi, l, u;
+    bool operator==(Search const& o) const { return std::tie(pi, l, u) == std::tie(o.pi, o.l, o.u); }
+};
+using Scheme = std::vector<Search>;
+
+inline auto isValid(Search const& s) -> bool {   // isValid.h:55-93
+    if (s.pi.empty() || s.pi.size() != s.l.size() || s.pi.size() != s.u.size()) return false;
+    size_t lo = s.pi[0], hi = s.pi[0];
+    for (size_t i = 1; i < s.pi.size(); ++i) {
+        if (s.pi[i] == hi + 1) hi = s.pi[i];
+        else if (s.pi[i] + 1 == lo) lo = s.pi[i];
+        else return false;
+    }
+    if (lo != 0) return false;
+    for (size_t i = 0; i < s.pi.size(); ++i) {
+        if (i && (s.l[i - 1] > s.l[i] || s.u[i - 1] > s.u[i])) return false;
+        if (s.l[i] > s.u[i]) return false;
+    }
+    return true;
+}
+inline auto isValid(Scheme const& ss) -> bool {
+    return std::all_of(ss.begin(), ss.end(), [&](Search const& s) { return isValid(s) && s.pi.size() == ss.front().pi.size(); });
+}
+
+inline auto createUniformPartition(size_t parts, size_t totalSum) -> std::vector<size_t> {   // expand.h:324-335
+    if (parts == 0 || totalSum < parts) throw std::invalid_argument("createUniformPartition: need 0 < parts <= totalSum");
+    auto counts = std::vector<size_t>(parts, totalSum / parts);
+    for (size_t i = 0; i < totalSum % parts; ++i) counts[i] += 1;
+    return counts;
+}
+inline auto createUniformPartition(Scheme const& ss, size_t totalSum) -> std::vector<size_t> {
+    if (ss.empty()) throw std::invalid_argument("createUniformPartition: empty scheme");
+    return createUniformPartition(ss[0].pi.size(), totalSum);
+}
+
+inline auto expand(Search const& s, size_t newLen) -> std::optional<Search> {   // expand.h:146-155
+    size_t P = s.pi.size();
+    std::vector<size_t> counts(P, newLen / P), starts(P, 0);
+    for (size_t i = 0; i < newLen % P; ++i) counts[i] += 1;
+    for (size_t i = 1; i < P; ++i) starts[i] = starts[i - 1] + counts[i - 1];
+    Search r;
+    for (size_t i = 0; i < P; ++i) {
+        bool forward = i == 0 ? (P == 1 || s.pi[1] > s.pi[0]) : s.pi[i] > s.pi[i - 1];
+        size_t lo = starts[s.pi[i]], cnt = counts[s.pi[i]];
+        for (size_t j = 0; j < cnt; ++j) r.pi.push_back(forward ? lo + j : lo + cnt - 1 - j);
+        if (cnt >= 1) { for (size_t j = 1; j < cnt; ++j) r.l.push_back(i ? s.l[i - 1] : 0); r.l.push_back(s.l[i]); }
+        else if (!r.l.empty()) r.l.back() = s.l[i];
+        for (size_t j = 0; j < cnt; ++j) r.u.push_back(s.u[i]);
+    }
+    if (r.pi.size() != newLen || !isValid(r)) return std::nullopt;
+    return r;
+}
+inline auto expand(Scheme const& ss, size_t newLen) -> Scheme {
+    Scheme r;
+    for (auto const& s : ss) if (auto o = expand(s, newLen)) r.push_back(*o);
+    return r;
+}
+inline auto limitToHamming(Scheme ss) -> Scheme {   // expand.h:301-319
+    for (auto& s : ss) {
+        for (size_t i = s.pi.size() - 1; i > 0; --i) { if (s.l[i] == 0) break; s.l[i - 1] = std::max(s.l[i - 1], s.l[i] - 1); }
+        for (size_t i = 1; i < s.pi.size(); ++i) s.u[i] = std::min(s.u[i], s.u[i - 1] + 1);
+    }
+    return ss;
+}
+inline auto isComplete(Scheme const& ss, size_t minK, size_t maxK) -> bool {   // isComplete.h:69-84
+    if (ss.empty()) return false;
+    size_t P = ss[0].pi.size();
+    std::vector<size_t> cfg(P, 0);
+    auto covered = [&]() {
+        for (auto const& s : ss) {
+            size_t a = 0; bool ok = true;
+            for (size_t i = 0; i < P && ok; ++i) { a += cfg[s.pi[i]]; ok = s.l[i] <= a && a <= s.u[i]; }
+            if (ok) return true;
+        }
+        return false;
+    };
+    bool complete = minK > 0 || covered();
+    auto rec = [&](auto&& self, size_t k, size_t start) -> void {
+        if (k >= maxK || !complete) return;
+        for (size_t i = start; i < P && complete; ++i) {
+            cfg[i] += 1;
+            if (k + 1 >= minK && !covered()) complete = false;
+            self(self, k + 1, i);
+            cfg[i] -= 1;
+        }
+    };
+    rec(rec, 0, 0);
+    return complete;
+}
+
+namespace generator {
+inline auto backtracking(size_t N, size_t minK, size_t K) -> Scheme {   // generator/backtracking.h:14-21
+    Search s{std::vector<size_t>(N), std::vector<size_t>(N, 0), std::vector<size_t>(N, K)};
+    std::iota(s.pi.begin(), s.pi.end(), size_t{0});
+    s.l.back() = minK;
+    return {s};
+}
+inline auto pigeon(size_t minK, size_t K, bool opt) -> Scheme {   // generator/pigeon.h:14-102
+    size_t N = K + 1;
+    Scheme res;
+    for (size_t i = 0; i < N; ++i) {
+        Search s;
+        s.pi.push_back(i); s.l.push_back(0); s.u.push_back(0);
+        for (size_t j = i; j > 0; --j) { s.pi.push_back(j - 1); s.l.push_back(opt ? i - j + 1 : 0); s.u.push_back(opt ? K - j + 1 : K); }
+        for (size_t j = i + 1; j < N; ++j) { s.pi.push_back(j); s.l.push_back(opt ? i : 0); s.u.push_back(K); }
+        s.l.back() = std::max(s.l.back(), minK);
+        res.push_back(s);
+    }
+    return res;
+}
+inline auto pigeon_opt(size_t minK, size_t K) -> Scheme { return pigeon(minK, K, true); }
+inline auto pigeon_trivial(size_t minK, size_t K) -> Scheme { return pigeon(minK, K, false); }
+
+inline auto h2(size_t N, size_t minK, size_t K) -> Scheme {   // generator/h2.h:128-153
+    if (N <= K || minK > K) throw std::invalid_argument("h2(N, minK, K) needs N > K >= minK");
+    size_t R = K + 1;
+    auto at = [&](std::vector<size_t>& m, size_t r, size_t c) -> size_t& { return m[r * N + c]; };
+    std::vector<size_t> pi(R * N), l(R * N, 0), u(R * N, 0), d(R * N, 0);
+    for (size_t r = 0; r < R; ++r) for (size_t c = 0; c < N; ++c) {
+        size_t skip = K - r;
+        at(pi, r, c) = c < N - skip ? c + skip : N - c - 1;
+        if (c >= N - (K - r + 1)) at(l, r, c) = r;
+        at(d, r, c) = c >= K ? K - r : (r < K ? (r + K - c) % K : K);
+    }
+    auto fits = [&](size_t row, size_t col, size_t v) {
+        if (row == col) return false;
+        if (row > col) { for (size_t i = 0; i < col; ++i) if (at(d, row, i) < v) return false; }
+        else for (size_t i = row + 1; i < col; ++i) if (at(d, row, i) > v) return false;
+        return true;
+    };
+    for (size_t c = 0; c < N; ++c) for (size_t r = 0; r < R; ++r) {
+        if (c == r || at(d, r, c) == 0 || fits(r, c, at(d, r, c))) continue;
+        for (size_t o = r + 1; o < R; ++o)
+            if (fits(r, c, at(d, o, c)) && fits(o, c, at(d, r, c))) { std::swap(at(d, r, c), at(d, o, c)); break; }
+    }
+    for (size_t c = 1; c < N; ++c) for (size_t r = R; r-- > 0;)
+        at(u, r, c) = std::max(at(u, r, c - 1), at(l, r, c - 1) + at(d, K - r, at(pi, r, c)));
+    Scheme ss;
+    for (size_t r = 0; r < R; ++r) {
+        Search s;
+        s.pi.assign(pi.begin() + r * N, pi.begin() + (r + 1) * N);
+        s.l.assign(l.begin() + r * N, l.begin() + (r + 1) * N);
+        s.u.assign(u.begin() + r * N, u.begin() + (r + 1) * N);
+        s.l.back() = std::max(s.l.back(), minK);
+        ss.push_back(s);
+    }
+    return ss;
+}
+}  // namespace generator
+}  // namespace search_scheme
+
+// ------------------------------------------------------------------------------------------------ searches
+namespace detail {
+template <typename Index, typename Delegate>
+void report(Index const& index, std::vector<fmgpu_hit>& hits, Delegate&& delegate) {
+    std::sort(hits.begin(), hits.end(), [](fmgpu_hit const& a, fmgpu_hit const& b) { return std::tie(a.qidx, a.seq) < std::tie(b.qidx, b.seq); });
+    using cursor_t = select_cursor_t<Index>;
+    for (auto const& h : hits) {
+        cursor_t cur{};
+        cur.index = &index; cur.lb = h.lb; cur.len = h.len;
+        if constexpr (std::is_same_v<cursor_t, BiFMIndexCursor<Index>>) cur.lbRev = h.lb_rev;
+        delegate(static_cast<size_t>(h.qidx), cur, static_cast<size_t>(h.errors));
+    }
+}
+template <typename Call>
+std::vector<fmgpu_hit> run_hits(size_t nq, Call&& call) {
+    std::vector<fmgpu_hit> hits(std::max<size_t>(1024, 4 * nq));
+    for (;;) {
+        uint64_t count = 0;
+        int rc = call(hits.data(), hits.size(), &count);
+        if (rc == FMGPU_ERR_CAPACITY) { hits.resize(count); continue; }
+        check(rc);
+        hits.resize(count);
+        return hits;
+    }
+}
+}  // namespace detail
+
+namespace search_no_errors {
+// search(index, queries, delegate(qidx, cursor)) — search/SearchNoErrors.h:28-86; only non-empty cursors are reported
+template <typename Index, typename Queries, typename Delegate>
+void search(Index const& index, Queries const& queries, Delegate&& delegate, size_t /*BatchSize*/ = 32) {
+    std::vector<uint8_t> buf; std::vector<uint64_t> off;
+    detail::flatten(queries, buf, off);
+    size_t nq = off.size() - 1;
+    std::vector<uint64_t> lb(nq), len(nq);
+    detail::check(fmgpu_search_exact(index.handle, buf.data(), off.data(), nq, lb.data(), len.data(), nullptr, nullptr));
+    using cursor_t = select_cursor_t<Index>;
+    for (size_t q = 0; q < nq; ++q) {
+        if (len[q] == 0) continue;
+        cursor_t cur{};
+        cur.index = &index; cur.lb = lb[q]; cur.len = len[q];
+        delegate(q, cur);
+    }
+}
+}  // namespace search_no_errors
+
+namespace search_backtracking {
+// search(index, queries, maxError, delegate(qidx, cursor, errors)) — search/Backtracking.h:85-89
+template <typename Index, typename Queries, typename Delegate>
+void search(Index const& index, Queries const& queries, size_t maxError, Delegate&& delegate) {
+    std::vector<uint8_t> buf; std::vector<uint64_t> off;
+    detail::flatten(queries, buf, off);
+    size_t nq = off.size() - 1;
+    auto hits = detail::run_hits(nq, [&](fmgpu_hit* out, uint64_t cap, uint64_t* count) {
+        return fmgpu_search_backtracking(index.handle, buf.data(), off.data(), nq, maxError, out, cap, count, nullptr, nullptr);
+    });
+    detail::report(index, hits, delegate);
+}
+}  // namespace search_backtracking
+
+namespace search_ng26 {
+// search<Edit>(index, queries, scheme, partition, delegate(qidx, cursor, errors), n) — search/SearchNg26.h:426-433
+template <bool Edit = true, typename Index, typename Queries, typename Delegate>
+void search(Index const& index, Queries const& queries, search_scheme::Scheme const& scheme, std::vector<size_t> const& partition,
+            Delegate&& delegate, size_t n = std::numeric_limits<size_t>::max()) {
+    if constexpr (Edit) throw std::runtime_error("fmindex-collection (gpu): edit distance is outside the accelerated path, use search<false>");
+    std::vector<uint8_t> buf; std::vector<uint64_t> off;
+    detail::flatten(queries, buf, off);
+    size_t nq = off.size() - 1;
+    if (scheme.empty() || nq == 0 || n == 0) return;
+    size_t P = scheme[0].pi.size();
+    std::vector<uint64_t> pi, l, u, part(partition.begin(), partition.end());
+    for (auto const& s : scheme) {
+        if (s.pi.size() != P) throw std::runtime_error("fmindex-collection (gpu): searches of a scheme must have the same number of parts");
+        pi.insert(pi.end(), s.pi.begin(), s.pi.end()); l.insert(l.end(), s.l.begin(), s.l.end()); u.insert(u.end(), s.u.begin(), s.u.end());
+    }
+    fmgpu_scheme sc{static_cast<int32_t>(scheme.size()), static_cast<int32_t>(P), pi.data(), l.data(), u.data(), part.empty() ? nullptr : part.data()};
+    auto hits = detail::run_hits(nq, [&](fmgpu_hit* out, uint64_t cap, uint64_t* count) {
+        return fmgpu_search_scheme(index.handle, buf.data(), off.data(), nq, &sc, n, out, cap, count, nullptr, nullptr);
+    });
+    detail::report(index, hits, delegate);
+}
+// search<Edit>(index, queries, maxErrors, delegate, n) — search/SearchNg26.h:436-444: h2(maxErrors+2, 0, maxErrors), uniform partition per
+// query length.  (The reference additionally applies limitToHamming to the un-expanded scheme, which loses hits: SURVEY.md §0.3.)
+template <bool Edit = true, typename Index, typename Queries, typename Delegate>
+void search(Index const& index, Queries const& queries, size_t maxErrors, Delegate&& delegate, size_t n = std::numeric_limits<size_t>::max()) {
+    search<Edit>(index, queries, search_scheme::generator::h2(maxErrors + 2, 0, maxErrors), {}, std::forward<Delegate>(delegate), n);
+}
+}  // namespace search_ng26
+
+// fmc::search<EditDistance>(index, queries, errors, delegate(qidx, cursor, errors)) — search/search.h:26-35
+template <bool EditDistance, typename Index, typename Queries, typename Delegate>
+void search(Index const& index, Queries const& queries, size_t errors, Delegate&& delegate) {
+    if (errors == 0) search_no_errors::search(index, queries, [&](size_t qidx, auto const& cursor) { delegate(qidx, cursor, size_t{0}); });
+    else search_ng26::search<EditDistance>(index, queries, errors, std::forward<Delegate>(delegate));
+}
+
+// LocateLinear{index, cursor}: for (auto [seqId, pos, offset] : LocateLinear{index, cursor}) — locate.h:14-57 (one batched call)
+template <typename Index, typename Cursor>
+struct LocateLinear {
+    std::vector<typename Index::LEntry> entries;
+    LocateLinear(Index const& index, Cursor const& cursor) {
+        std::vector<uint64_t> rows(cursor.len);
+        std::iota(rows.begin(), rows.end(), uint64_t{cursor.lb});
+        entries = index.locate(rows);
+    }
+    auto begin() const { return entries.begin(); }
+    auto end() const { return entries.end(); }
+};
+template <typename Index, typename Cursor> LocateLinear(Index const&, Cursor const&) -> LocateLinear<Index, Cursor>;
+
+}  // namespace fmc

@@ -1,0 +1,115 @@
+// The reference's own tests for the path, re-stated against include/fmc_gpu.hpp (same calls, same expected values):
+// search/checkSearches.cpp:14-72, :104-117, :1173-1199; search/checkSearchBacktracking.cpp:42-102; fmindex/checkBiFMIndexCursor.cpp:12-30;
+// search_scheme/expand.cpp:11-60; search_scheme/checkGeneratorsIsComplete.cpp:48-60.  Needs a GPU; exit code 0 = all checks passed.
+#include "../../include/fmc_gpu.hpp"
+
+#include <cstdio>
+#include <tuple>
+#include <vector>
+
+static int failures = 0;
+#define CHECK(x) do { if (!(x)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #x); ++failures; } } while (0)
+
+using Results = std::vector<std::tuple<size_t, size_t, size_t>>;
+
+int main() {
+    namespace ss = fmc::search_scheme;
+    {   // search_scheme/expand.cpp
+        auto real = ss::expand(ss::Scheme{ss::Search{{0, 1}, {0, 0}, {0, 1}}}, 4);
+        CHECK(ss::isValid(real));
+        CHECK((real == ss::Scheme{ss::Search{{0, 1, 2, 3}, {0, 0, 0, 0}, {0, 0, 1, 1}}}));
+        real = ss::expand(ss::Scheme{ss::Search{{0, 1}, {0, 0}, {0, 0}}}, 10);
+        CHECK(real.size() == 1 && real[0].pi.size() == 10 && real[0].u.back() == 0);
+        for (size_t N = 1; N < 10; ++N)
+            for (size_t minK = 0; minK < std::min(N, size_t{5}); ++minK)
+                for (size_t maxK = minK; maxK < std::min(N, size_t{5}); ++maxK)
+                    CHECK(ss::isComplete(ss::generator::h2(N, minK, maxK), minK, maxK));
+        auto h = ss::generator::h2(4, 0, 2);
+        CHECK((h[0] == ss::Search{{2, 3, 1, 0}, {0, 0, 0, 0}, {0, 0, 2, 2}}));
+        CHECK((h[1] == ss::Search{{1, 2, 3, 0}, {0, 0, 1, 1}, {0, 1, 1, 2}}));
+        CHECK((h[2] == ss::Search{{0, 1, 2, 3}, {0, 0, 0, 2}, {0, 1, 2, 2}}));
+        CHECK((ss::createUniformPartition(h, 101) == std::vector<size_t>{26, 25, 25, 25}));
+    }
+    int ndev = 0;
+    if (fmgpu_device_count(&ndev) != 0 || ndev == 0) { std::printf("no GPU: host-only checks %s\n", failures ? "FAILED" : "passed"); return failures ? 1 : 77; }
+
+    auto input = std::vector<std::vector<uint8_t>>{{'A', 'A', 'A', 'C', 'A', 'A', 'A', 'B', 'A', 'A', 'A'}, {'A', 'A', 'A', 'B', 'A', 'A', 'A', 'C', 'A', 'A', 'A'}};
+    auto queries = std::vector<std::vector<uint8_t>>{{'C', 'C'}, {'B', 'B'}};
+    auto expected = Results{{0, 0, 2}, {0, 0, 3}, {0, 1, 6}, {0, 1, 7}, {1, 0, 6}, {1, 0, 7}, {1, 1, 2}, {1, 1, 3}};
+    {   // "check searches with errors": BiFMIndex<256>, samplingRate 1
+        using Index = fmc::BiFMIndex<256>;
+        auto index = Index{input, /*samplingRate*/ 1, /*threadNbr*/ 1};
+        auto results = Results{};
+        fmc::search_backtracking::search(index, queries, 1, [&](auto qidx, auto cursor, auto errors) {
+            (void)errors;
+            for (auto [sid, spos, offset] : fmc::LocateLinear{index, cursor}) results.emplace_back(qidx, sid, spos + offset);
+        });
+        std::sort(results.begin(), results.end());
+        CHECK(results == expected);
+
+        results.clear();
+        fmc::search_no_errors::search(index, queries, [&](auto qidx, auto cursor) {
+            for (auto [sid, spos, offset] : fmc::LocateLinear{index, cursor}) results.emplace_back(qidx, sid, spos + offset);
+        });
+        CHECK(results.empty());
+
+        results.clear();
+        auto scheme = ss::generator::pigeon_opt(0, 1);
+        auto partition = ss::createUniformPartition(scheme, queries[0].size());
+        fmc::search_ng26::search</*EditDistance=*/false>(index, queries, scheme, partition, [&](auto qidx, auto cursor, auto errors) {
+            (void)errors;
+            for (auto [sid, spos, offset] : fmc::LocateLinear{index, cursor}) results.emplace_back(qidx, sid, spos + offset);
+        });
+        std::sort(results.begin(), results.end());
+        CHECK(results == expected);
+
+        bool threw = false;
+        try { fmc::search_ng26::search(index, queries, scheme, partition, [](auto, auto, auto) {}); } catch (std::runtime_error const&) { threw = true; }
+        CHECK(threw);   // Edit = true (the reference's default) is outside the accelerated path
+    }
+    {   // "backtracking with errors": FMIndex<256>
+        auto index = fmc::FMIndex<256>{input, 1, 1};
+        auto results = Results{};
+        fmc::search_backtracking::search(index, queries, 1, [&](auto qidx, auto cursor, auto errors) {
+            (void)errors;
+            for (auto [sid, spos, offset] : fmc::LocateLinear{index, cursor}) results.emplace_back(qidx, sid, spos + offset);
+        });
+        std::sort(results.begin(), results.end());
+        CHECK(results == expected);
+    }
+    {   // "searching with collection and backtracking": interval of 'A' and the locate table
+        auto in2 = std::vector<std::vector<uint8_t>>{{'A', 'A', 'A', 'C', 'A', 'A', 'A', 'C', 'A', 'A', 'A'}, {'A', 'A', 'A', 'B', 'A', 'A', 'A', 'B', 'A', 'A', 'A'}};
+        auto index = fmc::BiFMIndex<255>{in2, 1, 1};
+        CHECK(index.size() == 24);
+        auto query = std::vector<std::vector<uint8_t>>{{'A'}};
+        size_t calls = 0;
+        fmc::search_backtracking::search(index, query, 0, [&](auto qidx, auto result, auto errors) {
+            ++calls;
+            CHECK(qidx == 0); CHECK(errors == 0); CHECK(result.lb == 2); CHECK(result.count() == 18);
+        });
+        CHECK(calls == 1);
+        auto exp = std::vector<std::tuple<uint32_t, uint32_t>>{{1, 11}, {0, 11}, {1, 10}, {0, 10}, {1, 9}, {0, 9}, {1, 8}, {0, 8}, {1, 4}, {1, 0}, {0, 4}, {0, 0},
+                                                               {1, 5}, {1, 1}, {0, 5}, {0, 1}, {1, 6}, {1, 2}, {0, 6}, {0, 2}, {1, 7}, {1, 3}, {0, 7}, {0, 3}};
+        for (size_t i = 0; i < exp.size(); ++i) {
+            auto [il, pl, offset] = index.locate(i);
+            CHECK(il == std::get<0>(exp[i])); CHECK(pl + offset == std::get<1>(exp[i]));
+        }
+    }
+    {   // fmc::search<false> facade, k = 1 on 20-symbol reads
+        auto text = std::vector<std::vector<uint8_t>>{std::vector<uint8_t>(400)};
+        uint64_t s = 42;
+        for (auto& c : text[0]) { s = s * 6364136223846793005ull + 1442695040888963407ull; c = 1 + (s >> 33) % 4; }
+        auto index = fmc::BiFMIndex<5>{text, 4, 1};
+        auto reads = std::vector<std::vector<uint8_t>>{};
+        for (size_t p = 0; p + 20 <= 400; p += 37) { reads.emplace_back(text[0].begin() + p, text[0].begin() + p + 20); }
+        reads[1][7] = reads[1][7] % 4 + 1;
+        size_t found = 0;
+        fmc::search<false>(index, reads, 1, [&](size_t qidx, auto cursor, size_t errors) {
+            for (auto [sid, spos, offset] : fmc::LocateLinear{index, cursor})
+                if (sid == 0 && spos + offset == qidx * 37) { ++found; CHECK(errors == (qidx == 1 ? 1u : 0u)); }
+        });
+        CHECK(found == reads.size());
+    }
+    std::printf("%s (%d failures)\n", failures ? "FAILED" : "all checks passed", failures);
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,29 @@
+"""condense a tools/profile_round.sh output directory into the summary that is committed under profiles/ (dev tool)"""
+import csv, glob, collections, json, sys
+d, pat, out = sys.argv[1], sys.argv[2], sys.argv[3]
+res = {"source": d, "kernel_filter": pat, "kernel_stats": [], "counters_per_launch": {}}
+for f in glob.glob(d + "/trace/*/*_kernel_stats.csv"):
+    for r in list(csv.DictReader(open(f)))[:12]:
+        res["kernel_stats"].append({"name": r["Name"][:110], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                    "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6, "pct": float(r["Percentage"])})
+for f in sorted(glob.glob(d + "/pmc_*/*/*_counter_collection.csv")):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        res["counters_per_launch"][k] = {"mean": sum(v) / len(v), "launches": len(v)}
+c = res["counters_per_launch"]
+if "FETCH_SIZE" in c:
+    fetch_kb = c["FETCH_SIZE"]["mean"]; write_kb = c.get("WRITE_SIZE", {"mean": 0})["mean"]
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE is in KB and, on gfx950, tallies each 128-byte fill at 64 bytes -> x2; WRITE_SIZE reads exactly
+    res["hbm_traffic_bytes_per_launch"] = {"fetch_raw_kb": fetch_kb, "write_kb": write_kb,
+                                           "corrected_bytes": (2 * fetch_kb + write_kb) * 1024,
+                                           "correction": "FETCH_SIZE x 2 (128-B requests tallied at 64 B on gfx950, confirmed by tools/membench.hip mode 1) + WRITE_SIZE"}
+try:
+    res["bench_line"] = json.loads(open(d + "/bench_line.json").read())
+except Exception:
+    pass
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({k: res[k] for k in ("hbm_traffic_bytes_per_launch",) if k in res}))
+print([ (k["name"][:60], k["avg_ms"]) for k in res["kernel_stats"][:4]])
