@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the text (dev runs only; the judged run uses 1.0)")
     ap.add_argument("--nq", type=int, default=10_000_000)
     ap.add_argument("--read-len", type=int, default=101)
+    ap.add_argument("--kstep", type=int, default=3, help="exact search: symbols per table step (fmgpu_index_accelerate); 1 = plain occurrence table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -109,6 +110,8 @@ def main():
     t0 = time.time()
     cls = fm.BiFMIndex if bidir else fm.FMIndex
     index = cls.from_sequences((_Dev(text), _Dev(seq_off)), 5, "IB16", 16, keep_host=want_cpu)
+    if not bidir and args.kstep > 1:
+        index.accelerate(args.kstep)
     build_s = time.time() - t0
     if not want_cpu:
         del text
@@ -173,13 +176,16 @@ def main():
     alg_bytes = steps_per_launch * 2 * BLOCK_BYTES_IB16_S5
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     hits = int((out_len > 0).sum().item()) if not bidir else int(stats.hits)
-    traffic = None                                            # HBM bytes per launch from the committed PMC passes of this workload
+    traffic, lines = None, None                               # HBM bytes / line requests per launch from the committed PMC passes
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["grch38_%s" % ("exact" if not bidir else "k2")]
+        tall = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = "grch38_k2" if bidir else ("grch38_exact" if args.kstep == 3 else "grch38_exact_kstep%d" % args.kstep)
+        tj = tall[key]
         if args.scale == 1.0 and nq == 10_000_000 and L == 101:
-            traffic = tj["bytes_per_launch"]
+            traffic, lines = tj["bytes_per_launch"], tj["line_requests_per_launch"]
+            ceiling = tall["_random_line_ceiling_G_per_s"]["value"]
     except Exception:
-        traffic = None
+        traffic, lines = None, None
     result = {
         "metric": "queries/sec (GRCh38-sized index, 10M x 101bp, %s)" % ("exact" if not bidir else "k=2 Hamming, h2(4,0,2)"),
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,14 +193,21 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "grch38_%s" % ("exact" if not bidir else "k2"), "text_symbols": total, "sequences": len(lengths),
                    "sigma": 5, "layout": "InterleavedBitvector16", "queries_per_gpu": nq, "read_len": L,
-                   "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale,
+                   "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale, "kstep_table": (args.kstep if not bidir else 1),
                    "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
         "gbp_per_s": qps * L / 1e9,
         "hits": hits,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "k_exact_a" if not bidir else "k_scheme_fast", "kernel_ms": k_ms,
-                     "units_per_launch": steps_per_launch, "bytes_per_unit": 2 * BLOCK_BYTES_IB16_S5},
+                     "traffic": traffic, "kernel": ("k_exact_kstep" if args.kstep > 1 else "k_exact_a") if not bidir else "k_scheme_fast", "kernel_ms": k_ms,
+                     "units_per_launch": steps_per_launch, "bytes_per_unit": 2 * BLOCK_BYTES_IB16_S5,
+                     "unit": "GB/s", "note": "unit = executed LF step (exact) / visited node (k=2), identical to the CPU walk; bytes_per_unit = "
+                             "2 x sizeof(InterleavedBitvector16<5>::Block) of the reference layout (SURVEY 8d). The kstep table serves 3 LF steps "
+                             "per touched line, so algorithmic bytes exceed the traffic; see line_rate for the hardware bound"},
     }
+    if lines is not None:
+        result["roofline"]["line_rate"] = {"achieved_G_per_s": lines / (k_ms * 1e-3) / 1e9, "ceiling_G_per_s": ceiling,
+                                           "frac": lines / (k_ms * 1e-3) / 1e9 / ceiling,
+                                           "what": "L2->fabric 128-byte line requests per second (TCC_EA0_RDREQ) vs the measured ceiling for dependent random line reads"}
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, args.cpu_sample, out_lb, out_len)
     print(json.dumps(result), flush=True)

@@ -177,6 +177,14 @@ class FMIndex:
     def size(self):
         return self.n
 
+    def accelerate(self, kstep=3):
+        """add (kstep >= 2) or drop (0) the multi-symbol-step table used by exact search; results are unchanged"""
+        capi.check(capi.lib().fmgpu_index_accelerate(self._h, kstep))
+        n, sigma, layout, bidir, dbytes = C.c_uint64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()
+        capi.check(capi.lib().fmgpu_index_info(self._h, C.byref(n), C.byref(sigma), C.byref(layout), C.byref(bidir), C.byref(dbytes)))
+        self.device_bytes = dbytes.value
+        return self
+
     # -------------------------------------------------------------- String_c batch (string/concepts.h:25-87)
     def _string_query(self, which, idx, symb, what):
         idx = _u64(idx)

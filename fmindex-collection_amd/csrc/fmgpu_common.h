@@ -363,6 +363,10 @@ struct DevString {
     // explicit LF mapping: lf_table[i] = C[s[i]] + rank(i, s[i])  (n entries; the symbol is recovered from C).
     // 4 bytes per row buy one-load single-row DFS nodes and one-load locate steps; skipped with FMGPU_LF_TABLE=0.
     idx_t* lf_table = nullptr;
+    // multi-symbol-step table (fmgpu_index_accelerate): block B, context w at  kblk + (B * kcodes + w) * 16 :
+    //   { u32 cnt = LF_k(64B, w); u32 bits_lo; u32 bits_hi; u32 0 }   (bit r: the kstep symbols preceding suffix 64B+r spell w;
+    //   the first 12 bytes are fetched with one dwordx3 load, like a Format A entry)
+    uint8_t* kblk = nullptr; uint32_t kstep = 0, kcodes = 0; size_t kblk_bytes = 0;
 };
 
 // fills s.lf_table from the device string (all layouts); defined in fmgpu_index.hip

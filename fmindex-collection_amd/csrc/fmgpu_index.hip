@@ -141,7 +141,8 @@ void free_string(DevString& s) {
     if (s.blk) (void)hipFree(s.blk);
     if (s.aux) (void)hipFree(s.aux);
     if (s.lf_table) (void)hipFree(s.lf_table);
-    s.blk = s.aux = nullptr; s.lf_table = nullptr;
+    if (s.kblk) (void)hipFree(s.kblk);
+    s.blk = s.aux = nullptr; s.lf_table = nullptr; s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0;
 }
 
 template <class Occ>
@@ -259,6 +260,103 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
     return 0;
 }
 
+// ------------------------------------------------------------------ multi-symbol-step table
+// context code of row j: walk K LF steps from j collecting the BWT symbols s_1 (immediately before the suffix), s_2, ...;
+// w = s_K ... s_1 in text order, code = sum (s_t - 1) * R^(t-1) with R = sigma - 1; 255 if a delimiter is met.
+template <class Occ>
+__global__ __launch_bounds__(256) void k_kstep_codes(Occ occ, const idx_t* __restrict__ lf_table, uint64_t n, uint32_t K, uint32_t R, uint8_t* __restrict__ code) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    idx_t row = (idx_t)j;
+    uint32_t c = 0, mul = 1; bool ok = true;
+    for (uint32_t t = 0; t < K; ++t) {
+        uint32_t s;
+        row = occ.lf_symbol(row, s);
+        if (s == 0) { ok = false; break; }
+        c += (s - 1) * mul; mul *= R;
+    }
+    (void)lf_table;
+    code[j] = ok ? (uint8_t)c : (uint8_t)255;
+}
+// one wave per 64-row block: plane bits by ballot; per-block counts into cnt[w * nblocks + B]
+__global__ __launch_bounds__(256) void k_kstep_bits(const uint8_t* __restrict__ code, uint64_t n, uint64_t nblocks, uint32_t ncodes,
+                                                    uint8_t* __restrict__ kblk, uint32_t* __restrict__ cnt) {
+    uint64_t B = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t lane = threadIdx.x & 63u;
+    if (B >= nblocks) return;
+    uint64_t row = B * 64 + lane;
+    uint32_t s = row < n ? code[row] : 0xffffffffu;
+    for (uint32_t c0 = 0; c0 < ncodes; c0 += 64) {
+        uint64_t mine = 0;
+        for (uint32_t c = c0; c < ncodes && c < c0 + 64; ++c) {
+            uint64_t bits = __ballot(s == c);
+            if (lane == c - c0) mine = bits;
+        }
+        uint32_t c = c0 + lane;
+        if (c < ncodes) {
+            uint32_t* o = reinterpret_cast<uint32_t*>(kblk + (B * ncodes + c) * 16ull);
+            o[1] = (uint32_t)mine; o[2] = (uint32_t)(mine >> 32); o[3] = 0;
+            cnt[(uint64_t)c * nblocks + B] = (uint32_t)__popcll(mine);
+        }
+    }
+}
+// C_k[w] = LF_k(0, w): the k single steps of the context from row 0, last symbol first
+template <class Occ>
+__global__ void k_kstep_base(Occ occ, uint32_t K, uint32_t R, uint32_t ncodes, idx_t* __restrict__ base) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= ncodes) return;
+    idx_t i = 0; uint32_t rest = w;
+    for (uint32_t t = 0; t < K; ++t) { uint32_t s = rest % R + 1; rest /= R; i = occ.lf(i, s); }
+    base[w] = i;
+}
+__global__ __launch_bounds__(256) void k_kstep_counts(const uint32_t* __restrict__ cnt, const idx_t* __restrict__ base, uint64_t nblocks, uint32_t ncodes,
+                                                      uint8_t* __restrict__ kblk) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblocks * ncodes) return;
+    uint64_t B = t % nblocks; uint32_t c = (uint32_t)(t / nblocks);
+    *reinterpret_cast<uint32_t*>(kblk + (B * ncodes + c) * 16ull) = cnt[t] + base[c];
+}
+
+}  // namespace fmgpu
+
+#include <hipcub/hipcub.hpp>
+
+namespace fmgpu {
+
+template <class Occ>
+static int accelerate_with(DevString& s, Occ occ, uint32_t K) {
+    const uint32_t R = (uint32_t)s.sigma - 1;
+    uint64_t nc = 1;
+    for (uint32_t t = 0; t < K; ++t) { nc *= R; if (nc > 255) return fail(FMGPU_ERR_UNSUPPORTED, "(sigma-1)^kstep must be <= 255"); }
+    const uint32_t ncodes = (uint32_t)nc;
+    const uint64_t n = s.n, nblocks = n / 64 + 1;
+    uint8_t* code = nullptr; uint32_t* cnt = nullptr; idx_t* base = nullptr; uint8_t* kblk = nullptr; void* tmp = nullptr;
+    auto cleanup = [&]() { for (void* p : {(void*)code, (void*)cnt, (void*)base, tmp}) if (p) (void)hipFree(p); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&code, n + 64)) != hipSuccess || (e = hipMalloc((void**)&cnt, (size_t)ncodes * nblocks * 4)) != hipSuccess ||
+        (e = hipMalloc((void**)&base, ncodes * sizeof(idx_t))) != hipSuccess || (e = hipMalloc((void**)&kblk, (size_t)nblocks * ncodes * 16 + 128)) != hipSuccess) {
+        cleanup(); if (kblk) (void)hipFree(kblk); return hip_fail(e, "hipMalloc(k-step table)");
+    }
+    k_kstep_codes<Occ><<<dim3((unsigned)((n + 255) / 256)), 256>>>(occ, s.lf_table, n, K, R, code);
+    k_kstep_bits<<<dim3((unsigned)((nblocks * 64 + 255) / 256)), 256>>>(code, n, nblocks, ncodes, kblk, cnt);
+    k_kstep_base<Occ><<<dim3((ncodes + 63) / 64), 64>>>(occ, K, R, ncodes, base);
+    size_t tb = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, cnt, (size_t)nblocks);
+    if ((e = hipMalloc(&tmp, tb ? tb : 8)) != hipSuccess) { cleanup(); (void)hipFree(kblk); return hip_fail(e, "hipMalloc(scan)"); }
+    for (uint32_t c = 0; c < ncodes; ++c) {
+        uint32_t* p = cnt + (uint64_t)c * nblocks;
+        size_t b2 = tb;
+        if ((e = hipcub::DeviceScan::ExclusiveSum(tmp, b2, p, p, (size_t)nblocks)) != hipSuccess) { cleanup(); (void)hipFree(kblk); return hip_fail(e, "ExclusiveSum"); }
+    }
+    k_kstep_counts<<<dim3((unsigned)((nblocks * ncodes + 255) / 256)), 256>>>(cnt, base, nblocks, ncodes, kblk);
+    e = hipDeviceSynchronize();
+    cleanup();
+    if (e != hipSuccess) { (void)hipFree(kblk); return hip_fail(e, "k-step table kernels"); }
+    if (s.kblk) (void)hipFree(s.kblk);
+    s.kblk = kblk; s.kstep = K; s.kcodes = ncodes; s.kblk_bytes = (size_t)nblocks * ncodes * 16 + 128;
+    return 0;
+}
+
 // ------------------------------------------------------------------ String_c batch kernel
 template <class Occ>
 __global__ __launch_bounds__(256) void k_string_query(Occ occ, const uint64_t* __restrict__ idx, const uint8_t* __restrict__ symb,
@@ -361,6 +459,25 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
     }
     *out = reinterpret_cast<fmgpu_index_t>(x.release());
     return 0;
+}
+
+int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    DevString& s = x->bwt;
+    if (kstep < 0 || kstep > 8) return fail(FMGPU_ERR_INVALID, "kstep must be in [0, 8]");
+    x->device_bytes -= s.kblk_bytes;
+    if (s.kblk) { (void)hipFree(s.kblk); s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0; }
+    if (kstep <= 1 || s.n == 0) return 0;
+    int rc;
+    switch (s.family) {
+    case FAM_A:     rc = s.sigma == 5 ? accelerate_with(s, OccA<5>{s.va}, (uint32_t)kstep) : accelerate_with(s, OccA<0>{s.va}, (uint32_t)kstep); break;
+    case FAM_EPR:   rc = accelerate_with(s, OccR<false>{s.vr}, (uint32_t)kstep); break;
+    case FAM_EPRV2: rc = accelerate_with(s, OccR<true>{s.vr}, (uint32_t)kstep); break;
+    default:        rc = accelerate_with(s, OccW{s.vw}, (uint32_t)kstep); break;
+    }
+    if (rc == 0) x->device_bytes += s.kblk_bytes;
+    return rc;
 }
 
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes) {

@@ -506,14 +506,14 @@ __device__ __forceinline__ uint32_t symbol_of_lf(const FastArgs& fa, const idx_t
 }
 
 // wave-synchronous staging of one query per lane: all loads of a chunk are issued before the first is consumed
-__device__ __forceinline__ void qstage_load_sync(const QStage& st, const uint8_t* qbuf, uint64_t off, uint32_t m, uint32_t sigma, bool active) {
+__device__ __forceinline__ void qstage_load_sync(const QStage& st, const uint8_t* qbuf, uint64_t off, uint32_t m, uint32_t sigma, bool active, uint32_t maxm) {
     const uint64_t addr = (uint64_t)qbuf + off;
     const uint32_t mis = (uint32_t)(addr & 7ull);
     const uint64_t* base = reinterpret_cast<const uint64_t*>(addr - mis);
     const uint32_t nw = active ? ((mis + m + 7u) >> 3) : 0u;        // aligned 64-bit words that hold query bytes
     uint64_t carry = 0;
     uint32_t wi = 0;
-    for (uint32_t k0 = 0; k0 <= ((m + 14u) >> 3); k0 += 8) {        // wave-uniform trip count (m is uniform); word nw flushes the last bytes
+    for (uint32_t k0 = 0; k0 <= ((maxm + 14u) >> 3); k0 += 8) {     // uniform trip count (maxm >= every lane's m); word nw flushes the last bytes
         uint64_t r[8];
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) r[k] = (k0 + k < nw) ? base[k0 + k] : 0ull;
@@ -545,6 +545,72 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off, 64); if (lane >= (uint32_t)off) x += y; }
     return x - v;
+}
+
+// ---- exact search over the multi-symbol-step table (fmgpu_index_accelerate) ---------------------------------------
+// One table entry advances the cursor by K query symbols, so a query touches 1/K as many lines.  A chunk that holds a
+// symbol outside [1, sigma), or that empties the interval, is (re-)walked with single steps so that the reported cursor
+// and step count are exactly those of search/SearchNoErrors.h:12-26.  The query is staged in LDS up front (one query per
+// lane: the staging is wave-synchronous by construction); the next chunk's context code is fetched from LDS while the
+// table entries of the current chunk are in flight, and both interval ends are loaded together.
+template <class Occ>
+__global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, const uint8_t* __restrict__ kblk, uint32_t K, uint32_t ncodes, uint32_t R,
+                                                     const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
+                                                     uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
+                                                     unsigned long long* __restrict__ steps_total, uint32_t qwords, uint32_t qnib, uint32_t maxm) {
+    extern __shared__ uint32_t s_dyn[];
+    const QStage qst{s_dyn, qwords, qnib};
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = q < nq;
+    const uint64_t o = active ? qoff[q] : 0;
+    const uint32_t m = active ? (uint32_t)(qoff[q + 1] - o) : 0;
+    const uint8_t* sq = qbuf + o;
+    const uint32_t sigma = occ.sigma();
+    qstage_load_sync(qst, qbuf, o, m, sigma, active && m != 0, maxm);
+    uint32_t steps = 0;
+    if (active) {
+        idx_t lb = 0, len = n;
+        uint32_t done = 0;                                       // symbols consumed (from the right end)
+        auto chunk_code = [&](uint32_t from, bool& valid) -> uint32_t {   // context code of the K symbols ending at position m-1-from
+            uint32_t code = 0, mul = 1; valid = m - from >= K;
+            if (valid) for (uint32_t t = 0; t < K; ++t) {
+                uint32_t c = qstage_get(qst, sq, m - 1 - from - t);
+                valid = valid && c >= 1 && c < sigma;
+                code += (c - 1) * mul; mul *= R;
+            }
+            return code;
+        };
+        bool valid = false;
+        uint32_t code = m ? chunk_code(0, valid) : 0;
+        // main phase: whole chunks through the table.  A chunk that empties the interval (or holds an odd symbol) ends the
+        // phase for this lane WITHOUT touching the cursor: its single-step walk is deferred to the tail phase, where all lanes
+        // of the wave are convergent again (a lane-private re-walk here would stall the other 63 lanes for up to K round trips).
+        while (valid) {
+            const idx_t a = lb, b = lb + len;
+            EntryA ea = load_entry_a(kblk + (size_t)code * 16u, ncodes * 16u, a, 0);       // same 12-byte entry shape as Format A
+            EntryA eb = ea;
+            if ((a >> 6) != (b >> 6)) eb = load_entry_a(kblk + (size_t)code * 16u, ncodes * 16u, b, 0);
+            bool nvalid = false;
+            const uint32_t ncode = chunk_code(done + K, nvalid);   // LDS reads overlap the table loads
+            idx_t ra = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
+            idx_t rb = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
+            if (rb == ra) break;
+            lb = ra; len = rb - ra; steps += K; done += K; code = ncode; valid = nvalid;
+        }
+        // tail phase: single steps — the chunk that failed in the table (at most K steps until the interval is empty), the
+        // symbols after an odd one, or the m mod K left-over symbols
+        while (len != 0 && done < m) {
+            uint32_t c = qstage_get(qst, sq, m - 1 - done);
+            ++steps; ++done;
+            if (c >= sigma) { lb = 0; len = 0; break; }
+            idx_t ra, rb;
+            occ.lf2(lb, lb + len, c, ra, rb);
+            lb = ra; len = rb - ra;
+        }
+        out_lb[q] = lb; out_len[q] = len;
+    }
+    uint32_t tot = wave_sum(steps);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
 }
 
 constexpr uint32_t kHitBuf = 2;      // hits buffered per lane and round in LDS; further hits of the same query are emitted directly
@@ -580,7 +646,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
         const bool active = q < nq;
         const uint64_t qo = active ? qoff[q] : 0;
         const uint8_t* qs = qbuf + qo;
-        qstage_load_sync(qst, qbuf, qo, m, sigma, active);
+        qstage_load_sync(qst, qbuf, qo, m, sigma, active, m);
 
         uint64_t quota = max_hits; uint32_t seq = 0, nh = 0;
         uint32_t si = 0, e = 0, j = 0, sp = 0, resume = kNoResume;
@@ -942,7 +1008,23 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     const idx_t n = (idx_t)x->bwt.n;
     const int variant = [] { const char* e = getenv("FMGPU_EXACT_VARIANT"); return e ? atoi(e) : 2; }();   // dev knob
     timer.start();
-    if (x->bwt.family == FAM_A && variant >= 1) {
+    uint32_t kq_words = 0, kq_max = 0, kq_nib = x->bwt.sigma <= 15 ? 1u : 0u;
+    if (x->bwt.kblk && variant != 0) {                           // LDS staging needs the longest query of the batch
+        uint32_t mn = 0;
+        if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &kq_max, &mn))) { (void)hipFree(dsteps); return rc; }
+        kq_words = kq_nib ? (kq_max + 7) / 8 : (kq_max + 3) / 4;
+        if ((size_t)kq_words * 1024 > 48 * 1024) kq_words = 0;  // very long queries: read them from global memory
+        timer.start();
+    }
+    if (x->bwt.kblk && variant != 0) {
+        const DevString& bs = x->bwt;
+        rc = dispatch_occ(bs, [&](auto occ, auto) {
+            k_exact_kstep<decltype(occ)><<<grid, block, (size_t)kq_words * 1024, stream>>>(occ, bs.kblk, bs.kstep, bs.kcodes, (uint32_t)bs.sigma - 1,
+                                                                    (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev,
+                                                                    (uint64_t*)slen.dev, dsteps, kq_words, kq_nib, kq_max);
+            return 0;
+        });
+    } else if (x->bwt.family == FAM_A && variant >= 1) {
         auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
         auto launch = [&](auto occ) {
             using O = decltype(occ);

@@ -128,6 +128,12 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out);
 int fmgpu_index_destroy(fmgpu_index_t h);
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes);
 
+/* Optional accelerator for fmgpu_search_exact: a k-symbol-step occurrence table (one table entry advances a cursor by `kstep`
+ * symbols, so a query touches 1/kstep as many HBM lines).  Built on the device from the index itself; needs
+ * (sigma-1)^kstep <= 255 contexts and 16 * (sigma-1)^kstep / 64 bytes per row of HBM (DNA, kstep 3: 16 B/row).  Results of every search
+ * stay identical; kstep = 0 or 1 removes the accelerator.  Same idea as the reference's BiFMIndexKStep (fmindex/BiFMIndexKStep.h). */
+int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep);
+
 /* String_c batch evaluation (string/concepts.h:25-87): what[i] selects 0 = rank(idx,symb), 1 = prefix_rank(idx,symb),
  * 2 = symbol(idx); which = 0 -> bwt, 1 -> bwtRev */
 int fmgpu_string_query(fmgpu_index_t h, int which, const uint64_t* idx, const uint8_t* symb, const uint8_t* what,

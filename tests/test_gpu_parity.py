@@ -133,6 +133,33 @@ def test_exact_search_edge_cases():
     assert np.array_equal(dlb.to_array(np.uint64, len(queries)), olb)
 
 
+@pytest.mark.parametrize("layout,sigma,kstep", [("IB16", 5, 2), ("IB16", 5, 3), ("IB16A", 4, 2), ("EPRV2_16", 5, 3), ("WAVELET", 5, 2), ("IB16", 6, 3)])
+def test_exact_search_with_kstep_accelerator(layout, sigma, kstep):
+    """fmgpu_index_accelerate: same cursors (also for misses: lb/len of the step that emptied the interval) and same step counts"""
+    rng = np.random.default_rng(kstep + sigma)
+    base = rng.integers(1, sigma, size=1500, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[200:700]]), rng.integers(1, sigma, size=900, dtype=np.uint8), np.array([1, 1, 2], dtype=np.uint8)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 8, False)
+    gx = gpu_index(ox).accelerate(kstep)
+    queries = []
+    for i in range(900):
+        s = seqs[i % 2]; m = int(rng.integers(1, 80)); p = int(rng.integers(0, len(s) - m)); q = s[p: p + m].copy()
+        if i % 3 == 0:
+            q[int(rng.integers(0, m))] = rng.integers(1, sigma)
+        queries.append(q)
+    queries += [[], [1], [0], [1, 0, 1, 1], [sigma - 1] * 7, [1, 9, 1, 1, 1, 1]]
+    qbuf, qoff = fm.flatten(queries)
+    lb, ln, st = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+    valid = [i for i, q in enumerate(queries) if all(c < sigma for c in q)]
+    vb, vo = fm.flatten([queries[i] for i in valid])
+    olb, oln, ost = ox.search_exact(vb, vo, want_steps=True)
+    assert np.array_equal(lb[valid], olb) and np.array_equal(ln[valid], oln)
+    assert ln[-1] == 0
+    gx.accelerate(0)
+    lb2, ln2 = fm.search_no_errors.search(gx, (qbuf, qoff))
+    assert np.array_equal(lb2, lb) and np.array_equal(ln2, ln)
+
+
 def test_exact_search_tiny_indices():
     for seqs in ([[1]], [[]], [[1], [1], [2, 1]], [[3] * 70]):
         ox = fo.OraIndex.build("IB16", 5, seqs, 1, True)
