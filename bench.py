@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--nq", type=int, default=10_000_000)
     ap.add_argument("--read-len", type=int, default=101)
     ap.add_argument("--kstep", type=int, default=3, help="exact search: symbols per table step (fmgpu_index_accelerate); 1 = plain occurrence table")
+    ap.add_argument("--no-search-accel", action="store_true", help="k2: no prefix / walk tables (fmgpu_index_accelerate_search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -112,6 +113,8 @@ def main():
     index = cls.from_sequences((_Dev(text), _Dev(seq_off)), 5, "IB16", 16, keep_host=want_cpu)
     if not bidir and args.kstep > 1:
         index.accelerate(args.kstep)
+    if bidir and not args.no_search_accel:
+        index.accelerate_search(11, True)
     build_s = time.time() - t0
     if not want_cpu:
         del text

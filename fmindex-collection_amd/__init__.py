@@ -177,6 +177,14 @@ class FMIndex:
     def size(self):
         return self.n
 
+    def accelerate_search(self, prefix_len=11, walk=True):
+        """BiFMIndex: prefix table for the exact first part of a search + LF/LF^2/LF^3 walk tables; results are unchanged"""
+        capi.check(capi.lib().fmgpu_index_accelerate_search(self._h, prefix_len, 1 if walk else 0))
+        dbytes = C.c_uint64()
+        capi.check(capi.lib().fmgpu_index_info(self._h, None, None, None, None, C.byref(dbytes)))
+        self.device_bytes = dbytes.value
+        return self
+
     def accelerate(self, kstep=3):
         """add (kstep >= 2) or drop (0) the multi-symbol-step table used by exact search; results are unchanged"""
         capi.check(capi.lib().fmgpu_index_accelerate(self._h, kstep))

@@ -367,6 +367,8 @@ struct DevString {
     //   { u32 cnt = LF_k(64B, w); u32 bits_lo; u32 bits_hi; u32 0 }   (bit r: the kstep symbols preceding suffix 64B+r spell w;
     //   the first 12 bytes are fetched with one dwordx3 load, like a Format A entry)
     uint8_t* kblk = nullptr; uint32_t kstep = 0, kcodes = 0; size_t kblk_bytes = 0;
+    // walk table (fmgpu_index_accelerate_search): walk3[3*i .. 3*i+2] = LF(i), LF^2(i), LF^3(i)
+    idx_t* walk3 = nullptr;
 };
 
 // fills s.lf_table from the device string (all layouts); defined in fmgpu_index.hip
@@ -383,6 +385,8 @@ struct Index {
     void *sa_l0 = nullptr, *sa_l1 = nullptr, *sa_bits = nullptr, *sa_f0 = nullptr, *sa_f1 = nullptr;
     ViewSA vsa{};
     size_t device_bytes = 0;
+    // prefix table (fmgpu_index_accelerate_search): lut[code(w)] = { lb, lbRev, len, symbols consumed before the interval emptied (or L) }
+    uint4* lut = nullptr; uint32_t lut_len = 0; uint64_t lut_entries = 0;
 };
 
 void set_error(const std::string& msg);

@@ -142,7 +142,8 @@ void free_string(DevString& s) {
     if (s.aux) (void)hipFree(s.aux);
     if (s.lf_table) (void)hipFree(s.lf_table);
     if (s.kblk) (void)hipFree(s.kblk);
-    s.blk = s.aux = nullptr; s.lf_table = nullptr; s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0;
+    if (s.walk3) (void)hipFree(s.walk3);
+    s.blk = s.aux = nullptr; s.lf_table = nullptr; s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0; s.walk3 = nullptr;
 }
 
 template <class Occ>
@@ -317,6 +318,36 @@ __global__ __launch_bounds__(256) void k_kstep_counts(const uint32_t* __restrict
     *reinterpret_cast<uint32_t*>(kblk + (B * ncodes + c) * 16ull) = cnt[t] + base[c];
 }
 
+// ------------------------------------------------------------------ search accelerators (prefix table, walk table)
+__global__ __launch_bounds__(256) void k_walk3(const idx_t* __restrict__ lf, uint64_t n, idx_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    idx_t a = lf[i], b = lf[a], c = lf[b];
+    out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
+}
+// bidirectional interval of every string w of L symbols in [1, sigma): extendRight symbol by symbol (fmindex/BiFMIndexCursor.h:121-128)
+template <class Occ>
+__global__ __launch_bounds__(256) void k_prefix_lut(Occ rv, uint64_t entries, uint32_t L, uint32_t R, idx_t n, uint4* __restrict__ lut) {
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= entries) return;
+    idx_t lb = 0, lbRev = 0, len = n;
+    uint32_t used = 0;
+    uint64_t rest = w;
+    const uint32_t sigma = rv.sigma();
+    for (uint32_t t = 0; t < L && len != 0; ++t) {
+        uint32_t c = (uint32_t)(rest % R) + 1; rest /= R;
+        idx_t pre = 0, ra = 0, rb = 0;
+        for (uint32_t d = 0; d <= c && d < sigma; ++d) {
+            idx_t x, y;
+            rv.lf2(lbRev, lbRev + len, d, x, y);
+            if (d < c) pre += y - x; else { ra = x; rb = y; }
+        }
+        lb += pre; lbRev = ra; len = rb - ra;
+        ++used;
+    }
+    lut[w] = make_uint4(lb, lbRev, len, used);
+}
+
 }  // namespace fmgpu
 
 #include <hipcub/hipcub.hpp>
@@ -396,7 +427,7 @@ int fmgpu_index_destroy(fmgpu_index_t h) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return 0;
     free_string(x->bwt); free_string(x->rev);
-    for (void* p : {(void*)x->dC, x->sa_l0, x->sa_l1, x->sa_bits, x->sa_f0, x->sa_f1}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)x->dC, x->sa_l0, x->sa_l1, x->sa_bits, x->sa_f0, x->sa_f1, (void*)x->lut}) if (p) (void)hipFree(p);
     delete x;
     return 0;
 }
@@ -478,6 +509,48 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
     }
     if (rc == 0) x->device_bytes += s.kblk_bytes;
     return rc;
+}
+
+int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t walk) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (!x->bidirectional) return fail(FMGPU_ERR_INVALID, "search accelerators need a BiFMIndex");
+    if (prefix_len < 0 || prefix_len > 32) return fail(FMGPU_ERR_INVALID, "prefix_len must be in [0, 32]");
+    const uint64_t n = x->bwt.n;
+    // drop what exists
+    if (x->lut) { (void)hipFree(x->lut); x->device_bytes -= x->lut_entries * 16; x->lut = nullptr; x->lut_len = 0; x->lut_entries = 0; }
+    for (DevString* s : {&x->bwt, &x->rev}) if (s->walk3) { (void)hipFree(s->walk3); s->walk3 = nullptr; x->device_bytes -= n * 12; }
+    if (n == 0) return 0;
+    if (walk) {
+        for (DevString* s : {&x->bwt, &x->rev}) {
+            if (!s->lf_table) return fail(FMGPU_ERR_INVALID, "walk tables need the LF tables (FMGPU_LF_TABLE=0 was set)");
+            FM_HIP(hipMalloc((void**)&s->walk3, n * 12 + 16));
+            k_walk3<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s->lf_table, n, s->walk3);
+            x->device_bytes += n * 12;
+        }
+        FM_HIP(hipDeviceSynchronize());
+    }
+    if (prefix_len > 0) {
+        const uint32_t R = (uint32_t)x->bwt.sigma - 1;
+        uint64_t entries = 1;
+        for (int t = 0; t < prefix_len; ++t) { entries *= R; if (entries > (1ull << 26)) return fail(FMGPU_ERR_UNSUPPORTED, "prefix table would exceed 2^26 entries"); }
+        FM_HIP(hipMalloc((void**)&x->lut, entries * 16));
+        dim3 grid((unsigned)((entries + 255) / 256)), block(256);
+        const DevString& r = x->rev;
+        switch (r.family) {
+        case FAM_A:
+            if (r.sigma == 5) k_prefix_lut<OccA<5>><<<grid, block>>>(OccA<5>{r.va}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut);
+            else k_prefix_lut<OccA<0>><<<grid, block>>>(OccA<0>{r.va}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut);
+            break;
+        case FAM_EPR:   k_prefix_lut<OccR<false>><<<grid, block>>>(OccR<false>{r.vr}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut); break;
+        case FAM_EPRV2: k_prefix_lut<OccR<true>><<<grid, block>>>(OccR<true>{r.vr}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut); break;
+        default:        k_prefix_lut<OccW><<<grid, block>>>(OccW{r.vw}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut); break;
+        }
+        FM_HIP(hipDeviceSynchronize());
+        x->lut_len = (uint32_t)prefix_len; x->lut_entries = entries;
+        x->device_bytes += entries * 16;
+    }
+    return 0;
 }
 
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes) {

@@ -488,7 +488,9 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
 // ONE 4-byte load; the symbol is recovered from C.  Multi-row cursors use the 64-byte blocks as before.
 struct FastArgs {
     const idx_t* lf_fw; const idx_t* lf_rv;     // LF tables of bwt / bwtRev
-    const uint32_t* steps;                      // [S][m + 1]: pos:16 | right:1 | lastOfPart:1 | minE:6 | maxE:8; entry m = final window
+    const idx_t* w3_fw; const idx_t* w3_rv;     // LF, LF^2, LF^3 per row (fmgpu_index_accelerate_search), or null
+    const uint4* lut; uint32_t lutL, lut_ok;    // prefix table, its string length, bit s: search s may start from it
+    const uint32_t* steps;                      // [S][m + 1]: pos:16 | right:1 | lastOfPart:1 | minE:5 | maxE:7 | run:2; entry m = final window
     uint32_t S, m;
     idx_t C1[8];                                // C[1..] for sigma <= 8 (symbol of an LF value), unused otherwise
 };
@@ -622,8 +624,12 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                                                                           uint32_t qwords, uint32_t qnib, int dev_flags) {
     // Wave-synchronous rounds.  A wave pays for every slow path any of its 64 lanes takes, so nothing with a dependent
     // memory round trip is lane-private: the 64 lanes fetch and stage their next queries TOGETHER (one atomicAdd per wave,
-    // query words issued back to back), walk the searches in a flat loop that performs exactly one memory phase per
-    // iteration, keep their hits in LDS, and flush them together (one atomicAdd per wave).
+    // query words issued back to back), start every search of the scheme TOGETHER (so the few wide-interval steps at a
+    // search's start coincide; a round lasts as long as its slowest lane anyway), keep their hits in LDS and flush them
+    // together (one atomicAdd per wave).  Inside a search the loop performs one memory phase per iteration:
+    //   multi-row cursor : the 64-byte blocks at both ends (extend-all);
+    //   single-row cursor: ONE load of LF, LF^2, LF^3 and up to three steps from it (or one LF-table load and one step);
+    //   search start     : the prefix table entry of the first L symbols of the always-exact first part.
     extern __shared__ uint32_t s_dyn[];
     uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
 
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t sigma = fw.sigma();
+    const uint32_t sigma = fw.sigma(), R = sigma - 1;
     uint32_t nodes = 0;
     for (;;) {
         // ---- round start: 64 consecutive queries for this wave
@@ -643,83 +649,128 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
         base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
         if (base >= nq) break;
         const uint64_t q = base + lane;
-        const bool active = q < nq;
-        const uint64_t qo = active ? qoff[q] : 0;
+        const bool active = q < nq && n != 0;
+        const uint64_t qo = q < nq ? qoff[q] : 0;
         const uint8_t* qs = qbuf + qo;
-        qstage_load_sync(qst, qbuf, qo, m, sigma, active, m);
+        qstage_load_sync(qst, qbuf, qo, m, sigma, q < nq, m);
 
         uint64_t quota = max_hits; uint32_t seq = 0, nh = 0;
-        uint32_t si = 0, e = 0, j = 0, sp = 0, resume = kNoResume;
-        bool in_tail = false, done = !active || n == 0;
-        Cur cur{0, 0, n};                                           // run(): SearchNg26.h:62-79
-        const uint32_t* tab = s_steps;
-        while (__ballot(!done) != 0ull) {
-            if (!done) {
+        bool query_over = !active;
+        for (uint32_t si = 0; si < S; ++si) {                       // search_impl (SearchNg26.h:385-390), all lanes in step
+            const uint32_t* tab = s_steps + si * stride;
+            bool done = query_over;
+            Cur cur{0, 0, n};                                       // run(): SearchNg26.h:62-79
+            uint32_t e = 0, j = 0, sp = 0, resume = kNoResume;
+            bool in_tail = false;
+            if (fa.lut && ((fa.lut_ok >> si) & 1u) && n > 1) {      // the exact first part starts from the prefix table
+                uint32_t code = 0, mul = 1; bool valid = !done;
+                for (uint32_t t = 0; t < fa.lutL; ++t) {
+                    uint32_t c = qstage_get(qst, qs, tab[t] & 0xffffu);
+                    valid = valid && c >= 1 && c < sigma;
+                    code += (c - 1) * mul; mul *= R;
+                }
+                if (valid) {
+                    const uint4 en = fa.lut[code];
+                    cur = Cur{en.x, en.y, en.z};
+                    nodes += en.w;                                  // the extensions the reference performs before the interval is empty (:225-250)
+                    j = fa.lutL; in_tail = true;
+                    if (en.z == 0) done = true;
+                }
+            }
+            while (__ballot(!done) != 0ull) {
+                if (done) continue;
                 const uint32_t ent = tab[j];
-                const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x3fu, maxE = ent >> 24;
-                const bool right = (ent >> 16) & 1u, lastp = (ent >> 17) & 1u;
+                const bool right = (ent >> 16) & 1u;
                 const bool multi = cur.len > 1;
                 const idx_t a = right ? cur.lbRev : cur.lb;
-                idx_t lfa[MAXSIG], lfb[MAXSIG];
-                idx_t t = 0;
-                SymSet<MAXSIG> alive; alive.clear();
-                if (multi) {                                       // extend-all on the blocks (fmindex/BiFMIndexCursor.h:58-82)
+                bool back = false;
+                if (multi) {
+                    // ---- extend-all node (search_next_dir, :143-224) or exact-tail step over several rows
+                    const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x7fu;
+                    const bool lastp = (ent >> 17) & 1u;
+                    idx_t lfa[MAXSIG], lfb[MAXSIG];
                     const OccA<SIGMA>& occ = right ? rv : fw;
                     occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
-                    alive = alive_set<MAXSIG>(lfa, lfb, sigma);
-                } else {                                           // symbolLeft/Right + extend by that symbol (:267-277): one LF-table load
-                    t = (right ? fa.lf_rv : fa.lf_fw)[a];
-                    const uint32_t b1 = symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, t);
-                    if (b1 >= 1) { if (MAXSIG <= 32) alive.w[0] = 1u << b1; else alive.w[b1 >> 5] = 1u << (b1 & 31u); }   // :295-297: a delimiter row ends the walk
-                }
-                const uint32_t c = qstage_get(qst, qs, pos);
-                const bool c_alive = alive.test(c);
-                const bool resuming = resume != kNoResume;
-                const bool mOK = minE <= e && e <= maxE;
-                const bool sOK = minE <= e + 1 && e + 1 <= maxE;
-                const bool xOK = e + 1 <= maxE;
-                SymSet<MAXSIG> subs = alive;                       // substitution children: FirstSymb = 1 (fmindex/BiFMIndex.h:26), != query symbol
-                subs.remove(0); subs.remove(c);
-                if (!sOK) subs.clear();
-                if (resuming) subs.clear_below(resume);
-                const bool take_match = !resuming && mOK && c_alive;   // match child first (:171-181); in a single row it is the only candidate
-                const bool take_sub = !take_match && subs.any();
-                const bool ok = take_match || take_sub;
-                uint32_t take = c;
-                if (take_sub) { take = subs.first(); subs.remove(take); }
-                // node accounting as the reference works (see k_scheme)
-                nodes += multi ? ((!resuming && (in_tail || xOK || mOK)) ? 1u : 0u) : (1u + ((!in_tail && take_match && !xOK) ? 1u : 0u));
-                if (ok && multi && subs.any()) {                   // (re-)push the parent: remaining siblings start at subs.first()
-                    uint64_t o = (uint64_t)sp * stk.nlanes + gid;
-                    stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
-                    stk.p1[o] = (uint64_t)cur.len | ((uint64_t)(j & 0xffffu) << 32) | ((uint64_t)(e & 0xffu) << 48) | ((uint64_t)(subs.first() & 0xffu) << 56);
-                    ++sp;
-                }
-                resume = kNoResume;
-                bool back = !ok, search_over = false;
-                if (ok) {
-                    if (multi) cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
-                    else { if (right) cur.lbRev = t; else cur.lb = t; }   // single row: the other side's prefix count is 0
-                    if (take_sub) e += 1;
-                    in_tail = !lastp && (in_tail || (take_match && !xOK));
-                    ++j;
-                    if (j == m) {                                  // search_next at part == P (:101-108)
-                        const uint32_t fin = tab[m];
-                        if (((fin >> 18) & 0x3fu) <= e && e <= (fin >> 24)) {
-                            Cur r = cur;
-                            if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
-                            quota -= r.len;
-                            if (!(dev_flags & 1)) {
-                                if (nh < kHitBuf) {                // buffered; written out at the end of the round
-                                    uint32_t* h = s_hits + (size_t)nh * 5u * 256u + threadIdx.x;
-                                    h[0] = r.lb; h[256] = r.lbRev; h[512] = r.len; h[768] = e; h[1024] = seq;
-                                } else emit_hit(out, cap, ctr, q, r, e, seq);
-                            }
-                            ++nh; ++seq;
-                            if (quota == 0) { search_over = true; si = S; }   // delegate returned true: no further searches (:372-383)
-                        }
-                        back = !search_over;
+                    const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+                    const uint32_t c = qstage_get(qst, qs, pos);
+                    const bool c_alive = alive.test(c);
+                    const bool resuming = resume != kNoResume;
+                    const bool mOK = minE <= e && e <= maxE;
+                    const bool sOK = minE <= e + 1 && e + 1 <= maxE;
+                    const bool xOK = e + 1 <= maxE;
+                    SymSet<MAXSIG> subs = alive;                   // substitution children: FirstSymb = 1 (fmindex/BiFMIndex.h:26), != query symbol
+                    subs.remove(0); subs.remove(c);
+                    if (!sOK) subs.clear();
+                    if (resuming) subs.clear_below(resume);
+                    const bool take_match = !resuming && mOK && c_alive;   // match child first (:171-181)
+                    const bool take_sub = !take_match && subs.any();
+                    uint32_t take = c;
+                    if (take_sub) { take = subs.first(); subs.remove(take); }
+                    nodes += (!resuming && (in_tail || xOK || mOK)) ? 1u : 0u;   // node accounting as the reference works (see k_scheme)
+                    if ((take_match || take_sub) && subs.any()) {  // (re-)push the parent: remaining siblings start at subs.first()
+                        uint64_t o = (uint64_t)sp * stk.nlanes + gid;
+                        stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
+                        stk.p1[o] = (uint64_t)cur.len | ((uint64_t)(j & 0xffffu) << 32) | ((uint64_t)(e & 0xffu) << 48) | ((uint64_t)(subs.first() & 0xffu) << 56);
+                        ++sp;
                     }
+                    resume = kNoResume;
+                    if (take_match || take_sub) {
+                        cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+                        if (take_sub) e += 1;
+                        in_tail = !lastp && (in_tail || (take_match && !xOK));
+                        ++j;
+                    } else back = true;
+                } else {
+                    // ---- single row (search_next_dir_single, :251-365): the only child is the BWT symbol of the row; up to `run` steps per load
+                    const idx_t* w3 = right ? fa.w3_rv : fa.w3_fw;
+                    const uint32_t run = w3 ? (ent >> 30) : 1u;    // consecutive steps in this direction (<= 3), never past the query end
+                    idx_t t0, t1 = 0, t2 = 0;
+                    if (w3) { const idx_t* p = w3 + 3u * (size_t)a; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
+                    else t0 = (right ? fa.lf_rv : fa.lf_fw)[a];
+                    idx_t tk = t0, last = t0;
+                    uint32_t k = 0;
+                    bool dead = false;
+#pragma unroll
+                    for (uint32_t kk = 0; kk < 3; ++kk) {
+                        if (kk < run && !dead) {
+                            const uint32_t en = kk == 0 ? ent : tab[j + kk];
+                            const uint32_t pos = en & 0xffffu, minE = (en >> 18) & 0x1fu, maxE = (en >> 23) & 0x7fu;
+                            const bool lastp = (en >> 17) & 1u;
+                            tk = kk == 0 ? t0 : (kk == 1 ? t1 : t2);
+                            const uint32_t b = symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, tk);
+                            const uint32_t c = qstage_get(qst, qs, pos);
+                            const bool mOK = minE <= e && e <= maxE;
+                            const bool sOK = minE <= e + 1 && e + 1 <= maxE;
+                            const bool xOK = e + 1 <= maxE;
+                            const bool is_match = b >= 1 && b == c && mOK;
+                            nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
+                            if (b < 1) dead = true;                 // :295-297: a delimiter row ends the walk
+                            else if (b == c) { if (!mOK) dead = true; }
+                            else if (sOK) e += 1;
+                            else dead = true;
+                            if (!dead) { in_tail = !lastp && (in_tail || (is_match && !xOK)); last = tk; ++k; }
+                        }
+                    }
+                    if (dead) back = true;
+                    else { if (right) cur.lbRev = last; else cur.lb = last; j += k; }   // one row: the other side's prefix count is 0
+                }
+                bool search_over = false;
+                if (!back && j == m) {                              // search_next at part == P (:101-108)
+                    const uint32_t fin = tab[m];
+                    if (((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x7fu)) {
+                        Cur r = cur;
+                        if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
+                        quota -= r.len;
+                        if (!(dev_flags & 1)) {
+                            if (nh < kHitBuf) {                    // buffered; written out at the end of the round
+                                uint32_t* h = s_hits + (size_t)nh * 5u * 256u + threadIdx.x;
+                                h[0] = r.lb; h[256] = r.lbRev; h[512] = r.len; h[768] = e; h[1024] = seq;
+                            } else emit_hit(out, cap, ctr, q, r, e, seq);
+                        }
+                        ++nh; ++seq;
+                        if (quota == 0) { search_over = true; query_over = true; }   // delegate returned true: no further searches (:372-383)
+                    }
+                    back = !search_over;
                 }
                 if (back) {
                     if (sp == 0) search_over = true;
@@ -732,11 +783,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                         in_tail = false;
                     }
                 }
-                if (search_over) {                                 // search_impl: next search of the scheme (:385-390) or the query is finished
-                    ++si;
-                    if (si >= S) done = true;
-                    else { tab = s_steps + si * stride; cur = Cur{0, 0, n}; e = 0; j = 0; sp = 0; resume = kNoResume; in_tail = false; }
-                }
+                if (search_over) done = true;
             }
         }
         // ---- round end: flush the buffered hits of the wave with one reservation
@@ -923,9 +970,11 @@ static int query_len_range(const uint64_t* dqoff, uint64_t nq, hipStream_t strea
     return 0;
 }
 
-// expands a scheme for queries of length m into the fast kernel's per-step table (see k_scheme_fast); false if it does not fit
-static bool build_step_table(const SchemeDev& sd, uint32_t m, std::vector<uint32_t>& tab) {
+// expands a scheme for queries of length m into the fast kernel's per-step table (see k_scheme_fast); false if it does not fit.
+// lut_ok: bit s set if search s may start from a prefix table of lutL symbols (first part longer than lutL and error free)
+static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, std::vector<uint32_t>& tab, uint32_t& lut_ok) {
     const uint32_t S = (uint32_t)sd.S, P = (uint32_t)sd.P;
+    lut_ok = 0;
     if (m < P || m > 0xfffeu || (uint64_t)S * (m + 1) > 4096) return false;
     std::vector<uint32_t> plen(P);
     uint32_t sum = 0;
@@ -934,21 +983,27 @@ static bool build_step_table(const SchemeDev& sd, uint32_t m, std::vector<uint32
     tab.assign((size_t)S * (m + 1), 0);
     for (uint32_t s = 0; s < S; ++s) {
         const uint8_t* pi = sd.pi + s * kMaxParts; const uint8_t* L = sd.l + s * kMaxParts; const uint8_t* U = sd.u + s * kMaxParts;
+        uint32_t* T = tab.data() + (size_t)s * (m + 1);
         uint32_t start = 0;
         for (uint32_t i = 0; i < pi[0]; ++i) start += plen[i];
         uint32_t qR = start, qL = start - 1, j = 0;              // SearchNg26.h:62-79
         for (uint32_t p = 0; p < P; ++p) {
-            if (L[p] > U[p] || L[p] > 63) return false;          // the table form relies on l <= u (search_scheme/isValid.h:87-91)
+            if (L[p] > U[p] || L[p] > 31 || U[p] > 127) return false;   // the table form relies on l <= u (search_scheme/isValid.h:87-91)
             const bool right = p == 0 || pi[p - 1] < pi[p];      // :111
             const uint32_t len = plen[pi[p]];
             for (uint32_t k = 0; k < len; ++k, ++j) {
                 const uint32_t pos = right ? qR++ : qL--;
                 const bool last = k + 1 == len;
-                tab[(size_t)s * (m + 1) + j] = (pos & 0xffffu) | ((right ? 1u : 0u) << 16) | ((last ? 1u : 0u) << 17) |
-                                               ((last ? (uint32_t)L[p] : 0u) << 18) | ((uint32_t)U[p] << 24);
+                T[j] = (pos & 0xffffu) | ((right ? 1u : 0u) << 16) | ((last ? 1u : 0u) << 17) | ((last ? (uint32_t)L[p] : 0u) << 18) | ((uint32_t)U[p] << 23);
             }
         }
-        tab[(size_t)s * (m + 1) + m] = ((uint32_t)L[P - 1] << 18) | ((uint32_t)U[P - 1] << 24);
+        T[m] = ((uint32_t)L[P - 1] << 18) | ((uint32_t)U[P - 1] << 23);
+        for (uint32_t k = 0; k < m; ++k) {                       // run: steps from k on with the same direction, capped at 3 and at the query end
+            uint32_t run = 1;
+            while (run < 3 && k + run < m && ((T[k + run] >> 16) & 1u) == ((T[k] >> 16) & 1u)) ++run;
+            T[k] |= run << 30;
+        }
+        if (lutL && plen[pi[0]] > lutL && U[0] == 0) lut_ok |= 1u << s;
     }
     return true;
 }
@@ -1133,8 +1188,9 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     dim3 grid(ws.grid), block(256);
     // fast path: equal-length batch on a Format-A BiFMIndex with LF tables
     std::vector<uint32_t> step_tab;
+    uint32_t lut_ok = 0;
     const bool fast = scheme_mode && x->bwt.family == FAM_A && x->bwt.lf_table && x->rev.lf_table && minlen == maxlen &&
-                      x->bwt.sigma <= 32 && !(sd.dev_flags & 2) && build_step_table(sd, maxlen, step_tab);
+                      x->bwt.sigma <= 32 && !(sd.dev_flags & 2) && build_step_table(sd, maxlen, (sd.dev_flags & 4) ? 0 : x->lut_len, step_tab, lut_ok);
     uint32_t* d_steps = nullptr;
     if (fast) {
         FM_HIP(hipMalloc((void**)&d_steps, step_tab.size() * 4));
@@ -1144,6 +1200,8 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (fast) {
         FastArgs fa{};
         fa.lf_fw = x->bwt.lf_table; fa.lf_rv = x->rev.lf_table; fa.steps = d_steps; fa.S = (uint32_t)sd.S; fa.m = maxlen;
+        if (!(sd.dev_flags & 8)) { fa.w3_fw = x->bwt.walk3; fa.w3_rv = x->rev.walk3; }
+        fa.lut = lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = lut_ok;
         for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
         const size_t lds_fast = lds_bytes + step_tab.size() * 4 + (size_t)kHitBuf * 5 * 256 * 4;
         FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));       // the fast kernel hands out 64-query rounds from 0

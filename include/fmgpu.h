@@ -134,6 +134,12 @@ int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layo
  * stay identical; kstep = 0 or 1 removes the accelerator.  Same idea as the reference's BiFMIndexKStep (fmindex/BiFMIndexKStep.h). */
 int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep);
 
+/* Optional accelerators for fmgpu_search_scheme on a BiFMIndex (results unchanged):
+ *   prefix_len > 0: table of the bidirectional SA interval of every string of `prefix_len` symbols ((sigma-1)^prefix_len entries of 16 bytes; DNA,
+ *                   11 symbols: 67 MB) — the always-exact first part of a search (u[0] = 0, search_scheme/generator/h2.h) starts from its entry;
+ *   walk != 0:      per row and direction LF, LF^2, LF^3 (12 bytes): a cursor of one row advances up to three symbols per load. */
+int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t walk);
+
 /* String_c batch evaluation (string/concepts.h:25-87): what[i] selects 0 = rank(idx,symb), 1 = prefix_rank(idx,symb),
  * 2 = symbol(idx); which = 0 -> bwt, 1 -> bwtRev */
 int fmgpu_string_query(fmgpu_index_t h, int which, const uint64_t* idx, const uint8_t* symb, const uint8_t* what,

@@ -212,10 +212,15 @@ def test_scheme_search_equal_length_fast_path(k, length):
     queries = mutated_queries(seqs, 1500, length, length + 1, k + 1, seed=11 + k)
     assert len({len(q) for q in queries}) == 1
     qbuf, qoff = fm.flatten(queries)
-    for sch in (fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k)):
-        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True)
-        ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch)
-        assert same_hits(hits, ohits) and st.lf_steps == nodes
+    for accel in (None, (0, True), (3, False), (4, True), (2, True)):     # plain, walk tables only, prefix table only, both
+        if accel is not None:
+            gx.accelerate_search(*accel)
+        for sch in (fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k), fm.search_scheme.backtracking(2, 0, k)):
+            hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True)
+            ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch)
+            assert same_hits(hits, ohits) and st.lf_steps == nodes, (accel, k, length)
+        hits = fm.search_ng26.search(gx, (qbuf, qoff), fm.search_scheme.h2(k + 2, 0, k), n=2)
+        assert same_hits(hits, ox.search_ng26(qbuf, qoff, fm.search_scheme.h2(k + 2, 0, k), max_hits=2)[0])
     os.environ["FMGPU_DEV_FLAGS"] = "2"                       # force the generic kernel: both kernels agree
     try:
         hits2 = fm.search_ng26.search(gx, (qbuf, qoff), fm.search_scheme.h2(k + 2, 0, k))
