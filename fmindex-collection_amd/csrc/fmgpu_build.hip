@@ -309,6 +309,140 @@ static int make_format_a(const uint8_t* bwt, uint64_t n, uint32_t sigma, const i
     return 0;
 }
 
+// ------------------------------------------------------------------ Format W from the BWT (string/Wavelet.h:40-72 restated as bulk passes)
+// Level b of the reference's tree sees the symbols stably ordered by their top b bits (each push_back appends to the node of the
+// symbol's prefix, Wavelet.h:56-65): one stable radix sort on those bits yields every node of the level as a contiguous slice.
+__global__ __launch_bounds__(256) void k_prefix_hist(const uint8_t* __restrict__ sym, uint64_t n, uint32_t shift, unsigned int* __restrict__ hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) atomicAdd(&h[sym[i] >> shift], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// one thread per 64-bit payload word; the six words of a line are handled by six neighbouring threads
+__global__ __launch_bounds__(256) void k_wavelet_words(const uint8_t* __restrict__ sorted, uint32_t bit, const uint32_t* __restrict__ node_base,
+                                                       const uint32_t* __restrict__ node_start, const uint32_t* __restrict__ node_len, uint32_t first_node, uint32_t nnodes_level,
+                                                       uint64_t first_line, uint64_t nlines, uint64_t* __restrict__ lines, uint32_t* __restrict__ line_ones) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlines * 6) return;
+    uint64_t L = first_line + t / 6; uint32_t j = (uint32_t)(t % 6);
+    uint32_t lo = 0, hi = nnodes_level;                 // last node of the level with node_base <= L
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (node_base[first_node + mid] <= L) lo = mid; else hi = mid; }
+    uint32_t id = first_node + lo;
+    uint64_t p0 = (L - node_base[id]) * 384 + (uint64_t)j * 64, len = node_len[id];
+    uint64_t w = 0;
+    if (p0 < len) {
+        uint32_t cnt = (uint32_t)(len - p0 < 64 ? len - p0 : 64);
+        const uint8_t* src = sorted + node_start[id] + p0;
+        for (uint32_t k = 0; k < cnt; ++k) w |= (uint64_t)((src[k] >> bit) & 1u) << k;
+    }
+    lines[L * 8 + 2 + j] = w;
+    atomicAdd(&line_ones[L - first_line], (uint32_t)__popcll(w));
+}
+
+__global__ __launch_bounds__(256) void k_wavelet_headers(const uint32_t* __restrict__ scan, const uint32_t* __restrict__ node_base, uint32_t first_node, uint32_t nnodes_level,
+                                                         uint64_t first_line, uint64_t nlines, uint64_t* __restrict__ lines) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlines) return;
+    uint64_t L = first_line + t;
+    uint32_t lo = 0, hi = nnodes_level;
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (node_base[first_node + mid] <= L) lo = mid; else hi = mid; }
+    uint32_t id = first_node + lo;
+    uint64_t* Lp = lines + L * 8;
+    Lp[0] = scan[t] - scan[node_base[id] - first_line];
+    uint64_t cum = 0, h1 = 0;
+    for (uint32_t j = 0; j < 6; ++j) {
+        if (j) h1 |= cum << (9 * (j - 1));
+        cum += (uint64_t)__popcll(Lp[2 + j]);
+    }
+    Lp[1] = h1;
+}
+
+static int make_format_w(const uint8_t* bwt, uint64_t n, uint32_t sigma, const idx_t* dC, DevString& s, int layout, hipStream_t stream) {
+    const uint32_t bits = bit_width64((uint64_t)sigma - 1) ? bit_width64((uint64_t)sigma - 1) : 1;    // Wavelet.h:26  bitct = bit_width(Sigma-1)
+    const uint32_t nnodes = 1u << bits;                                                                  // Wavelet.h:27  bvct  = bit_ceil(Sigma); the last id stays empty
+    s.layout = layout; s.sigma = (int)sigma; s.n = n; s.family = FAM_WAVELET; s.bitct = (int)bits;
+    std::vector<uint32_t> base(nnodes, 0), start(nnodes, 0), len(nnodes, 0);
+    DBuf hist, sorted; Temp tmp; int rc;
+    if ((rc = hist.alloc(256 * 4)) || (rc = sorted.alloc(n + 64))) return rc;
+    // pass 1: node lengths per level -> line offsets
+    uint64_t total_lines = 0;
+    for (uint32_t b = 0; b < bits; ++b) {
+        unsigned int hh[256];
+        FM_HIP(hipMemsetAsync(hist.p, 0, 256 * 4, stream));
+        k_prefix_hist<<<dim3(2048), 256, 0, stream>>>(bwt, n, bits - b, hist.as<unsigned int>());
+        FM_HIP(hipMemcpy(hh, hist.p, 256 * 4, hipMemcpyDeviceToHost));
+        uint64_t acc = 0;
+        for (uint32_t pfx = 0; pfx < (1u << b); ++pfx) {
+            uint32_t id = ((1u << b) - 1u) + pfx;
+            start[id] = (uint32_t)acc; len[id] = hh[pfx]; acc += hh[pfx];
+            base[id] = (uint32_t)total_lines;
+            total_lines += (uint64_t)hh[pfx] / 384 + 1;
+        }
+    }
+    base[nnodes - 1] = (uint32_t)total_lines; total_lines += 1;     // the unused last id: one empty line
+    if (total_lines >= 0xffffffffull) return fail(FMGPU_ERR_UNSUPPORTED, "wavelet too large for 32-bit line offsets");
+    s.blk_bytes = total_lines * 64; s.aux_bytes = nnodes * 4;
+    FM_HIP(hipMalloc(&s.blk, s.blk_bytes));
+    FM_HIP(hipMemsetAsync(s.blk, 0, s.blk_bytes, stream));
+    FM_HIP(hipMalloc(&s.aux, s.aux_bytes));
+    FM_HIP(hipMemcpy(s.aux, base.data(), nnodes * 4, hipMemcpyHostToDevice));
+    DBuf dstart, dlen, ones;
+    uint64_t max_level_lines = n / 384 + nnodes + 1;
+    if ((rc = dstart.alloc(nnodes * 4)) || (rc = dlen.alloc(nnodes * 4)) || (rc = ones.alloc((max_level_lines + 1) * 4))) return rc;
+    FM_HIP(hipMemcpy(dstart.p, start.data(), nnodes * 4, hipMemcpyHostToDevice));
+    FM_HIP(hipMemcpy(dlen.p, len.data(), nnodes * 4, hipMemcpyHostToDevice));
+    // pass 2: per level, sort by the top b bits, cut the slices into lines
+    for (uint32_t b = 0; b < bits; ++b) {
+        const uint8_t* src = bwt;
+        if (b > 0) {
+            rc = cub_call(tmp, [&](void* t, size_t& bytes) { return hipcub::DeviceRadixSort::SortKeys(t, bytes, bwt, sorted.as<uint8_t>(), (size_t)n, (int)(bits - b), (int)bits, stream); });
+            if (rc) return rc;
+            src = sorted.as<uint8_t>();
+        }
+        uint32_t first_node = (1u << b) - 1u, nl = 1u << b;
+        uint64_t first_line = base[first_node];
+        uint64_t last = first_node + nl - 1;
+        uint64_t nlines = (uint64_t)base[last] + len[last] / 384 + 1 - first_line;
+        FM_HIP(hipMemsetAsync(ones.p, 0, (nlines + 1) * 4, stream));
+        k_wavelet_words<<<grid_for(nlines * 6), 256, 0, stream>>>(src, bits - 1 - b, (const uint32_t*)s.aux, dstart.as<uint32_t>(), dlen.as<uint32_t>(), first_node, nl,
+                                                                   first_line, nlines, (uint64_t*)s.blk, ones.as<uint32_t>());
+        rc = cub_call(tmp, [&](void* t, size_t& bytes) { return hipcub::DeviceScan::ExclusiveSum(t, bytes, ones.as<uint32_t>(), ones.as<uint32_t>(), (size_t)(nlines + 1), stream); });
+        if (rc) return rc;
+        k_wavelet_headers<<<grid_for(nlines), 256, 0, stream>>>(ones.as<uint32_t>(), (const uint32_t*)s.aux, first_node, nl, first_line, nlines, (uint64_t*)s.blk);
+    }
+    FM_HIP(hipStreamSynchronize(stream));
+    s.vw = ViewW{(const uint64_t*)s.blk, (const uint32_t*)s.aux, dC, sigma, bits};
+    return 0;
+}
+
+template <class Occ>
+__global__ __launch_bounds__(256) void k_symbols(Occ occ, uint64_t n, uint8_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint8_t)occ.symbol((idx_t)i);
+}
+
+int build_format_a_shadow(DevString& s, const idx_t* dC, hipStream_t stream) {
+    if (s.family == FAM_A || s.shadow || s.n == 0) return 0;
+    DBuf sym; int rc;
+    if ((rc = sym.alloc(s.n + 64))) return rc;
+    switch (s.family) {
+    case FAM_EPR:   k_symbols<<<grid_for(s.n), 256, 0, stream>>>(OccR<false>{s.vr}, s.n, sym.as<uint8_t>()); break;
+    case FAM_EPRV2: k_symbols<<<grid_for(s.n), 256, 0, stream>>>(OccR<true>{s.vr}, s.n, sym.as<uint8_t>()); break;
+    default:        k_symbols<<<grid_for(s.n), 256, 0, stream>>>(OccW{s.vw}, s.n, sym.as<uint8_t>()); break;
+    }
+    DevString t;
+    if ((rc = make_format_a(sym.as<uint8_t>(), s.n, (uint32_t)s.sigma, dC, t, s.layout, stream))) { if (t.blk) (void)hipFree(t.blk); return rc; }
+    s.shadow = t.blk; s.shadow_bytes = t.blk_bytes; s.va = t.va;
+    return 0;
+}
+
+static int make_string(const uint8_t* bwt, uint64_t n, uint32_t sigma, const idx_t* dC, DevString& s, int layout, hipStream_t stream) {
+    return layout == FMGPU_WAVELET ? make_format_w(bwt, n, sigma, dC, s, layout, stream) : make_format_a(bwt, n, sigma, dC, s, layout, stream);
+}
+
 }  // namespace fmgpu
 
 using namespace fmgpu;
@@ -335,8 +469,8 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
     if (!seqs || !seq_off || nseq == 0) return fail(FMGPU_ERR_INVALID, "seqs / seq_off is null or nseq == 0");
     if (sigma < 2 || sigma > 256) return fail(FMGPU_ERR_INVALID, "sigma must be in [2, 256]");
     if (sampling_rate == 0) return fail(FMGPU_ERR_INVALID, "sampling_rate must be >= 1");
-    if (!(layout == FMGPU_IB8 || layout == FMGPU_IB16 || layout == FMGPU_IB32 || layout == FMGPU_IB16A || layout == FMGPU_IBP16))
-        return fail(FMGPU_ERR_UNSUPPORTED, "the GPU builder lays out InterleavedBitvector* indices; build other layouts from the returned BWT (keep_host)");
+    if (!(layout == FMGPU_IB8 || layout == FMGPU_IB16 || layout == FMGPU_IB32 || layout == FMGPU_IB16A || layout == FMGPU_IBP16 || layout == FMGPU_WAVELET))
+        return fail(FMGPU_ERR_UNSUPPORTED, "the GPU builder lays out InterleavedBitvector* and Wavelet indices; build other layouts from the returned BWT (keep_host)");
     hipStream_t stream = nullptr;
     Staged soff, sseq;
     int rc;
@@ -386,7 +520,7 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
         e2 = hipMemcpy(x->dC, c32.data(), (sigma + 1) * sizeof(idx_t), hipMemcpyHostToDevice);
         if (e2 != hipSuccess) return bail(hip_fail(e2, "hipMemcpy(C)"));
     }
-    if ((rc = make_format_a(bwt.as<uint8_t>(), n, (uint32_t)sigma, x->dC, x->bwt, layout, stream))) return bail(rc);
+    if ((rc = make_string(bwt.as<uint8_t>(), n, (uint32_t)sigma, x->dC, x->bwt, layout, stream))) return bail(rc);
     if (built) {
         built->part[0].resize(n);
         hipError_t e = hipMemcpy(built->part[0].data(), bwt.p, n, hipMemcpyDeviceToHost);
@@ -454,7 +588,7 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
         FM_HIP(hipMemcpyAsync(text.p, bwt.p, n, hipMemcpyDeviceToDevice, stream));
         if ((rc = build_suffix_array(text.as<uint8_t>(), n, (uint32_t)sigma, sa.as<uint32_t>(), stream))) return bail(rc);
         k_bwt<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), sa.as<uint32_t>(), n, bwt.as<uint8_t>());
-        if ((rc = make_format_a(bwt.as<uint8_t>(), n, (uint32_t)sigma, x->dC, x->rev, layout, stream))) return bail(rc);
+        if ((rc = make_string(bwt.as<uint8_t>(), n, (uint32_t)sigma, x->dC, x->rev, layout, stream))) return bail(rc);
         x->bidirectional = true;
         if (built) {
             built->part[1].resize(n);

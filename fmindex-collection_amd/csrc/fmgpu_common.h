@@ -16,10 +16,11 @@
 //
 //  Format R  (reference layout as is — InterleavedEPR*, InterleavedEPRV2*): blocks + superBlocks copied verbatim.
 //
-//  Format W  (wavelet, built from Wavelet::bitvector[*] by the host at upload): every node is an array of 64-byte
-//     lines { u64 ones_before_line; u64 bits[7] } (448 payload bits per line); nodes are concatenated, line offset
-//     of node k in node_base[k].  One node-rank = one line (the reference touches three arrays,
-//     bitvector/Bitvector.h:147-166).
+//  Format W  (wavelet; built from Wavelet::bitvector[*] at upload, or on the device by the builder): every node is an array
+//     of 64-byte lines { u64 hdr0 = ones before the line (within the node); u64 hdr1 = cum[1..5], 9 bits each, cum[k] = ones
+//     in bits[0..k); u64 bits[6] } (384 payload bits per line); nodes are concatenated, line offset of node k in node_base[k].
+//     One node-rank = one line, fetched with two loads (header + the word that holds the position); the reference touches
+//     three arrays (bitvector/Bitvector.h:147-166).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -254,22 +255,14 @@ struct OccW {
     __device__ __forceinline__ uint32_t sigma() const { return v.sigma; }
 
     __device__ __forceinline__ idx_t node_rank(uint32_t id, idx_t i, uint32_t* bit_out) const {
-        uint32_t line = i / 448u, r = i - line * 448u;
+        const uint32_t line = i / 384u, r = i - line * 384u;
+        const uint32_t k = r >> 6, part = r & 63u;
         const uint64_t* L = v.lines + ((size_t)v.node_base[id] + line) * 8u;
-        uint64_t w[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = L[k];
-        uint32_t full = r >> 6, part = r & 63u;
-        uint32_t acc = (uint32_t)w[0];
-        uint64_t cur = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 7; ++k) {
-            if (k < full) acc += popc64(w[k + 1]);
-            if (k == full) cur = w[k + 1];
-        }
-        acc += popc64(cur & lowmask(part));
-        if (bit_out) *bit_out = (uint32_t)((cur >> part) & 1ull);
-        return acc;
+        const uint64_t h0 = L[0], h1 = L[1];
+        const uint64_t w = L[2 + k];
+        const uint32_t cum = k ? (uint32_t)(h1 >> (9u * (k - 1u))) & 0x1ffu : 0u;
+        if (bit_out) *bit_out = (uint32_t)((w >> part) & 1ull);
+        return (idx_t)h0 + cum + popc64(w & lowmask(part));
     }
     __device__ __forceinline__ idx_t rank(idx_t i, uint32_t c) const {
         for (uint32_t b = 0; b < v.bitct; ++b) {
@@ -369,7 +362,14 @@ struct DevString {
     uint8_t* kblk = nullptr; uint32_t kstep = 0, kcodes = 0; size_t kblk_bytes = 0;
     // walk table (fmgpu_index_accelerate_search): walk3[3*i .. 3*i+2] = LF(i), LF^2(i), LF^3(i)
     idx_t* walk3 = nullptr;
+    // Format A shadow of a Format R / W string (fmgpu_index_accelerate, kstep >= 1): the searches then read `va` (one line per
+    // LF step instead of bitct lines); fmgpu_string_query keeps answering from the native format.
+    void* shadow = nullptr; size_t shadow_bytes = 0;
+    int search_family() const { return shadow ? (int)FAM_A : family; }
 };
+
+// builds s.shadow / s.va from the string's own symbols; defined in fmgpu_build.hip
+int build_format_a_shadow(DevString& s, const idx_t* dC, hipStream_t stream);
 
 // fills s.lf_table from the device string (all layouts); defined in fmgpu_index.hip
 int build_lf_table(DevString& s, hipStream_t stream);

@@ -143,6 +143,8 @@ void free_string(DevString& s) {
     if (s.lf_table) (void)hipFree(s.lf_table);
     if (s.kblk) (void)hipFree(s.kblk);
     if (s.walk3) (void)hipFree(s.walk3);
+    if (s.shadow) (void)hipFree(s.shadow);
+    s.shadow = nullptr; s.shadow_bytes = 0;
     s.blk = s.aux = nullptr; s.lf_table = nullptr; s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0; s.walk3 = nullptr;
 }
 
@@ -233,7 +235,7 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
     uint64_t total_lines = 0;
     for (uint64_t k = 0; k < nnodes; ++k) {
         base[k] = (uint32_t)total_lines;
-        total_lines += d.nodes[k].total_length / 448 + 1;
+        total_lines += d.nodes[k].total_length / 384 + 1;
         if (d.nodes[k].n_bits < d.nodes[k].total_length / 64 + 1) return fail(FMGPU_ERR_INVALID, "wavelet node bits array too short");
         if (total_lines >= 0xffffffffull) return fail(FMGPU_ERR_UNSUPPORTED, "wavelet too large for 32-bit line offsets");
     }
@@ -241,16 +243,20 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
     if (!lines) return fail(FMGPU_ERR_NOMEM, "host staging for wavelet lines");
     for (uint64_t k = 0; k < nnodes; ++k) {
         const fmgpu_wavelet_node& nd = d.nodes[k];
-        uint64_t nl = nd.total_length / 448 + 1, nwords = nd.total_length / 64 + 1, ones = 0;
+        uint64_t nl = nd.total_length / 384 + 1, nwords = nd.total_length / 64 + 1, ones = 0;
         for (uint64_t li = 0; li < nl; ++li) {
             uint64_t* Lp = lines.get() + (base[k] + li) * 8;
             Lp[0] = ones;
-            for (uint64_t j = 0; j < 7; ++j) {
-                uint64_t wi = li * 7 + j;
+            uint64_t cum = 0, h1 = 0;
+            for (uint64_t j = 0; j < 6; ++j) {
+                uint64_t wi = li * 6 + j;
                 uint64_t w = wi < nwords ? nd.bits[wi] : 0;
-                Lp[1 + j] = w;
-                ones += (uint64_t)__builtin_popcountll(w);
+                if (j) h1 |= cum << (9 * (j - 1));
+                Lp[2 + j] = w;
+                cum += (uint64_t)__builtin_popcountll(w);
             }
+            Lp[1] = h1;
+            ones += cum;
         }
     }
     int rc = upload(lines.get(), total_lines * 64, &s.blk); if (rc) return rc;
@@ -499,9 +505,19 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
     if (kstep < 0 || kstep > 8) return fail(FMGPU_ERR_INVALID, "kstep must be in [0, 8]");
     x->device_bytes -= s.kblk_bytes;
     if (s.kblk) { (void)hipFree(s.kblk); s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0; }
-    if (kstep <= 1 || s.n == 0) return 0;
-    int rc;
-    switch (s.family) {
+    if (kstep == 0) {                                  // drop the Format A shadows as well
+        for (DevString* t : {&x->bwt, &x->rev}) if (t->shadow) { (void)hipFree(t->shadow); x->device_bytes -= t->shadow_bytes; t->shadow = nullptr; t->shadow_bytes = 0; t->va = ViewA{}; }
+        return 0;
+    }
+    if (s.n == 0) return 0;
+    int rc = 0;
+    for (DevString* t : {&x->bwt, &x->rev}) {          // EPR / Wavelet strings: searches read a Format A expansion from here on
+        if (t->n == 0 || t->family == FAM_A || t->shadow) continue;
+        if ((rc = build_format_a_shadow(*t, x->dC, nullptr))) return rc;
+        x->device_bytes += t->shadow_bytes;
+    }
+    if (kstep <= 1) return 0;
+    switch (s.search_family()) {
     case FAM_A:     rc = s.sigma == 5 ? accelerate_with(s, OccA<5>{s.va}, (uint32_t)kstep) : accelerate_with(s, OccA<0>{s.va}, (uint32_t)kstep); break;
     case FAM_EPR:   rc = accelerate_with(s, OccR<false>{s.vr}, (uint32_t)kstep); break;
     case FAM_EPRV2: rc = accelerate_with(s, OccR<true>{s.vr}, (uint32_t)kstep); break;

@@ -314,6 +314,63 @@ __device__ __forceinline__ uint32_t qstage_get(const QStage& st, const uint8_t* 
     return (st.lds[(p >> 2) * 256u + threadIdx.x] >> ((p & 3u) * 8u)) & 255u;
 }
 
+// ---- exact search over Format W (wavelet) -----------------------------------------------------------------------
+// One LF step = bitct dependent node-ranks (string/Wavelet.h:104-119), each one 64-byte line: header + the payload word that
+// holds the position.  Both interval ends walk the same node path; once the interval is short they sit in the same line
+// (and mostly the same word), so the second end re-uses the first end's loads.  The query is staged in LDS, the node
+// offsets and C[] too, so that the only global loads of a step are the line reads on the dependent chain.
+__global__ __launch_bounds__(256) void k_exact_w(ViewW v, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
+                                                 uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len, unsigned long long* __restrict__ steps_total,
+                                                 uint32_t qwords) {
+    extern __shared__ uint32_t s_query[];
+    __shared__ uint32_t s_nb[256];
+    __shared__ idx_t s_C[257];
+    const uint32_t sigma = v.sigma, bits = v.bitct;
+    for (uint32_t i = threadIdx.x; i < (1u << bits); i += blockDim.x) s_nb[i] = v.node_base[i];
+    for (uint32_t i = threadIdx.x; i <= sigma; i += blockDim.x) s_C[i] = v.C[i];
+    __syncthreads();
+    const QStage qst{s_query, qwords, 0u};
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t steps = 0;
+    if (q < nq) {
+        uint64_t o = qoff[q];
+        uint32_t m = (uint32_t)(qoff[q + 1] - o);
+        const uint8_t* qs = qbuf + o;
+        if (m) qstage_load(qst, qbuf, o, m, sigma);
+        idx_t a = 0, b = n;
+        for (uint32_t i = m; i-- > 0;) {
+            uint32_t c = qstage_get(qst, qs, i);
+            ++steps;
+            if (c >= sigma) { a = b = 0; break; }
+            for (uint32_t lv = 0; lv < bits; ++lv) {
+                const uint32_t bitId = bits - lv - 1u;
+                const uint32_t bit = (c >> bitId) & 1u;
+                const uint32_t id = ((1u << lv) - 1u) + (c >> (bitId + 1u));
+                const uint64_t* node = v.lines + (size_t)s_nb[id] * 8u;
+                const uint32_t la = a / 384u, ra = a - la * 384u, ka = ra >> 6;
+                const uint32_t lb = b / 384u, rb = b - lb * 384u, kb = rb >> 6;
+                const uint64_t* pa = node + (size_t)la * 8u;
+                const uint64_t* pb = node + (size_t)lb * 8u;
+                uint64_t ha0 = pa[0], ha1 = pa[1], wa = pa[2 + ka];
+                uint64_t hb0 = ha0, hb1 = ha1, wb = wa;
+                if (lb != la) { hb0 = pb[0]; hb1 = pb[1]; }
+                if (lb != la || kb != ka) wb = pb[2 + kb];
+                const uint32_t ca = ka ? (uint32_t)(ha1 >> (9u * (ka - 1u))) & 0x1ffu : 0u;
+                const uint32_t cb = kb ? (uint32_t)(hb1 >> (9u * (kb - 1u))) & 0x1ffu : 0u;
+                const idx_t xa = (idx_t)ha0 + ca + popc64(wa & lowmask(ra & 63u));
+                const idx_t xb = (idx_t)hb0 + cb + popc64(wb & lowmask(rb & 63u));
+                a = bit ? xa : a - xa;
+                b = bit ? xb : b - xb;
+            }
+            a += s_C[c]; b += s_C[c];
+            if (a == b) break;
+        }
+        out_lb[q] = a; out_len[q] = b - a;
+    }
+    uint32_t tot = wave_sum(steps);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
+}
+
 // ---- search_ng26 Hamming --------------------------------------------------------------------------------------
 template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
@@ -923,7 +980,7 @@ struct EventTimer {
 
 template <class F>
 static int dispatch_occ(const DevString& s, F&& f) {
-    switch (s.family) {
+    switch (s.search_family()) {
     case FAM_A:
         if (s.sigma == 5) return f(OccA<5>{s.va}, std::integral_constant<int, 5>{});
         if (s.sigma <= 32) return f(OccA<0>{s.va}, std::integral_constant<int, 32>{});
@@ -1079,7 +1136,7 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
                                                                     (uint64_t*)slen.dev, dsteps, kq_words, kq_nib, kq_max);
             return 0;
         });
-    } else if (x->bwt.family == FAM_A && variant >= 1) {
+    } else if (x->bwt.search_family() == FAM_A && variant >= 1) {
         auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
         auto launch = [&](auto occ) {
             using O = decltype(occ);
@@ -1089,6 +1146,14 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
             else k_exact_a2<SG><<<dim3((unsigned)(((nq + 1) / 2 + 255) / 256)), block, 0, stream>>>(occ, qb, qo, nq, n, ol, on, dsteps);
         };
         if (x->bwt.sigma == 5) launch(OccA<5>{x->bwt.va}); else launch(OccA<0>{x->bwt.va});
+    } else if (x->bwt.search_family() == FAM_WAVELET && variant != 0) {
+        uint32_t mx = 0, mn = 0;
+        if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) { (void)hipFree(dsteps); return rc; }
+        uint32_t qw = (mx + 3) / 4;
+        if ((size_t)qw * 1024 > 48 * 1024) qw = 0;
+        timer.start();
+        k_exact_w<<<grid, block, (size_t)qw * 1024, stream>>>(x->bwt.vw, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
+                                                               (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps, qw);
     } else {
         rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
             k_exact<decltype(occ)><<<grid, block, 0, stream>>>(occ, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
@@ -1164,7 +1229,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     static std::mutex occ_mu; static std::map<std::tuple<int, int, int, size_t>, int> occ_cache;
     int bpc = 8;
     const size_t occ_lds = (size_t)((x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4)) * 1024 > 48 * 1024 ? 0 : (size_t)((x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4)) * 1024;
-    const auto occ_key = std::make_tuple(x->bwt.family, x->bwt.sigma, (int)scheme_mode, occ_lds);
+    const auto occ_key = std::make_tuple(x->bwt.search_family(), x->bwt.sigma, (int)scheme_mode, occ_lds);
     bool occ_known = false;
     { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(occ_key); if (it != occ_cache.end()) { bpc = it->second; occ_known = true; } }
     if (!occ_known) {   // residency of the kernel instantiation that will run (queried once: the call is slow)
@@ -1189,7 +1254,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     // fast path: equal-length batch on a Format-A BiFMIndex with LF tables
     std::vector<uint32_t> step_tab;
     uint32_t lut_ok = 0;
-    const bool fast = scheme_mode && x->bwt.family == FAM_A && x->bwt.lf_table && x->rev.lf_table && minlen == maxlen &&
+    const bool fast = scheme_mode && x->bwt.search_family() == FAM_A && x->bwt.lf_table && x->rev.lf_table && minlen == maxlen &&
                       x->bwt.sigma <= 32 && !(sd.dev_flags & 2) && build_step_table(sd, maxlen, (sd.dev_flags & 4) ? 0 : x->lut_len, step_tab, lut_ok);
     uint32_t* d_steps = nullptr;
     if (fast) {

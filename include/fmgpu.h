@@ -131,7 +131,11 @@ int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layo
 /* Optional accelerator for fmgpu_search_exact: a k-symbol-step occurrence table (one table entry advances a cursor by `kstep`
  * symbols, so a query touches 1/kstep as many HBM lines).  Built on the device from the index itself; needs
  * (sigma-1)^kstep <= 255 contexts and 16 * (sigma-1)^kstep / 64 bytes per row of HBM (DNA, kstep 3: 16 B/row).  Results of every search
- * stay identical; kstep = 0 or 1 removes the accelerator.  Same idea as the reference's BiFMIndexKStep (fmindex/BiFMIndexKStep.h). */
+ * stay identical; kstep = 1 removes the k-step table.  Same idea as the reference's BiFMIndexKStep (fmindex/BiFMIndexKStep.h).
+ * For InterleavedEPR* / InterleavedEPRV2* / Wavelet indices any kstep >= 1 first expands the occurrence table on the device into the
+ * one-line-per-LF-step block format the InterleavedBitvector* layouts are held in (12 * sigma / 64 bytes per row and direction; a
+ * Wavelet step otherwise touches bit_width(sigma-1) lines); every search kernel then reads that table, fmgpu_string_query keeps
+ * answering from the native layout.  kstep = 0 removes the k-step table and the expansion. */
 int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep);
 
 /* Optional accelerators for fmgpu_search_scheme on a BiFMIndex (results unchanged):

@@ -40,7 +40,7 @@ def repeat_text(seed, n=3000):
             np.tile(np.array([1, 2, 1, 3], dtype=np.uint8), 40)]
 
 
-def mutated_queries(seqs, count, lo, hi, maxsub, seed):
+def mutated_queries(seqs, count, lo, hi, maxsub, seed, sigma=5):
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(count):
@@ -49,7 +49,7 @@ def mutated_queries(seqs, count, lo, hi, maxsub, seed):
         p = int(rng.integers(0, len(s) - m + 1))
         q = s[p: p + m].copy()
         for _ in range(int(rng.integers(0, maxsub + 1))):
-            q[int(rng.integers(0, m))] = rng.integers(1, 5)
+            q[int(rng.integers(0, m))] = rng.integers(1, sigma)
         out.append(q)
     return out
 
@@ -294,6 +294,50 @@ def test_k_mismatch_other_layouts(layout, sigma):
     assert same_hits(fm.search_backtracking.search(gx, (qbuf, qoff), 1), ox.search_backtracking(qbuf, qoff, 1)[0])
 
 
+@pytest.mark.parametrize("layout,sigma", [("EPR16", 5), ("EPRV2_16", 5), ("EPRV2_8", 6), ("WAVELET", 5), ("WAVELET", 28), ("WAVELET", 256), ("EPR32", 21)])
+def test_occurrence_table_expansion(layout, sigma):
+    """fmgpu_index_accelerate(h, 1) on EPR / Wavelet indices: the searches read the expanded block table, results stay those of the
+    reference layout (exact, search scheme on the table-driven and the generic kernel, backtracking, locate); dropping it again too"""
+    rng = np.random.default_rng(sigma + len(layout))
+    base = rng.integers(1, sigma, size=1300, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[100:500]]), rng.integers(1, sigma, size=700, dtype=np.uint8)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 4, True)
+    gx = gpu_index(ox)
+    before = gx.device_bytes
+    gx.accelerate(1)
+    assert gx.device_bytes > before
+    same = [q for q in mutated_queries(seqs, 600, 24, 25, 2, seed=sigma, sigma=sigma)]
+    ragged = mutated_queries(seqs, 300, 1, 60, 1, seed=sigma + 1, sigma=sigma)
+    sch = fm.search_scheme.h2(3, 0, 1)
+    for queries in (same, ragged):
+        qbuf, qoff = fm.flatten(queries)
+        lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
+        olb, oln = ox.search_exact(qbuf, qoff)
+        assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
+        keep = [i for i, q in enumerate(queries) if len(q) >= 3]
+        kb, ko = fm.flatten([queries[i] for i in keep])
+        hits, st = fm.search_ng26.search(gx, (kb, ko), sch, want_stats=True)
+        ohits, _, nodes = ox.search_ng26(kb, ko, sch)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes
+        assert same_hits(fm.search_backtracking.search(gx, (qbuf, qoff), 1), ox.search_backtracking(qbuf, qoff, 1)[0])
+    rows = np.arange(0, ox.n, 7, dtype=np.uint64)
+    seq, pos, steps = gx.locate(rows)
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(seq, pos, steps)] == [ox.locate(int(r)) for r in rows]
+    idx = np.repeat(np.arange(0, ox.n + 1, 5, dtype=np.uint64), sigma); sym = np.tile(np.arange(sigma, dtype=np.uint8), len(idx) // sigma)
+    r1 = gx.rank(idx, sym)
+    if sigma <= 6:
+        gx.accelerate(2)                                           # k-step table over the expansion
+        qbuf, qoff = fm.flatten(ragged)
+        lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
+        olb, oln = ox.search_exact(qbuf, qoff)
+        assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
+    gx.accelerate(0)
+    assert gx.device_bytes == before
+    qbuf, qoff = fm.flatten(same)
+    assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch), ox.search_ng26(qbuf, qoff, sch)[0])
+    assert np.array_equal(gx.rank(idx, sym), r1)
+
+
 @pytest.mark.parametrize("bidir", [False, True])
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_backtracking(bidir, k):
@@ -432,6 +476,38 @@ def test_gpu_builder_other_alphabets_and_errors():
         fm.FMIndex.from_sequences([[1, 2]], 5, "EPR16")            # builder lays out InterleavedBitvector* only
     with pytest.raises(fm.FmgpuError):
         fm.FMIndex.from_sequences([[1, 2]], 5, "IB16", 0)
+
+
+@pytest.mark.parametrize("sigma,n", [(28, 6000), (5, 3000), (4, 900), (256, 2500), (21, 383), (6, 384 * 3)])
+def test_gpu_builder_wavelet(sigma, n):
+    """Wavelet indices built on the device (level-wise stable sort of the BWT) answer exactly like the reference's
+    string::Wavelet (string/Wavelet.h:40-72 push_back construction) over the same BWT: rank / prefix_rank / symbol for every
+    (row, symbol), exact and 1-mismatch searches, locate."""
+    seqs = [make_text(n, sigma, seed=sigma + 3), make_text(n // 4 + 1, sigma, seed=sigma + 9)]
+    gx = fm.BiFMIndex.from_sequences(seqs, sigma, "WAVELET", 4, keep_host=True)
+    ox = fo.OraIndex.build("WAVELET", sigma, seqs, 4, True)
+    N = ox.n
+    assert gx.n == N
+    for rev in (False, True):
+        st = ox.bwt_string(rev=rev)
+        ranks, pranks = st.rank_table()
+        rows = np.arange(0, N + 1, max(1, (N + 1) * sigma // 400_000), dtype=np.uint64)
+        idx = np.repeat(rows, sigma); sym = np.tile(np.arange(sigma, dtype=np.uint8), len(rows))
+        assert np.array_equal(gx.rank(idx, sym, rev=rev).reshape(len(rows), sigma), ranks[rows.astype(np.int64)])
+        assert np.array_equal(gx.prefix_rank(idx, sym, rev=rev).reshape(len(rows), sigma), pranks[rows.astype(np.int64)])
+        r2 = np.arange(N, dtype=np.uint64)
+        assert np.array_equal(gx.symbol(r2, rev=rev).astype(np.uint8), np.array([st.symbol(int(i)) for i in r2], dtype=np.uint8))
+    reads = sample_reads(seqs[0], 300, 14, seed=8, mutate=1, sigma=sigma)
+    qbuf, qoff = fm.flatten(reads)
+    lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
+    olb, oln = ox.search_exact(qbuf, qoff)
+    assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
+    sch = fm.search_scheme.h2(3, 0, 1)
+    hits = fm.search_ng26.search(gx, reads, sch)
+    assert same_hits(hits, ox.search_ng26(qbuf, qoff, sch)[0])
+    rows = np.arange(0, N, max(1, N // 300), dtype=np.uint64)
+    seq, pos, steps = gx.locate(rows)
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(seq, pos, steps)] == [ox.locate(int(r)) for r in rows]
 
 
 def test_index_create_argument_checks():
