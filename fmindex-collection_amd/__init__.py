@@ -45,8 +45,10 @@ def _u64(a):
 class _StringArrays:
     """host arrays of one reference String object, kept alive while the descriptor is in use"""
 
-    def __init__(self, layout, sigma, n, blocks=None, super_blocks=None, nodes=None):
+    def __init__(self, layout, sigma, n, blocks=None, super_blocks=None, nodes=None, levels=None):
         self.layout, self.sigma, self.n = layout, sigma, n
+        # EPRV3/4/5/7: `blocks` = the bits array, `levels` = counter arrays bottom-up (None where the layout has none)
+        self.levels = None if levels is None else [None if a is None else np.ascontiguousarray(a).view(np.uint8) for a in levels]
         self.blocks = None if blocks is None else np.ascontiguousarray(blocks).view(np.uint8)
         self.super_blocks = None if super_blocks is None else _u64(super_blocks).reshape(-1)
         self.nodes = nodes  # list of (superblocks u64, blocks u8, bits u64, total_length)
@@ -62,6 +64,11 @@ class _StringArrays:
             d.blocks_bytes = self.blocks.nbytes
             d.super_blocks = self.super_blocks.ctypes.data_as(capi.u64p)
             d.n_super_blocks = self.super_blocks.size // self.sigma
+        if self.levels is not None:
+            for k, a in enumerate(self.levels[:3]):
+                if a is not None and a.size:
+                    d.levels[k] = a.ctypes.data
+                    d.level_bytes[k] = a.nbytes
         if self.nodes is not None:
             arr = (capi.WaveletNode * len(self.nodes))()
             keep = []

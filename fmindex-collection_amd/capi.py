@@ -15,6 +15,7 @@ LAYOUTS = {
     "IB8": 0, "IB16": 1, "IB32": 2, "IB16A": 3, "IBP16": 4,
     "EPR8": 5, "EPR16": 6, "EPR32": 7,
     "EPRV2_8": 8, "EPRV2_16": 9, "EPRV2_32": 10, "WAVELET": 11,
+    "EPRV3_8": 12, "EPRV3_16": 13, "EPRV3_32": 14, "EPRV4": 15, "EPRV5": 16, "IEPRV7": 17,
 }
 LAYOUT_NAMES = {v: k for k, v in LAYOUTS.items()}
 UINT64_MAX = (1 << 64) - 1
@@ -43,7 +44,8 @@ class StringDesc(C.Structure):
     _fields_ = [("layout", C.c_int32), ("sigma", C.c_int32), ("n", C.c_uint64),
                 ("blocks", C.c_void_p), ("blocks_bytes", C.c_uint64),
                 ("super_blocks", u64p), ("n_super_blocks", C.c_uint64),
-                ("nodes", C.POINTER(WaveletNode)), ("n_nodes", C.c_uint64)]
+                ("nodes", C.POINTER(WaveletNode)), ("n_nodes", C.c_uint64),
+                ("levels", C.c_void_p * 3), ("level_bytes", C.c_uint64 * 3)]
 
 
 class DenseVectorDesc(C.Structure):

@@ -469,8 +469,9 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
     if (!seqs || !seq_off || nseq == 0) return fail(FMGPU_ERR_INVALID, "seqs / seq_off is null or nseq == 0");
     if (sigma < 2 || sigma > 256) return fail(FMGPU_ERR_INVALID, "sigma must be in [2, 256]");
     if (sampling_rate == 0) return fail(FMGPU_ERR_INVALID, "sampling_rate must be >= 1");
-    if (!(layout == FMGPU_IB8 || layout == FMGPU_IB16 || layout == FMGPU_IB32 || layout == FMGPU_IB16A || layout == FMGPU_IBP16 || layout == FMGPU_WAVELET))
-        return fail(FMGPU_ERR_UNSUPPORTED, "the GPU builder lays out InterleavedBitvector* and Wavelet indices; build other layouts from the returned BWT (keep_host)");
+    // the layout names the reference type the caller replaces; on the device every blocked layout is held as the LF-ready block
+    // table (Format A) and Wavelet as wavelet lines (Format W) — the answers of a String_c do not depend on its layout
+    if (layout < FMGPU_IB8 || layout > FMGPU_IEPRV7) return fail(FMGPU_ERR_INVALID, "unknown layout id");
     hipStream_t stream = nullptr;
     Staged soff, sseq;
     int rc;

@@ -129,6 +129,85 @@ __global__ __launch_bounds__(256) void k_convert_ib(const uint8_t* __restrict__ 
     o[0] = total; o[1] = (uint32_t)bits; o[2] = (uint32_t)(bits >> 32);
 }
 
+static int upload(const void* host, size_t bytes, void** dev);
+
+// EPRV3 / EPRV4 / EPRV5 / InterleavedEPRV7 -> Format A.  thread = (block B, symbol c): the symbol-match mask of the bit planes
+// (EPRV3.h:55-68) becomes the entry's bitmap (position p <-> bit p & 63, as in Format A), the counters of every level that
+// cover row 64B (EPRV3.h:205-213, EPRV4.h:128-142, EPRV5.h:126-139, InterleavedEPRV7.h:190-199) are summed into cnt.
+struct HierView {
+    const uint8_t* bits; uint32_t bits_stride;
+    const uint8_t* lev[3]; uint32_t lev_w[3], lev_shift[3], lev_stride[3], lev_off[3]; int nlev;
+    const uint64_t* super; uint32_t sshift;
+};
+__global__ __launch_bounds__(256) void k_convert_hier(HierView v, const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t nblocks, uint64_t n,
+                                                      uint32_t sigma, uint32_t bitct, uint32_t bstride) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblocks * sigma) return;
+    uint64_t B = t / sigma, row = B * 64;
+    uint32_t c = (uint32_t)(t % sigma);
+    uint64_t m = ~0ull;
+    for (uint32_t i = 0; i < bitct; ++i) {
+        uint64_t w; memcpy(&w, v.bits + B * v.bits_stride + 8ull * i, 8);            // V7's packed structs are not 8-byte aligned
+        m &= w ^ (0ull - (uint64_t)((~c >> i) & 1u));
+    }
+    if (n - row < 64) m &= (1ull << (n - row)) - 1ull;                                 // rows past the end read as symbol 0 in the planes
+    uint64_t cnt = v.super[(row >> v.sshift) * sigma + c];
+    for (int L = 0; L < v.nlev; ++L) {
+        const uint8_t* p = v.lev[L] + (row >> v.lev_shift[L]) * v.lev_stride[L] + v.lev_off[L] + (uint64_t)c * v.lev_w[L];
+        if (v.lev_w[L] == 1) cnt += *p;
+        else if (v.lev_w[L] == 2) { uint16_t x; memcpy(&x, p, 2); cnt += x; }
+        else { uint32_t x; memcpy(&x, p, 4); cnt += x; }
+    }
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + B * bstride + 12ull * c);
+    o[0] = (uint32_t)cnt + C[c]; o[1] = (uint32_t)m; o[2] = (uint32_t)(m >> 32);
+}
+
+static int create_hier(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
+    const uint32_t sigma = (uint32_t)d.sigma, bitct = (uint32_t)bit_width_u((uint64_t)sigma - 1);
+    HierView v{};
+    v.bits_stride = 8 * bitct;
+    switch (d.layout) {
+    case FMGPU_EPRV3_8: case FMGPU_EPRV3_16: case FMGPU_EPRV3_32: {
+        uint32_t bt = d.layout == FMGPU_EPRV3_8 ? 1 : (d.layout == FMGPU_EPRV3_16 ? 2 : 4);
+        v.nlev = 1; v.lev_w[0] = bt; v.lev_shift[0] = 6; v.sshift = 8 * bt; break;
+    }
+    case FMGPU_EPRV4: v.nlev = 3; v.lev_w[0] = 1; v.lev_w[1] = 2; v.lev_w[2] = 4; v.lev_shift[0] = 6; v.lev_shift[1] = 8; v.lev_shift[2] = 16; v.sshift = 32; break;
+    default:          v.nlev = 2; v.lev_w[0] = 1; v.lev_w[1] = 2; v.lev_shift[0] = 6; v.lev_shift[1] = 8; v.sshift = 16; break;
+    }
+    const bool v7 = d.layout == FMGPU_IEPRV7;
+    if (v7) v.bits_stride += sigma;
+    const uint64_t nblocks = d.n / 64 + 1, nsuper = (d.n >> v.sshift) + 1;
+    if (!d.blocks || !d.super_blocks) return fail(FMGPU_ERR_INVALID, "bits / super_blocks missing");
+    if (d.blocks_bytes < nblocks * v.bits_stride) return fail(FMGPU_ERR_INVALID, "bits array too short for n rows (expected >= " + std::to_string(nblocks * v.bits_stride) + " bytes)");
+    if (d.n_super_blocks < nsuper) return fail(FMGPU_ERR_INVALID, "too few super blocks for n rows");
+    void* held[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto drop = [&] { for (void* p : held) if (p) (void)hipFree(p); };
+    int rc = upload(d.blocks, nblocks * v.bits_stride, &held[0]); if (rc) { drop(); return rc; }
+    rc = upload(d.super_blocks, nsuper * sigma * 8, &held[1]); if (rc) { drop(); return rc; }
+    v.bits = (const uint8_t*)held[0]; v.super = (const uint64_t*)held[1];
+    for (int L = 0; L < v.nlev; ++L) {
+        v.lev_stride[L] = v.lev_w[L] * sigma; v.lev_off[L] = 0;
+        if (L == 0 && v7) { v.lev[0] = v.bits; v.lev_stride[0] = v.bits_stride; v.lev_off[0] = 8 * bitct; continue; }   // level0 inside the packed struct
+        const uint64_t need = ((d.n >> v.lev_shift[L]) + 1) * v.lev_stride[L];
+        if (!d.levels[L] || d.level_bytes[L] < need) { drop(); return fail(FMGPU_ERR_INVALID, "counter level " + std::to_string(L) + " missing or too short for n rows"); }
+        rc = upload(d.levels[L], need, &held[2 + L]); if (rc) { drop(); return rc; }
+        v.lev[L] = (const uint8_t*)held[2 + L];
+    }
+    const uint32_t bstride = sigma <= 5 ? 64u : 12u * sigma;
+    s.blk_bytes = nblocks * bstride + 64;
+    hipError_t e = hipMalloc(&s.blk, s.blk_bytes);
+    if (e != hipSuccess) { drop(); return hip_fail(e, "hipMalloc(format A)"); }
+    (void)hipMemset(s.blk, 0, s.blk_bytes);
+    const uint64_t threads = nblocks * sigma;
+    k_convert_hier<<<dim3((unsigned)((threads + 255) / 256)), dim3(256)>>>(v, dC, (uint8_t*)s.blk, nblocks, d.n, sigma, bitct, bstride);
+    e = hipDeviceSynchronize();
+    drop();
+    if (e != hipSuccess) return hip_fail(e, "k_convert_hier");
+    s.family = FAM_A; s.bitct = (int)bitct;
+    s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC};
+    return 0;
+}
+
 static int upload(const void* host, size_t bytes, void** dev) {
     *dev = nullptr;
     if (bytes == 0) bytes = 8;
@@ -179,6 +258,10 @@ int build_lf_table(DevString& s, hipStream_t stream) {
 static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
     if (d.sigma < 2 || d.sigma > 256) return fail(FMGPU_ERR_INVALID, "sigma must be in [2, 256]");
     if (d.n >= 0xffffffffull - 64) return fail(FMGPU_ERR_UNSUPPORTED, "this build indexes fewer than 2^32 - 64 rows per string");
+    if (d.layout >= FMGPU_EPRV3_8 && d.layout <= FMGPU_IEPRV7) {
+        s.layout = d.layout; s.sigma = d.sigma; s.n = d.n;
+        return create_hier(d, dC, s);
+    }
     RefLayout L{};
     if (ref_layout(d.layout, d.sigma, L) != 0) return fail(FMGPU_ERR_INVALID, "unknown layout id");
     s.layout = d.layout; s.sigma = d.sigma; s.n = d.n; s.bitct = (int)L.bitct;

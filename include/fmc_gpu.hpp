@@ -54,6 +54,19 @@ FMC_GPU_STRING_TAG(InterleavedBitvector16, FMGPU_IB16)
 FMC_GPU_STRING_TAG(InterleavedBitvector32, FMGPU_IB32)
 FMC_GPU_STRING_TAG(InterleavedBitvector16Aligned, FMGPU_IB16A)
 FMC_GPU_STRING_TAG(InterleavedBitvectorPrefix16, FMGPU_IBP16)
+FMC_GPU_STRING_TAG(InterleavedEPR8, FMGPU_EPR8)
+FMC_GPU_STRING_TAG(InterleavedEPR16, FMGPU_EPR16)
+FMC_GPU_STRING_TAG(InterleavedEPR32, FMGPU_EPR32)
+FMC_GPU_STRING_TAG(InterleavedEPRV2_8, FMGPU_EPRV2_8)
+FMC_GPU_STRING_TAG(InterleavedEPRV2_16, FMGPU_EPRV2_16)
+FMC_GPU_STRING_TAG(InterleavedEPRV2_32, FMGPU_EPRV2_32)
+FMC_GPU_STRING_TAG(Wavelet, FMGPU_WAVELET)
+FMC_GPU_STRING_TAG(EPRV3_8, FMGPU_EPRV3_8)
+FMC_GPU_STRING_TAG(EPRV3_16, FMGPU_EPRV3_16)
+FMC_GPU_STRING_TAG(EPRV3_32, FMGPU_EPRV3_32)
+FMC_GPU_STRING_TAG(EPRV4, FMGPU_EPRV4)
+FMC_GPU_STRING_TAG(EPRV5, FMGPU_EPRV5)
+FMC_GPU_STRING_TAG(InterleavedEPRV7, FMGPU_IEPRV7)
 #undef FMC_GPU_STRING_TAG
 }  // namespace string
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FMGPU_ABI_VERSION 1
+#define FMGPU_ABI_VERSION 2
 
 typedef enum fmgpu_status {
     FMGPU_OK = 0,
@@ -49,13 +49,20 @@ typedef enum fmgpu_layout {
     FMGPU_IBP16 = 4,                                                 /* InterleavedBitvectorPrefix.h:204-209 */
     FMGPU_EPR8 = 5, FMGPU_EPR16 = 6, FMGPU_EPR32 = 7,                /* InterleavedEPR.h:222-227 */
     FMGPU_EPRV2_8 = 8, FMGPU_EPRV2_16 = 9, FMGPU_EPRV2_32 = 10,      /* InterleavedEPRV2.h:289-309 */
-    FMGPU_WAVELET = 11                                               /* Wavelet.h:27-28 over bitvector::Bitvector */
+    FMGPU_WAVELET = 11,                                              /* Wavelet.h:27-28 over bitvector::Bitvector */
+    FMGPU_EPRV3_8 = 12, FMGPU_EPRV3_16 = 13, FMGPU_EPRV3_32 = 14,    /* EPRV3.h:263-272 */
+    FMGPU_EPRV4 = 15,                                                /* EPRV4.h:14 */
+    FMGPU_EPRV5 = 16,                                                /* EPRV5.h:14 */
+    FMGPU_IEPRV7 = 17                                                /* InterleavedEPRV7.h:15 */
 } fmgpu_layout;
 
 /* One reference String object, described by the arrays it already holds in host memory.
  * Blocked layouts: `blocks` = String::blocks.data() (sizeof(Block) stride),
  *                  `super_blocks` = String::superBlocks.data() ([k][sigma] uint64).
- * Wavelet:         `nodes` = bit_ceil(sigma) node descriptors = Wavelet::bitvector[i].{superblocks,blocks,bits,totalLength}. */
+ * Wavelet:         `nodes` = bit_ceil(sigma) node descriptors = Wavelet::bitvector[i].{superblocks,blocks,bits,totalLength}.
+ * EPRV3/4/5/7:     `blocks` = String::bits.data() (one InBits per 64 rows; V7: the packed {bits, level0} structs),
+ *                  `super_blocks` = String::superBlocks.data(), `levels[]` = the counter arrays bottom-up:
+ *                  EPRV3 {blocks_}, EPRV4 {level0, level1, level2}, EPRV5 {level0, level1}, InterleavedEPRV7 {NULL, level1}. */
 typedef struct fmgpu_wavelet_node {
     const uint64_t* superblocks; uint64_t n_superblocks;   /* bitvector/Bitvector.h:31 */
     const uint8_t*  blocks;      uint64_t n_blocks;        /* :32 */
@@ -70,6 +77,7 @@ typedef struct fmgpu_string_desc {
     const void*     blocks;       uint64_t blocks_bytes;
     const uint64_t* super_blocks; uint64_t n_super_blocks;
     const fmgpu_wavelet_node* nodes; uint64_t n_nodes;
+    const void* levels[3];        uint64_t level_bytes[3];
 } fmgpu_string_desc;
 
 /* suffixarray::SparseArray<std::tuple<uint32_t,uint32_t>, Bitvector2L<512,65536>> (suffixarray/SparseArray.h:31-76):
@@ -174,7 +182,7 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count,
 /* GPU index construction from sequences — replaces FMIndex(Sequences, samplingRate, threads) (fmindex/FMIndex.h:58-104) and
  * BiFMIndex(Sequences, samplingRate, threads) (fmindex/BiFMIndex.h:107-167), i.e. libsais (utils.h:97-129) + the String /
  * SparseArray constructors.  Sequence i = seqs[seq_off[i] .. seq_off[i+1]); a 0 delimiter follows every sequence
- * (utils.h:382-411).  `layout` must be an InterleavedBitvector* layout (others: build the String from the returned BWT).
+ * (utils.h:382-411).  `layout` names the reference String type being replaced: Wavelet is held as wavelet lines, every blocked layout as the LF-ready block table (the answers of a String_c do not depend on its layout).
  * keep_host != 0 additionally returns host copies of the by-products through fmgpu_built_get:
  *   part 0 BWT bytes, 1 BWT of the reversed text (BiFMIndex), 2 C (sigma+1 u64), 3 l0, 4 l1, 5 presence bits,
  *   6 / 7 DenseVector words of seqId / pos, 8 {bitCount, bits, largestValue, commonDivisor} x 2 (u64). */

@@ -20,7 +20,7 @@ static uint64_t bit_ceil_u64(uint64_t v) { uint64_t r = 1; while (r < v) r <<= 1
 /* =====================================================================================
  * strings with rank support
  * ===================================================================================== */
-enum family { FAM_IB, FAM_IBP, FAM_EPR, FAM_EPRV2, FAM_WAVELET };
+enum family { FAM_IB, FAM_IBP, FAM_EPR, FAM_EPRV2, FAM_WAVELET, FAM_EPRH };
 
 typedef struct ora_bitvector {               /* bitvector/Bitvector.h:30-179 */
     uint64_t* superblocks; uint64_t nsuper;  /* ones before bit 256k            */
@@ -46,6 +46,12 @@ struct ora_string {
     uint64_t maskEven, bitMask; uint64_t* rb;
     /* wavelet, string/Wavelet.h:31-57 */
     uint64_t nnodes; ora_bitvector* node;
+    /* EPRV3 / EPRV4 / EPRV5 / InterleavedEPRV7: bit-sliced 64-row blocks + counter levels in arrays of their own.
+     * level L: element width lev_w[L] bytes, one [sigma] entry per 2^lev_shift[L] rows; super-block per 2^sshift rows.
+     * V7 keeps level 0 inside the packed bits struct (hb_stride = 8*bitct + sigma, level0 at byte 8*bitct). */
+    int nlev, lev_w[3], lev_shift[3], sshift, v3, v7;
+    uint8_t* lev[3]; uint64_t lev_n[3];
+    uint8_t* hbits; uint64_t hb_stride, hblocks;
 };
 
 static uint64_t blk_count(const ora_string* s, uint64_t b, uint64_t c) {
@@ -122,6 +128,19 @@ static int layout_params(ora_string* s, int layout, int sigma) {
     case ORA_EPRV2_16: s->family = FAM_EPRV2; s->bt = 2; break;
     case ORA_EPRV2_32: s->family = FAM_EPRV2; s->bt = 4; break;
     case ORA_WAVELET:  s->family = FAM_WAVELET; s->bt = 0; return 0;
+    case ORA_EPRV3_8: case ORA_EPRV3_16: case ORA_EPRV3_32: {          /* EPRV3.h:128-133: blocks_ per 64 rows, super-block per 2^(8*sizeof(block_t)) rows */
+        s->family = FAM_EPRH; s->v3 = 1; s->bt = layout == ORA_EPRV3_8 ? 1 : (layout == ORA_EPRV3_16 ? 2 : 4);
+        s->nlev = 1; s->lev_w[0] = s->bt; s->lev_shift[0] = 6; s->sshift = 8 * s->bt;
+        s->hb_stride = 8 * (uint64_t)s->bitct; return 0;
+    }
+    case ORA_EPRV4:    /* EPRV4.h:27-42: u8 per 64 rows, u16 per 256, u32 per 65 536, super-block per 2^32 */
+        s->family = FAM_EPRH; s->nlev = 3; s->lev_w[0] = 1; s->lev_w[1] = 2; s->lev_w[2] = 4;
+        s->lev_shift[0] = 6; s->lev_shift[1] = 8; s->lev_shift[2] = 16; s->sshift = 32; s->hb_stride = 8 * (uint64_t)s->bitct; return 0;
+    case ORA_EPRV5:    /* EPRV5.h:27-42: u8 per 64 rows, u16 per 256, super-block per 65 536 */
+    case ORA_IEPRV7:   /* InterleavedEPRV7.h:23-26, :126-138: as V5 with the u8 level inside the packed bits struct */
+        s->family = FAM_EPRH; s->nlev = 2; s->lev_w[0] = 1; s->lev_w[1] = 2;
+        s->lev_shift[0] = 6; s->lev_shift[1] = 8; s->sshift = 16; s->v7 = layout == ORA_IEPRV7;
+        s->hb_stride = 8 * (uint64_t)s->bitct + (s->v7 ? (uint64_t)sigma : 0); return 0;
     default: return -1;
     }
     uint64_t full = 1ull << (8 * s->bt);      /* 2^(8*sizeof(block_t)) */
@@ -259,6 +278,109 @@ static void build_wavelet(ora_string* s, const uint8_t* t, uint64_t n) {
     }
 }
 
+/* ---- EPRV3/4/5/7 ---------------------------------------------------------------------- */
+static uint8_t* eprh_level_ptr(const ora_string* s, int L, uint64_t entry) {
+    if (L == 0 && s->v7) return s->hbits + entry * s->hb_stride + 8 * (uint64_t)s->bitct;
+    return s->lev[L] + entry * (uint64_t)s->lev_w[L] * (uint64_t)s->sigma;
+}
+static uint64_t eprh_level_get(const ora_string* s, int L, uint64_t entry, uint64_t c) {
+    const uint8_t* p = eprh_level_ptr(s, L, entry) + c * (uint64_t)s->lev_w[L];
+    switch (s->lev_w[L]) {
+    case 1: return *p;
+    case 2: { uint16_t v; memcpy(&v, p, 2); return v; }
+    default: { uint32_t v; memcpy(&v, p, 4); return v; }
+    }
+}
+static void eprh_level_set(ora_string* s, int L, uint64_t entry, const uint64_t* acc) {
+    for (uint64_t c = 0; c < (uint64_t)s->sigma; ++c) {
+        uint8_t* p = eprh_level_ptr(s, L, entry) + c * (uint64_t)s->lev_w[L];
+        switch (s->lev_w[L]) {                                   /* the accumulators have the level's own integer type */
+        case 1: { uint8_t v = (uint8_t)acc[c]; *p = v; break; }
+        case 2: { uint16_t v = (uint16_t)acc[c]; memcpy(p, &v, 2); break; }
+        default: { uint32_t v = (uint32_t)acc[c]; memcpy(p, &v, 4); break; }
+        }
+    }
+}
+static uint64_t eprh_word(const ora_string* s, uint64_t b, int plane) {
+    uint64_t v; memcpy(&v, s->hbits + b * s->hb_stride + 8 * (uint64_t)plane, 8); return v;
+}
+static void eprh_set_symbol(ora_string* s, uint64_t pos, uint64_t symb) {
+    for (int i = 0; i < s->bitct; ++i) {
+        uint8_t* p = s->hbits + (pos >> 6) * s->hb_stride + 8 * (uint64_t)i;
+        uint64_t v; memcpy(&v, p, 8); v |= ((symb >> i) & 1ull) << (pos & 63); memcpy(p, &v, 8);
+    }
+}
+static void build_eprh(ora_string* s, const uint8_t* t, uint64_t n) {
+    uint64_t sigma = (uint64_t)s->sigma;
+    uint64_t* sacc = calloc(sigma, 8);
+    uint64_t* acc[3] = {calloc(sigma, 8), calloc(sigma, 8), calloc(sigma, 8)};
+    if (s->v3) {
+        /* EPRV3.h:151-186: loop over super-blocks / blocks, then one more super-block, block and InBits "for safety" —
+         * the trailing block keeps the running count of the last super-block (not reset), which is what rank(n, c) reads
+         * when n is a multiple of 64 */
+        uint64_t per_super = (s->sshift >= 38 ? (1ull << 32) : (1ull << s->sshift) / 64);     /* blocks per super-block */
+        s->hblocks = (n + 63) / 64 + 1;
+        s->lev_n[0] = s->hblocks;
+        s->nsuper = (n == 0 ? 0 : ((n - 1) >> s->sshift) + 1) + 1;
+        s->hbits = calloc(s->hblocks * s->hb_stride + 8, 1);
+        s->lev[0] = calloc(s->lev_n[0] * sigma * (uint64_t)s->lev_w[0] + 8, 1);
+        s->super = calloc(s->nsuper * sigma, 8);
+        uint64_t size = 0, nb = 0, nsb = 0;
+        while (size < n) {
+            memcpy(s->super + nsb++ * sigma, sacc, sigma * 8);
+            memset(acc[0], 0, sigma * 8);
+            for (uint64_t blockId = 0; blockId < per_super && size < n; ++blockId) {
+                eprh_level_set(s, 0, nb++, acc[0]);
+                for (uint64_t bitId = 0; bitId < 64 && size < n; ++bitId, ++size) {
+                    eprh_set_symbol(s, size, t[size]);
+                    acc[0][t[size]] += 1; sacc[t[size]] += 1;
+                }
+            }
+        }
+        memcpy(s->super + nsb++ * sigma, sacc, sigma * 8);
+        eprh_level_set(s, 0, nb++, acc[0]);
+    } else {
+        /* EPRV4.h:56-99, EPRV5.h:49-97, InterleavedEPRV7.h:147-177: for size in [0, n]: open the blocks that start at `size`
+         * (the highest level whose period divides `size` stores its accumulator, every level below it starts from zero) */
+        s->hblocks = n / 64 + 1;
+        for (int L = 0; L < s->nlev; ++L) s->lev_n[L] = (n >> s->lev_shift[L]) + 1;
+        s->nsuper = (s->sshift >= 64 ? 0 : (n >> s->sshift)) + 1;
+        s->hbits = calloc(s->hblocks * s->hb_stride + 8, 1);
+        for (int L = (s->v7 ? 1 : 0); L < s->nlev; ++L) s->lev[L] = calloc(s->lev_n[L] * sigma * (uint64_t)s->lev_w[L] + 8, 1);
+        s->super = calloc(s->nsuper * sigma, 8);
+        uint64_t cnt[3] = {0, 0, 0}, nsb = 0;
+        for (uint64_t size = 0; size <= n; ++size) {
+            if ((size & ((1ull << s->sshift) - 1)) == 0) {
+                memcpy(s->super + nsb++ * sigma, sacc, sigma * 8);
+                for (int L = 0; L < s->nlev; ++L) { memset(acc[L], 0, sigma * 8); cnt[L]++; }       /* value-initialised entries */
+            } else {
+                for (int L = s->nlev - 1; L >= 0; --L) {
+                    if ((size & ((1ull << s->lev_shift[L]) - 1)) != 0) continue;
+                    eprh_level_set(s, L, cnt[L]++, acc[L]);
+                    for (int l = 0; l < L; ++l) { memset(acc[l], 0, sigma * 8); cnt[l]++; }
+                    break;
+                }
+            }
+            if (size == n) continue;
+            eprh_set_symbol(s, size, t[size]);
+            for (int L = 0; L < s->nlev; ++L) acc[L][t[size]] += 1;
+            sacc[t[size]] += 1;
+        }
+    }
+    free(sacc); free(acc[0]); free(acc[1]); free(acc[2]);
+}
+/* EPRV3.h:55-68 symbol-match mask over the bit planes */
+static uint64_t eprh_have(const ora_string* s, uint64_t b, uint64_t symb) {
+    uint64_t r = ~0ull;
+    for (int i = 0; i < s->bitct; ++i) r &= eprh_word(s, b, i) ^ (0 - ((~symb >> i) & 1));
+    return r;
+}
+static uint64_t eprh_counters(const ora_string* s, uint64_t idx, uint64_t c) {
+    uint64_t a = s->super[(s->sshift >= 64 ? 0 : idx >> s->sshift) * (uint64_t)s->sigma + c];
+    for (int L = 0; L < s->nlev; ++L) a += eprh_level_get(s, L, idx >> s->lev_shift[L], c);
+    return a;
+}
+
 ora_string* ora_string_build(int layout, int sigma, const uint8_t* symbols, uint64_t n) {
     if (sigma < 2 || sigma > 256) return NULL;
     for (uint64_t i = 0; i < n; ++i) if (symbols[i] >= sigma) return NULL;
@@ -271,6 +393,7 @@ ora_string* ora_string_build(int layout, int sigma, const uint8_t* symbols, uint
     case FAM_EPR:     build_epr(s, symbols, n); break;
     case FAM_EPRV2:   build_eprv2(s, symbols, n); break;
     case FAM_WAVELET: build_wavelet(s, symbols, n); break;
+    case FAM_EPRH:    build_eprh(s, symbols, n); break;
     }
     return s;
 }
@@ -278,6 +401,7 @@ ora_string* ora_string_build(int layout, int sigma, const uint8_t* symbols, uint
 void ora_string_free(ora_string* s) {
     if (!s) return;
     free(s->blocks); free(s->super); free(s->rb);
+    free(s->hbits); free(s->lev[0]); free(s->lev[1]); free(s->lev[2]);
     if (s->node) {
         for (uint64_t i = 0; i < s->nnodes; ++i) { free(s->node[i].superblocks); free(s->node[i].blocks); free(s->node[i].bits); }
         free(s->node);
@@ -301,6 +425,15 @@ int ora_string_raw(const ora_string* s, int part, const void** ptr, uint64_t* by
         case 2: *ptr = v->bits;        *bytes = v->nbits * 8; return 0;
         default: *ptr = &v->totalLength; *bytes = 8; return 0;
         }
+    }
+    if (s->family == FAM_EPRH) {
+        if (part == 0) { *ptr = s->hbits; *bytes = s->hblocks * s->hb_stride; return 0; }
+        if (part == 1) { *ptr = s->super; *bytes = s->nsuper * (uint64_t)s->sigma * 8; return 0; }
+        if (part >= 2 && part < 2 + s->nlev) {
+            int L = part - 2;
+            *ptr = s->lev[L]; *bytes = s->lev[L] ? s->lev_n[L] * (uint64_t)s->sigma * (uint64_t)s->lev_w[L] : 0; return 0;
+        }
+        return -1;
     }
     if (part == 0) { *ptr = s->blocks; *bytes = s->nblocks * s->stride; return 0; }
     if (part == 1) { *ptr = s->super; *bytes = s->nsuper * (uint64_t)s->sigma * 8; return 0; }
@@ -356,6 +489,8 @@ uint64_t ora_rank(const ora_string* s, uint64_t idx, uint64_t symb) {
         uint64_t b = idx >> 6, sb = idx / s->period, bit = idx & 63;
         return blk_count(s, b, symb) + POPC(shl64(eprv2_have(s, b, symb), 64 - bit)) + s->super[sb * sigma + symb];
     }
+    case FAM_EPRH:      /* EPRV3.h:205-213, EPRV4.h:128-142, EPRV5.h:126-139, InterleavedEPRV7.h:190-199 */
+        return eprh_counters(s, idx, symb) + POPC(shl64(eprh_have(s, idx >> 6, symb), 64 - (idx & 63)));
     default: {          /* Wavelet.h:104-119 */
         for (int b = 0; b < s->bitct; ++b) {
             int bit; uint64_t id; wavelet_step(s, symb, b, &bit, &id);
@@ -391,6 +526,11 @@ uint64_t ora_prefix_rank(const ora_string* s, uint64_t idx, uint64_t symb) {
         for (uint64_t i = 0; i < symb; ++i) { w |= eprv2_have(s, b, i); a += blk_count(s, b, i) + s->super[sb * sigma + i]; }
         return a + POPC(shl64(w, 64 - bit));
     }
+    case FAM_EPRH: {    /* EPRV3.h:215-227, EPRV4.h:144-160, EPRV5.h:141-157, InterleavedEPRV7.h:201-214 */
+        uint64_t w = 0, a = 0;
+        for (uint64_t i = 0; i < symb; ++i) { w |= eprh_have(s, idx >> 6, i); a += eprh_counters(s, idx, i); }
+        return a + POPC(shl64(w, 64 - (idx & 63)));
+    }
     default: {          /* Wavelet.h:121-141 */
         if (symb == 0) return 0;
         symb -= 1;
@@ -419,6 +559,11 @@ uint64_t ora_symbol(const ora_string* s, uint64_t idx) {
     case FAM_EPRV2: {              /* InterleavedEPRV2.h:191-195, :98-105 */
         uint64_t b = idx >> 6, bit = idx & 63, symb = 0;
         for (int i = s->bitct; i > 0; --i) symb = (symb << 1) | ((blk_word(s, b, (uint64_t)i - 1) >> bit) & 1);
+        return symb;
+    }
+    case FAM_EPRH: {               /* EPRV3.h:199-203, :45-52 */
+        uint64_t symb = 0;
+        for (int i = s->bitct; i > 0; --i) symb = (symb << 1) | ((eprh_word(s, idx >> 6, i - 1) >> (idx & 63)) & 1);
         return symb;
     }
     default: {                     /* Wavelet.h:77-102 */

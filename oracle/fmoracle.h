@@ -37,7 +37,11 @@ enum ora_layout {
     ORA_EPR8 = 5, ORA_EPR16 = 6, ORA_EPR32 = 7,              /* string/InterleavedEPR.h:222-227 */
     ORA_EPRV2_8 = 8, ORA_EPRV2_16 = 9, ORA_EPRV2_32 = 10,    /* string/InterleavedEPRV2.h:289-309 */
     ORA_WAVELET = 11,                                        /* string/Wavelet.h:27-28 */
-    ORA_LAYOUT_COUNT = 12
+    ORA_EPRV3_8 = 12, ORA_EPRV3_16 = 13, ORA_EPRV3_32 = 14,  /* string/EPRV3.h:263-272 */
+    ORA_EPRV4 = 15,                                          /* string/EPRV4.h:14 */
+    ORA_EPRV5 = 16,                                          /* string/EPRV5.h:14 */
+    ORA_IEPRV7 = 17,                                         /* string/InterleavedEPRV7.h:15 */
+    ORA_LAYOUT_COUNT = 18
 };
 
 /* ---------------------------------------------------------------- strings with rank support */
@@ -55,7 +59,9 @@ uint64_t    ora_symbol(const ora_string* s, uint64_t idx);
 void        ora_all_ranks_and_prefix_ranks(const ora_string* s, uint64_t idx, uint64_t* rs, uint64_t* prs);
 /* raw arrays in the reference's in-memory layout.
  * blocked layouts: part 0 = blocks, part 1 = superBlocks ([k][sigma] u64)
- * wavelet:         part node*4 + {0: superblocks u64, 1: blocks u8, 2: bits u64, 3: totalLength u64} */
+ * wavelet:         part node*4 + {0: superblocks u64, 1: blocks u8, 2: bits u64, 3: totalLength u64}
+ * EPRV3/4/5/7:     part 0 = bits (InBits per 64 rows; V7: the packed {bits, level0} structs), part 1 = superBlocks,
+ *                  part 2.. = counter levels bottom-up (V3: blocks_; V4: level0, level1, level2; V5: level0, level1; V7: level1 at part 3) */
 int         ora_string_raw(const ora_string* s, int part, const void** ptr, uint64_t* bytes);
 uint64_t    ora_string_block_stride(const ora_string* s);
 uint64_t    ora_string_bits_offset(const ora_string* s);

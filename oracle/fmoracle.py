@@ -18,7 +18,9 @@ LAYOUTS = {
     "IB8": 0, "IB16": 1, "IB32": 2, "IB16A": 3, "IBP16": 4,
     "EPR8": 5, "EPR16": 6, "EPR32": 7,
     "EPRV2_8": 8, "EPRV2_16": 9, "EPRV2_32": 10, "WAVELET": 11,
+    "EPRV3_8": 12, "EPRV3_16": 13, "EPRV3_32": 14, "EPRV4": 15, "EPRV5": 16, "IEPRV7": 17,
 }
+HIER_LAYOUTS = ("EPRV3_8", "EPRV3_16", "EPRV3_32", "EPRV4", "EPRV5", "IEPRV7")   # bit planes + counter levels in arrays of their own
 UINT64_MAX = (1 << 64) - 1
 
 u8p = C.POINTER(C.c_uint8)
@@ -165,8 +167,18 @@ class _StringBase:
         buf = (C.c_uint8 * nbytes.value).from_address(ptr.value)
         return np.frombuffer(buf, dtype=np.uint8).copy()
 
+    def level_fields(self):
+        """EPRV3/4/5/7: the raw arrays [bits, superBlocks, level0 / blocks_, level1, level2] (missing ones empty)"""
+        out = []
+        for part in range(5):
+            r = self.raw(part)
+            out.append(r if r is not None else np.zeros(0, dtype=np.uint8))
+        return out
+
     def block_fields(self):
         """blocked layouts: (counts [nblocks, sigma], words [nblocks, K] u64, superBlocks [k, sigma] u64)"""
+        if self.layout in HIER_LAYOUTS:
+            return tuple(self.level_fields())
         bt = {"IB8": 1, "IB16": 2, "IB32": 4, "IB16A": 2, "IBP16": 2, "EPR8": 1, "EPR16": 2, "EPR32": 4,
               "EPRV2_8": 1, "EPRV2_16": 2, "EPRV2_32": 4}[self.layout]
         stride = self.block_stride()

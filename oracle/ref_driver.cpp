@@ -17,6 +17,10 @@
 #include <string/InterleavedEPR.h>
 #include <string/InterleavedEPRV2.h>
 #include <string/Wavelet.h>
+#include <string/EPRV3.h>
+#include <string/EPRV4.h>
+#include <string/EPRV5.h>
+#include <string/InterleavedEPRV7.h>
 #include <bitvector/Bitvector.h>
 #include <search_scheme/generator/h2.h>
 #include <search_scheme/generator/pigeon.h>
@@ -41,6 +45,7 @@ enum Layout : int {
     L_EPR8 = 5, L_EPR16 = 6, L_EPR32 = 7,
     L_EPRV2_8 = 8, L_EPRV2_16 = 9, L_EPRV2_32 = 10,
     L_WAVELET = 11,
+    L_EPRV3_8 = 12, L_EPRV3_16 = 13, L_EPRV3_32 = 14, L_EPRV4 = 15, L_EPRV5 = 16, L_IEPRV7 = 17,
 };
 
 struct AnyString {
@@ -102,6 +107,34 @@ struct Wave : AnyString {
     uint64_t block_stride() const override { return 0; }
 };
 
+// EPRV3 / EPRV4 / EPRV5 / InterleavedEPRV7: part 0 = bits, 1 = superBlocks, 2.. = counter levels bottom-up
+template <typename S>
+struct Hier : AnyString {
+    S s;
+    explicit Hier(std::span<uint8_t const> t) : s{t} {}
+    uint64_t size() const override { return s.size(); }
+    uint64_t rank(uint64_t i, uint64_t c) const override { return s.rank(i, c); }
+    uint64_t prefix_rank(uint64_t i, uint64_t c) const override { return s.prefix_rank(i, c); }
+    uint64_t symbol(uint64_t i) const override { return s.symbol(i); }
+    void all_ranks_and_prefix_ranks(uint64_t i, uint64_t* rs, uint64_t* prs) const override {
+        auto [a, b] = s.all_ranks_and_prefix_ranks(i);
+        for (size_t k = 0; k < S::Sigma; ++k) { rs[k] = a[k]; prs[k] = b[k]; }
+    }
+    template <typename V>
+    static int give(V const& v, void const** ptr, uint64_t* bytes) { *ptr = v.data(); *bytes = v.size() * sizeof(v[0]); return 0; }
+    int raw(int part, void const** ptr, uint64_t* bytes) const override {
+        if (part == 0) return give(s.bits, ptr, bytes);
+        if (part == 1) return give(s.superBlocks, ptr, bytes);
+        if constexpr (requires { s.blocks_; }) { if (part == 2) return give(s.blocks_, ptr, bytes); }
+        if constexpr (requires { s.level0; }) { if (part == 2) return give(s.level0, ptr, bytes); }
+        else if (part == 2) { *ptr = nullptr; *bytes = 0; return 0; }
+        if constexpr (requires { s.level1; }) { if (part == 3) return give(s.level1, ptr, bytes); }
+        if constexpr (requires { s.level2; }) { if (part == 4) return give(s.level2, ptr, bytes); }
+        return -1;
+    }
+    uint64_t block_stride() const override { return sizeof(s.bits[0]); }
+};
+
 template <size_t Sigma>
 AnyString* make(int layout, std::span<uint8_t const> t) {
     using namespace fmc::string;
@@ -118,6 +151,12 @@ AnyString* make(int layout, std::span<uint8_t const> t) {
     case L_EPRV2_16: return new Blocked<InterleavedEPRV2_16<Sigma>>{t};
     case L_EPRV2_32: return new Blocked<InterleavedEPRV2_32<Sigma>>{t};
     case L_WAVELET:  return new Wave<Wavelet<Sigma>>{t};
+    case L_EPRV3_8:  return new Hier<EPRV3_8<Sigma>>{t};
+    case L_EPRV3_16: return new Hier<EPRV3_16<Sigma>>{t};
+    case L_EPRV3_32: return new Hier<EPRV3_32<Sigma>>{t};
+    case L_EPRV4:    return new Hier<EPRV4<Sigma>>{t};
+    case L_EPRV5:    return new Hier<EPRV5<Sigma>>{t};
+    case L_IEPRV7:   return new Hier<InterleavedEPRV7<Sigma>>{t};
     }
     return nullptr;
 }

@@ -110,6 +110,30 @@ int main() {
         });
         CHECK(found == reads.size());
     }
+    {   // the same reads through FMIndex<28, Wavelet> (exact) and BiFMIndex<5, EPRV5> (k = 1): other String types, same answers
+        auto text = std::vector<std::vector<uint8_t>>{std::vector<uint8_t>(600)};
+        uint64_t s = 7;
+        for (auto& c : text[0]) { s = s * 6364136223846793005ull + 1442695040888963407ull; c = 1 + (s >> 33) % 27; }
+        auto index = fmc::FMIndex<28, fmc::string::Wavelet>{text, 4, 1};
+        auto reads = std::vector<std::vector<uint8_t>>{};
+        for (size_t p = 0; p + 12 <= 600; p += 49) reads.emplace_back(text[0].begin() + p, text[0].begin() + p + 12);
+        size_t found = 0;
+        fmc::search_no_errors::search(index, reads, [&](size_t qidx, auto cursor) {
+            for (auto [sid, spos, offset] : fmc::LocateLinear{index, cursor}) if (sid == 0 && spos + offset == qidx * 49) ++found;
+        });
+        CHECK(found == reads.size());
+        for (auto& c : text[0]) c = 1 + c % 4;
+        auto bi = fmc::BiFMIndex<5, fmc::string::EPRV5>{text, 4, 1};
+        reads.clear();
+        for (size_t p = 0; p + 24 <= 600; p += 49) reads.emplace_back(text[0].begin() + p, text[0].begin() + p + 24);
+        reads[2][5] = reads[2][5] % 4 + 1;
+        found = 0;
+        fmc::search<false>(bi, reads, 1, [&](size_t qidx, auto cursor, size_t errors) {
+            for (auto [sid, spos, offset] : fmc::LocateLinear{bi, cursor})
+                if (sid == 0 && spos + offset == qidx * 49) { ++found; CHECK(errors == (qidx == 2 ? 1u : 0u)); }
+        });
+        CHECK(found == reads.size());
+    }
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "all checks passed", failures);
     return failures ? 1 : 0;
 }

@@ -148,7 +148,9 @@ def ref_vectors():
     cases = [("IB16", 5, 300), ("IB16", 5, 4100), ("IB8", 5, 600), ("IB32", 5, 200), ("IB16A", 5, 300), ("IBP16", 5, 700),
              ("EPR16", 5, 500), ("EPR8", 5, 504), ("EPR8", 5, 700), ("EPRV2_16", 5, 600), ("EPRV2_8", 5, 512), ("EPRV2_8", 5, 700),
              ("WAVELET", 5, 900), ("WAVELET", 28, 1200), ("IB16", 28, 400), ("EPR16", 28, 300), ("EPRV2_16", 28, 300),
-             ("IB16", 255, 310), ("WAVELET", 255, 310), ("IB16", 4, 257), ("EPRV2_16", 6, 129), ("IB16", 21, 200)]
+             ("IB16", 255, 310), ("WAVELET", 255, 310), ("IB16", 4, 257), ("EPRV2_16", 6, 129), ("IB16", 21, 200),
+             ("EPRV3_8", 5, 512), ("EPRV3_8", 5, 700), ("EPRV3_16", 5, 600), ("EPRV3_32", 5, 300), ("EPRV4", 5, 900), ("EPRV5", 5, 1024),
+             ("EPRV5", 28, 300), ("IEPRV7", 5, 777), ("IEPRV7", 28, 256), ("EPRV4", 255, 310), ("EPRV3_16", 6, 129)]
     for layout, sigma, n in cases:
         text = make_text(n, sigma, seed=n + sigma, lo=0)
         r = fo.RefString(layout, sigma, text)
@@ -158,7 +160,10 @@ def ref_vectors():
                  "rank_crc": zlib.crc32(rk.tobytes()), "prefix_rank_crc": zlib.crc32(pr.tobytes()),
                  "symbol_crc": zlib.crc32(np.array(sym, dtype=np.uint8).tobytes()),
                  "rank_last_row": rk[-1].tolist(), "prefix_last_row": pr[-1].tolist()}
-        if layout != "WAVELET":
+        if layout in fo.HIER_LAYOUTS:
+            entry["level_crc"] = [zlib.crc32(a.tobytes()) for a in r.level_fields()]
+            entry["level_bytes"] = [int(a.size) for a in r.level_fields()]
+        elif layout != "WAVELET":
             cnt, words, sup = r.block_fields()
             entry.update({"n_blocks": int(cnt.shape[0]), "n_super": int(sup.shape[0]),
                           "counts_crc": zlib.crc32(cnt.tobytes()), "words_crc": zlib.crc32(words.tobytes()), "super_crc": zlib.crc32(sup.tobytes())})

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 REF = json.load(open(os.path.join(GOLD, "reference_tests.json")))
-LAYOUTS = ["IB8", "IB16", "IB32", "IB16A", "IBP16", "EPR8", "EPR16", "EPR32", "EPRV2_8", "EPRV2_16", "EPRV2_32", "WAVELET"]
+LAYOUTS = ["IB8", "IB16", "IB32", "IB16A", "IBP16", "EPR8", "EPR16", "EPR32", "EPRV2_8", "EPRV2_16", "EPRV2_32", "WAVELET",
+           "EPRV3_8", "EPRV3_16", "EPRV3_32", "EPRV4", "EPRV5", "IEPRV7"]
 HIT_KEYS = ("qidx", "lb", "lb_rev", "len", "errors")
 
 
@@ -59,7 +60,7 @@ def mutated_queries(seqs, count, lo, hi, maxsub, seed, sigma=5):
 @pytest.mark.parametrize("sigma", [4, 5, 28, 255])
 def test_string_concept_all_layouts(layout, sigma):
     """rank / prefix_rank / symbol for every idx and symbol (string/concepts.h:50-64), sizes around block / super-block edges"""
-    for n in (1, 64, 65, 300, 1300):
+    for n in (1, 64, 65, 256, 300, 1300):
         if sigma == 255 and n > 300:
             continue
         text = make_text(n, sigma, seed=n + sigma, lo=0)
@@ -275,7 +276,8 @@ def test_scheme_search_variants():
         fm.search_ng26.search(fx, (qbuf, qoff), sch)
 
 
-@pytest.mark.parametrize("layout,sigma", [("IB16", 5), ("IBP16", 5), ("EPR16", 5), ("EPRV2_16", 5), ("WAVELET", 5), ("WAVELET", 28), ("IB16", 28), ("IB8", 6)])
+@pytest.mark.parametrize("layout,sigma", [("IB16", 5), ("IBP16", 5), ("EPR16", 5), ("EPRV2_16", 5), ("WAVELET", 5), ("WAVELET", 28), ("IB16", 28), ("IB8", 6),
+                                          ("EPRV5", 5), ("IEPRV7", 5), ("EPRV3_16", 28), ("EPRV4", 6)])
 def test_k_mismatch_other_layouts(layout, sigma):
     rng = np.random.default_rng(sigma)
     base = rng.integers(1, sigma, size=900, dtype=np.uint8)
@@ -472,8 +474,11 @@ def test_gpu_builder_other_alphabets_and_errors():
     with pytest.raises(fm.FmgpuError) as e:
         fm.FMIndex.from_sequences([[1, 7, 2]], 5)                 # symbol >= sigma
     assert e.value.code == capi.FMGPU_ERR_INVALID
-    with pytest.raises(fm.FmgpuError):
-        fm.FMIndex.from_sequences([[1, 2]], 5, "EPR16")            # builder lays out InterleavedBitvector* only
+    gx = fm.BiFMIndex.from_sequences(seqs, sigma, "EPRV5", 8)    # any blocked layout name: held as the block table on the device
+    assert gx.layout == "EPRV5"
+    sch = fm.search_scheme.h2(3, 0, 1)
+    ox = fo.OraIndex.build("EPRV5", sigma, seqs, 8, True)
+    assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch), ox.search_ng26(qbuf, qoff, sch)[0])
     with pytest.raises(fm.FmgpuError):
         fm.FMIndex.from_sequences([[1, 2]], 5, "IB16", 0)
 

@@ -73,7 +73,10 @@ def test_strings_against_real_reference_vectors(case):
     assert rk[-1].tolist() == case["rank_last_row"] and pr[-1].tolist() == case["prefix_last_row"]
     sym = np.array([s.symbol(i) for i in range(case["n"])], dtype=np.uint8)
     assert zlib.crc32(sym.tobytes()) == case["symbol_crc"] and np.array_equal(sym, text)
-    if case["layout"] != "WAVELET":
+    if case["layout"] in fo.HIER_LAYOUTS:
+        assert [zlib.crc32(a.tobytes()) for a in s.level_fields()] == case["level_crc"]
+        assert [int(a.size) for a in s.level_fields()] == case["level_bytes"]
+    elif case["layout"] != "WAVELET":
         assert s.block_stride() == case["block_stride"]
         cnt, words, sup = s.block_fields()
         assert (cnt.shape[0], sup.shape[0]) == (case["n_blocks"], case["n_super"])

@@ -47,6 +47,10 @@ def string_arrays(s):
         for k in range(nn):
             nodes.append((s.raw(4 * k).view("<u8"), s.raw(4 * k + 1), s.raw(4 * k + 2).view("<u8"), int(s.raw(4 * k + 3).view("<u8")[0])))
         d["nodes"] = nodes
+    elif s.layout in ("EPRV3_8", "EPRV3_16", "EPRV3_32", "EPRV4", "EPRV5", "IEPRV7"):
+        d["blocks"] = s.raw(0)                                   # String::bits
+        d["super_blocks"] = s.raw(1).view("<u8")
+        d["levels"] = [s.raw(2), s.raw(3), s.raw(4)]             # blocks_ / level0, level1, level2 (None or empty where absent)
     else:
         d["blocks"] = s.raw(0)
         d["super_blocks"] = s.raw(1).view("<u8")
