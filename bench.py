@@ -12,7 +12,8 @@ exact search.  `--workload k2` runs configs[2] (BiFMIndex, h2(4,0,2) search sche
 
 N > 1: launched by torch.distributed.run, one rank per GPU; the index is replicated, every rank searches its own
 batch (weak scaling: per-GPU work fixed), and the resulting SA intervals are gathered to rank 0 over RCCL inside
-the timed region — the path's only exchange step.
+the timed region — the path's only exchange step.  Result buffers are double-buffered so that the gather of step i
+crosses xGMI while the kernel of step i+1 runs; the last gather is drained before the closing barrier.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (executed LF steps x
 2 x sizeof(InterleavedBitvector16<5>::Block) = 112 B) / the search kernel's launch duration, measured with HIP
@@ -55,6 +56,9 @@ def parse():
                     "protein: 1 = block-table expansion of the wavelet (default), 0 = search the wavelet lines themselves")
     ap.add_argument("--no-search-accel", action="store_true", help="k2: no prefix / walk tables (fmgpu_index_accelerate_search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="rehearsal only: gloo runs the N > 1 control flow where RCCL cannot (all ranks on one card); results travel through host memory")
+    ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -71,13 +75,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.all_ranks_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     capi.check(capi.lib().fmgpu_set_device(local_rank))
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     # ---------------------------------------------------------------- synthetic inputs, generated in HBM
     protein = args.workload == "protein"
@@ -143,38 +152,65 @@ def main():
         del text
     torch.cuda.empty_cache()
 
-    out = torch.empty(2 * nq, dtype=torch.int64, device=dev)     # [lb | len], one buffer so that the gather sends it as is
-    out_lb, out_len = out[:nq], out[nq:]
+    # results are double-buffered: the gather of step i travels over xGMI while the kernel of step i+1 runs
+    outs = [torch.empty(2 * nq, dtype=torch.int64, device=dev) for _ in range(2 if world > 1 else 1)]   # [lb | len], one buffer so that the gather sends it as is
     scheme = fm.search_scheme.h2(4, 0, 2)
     hit_cap = 4 * nq
-    hits_buf = torch.empty(hit_cap * 40, dtype=torch.uint8, device=dev) if bidir else None
-    payload = out if not bidir else hits_buf[: 2 * nq * 40]      # k=2: the first 2*nq hit records (fixed-size message)
+    hits_bufs = [torch.empty(hit_cap * 40, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)] if bidir else None
+    via_host = world > 1 and args.dist_backend == "gloo"
+    count_dev = torch.zeros(1, dtype=torch.int64, device="cpu" if via_host else dev)
     gathered = None
-    if world > 1 and rank == 0:
-        gathered = [torch.empty_like(payload) for _ in range(world)]
+    if world > 1 and rank == 0:                               # k=2 messages are sized per step (largest hit count over the ranks), at most 2*nq records
+        full = 2 * nq * (40 if bidir else 8)
+        gathered = [[torch.empty(full, dtype=torch.uint8, device="cpu" if via_host else dev) for _ in range(world)] for _ in range(2)]
 
     import ctypes as C
     stats = capi.Stats()
     kernel_ms, units = [], []
+    pending = [None, None]
+    state = {"i": 0, "out": outs[0]}
 
     def step():
+        b = state["i"] % len(outs)
+        state["i"] += 1
+        if pending[b] is not None:                             # the buffer's previous gather must have left before it is overwritten
+            pending[b].wait(); pending[b] = None
+        out = outs[b]
+        state["out"] = out
         if not bidir:
             capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
-                                                     C.c_void_p(out_lb.data_ptr()), C.c_void_p(out_len.data_ptr()),
+                                                     C.c_void_p(out[:nq].data_ptr()), C.c_void_p(out[nq:].data_ptr()),
                                                      C.byref(stats), None))
         else:
             sc = _scheme_struct(capi, scheme)
             cnt = C.c_uint64()
             capi.check(capi.lib().fmgpu_search_scheme(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
-                                                      C.byref(sc[0]), capi.UINT64_MAX, C.c_void_p(hits_buf.data_ptr()), hit_cap,
+                                                      C.byref(sc[0]), capi.UINT64_MAX, C.c_void_p(hits_bufs[b].data_ptr()), hit_cap,
                                                       C.byref(cnt), C.byref(stats), None))
         kernel_ms.append(stats.kernel_ms)
         units.append(stats.lf_steps)
         if world > 1:                                          # the path's one exchange: SA intervals to rank 0 over RCCL/xGMI
-            dist.gather(payload, gathered, dst=0)
+            if bidir:
+                count_dev.fill_(int(cnt.value))
+                dist.all_reduce(count_dev, op=dist.ReduceOp.MAX)
+                m = (int(count_dev.item()) + 65535) // 65536 * 65536
+                if m > 2 * nq:
+                    raise SystemExit("more than 2 hits per read on average: raise the gather buffers")
+                payload = hits_bufs[b][: m * 40]
+            else:
+                payload = out.view(torch.uint8)
+            if via_host:
+                payload = payload.cpu()
+            pending[b] = dist.gather(payload, [g[: payload.numel()] for g in gathered[b]] if rank == 0 else None, dst=0, async_op=True)
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait(); pending[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     kernel_ms.clear(); units.clear()
     if world > 1:
         dist.barrier()
@@ -182,6 +218,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -202,6 +239,7 @@ def main():
     unit_bytes = 2 * 5 * 17 if protein else 2 * BLOCK_BYTES_IB16_S5      # Wavelet 2 x levels x (8 + 1 + 8) B per LF step
     alg_bytes = steps_per_launch * unit_bytes
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    out_lb, out_len = state["out"][:nq], state["out"][nq:]
     hits = int((out_len > 0).sum().item()) if not bidir else int(stats.hits)
     traffic, lines = None, None                               # HBM bytes / line requests per launch from the committed PMC passes
     try:
@@ -275,12 +313,12 @@ def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_le
     hq_all = qbuf.cpu().numpy()
     ho_all = qoff.cpu().numpy().astype(np.uint64)
 
-    def run(count):
+    def run(count, threads=cores):
         t0 = time.time()
         if not bidir:
-            r = ox.search_exact(hq_all[: count * L], ho_all[: count + 1], nthreads=cores)
+            r = ox.search_exact(hq_all[: count * L], ho_all[: count + 1], nthreads=threads)
         else:
-            r = ox.search_ng26(hq_all[: count * L], ho_all[: count + 1], scheme, nthreads=cores)
+            r = ox.search_ng26(hq_all[: count * L], ho_all[: count + 1], scheme, nthreads=threads)
         return r, time.time() - t0
 
     pilot = min(nq, 200_000 if not bidir else 50_000)
@@ -294,7 +332,10 @@ def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_le
                   np.array_equal(ln, out_len[:sample].cpu().numpy().astype(np.uint64)))
     else:
         ok = None                                             # (hit-by-hit parity of k-mismatch search is covered by tests/test_gpu_parity.py)
+    one = max(1000, min(sample, int(sample / dt * 3.0 / cores)))          # ~3 s on one thread (single-thread figure beside all cores)
+    _, dt1 = run(one, threads=1)
     return {"value": sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+            "single_thread": {"value": one / dt1, "unit": "queries/s", "sample": "the first %d reads, one thread" % one},
             "sample": "the first %d reads of the same batch, OpenMP over queries on all host cores; index rebuilt on the host from the "
                       "GPU-built BWT in %.0f s" % (sample, build),
             "seconds": dt, "gpu_results_match_on_sample": ok}
