@@ -45,8 +45,9 @@ def _u64(a):
 class _StringArrays:
     """host arrays of one reference String object, kept alive while the descriptor is in use"""
 
-    def __init__(self, layout, sigma, n, blocks=None, super_blocks=None, nodes=None, levels=None):
+    def __init__(self, layout, sigma, n, blocks=None, super_blocks=None, nodes=None, levels=None, super_row=None):
         self.layout, self.sigma, self.n = layout, sigma, n
+        self.super_row = super_row or sigma                      # entries per super-block row (FlattenedBitvectors2L::l0 has sigma + 1)
         # EPRV3/4/5/7: `blocks` = the bits array, `levels` = counter arrays bottom-up (None where the layout has none)
         self.levels = None if levels is None else [None if a is None else np.ascontiguousarray(a).view(np.uint8) for a in levels]
         self.blocks = None if blocks is None else np.ascontiguousarray(blocks).view(np.uint8)
@@ -63,7 +64,7 @@ class _StringArrays:
             d.blocks = self.blocks.ctypes.data
             d.blocks_bytes = self.blocks.nbytes
             d.super_blocks = self.super_blocks.ctypes.data_as(capi.u64p)
-            d.n_super_blocks = self.super_blocks.size // self.sigma
+            d.n_super_blocks = self.super_blocks.size // self.super_row
         if self.levels is not None:
             for k, a in enumerate(self.levels[:3]):
                 if a is not None and a.size:

@@ -16,6 +16,7 @@ LAYOUTS = {
     "EPR8": 5, "EPR16": 6, "EPR32": 7,
     "EPRV2_8": 8, "EPRV2_16": 9, "EPRV2_32": 10, "WAVELET": 11,
     "EPRV3_8": 12, "EPRV3_16": 13, "EPRV3_32": 14, "EPRV4": 15, "EPRV5": 16, "IEPRV7": 17,
+    "FBV_64_64K": 18, "FBV_512_64K": 19, "FBV_2048_64K": 20,
 }
 LAYOUT_NAMES = {v: k for k, v in LAYOUTS.items()}
 UINT64_MAX = (1 << 64) - 1

@@ -471,7 +471,7 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
     if (sampling_rate == 0) return fail(FMGPU_ERR_INVALID, "sampling_rate must be >= 1");
     // the layout names the reference type the caller replaces; on the device every blocked layout is held as the LF-ready block
     // table (Format A) and Wavelet as wavelet lines (Format W) — the answers of a String_c do not depend on its layout
-    if (layout < FMGPU_IB8 || layout > FMGPU_IEPRV7) return fail(FMGPU_ERR_INVALID, "unknown layout id");
+    if (layout < FMGPU_IB8 || layout > FMGPU_FBV_2048_64K) return fail(FMGPU_ERR_INVALID, "unknown layout id");
     hipStream_t stream = nullptr;
     Staged soff, sseq;
     int rc;

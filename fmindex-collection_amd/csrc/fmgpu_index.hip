@@ -208,6 +208,60 @@ static int create_hier(const fmgpu_string_desc& d, const idx_t* dC, DevString& s
     return 0;
 }
 
+// FlattenedBitvectors2L<sigma, l1_bits, 65536> -> Format A (FlattenedBitvectors2L.h:209-224): thread = (64-row block B, symbol c)
+__global__ __launch_bounds__(256) void k_convert_fbv(const uint8_t* __restrict__ bits, const uint64_t* __restrict__ l0, const uint16_t* __restrict__ l1,
+                                                     const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t nblocks, uint64_t n,
+                                                     uint32_t sigma, uint32_t bitct, uint32_t l1_bits, uint32_t bstride) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblocks * sigma) return;
+    const uint64_t B = t / sigma, row = B * 64, blk = row / l1_bits, sb = row >> 16;
+    const uint32_t c = (uint32_t)(t % sigma), w = (uint32_t)((row % l1_bits) / 64), sig1 = sigma + 1;
+    const uint8_t* base = bits + blk * ((uint64_t)bitct * l1_bits / 8);
+    auto have = [&](uint32_t word) -> uint64_t {
+        uint64_t m = ~0ull;
+        for (uint32_t i = 0; i < bitct; ++i) {
+            uint64_t v = *reinterpret_cast<const uint64_t*>(base + (uint64_t)i * (l1_bits / 8) + 8ull * word);
+            m &= v ^ (0ull - (uint64_t)((~c >> i) & 1u));
+        }
+        return m;
+    };
+    uint64_t cnt = l0[sb * sig1 + c + 1] - l0[sb * sig1 + c] + (uint64_t)l1[blk * sig1 + c + 1] - (uint64_t)l1[blk * sig1 + c];
+    for (uint32_t j = 0; j < w; ++j) cnt += (uint64_t)__popcll(have(j));
+    uint64_t m = have(w);
+    if (n - row < 64) m &= (1ull << (n - row)) - 1ull;
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + B * bstride + 12ull * c);
+    o[0] = (uint32_t)cnt + C[c]; o[1] = (uint32_t)m; o[2] = (uint32_t)(m >> 32);
+}
+
+static int create_fbv(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
+    const uint32_t sigma = (uint32_t)d.sigma, bitct = (uint32_t)bit_width_u((uint64_t)sigma - 1);
+    const uint32_t l1_bits = d.layout == FMGPU_FBV_64_64K ? 64u : (d.layout == FMGPU_FBV_512_64K ? 512u : 2048u);
+    const uint64_t nsuper = d.n / 65536 + 1, nl1 = nsuper * (65536 / l1_bits), stride = (uint64_t)bitct * l1_bits / 8, nblocks = d.n / 64 + 1;
+    if (!d.blocks || !d.super_blocks || !d.levels[0]) return fail(FMGPU_ERR_INVALID, "bits / l0 (super_blocks) / l1 (levels[0]) missing");
+    if (d.blocks_bytes < nl1 * stride) return fail(FMGPU_ERR_INVALID, "bits array too short for n rows (expected " + std::to_string(nl1 * stride) + " bytes)");
+    if (d.n_super_blocks < nsuper) return fail(FMGPU_ERR_INVALID, "too few l0 blocks for n rows");
+    if (d.level_bytes[0] < nl1 * (sigma + 1) * 2) return fail(FMGPU_ERR_INVALID, "l1 array too short for n rows");
+    void *db = nullptr, *d0 = nullptr, *d1 = nullptr;
+    auto drop = [&] { if (db) (void)hipFree(db); if (d0) (void)hipFree(d0); if (d1) (void)hipFree(d1); };
+    int rc = upload(d.blocks, nl1 * stride, &db); if (rc) { drop(); return rc; }
+    rc = upload(d.super_blocks, nsuper * (sigma + 1) * 8, &d0); if (rc) { drop(); return rc; }
+    rc = upload(d.levels[0], nl1 * (sigma + 1) * 2, &d1); if (rc) { drop(); return rc; }
+    const uint32_t bstride = sigma <= 5 ? 64u : 12u * sigma;
+    s.blk_bytes = nblocks * bstride + 64;
+    hipError_t e = hipMalloc(&s.blk, s.blk_bytes);
+    if (e != hipSuccess) { drop(); return hip_fail(e, "hipMalloc(format A)"); }
+    (void)hipMemset(s.blk, 0, s.blk_bytes);
+    const uint64_t threads = nblocks * sigma;
+    k_convert_fbv<<<dim3((unsigned)((threads + 255) / 256)), dim3(256)>>>((const uint8_t*)db, (const uint64_t*)d0, (const uint16_t*)d1, dC, (uint8_t*)s.blk,
+                                                                            nblocks, d.n, sigma, bitct, l1_bits, bstride);
+    e = hipDeviceSynchronize();
+    drop();
+    if (e != hipSuccess) return hip_fail(e, "k_convert_fbv");
+    s.family = FAM_A; s.bitct = (int)bitct;
+    s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC};
+    return 0;
+}
+
 static int upload(const void* host, size_t bytes, void** dev) {
     *dev = nullptr;
     if (bytes == 0) bytes = 8;
@@ -261,6 +315,10 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
     if (d.layout >= FMGPU_EPRV3_8 && d.layout <= FMGPU_IEPRV7) {
         s.layout = d.layout; s.sigma = d.sigma; s.n = d.n;
         return create_hier(d, dC, s);
+    }
+    if (d.layout >= FMGPU_FBV_64_64K && d.layout <= FMGPU_FBV_2048_64K) {
+        s.layout = d.layout; s.sigma = d.sigma; s.n = d.n;
+        return create_fbv(d, dC, s);
     }
     RefLayout L{};
     if (ref_layout(d.layout, d.sigma, L) != 0) return fail(FMGPU_ERR_INVALID, "unknown layout id");

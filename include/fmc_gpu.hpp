@@ -67,6 +67,9 @@ FMC_GPU_STRING_TAG(EPRV3_32, FMGPU_EPRV3_32)
 FMC_GPU_STRING_TAG(EPRV4, FMGPU_EPRV4)
 FMC_GPU_STRING_TAG(EPRV5, FMGPU_EPRV5)
 FMC_GPU_STRING_TAG(InterleavedEPRV7, FMGPU_IEPRV7)
+FMC_GPU_STRING_TAG(FlattenedBitvectors_64_64k, FMGPU_FBV_64_64K)
+FMC_GPU_STRING_TAG(FlattenedBitvectors_512_64k, FMGPU_FBV_512_64K)
+FMC_GPU_STRING_TAG(FlattenedBitvectors_2048_64k, FMGPU_FBV_2048_64K)
 #undef FMC_GPU_STRING_TAG
 }  // namespace string
 
@@ -112,11 +115,11 @@ struct GpuIndexBase {
     }
 };
 
-template <size_t TSigma, template <size_t> class String = string::InterleavedBitvector16>
+template <size_t TSigma, template <size_t> class String = string::FlattenedBitvectors_512_64k>   // fmindex/FMIndex.h:14
 struct FMIndex : GpuIndexBase<TSigma, String, false> {
     using GpuIndexBase<TSigma, String, false>::GpuIndexBase;
 };
-template <size_t TSigma, template <size_t> class String = string::InterleavedBitvector16>
+template <size_t TSigma, template <size_t> class String = string::FlattenedBitvectors_512_64k>   // fmindex/BiFMIndex.h:17
 struct BiFMIndex : GpuIndexBase<TSigma, String, true> {
     using GpuIndexBase<TSigma, String, true>::GpuIndexBase;
 };

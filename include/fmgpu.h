@@ -53,7 +53,8 @@ typedef enum fmgpu_layout {
     FMGPU_EPRV3_8 = 12, FMGPU_EPRV3_16 = 13, FMGPU_EPRV3_32 = 14,    /* EPRV3.h:263-272 */
     FMGPU_EPRV4 = 15,                                                /* EPRV4.h:14 */
     FMGPU_EPRV5 = 16,                                                /* EPRV5.h:14 */
-    FMGPU_IEPRV7 = 17                                                /* InterleavedEPRV7.h:15 */
+    FMGPU_IEPRV7 = 17,                                               /* InterleavedEPRV7.h:15 */
+    FMGPU_FBV_64_64K = 18, FMGPU_FBV_512_64K = 19, FMGPU_FBV_2048_64K = 20   /* FlattenedBitvectors2L.h:274-279; _512_64k is FMIndex's default String (fmindex/FMIndex.h:14) */
 } fmgpu_layout;
 
 /* One reference String object, described by the arrays it already holds in host memory.
@@ -62,7 +63,9 @@ typedef enum fmgpu_layout {
  * Wavelet:         `nodes` = bit_ceil(sigma) node descriptors = Wavelet::bitvector[i].{superblocks,blocks,bits,totalLength}.
  * EPRV3/4/5/7:     `blocks` = String::bits.data() (one InBits per 64 rows; V7: the packed {bits, level0} structs),
  *                  `super_blocks` = String::superBlocks.data(), `levels[]` = the counter arrays bottom-up:
- *                  EPRV3 {blocks_}, EPRV4 {level0, level1, level2}, EPRV5 {level0, level1}, InterleavedEPRV7 {NULL, level1}. */
+ *                  EPRV3 {blocks_}, EPRV4 {level0, level1, level2}, EPRV5 {level0, level1}, InterleavedEPRV7 {NULL, level1}.
+ * FlattenedBitvectors2L: `blocks` = String::bits.data() (bitct bitsets of l1_bits per block), `super_blocks` = String::l0.data()
+ *                  ([k][sigma+1] uint64, n_super_blocks = k), `levels[0]` = String::l1.data() ([k][sigma+1] uint16). */
 typedef struct fmgpu_wavelet_node {
     const uint64_t* superblocks; uint64_t n_superblocks;   /* bitvector/Bitvector.h:31 */
     const uint8_t*  blocks;      uint64_t n_blocks;        /* :32 */

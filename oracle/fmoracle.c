@@ -20,7 +20,7 @@ static uint64_t bit_ceil_u64(uint64_t v) { uint64_t r = 1; while (r < v) r <<= 1
 /* =====================================================================================
  * strings with rank support
  * ===================================================================================== */
-enum family { FAM_IB, FAM_IBP, FAM_EPR, FAM_EPRV2, FAM_WAVELET, FAM_EPRH };
+enum family { FAM_IB, FAM_IBP, FAM_EPR, FAM_EPRV2, FAM_WAVELET, FAM_EPRH, FAM_FBV };
 
 typedef struct ora_bitvector {               /* bitvector/Bitvector.h:30-179 */
     uint64_t* superblocks; uint64_t nsuper;  /* ones before bit 256k            */
@@ -52,6 +52,9 @@ struct ora_string {
     int nlev, lev_w[3], lev_shift[3], sshift, v3, v7;
     uint8_t* lev[3]; uint64_t lev_n[3];
     uint8_t* hbits; uint64_t hb_stride, hblocks;
+    /* FlattenedBitvectors2L<sigma, l1_bits, 65536>: hbits = InBits per l1_bits rows (bitct bitsets of l1_bits bits, plane-major),
+     * fl1 = u16 [nl1][sigma+1], super = u64 [nsuper][sigma+1]; entry [c] = number of symbols < c before the block */
+    uint64_t l1_bits; uint16_t* fl1; uint64_t nl1;
 };
 
 static uint64_t blk_count(const ora_string* s, uint64_t b, uint64_t c) {
@@ -141,6 +144,9 @@ static int layout_params(ora_string* s, int layout, int sigma) {
         s->family = FAM_EPRH; s->nlev = 2; s->lev_w[0] = 1; s->lev_w[1] = 2;
         s->lev_shift[0] = 6; s->lev_shift[1] = 8; s->sshift = 16; s->v7 = layout == ORA_IEPRV7;
         s->hb_stride = 8 * (uint64_t)s->bitct + (s->v7 ? (uint64_t)sigma : 0); return 0;
+    case ORA_FBV_64_64K: case ORA_FBV_512_64K: case ORA_FBV_2048_64K:   /* FlattenedBitvectors2L.h:23-36, :274-279 */
+        s->family = FAM_FBV; s->l1_bits = layout == ORA_FBV_64_64K ? 64 : (layout == ORA_FBV_512_64K ? 512 : 2048);
+        s->hb_stride = (uint64_t)s->bitct * s->l1_bits / 8; return 0;
     default: return -1;
     }
     uint64_t full = 1ull << (8 * s->bt);      /* 2^(8*sizeof(block_t)) */
@@ -381,6 +387,58 @@ static uint64_t eprh_counters(const ora_string* s, uint64_t idx, uint64_t c) {
     return a;
 }
 
+/* ---- FlattenedBitvectors2L ---------------------------------------------------------------- */
+static uint64_t fbv_word(const ora_string* s, uint64_t blk, int plane, uint64_t w) {
+    uint64_t v; memcpy(&v, s->hbits + blk * s->hb_stride + (uint64_t)plane * (s->l1_bits / 8) + 8 * w, 8); return v;
+}
+static uint64_t fbv_have(const ora_string* s, uint64_t blk, uint64_t w, uint64_t symb) {      /* ternarylogic.h:731-744 mark_exact_large */
+    uint64_t r = ~0ull;
+    for (int i = 0; i < s->bitct; ++i) r &= fbv_word(s, blk, i, w) ^ (0 - ((~symb >> i) & 1));
+    return r;
+}
+static void build_fbv(ora_string* s, const uint8_t* t, uint64_t n) {      /* FlattenedBitvectors2L.h:131-192 */
+    const uint64_t sig1 = (uint64_t)s->sigma + 1, per = 65536 / s->l1_bits;
+    s->nsuper = n / 65536 + 1;
+    s->nl1 = s->hblocks = s->nsuper * per;
+    s->hbits = calloc(s->hblocks * s->hb_stride + 8, 1);
+    s->fl1 = calloc(s->nl1 * sig1, 2);
+    s->super = calloc(s->nsuper * sig1, 8);
+    for (uint64_t i = 0; i < n; ++i)                                        /* InBits::setSymbol, :76-82 */
+        for (int j = 0; j < s->bitct; ++j) {
+            uint8_t* p = s->hbits + (i / s->l1_bits) * s->hb_stride + (uint64_t)j * (s->l1_bits / 8) + ((i % s->l1_bits) / 64) * 8;
+            uint64_t v; memcpy(&v, p, 8); v |= (uint64_t)((t[i] >> j) & 1) << (i & 63); memcpy(p, &v, 8);
+        }
+    uint64_t* l0acc = calloc(sig1, 8); uint64_t* acc = calloc(sig1, 8);
+    for (uint64_t sb = 0; sb < s->nsuper; ++sb) {
+        memcpy(s->super + sb * sig1, l0acc, sig1 * 8);
+        memset(acc, 0, sig1 * 8);
+        for (uint64_t i = 0; i < per; ++i) {
+            uint64_t blk = sb * per + i;
+            for (uint64_t c = 0; c < sig1; ++c) s->fl1[blk * sig1 + c] = (uint16_t)acc[c];
+            uint64_t a = 0;                                                 /* all_ranks(l1_bits): the unused tail of the last block counts as symbol 0 */
+            for (uint64_t c = 0; c + 1 < sig1; ++c) {
+                uint64_t cnt = 0;
+                for (uint64_t w = 0; w < s->l1_bits / 64; ++w) cnt += POPC(fbv_have(s, blk, w, c));
+                a += cnt; acc[c + 1] += a;
+            }
+        }
+        for (uint64_t c = 0; c < sig1; ++c) l0acc[c] += acc[c];
+    }
+    free(l0acc); free(acc);
+}
+/* positions < bit of block `blk` holding a symbol for which pred: exact == 1: symbol == symb, else symbol < symb */
+static uint64_t fbv_inblock(const ora_string* s, uint64_t blk, uint64_t bit, uint64_t symb, int exact) {
+    uint64_t r = 0;
+    for (uint64_t w = 0; w * 64 < bit; ++w) {
+        uint64_t m = 0;
+        if (exact) m = fbv_have(s, blk, w, symb);
+        else for (uint64_t d = 0; d < symb; ++d) m |= fbv_have(s, blk, w, d);
+        uint64_t k = bit - w * 64;
+        r += POPC(k >= 64 ? m : (m & ((1ull << k) - 1)));
+    }
+    return r;
+}
+
 ora_string* ora_string_build(int layout, int sigma, const uint8_t* symbols, uint64_t n) {
     if (sigma < 2 || sigma > 256) return NULL;
     for (uint64_t i = 0; i < n; ++i) if (symbols[i] >= sigma) return NULL;
@@ -394,6 +452,7 @@ ora_string* ora_string_build(int layout, int sigma, const uint8_t* symbols, uint
     case FAM_EPRV2:   build_eprv2(s, symbols, n); break;
     case FAM_WAVELET: build_wavelet(s, symbols, n); break;
     case FAM_EPRH:    build_eprh(s, symbols, n); break;
+    case FAM_FBV:     build_fbv(s, symbols, n); break;
     }
     return s;
 }
@@ -401,7 +460,7 @@ ora_string* ora_string_build(int layout, int sigma, const uint8_t* symbols, uint
 void ora_string_free(ora_string* s) {
     if (!s) return;
     free(s->blocks); free(s->super); free(s->rb);
-    free(s->hbits); free(s->lev[0]); free(s->lev[1]); free(s->lev[2]);
+    free(s->hbits); free(s->lev[0]); free(s->lev[1]); free(s->lev[2]); free(s->fl1);
     if (s->node) {
         for (uint64_t i = 0; i < s->nnodes; ++i) { free(s->node[i].superblocks); free(s->node[i].blocks); free(s->node[i].bits); }
         free(s->node);
@@ -425,6 +484,12 @@ int ora_string_raw(const ora_string* s, int part, const void** ptr, uint64_t* by
         case 2: *ptr = v->bits;        *bytes = v->nbits * 8; return 0;
         default: *ptr = &v->totalLength; *bytes = 8; return 0;
         }
+    }
+    if (s->family == FAM_FBV) {
+        if (part == 0) { *ptr = s->hbits; *bytes = s->hblocks * s->hb_stride; return 0; }
+        if (part == 1) { *ptr = s->super; *bytes = s->nsuper * ((uint64_t)s->sigma + 1) * 8; return 0; }
+        if (part == 2) { *ptr = s->fl1; *bytes = s->nl1 * ((uint64_t)s->sigma + 1) * 2; return 0; }
+        return -1;
     }
     if (s->family == FAM_EPRH) {
         if (part == 0) { *ptr = s->hbits; *bytes = s->hblocks * s->hb_stride; return 0; }
@@ -489,6 +554,11 @@ uint64_t ora_rank(const ora_string* s, uint64_t idx, uint64_t symb) {
         uint64_t b = idx >> 6, sb = idx / s->period, bit = idx & 63;
         return blk_count(s, b, symb) + POPC(shl64(eprv2_have(s, b, symb), 64 - bit)) + s->super[sb * sigma + symb];
     }
+    case FAM_FBV: {     /* FlattenedBitvectors2L.h:209-224 */
+        uint64_t blk = idx / s->l1_bits, sb = idx / 65536, sig1 = sigma + 1;
+        return s->super[sb * sig1 + symb + 1] + s->fl1[blk * sig1 + symb + 1] + fbv_inblock(s, blk, idx % s->l1_bits, symb, 1)
+             - s->super[sb * sig1 + symb] - s->fl1[blk * sig1 + symb];
+    }
     case FAM_EPRH:      /* EPRV3.h:205-213, EPRV4.h:128-142, EPRV5.h:126-139, InterleavedEPRV7.h:190-199 */
         return eprh_counters(s, idx, symb) + POPC(shl64(eprh_have(s, idx >> 6, symb), 64 - (idx & 63)));
     default: {          /* Wavelet.h:104-119 */
@@ -526,6 +596,10 @@ uint64_t ora_prefix_rank(const ora_string* s, uint64_t idx, uint64_t symb) {
         for (uint64_t i = 0; i < symb; ++i) { w |= eprv2_have(s, b, i); a += blk_count(s, b, i) + s->super[sb * sigma + i]; }
         return a + POPC(shl64(w, 64 - bit));
     }
+    case FAM_FBV: {     /* FlattenedBitvectors2L.h:226-239 */
+        uint64_t blk = idx / s->l1_bits, sb = idx / 65536, sig1 = sigma + 1;
+        return fbv_inblock(s, blk, idx % s->l1_bits, symb, 0) + s->super[sb * sig1 + symb] + s->fl1[blk * sig1 + symb];
+    }
     case FAM_EPRH: {    /* EPRV3.h:215-227, EPRV4.h:144-160, EPRV5.h:141-157, InterleavedEPRV7.h:201-214 */
         uint64_t w = 0, a = 0;
         for (uint64_t i = 0; i < symb; ++i) { w |= eprh_have(s, idx >> 6, i); a += eprh_counters(s, idx, i); }
@@ -559,6 +633,11 @@ uint64_t ora_symbol(const ora_string* s, uint64_t idx) {
     case FAM_EPRV2: {              /* InterleavedEPRV2.h:191-195, :98-105 */
         uint64_t b = idx >> 6, bit = idx & 63, symb = 0;
         for (int i = s->bitct; i > 0; --i) symb = (symb << 1) | ((blk_word(s, b, (uint64_t)i - 1) >> bit) & 1);
+        return symb;
+    }
+    case FAM_FBV: {                /* FlattenedBitvectors2L.h:197-206, :41-50 */
+        uint64_t symb = 0, blk = idx / s->l1_bits, bit = idx % s->l1_bits;
+        for (int i = s->bitct; i > 0; --i) symb = (symb << 1) | ((fbv_word(s, blk, i - 1, bit / 64) >> (bit & 63)) & 1);
         return symb;
     }
     case FAM_EPRH: {               /* EPRV3.h:199-203, :45-52 */

@@ -41,7 +41,8 @@ enum ora_layout {
     ORA_EPRV4 = 15,                                          /* string/EPRV4.h:14 */
     ORA_EPRV5 = 16,                                          /* string/EPRV5.h:14 */
     ORA_IEPRV7 = 17,                                         /* string/InterleavedEPRV7.h:15 */
-    ORA_LAYOUT_COUNT = 18
+    ORA_FBV_64_64K = 18, ORA_FBV_512_64K = 19, ORA_FBV_2048_64K = 20,   /* string/FlattenedBitvectors2L.h:274-279 (512_64k: the default String of FMIndex, fmindex/FMIndex.h:14) */
+    ORA_LAYOUT_COUNT = 21
 };
 
 /* ---------------------------------------------------------------- strings with rank support */
@@ -61,7 +62,10 @@ void        ora_all_ranks_and_prefix_ranks(const ora_string* s, uint64_t idx, ui
  * blocked layouts: part 0 = blocks, part 1 = superBlocks ([k][sigma] u64)
  * wavelet:         part node*4 + {0: superblocks u64, 1: blocks u8, 2: bits u64, 3: totalLength u64}
  * EPRV3/4/5/7:     part 0 = bits (InBits per 64 rows; V7: the packed {bits, level0} structs), part 1 = superBlocks,
- *                  part 2.. = counter levels bottom-up (V3: blocks_; V4: level0, level1, level2; V5: level0, level1; V7: level1 at part 3) */
+ *                  part 2.. = counter levels bottom-up (V3: blocks_; V4: level0, level1, level2; V5: level0, level1; V7: level1 at part 3)
+ * FlattenedBitvectors2L: part 0 = bits (bitct bitsets of l1_bits per block), part 1 = l0 ([k][sigma+1] u64), part 2 = l1 ([k][sigma+1] u16).
+ *                  This header includes ../utils.h (libsais, mmser) and cannot be compiled here: the array layout is restated from the
+ *                  source text and pinned only through the reference's String unit-test vectors (values, not bytes). */
 int         ora_string_raw(const ora_string* s, int part, const void** ptr, uint64_t* bytes);
 uint64_t    ora_string_block_stride(const ora_string* s);
 uint64_t    ora_string_bits_offset(const ora_string* s);

@@ -19,8 +19,10 @@ LAYOUTS = {
     "EPR8": 5, "EPR16": 6, "EPR32": 7,
     "EPRV2_8": 8, "EPRV2_16": 9, "EPRV2_32": 10, "WAVELET": 11,
     "EPRV3_8": 12, "EPRV3_16": 13, "EPRV3_32": 14, "EPRV4": 15, "EPRV5": 16, "IEPRV7": 17,
+    "FBV_64_64K": 18, "FBV_512_64K": 19, "FBV_2048_64K": 20,
 }
-HIER_LAYOUTS = ("EPRV3_8", "EPRV3_16", "EPRV3_32", "EPRV4", "EPRV5", "IEPRV7")   # bit planes + counter levels in arrays of their own
+REF_UNBUILDABLE = ("FBV_64_64K", "FBV_512_64K", "FBV_2048_64K")    # FlattenedBitvectors2L.h includes ../utils.h (libsais / mmser): no live reference
+HIER_LAYOUTS = ("EPRV3_8", "EPRV3_16", "EPRV3_32", "EPRV4", "EPRV5", "IEPRV7", "FBV_64_64K", "FBV_512_64K", "FBV_2048_64K")   # bit planes + counter levels in arrays of their own
 UINT64_MAX = (1 << 64) - 1
 
 u8p = C.POINTER(C.c_uint8)

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 REF = json.load(open(os.path.join(GOLD, "reference_tests.json")))
 LAYOUTS = ["IB8", "IB16", "IB32", "IB16A", "IBP16", "EPR8", "EPR16", "EPR32", "EPRV2_8", "EPRV2_16", "EPRV2_32", "WAVELET",
-           "EPRV3_8", "EPRV3_16", "EPRV3_32", "EPRV4", "EPRV5", "IEPRV7"]
+           "EPRV3_8", "EPRV3_16", "EPRV3_32", "EPRV4", "EPRV5", "IEPRV7", "FBV_64_64K", "FBV_512_64K", "FBV_2048_64K"]
 HIT_KEYS = ("qidx", "lb", "lb_rev", "len", "errors")
 
 
@@ -277,7 +277,7 @@ def test_scheme_search_variants():
 
 
 @pytest.mark.parametrize("layout,sigma", [("IB16", 5), ("IBP16", 5), ("EPR16", 5), ("EPRV2_16", 5), ("WAVELET", 5), ("WAVELET", 28), ("IB16", 28), ("IB8", 6),
-                                          ("EPRV5", 5), ("IEPRV7", 5), ("EPRV3_16", 28), ("EPRV4", 6)])
+                                          ("EPRV5", 5), ("IEPRV7", 5), ("EPRV3_16", 28), ("EPRV4", 6), ("FBV_512_64K", 5), ("FBV_2048_64K", 28)])
 def test_k_mismatch_other_layouts(layout, sigma):
     rng = np.random.default_rng(sigma)
     base = rng.integers(1, sigma, size=900, dtype=np.uint8)

@@ -47,6 +47,11 @@ def string_arrays(s):
         for k in range(nn):
             nodes.append((s.raw(4 * k).view("<u8"), s.raw(4 * k + 1), s.raw(4 * k + 2).view("<u8"), int(s.raw(4 * k + 3).view("<u8")[0])))
         d["nodes"] = nodes
+    elif s.layout.startswith("FBV_"):
+        d["blocks"] = s.raw(0)                                   # String::bits
+        d["super_blocks"] = s.raw(1).view("<u8")                 # String::l0, [k][sigma + 1]
+        d["levels"] = [s.raw(2), None, None]                     # String::l1
+        d["super_row"] = s.sigma + 1
     elif s.layout in ("EPRV3_8", "EPRV3_16", "EPRV3_32", "EPRV4", "EPRV5", "IEPRV7"):
         d["blocks"] = s.raw(0)                                   # String::bits
         d["super_blocks"] = s.raw(1).view("<u8")
