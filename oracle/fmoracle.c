@@ -1125,6 +1125,191 @@ uint64_t ora_search_ng26_hamming(const ora_index* x, const uint8_t* qbuf, const 
     return total;
 }
 
+/* ---- search_ng26<Edit> (search/SearchNg26.h:18-366), the whole state machine incl. the Edit = true branches ----------
+ * Separate from the Hamming reduction above on purpose: ng_* stays the pinned restatement of SURVEY appendix A, nge_* follows
+ * the header line by line (State :41-53) and must agree with it for edit == 0 (tests/test_oracle_golden.py). */
+typedef struct nge_state {
+    ora_cursor cur;
+    uint8_t lastRank[2], lastQRank[2];      /* side[0] = left, side[1] = right (:36-39, indexed by state.Right) */
+    uint64_t e, part, pev, qL, qR;
+    char LInfo, RInfo;
+    int Right, NextPos;
+} nge_state;
+typedef struct nge_search { ng_search b; int edit; } nge_search;
+
+static int nge_next(const nge_search* s, nge_state st);
+static int nge_dir(const nge_search* s, nge_state st);
+static int nge_single(const nge_search* s, nge_state st);
+
+static ora_cursor nge_extend(const nge_search* s, const nge_state* st, uint64_t c) {
+    s->b.e->nodes++;
+    return st->Right ? ora_extend_right(s->b.x, st->cur, c) : ora_extend_left(s->b.x, st->cur, c);
+}
+static int nge_next(const nge_search* s, nge_state st) {          /* search_next, :98-117 */
+    const ng_search* b = &s->b;
+    if (st.cur.len == 0) return 0;
+    if (st.part == (uint64_t)b->P) {
+        if (!s->edit || ((st.LInfo == 'M' || st.LInfo == 'I') && (st.RInfo == 'M' || st.RInfo == 'I')))
+            if (b->l[b->P - 1] <= st.e && st.e <= b->u[b->P - 1]) return ng_report(b, st.cur, st.e);
+        return 0;
+    }
+    st.Right = (st.part == 0) || (b->pi[st.part - 1] < b->pi[st.part]);
+    return st.cur.len > 1 ? nge_dir(s, st) : nge_single(s, st);
+}
+static int nge_pos(const nge_search* s, nge_state st) {           /* search_next_pos, :119-141 */
+    const ng_search* b = &s->b;
+    if (st.cur.len == 0) return 0;
+    if (st.NextPos) {
+        if (st.Right) st.qR += 1; else st.qL -= 1;
+        st.pev -= 1;
+        if (st.pev == 0) {
+            st.part += 1;
+            if (st.part != (uint64_t)b->P) st.pev = b->part[b->pi[st.part]];
+            return nge_next(s, st);
+        }
+    }
+    return st.cur.len > 1 ? nge_dir(s, st) : nge_single(s, st);
+}
+static int nge_no_errors(const nge_search* s, nge_state st) {     /* search_next_dir_no_errors, :225-250 */
+    const ng_search* b = &s->b;
+    uint64_t loops = st.pev, c = 0;
+    for (uint64_t i = 0; i < loops; ++i) {
+        c = b->q[st.Right ? st.qR + i : st.qL - i];
+        st.cur = nge_extend(s, &st, c);
+        if (st.cur.len == 0) return 0;
+    }
+    st.lastRank[st.Right] = (uint8_t)c; st.lastQRank[st.Right] = (uint8_t)c;
+    st.part += 1; st.pev = 0;
+    if (st.part != (uint64_t)b->P) st.pev = b->part[b->pi[st.part]];
+    if (st.Right) { st.qR += loops; st.RInfo = 'M'; } else { st.qL -= loops; st.LInfo = 'M'; }
+    return nge_next(s, st);
+}
+#define NGE_INFO(n, kind) do { if (st.Right) (n).RInfo = (kind); else (n).LInfo = (kind); } while (0)   /* OnMatchL/R ... :149-156 */
+static int nge_dir(const nge_search* s, nge_state st) {           /* search_next_dir, :143-224 */
+    const ng_search* b = &s->b;
+    const char T = st.Right ? st.RInfo : st.LInfo;
+    const int Deletion = (T != 'S' && T != 'I') && s->edit, Insertion = (T != 'S' && T != 'D') && s->edit;
+    const uint64_t c = b->q[st.Right ? st.qR : st.qL];
+    const int mOK = (st.pev > 1 || b->l[st.part] <= st.e) && st.e <= b->u[st.part]
+                    && (T != 'I' || c != st.lastQRank[st.Right]) && (T != 'D' || c != st.lastRank[st.Right]);
+    const int iOK = (st.pev > 1 || b->l[st.part] <= st.e + 1) && st.e + 1 <= b->u[st.part];
+    const int sOK = iOK, xOK = st.e + 1 <= b->u[st.part];
+    if (xOK) {
+        ora_cursor kids[256];
+        b->e->nodes++;
+        if (st.Right) ora_extend_right_all(b->x, st.cur, kids); else ora_extend_left_all(b->x, st.cur, kids);
+        if (mOK) {
+            nge_state n = st; n.cur = kids[c]; n.lastRank[st.Right] = (uint8_t)c; n.lastQRank[st.Right] = (uint8_t)c;
+            NGE_INFO(n, 'M'); n.NextPos = 1;
+            if (nge_pos(s, n)) return 1;
+        }
+        for (uint64_t i = 1 /* FirstSymb */; i < (uint64_t)b->x->sigma; ++i) {
+            nge_state n = st; n.e = st.e + 1; n.cur = kids[i]; n.lastRank[st.Right] = (uint8_t)i;
+            if (Deletion) { NGE_INFO(n, 'D'); n.NextPos = 0; if (nge_pos(s, n)) return 1; }
+            if (!sOK) continue;
+            if (i == c) continue;
+            n.lastQRank[st.Right] = (uint8_t)c; NGE_INFO(n, 'S'); n.NextPos = 1;
+            if (nge_pos(s, n)) return 1;
+        }
+        if (Insertion && iOK) {
+            nge_state n = st; n.e = st.e + 1; n.lastQRank[st.Right] = (uint8_t)c; NGE_INFO(n, 'I'); n.NextPos = 1;
+            if (nge_pos(s, n)) return 1;
+        }
+    } else if (mOK) {
+        if (nge_no_errors(s, st)) return 1;
+    }
+    return 0;
+}
+static int nge_single(const nge_search* s, nge_state st) {        /* search_next_dir_single, :251-365 */
+    const ng_search* b = &s->b;
+    const char T = st.Right ? st.RInfo : st.LInfo;
+    const int Deletion = (T != 'S' && T != 'I') && s->edit, Insertion = (T != 'S' && T != 'D') && s->edit;
+    const uint64_t bs = st.Right ? ora_symbol(b->x->bwt_rev, st.cur.lb_rev) : ora_symbol(b->x->bwt, st.cur.lb);
+    const ora_cursor nx = nge_extend(s, &st, bs);
+    const uint64_t c = b->q[st.Right ? st.qR : st.qL];
+    const int iOK = (st.pev > 1 || b->l[st.part] <= st.e + 1) && st.e + 1 <= b->u[st.part];
+    const int sOK = iOK, xOK = st.e + 1 <= b->u[st.part];
+    if (Insertion && iOK) {
+        nge_state n = st; n.e = st.e + 1; n.lastQRank[st.Right] = (uint8_t)c; NGE_INFO(n, 'I'); n.NextPos = 1;
+        if (nge_pos(s, n)) return 1;
+    }
+    if (bs < 1 /* FirstSymb */) return 0;
+    const int mOK = (st.pev > 1 || b->l[st.part] <= st.e) && st.e <= b->u[st.part]
+                    && (T != 'I' || c != st.lastQRank[st.Right]) && (T != 'D' || c != st.lastRank[st.Right]);
+    if (bs == c) {
+        if (mOK) {
+            if (!xOK) return nge_no_errors(s, st);
+            nge_state n = st; n.lastRank[st.Right] = (uint8_t)c; n.lastQRank[st.Right] = (uint8_t)c; n.cur = nx;
+            NGE_INFO(n, 'M'); n.NextPos = 1;
+            if (nge_pos(s, n)) return 1;
+        }
+        if (Deletion && xOK) {
+            nge_state n = st; n.e = st.e + 1; n.lastRank[st.Right] = (uint8_t)bs; n.cur = nx; NGE_INFO(n, 'D'); n.NextPos = 0;
+            if (nge_pos(s, n)) return 1;
+        }
+    } else if (xOK) {
+        nge_state n = st; n.e = st.e + 1; n.lastRank[st.Right] = (uint8_t)bs; n.cur = nx;
+        if (sOK) {
+            nge_state m = n; m.lastQRank[st.Right] = (uint8_t)c; NGE_INFO(m, 'S'); m.NextPos = 1;       /* Restore{} :341 */
+            if (nge_pos(s, m)) return 1;
+        }
+        if (Deletion) { NGE_INFO(n, 'D'); n.NextPos = 0; if (nge_pos(s, n)) return 1; }
+    }
+    return 0;
+}
+static int nge_run(const nge_search* s) {                          /* run, :62-79 */
+    const ng_search* b = &s->b;
+    nge_state st; memset(&st, 0, sizeof st);
+    for (uint64_t i = 0; i < b->pi[0]; ++i) { st.qL += b->part[i]; st.qR += b->part[i]; }
+    st.qL -= 1;
+    st.pev = b->part[b->pi[0]];
+    st.cur = ora_cursor_init(b->x);
+    st.LInfo = 'M'; st.RInfo = 'M';
+    return nge_next(s, st);
+}
+
+uint64_t ora_search_ng26(const ora_index* x, int edit, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                         int nsearch, int nparts, const uint64_t* pi, const uint64_t* l, const uint64_t* u,
+                         const uint64_t* partition, uint64_t max_hits_per_query,
+                         ora_hit* out, uint64_t cap, uint64_t* out_qcount, uint64_t* out_nodes, int nthreads) {
+    if (!x->bidirectional || nq == 0 || max_hits_per_query == 0) { if (out_nodes) *out_nodes = 0; return 0; }
+    int T = nthreads > 0 ? nthreads : 1;
+    uint64_t total = 0, total_nodes = 0;
+    if (T == 1) {
+        emit_ctx e = {out, cap, 0, 0, 0, 0};
+        for (uint64_t q = 0; q < nq; ++q) {
+            uint64_t before = e.count, part_buf[64];
+            uint64_t m = qoff[q + 1] - qoff[q];
+            const uint64_t* part = partition;
+            if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
+            e.qidx = q; e.quota = max_hits_per_query;
+            for (int si = 0; si < nsearch; ++si) {
+                nge_search s = {{x, qbuf + qoff[q], m, nparts, pi + si * nparts, l + si * nparts, u + si * nparts, part, &e}, edit};
+                if (nge_run(&s)) break;
+            }
+            if (out_qcount) out_qcount[q] = e.count - before;
+        }
+        total = e.count; total_nodes = e.nodes;
+    } else {
+        #pragma omp parallel for schedule(dynamic, 64) num_threads(T) reduction(+:total, total_nodes)
+        for (int64_t q = 0; q < (int64_t)nq; ++q) {
+            emit_ctx e = {NULL, 0, 0, (uint64_t)q, 0, max_hits_per_query};
+            uint64_t part_buf[64];
+            uint64_t m = qoff[q + 1] - qoff[q];
+            const uint64_t* part = partition;
+            if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
+            for (int si = 0; si < nsearch; ++si) {
+                nge_search s = {{x, qbuf + qoff[q], m, nparts, pi + si * nparts, l + si * nparts, u + si * nparts, part, &e}, edit};
+                if (nge_run(&s)) break;
+            }
+            if (out_qcount) out_qcount[q] = e.count;
+            total += e.count; total_nodes += e.nodes;
+        }
+    }
+    if (out_nodes) *out_nodes = total_nodes;
+    return total;
+}
+
 /* =====================================================================================
  * search schemes
  * ===================================================================================== */

@@ -144,6 +144,12 @@ uint64_t ora_search_ng26_hamming(const ora_index* x, const uint8_t* qbuf, const 
                                  const uint64_t* partition /* nparts, or NULL = uniform per query length */,
                                  uint64_t max_hits_per_query,
                                  ora_hit* out, uint64_t cap, uint64_t* out_qcount, uint64_t* out_nodes, int nthreads);
+/* search_ng26::search<Edit> (search/SearchNg26.h:18-366, :407-433) with both values of Edit: edit != 0 adds insertions / deletions
+ * (the :146-218 and :286-362 branches).  For edit == 0 it must equal ora_search_ng26_hamming. */
+uint64_t ora_search_ng26(const ora_index* x, int edit, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                         int nsearch, int nparts, const uint64_t* pi, const uint64_t* l, const uint64_t* u,
+                         const uint64_t* partition, uint64_t max_hits_per_query,
+                         ora_hit* out, uint64_t cap, uint64_t* out_qcount, uint64_t* out_nodes, int nthreads);
 
 /* ---------------------------------------------------------------- search schemes (flattened [search][part]) */
 int  ora_scheme_h2(uint64_t N, uint64_t minK, uint64_t K, uint64_t* pi, uint64_t* l, uint64_t* u);           /* search_scheme/generator/h2.h:128-153; returns #searches (K+1), parts = N */

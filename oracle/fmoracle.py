@@ -122,6 +122,9 @@ def lib():
         L.ora_search_ng26_hamming.argtypes = [C.POINTER(IndexStruct), u8p, u64p, C.c_uint64, C.c_int, C.c_int,
                                               u64p, u64p, u64p, u64p, C.c_uint64, C.c_void_p, C.c_uint64,
                                               u64p, u64p, C.c_int]
+        L.ora_search_ng26.restype = C.c_uint64
+        L.ora_search_ng26.argtypes = [C.POINTER(IndexStruct), C.c_int, u8p, u64p, C.c_uint64, C.c_int, C.c_int,
+                                      u64p, u64p, u64p, u64p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, u64p, C.c_int]
         for f in ("ora_scheme_h2", "ora_scheme_backtracking"):
             getattr(L, f).argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p, u64p]
         for f in ("ora_scheme_pigeon_opt", "ora_scheme_pigeon_trivial"):
@@ -358,7 +361,10 @@ class OraIndex:
             return self.search_backtracking(qbuf, qoff, k, cap=int(n))
         return out[:n], nodes.value
 
-    def search_ng26(self, qbuf, qoff, scheme, partition=None, max_hits=UINT64_MAX, cap=1 << 20, nthreads=1):
+    def search_ng26(self, qbuf, qoff, scheme, partition=None, max_hits=UINT64_MAX, cap=1 << 20, nthreads=1, edit=None):
+        """edit=None: the Hamming reduction; edit=False / True: the full state machine with Edit = false / true"""
+        if edit is not None:
+            return self._search_ng26_full(qbuf, qoff, scheme, partition, max_hits, cap, nthreads, bool(edit))
         pi, l, u = scheme
         nsearch, nparts = pi.shape
         nq = len(qoff) - 1
@@ -372,6 +378,23 @@ class OraIndex:
                                           cap if nthreads == 1 else 0, _p64(qcount), C.byref(nodes), nthreads)
         if nthreads == 1 and n > cap:
             return self.search_ng26(qbuf, qoff, scheme, partition, max_hits, cap=int(n), nthreads=1)
+        return out[: n if nthreads == 1 else 0], qcount, nodes.value
+
+
+    def _search_ng26_full(self, qbuf, qoff, scheme, partition, max_hits, cap, nthreads, edit):
+        pi, l, u = scheme
+        nsearch, nparts = pi.shape
+        nq = len(qoff) - 1
+        out = np.zeros(cap, dtype=HIT_DTYPE)
+        qcount = np.zeros(nq, dtype=np.uint64)
+        nodes = C.c_uint64()
+        part = as_u64(partition) if partition is not None else None
+        n = lib().ora_search_ng26(self.p, 1 if edit else 0, _p8(qbuf), _p64(qoff), nq, nsearch, nparts,
+                                  _p64(as_u64(pi)), _p64(as_u64(l)), _p64(as_u64(u)), _p64(part),
+                                  max_hits, out.ctypes.data if nthreads == 1 else None,
+                                  cap if nthreads == 1 else 0, _p64(qcount), C.byref(nodes), nthreads)
+        if nthreads == 1 and n > cap:
+            return self._search_ng26_full(qbuf, qoff, scheme, partition, max_hits, int(n), 1, edit)
         return out[: n if nthreads == 1 else 0], qcount, nodes.value
 
 

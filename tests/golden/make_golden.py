@@ -111,9 +111,20 @@ def reference_tests():
     exph = [exp[k: k + 3] for k in range(0, len(exp), 3)]
     i = src.index('SECTION("search no errors, all search")')
     exp, _ = _list_after(src, "auto expected = std::vector<std::tuple<size_t, size_t, size_t>> {", i)
+    def expected_of(section, start=0):
+        k = src.index('SECTION("%s")' % section, start)
+        e, _ = _list_after(src, "auto expected = std::vector<std::tuple<size_t, size_t, size_t>> {", k)
+        return [e[j: j + 3] for j in range(0, len(e), 3)]
+    live = src.index("#endif", src.index('SECTION("search ng26, all search")'))          # the second "no search scheme" sections are the compiled ones
     out["searches"] = {"source": "search/checkSearches.cpp:14-72, :104-117, :1173-1199, :1482-1505", "sigma": 256, "sampling_rate": 1,
                        "input": inp, "queries": [[Cc, Cc], [B, B]],
                        "backtracking_k1": exp8, "hamming_k1_facade": exph, "no_errors": [exp[k: k + 3] for k in range(0, len(exp), 3)]}
+    # --- edit distance (Edit = true is search_ng26::search's default template argument)
+    out["searches_edit"] = {"source": "search/checkSearches.cpp:1093-1121, :1148-1171, :1422-1444, :1446-1466", "sigma": 256, "sampling_rate": 1, "input": inp,
+                            "ng26_pigeon_opt_CD_DB": {"queries": [[Cc, D], [D, B]], "expected": expected_of("search ng26, all search")},
+                            "ng26_pigeon_opt_n3": {"queries": [[Cc, Cc], [B, B]], "n": 3, "expected": expected_of("search ng26, all search_n")},
+                            "facade_k1": {"queries": [[Cc, Cc], [B, B]], "expected": expected_of("search, all search, no search scheme", live)},
+                            "facade_k1_n3": {"queries": [[Cc, Cc], [B, B]], "n": 3, "expected": expected_of("search, all search_n, no search scheme", live)}}
     src = open(f"{TESTS}/search/checkSearchBacktracking.cpp").read()
     i = src.index("searching with collection and backtracking")
     bexp, p = _list_after(src, "auto expected = std::vector<uint8_t>{", i)

@@ -337,6 +337,97 @@ def test_ng26_equals_backtracking_equals_text_scan(k):
         assert sorted(got) == sorted(ok), q
 
 
+# ------------------------------------------------------------------------------------------------ edit distance
+def test_edit_distance_fixtures():
+    """search/checkSearches.cpp:1093-1121, :1148-1171 (search_ng26::search, Edit = true by default, pigeon_opt(0,1)) and :1422-1466
+    (fmc::search<true> / search_n<true>: h2(2,0,1) for length-2 queries, CachedSearchScheme.h:16-36): same located multiset"""
+    g = REF["searches_edit"]
+    x = fo.OraIndex.build("IB16", g["sigma"], g["input"], g["sampling_rate"], True)
+    for key, sch in (("ng26_pigeon_opt_CD_DB", fo.scheme_pigeon_opt(0, 1)), ("ng26_pigeon_opt_n3", fo.scheme_pigeon_opt(0, 1)),
+                     ("facade_k1", fo.scheme_h2(2, 0, 1)), ("facade_k1_n3", fo.scheme_h2(2, 0, 1))):
+        c = g[key]
+        qbuf, qoff = fo.flatten_queries(c["queries"])
+        hits, _, _ = x.search_ng26(qbuf, qoff, sch, max_hits=c.get("n", fo.UINT64_MAX), edit=True)
+        assert _located(x, hits) == c["expected"], key
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_ng26_full_state_machine_equals_hamming_reduction(k):
+    """the line-by-line restatement (nge_*, Edit = false) and the Hamming reduction of SURVEY appendix A (ng_*) agree hit by hit,
+    in callback order, and in the number of cursor extensions"""
+    rng = np.random.default_rng(k)
+    base = rng.integers(1, 5, size=500, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[100:300]]), rng.integers(1, 5, size=200, dtype=np.uint8)]
+    x = fo.OraIndex.build("IB16", 5, seqs, 2, True)
+    queries = []
+    for i in range(150):
+        m = int(rng.integers(k + 2, 45)); p = int(rng.integers(0, len(seqs[0]) - m)); q = seqs[0][p: p + m].copy()
+        for _ in range(int(rng.integers(0, k + 2))):
+            q[int(rng.integers(0, m))] = rng.integers(1, 5)
+        queries.append(q)
+    qbuf, qoff = fo.flatten_queries(queries)
+    for sch in (fo.scheme_h2(k + 2, 0, k), fo.scheme_pigeon_opt(0, k), fo.scheme_backtracking(2, 0, k)):
+        for n in (fo.UINT64_MAX, 2):
+            a, qa, na = x.search_ng26(qbuf, qoff, sch, max_hits=n)
+            b, qb, nb = x.search_ng26(qbuf, qoff, sch, max_hits=n, edit=False)
+            assert a.tobytes() == b.tobytes() and np.array_equal(qa, qb) and na == nb
+
+
+def _edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i in range(1, len(a) + 1):
+        cur = [i] + [0] * len(b)
+        for j in range(1, len(b) + 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (a[i - 1] != b[j - 1]))
+        prev = cur
+    return prev[len(b)]
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_edit_distance_sound_and_covering(k):
+    """Edit = true reports cursors, not alignments, and prunes equivalent alignments (SearchNg26.h:146-147, :103: no deletion /
+    substitution at either end), so the checkable properties are: every reported occurrence lies within its reported error count of
+    the query for some length in [m - e, m + e]; and every text substring within edit distance k of the query has a reported
+    occurrence starting at most k positions away."""
+    rng = np.random.default_rng(40 + k)
+    seqs = [rng.integers(1, 5, size=260, dtype=np.uint8), rng.integers(1, 5, size=120, dtype=np.uint8)]
+    text = _concat(seqs)
+    x = fo.OraIndex.build("IB16", 5, seqs, 1, True)
+    starts = np.cumsum([0] + [len(s) + 1 for s in seqs])
+    queries = []
+    for i in range(25):
+        m = int(rng.integers(k + 3, 16)); p = int(rng.integers(0, len(seqs[0]) - m - 2)); q = list(seqs[0][p: p + m])
+        for _ in range(int(rng.integers(0, k + 1))):
+            op = int(rng.integers(0, 3)); j = int(rng.integers(0, len(q)))
+            if op == 0: q[j] = int(rng.integers(1, 5))
+            elif op == 1: q.insert(j, int(rng.integers(1, 5)))
+            elif len(q) > k + 3: del q[j]
+        queries.append(np.array(q, dtype=np.uint8))
+    qbuf, qoff = fo.flatten_queries(queries)
+    hits, _, _ = x.search_ng26(qbuf, qoff, fo.scheme_h2(k + 2, 0, k), edit=True)
+    assert len(hits) > 0
+    for qi, q in enumerate(queries):
+        m = len(q)
+        rep = []
+        for h in hits[hits["qidx"] == qi]:
+            e = int(h["errors"])
+            assert e <= k
+            for r in range(int(h["lb"]), int(h["lb"] + h["len"])):
+                s, p, o = x.locate(r)
+                g = int(starts[s]) + p + o
+                rep.append(g)
+                best = min(_edit_distance(list(text[g: g + L]), list(q)) for L in range(max(0, m - e), m + e + 1) if g + L <= len(text))
+                assert best <= e, (qi, g, e, best)
+        rep = set(rep)
+        for g in range(len(text)):
+            for L in range(max(1, m - k), m + k + 1):
+                sub = text[g: g + L]
+                if len(sub) < L or 0 in sub:
+                    continue
+                if _edit_distance(list(sub), list(q)) <= k:
+                    assert any(abs(g - r) <= k for r in rep), (qi, g, L)
+
+
 def test_search_n_clips_like_the_reference():
     """search_ng26 search_n semantics (SearchNg26.h:407-423): stop after exactly n rows, clip the last cursor"""
     seqs = [np.array([1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 1, 2, 3], dtype=np.uint8)]
