@@ -291,10 +291,10 @@ class search_backtracking:
 
 
 class search_ng26:
-    """search/SearchNg26.h with Edit = false (Hamming distance)"""
+    """search/SearchNg26.h: Hamming distance (Edit = false, default here) or edit distance (edit=True, the reference's default)"""
 
     @staticmethod
-    def search(index, queries, scheme, partition=None, n=UINT64_MAX, capacity=None, want_stats=False):
+    def search(index, queries, scheme, partition=None, n=UINT64_MAX, capacity=None, want_stats=False, edit=False):
         """scheme = (pi, l, u) arrays [searches][parts]; partition = explicit part lengths or None (uniform per query)"""
         qbuf, qoff, nq = _queries(queries)
         pi, l, u = (_u64(x) for x in scheme)
@@ -303,14 +303,16 @@ class search_ng26:
         sc.pi, sc.l, sc.u = (x.ctypes.data_as(capi.u64p) for x in (pi, l, u))
         part = _u64(partition) if partition is not None else None
         sc.partition = part.ctypes.data_as(capi.u64p) if part is not None else None
+        sc.edit = 1 if edit else 0
         cap = capacity if capacity is not None else max(1024, 4 * nq)
         hits, st = _run_hits(lambda out, c, cnt, st: capi.lib().fmgpu_search_scheme(
             index._h, capi.ptr(qbuf), capi.ptr(qoff), nq, C.byref(sc), n, capi.ptr(out), c, C.byref(cnt), C.byref(st), None), cap)
         return (hits, st) if want_stats else hits
 
 
-def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False):
-    """fmc::search<EditDistance=false> (search/search.h:26-35): errors == 0 -> search_no_errors, else search_ng26 with
+def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False, edit=False):
+    """fmc::search<EditDistance> / search_n (search/search.h:26-46; edit=False: Hamming, edit=True: edit distance, the reference's
+    default): errors == 0 -> search_no_errors, else search_ng26 with
     h2(errors+2, 0, errors) and a uniform partition.  The reference's convenience overload additionally applies
     limitToHamming to the un-expanded scheme (search/CachedSearchScheme.h:26-30), which loses hits (SURVEY.md §0.3);
     compat_auto_scheme=True reproduces exactly that."""
@@ -330,7 +332,7 @@ def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False):
     def scheme_for(short):
         # getCachedSearchScheme<false>(0, k, shortLen = (length == 2)): search/SearchNg26.h:436-444, CachedSearchScheme.h:16-36
         sc = search_scheme.h2(errors + (1 if short else 2), 0, errors)
-        return search_scheme.limitToHamming(sc) if compat_auto_scheme else sc
+        return search_scheme.limitToHamming(sc) if (compat_auto_scheme and not edit) else sc
 
     parts = []
     for short in (False, True):
@@ -339,7 +341,7 @@ def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False):
             continue
         sub = [qbuf[int(qoff[i]): int(qoff[i + 1])] for i in sel] if sel.size != nq else None
         qb, qo = (qbuf, qoff) if sub is None else flatten(sub)
-        hits = search_ng26.search(index, (qb, qo), scheme_for(short), None, n)
+        hits = search_ng26.search(index, (qb, qo), scheme_for(short), None, n, edit=edit)
         if sub is not None:
             hits = hits.copy()
             hits["qidx"] = sel.astype(np.uint64)[hits["qidx"].astype(np.int64)]

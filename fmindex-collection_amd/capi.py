@@ -75,7 +75,7 @@ assert HIT_DTYPE.itemsize == C.sizeof(Hit) == 40
 
 class Scheme(C.Structure):
     _fields_ = [("n_searches", C.c_int32), ("n_parts", C.c_int32), ("pi", u64p), ("l", u64p), ("u", u64p),
-                ("partition", u64p)]
+                ("partition", u64p), ("edit", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):

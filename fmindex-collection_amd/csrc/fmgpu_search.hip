@@ -179,7 +179,7 @@ struct SchemeDev {             // flattened [search][part]; values fit a byte (e
 struct Counters { unsigned long long hits, nodes, next; };
 
 // lane-interleaved frame stack: frame d of lane g at word (d * nlanes + g) of three u64 planes
-struct StackView { uint64_t *p0, *p1, *p2; uint64_t nlanes; uint32_t depth; };
+struct StackView { uint64_t *p0, *p1, *p2, *p3; uint64_t nlanes; uint32_t depth; };   // p3: edit-distance kernel only
 
 struct Cur { idx_t lb, lbRev, len; };
 
@@ -528,6 +528,210 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
             resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
             right = (w2 >> 47) & 1u;
             qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
+            tail = 0;
+        }
+    }
+    uint32_t tot = wave_sum(nodes);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
+}
+
+// ---- search_ng26, Edit = true (SearchNg26.h:143-224, :251-365 with insertions and deletions) ------------------------------------
+// Same flat (query, search, node) loop and frame stack as k_scheme; a node's children are numbered in the reference's call order
+//   several rows:  0 match | 2i-1 deletion of index symbol i | 2i substitution by i  (i = 1 .. sigma-1) | 2*sigma-1 insertion
+//   one row:       0 insertion | 1 match or substitution (the row's symbol) | 2 deletion
+// a frame keeps the parent and the number of its next child; the child cursor comes from the parent's extend-all, which is
+// recomputed when the frame is resumed.  State beyond the Hamming kernel's: the last index / query symbol per side (:36-39) and
+// the last operation per side (LInfo / RInfo: 0 M, 1 S, 2 I, 3 D).
+template <class Occ, int MAXSIG>
+__global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
+                                                     const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
+                                                     fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, uint32_t maxm) {
+    extern __shared__ uint32_t s_query[];
+    const QStage qst{s_query, qwords, qnib};
+    __shared__ uint8_t s_pi[kMaxSearches * kMaxParts], s_l[kMaxSearches * kMaxParts], s_u[kMaxSearches * kMaxParts];
+    __shared__ uint32_t s_part[kMaxParts];
+    for (int i = threadIdx.x; i < kMaxSearches * kMaxParts; i += blockDim.x) { s_pi[i] = sch.pi[i]; s_l[i] = sch.l[i]; s_u[i] = sch.u[i]; }
+    if (threadIdx.x < kMaxParts) s_part[threadIdx.x] = sch.partition[threadIdx.x];
+    __syncthreads();
+
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sigma = fw.sigma();
+    const uint32_t P = (uint32_t)sch.P, S = (uint32_t)sch.S;
+    const uint32_t INS = 2u * sigma - 1u;
+    uint32_t nodes = 0;
+    constexpr uint64_t kBatch = 4;
+    uint64_t q = gid * kBatch, q_end = q + kBatch;
+    uint64_t next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
+    uint32_t si = S;
+    bool first = true;
+    const uint8_t* qs = qbuf; uint32_t m = 0, pbase = 0, prem = 0;
+    uint64_t quota = 0; uint32_t seq = 0;
+    Cur cur{0, 0, 0};
+    uint32_t e = 0, part = 0, qL = 0, qR = 0, pev = 0, tail = 0, sp = 0, resume = kNoResume;
+    uint32_t side = 0;                      // lastRank[left] | lastRank[right] << 8 | lastQRank[left] << 16 | lastQRank[right] << 24
+    uint32_t info = 0;                      // LInfo | RInfo << 2
+    bool right = true;
+    const uint8_t *pi = s_pi, *L = s_l, *U = s_u;
+    auto part_len = [&](uint32_t p) -> uint32_t { return sch.uniform ? pbase + (p < prem ? 1u : 0u) : s_part[p]; };
+    bool need_search = true;
+    for (;;) {
+        if (need_search) {
+            if (si + 1 < S && !first && quota != 0) ++si;
+            else {
+                if (!first) ++q;
+                first = false;
+                bool found = false;
+                for (;;) {
+                    if (q >= q_end) {
+                        q = next_batch; q_end = q + kBatch;
+                        if (q >= nq) break;
+                        next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
+                    }
+                    if (q >= nq) break;
+                    const uint64_t qo = qoff[q];
+                    m = (uint32_t)(qoff[q + 1] - qo);
+                    qs = qbuf + qo;
+                    if (m >= P && m <= maxm && (sch.uniform || m == sch.psum) && n != 0) { found = true; break; }
+                    ++q;
+                }
+                if (!found) break;
+                si = 0; quota = max_hits; seq = 0;
+                pbase = m / P; prem = m - pbase * P;
+                qstage_load(qst, qbuf, qoff[q], m, sigma);
+            }
+            pi = s_pi + si * kMaxParts; L = s_l + si * kMaxParts; U = s_u + si * kMaxParts;
+            cur = Cur{0, 0, n};                                    // run(): :62-79
+            e = 0; part = 0; qL = 0; qR = 0; tail = 0; sp = 0; resume = kNoResume; side = 0; info = 0;
+            for (uint32_t i = 0; i < pi[0]; ++i) { uint32_t pl = part_len(i); qL += pl; qR += pl; }
+            qL -= 1;
+            pev = part_len(pi[0]);
+            right = true;
+            need_search = false;
+        }
+        const Occ& occ = right ? rv : fw;
+        const idx_t a = right ? cur.lbRev : cur.lb;
+        idx_t lfa[MAXSIG], lfb[MAXSIG];
+        occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
+        const uint32_t c = qstage_get(qst, qs, right ? qR : qL);
+        const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+        const bool c_alive = alive.test(c);
+        const uint32_t d = right ? 1u : 0u;
+        const uint32_t T = (info >> (2u * d)) & 3u;
+        const uint32_t lastR = (side >> (8u * d)) & 255u, lastQ = (side >> (16u + 8u * d)) & 255u;
+        const bool Deletion = T != 1u && T != 2u, Insertion = T != 1u && T != 3u;                      // :146-147
+        const bool in_tail = tail != 0, multi = cur.len > 1, resuming = resume != kNoResume;
+        const uint32_t Lp = L[part], Up = U[part];
+        const bool mOK = (pev > 1 || Lp <= e) && e <= Up && (T != 2u || c != lastQ) && (T != 3u || c != lastR);   // :160-163
+        const bool iOK = (pev > 1 || Lp <= e + 1) && e + 1 <= Up;                                        // insertion / substitution allowed
+        const bool xOK = e + 1 <= Up;
+        const uint32_t start = resuming ? resume : 0u;
+        // kind: 0 match, 1 substitution, 2 deletion, 3 insertion, 4 nothing left; `take` = index symbol of the child; `nxt` = number of the following child
+        uint32_t kind = 4u, take = c, nxt = kNoResume;
+        bool start_tail = false;
+        if (in_tail) { if (c_alive) kind = 0u; }
+        else if (multi) {
+            if (!xOK) { if (!resuming && mOK && c_alive) { kind = 0u; start_tail = true; } }
+            else {
+                SymSet<MAXSIG> dels = alive; dels.remove(0); if (!Deletion) dels.clear();
+                SymSet<MAXSIG> subs = alive; subs.remove(0); subs.remove(c); if (!iOK) subs.clear();
+                const bool insOK = Insertion && iOK;
+                auto child_from = [&](uint32_t s0) -> uint32_t {                // number of the first existing child >= s0
+                    if (s0 == 0u && mOK && c_alive) return 0u;
+                    SymSet<MAXSIG> dd = dels, ss = subs;
+                    dd.clear_below(s0 <= 1u ? 1u : (s0 + 2u) >> 1);              // 2i - 1 >= s0
+                    ss.clear_below(s0 <= 2u ? 1u : (s0 + 1u) >> 1);              // 2i     >= s0
+                    uint32_t best = kNoResume;
+                    if (dd.any()) best = 2u * dd.first() - 1u;
+                    if (ss.any()) { uint32_t v = 2u * ss.first(); if (v < best) best = v; }
+                    if (best == kNoResume && insOK && s0 <= INS) best = INS;
+                    return best;
+                };
+                const uint32_t idx = child_from(start);
+                if (idx != kNoResume) {
+                    if (idx == 0u) kind = 0u;
+                    else if (idx == INS) kind = 3u;
+                    else { kind = (idx & 1u) ? 2u : 1u; take = (idx + 1u) >> 1; }
+                    if (idx != INS) nxt = child_from(idx + 1u);
+                }
+            }
+        } else {
+            const uint32_t b = alive.first();                       // the row's symbol (symbolLeft / symbolRight, :267-277)
+            const bool valid = alive.any() && b >= 1u;              // :298-301 only insertions below FirstSymb
+            const bool same = valid && b == c;
+            const bool en0 = Insertion && iOK;
+            const bool en1 = same ? mOK : (valid && xOK && iOK);
+            const bool en2 = Deletion && valid && xOK;
+            uint32_t idx = kNoResume;
+            if (start <= 0u && en0) idx = 0u; else if (start <= 1u && en1) idx = 1u; else if (start <= 2u && en2) idx = 2u;
+            if (idx == 0u) { kind = 3u; nxt = en1 ? 1u : (en2 ? 2u : kNoResume); }
+            else if (idx == 1u) {
+                take = b;
+                if (same) { kind = 0u; start_tail = !xOK; nxt = (en2 && xOK) ? 2u : kNoResume; }   // :310-314: the exact tail's result is returned as is
+                else { kind = 1u; nxt = en2 ? 2u : kNoResume; }
+            } else if (idx == 2u) { kind = 2u; take = b; }
+        }
+        nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + ((start_tail) ? 1u : 0u))));
+        if (kind != 4u && nxt != kNoResume) {                       // keep the parent: its remaining children start at nxt
+            uint64_t o = (uint64_t)sp * stk.nlanes + gid;
+            stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
+            stk.p1[o] = (uint64_t)cur.len | ((uint64_t)(pev & 0xffffu) << 32) | ((uint64_t)(qR & 0xffffu) << 48);
+            stk.p2[o] = (uint64_t)nxt | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
+                        ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
+            stk.p3[o] = (uint64_t)side | ((uint64_t)info << 32);
+            ++sp;
+        }
+        resume = kNoResume;
+        bool back = kind == 4u, to_next = false;
+        if (kind != 4u) {
+            if (kind != 3u) cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+            if (kind != 0u) e += 1;
+            const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
+            if (kind == 0u) {                                       // in the exact tail the values written last survive (:236-237)
+                side = (side & rmask & qmask) | (c << (8u * d)) | (c << (16u + 8u * d));
+                info = info & imask;
+            } else if (kind == 1u) {
+                side = (side & rmask & qmask) | (take << (8u * d)) | (c << (16u + 8u * d));
+                info = (info & imask) | (1u << (2u * d));
+            } else if (kind == 2u) {
+                side = (side & rmask) | (take << (8u * d));
+                info = (info & imask) | (3u << (2u * d));
+            } else {
+                side = (side & qmask) | (c << (16u + 8u * d));
+                info = (info & imask) | (2u << (2u * d));
+            }
+            if (kind != 2u) {                                       // NextPos: one query symbol consumed (:122-133)
+                if (right) ++qR; else --qL;
+                if (in_tail) { to_next = --tail == 0; if (to_next) { ++part; pev = part != P ? part_len(pi[part]) : 0; } }
+                else if (start_tail) { tail = pev - 1; to_next = tail == 0; if (to_next) { ++part; pev = part != P ? part_len(pi[part]) : 0; } }
+                else { to_next = --pev == 0; if (to_next) { ++part; if (part != P) pev = part_len(pi[part]); } }
+            }
+        }
+        if (to_next) {                                             // search_next, :98-117
+            if (part == P) {
+                const uint32_t li = info & 3u, ri = (info >> 2) & 3u;
+                if ((li == 0u || li == 2u) && (ri == 0u || ri == 2u) && L[P - 1] <= e && e <= U[P - 1]) {
+                    Cur r = cur;
+                    if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
+                    quota -= r.len;
+                    if (sch.dev_flags & 1) ++seq; else emit_hit(out, cap, ctr, q, r, e, seq++);
+                    if (quota == 0) { need_search = true; continue; }
+                }
+                back = true;
+            } else {
+                right = pi[part - 1] < pi[part];
+            }
+        }
+        if (back) {
+            if (sp == 0) { need_search = true; continue; }
+            --sp;
+            uint64_t o = (uint64_t)sp * stk.nlanes + gid;
+            uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o], w3 = stk.p3[o];
+            cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32);
+            cur.len = (idx_t)w1; pev = (uint32_t)(w1 >> 32) & 0xffffu; qR = (uint32_t)(w1 >> 48) & 0xffffu;
+            resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
+            right = (w2 >> 47) & 1u;
+            qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
+            side = (uint32_t)w3; info = (uint32_t)(w3 >> 32);
             tail = 0;
         }
     }
@@ -1070,7 +1274,7 @@ struct DfsWorkspace {
     unsigned grid = 0;
     // blocks_per_cu: resident 256-lane blocks of the kernel that will run (the lanes walk the batch with a static stride, so
     // every block must be resident from the start or the late ones form a tail)
-    int init(uint32_t depth, uint64_t nq, int blocks_per_cu, hipStream_t stream) {
+    int init(uint32_t depth, uint64_t nq, int blocks_per_cu, hipStream_t stream, int nplanes = 3) {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1078,8 +1282,8 @@ struct DfsWorkspace {
         grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (nq + 255) / 256));
         view.nlanes = (uint64_t)grid * 256; view.depth = depth;
         uint64_t words = view.nlanes * ((uint64_t)depth + 1);
-        FM_HIP(hipMalloc((void**)&planes, words * 8 * 3));
-        view.p0 = planes; view.p1 = planes + words; view.p2 = planes + 2 * words;
+        FM_HIP(hipMalloc((void**)&planes, words * 8 * (size_t)nplanes));
+        view.p0 = planes; view.p1 = planes + words; view.p2 = planes + 2 * words; view.p3 = nplanes > 3 ? planes + 3 * words : nullptr;
         FM_HIP(hipMalloc((void**)&ctr, sizeof(Counters)));
         Counters init{0, 0, view.nlanes * 4ull};                            // next: the first batch of every lane is static (kBatch = 4)
         FM_HIP(hipMemcpyAsync(ctr, &init, sizeof(Counters), hipMemcpyHostToDevice, stream));
@@ -1185,6 +1389,8 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (nq == 0) return 0;
     if (!qbuf || !qoff || (!out && capacity) || !out_count) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out / out_count is null");
     SchemeDev sd{};
+    bool edit = false;
+    uint32_t max_u = 0;
     if (scheme_mode) {
         if (!x->bidirectional) return fail(FMGPU_ERR_INVALID, "search_ng26 needs a BiFMIndex (bwt_rev)");
         if (!scheme || !scheme->pi || !scheme->l || !scheme->u) return fail(FMGPU_ERR_INVALID, "scheme is null");
@@ -1192,13 +1398,14 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             return fail(FMGPU_ERR_UNSUPPORTED, "scheme larger than 16 searches x 16 parts");
         if (max_hits == 0 || scheme->n_searches == 0) return 0;                       // SearchNg26.h:408-409
         sd.S = scheme->n_searches; sd.P = scheme->n_parts; sd.uniform = scheme->partition ? 0 : 1;
+        edit = scheme->edit != 0;
         { const char* e = getenv("FMGPU_DEV_FLAGS"); sd.dev_flags = e ? atoi(e) : 0; }
         for (int s = 0; s < sd.S; ++s) {
             uint32_t seen = 0;
             for (int p = 0; p < sd.P; ++p) {
                 uint64_t pi = scheme->pi[s * sd.P + p], l = scheme->l[s * sd.P + p], u = scheme->u[s * sd.P + p];
                 if (pi >= (uint64_t)sd.P || l > 255 || u > 254) return fail(FMGPU_ERR_INVALID, "scheme entry out of range");
-                seen |= 1u << pi;
+                seen |= 1u << pi; max_u = std::max<uint32_t>(max_u, (uint32_t)u);
                 sd.pi[s * kMaxParts + p] = (uint8_t)pi; sd.l[s * kMaxParts + p] = (uint8_t)l; sd.u[s * kMaxParts + p] = (uint8_t)u;
             }
             if (seen != (1u << sd.P) - 1u) return fail(FMGPU_ERR_INVALID, "scheme pi is not a permutation of the parts");
@@ -1229,14 +1436,15 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     static std::mutex occ_mu; static std::map<std::tuple<int, int, int, size_t>, int> occ_cache;
     int bpc = 8;
     const size_t occ_lds = (size_t)((x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4)) * 1024 > 48 * 1024 ? 0 : (size_t)((x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4)) * 1024;
-    const auto occ_key = std::make_tuple(x->bwt.search_family(), x->bwt.sigma, (int)scheme_mode, occ_lds);
+    const auto occ_key = std::make_tuple(x->bwt.search_family(), x->bwt.sigma, (int)scheme_mode + (edit ? 2 : 0), occ_lds);
     bool occ_known = false;
     { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(occ_key); if (it != occ_cache.end()) { bpc = it->second; occ_known = true; } }
     if (!occ_known) {   // residency of the kernel instantiation that will run (queried once: the call is slow)
         auto occ_of = [&](auto kernel) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, occ_lds) == hipSuccess && nb > 0) bpc = nb; else (void)hipGetLastError(); };
         dispatch_occ(x->bwt, [&](auto occ, auto ms) {
             using O = decltype(occ);
-            if (scheme_mode) occ_of(k_scheme<O, decltype(ms)::value>); else occ_of(k_backtracking<O, decltype(ms)::value>);
+            if (scheme_mode && edit) occ_of(k_scheme_edit<O, decltype(ms)::value>);
+            else if (scheme_mode) occ_of(k_scheme<O, decltype(ms)::value>); else occ_of(k_backtracking<O, decltype(ms)::value>);
             return 0;
         });
         std::lock_guard<std::mutex> g(occ_mu); occ_cache[occ_key] = bpc;
@@ -1247,14 +1455,15 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if ((size_t)qwords * 1024 > 48 * 1024) qwords = 0;
     const size_t lds_bytes = (size_t)qwords * 1024;
     DfsWorkspace ws;
-    if ((rc = ws.init(maxlen, nq, bpc, stream))) return rc;
+    // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
+    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? 4 : 3))) return rc;
     EventTimer timer(stream, stats != nullptr);
     const idx_t n = (idx_t)x->bwt.n;
     dim3 grid(ws.grid), block(256);
     // fast path: equal-length batch on a Format-A BiFMIndex with LF tables
     std::vector<uint32_t> step_tab;
     uint32_t lut_ok = 0;
-    const bool fast = scheme_mode && x->bwt.search_family() == FAM_A && x->bwt.lf_table && x->rev.lf_table && minlen == maxlen &&
+    const bool fast = scheme_mode && !edit && x->bwt.search_family() == FAM_A && x->bwt.lf_table && x->rev.lf_table && minlen == maxlen &&
                       x->bwt.sigma <= 32 && !(sd.dev_flags & 2) && build_step_table(sd, maxlen, (sd.dev_flags & 4) ? 0 : x->lut_len, step_tab, lut_ok);
     uint32_t* d_steps = nullptr;
     if (fast) {
@@ -1284,6 +1493,11 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             if constexpr (std::is_same_v<O, OccA<5>> || std::is_same_v<O, OccA<0>>) r = O{rv.va};
             else if constexpr (std::is_same_v<O, OccW>) r = O{rv.vw};
             else r = O{rv.vr};
+            if (edit) {
+                k_scheme_edit<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
+                                                                                  max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, maxlen);
+                return 0;
+            }
             k_scheme<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
                                                                          max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib);
             return 0;

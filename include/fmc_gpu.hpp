@@ -8,8 +8,8 @@
 // limitToHamming, isValid, isComplete} (search_scheme/).
 //
 // Differences that follow from batching on a GPU: searches run over the whole `queries` range in one call and the delegates
-// are invoked on the host afterwards — in ascending qidx and, inside a query, in the reference's callback order.  Edit
-// distance (Edit = true) is outside the accelerated path and throws std::runtime_error.
+// are invoked on the host afterwards — in ascending qidx and, inside a query, in the reference's callback order.  Both Hamming
+// (Edit = false) and edit distance (Edit = true, the reference's default) run on the GPU.
 #pragma once
 
 #include "fmgpu.h"
@@ -370,32 +370,57 @@ void search(Index const& index, Queries const& queries, size_t maxError, Delegat
 }  // namespace search_backtracking
 
 namespace search_ng26 {
-// search<Edit>(index, queries, scheme, partition, delegate(qidx, cursor, errors), n) — search/SearchNg26.h:426-433
-template <bool Edit = true, typename Index, typename Queries, typename Delegate>
-void search(Index const& index, Queries const& queries, search_scheme::Scheme const& scheme, std::vector<size_t> const& partition,
-            Delegate&& delegate, size_t n = std::numeric_limits<size_t>::max()) {
-    if constexpr (Edit) throw std::runtime_error("fmindex-collection (gpu): edit distance is outside the accelerated path, use search<false>");
-    std::vector<uint8_t> buf; std::vector<uint64_t> off;
-    detail::flatten(queries, buf, off);
+namespace detail2 {
+// one scheme over one batch; qmap (optional) renames the batch's query numbers
+template <bool Edit, typename Index>
+std::vector<fmgpu_hit> run(Index const& index, std::vector<uint8_t> const& buf, std::vector<uint64_t> const& off, search_scheme::Scheme const& scheme,
+                           std::vector<size_t> const& partition, size_t n, std::vector<uint64_t> const* qmap) {
     size_t nq = off.size() - 1;
-    if (scheme.empty() || nq == 0 || n == 0) return;
+    if (scheme.empty() || nq == 0 || n == 0) return {};
     size_t P = scheme[0].pi.size();
     std::vector<uint64_t> pi, l, u, part(partition.begin(), partition.end());
     for (auto const& s : scheme) {
         if (s.pi.size() != P) throw std::runtime_error("fmindex-collection (gpu): searches of a scheme must have the same number of parts");
         pi.insert(pi.end(), s.pi.begin(), s.pi.end()); l.insert(l.end(), s.l.begin(), s.l.end()); u.insert(u.end(), s.u.begin(), s.u.end());
     }
-    fmgpu_scheme sc{static_cast<int32_t>(scheme.size()), static_cast<int32_t>(P), pi.data(), l.data(), u.data(), part.empty() ? nullptr : part.data()};
+    fmgpu_scheme sc{static_cast<int32_t>(scheme.size()), static_cast<int32_t>(P), pi.data(), l.data(), u.data(), part.empty() ? nullptr : part.data(),
+                    Edit ? 1 : 0, 0};
     auto hits = detail::run_hits(nq, [&](fmgpu_hit* out, uint64_t cap, uint64_t* count) {
         return fmgpu_search_scheme(index.handle, buf.data(), off.data(), nq, &sc, n, out, cap, count, nullptr, nullptr);
     });
+    if (qmap) for (auto& h : hits) h.qidx = (*qmap)[h.qidx];
+    return hits;
+}
+}  // namespace detail2
+
+// search<Edit>(index, queries, scheme, partition, delegate(qidx, cursor, errors), n) — search/SearchNg26.h:426-433.
+// Edit = true (the reference's default) adds insertions and deletions (:146-218, :286-362); Edit = false is Hamming distance.
+template <bool Edit = true, typename Index, typename Queries, typename Delegate>
+void search(Index const& index, Queries const& queries, search_scheme::Scheme const& scheme, std::vector<size_t> const& partition,
+            Delegate&& delegate, size_t n = std::numeric_limits<size_t>::max()) {
+    std::vector<uint8_t> buf; std::vector<uint64_t> off;
+    detail::flatten(queries, buf, off);
+    auto hits = detail2::run<Edit>(index, buf, off, scheme, partition, n, nullptr);
     detail::report(index, hits, delegate);
 }
-// search<Edit>(index, queries, maxErrors, delegate, n) — search/SearchNg26.h:436-444: h2(maxErrors+2, 0, maxErrors), uniform partition per
-// query length.  (The reference additionally applies limitToHamming to the un-expanded scheme, which loses hits: SURVEY.md §0.3.)
+// search<Edit>(index, queries, maxErrors, delegate, n) — search/SearchNg26.h:436-444: per query length the cached scheme
+// h2(maxErrors + (length == 2 ? 1 : 2), 0, maxErrors) (CachedSearchScheme.h:16-36) with a uniform partition.  For Edit = false the
+// reference additionally applies limitToHamming to the un-expanded scheme, which loses hits — not reproduced here.
 template <bool Edit = true, typename Index, typename Queries, typename Delegate>
 void search(Index const& index, Queries const& queries, size_t maxErrors, Delegate&& delegate, size_t n = std::numeric_limits<size_t>::max()) {
-    search<Edit>(index, queries, search_scheme::generator::h2(maxErrors + 2, 0, maxErrors), {}, std::forward<Delegate>(delegate), n);
+    std::vector<fmgpu_hit> all;
+    for (int shortLen = 0; shortLen < 2; ++shortLen) {
+        std::vector<uint8_t> buf; std::vector<uint64_t> off{0}, qmap;
+        size_t qidx = 0;
+        for (auto const& q : queries) {
+            if ((q.size() == 2) == (shortLen == 1)) { buf.insert(buf.end(), q.begin(), q.end()); off.push_back(buf.size()); qmap.push_back(qidx); }
+            ++qidx;
+        }
+        if (qmap.empty()) continue;
+        auto hits = detail2::run<Edit>(index, buf, off, search_scheme::generator::h2(maxErrors + (shortLen ? 1 : 2), 0, maxErrors), {}, n, &qmap);
+        all.insert(all.end(), hits.begin(), hits.end());
+    }
+    detail::report(index, all, delegate);
 }
 }  // namespace search_ng26
 
@@ -404,6 +429,11 @@ template <bool EditDistance, typename Index, typename Queries, typename Delegate
 void search(Index const& index, Queries const& queries, size_t errors, Delegate&& delegate) {
     if (errors == 0) search_no_errors::search(index, queries, [&](size_t qidx, auto const& cursor) { delegate(qidx, cursor, size_t{0}); });
     else search_ng26::search<EditDistance>(index, queries, errors, std::forward<Delegate>(delegate));
+}
+// fmc::search_n<EditDistance>(index, queries, errors, n, delegate) — search/search.h:43-46
+template <bool EditDistance, typename Index, typename Queries, typename Delegate>
+void search_n(Index const& index, Queries const& queries, size_t errors, size_t n, Delegate&& delegate) {
+    search_ng26::search<EditDistance>(index, queries, errors, std::forward<Delegate>(delegate), n);
 }
 
 // LocateLinear{index, cursor}: for (auto [seqId, pos, offset] : LocateLinear{index, cursor}) — locate.h:14-57 (one batched call)

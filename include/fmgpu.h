@@ -120,6 +120,8 @@ typedef struct fmgpu_scheme {
     int32_t n_searches, n_parts;
     const uint64_t* pi; const uint64_t* l; const uint64_t* u;
     const uint64_t* partition;   /* n_parts entries, or NULL = createUniformPartition per query length (expand.h:324-343) */
+    int32_t edit;                /* 0: Hamming distance (search_ng26::search<false>); != 0: edit distance (search<true>, the reference's default) */
+    int32_t reserved;
 } fmgpu_scheme;
 
 typedef struct fmgpu_stats {

@@ -63,9 +63,29 @@ int main() {
         std::sort(results.begin(), results.end());
         CHECK(results == expected);
 
-        bool threw = false;
-        try { fmc::search_ng26::search(index, queries, scheme, partition, [](auto, auto, auto) {}); } catch (std::runtime_error const&) { threw = true; }
-        CHECK(threw);   // Edit = true (the reference's default) is outside the accelerated path
+        // edit distance (Edit = true is the default template argument): checkSearches.cpp "search ng26, all search" / "all search_n",
+        // "search, all search, no search scheme", "search, all search_n, no search scheme"
+        auto locate_all = [&](auto qidx, auto cursor, auto errors) {
+            (void)errors;
+            for (auto [sid, spos, offset] : fmc::LocateLinear{index, cursor}) results.emplace_back(qidx, sid, spos + offset);
+        };
+        auto q2 = std::vector<std::vector<uint8_t>>{{'C', 'D'}, {'D', 'B'}};
+        results.clear();
+        fmc::search_ng26::search(index, q2, scheme, partition, locate_all);
+        std::sort(results.begin(), results.end());
+        CHECK((results == Results{{0, 0, 3}, {0, 1, 7}, {1, 0, 7}, {1, 1, 3}}));
+        results.clear();
+        fmc::search_ng26::search(index, queries, scheme, partition, locate_all, 3);
+        std::sort(results.begin(), results.end());
+        CHECK((results == Results{{0, 0, 3}, {0, 1, 7}, {0, 1, 7}, {1, 0, 7}, {1, 0, 7}, {1, 1, 3}}));
+        results.clear();
+        fmc::search</*EditDistance=*/true>(index, queries, /*maxErrors*/ 1, locate_all);
+        std::sort(results.begin(), results.end());
+        CHECK((results == Results{{0, 0, 3}, {0, 0, 3}, {0, 1, 7}, {0, 1, 7}, {1, 0, 7}, {1, 0, 7}, {1, 1, 3}, {1, 1, 3}}));
+        results.clear();
+        fmc::search_n</*EditDistance=*/true>(index, queries, /*maxErrors*/ 1, /*n*/ 3, locate_all);
+        std::sort(results.begin(), results.end());
+        CHECK((results == Results{{0, 0, 3}, {0, 1, 7}, {0, 1, 7}, {1, 0, 7}, {1, 0, 7}, {1, 1, 3}}));
     }
     {   // "backtracking with errors": FMIndex<256>
         auto index = fmc::FMIndex<256>{input, 1, 1};

@@ -340,6 +340,61 @@ def test_occurrence_table_expansion(layout, sigma):
     assert np.array_equal(gx.rank(idx, sym), r1)
 
 
+# ------------------------------------------------------------------------------------------------ edit distance
+def test_edit_distance_reference_vectors():
+    """search/checkSearches.cpp:1093-1121, :1148-1171, :1422-1466 — the located multisets the reference's own tests expect from
+    search_ng26::search (Edit = true by default) and fmc::search<true> / search_n<true>"""
+    g = REF["searches_edit"]
+    ox = fo.OraIndex.build("IB16", g["sigma"], g["input"], g["sampling_rate"], True)
+    gx = gpu_index(ox)
+    for key, sch in (("ng26_pigeon_opt_CD_DB", fm.search_scheme.pigeon_opt(0, 1)), ("ng26_pigeon_opt_n3", fm.search_scheme.pigeon_opt(0, 1))):
+        c = g[key]
+        hits = fm.search_ng26.search(gx, c["queries"], sch, n=c.get("n", fm.UINT64_MAX), edit=True)
+        owner, seq, pos, steps = fm.LocateLinear(gx, hits["lb"], hits["len"])()
+        got = sorted([int(hits["qidx"][o]), int(a), int(b + s)] for o, a, b, s in zip(owner, seq, pos, steps))
+        assert got == c["expected"], key
+    for key in ("facade_k1", "facade_k1_n3"):
+        c = g[key]
+        hits = fm.search(gx, c["queries"], 1, n=c.get("n", fm.UINT64_MAX), edit=True)
+        owner, seq, pos, steps = fm.LocateLinear(gx, hits["lb"], hits["len"])()
+        got = sorted([int(hits["qidx"][o]), int(a), int(b + s)] for o, a, b, s in zip(owner, seq, pos, steps))
+        assert got == c["expected"], key
+
+
+@pytest.mark.parametrize("layout,sigma,k", [("IB16", 5, 1), ("IB16", 5, 2), ("IB16", 5, 3), ("WAVELET", 28, 1), ("EPRV2_16", 5, 2), ("IB16", 256, 1), ("EPR16", 6, 2)])
+def test_edit_distance_matches_the_cpu_walk(layout, sigma, k):
+    """search_ng26<Edit = true>: same cursors, error counts, callback order and number of extensions as the CPU restatement, for
+    equal and ragged query lengths, several schemes, search_n clipping and an explicit partition"""
+    rng = np.random.default_rng(sigma + k)
+    base = rng.integers(1, min(sigma, 8), size=700, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[100:400]]), rng.integers(1, min(sigma, 8), size=300, dtype=np.uint8)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 4, True)
+    gx = gpu_index(ox)
+    queries = []
+    for i in range(250 if k < 3 else 80):
+        m = int(rng.integers(k + 2, 36 if k < 3 else 22)); p = int(rng.integers(0, len(seqs[0]) - m - 1)); q = list(seqs[0][p: p + m])
+        for _ in range(int(rng.integers(0, k + 2))):
+            op = int(rng.integers(0, 3)); j = int(rng.integers(0, len(q)))
+            if op == 0: q[j] = int(rng.integers(1, min(sigma, 8)))
+            elif op == 1: q.insert(j, int(rng.integers(1, min(sigma, 8))))
+            elif len(q) > k + 3: del q[j]
+        queries.append(np.array(q, dtype=np.uint8))
+    qbuf, qoff = fm.flatten(queries)
+    for sch in (fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k), fm.search_scheme.backtracking(2, 0, k)):
+        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True)
+        ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch, edit=True)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes and len(ohits) > 0, (layout, k)
+    sch = fm.search_scheme.h2(k + 2, 0, k)
+    for n in (1, 3):
+        assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=n, edit=True), ox.search_ng26(qbuf, qoff, sch, max_hits=n, edit=True)[0])
+    same = [q for q in queries if len(q) == 20][:1] * 3 + [np.array(list(seqs[0][5:25]), dtype=np.uint8)]
+    sb, so = fm.flatten(same)
+    part = np.array([20 - 3 * (k + 1)] + [3] * (k + 1), dtype=np.uint64)
+    assert same_hits(fm.search_ng26.search(gx, (sb, so), sch, partition=part, edit=True), ox.search_ng26(sb, so, sch, partition=part, edit=True)[0])
+    # Edit = false through the same entry point still takes the Hamming kernels
+    assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch), ox.search_ng26(qbuf, qoff, sch)[0])
+
+
 @pytest.mark.parametrize("bidir", [False, True])
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_backtracking(bidir, k):
