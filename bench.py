@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--kstep", type=int, default=-1, help="exact search: symbols per table step (fmgpu_index_accelerate); 1 = plain occurrence table; "
                     "protein: 1 = block-table expansion of the wavelet (default), 0 = search the wavelet lines themselves")
     ap.add_argument("--no-search-accel", action="store_true", help="k2: no prefix / walk tables (fmgpu_index_accelerate_search)")
+    ap.add_argument("--edit", action="store_true", help="k2: edit distance (search_ng26<Edit = true>) instead of Hamming distance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="rehearsal only: gloo runs the N > 1 control flow where RCCL cannot (all ranks on one card); results travel through host memory")
@@ -155,7 +156,7 @@ def main():
     # results are double-buffered: the gather of step i travels over xGMI while the kernel of step i+1 runs
     outs = [torch.empty(2 * nq, dtype=torch.int64, device=dev) for _ in range(2 if world > 1 else 1)]   # [lb | len], one buffer so that the gather sends it as is
     scheme = fm.search_scheme.h2(4, 0, 2)
-    hit_cap = 4 * nq
+    hit_cap = (16 if args.edit else 4) * nq
     hits_bufs = [torch.empty(hit_cap * 40, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)] if bidir else None
     via_host = world > 1 and args.dist_backend == "gloo"
     count_dev = torch.zeros(1, dtype=torch.int64, device="cpu" if via_host else dev)
@@ -183,6 +184,7 @@ def main():
                                                      C.byref(stats), None))
         else:
             sc = _scheme_struct(capi, scheme)
+            sc[0].edit = 1 if args.edit else 0
             cnt = C.c_uint64()
             capi.check(capi.lib().fmgpu_search_scheme(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
                                                       C.byref(sc[0]), capi.UINT64_MAX, C.c_void_p(hits_bufs[b].data_ptr()), hit_cap,
@@ -244,7 +246,7 @@ def main():
     traffic, lines = None, None                               # HBM bytes / line requests per launch from the committed PMC passes
     try:
         tall = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = ("protein_exact" if args.kstep else "protein_exact_wavelet_lines") if protein else "grch38_k2" if bidir else ("grch38_exact" if args.kstep == 3 else "grch38_exact_kstep%d" % args.kstep)
+        key = ("protein_exact" if args.kstep else "protein_exact_wavelet_lines") if protein else ("grch38_k2_edit" if args.edit else "grch38_k2") if bidir else ("grch38_exact" if args.kstep == 3 else "grch38_exact_kstep%d" % args.kstep)
         tj = tall[key]
         if args.scale == 1.0 and nq == 10_000_000 and L == (40 if protein else 101):
             traffic, lines = tj["bytes_per_launch"], tj["line_requests_per_launch"]
@@ -253,11 +255,11 @@ def main():
         traffic, lines = None, None
     result = {
         "metric": ("queries/sec (sigma=28 protein index, 10M x 40aa, exact, Wavelet)" if protein else
-                   "queries/sec (GRCh38-sized index, 10M x 101bp, %s)" % ("exact" if not bidir else "k=2 Hamming, h2(4,0,2)")),
+                   "queries/sec (GRCh38-sized index, 10M x 101bp, %s)" % ("exact" if not bidir else ("k=2 edit distance, h2(4,0,2)" if args.edit else "k=2 Hamming, h2(4,0,2)"))),
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "protein_exact" if protein else "grch38_%s" % ("exact" if not bidir else "k2"), "text_symbols": total, "sequences": len(lengths),
+        "config": {"workload": "protein_exact" if protein else "grch38_%s" % ("exact" if not bidir else ("k2_edit" if args.edit else "k2")), "text_symbols": total, "sequences": len(lengths),
                    "sigma": sigma, "layout": "Wavelet" if protein else "InterleavedBitvector16", "queries_per_gpu": nq, "read_len": L,
                    "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale, "kstep_table": (args.kstep if not bidir else 1),
                    "device_table": ("block table expanded from the wavelet" if args.kstep else "wavelet lines") if protein else "block table",
@@ -265,7 +267,7 @@ def main():
         "gbp_per_s": qps * L / 1e9,
         "hits": hits,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": ("k_exact_a" if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if args.kstep > 1 else "k_exact_a") if not bidir else "k_scheme_fast", "kernel_ms": k_ms,
+                     "traffic": traffic, "kernel": ("k_exact_a" if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if args.kstep > 1 else "k_exact_a") if not bidir else ("k_scheme_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
                      "units_per_launch": steps_per_launch, "bytes_per_unit": unit_bytes,
                      "unit": "GB/s", "note": NOTE_PROTEIN if protein else NOTE_DNA},
     }
@@ -274,7 +276,7 @@ def main():
                                            "frac": lines / (k_ms * 1e-3) / 1e9 / ceiling,
                                            "what": "L2->fabric 128-byte line requests per second (TCC_EA0_RDREQ) vs the measured ceiling for dependent random line reads"}
     if want_cpu:
-        result["cpu_baseline"] = cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, args.cpu_sample, out_lb, out_len, layout, sigma)
+        result["cpu_baseline"] = cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, args.cpu_sample, out_lb, out_len, layout, sigma, args.edit)
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -299,7 +301,7 @@ def _scheme_struct(capi, scheme):
     return sc, (pi, l, u)
 
 
-def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_len, layout="IB16", sigma=5):
+def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_len, layout="IB16", sigma=5, edit=False):
     """the CPU restatement (oracle/) on the host cores, bounded sample of the same reads; also a parity spot-check"""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -318,10 +320,10 @@ def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_le
         if not bidir:
             r = ox.search_exact(hq_all[: count * L], ho_all[: count + 1], nthreads=threads)
         else:
-            r = ox.search_ng26(hq_all[: count * L], ho_all[: count + 1], scheme, nthreads=threads)
+            r = ox.search_ng26(hq_all[: count * L], ho_all[: count + 1], scheme, nthreads=threads, edit=True if edit else None)
         return r, time.time() - t0
 
-    pilot = min(nq, 200_000 if not bidir else 50_000)
+    pilot = min(nq, 200_000 if not bidir else (5_000 if edit else 50_000))
     _, dt = run(pilot)                                        # also warms the caches / OpenMP team
     if sample <= 0:                                           # aim at ~15 s of CPU work, bounded by the batch
         sample = int(min(nq, max(pilot, pilot * 15.0 / max(dt, 1e-3))))

@@ -179,7 +179,7 @@ struct SchemeDev {             // flattened [search][part]; values fit a byte (e
 struct Counters { unsigned long long hits, nodes, next; };
 
 // lane-interleaved frame stack: frame d of lane g at word (d * nlanes + g) of three u64 planes
-struct StackView { uint64_t *p0, *p1, *p2, *p3; uint64_t nlanes; uint32_t depth; };   // p3: edit-distance kernel only
+struct StackView { uint64_t *p0, *p1, *p2, *p3; uint64_t nlanes; uint32_t depth; uint32_t batch; };   // p3: edit-distance kernel only
 
 struct Cur { idx_t lb, lbRev, len; };
 
@@ -215,6 +215,11 @@ struct SymSet {
         if (s >= (uint32_t)MAXSIG) return;
 #pragma unroll
         for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) w[i] &= ~(1u << (s & 31u));
+    }
+    __device__ __forceinline__ void insert(uint32_t s) {
+        if (s >= (uint32_t)MAXSIG) return;
+#pragma unroll
+        for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) w[i] |= 1u << (s & 31u);
     }
     __device__ __forceinline__ bool any() const {
         uint32_t r = 0;
@@ -272,6 +277,15 @@ __device__ __forceinline__ Cur kid_of(const idx_t* lfa, const idx_t* lfb, Cur cu
 }
 
 constexpr uint32_t kNoResume = 0xffffffffu;
+
+// one-row cursors with the explicit LF table (DevString::lf_table): LF(row) in one 4-byte load; the row's symbol is the k with
+// C[k] <= LF(row) < C[k+1] (C staged in LDS)
+struct LfView { const idx_t* fw; const idx_t* rv; const idx_t* C; };
+__device__ __forceinline__ uint32_t symbol_of_lf_lds(const idx_t* sC, uint32_t sigma, idx_t t) {
+    uint32_t lo = 0, hi = sigma;                    // invariant: sC[lo] <= t < sC[hi]   (sC[sigma] = n > t)
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sC[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
 
 // ---- per-lane query staging in LDS ------------------------------------------------------------------------------
 // A DFS visits a few hundred nodes per query; reading the query symbol of every node from global memory costs a
@@ -375,13 +389,15 @@ __global__ __launch_bounds__(256) void k_exact_w(ViewW v, const uint8_t* __restr
 template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
                                                 const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
-                                                fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib) {
+                                                fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv) {
     extern __shared__ uint32_t s_query[];
     const QStage qst{s_query, qwords, qnib};
     __shared__ uint8_t s_pi[kMaxSearches * kMaxParts], s_l[kMaxSearches * kMaxParts], s_u[kMaxSearches * kMaxParts];
     __shared__ uint32_t s_part[kMaxParts];
     for (int i = threadIdx.x; i < kMaxSearches * kMaxParts; i += blockDim.x) { s_pi[i] = sch.pi[i]; s_l[i] = sch.l[i]; s_u[i] = sch.u[i]; }
     if (threadIdx.x < kMaxParts) s_part[threadIdx.x] = sch.partition[threadIdx.x];
+    __shared__ idx_t s_C[257];
+    if (lfv.fw) for (uint32_t i = threadIdx.x; i <= fw.sigma(); i += blockDim.x) s_C[i] = lfv.C[i];
     __syncthreads();
 
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
     // Queries are handed out in batches of kBatch through a global counter (the first batch of every lane is static);
     // the atomicAdd for the NEXT batch is issued when a batch is started, so its latency never sits on the critical
     // path, and the grid needs no assumption about how many blocks are resident.
-    constexpr uint64_t kBatch = 4;
+    const uint64_t kBatch = stk.batch;                        // 4, or 1 when the batch has too few queries to give every lane four
     uint64_t q = gid * kBatch, q_end = q + kBatch;            // current query / end of the current batch
     uint64_t next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
     uint32_t si = S;                        // current search; si == S: fetch the next query first
@@ -453,9 +469,14 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
         const Occ& occ = right ? rv : fw;
         const idx_t a = right ? cur.lbRev : cur.lb;
         idx_t lfa[MAXSIG], lfb[MAXSIG];
-        occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);       // the memory phase
+        const bool via_lf = lfv.fw != nullptr && cur.len == 1;      // one row: its only child comes from the LF table
+        idx_t lf1 = 0;
+        if (via_lf) lf1 = (right ? lfv.rv : lfv.fw)[a];
+        else occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);       // the memory phase
         const uint32_t c = qstage_get(qst, qs, right ? qR : qL);
-        const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+        SymSet<MAXSIG> alive;
+        if (via_lf) { alive.clear(); alive.insert(symbol_of_lf_lds(s_C, sigma, lf1)); }
+        else alive = alive_set<MAXSIG>(lfa, lfb, sigma);
         const bool c_alive = alive.test(c);
 
         // ---- case analysis -> (ok, take, is_sub, start_tail, push) ------------------------------------------------
@@ -497,7 +518,8 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
         resume = kNoResume;
         bool back = !ok, to_next = false;
         if (ok) {
-            cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+            if (via_lf) cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
+            else cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
             if (take_sub) e += 1;
             if (right) ++qR; else --qL;                            // one query symbol consumed (search_next_pos :122-124 / tail)
             if (in_tail) { to_next = --tail == 0; if (to_next) { ++part; pev = part != P ? part_len(pi[part]) : 0; } }
@@ -545,13 +567,15 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
 template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
                                                      const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
-                                                     fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, uint32_t maxm) {
+                                                     fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv, uint32_t maxm) {
     extern __shared__ uint32_t s_query[];
     const QStage qst{s_query, qwords, qnib};
     __shared__ uint8_t s_pi[kMaxSearches * kMaxParts], s_l[kMaxSearches * kMaxParts], s_u[kMaxSearches * kMaxParts];
     __shared__ uint32_t s_part[kMaxParts];
     for (int i = threadIdx.x; i < kMaxSearches * kMaxParts; i += blockDim.x) { s_pi[i] = sch.pi[i]; s_l[i] = sch.l[i]; s_u[i] = sch.u[i]; }
     if (threadIdx.x < kMaxParts) s_part[threadIdx.x] = sch.partition[threadIdx.x];
+    __shared__ idx_t s_C[257];
+    if (lfv.fw) for (uint32_t i = threadIdx.x; i <= fw.sigma(); i += blockDim.x) s_C[i] = lfv.C[i];
     __syncthreads();
 
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -559,7 +583,7 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
     const uint32_t P = (uint32_t)sch.P, S = (uint32_t)sch.S;
     const uint32_t INS = 2u * sigma - 1u;
     uint32_t nodes = 0;
-    constexpr uint64_t kBatch = 4;
+    const uint64_t kBatch = stk.batch;
     uint64_t q = gid * kBatch, q_end = q + kBatch;
     uint64_t next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
     uint32_t si = S;
@@ -611,9 +635,14 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
         const Occ& occ = right ? rv : fw;
         const idx_t a = right ? cur.lbRev : cur.lb;
         idx_t lfa[MAXSIG], lfb[MAXSIG];
-        occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
+        const bool via_lf = lfv.fw != nullptr && cur.len == 1;      // one row: its only child comes from the LF table
+        idx_t lf1 = 0;
+        if (via_lf) lf1 = (right ? lfv.rv : lfv.fw)[a];
+        else occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
         const uint32_t c = qstage_get(qst, qs, right ? qR : qL);
-        const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+        SymSet<MAXSIG> alive;
+        if (via_lf) { alive.clear(); alive.insert(symbol_of_lf_lds(s_C, sigma, lf1)); }
+        else alive = alive_set<MAXSIG>(lfa, lfb, sigma);
         const bool c_alive = alive.test(c);
         const uint32_t d = right ? 1u : 0u;
         const uint32_t T = (info >> (2u * d)) & 3u;
@@ -683,7 +712,10 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
         resume = kNoResume;
         bool back = kind == 4u, to_next = false;
         if (kind != 4u) {
-            if (kind != 3u) cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+            if (kind != 3u) {
+                if (via_lf) cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
+                else cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+            }
             if (kind != 0u) e += 1;
             const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
             if (kind == 0u) {                                       // in the exact tail the values written last survive (:236-237)
@@ -1285,7 +1317,8 @@ struct DfsWorkspace {
         FM_HIP(hipMalloc((void**)&planes, words * 8 * (size_t)nplanes));
         view.p0 = planes; view.p1 = planes + words; view.p2 = planes + 2 * words; view.p3 = nplanes > 3 ? planes + 3 * words : nullptr;
         FM_HIP(hipMalloc((void**)&ctr, sizeof(Counters)));
-        Counters init{0, 0, view.nlanes * 4ull};                            // next: the first batch of every lane is static (kBatch = 4)
+        view.batch = nq >= view.nlanes * 8ull ? 4u : 1u;                    // queries per hand-out
+        Counters init{0, 0, view.nlanes * (uint64_t)view.batch};           // next: the first batch of every lane is static
         FM_HIP(hipMemcpyAsync(ctr, &init, sizeof(Counters), hipMemcpyHostToDevice, stream));
         FM_HIP(hipStreamSynchronize(stream));
         return 0;
@@ -1487,6 +1520,8 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                                                                     nq, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags);
     } else if (scheme_mode) {
         const DevString& rv = x->rev;
+        LfView lfv{nullptr, nullptr, nullptr};
+        if (x->bwt.lf_table && rv.lf_table && !(sd.dev_flags & 16)) lfv = LfView{x->bwt.lf_table, rv.lf_table, x->dC};
         rc = dispatch_occ(x->bwt, [&](auto occ, auto ms) {
             using O = decltype(occ);
             O r{};
@@ -1495,11 +1530,11 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             else r = O{rv.vr};
             if (edit) {
                 k_scheme_edit<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
-                                                                                  max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, maxlen);
+                                                                                  max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, maxlen);
                 return 0;
             }
             k_scheme<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
-                                                                         max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib);
+                                                                         max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv);
             return 0;
         });
     } else {
