@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--kstep", type=int, default=-1, help="exact search: symbols per table step (fmgpu_index_accelerate); 1 = plain occurrence table; "
                     "protein: 1 = block-table expansion of the wavelet (default), 0 = search the wavelet lines themselves")
     ap.add_argument("--no-search-accel", action="store_true", help="k2: no prefix / walk tables (fmgpu_index_accelerate_search)")
+    ap.add_argument("--no-exact-tables", action="store_true", help="exact / protein: only the k-step table (no suffix-interval table, no walk table)")
     ap.add_argument("--edit", action="store_true", help="k2: edit distance (search_ng26<Edit = true>) instead of Hamming distance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -145,7 +146,10 @@ def main():
     if args.kstep < 0:
         args.kstep = 1 if protein else 3
     if not bidir and (args.kstep > 1 or (protein and args.kstep == 1)):
-        index.accelerate(args.kstep)
+        if args.no_exact_tables:
+            index.accelerate(args.kstep)
+        else:                                                   # + interval table of the last 12 bp / 4 aa, + per-row LF^J walk table (J = 16 bp / 6 aa)
+            index.accelerate(args.kstep, lut_len=4 if protein else 12, walk=True)
     if bidir and not args.no_search_accel:
         index.accelerate_search(11, True)
     build_s = time.time() - t0
@@ -263,11 +267,12 @@ def main():
                    "sigma": sigma, "layout": "Wavelet" if protein else "InterleavedBitvector16", "queries_per_gpu": nq, "read_len": L,
                    "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale, "kstep_table": (args.kstep if not bidir else 1),
                    "device_table": ("block table expanded from the wavelet" if args.kstep else "wavelet lines") if protein else "block table",
+                   "exact_tables": None if (bidir or args.no_exact_tables or (protein and not args.kstep)) else {"suffix_interval_symbols": 4 if protein else 12, "walk_symbols_per_load": 6 if protein else 16},
                    "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
         "gbp_per_s": qps * L / 1e9,
         "hits": hits,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": ("k_exact_a" if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if args.kstep > 1 else "k_exact_a") if not bidir else ("k_scheme_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
+                     "traffic": traffic, "kernel": (("k_exact_a" if args.no_exact_tables else "k_exact_kstep") if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if args.kstep > 1 else "k_exact_a") if not bidir else ("k_scheme_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
                      "units_per_launch": steps_per_launch, "bytes_per_unit": unit_bytes,
                      "unit": "GB/s", "note": NOTE_PROTEIN if protein else NOTE_DNA},
     }

@@ -362,6 +362,11 @@ struct DevString {
     uint8_t* kblk = nullptr; uint32_t kstep = 0, kcodes = 0; size_t kblk_bytes = 0;
     // walk table (fmgpu_index_accelerate_search): walk3[3*i .. 3*i+2] = LF(i), LF^2(i), LF^3(i)
     idx_t* walk3 = nullptr;
+    // exact-search accelerators (fmgpu_index_accelerate_exact):
+    //   slut[code] = {lb, len} of the backward search of the slut_len symbols with code = sum (c_t - 1) * (sigma-1)^t, c_0 = the LAST symbol;
+    //   walkj[row] = {LF^J(row), sum (s_t - 1) << (walk_bits * t)} with s_1.. the symbols met (s_0 = BWT symbol of row), or {~0, 0} if a delimiter is met
+    uint2* slut = nullptr; uint32_t slut_len = 0; uint64_t slut_entries = 0;
+    uint2* walkj = nullptr; uint32_t walk_J = 0, walk_bits = 0;
     // Format A shadow of a Format R / W string (fmgpu_index_accelerate, kstep >= 1): the searches then read `va` (one line per
     // LF step instead of bitct lines); fmgpu_string_query keeps answering from the native format.
     void* shadow = nullptr; size_t shadow_bytes = 0;

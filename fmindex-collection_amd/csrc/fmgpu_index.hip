@@ -278,6 +278,9 @@ void free_string(DevString& s) {
     if (s.walk3) (void)hipFree(s.walk3);
     if (s.shadow) (void)hipFree(s.shadow);
     s.shadow = nullptr; s.shadow_bytes = 0;
+    if (s.slut) (void)hipFree(s.slut);
+    if (s.walkj) (void)hipFree(s.walkj);
+    s.slut = nullptr; s.walkj = nullptr; s.slut_len = 0; s.slut_entries = 0; s.walk_J = 0;
     s.blk = s.aux = nullptr; s.lf_table = nullptr; s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0; s.walk3 = nullptr;
 }
 
@@ -471,6 +474,41 @@ __global__ __launch_bounds__(256) void k_walk3(const idx_t* __restrict__ lf, uin
     if (i >= n) return;
     idx_t a = lf[i], b = lf[a], c = lf[b];
     out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
+}
+// suffix table for exact search: the interval of the L symbols c_0 (consumed first = the query's last symbol), c_1, ...
+template <class Occ>
+__global__ __launch_bounds__(256) void k_suffix_lut(Occ occ, uint64_t entries, uint32_t L, uint32_t R, idx_t n, uint2* __restrict__ lut) {
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= entries) return;
+    idx_t lb = 0, len = n;
+    uint64_t rest = w;
+    for (uint32_t t = 0; t < L && len != 0; ++t) {
+        uint32_t c = (uint32_t)(rest % R) + 1; rest /= R;
+        idx_t ra, rb;
+        occ.lf2(lb, lb + len, c, ra, rb);
+        lb = ra; len = rb - ra;
+    }
+    lut[w] = make_uint2(lb, len);
+}
+// J LF steps from every row, remembering the symbols met
+__global__ __launch_bounds__(256) void k_walkj(const idx_t* __restrict__ lf, const idx_t* __restrict__ C, uint32_t sigma, uint64_t n, uint32_t J, uint32_t bits,
+                                               uint2* __restrict__ out) {
+    __shared__ idx_t sC[257];
+    for (uint32_t i = threadIdx.x; i <= sigma; i += blockDim.x) sC[i] = C[i];
+    __syncthreads();
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    idx_t r = (idx_t)i;
+    uint32_t code = 0; bool ok = true;
+    for (uint32_t t = 0; t < J; ++t) {
+        idx_t nr = lf[r];
+        uint32_t lo = 0, hi = sigma;                   // symbol of the step: C[s] <= LF < C[s+1]
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sC[mid] <= nr) lo = mid; else hi = mid; }
+        if (lo == 0) { ok = false; break; }
+        code |= (lo - 1u) << (bits * t);
+        r = nr;
+    }
+    out[i] = ok ? make_uint2(r, code) : make_uint2(0xffffffffu, 0u);
 }
 // bidirectional interval of every string w of L symbols in [1, sigma): extendRight symbol by symbol (fmindex/BiFMIndexCursor.h:121-128)
 template <class Occ>
@@ -666,6 +704,49 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
     }
     if (rc == 0) x->device_bytes += s.kblk_bytes;
     return rc;
+}
+
+int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (lut_len < 0 || lut_len > 32) return fail(FMGPU_ERR_INVALID, "lut_len must be in [0, 32]");
+    int rc = fmgpu_index_accelerate(h, kstep);
+    if (rc) return rc;
+    DevString& s = x->bwt;
+    const uint64_t n = s.n;
+    if (s.slut) { (void)hipFree(s.slut); x->device_bytes -= s.slut_entries * 8; s.slut = nullptr; s.slut_len = 0; s.slut_entries = 0; }
+    if (s.walkj) { (void)hipFree(s.walkj); x->device_bytes -= n * 8; s.walkj = nullptr; s.walk_J = 0; }
+    if (n == 0) return 0;
+    const uint32_t sigma = (uint32_t)s.sigma, R = sigma - 1;
+    if (lut_len > 0) {
+        uint64_t entries = 1;
+        for (int t = 0; t < lut_len; ++t) { entries *= R; if (entries > (1ull << 28)) return fail(FMGPU_ERR_UNSUPPORTED, "suffix table would exceed 2^28 entries"); }
+        FM_HIP(hipMalloc((void**)&s.slut, entries * 8));
+        dim3 grid((unsigned)((entries + 255) / 256)), block(256);
+        switch (s.search_family()) {
+        case FAM_A:
+            if (s.sigma == 5) k_suffix_lut<OccA<5>><<<grid, block>>>(OccA<5>{s.va}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut);
+            else k_suffix_lut<OccA<0>><<<grid, block>>>(OccA<0>{s.va}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut);
+            break;
+        case FAM_EPR:   k_suffix_lut<OccR<false>><<<grid, block>>>(OccR<false>{s.vr}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut); break;
+        case FAM_EPRV2: k_suffix_lut<OccR<true>><<<grid, block>>>(OccR<true>{s.vr}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut); break;
+        default:        k_suffix_lut<OccW><<<grid, block>>>(OccW{s.vw}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut); break;
+        }
+        FM_HIP(hipDeviceSynchronize());
+        s.slut_len = (uint32_t)lut_len; s.slut_entries = entries;
+        x->device_bytes += entries * 8;
+    }
+    if (walk) {
+        if (!s.lf_table) return fail(FMGPU_ERR_INVALID, "the walk table needs the LF table (FMGPU_LF_TABLE=0 was set)");
+        uint32_t bits = 1; while ((1u << bits) < R) ++bits;               // symbols 1 .. sigma-1 stored as 0 .. sigma-2
+        const uint32_t J = 32u / bits;
+        FM_HIP(hipMalloc((void**)&s.walkj, n * 8 + 16));
+        k_walkj<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s.lf_table, x->dC, sigma, n, J, bits, s.walkj);
+        FM_HIP(hipDeviceSynchronize());
+        s.walk_J = J; s.walk_bits = bits;
+        x->device_bytes += n * 8;
+    }
+    return 0;
 }
 
 int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t walk) {

@@ -848,8 +848,14 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
 // and step count are exactly those of search/SearchNoErrors.h:12-26.  The query is staged in LDS up front (one query per
 // lane: the staging is wave-synchronous by construction); the next chunk's context code is fetched from LDS while the
 // table entries of the current chunk are in flight, and both interval ends are loaded together.
+struct ExactAccel {
+    const uint8_t* kblk; uint32_t K, ncodes;        // k-symbol-step table (or null)
+    const uint2* slut; uint32_t lutL;               // interval of the query's last lutL symbols (or null)
+    const uint2* walk; uint32_t J, wbits;           // per row LF^J + the J symbols met (or null)
+};
+
 template <class Occ>
-__global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, const uint8_t* __restrict__ kblk, uint32_t K, uint32_t ncodes, uint32_t R,
+__global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uint32_t R,
                                                      const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
                                                      uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                      unsigned long long* __restrict__ steps_total, uint32_t qwords, uint32_t qnib, uint32_t maxm) {
@@ -861,39 +867,64 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, const uint8_t* __r
     const uint32_t m = active ? (uint32_t)(qoff[q + 1] - o) : 0;
     const uint8_t* sq = qbuf + o;
     const uint32_t sigma = occ.sigma();
+    const uint32_t K = ac.K, ncodes = ac.ncodes;
     qstage_load_sync(qst, qbuf, o, m, sigma, active && m != 0, maxm);
     uint32_t steps = 0;
     if (active) {
         idx_t lb = 0, len = n;
         uint32_t done = 0;                                       // symbols consumed (from the right end)
-        auto chunk_code = [&](uint32_t from, bool& valid) -> uint32_t {   // context code of the K symbols ending at position m-1-from
-            uint32_t code = 0, mul = 1; valid = m - from >= K;
-            if (valid) for (uint32_t t = 0; t < K; ++t) {
+        // code of the `cnt` symbols ending at position m-1-from, radix R (tables indexed by contexts) or `shift` bits per symbol (walk table)
+        auto code_of = [&](uint32_t from, uint32_t cnt, uint32_t shift, bool& valid) -> uint32_t {
+            uint32_t code = 0, mul = 1; valid = m - from >= cnt;
+            if (valid) for (uint32_t t = 0; t < cnt; ++t) {
                 uint32_t c = qstage_get(qst, sq, m - 1 - from - t);
                 valid = valid && c >= 1 && c < sigma;
-                code += (c - 1) * mul; mul *= R;
+                if (shift) code |= (c - 1) << (shift * t); else { code += (c - 1) * mul; mul *= R; }
             }
             return code;
         };
-        bool valid = false;
-        uint32_t code = m ? chunk_code(0, valid) : 0;
-        // main phase: whole chunks through the table.  A chunk that empties the interval (or holds an odd symbol) ends the
-        // phase for this lane WITHOUT touching the cursor: its single-step walk is deferred to the tail phase, where all lanes
-        // of the wave are convergent again (a lane-private re-walk here would stall the other 63 lanes for up to K round trips).
-        while (valid) {
+        if (ac.slut && n > 1) {                                  // the last lutL symbols at once; an empty entry is walked step by step instead
+            bool v = false;                                      // (the reference's cursor and step count at the failing step are part of the result)
+            const uint32_t code = code_of(0, ac.lutL, 0, v);
+            if (v) { const uint2 en = ac.slut[code]; if (en.y != 0) { lb = en.x; len = en.y; done = ac.lutL; steps = ac.lutL; } }
+        }
+        // main phase: one table load per iteration.  One row left: J symbols per load from the walk table; otherwise K symbols from the
+        // context table.  A step that would empty the interval (or meets an odd symbol) ends the phase WITHOUT touching the cursor:
+        // its single-step walk is left to the tail phase, where the lanes of the wave are convergent again.
+        for (;;) {
+            if (ac.walk && len == 1 && m - done >= ac.J) {
+                bool v = false;
+                const uint32_t qc = code_of(done, ac.J, ac.wbits, v);
+                if (!v) break;
+                const uint2 en = ac.walk[lb];
+                if (en.x == 0xffffffffu || en.y != qc) break;
+                lb = en.x; done += ac.J; steps += ac.J;
+                continue;
+            }
+            if (!ac.kblk) {                                      // no context table: one symbol per iteration from the occurrence table itself
+                if (done >= m) break;
+                const uint32_t c = qstage_get(qst, sq, m - 1 - done);
+                if (c >= sigma) break;
+                idx_t ra, rb;
+                occ.lf2(lb, lb + len, c, ra, rb);
+                if (rb == ra) break;
+                lb = ra; len = rb - ra; ++steps; ++done;
+                continue;
+            }
+            bool valid = false;
+            const uint32_t code = code_of(done, K, 0, valid);
+            if (!valid) break;
             const idx_t a = lb, b = lb + len;
-            EntryA ea = load_entry_a(kblk + (size_t)code * 16u, ncodes * 16u, a, 0);       // same 12-byte entry shape as Format A
+            EntryA ea = load_entry_a(ac.kblk + (size_t)code * 16u, ncodes * 16u, a, 0);       // same 12-byte entry shape as Format A
             EntryA eb = ea;
-            if ((a >> 6) != (b >> 6)) eb = load_entry_a(kblk + (size_t)code * 16u, ncodes * 16u, b, 0);
-            bool nvalid = false;
-            const uint32_t ncode = chunk_code(done + K, nvalid);   // LDS reads overlap the table loads
+            if ((a >> 6) != (b >> 6)) eb = load_entry_a(ac.kblk + (size_t)code * 16u, ncodes * 16u, b, 0);
             idx_t ra = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
             idx_t rb = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
             if (rb == ra) break;
-            lb = ra; len = rb - ra; steps += K; done += K; code = ncode; valid = nvalid;
+            lb = ra; len = rb - ra; steps += K; done += K;
         }
-        // tail phase: single steps — the chunk that failed in the table (at most K steps until the interval is empty), the
-        // symbols after an odd one, or the m mod K left-over symbols
+        // tail phase: single steps — the step that failed in a table (until the interval is empty), the symbols after an odd one,
+        // or the left-over symbols
         while (len != 0 && done < m) {
             uint32_t c = qstage_get(qst, sq, m - 1 - done);
             ++steps; ++done;
@@ -1358,17 +1389,19 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     const int variant = [] { const char* e = getenv("FMGPU_EXACT_VARIANT"); return e ? atoi(e) : 2; }();   // dev knob
     timer.start();
     uint32_t kq_words = 0, kq_max = 0, kq_nib = x->bwt.sigma <= 15 ? 1u : 0u;
-    if (x->bwt.kblk && variant != 0) {                           // LDS staging needs the longest query of the batch
+    const bool accel = (x->bwt.kblk || x->bwt.slut || x->bwt.walkj) && variant != 0;
+    if (accel) {                                                 // LDS staging needs the longest query of the batch
         uint32_t mn = 0;
         if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &kq_max, &mn))) { (void)hipFree(dsteps); return rc; }
         kq_words = kq_nib ? (kq_max + 7) / 8 : (kq_max + 3) / 4;
         if ((size_t)kq_words * 1024 > 48 * 1024) kq_words = 0;  // very long queries: read them from global memory
         timer.start();
     }
-    if (x->bwt.kblk && variant != 0) {
+    if (accel) {
         const DevString& bs = x->bwt;
+        ExactAccel ac{bs.kblk, bs.kstep, bs.kcodes, bs.slut, bs.slut_len, bs.walkj, bs.walk_J, bs.walk_bits};
         rc = dispatch_occ(bs, [&](auto occ, auto) {
-            k_exact_kstep<decltype(occ)><<<grid, block, (size_t)kq_words * 1024, stream>>>(occ, bs.kblk, bs.kstep, bs.kcodes, (uint32_t)bs.sigma - 1,
+            k_exact_kstep<decltype(occ)><<<grid, block, (size_t)kq_words * 1024, stream>>>(occ, ac, (uint32_t)bs.sigma - 1,
                                                                     (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev,
                                                                     (uint64_t*)slen.dev, dsteps, kq_words, kq_nib, kq_max);
             return 0;

@@ -151,6 +151,13 @@ int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layo
  * answering from the native layout.  kstep = 0 removes the k-step table and the expansion. */
 int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep);
 
+/* fmgpu_index_accelerate plus two more optional tables for fmgpu_search_exact (results unchanged):
+ *   lut_len > 0: the interval of every string of `lut_len` symbols ((sigma-1)^lut_len entries of 8 bytes; DNA, 12 symbols: 134 MB) — a query
+ *                starts from the entry of its last lut_len symbols instead of lut_len wide-interval steps;
+ *   walk != 0:   per row LF^J and the J symbols met on the way, J = 32 / bit_width(sigma-2) (DNA: 16 symbols, protein: 6; 8 bytes per row):
+ *                once the interval is one row, J query symbols are checked and consumed with one load. */
+int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk);
+
 /* Optional accelerators for fmgpu_search_scheme on a BiFMIndex (results unchanged):
  *   prefix_len > 0: table of the bidirectional SA interval of every string of `prefix_len` symbols ((sigma-1)^prefix_len entries of 16 bytes; DNA,
  *                   11 symbols: 67 MB) — the always-exact first part of a search (u[0] = 0, search_scheme/generator/h2.h) starts from its entry;

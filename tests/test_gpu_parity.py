@@ -134,7 +134,7 @@ def test_exact_search_edge_cases():
     assert np.array_equal(dlb.to_array(np.uint64, len(queries)), olb)
 
 
-@pytest.mark.parametrize("layout,sigma,kstep", [("IB16", 5, 2), ("IB16", 5, 3), ("IB16A", 4, 2), ("EPRV2_16", 5, 3), ("WAVELET", 5, 2), ("IB16", 6, 3)])
+@pytest.mark.parametrize("layout,sigma,kstep", [("IB16", 5, 2), ("IB16", 5, 3), ("IB16A", 4, 2), ("EPRV2_16", 5, 3), ("WAVELET", 5, 2), ("IB16", 6, 3), ("WAVELET", 28, 1), ("IB16", 28, 1)])
 def test_exact_search_with_kstep_accelerator(layout, sigma, kstep):
     """fmgpu_index_accelerate: same cursors (also for misses: lb/len of the step that emptied the interval) and same step counts"""
     rng = np.random.default_rng(kstep + sigma)
@@ -156,6 +156,10 @@ def test_exact_search_with_kstep_accelerator(layout, sigma, kstep):
     olb, oln, ost = ox.search_exact(vb, vo, want_steps=True)
     assert np.array_equal(lb[valid], olb) and np.array_equal(ln[valid], oln)
     assert ln[-1] == 0
+    for lut_len, walk, ks in ((4, False, kstep), (0, True, kstep), (5, True, kstep), (3, True, 1), (2, False, 1)):   # suffix table / walk table, with and without the k-step table
+        gx.accelerate(ks, lut_len=lut_len, walk=walk)
+        lb3, ln3, st3 = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+        assert np.array_equal(lb3, lb) and np.array_equal(ln3, ln) and st3.lf_steps == st.lf_steps, (lut_len, walk, ks)
     gx.accelerate(0)
     lb2, ln2 = fm.search_no_errors.search(gx, (qbuf, qoff))
     assert np.array_equal(lb2, lb) and np.array_equal(ln2, ln)
