@@ -35,10 +35,10 @@ GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 1708059
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BLOCK_BYTES_IB16_S5 = 56       # sizeof(InterleavedBitvector16<5>::Block), SURVEY.md appendix B
 NOTE_DNA = ("unit = executed LF step (exact) / visited node (k=2), identical to the CPU walk; bytes_per_unit = 2 x sizeof(InterleavedBitvector16<5>::Block) "
-            "of the reference layout (SURVEY 8d). The kstep table serves 3 LF steps per touched line, so algorithmic bytes exceed the traffic; see "
-            "line_rate for the hardware bound")
+            "of the reference layout (SURVEY 8d). The tables serve many LF steps per touched line (12 from the interval table, 3 per k-step entry, 16 per "
+            "walk entry), so algorithmic bytes exceed the traffic; see line_rate for the hardware bound")
 NOTE_PROTEIN = ("unit = executed LF step, identical to the CPU walk; bytes_per_unit = 2 ends x 5 levels x (8 + 1 + 8) B the reference's Wavelet rank reads "
-                "(SURVEY 8d). The expanded block table answers a step from one 12-byte entry per end, so algorithmic bytes exceed the traffic; see "
+                "(SURVEY 8d). The expanded block table answers a step from one 12-byte entry per end and the walk table 6 steps per entry, so algorithmic bytes exceed the traffic; see "
                 "line_rate for the hardware bound")
 PROTEIN_SEQS, PROTEIN_SEQ_LEN = 4_000_000, 500      # UniRef50 stand-in (the release itself is not available offline): 2.0e9 residues
 
@@ -250,7 +250,14 @@ def main():
     traffic, lines = None, None                               # HBM bytes / line requests per launch from the committed PMC passes
     try:
         tall = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = ("protein_exact" if args.kstep else "protein_exact_wavelet_lines") if protein else ("grch38_k2_edit" if args.edit else "grch38_k2") if bidir else ("grch38_exact" if args.kstep == 3 else "grch38_exact_kstep%d" % args.kstep)
+        if protein:
+            key = "protein_exact_wavelet_lines" if not args.kstep else ("protein_exact_block_table_only" if args.no_exact_tables else "protein_exact")
+        elif bidir:
+            key = "grch38_k2_edit" if args.edit else "grch38_k2"
+        elif args.no_exact_tables:
+            key = "grch38_exact_kstep3_only" if args.kstep == 3 else "grch38_exact_kstep%d" % args.kstep
+        else:
+            key = "grch38_exact" if args.kstep == 3 else "grch38_exact_kstep%d_tables" % args.kstep
         tj = tall[key]
         if args.scale == 1.0 and nq == 10_000_000 and L == (40 if protein else 101):
             traffic, lines = tj["bytes_per_launch"], tj["line_requests_per_launch"]
