@@ -151,7 +151,7 @@ def main():
         else:                                                   # + interval table of the last 12 bp / 4 aa, + per-row LF^J walk table (J = 16 bp / 6 aa)
             index.accelerate(args.kstep, lut_len=4 if protein else 12, walk=True)
     if bidir and not args.no_search_accel:
-        index.accelerate_search(11, True)
+        index.accelerate_search(11, 3)
     build_s = time.time() - t0
     if not want_cpu:
         del text

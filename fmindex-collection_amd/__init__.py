@@ -186,8 +186,9 @@ class FMIndex:
         return self.n
 
     def accelerate_search(self, prefix_len=11, walk=True):
-        """BiFMIndex: prefix table for the exact first part of a search + LF/LF^2/LF^3 walk tables; results are unchanged"""
-        capi.check(capi.lib().fmgpu_index_accelerate_search(self._h, prefix_len, 1 if walk else 0))
+        """BiFMIndex: prefix table for the exact first part of a search + walk tables (walk: True / 1 = LF, LF^2, LF^3 per row; 2 = LF^16 with
+        the 16 symbols met; 3 = both); results are unchanged"""
+        capi.check(capi.lib().fmgpu_index_accelerate_search(self._h, prefix_len, int(walk)))
         dbytes = C.c_uint64()
         capi.check(capi.lib().fmgpu_index_info(self._h, None, None, None, None, C.byref(dbytes)))
         self.device_bytes = dbytes.value

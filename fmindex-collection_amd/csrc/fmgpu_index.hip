@@ -758,13 +758,24 @@ int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t w
     // drop what exists
     if (x->lut) { (void)hipFree(x->lut); x->device_bytes -= x->lut_entries * 16; x->lut = nullptr; x->lut_len = 0; x->lut_entries = 0; }
     for (DevString* s : {&x->bwt, &x->rev}) if (s->walk3) { (void)hipFree(s->walk3); s->walk3 = nullptr; x->device_bytes -= n * 12; }
+    if (x->rev.walkj) { (void)hipFree(x->rev.walkj); x->rev.walkj = nullptr; x->rev.walk_J = 0; x->device_bytes -= n * 8; }
     if (n == 0) return 0;
     if (walk) {
+        const uint32_t sigma = (uint32_t)x->bwt.sigma;
+        uint32_t bits = 1; while ((1u << bits) < sigma - 1) ++bits;
         for (DevString* s : {&x->bwt, &x->rev}) {
             if (!s->lf_table) return fail(FMGPU_ERR_INVALID, "walk tables need the LF tables (FMGPU_LF_TABLE=0 was set)");
-            FM_HIP(hipMalloc((void**)&s->walk3, n * 12 + 16));
-            k_walk3<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s->lf_table, n, s->walk3);
-            x->device_bytes += n * 12;
+            if (walk & 1) {
+                FM_HIP(hipMalloc((void**)&s->walk3, n * 12 + 16));
+                k_walk3<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s->lf_table, n, s->walk3);
+                x->device_bytes += n * 12;
+            }
+            if ((walk & 2) && !s->walkj) {                          // (the forward one may exist already: fmgpu_index_accelerate_exact)
+                FM_HIP(hipMalloc((void**)&s->walkj, n * 8 + 16));
+                k_walkj<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s->lf_table, x->dC, sigma, n, 32u / bits, bits, s->walkj);
+                s->walk_J = 32u / bits; s->walk_bits = bits;
+                x->device_bytes += n * 8;
+            }
         }
         FM_HIP(hipDeviceSynchronize());
     }

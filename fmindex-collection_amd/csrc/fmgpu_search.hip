@@ -783,7 +783,9 @@ struct FastArgs {
     const idx_t* lf_fw; const idx_t* lf_rv;     // LF tables of bwt / bwtRev
     const idx_t* w3_fw; const idx_t* w3_rv;     // LF, LF^2, LF^3 per row (fmgpu_index_accelerate_search), or null
     const uint4* lut; uint32_t lutL, lut_ok;    // prefix table, its string length, bit s: search s may start from it
-    const uint32_t* steps;                      // [S][m + 1]: pos:16 | right:1 | lastOfPart:1 | minE:5 | maxE:7 | run:2; entry m = final window
+    const uint2* wj_fw; const uint2* wj_rv;     // per row {LF^16, the 16 symbols met} (2 bits each), or null
+    const uint32_t* steps;                      // [S][m + 1]: pos:16 | right:1 | lastOfPart:1 | minE:5 | maxE:6 | run16:1 | run:2; entry m = final window;
+                                                // followed by [S][m + 1] stretch words for run16 steps: tb:5 | hi1:6 | hi2:6 | lo:5 | simple:1 (see build_step_table)
     uint32_t S, m;
     idx_t C1[8];                                // C[1..] for sigma <= 8 (symbol of an LF value), unused otherwise
 };
@@ -957,9 +959,10 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
     extern __shared__ uint32_t s_dyn[];
     uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
-    uint32_t* s_hits = s_steps + S * stride;                        // [kHitBuf][5][256]: lb, lbRev, len, e, seq
+    const uint32_t* s_stretch = s_steps + S * stride;               // stretch words of the run16 steps
+    uint32_t* s_hits = s_steps + 2u * S * stride;                   // [kHitBuf][5][256]: lb, lbRev, len, e, seq
     const QStage qst{s_dyn, qwords, qnib};
-    for (uint32_t i = threadIdx.x; i < S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
+    for (uint32_t i = threadIdx.x; i < 2u * S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
     __syncthreads();
 
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1010,7 +1013,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                 bool back = false;
                 if (multi) {
                     // ---- extend-all node (search_next_dir, :143-224) or exact-tail step over several rows
-                    const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x7fu;
+                    const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
                     const bool lastp = (ent >> 17) & 1u;
                     idx_t lfa[MAXSIG], lfb[MAXSIG];
                     const OccA<SIGMA>& occ = right ? rv : fw;
@@ -1046,6 +1049,64 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                     } else back = true;
                 } else {
                     // ---- single row (search_next_dir_single, :251-365): the only child is the BWT symbol of the row; up to `run` steps per load
+                    const uint2* wj = right ? fa.wj_rv : fa.wj_fw;
+                    bool walked = false;
+                    if (wj && ((ent >> 29) & 1u)) {
+                        // 16 steps in one go: the walk table gives LF^16 and the 16 symbols met; they are compared with the query's 16 symbols as
+                        // two 32-bit codes.  All equal and one window check for the whole stretch: done; otherwise step by step from registers.
+                        const uint2 we = wj[a];
+                        if (we.x != 0xffffffffu) {
+                            walked = true;
+                            const uint32_t pos = ent & 0xffffu;
+                            const uint32_t p0 = right ? pos : pos - 15u;                 // lowest query position of the stretch
+                            const uint32_t w0 = qst.lds[(p0 >> 3) * 256u + threadIdx.x], w1 = qst.lds[((p0 >> 3) + 1u) * 256u + threadIdx.x];
+                            const uint32_t w2 = (p0 & 7u) ? qst.lds[((p0 >> 3) + 2u) * 256u + threadIdx.x] : 0u;
+                            const uint32_t sh = 4u * (p0 & 7u);
+                            uint64_t x = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh;
+                            if (sh) x |= (uint64_t)w2 << (64u - sh);
+                            const uint64_t v = x - 0x1111111111111111ull;                // nibbles 1..4 -> 0..3
+                            const bool qvalid = ((v & ~x & 0x8888888888888888ull) == 0ull) && ((v & 0xccccccccccccccccull) == 0ull);
+                            uint64_t t = v & 0x3333333333333333ull;
+                            t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full; t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
+                            t = (t | (t >> 8)) & 0x0000ffff0000ffffull; t = (t | (t >> 16)) & 0x00000000ffffffffull;
+                            uint32_t qc = (uint32_t)t;                                   // symbol at position p0 + k in bits 2k
+                            if (!right) { qc = __brev(qc); qc = ((qc >> 1) & 0x55555555u) | ((qc & 0x55555555u) << 1); }   // ... at position pos - k
+                            const uint32_t sw = s_stretch[si * stride + j];
+                            const uint32_t tb = sw & 31u, hi1 = (sw >> 5) & 63u, hi2 = (sw >> 11) & 63u, lo = (sw >> 17) & 31u;
+                            if (qvalid && qc == we.y && ((sw >> 22) & 1u) && lo <= e && e <= hi1) {
+                                // every step is a match inside its window; extensions as the reference counts them: one per step plus one where an
+                                // exact tail starts (no error left in the part and not in a tail yet), :310-314
+                                uint32_t bonus = (!in_tail && e == hi1) ? 1u : 0u;
+                                bool it = tb < 16u ? false : (in_tail || e == hi1);
+                                if (tb < 15u) { bonus += (e == hi2) ? 1u : 0u; it = e == hi2; }
+                                nodes += 16u + bonus;
+                                in_tail = it;
+                                if (right) cur.lbRev = we.x; else cur.lb = we.x;
+                                j += 16u;
+                            } else {
+                                bool dead = false;
+                                for (uint32_t kk = 0; kk < 16u && !dead; ++kk) {
+                                    const uint32_t en = tab[j + kk];
+                                    const uint32_t minE = (en >> 18) & 0x1fu, maxE = (en >> 23) & 0x3fu;
+                                    const bool lastp = (en >> 17) & 1u;
+                                    const uint32_t b = ((we.y >> (2u * kk)) & 3u) + 1u;
+                                    const uint32_t c = qstage_get(qst, qs, en & 0xffffu);
+                                    const bool mOK = minE <= e && e <= maxE;
+                                    const bool sOK = minE <= e + 1 && e + 1 <= maxE;
+                                    const bool xOK = e + 1 <= maxE;
+                                    const bool is_match = b == c && mOK;
+                                    nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
+                                    if (b == c) { if (!mOK) dead = true; }
+                                    else if (sOK) e += 1;
+                                    else dead = true;
+                                    if (!dead) in_tail = !lastp && (in_tail || (is_match && !xOK));
+                                }
+                                if (dead) back = true;
+                                else { if (right) cur.lbRev = we.x; else cur.lb = we.x; j += 16u; }
+                            }
+                        }
+                    }
+                    if (!walked) {
                     const idx_t* w3 = right ? fa.w3_rv : fa.w3_fw;
                     const uint32_t run = w3 ? (ent >> 30) : 1u;    // consecutive steps in this direction (<= 3), never past the query end
                     idx_t t0, t1 = 0, t2 = 0;
@@ -1058,7 +1119,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                     for (uint32_t kk = 0; kk < 3; ++kk) {
                         if (kk < run && !dead) {
                             const uint32_t en = kk == 0 ? ent : tab[j + kk];
-                            const uint32_t pos = en & 0xffffu, minE = (en >> 18) & 0x1fu, maxE = (en >> 23) & 0x7fu;
+                            const uint32_t pos = en & 0xffffu, minE = (en >> 18) & 0x1fu, maxE = (en >> 23) & 0x3fu;
                             const bool lastp = (en >> 17) & 1u;
                             tk = kk == 0 ? t0 : (kk == 1 ? t1 : t2);
                             const uint32_t b = symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, tk);
@@ -1077,11 +1138,12 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                     }
                     if (dead) back = true;
                     else { if (right) cur.lbRev = last; else cur.lb = last; j += k; }   // one row: the other side's prefix count is 0
+                    }
                 }
                 bool search_over = false;
                 if (!back && j == m) {                              // search_next at part == P (:101-108)
                     const uint32_t fin = tab[m];
-                    if (((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x7fu)) {
+                    if (((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x3fu)) {
                         Cur r = cur;
                         if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
                         quota -= r.len;
@@ -1296,7 +1358,7 @@ static int query_len_range(const uint64_t* dqoff, uint64_t nq, hipStream_t strea
 
 // expands a scheme for queries of length m into the fast kernel's per-step table (see k_scheme_fast); false if it does not fit.
 // lut_ok: bit s set if search s may start from a prefix table of lutL symbols (first part longer than lutL and error free)
-static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, std::vector<uint32_t>& tab, uint32_t& lut_ok) {
+static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, uint32_t J, std::vector<uint32_t>& tab, uint32_t& lut_ok) {
     const uint32_t S = (uint32_t)sd.S, P = (uint32_t)sd.P;
     lut_ok = 0;
     if (m < P || m > 0xfffeu || (uint64_t)S * (m + 1) > 4096) return false;
@@ -1304,15 +1366,18 @@ static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, std
     uint32_t sum = 0;
     for (uint32_t p = 0; p < P; ++p) { plen[p] = sd.uniform ? m / P + (p < m % P ? 1u : 0u) : sd.partition[p]; sum += plen[p]; }
     if (sum != m) return false;
-    tab.assign((size_t)S * (m + 1), 0);
+    const size_t half = (size_t)S * (m + 1);
+    tab.assign(2 * half, 0);
     for (uint32_t s = 0; s < S; ++s) {
         const uint8_t* pi = sd.pi + s * kMaxParts; const uint8_t* L = sd.l + s * kMaxParts; const uint8_t* U = sd.u + s * kMaxParts;
         uint32_t* T = tab.data() + (size_t)s * (m + 1);
+        uint32_t* T2 = tab.data() + half + (size_t)s * (m + 1);
         uint32_t start = 0;
         for (uint32_t i = 0; i < pi[0]; ++i) start += plen[i];
         uint32_t qR = start, qL = start - 1, j = 0;              // SearchNg26.h:62-79
         for (uint32_t p = 0; p < P; ++p) {
-            if (L[p] > U[p] || L[p] > 31 || U[p] > 127) return false;   // the table form relies on l <= u (search_scheme/isValid.h:87-91)
+            if (L[p] > U[p] || L[p] > 31 || U[p] > 63) return false;    // the table form relies on l <= u (search_scheme/isValid.h:87-91)
+            if (p && (U[p] < U[p - 1] || L[p] < L[p - 1])) return false; // ... and on bounds that never shrink
             const bool right = p == 0 || pi[p - 1] < pi[p];      // :111
             const uint32_t len = plen[pi[p]];
             for (uint32_t k = 0; k < len; ++k, ++j) {
@@ -1326,6 +1391,20 @@ static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, std
             uint32_t run = 1;
             while (run < 3 && k + run < m && ((T[k + run] >> 16) & 1u) == ((T[k] >> 16) & 1u)) ++run;
             T[k] |= run << 30;
+            // run16: J steps in this direction from k on.  Their stretch word: tb = offset of the first part end inside the stretch (J if none),
+            // hi1 / hi2 = upper bound before / after it, lo = the largest lower bound that applies inside, simple = at most one part end
+            if (J && J <= 31 && k + J <= m) {
+                bool same = true; uint32_t tb = J, ends = 0, lo = 0;
+                for (uint32_t t = 0; t < J; ++t) {
+                    same = same && ((T[k + t] >> 16) & 1u) == ((T[k] >> 16) & 1u);
+                    if ((T[k + t] >> 17) & 1u) { if (!ends) tb = t; ++ends; lo = std::max(lo, (T[k + t] >> 18) & 0x1fu); }
+                }
+                if (same) {
+                    T[k] |= 1u << 29;
+                    const uint32_t hi1 = (T[k] >> 23) & 0x3fu, hi2 = tb + 1 < J ? (T[k + tb + 1] >> 23) & 0x3fu : hi1;
+                    T2[k] = tb | (hi1 << 5) | (hi2 << 11) | (lo << 17) | ((ends <= 1 ? 1u : 0u) << 22);
+                }
+            }
         }
         if (lutL && plen[pi[0]] > lutL && U[0] == 0) lut_ok |= 1u << s;
     }
@@ -1529,8 +1608,10 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     // fast path: equal-length batch on a Format-A BiFMIndex with LF tables
     std::vector<uint32_t> step_tab;
     uint32_t lut_ok = 0;
+    // 16-symbol walk: 2-bit symbols, queries staged in LDS as nibbles
+    const bool use_wj = !(sd.dev_flags & 32) && x->bwt.walkj && x->rev.walkj && x->bwt.walk_bits == 2 && x->rev.walk_bits == 2 && qnib && qwords;
     const bool fast = scheme_mode && !edit && x->bwt.search_family() == FAM_A && x->bwt.lf_table && x->rev.lf_table && minlen == maxlen &&
-                      x->bwt.sigma <= 32 && !(sd.dev_flags & 2) && build_step_table(sd, maxlen, (sd.dev_flags & 4) ? 0 : x->lut_len, step_tab, lut_ok);
+                      x->bwt.sigma <= 32 && !(sd.dev_flags & 2) && build_step_table(sd, maxlen, (sd.dev_flags & 4) ? 0 : x->lut_len, use_wj ? 16u : 0u, step_tab, lut_ok);
     uint32_t* d_steps = nullptr;
     if (fast) {
         FM_HIP(hipMalloc((void**)&d_steps, step_tab.size() * 4));
@@ -1541,6 +1622,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         FastArgs fa{};
         fa.lf_fw = x->bwt.lf_table; fa.lf_rv = x->rev.lf_table; fa.steps = d_steps; fa.S = (uint32_t)sd.S; fa.m = maxlen;
         if (!(sd.dev_flags & 8)) { fa.w3_fw = x->bwt.walk3; fa.w3_rv = x->rev.walk3; }
+        if (use_wj) { fa.wj_fw = x->bwt.walkj; fa.wj_rv = x->rev.walkj; }
         fa.lut = lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = lut_ok;
         for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
         const size_t lds_fast = lds_bytes + step_tab.size() * 4 + (size_t)kHitBuf * 5 * 256 * 4;

@@ -208,7 +208,7 @@ def test_scheme_search_matches_reference_order(k):
         assert hits[hits["qidx"] == q]["seq"].tolist() == list(range(int(qc[q])))
 
 
-@pytest.mark.parametrize("k,length", [(1, 20), (2, 31), (2, 101), (3, 64)])
+@pytest.mark.parametrize("k,length", [(1, 20), (2, 31), (2, 101), (3, 64), (2, 151), (1, 40)])
 def test_scheme_search_equal_length_fast_path(k, length):
     """equal-length batches take the table-driven kernel (k_scheme_fast): same hits, order and node count as the reference walk"""
     seqs = repeat_text(40 + k, n=6000)
@@ -217,7 +217,7 @@ def test_scheme_search_equal_length_fast_path(k, length):
     queries = mutated_queries(seqs, 1500, length, length + 1, k + 1, seed=11 + k)
     assert len({len(q) for q in queries}) == 1
     qbuf, qoff = fm.flatten(queries)
-    for accel in (None, (0, True), (3, False), (4, True), (2, True)):     # plain, walk tables only, prefix table only, both
+    for accel in (None, (0, True), (3, False), (4, True), (2, True), (0, 2), (4, 3), (3, 2)):     # plain, walk tables only, prefix table only, both; 16-symbol walk tables
         if accel is not None:
             gx.accelerate_search(*accel)
         for sch in (fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k), fm.search_scheme.backtracking(2, 0, k)):
