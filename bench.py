@@ -164,6 +164,7 @@ def main():
     hits_bufs = [torch.empty(hit_cap * 40, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)] if bidir else None
     via_host = world > 1 and args.dist_backend == "gloo"
     count_dev = torch.zeros(1, dtype=torch.int64, device="cpu" if via_host else dev)
+    packed = [torch.empty(nq, dtype=torch.int64, device=dev) for _ in range(2)] if (world > 1 and not bidir) else None
     gathered = None
     if world > 1 and rank == 0:                               # k=2 messages are sized per step (largest hit count over the ranks), at most 2*nq records
         full = 2 * nq * (40 if bidir else 8)
@@ -203,8 +204,9 @@ def main():
                 if m > 2 * nq:
                     raise SystemExit("more than 2 hits per read on average: raise the gather buffers")
                 payload = hits_bufs[b][: m * 40]
-            else:
-                payload = out.view(torch.uint8)
+            else:                                              # (lb, len) as one 64-bit word per read: rows are < 2^32, 80 MB per rank instead of 160
+                torch.bitwise_or(out[:nq] << 32, out[nq:], out=packed[b])
+                payload = packed[b].view(torch.uint8)
             if via_host:
                 payload = payload.cpu()
             pending[b] = dist.gather(payload, [g[: payload.numel()] for g in gathered[b]] if rank == 0 else None, dst=0, async_op=True)
