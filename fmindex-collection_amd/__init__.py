@@ -194,6 +194,14 @@ class FMIndex:
         self.device_bytes = dbytes.value
         return self
 
+    def accelerate_locate(self, enable=True):
+        """keep the (seqId, pos, steps) answer of every row (12 bytes per row): locate becomes one load per row; results are unchanged"""
+        capi.check(capi.lib().fmgpu_index_accelerate_locate(self._h, 1 if enable else 0))
+        dbytes = C.c_uint64()
+        capi.check(capi.lib().fmgpu_index_info(self._h, None, None, None, None, C.byref(dbytes)))
+        self.device_bytes = dbytes.value
+        return self
+
     def accelerate(self, kstep=3, lut_len=0, walk=False):
         """add (kstep >= 2) or drop (0) the multi-symbol-step table used by exact search; lut_len > 0 adds the table of the
         intervals of all strings of that many symbols, walk=True the per-row LF^J + symbols table; results are unchanged"""

@@ -389,6 +389,8 @@ struct Index {
     // sampled SA
     void *sa_l0 = nullptr, *sa_l1 = nullptr, *sa_bits = nullptr, *sa_f0 = nullptr, *sa_f1 = nullptr;
     ViewSA vsa{};
+    // fmgpu_index_accelerate_locate: the (seqId, pos, steps) answer of every row, 3 x u32 per row (or null)
+    uint32_t* loc_tab = nullptr;
     size_t device_bytes = 0;
     // prefix table (fmgpu_index_accelerate_search): lut[code(w)] = { lb, lbRev, len, symbols consumed before the interval emptied (or L) }
     uint4* lut = nullptr; uint32_t lut_len = 0; uint64_t lut_entries = 0;

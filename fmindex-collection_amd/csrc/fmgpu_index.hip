@@ -612,7 +612,7 @@ int fmgpu_index_destroy(fmgpu_index_t h) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return 0;
     free_string(x->bwt); free_string(x->rev);
-    for (void* p : {(void*)x->dC, x->sa_l0, x->sa_l1, x->sa_bits, x->sa_f0, x->sa_f1, (void*)x->lut}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)x->dC, x->sa_l0, x->sa_l1, x->sa_bits, x->sa_f0, x->sa_f1, (void*)x->lut, (void*)x->loc_tab}) if (p) (void)hipFree(p);
     delete x;
     return 0;
 }

@@ -28,6 +28,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// step counters of the one-thread-per-query kernels: striped over kCounterStripes words (a single word would serialise one
+// atomic per wave — 156 k of them for 10 M queries — behind each other)
+constexpr uint32_t kCounterStripes = 64;
+
 // ------------------------------------------------------------------ exact search
 template <class Occ>
 __global__ __launch_bounds__(256) void k_exact(Occ occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(256) void k_exact(Occ occ, const uint8_t* __restric
         out_lb[q] = lb; out_len[q] = len;
     }
     uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
 }
 
 // ---- exact search, tuned variants (Format A only) ---------------------------------------------------------------
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
         out_lb[q] = lb; out_len[q] = len;
     }
     uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
 }
 
 // two queries per lane, interleaved: twice the loads in flight per wave
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void k_exact_a2(OccA<SIGMA> occ, const uint8_t
         if (has1) { out_lb[q1] = lb1; out_len[q1] = len1; }
     }
     uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
 }
 
 // ------------------------------------------------------------------ DFS machinery
@@ -177,6 +181,7 @@ struct SchemeDev {             // flattened [search][part]; values fit a byte (e
 };
 
 struct Counters { unsigned long long hits, nodes, next; };
+
 
 // lane-interleaved frame stack: frame d of lane g at word (d * nlanes + g) of three u64 planes
 struct StackView { uint64_t *p0, *p1, *p2, *p3; uint64_t nlanes; uint32_t depth; uint32_t batch; };   // p3: edit-distance kernel only
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) void k_exact_w(ViewW v, const uint8_t* __restr
         out_lb[q] = a; out_len[q] = b - a;
     }
     uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
 }
 
 // ---- search_ng26 Hamming --------------------------------------------------------------------------------------
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
         out_lb[q] = lb; out_len[q] = len;
     }
     uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
 }
 
 constexpr uint32_t kHitBuf = 2;      // hits buffered per lane and round in LDS; further hits of the same query are emitted directly
@@ -1265,6 +1270,25 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
 }
 
 // ------------------------------------------------------------------ locate
+// with the per-row answer table (fmgpu_index_accelerate_locate): one 12-byte load per row
+__global__ __launch_bounds__(256) void k_locate_tab(const uint32_t* __restrict__ tab, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
+                                                    uint64_t* __restrict__ out_seq, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_steps,
+                                                    unsigned long long* __restrict__ steps_total) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t steps = 0;
+    if (t < count) {
+        uint64_t r = rows[t], seq = ~0ull, pos = ~0ull, st = ~0ull;
+        if (r < n) {
+            const uint32_t* p = tab + 3u * (size_t)r;
+            const uint32_t a = p[0], b = p[1], c = p[2];
+            if (c != 0xffffffffu) { seq = a; pos = b; st = c; steps = c; }
+        }
+        out_seq[t] = seq; out_pos[t] = pos; out_steps[t] = st;
+    }
+    uint32_t tot = wave_sum(steps);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
+}
+
 constexpr uint32_t kLocateStepCap = 1u << 24;   // a valid index reaches a sampled row long before; bounds a corrupt one
 
 template <class Occ>
@@ -1293,7 +1317,7 @@ __global__ __launch_bounds__(256) void k_locate(Occ occ, const idx_t* __restrict
         out_seq[t] = seq; out_pos[t] = pos; out_steps[t] = st;
     }
     uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(steps_total, (unsigned long long)tot);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
 }
 
 // ------------------------------------------------------------------ host launchers
@@ -1440,6 +1464,34 @@ struct DfsWorkspace {
 
 using namespace fmgpu;
 
+namespace {
+// per host thread and device: one zero-on-demand counter block for calls that report stats (they synchronise before returning, so it
+// is idle between calls) and one sink for calls that do not (never read)
+struct StepScratch { unsigned long long* ctr = nullptr; unsigned long long* sink = nullptr; int dev = -1; };
+int step_counters(bool want, hipStream_t stream, unsigned long long** out) {
+    static thread_local StepScratch sc;
+    int dev = 0;
+    FM_HIP(hipGetDevice(&dev));
+    if (sc.dev != dev) {                                          // first use on this device (blocks of an earlier device are left to the process)
+        sc.ctr = sc.sink = nullptr; sc.dev = dev;
+        FM_HIP(hipMalloc((void**)&sc.ctr, kCounterStripes * 8));
+        FM_HIP(hipMalloc((void**)&sc.sink, kCounterStripes * 8));
+    }
+    if (want) FM_HIP(hipMemsetAsync(sc.ctr, 0, kCounterStripes * 8, stream));
+    *out = want ? sc.ctr : sc.sink;
+    return 0;
+}
+int read_step_counters(const unsigned long long* dev, hipStream_t stream, unsigned long long* total) {
+    unsigned long long h[kCounterStripes];
+    FM_HIP(hipMemcpyAsync(h, dev, sizeof h, hipMemcpyDeviceToHost, stream));
+    FM_HIP(hipStreamSynchronize(stream));
+    unsigned long long t = 0;
+    for (unsigned long long v : h) t += v;
+    *total = t;
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
@@ -1460,8 +1512,7 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     if ((rc = slb.out(out_lb, nq * 8, stream))) return rc;
     if ((rc = slen.out(out_len, nq * 8, stream))) return rc;
     unsigned long long* dsteps = nullptr;
-    FM_HIP(hipMalloc((void**)&dsteps, 8));
-    FM_HIP(hipMemsetAsync(dsteps, 0, 8, stream));
+    if ((rc = step_counters(stats != nullptr, stream, &dsteps))) return rc;
     EventTimer timer(stream, stats != nullptr);
     dim3 grid((unsigned)((nq + 255) / 256)), block(256);
     const idx_t n = (idx_t)x->bwt.n;
@@ -1471,7 +1522,7 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     const bool accel = (x->bwt.kblk || x->bwt.slut || x->bwt.walkj) && variant != 0;
     if (accel) {                                                 // LDS staging needs the longest query of the batch
         uint32_t mn = 0;
-        if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &kq_max, &mn))) { (void)hipFree(dsteps); return rc; }
+        if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &kq_max, &mn))) return rc;
         kq_words = kq_nib ? (kq_max + 7) / 8 : (kq_max + 3) / 4;
         if ((size_t)kq_words * 1024 > 48 * 1024) kq_words = 0;  // very long queries: read them from global memory
         timer.start();
@@ -1497,7 +1548,7 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
         if (x->bwt.sigma == 5) launch(OccA<5>{x->bwt.va}); else launch(OccA<0>{x->bwt.va});
     } else if (x->bwt.search_family() == FAM_WAVELET && variant != 0) {
         uint32_t mx = 0, mn = 0;
-        if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) { (void)hipFree(dsteps); return rc; }
+        if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) return rc;
         uint32_t qw = (mx + 3) / 4;
         if ((size_t)qw * 1024 > 48 * 1024) qw = 0;
         timer.start();
@@ -1512,18 +1563,15 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     }
     timer.stop();
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { (void)hipFree(dsteps); return hip_fail(e, "k_exact launch"); }
+    if (e != hipSuccess) return hip_fail(e, "k_exact launch");
     if (stats) {
         unsigned long long hs = 0;
-        e = hipMemcpyAsync(&hs, dsteps, 8, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) { (void)hipFree(dsteps); return hip_fail(e, "k_exact"); }
+        if ((rc = read_step_counters(dsteps, stream, &hs))) return rc;
         stats->lf_steps = hs; stats->hits = nq; stats->kernel_ms = timer.ms();
     }
-    if ((rc = slb.finish())) { (void)hipFree(dsteps); return rc; }
-    if ((rc = slen.finish())) { (void)hipFree(dsteps); return rc; }
+    if ((rc = slb.finish())) return rc;
+    if ((rc = slen.finish())) return rc;
     if (stats || slb.owned || slen.owned) (void)hipStreamSynchronize(stream);
-    (void)hipFree(dsteps);   // hipFree synchronises the device: the counter is no longer in use afterwards
     return 0;
 }
 
@@ -1708,31 +1756,72 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
     if ((rc = spos.out(out_pos, count * 8, stream))) return rc;
     if ((rc = sst.out(out_steps, count * 8, stream))) return rc;
     unsigned long long* dsteps = nullptr;
-    FM_HIP(hipMalloc((void**)&dsteps, 8));
-    FM_HIP(hipMemsetAsync(dsteps, 0, 8, stream));
+    if ((rc = step_counters(stats != nullptr, stream, &dsteps))) return rc;
     EventTimer timer(stream, stats != nullptr);
     dim3 grid((unsigned)((count + 255) / 256)), block(256);
     const idx_t n = (idx_t)x->bwt.n;
     timer.start();
-    rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
+    if (x->loc_tab)
+        k_locate_tab<<<grid, block, 0, stream>>>(x->loc_tab, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
+    else rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
         k_locate<decltype(occ)><<<grid, block, 0, stream>>>(occ, x->bwt.lf_table, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev,
                                                            (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
         return 0;
     });
     timer.stop();
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { (void)hipFree(dsteps); return hip_fail(e, "k_locate launch"); }
+    if (e != hipSuccess) return hip_fail(e, "k_locate launch");
     if (stats) {
         unsigned long long hs = 0;
-        e = hipMemcpyAsync(&hs, dsteps, 8, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) { (void)hipFree(dsteps); return hip_fail(e, "k_locate"); }
+        if ((rc = read_step_counters(dsteps, stream, &hs))) return rc;
         stats->lf_steps = hs; stats->hits = count; stats->kernel_ms = timer.ms();
     }
     rc = sseq.finish(); if (!rc) rc = spos.finish(); if (!rc) rc = sst.finish();
-    (void)hipStreamSynchronize(stream);
-    (void)hipFree(dsteps);
+    if (stats || sseq.owned || spos.owned || sst.owned) (void)hipStreamSynchronize(stream);
     return rc;
+}
+
+// answer table for locate: every row is located once, the triples are kept (12 bytes per row)
+__global__ __launch_bounds__(256) void k_pack_locate(const uint64_t* __restrict__ seq, const uint64_t* __restrict__ pos, const uint64_t* __restrict__ st, uint64_t first,
+                                                     uint64_t count, uint32_t* __restrict__ tab) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    uint32_t* p = tab + 3u * (size_t)(first + t);
+    const bool ok = st[t] != ~0ull && seq[t] <= 0xfffffffeull && pos[t] <= 0xffffffffull;
+    p[0] = ok ? (uint32_t)seq[t] : 0u; p[1] = ok ? (uint32_t)pos[t] : 0u; p[2] = ok ? (uint32_t)st[t] : 0xffffffffu;
+}
+__global__ __launch_bounds__(256) void k_iota64(uint64_t* __restrict__ out, uint64_t first, uint64_t count) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) out[t] = first + t;
+}
+
+int fmgpu_index_accelerate_locate(fmgpu_index_t h, int32_t enable) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    const uint64_t n = x->bwt.n;
+    if (x->loc_tab) { (void)hipFree(x->loc_tab); x->loc_tab = nullptr; x->device_bytes -= n * 12; }
+    if (!enable || n == 0) return 0;
+    if (!x->has_sa) return fail(FMGPU_ERR_INVALID, "index was created without an annotated (sampled suffix) array");
+    uint32_t* tab = nullptr;
+    FM_HIP(hipMalloc((void**)&tab, n * 12 + 16));
+    const uint64_t chunk = 1ull << 26;
+    uint64_t* buf = nullptr;                                       // rows | seq | pos | steps of one chunk
+    hipError_t e = hipMalloc((void**)&buf, chunk * 8 * 4);
+    if (e != hipSuccess) { (void)hipFree(tab); return hip_fail(e, "hipMalloc(locate staging)"); }
+    int rc = 0;
+    for (uint64_t first = 0; first < n && rc == 0; first += chunk) {
+        const uint64_t cnt = std::min(chunk, n - first);
+        k_iota64<<<dim3((unsigned)((cnt + 255) / 256)), 256>>>(buf, first, cnt);
+        rc = fmgpu_locate(h, buf, cnt, buf + chunk, buf + 2 * chunk, buf + 3 * chunk, nullptr, nullptr);
+        if (rc == 0) k_pack_locate<<<dim3((unsigned)((cnt + 255) / 256)), 256>>>(buf + chunk, buf + 2 * chunk, buf + 3 * chunk, first, cnt, tab);
+    }
+    e = hipDeviceSynchronize();
+    (void)hipFree(buf);
+    if (rc == 0 && e != hipSuccess) rc = hip_fail(e, "locate table");
+    if (rc) { (void)hipFree(tab); return rc; }
+    x->loc_tab = tab;
+    x->device_bytes += n * 12;
+    return 0;
 }
 
 }  // extern "C"

@@ -166,6 +166,10 @@ int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len
  *                   one-row cursor advances 16 symbols per load wherever 16 steps of a search go in one direction. */
 int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t walk);
 
+/* Optional accelerator for fmgpu_locate (results unchanged): every row is located once and its (seqId, pos, steps) answer kept,
+ * 12 bytes per row — one load per located row instead of ~samplingRate/2 LF steps with a presence-bit probe each.  enable = 0 drops it. */
+int fmgpu_index_accelerate_locate(fmgpu_index_t h, int32_t enable);
+
 /* String_c batch evaluation (string/concepts.h:25-87): what[i] selects 0 = rank(idx,symb), 1 = prefix_rank(idx,symb),
  * 2 = symbol(idx); which = 0 -> bwt, 1 -> bwtRev */
 int fmgpu_string_query(fmgpu_index_t h, int which, const uint64_t* idx, const uint8_t* symb, const uint8_t* what,

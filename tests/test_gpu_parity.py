@@ -574,6 +574,26 @@ def test_gpu_builder_wavelet(sigma, n):
     assert [(int(a), int(b), int(c)) for a, b, c in zip(seq, pos, steps)] == [ox.locate(int(r)) for r in rows]
 
 
+@pytest.mark.parametrize("layout,sigma,rate", [("IB16", 5, 16), ("IB16", 5, 1), ("WAVELET", 28, 4), ("EPRV2_16", 5, 7)])
+def test_locate_answer_table(layout, sigma, rate):
+    """fmgpu_index_accelerate_locate: the per-row answer table returns the triples of the LF walk (fmindex/FMIndex.h:113-124), also for
+    rows outside the index and after the table is dropped again"""
+    seqs = [make_text(3000, sigma, seed=rate), make_text(41, sigma, seed=rate + 1), make_text(700, sigma, seed=rate + 2)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, rate, True)
+    gx = gpu_index(ox)
+    rows = np.concatenate([np.arange(ox.n, dtype=np.uint64), np.array([ox.n, ox.n + 5, 2 ** 40], dtype=np.uint64)])
+    want = gx.locate(rows)
+    before = gx.device_bytes
+    gx.accelerate_locate()
+    assert gx.device_bytes == before + 12 * ox.n
+    *got, st = gx.locate(rows, want_stats=True)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert st.lf_steps == int(want[2][: ox.n].sum())
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(*[g[: ox.n: 37] for g in got])] == [ox.locate(int(r)) for r in range(0, ox.n, 37)]
+    gx.accelerate_locate(False)
+    assert gx.device_bytes == before and all(np.array_equal(a, b) for a, b in zip(gx.locate(rows), want))
+
+
 def test_index_create_argument_checks():
     text = make_text(500, 5, 3)
     ox = fo.OraIndex.build("IB16", 5, [text], 4, True)
