@@ -706,12 +706,12 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
         }
         nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + ((start_tail) ? 1u : 0u))));
         if (kind != 4u && nxt != kNoResume) {                       // keep the parent: its remaining children start at nxt
-            uint64_t o = (uint64_t)sp * stk.nlanes + gid;
-            stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
-            stk.p1[o] = (uint64_t)cur.len | ((uint64_t)(pev & 0xffffu) << 32) | ((uint64_t)(qR & 0xffffu) << 48);
-            stk.p2[o] = (uint64_t)nxt | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
-                        ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
-            stk.p3[o] = (uint64_t)side | ((uint64_t)info << 32);
+            // one 32-byte record per frame (two 16-byte stores into one line), lanes interleaved
+            uint4* f = reinterpret_cast<uint4*>(stk.p0) + 2u * ((uint64_t)sp * stk.nlanes + gid);
+            const uint64_t w2 = (uint64_t)nxt | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
+                                ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
+            f[0] = make_uint4(cur.lb, cur.lbRev, cur.len, (pev & 0xffffu) | ((qR & 0xffffu) << 16));
+            f[1] = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), side, info);
             ++sp;
         }
         resume = kNoResume;
@@ -761,14 +761,14 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
         if (back) {
             if (sp == 0) { need_search = true; continue; }
             --sp;
-            uint64_t o = (uint64_t)sp * stk.nlanes + gid;
-            uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o], w3 = stk.p3[o];
-            cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32);
-            cur.len = (idx_t)w1; pev = (uint32_t)(w1 >> 32) & 0xffffu; qR = (uint32_t)(w1 >> 48) & 0xffffu;
+            const uint4* f = reinterpret_cast<const uint4*>(stk.p0) + 2u * ((uint64_t)sp * stk.nlanes + gid);
+            const uint4 a0 = f[0], a1 = f[1];
+            const uint64_t w2 = (uint64_t)a1.x | ((uint64_t)a1.y << 32);
+            cur.lb = a0.x; cur.lbRev = a0.y; cur.len = a0.z; pev = a0.w & 0xffffu; qR = a0.w >> 16;
             resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
             right = (w2 >> 47) & 1u;
             qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
-            side = (uint32_t)w3; info = (uint32_t)(w3 >> 32);
+            side = a1.z; info = a1.w;
             tail = 0;
         }
     }
