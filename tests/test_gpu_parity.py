@@ -659,3 +659,67 @@ def test_full_size_properties():
     fm.search_no_errors.search(gx, (V(reads), V(qoff)), out=(V(lbv), V(lnv)))
     torch.cuda.synchronize()
     assert int((lnv == 0).sum()) >= nq - 10
+    miss_lb = lbv.clone()                                      # cursor of the step that emptied the interval: part of the result
+    # ---- the optional tables do not change a single cursor at this size (rows close to 2^32 exercise the 32-bit row arithmetic)
+    reads[:, 50] = (reads[:, 50] + 2) % 4 + 1                  # undo the substitution ((x % 4 + 1) is a 4-cycle: three more steps)
+    for tables in ((3, 0, False), (3, 12, True), (1, 10, True)):
+        gx.accelerate(tables[0], lut_len=tables[1], walk=tables[2])
+        fm.search_no_errors.search(gx, (V(reads), V(qoff)), out=(V(lbv), V(lnv)))
+        torch.cuda.synchronize()
+        assert int((lbv * 31 + lnv).sum().item()) == chk1, tables
+    reads[:, 50] = reads[:, 50] % 4 + 1                        # mutated again: misses report the same cursor with every table
+    fm.search_no_errors.search(gx, (V(reads), V(qoff)), out=(V(lbv), V(lnv)))
+    torch.cuda.synchronize()
+    assert bool(torch.equal(lbv, miss_lb)) and int((lnv == 0).sum()) >= nq - 10
+    gx.accelerate_locate()
+    seq2 = torch.empty_like(rows); pos2 = torch.empty_like(rows); steps2 = torch.empty_like(rows)
+    capi.check(capi.lib().fmgpu_locate(gx._h, C.c_void_p(rows.data_ptr()), rows.numel(), C.c_void_p(seq2.data_ptr()),
+                                       C.c_void_p(pos2.data_ptr()), C.c_void_p(steps2.data_ptr()), None, None))
+    torch.cuda.synchronize()
+    assert bool(torch.equal(seq, seq2) and torch.equal(pos, pos2) and torch.equal(steps, steps2))
+
+
+def test_full_size_k2_tables_agree():
+    """BASELINE.json configs[2] at full index size (3.09 Gbp BiFMIndex), 1 M reads: the table-driven kernel with every accelerator reports
+    the same hit records and node count as without any, and as the general kernel (the small-case parity against the CPU walk carries over)"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    n, nq, L = 3_088_286_401, 1_000_000, 101
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    text = torch.empty(n, dtype=torch.uint8, device=dev)
+    for lo in range(0, n, 1 << 28):
+        hi = min(n, lo + (1 << 28))
+        text[lo:hi] = torch.randint(1, 5, (hi - lo,), generator=g, device=dev, dtype=torch.uint8)
+    starts = torch.randint(0, n - L, (nq,), generator=g, device=dev, dtype=torch.int64)
+    reads = text[starts[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
+    rows = torch.arange(nq, device=dev)
+    for k in range(2):                                         # 0 / 1 / 2 substitutions
+        sel = rows[rows % 3 > k]
+        p = torch.randint(0, L, (sel.numel(),), generator=g, device=dev)
+        reads[sel, p] = reads[sel, p] % 4 + 1
+    seq_off = torch.tensor([0, n], dtype=torch.int64, device=dev)
+
+    class V:
+        def __init__(self, t):
+            self.t, self.ptr, self.nbytes = t, t.data_ptr(), t.numel() * t.element_size()
+    gx = fm.BiFMIndex.from_sequences((V(text), V(seq_off)), 5, "IB16", 16)
+    del text
+    qoff = torch.arange(nq + 1, device=dev, dtype=torch.int64) * L
+    sch = fm.search_scheme.h2(4, 0, 2)
+    hq, ho = reads.reshape(-1).cpu().numpy(), qoff.cpu().numpy().astype(np.uint64)
+
+    def run():
+        hits, st = fm.search_ng26.search(gx, (hq, ho), sch, want_stats=True)
+        return hits, st.lf_steps
+    base, nodes = run()
+    assert len(base) >= nq - 100 and int(base["errors"].max()) == 2
+    for accel in ((11, 1), (0, 2), (11, 3)):
+        gx.accelerate_search(*accel)
+        hits, nn = run()
+        assert nn == nodes and hits.tobytes() == base.tobytes(), accel
+    os.environ["FMGPU_DEV_FLAGS"] = "2"                        # the general kernel
+    try:
+        hits, nn = run()
+    finally:
+        del os.environ["FMGPU_DEV_FLAGS"]
+    assert nn == nodes and hits.tobytes() == base.tobytes()
