@@ -283,6 +283,57 @@ __device__ __forceinline__ Cur kid_of(const idx_t* lfa, const idx_t* lfb, Cur cu
 
 constexpr uint32_t kNoResume = 0xffffffffu;
 
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off, 64); if (lane >= (uint32_t)off) x += y; }
+    return x - v;
+}
+
+// ---- wave-level reservations for the DFS kernels ----------------------------------------------------------------------------------
+// One atomicAdd per hit (or per query handed out) queues millions of atomics behind each other on one address: ~9 ns each, more than the
+// searches themselves.  Instead every lane of a wave passes a synchronous section in each loop iteration (a lane without work idles until
+// the whole wave is done): queries are handed out with one reservation for all lanes that want one, hits are kept in LDS
+// (kWaveHitBuf per lane) and written out by the whole wave with one reservation as soon as some lane's buffer is full.
+constexpr uint32_t kWaveHitBuf = 2;
+constexpr uint32_t kWaveHitWords = kWaveHitBuf * 7u * 256u;       // [slot][qidx lo, qidx hi, lb, lbRev, len, e, seq][thread]
+
+__device__ __forceinline__ uint64_t wave_hand_out(bool want, Counters* ctr, uint32_t lane) {     // all lanes call; valid for lanes with `want`
+    const uint64_t wm = __ballot(want);
+    if (!wm) return 0;
+    const uint32_t leader = (uint32_t)__ffsll((unsigned long long)wm) - 1u;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(&ctr->next, (unsigned long long)__popcll(wm));
+    base = ((unsigned long long)__shfl((uint32_t)(base >> 32), leader, 64) << 32) | __shfl((uint32_t)base, leader, 64);
+    return base + (uint64_t)__popcll(wm & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ void wave_keep_hit(uint32_t* s_hb, uint32_t& nh, fmgpu_hit* out, uint64_t cap, Counters* ctr, uint64_t q, Cur r, uint32_t e, uint32_t seq) {
+    if (nh < kWaveHitBuf) {
+        uint32_t* h = s_hb + (size_t)nh * 7u * 256u + threadIdx.x;
+        h[0] = (uint32_t)q; h[256] = (uint32_t)(q >> 32); h[512] = r.lb; h[768] = r.lbRev; h[1024] = r.len; h[1280] = e; h[1536] = seq;
+        ++nh;
+    } else emit_hit(out, cap, ctr, q, r, e, seq);                  // (cannot happen while the wave flushes whenever a buffer is full)
+}
+__device__ __forceinline__ void wave_flush_hits(const uint32_t* s_hb, uint32_t& nh, uint32_t lane, fmgpu_hit* out, uint64_t cap, Counters* ctr) {   // all lanes call
+    const uint32_t before = wave_excl_scan(nh, lane);
+    const uint32_t total = __shfl(before + nh, 63, 64);
+    unsigned long long slot = 0;
+    if (lane == 0 && total) slot = atomicAdd(&ctr->hits, (unsigned long long)total);
+    slot = ((unsigned long long)__shfl((uint32_t)(slot >> 32), 0, 64) << 32) | __shfl((uint32_t)slot, 0, 64);
+    for (uint32_t k = 0; k < nh; ++k) {
+        const uint32_t* h = s_hb + (size_t)k * 7u * 256u + threadIdx.x;
+        const unsigned long long at = slot + before + k;
+        if (at < cap) {
+            fmgpu_hit rec;
+            rec.qidx = (uint64_t)h[0] | ((uint64_t)h[256] << 32); rec.lb = h[512]; rec.lb_rev = h[768]; rec.len = h[1024];
+            rec.errors = h[1280]; rec.seq = h[1536];
+            out[at] = rec;
+        }
+    }
+    nh = 0;
+}
+
+
 // one-row cursors with the explicit LF table (DevString::lf_table): LF(row) in one 4-byte load; the row's symbol is the k with
 // C[k] <= LF(row) < C[k+1] (C staged in LDS)
 struct LfView { const idx_t* fw; const idx_t* rv; const idx_t* C; };
@@ -415,14 +466,13 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
     // slowest search.  The node logic is written branch-light: the reference's case analysis (exact tail / extend-all
     // node / single-row fast path / resumed sibling) is folded into a few predicates that pick ONE child symbol
     // `take`; the child cursor is then computed once for all cases.
-    // Queries are handed out in batches of kBatch through a global counter (the first batch of every lane is static);
-    // the atomicAdd for the NEXT batch is issued when a batch is started, so its latency never sits on the critical
-    // path, and the grid needs no assumption about how many blocks are resident.
-    const uint64_t kBatch = stk.batch;                        // 4, or 1 when the batch has too few queries to give every lane four
-    uint64_t q = gid * kBatch, q_end = q + kBatch;            // current query / end of the current batch
-    uint64_t next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
-    uint32_t si = S;                        // current search; si == S: fetch the next query first
-    bool first = true;
+    // Queries are handed out and hits written out by whole waves (see wave_hand_out / wave_flush_hits above).
+    const uint32_t lane = threadIdx.x & 63u;
+    __shared__ uint32_t s_hb[kWaveHitWords];
+    uint32_t nh = 0;
+    uint64_t q = 0;
+    uint32_t si = 0;                        // current search
+    bool idle = false, have_query = false, fresh = false;
     const uint8_t* qs = qbuf; uint32_t m = 0, pbase = 0, prem = 0;
     uint64_t quota = 0; uint32_t seq = 0;
     Cur cur{0, 0, 0};
@@ -434,32 +484,32 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
     };
     bool need_search = true;
     for (;;) {
-        if (need_search) {
-            // search_impl / search_n_impl driver (SearchNg26.h:369-391, :407-423)
-            if (si + 1 < S && !first && quota != 0) ++si;
+        // ---- wave-synchronous part: all 64 lanes pass here in every iteration
+        const bool want_q = !idle && need_search && !(have_query && si + 1 < S && quota != 0);   // search_impl / search_n_impl, SearchNg26.h:369-391, :407-423
+        const uint64_t got = wave_hand_out(want_q, ctr, lane);
+        if (want_q) {
+            q = got;
+            have_query = false;
+            if (q >= nq) idle = true;
             else {
-                if (!first) ++q;
-                first = false;
-                bool found = false;
-                for (;;) {
-                    if (q >= q_end) {                             // batch exhausted: switch to the prefetched one, prefetch another
-                        q = next_batch; q_end = q + kBatch;
-                        if (q >= nq) break;
-                        next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
-                    }
-                    if (q >= nq) break;
-                    const uint64_t qo = qoff[q];
-                    m = (uint32_t)(qoff[q + 1] - qo);
-                    qs = qbuf + qo;
-                    // expand.h:325-327 precondition (the reference asserts); an explicit partition must cover the query exactly
-                    if (m >= P && m <= stk.depth && (sch.uniform || m == sch.psum) && n != 0) { found = true; break; }
-                    ++q;
-                }
-                if (!found) break;
-                si = 0; quota = max_hits; seq = 0;
+                const uint64_t qo = qoff[q];
+                m = (uint32_t)(qoff[q + 1] - qo);
+                qs = qbuf + qo;
+                // expand.h:325-327 precondition (the reference asserts); an explicit partition must cover the query exactly
+                if (m >= P && m <= stk.depth && (sch.uniform || m == sch.psum) && n != 0) { have_query = true; fresh = true; }
+            }
+        }
+        const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(!idle);
+        if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
+        if (!busy) break;
+        if (idle) continue;
+        if (need_search) {
+            if (!have_query) continue;                             // the query fetched was unusable: the next iteration fetches another
+            if (fresh) {
+                fresh = false; si = 0; quota = max_hits; seq = 0;
                 pbase = m / P; prem = m - pbase * P;
                 qstage_load(qst, qbuf, qoff[q], m, sigma);
-            }
+            } else ++si;
             pi = s_pi + si * kMaxParts; L = s_l + si * kMaxParts; U = s_u + si * kMaxParts;
             // run(): SearchNg26.h:62-79
             cur = Cur{0, 0, n};
@@ -537,7 +587,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
                     Cur r = cur;
                     if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
                     quota -= r.len;
-                    if (sch.dev_flags & 1) ++seq; else emit_hit(out, cap, ctr, q, r, e, seq++);
+                    if (sch.dev_flags & 1) ++seq; else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
                     if (quota == 0) { need_search = true; continue; }     // delegate returned true: skip the remaining searches
                 }
                 back = true;
@@ -569,8 +619,9 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
 // a frame keeps the parent and the number of its next child; the child cursor comes from the parent's extend-all, which is
 // recomputed when the frame is resumed.  State beyond the Hamming kernel's: the last index / query symbol per side (:36-39) and
 // the last operation per side (LInfo / RInfo: 0 M, 1 S, 2 I, 3 D).
+constexpr int kEditWaves = 4;         // waves per SIMD the register allocation aims at (6 or 8 spill and measure the same)
 template <class Occ, int MAXSIG>
-__global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
+__global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_edit(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
                                                      const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                      fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv, uint32_t maxm) {
     extern __shared__ uint32_t s_query[];
@@ -588,11 +639,12 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
     const uint32_t P = (uint32_t)sch.P, S = (uint32_t)sch.S;
     const uint32_t INS = 2u * sigma - 1u;
     uint32_t nodes = 0;
-    const uint64_t kBatch = stk.batch;
-    uint64_t q = gid * kBatch, q_end = q + kBatch;
-    uint64_t next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
-    uint32_t si = S;
-    bool first = true;
+    const uint32_t lane = threadIdx.x & 63u;
+    __shared__ uint32_t s_hb[kWaveHitWords];
+    uint32_t nh = 0;
+    uint64_t q = 0;
+    uint32_t si = 0;
+    bool idle = false, have_query = false, fresh = false;
     const uint8_t* qs = qbuf; uint32_t m = 0, pbase = 0, prem = 0;
     uint64_t quota = 0; uint32_t seq = 0;
     Cur cur{0, 0, 0};
@@ -604,30 +656,32 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
     auto part_len = [&](uint32_t p) -> uint32_t { return sch.uniform ? pbase + (p < prem ? 1u : 0u) : s_part[p]; };
     bool need_search = true;
     for (;;) {
-        if (need_search) {
-            if (si + 1 < S && !first && quota != 0) ++si;
+        // ---- wave-synchronous part: all 64 lanes pass here in every iteration (a lane without work idles until the wave is done)
+        const bool want_q = !idle && need_search && !(have_query && si + 1 < S && quota != 0);   // search_impl / search_n_impl, :369-391, :407-423
+        const uint64_t got = wave_hand_out(want_q, ctr, lane);
+        if (want_q) {
+            q = got;
+            have_query = false;
+            if (q >= nq) idle = true;
             else {
-                if (!first) ++q;
-                first = false;
-                bool found = false;
-                for (;;) {
-                    if (q >= q_end) {
-                        q = next_batch; q_end = q + kBatch;
-                        if (q >= nq) break;
-                        next_batch = atomicAdd(&ctr->next, (unsigned long long)kBatch);
-                    }
-                    if (q >= nq) break;
-                    const uint64_t qo = qoff[q];
-                    m = (uint32_t)(qoff[q + 1] - qo);
-                    qs = qbuf + qo;
-                    if (m >= P && m <= maxm && (sch.uniform || m == sch.psum) && n != 0) { found = true; break; }
-                    ++q;
-                }
-                if (!found) break;
-                si = 0; quota = max_hits; seq = 0;
+                const uint64_t qo = qoff[q];
+                m = (uint32_t)(qoff[q + 1] - qo);
+                qs = qbuf + qo;
+                // expand.h:325-327 precondition (the reference asserts); an explicit partition must cover the query exactly
+                if (m >= P && m <= maxm && (sch.uniform || m == sch.psum) && n != 0) { have_query = true; fresh = true; }
+            }
+        }
+        const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(!idle);
+        if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
+        if (!busy) break;
+        if (idle) continue;
+        if (need_search) {
+            if (!have_query) continue;                             // the query fetched was unusable: the next iteration fetches another
+            if (fresh) {
+                fresh = false; si = 0; quota = max_hits; seq = 0;
                 pbase = m / P; prem = m - pbase * P;
                 qstage_load(qst, qbuf, qoff[q], m, sigma);
-            }
+            } else ++si;
             pi = s_pi + si * kMaxParts; L = s_l + si * kMaxParts; U = s_u + si * kMaxParts;
             cur = Cur{0, 0, n};                                    // run(): :62-79
             e = 0; part = 0; qL = 0; qR = 0; tail = 0; sp = 0; resume = kNoResume; side = 0; info = 0;
@@ -706,8 +760,9 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
         }
         nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + ((start_tail) ? 1u : 0u))));
         if (kind != 4u && nxt != kNoResume) {                       // keep the parent: its remaining children start at nxt
-            // one 32-byte record per frame (two 16-byte stores into one line), lanes interleaved
-            uint4* f = reinterpret_cast<uint4*>(stk.p0) + 2u * ((uint64_t)sp * stk.nlanes + gid);
+            // one 32-byte record per frame; a lane's frames are consecutive in memory: a DFS pushes and pops them in order, so four share a
+            // 128-byte line (lanes of a wave sit at different depths — interleaving them by lane would touch one line per frame)
+            uint4* f = reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
             const uint64_t w2 = (uint64_t)nxt | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
                                 ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
             f[0] = make_uint4(cur.lb, cur.lbRev, cur.len, (pev & 0xffffu) | ((qR & 0xffffu) << 16));
@@ -750,7 +805,8 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
                     Cur r = cur;
                     if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
                     quota -= r.len;
-                    if (sch.dev_flags & 1) ++seq; else emit_hit(out, cap, ctr, q, r, e, seq++);
+                    if (sch.dev_flags & 1) ++seq;
+                    else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
                     if (quota == 0) { need_search = true; continue; }
                 }
                 back = true;
@@ -761,7 +817,7 @@ __global__ __launch_bounds__(256) void k_scheme_edit(Occ fw, Occ rv, SchemeDev s
         if (back) {
             if (sp == 0) { need_search = true; continue; }
             --sp;
-            const uint4* f = reinterpret_cast<const uint4*>(stk.p0) + 2u * ((uint64_t)sp * stk.nlanes + gid);
+            const uint4* f = reinterpret_cast<const uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
             const uint4 a0 = f[0], a1 = f[1];
             const uint64_t w2 = (uint64_t)a1.x | ((uint64_t)a1.y << 32);
             cur.lb = a0.x; cur.lbRev = a0.y; cur.len = a0.z; pev = a0.w & 0xffffu; qR = a0.w >> 16;
@@ -842,12 +898,6 @@ __device__ __forceinline__ void qstage_load_sync(const QStage& st, const uint8_t
     }
 }
 
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
-    uint32_t x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off, 64); if (lane >= (uint32_t)off) x += y; }
-    return x - v;
-}
 
 // ---- exact search over the multi-symbol-step table (fmgpu_index_accelerate) ---------------------------------------
 // One table entry advances the cursor by K query symbols, so a query touches 1/K as many lines.  A chunk that holds a
@@ -1691,6 +1741,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             if constexpr (std::is_same_v<O, OccA<5>> || std::is_same_v<O, OccA<0>>) r = O{rv.va};
             else if constexpr (std::is_same_v<O, OccW>) r = O{rv.vw};
             else r = O{rv.vr};
+            (void)hipMemsetAsync(&ws.ctr->next, 0, 8, stream);         // queries are handed out from 0, one reservation per wave
             if (edit) {
                 k_scheme_edit<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
                                                                                   max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, maxlen);
