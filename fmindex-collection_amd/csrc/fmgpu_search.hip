@@ -651,6 +651,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
     uint32_t e = 0, part = 0, qL = 0, qR = 0, pev = 0, tail = 0, sp = 0, resume = kNoResume;
     uint32_t side = 0;                      // lastRank[left] | lastRank[right] << 8 | lastQRank[left] << 16 | lastQRank[right] << 24
     uint32_t info = 0;                      // LInfo | RInfo << 2
+    idx_t cached_lf = 0;
     bool right = true;
     const uint8_t *pi = s_pi, *L = s_l, *U = s_u;
     auto part_len = [&](uint32_t p) -> uint32_t { return sch.uniform ? pbase + (p < prem ? 1u : 0u) : s_part[p]; };
@@ -695,8 +696,8 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
         const idx_t a = right ? cur.lbRev : cur.lb;
         idx_t lfa[MAXSIG], lfb[MAXSIG];
         const bool via_lf = lfv.fw != nullptr && cur.len == 1;      // one row: its only child comes from the LF table
-        idx_t lf1 = 0;
-        if (via_lf) lf1 = (right ? lfv.rv : lfv.fw)[a];
+        idx_t lf1 = cached_lf;                                      // a resumed one-row node brings its LF value along in the frame
+        if (via_lf) { if (resume == kNoResume) lf1 = (right ? lfv.rv : lfv.fw)[a]; }
         else occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
         const uint32_t c = qstage_get(qst, qs, right ? qR : qL);
         SymSet<MAXSIG> alive;
@@ -763,10 +764,10 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             // one 32-byte record per frame; a lane's frames are consecutive in memory: a DFS pushes and pops them in order, so four share a
             // 128-byte line (lanes of a wave sit at different depths — interleaving them by lane would touch one line per frame)
             uint4* f = reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
-            const uint64_t w2 = (uint64_t)nxt | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
+            const uint64_t w2 = (uint64_t)(nxt | (info << 16)) | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
                                 ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
             f[0] = make_uint4(cur.lb, cur.lbRev, cur.len, (pev & 0xffffu) | ((qR & 0xffffu) << 16));
-            f[1] = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), side, info);
+            f[1] = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), side, lf1);
             ++sp;
         }
         resume = kNoResume;
@@ -821,10 +822,10 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             const uint4 a0 = f[0], a1 = f[1];
             const uint64_t w2 = (uint64_t)a1.x | ((uint64_t)a1.y << 32);
             cur.lb = a0.x; cur.lbRev = a0.y; cur.len = a0.z; pev = a0.w & 0xffffu; qR = a0.w >> 16;
-            resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
+            resume = (uint32_t)w2 & 0xffffu; info = ((uint32_t)w2 >> 16) & 15u; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
             right = (w2 >> 47) & 1u;
             qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
-            side = a1.z; info = a1.w;
+            side = a1.z; cached_lf = a1.w;
             tail = 0;
         }
     }
