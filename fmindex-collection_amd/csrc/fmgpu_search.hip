@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_exact(Occ occ, const uint8_t* __restric
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
 }
 
-// ---- exact search, tuned variants (Format A only) ---------------------------------------------------------------
+// ---- exact search on Format A without accelerator tables --------------------------------------------------------
 // The query symbols are fetched as aligned 64-bit words one word ahead of use, so that the only load on the
 // dependent chain of an LF step is the occurrence-table entry; the second interval end re-uses the first end's
 // entry when both fall into the same 64-row block (the common case once the interval is short).
@@ -88,7 +88,7 @@ struct QueryReader {
     }
 };
 
-template <int SIGMA, int VARIANT>
+template <int SIGMA>
 __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                  unsigned long long* __restrict__ steps_total) {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
                 const idx_t a = lb, b = lb + len;
                 EntryA ea = load_entry_a(occ.v.blk, occ.v.bstride, a, c);
                 EntryA eb = ea;
-                if (VARIANT < 2 || (a >> 6) != (b >> 6)) eb = load_entry_a(occ.v.blk, occ.v.bstride, b, c);
+                if ((a >> 6) != (b >> 6)) eb = load_entry_a(occ.v.blk, occ.v.bstride, b, c);
                 idx_t ra = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
                 idx_t rb = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
                 lb = ra; len = rb - ra;
@@ -116,52 +116,6 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
             }
         }
         out_lb[q] = lb; out_len[q] = len;
-    }
-    uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
-}
-
-// two queries per lane, interleaved: twice the loads in flight per wave
-template <int SIGMA>
-__global__ __launch_bounds__(256) void k_exact_a2(OccA<SIGMA> occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
-                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
-                                                  unsigned long long* __restrict__ steps_total) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t half = (nq + 1) / 2;
-    uint32_t steps = 0;
-    if (t < half) {
-        const uint64_t q0 = t, q1 = t + half;
-        const bool has1 = q1 < nq;
-        const uint32_t sigma = occ.sigma();
-        uint64_t o0 = qoff[q0], o1 = has1 ? qoff[q1] : 0;
-        uint32_t m0 = (uint32_t)(qoff[q0 + 1] - o0), m1 = has1 ? (uint32_t)(qoff[q1 + 1] - o1) : 0;
-        idx_t lb0 = 0, len0 = n, lb1 = 0, len1 = n;
-        QueryReader r0, r1;
-        if (m0) r0.init(qbuf, o0, m0);
-        if (m1) r1.init(qbuf, o1, m1);
-        bool live0 = m0 != 0, live1 = m1 != 0;
-        uint32_t i0 = 0, i1 = 0;
-        while (live0 || live1) {
-            uint32_t c0 = 0, c1 = 0;
-            if (live0) { c0 = r0.next(); ++steps; if (c0 >= sigma) { lb0 = 0; len0 = 0; live0 = false; } }
-            if (live1) { c1 = r1.next(); ++steps; if (c1 >= sigma) { lb1 = 0; len1 = 0; live1 = false; } }
-            EntryA ea0{}, eb0{}, ea1{}, eb1{};
-            const idx_t a0 = lb0, b0 = lb0 + len0, a1 = lb1, b1 = lb1 + len1;
-            if (live0) { ea0 = load_entry_a(occ.v.blk, occ.v.bstride, a0, c0); eb0 = ea0; if ((a0 >> 6) != (b0 >> 6)) eb0 = load_entry_a(occ.v.blk, occ.v.bstride, b0, c0); }
-            if (live1) { ea1 = load_entry_a(occ.v.blk, occ.v.bstride, a1, c1); eb1 = ea1; if ((a1 >> 6) != (b1 >> 6)) eb1 = load_entry_a(occ.v.blk, occ.v.bstride, b1, c1); }
-            if (live0) {
-                idx_t ra = ea0.cnt + popc64(ea0.bits & lowmask(a0 & 63u)), rb = eb0.cnt + popc64(eb0.bits & lowmask(b0 & 63u));
-                lb0 = ra; len0 = rb - ra; ++i0;
-                if (len0 == 0 || i0 == m0) live0 = false;
-            }
-            if (live1) {
-                idx_t ra = ea1.cnt + popc64(ea1.bits & lowmask(a1 & 63u)), rb = eb1.cnt + popc64(eb1.bits & lowmask(b1 & 63u));
-                lb1 = ra; len1 = rb - ra; ++i1;
-                if (len1 == 0 || i1 == m1) live1 = false;
-            }
-        }
-        out_lb[q0] = lb0; out_len[q0] = len0;
-        if (has1) { out_lb[q1] = lb1; out_len[q1] = len1; }
     }
     uint32_t tot = wave_sum(steps);
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
@@ -1567,10 +1521,9 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     EventTimer timer(stream, stats != nullptr);
     dim3 grid((unsigned)((nq + 255) / 256)), block(256);
     const idx_t n = (idx_t)x->bwt.n;
-    const int variant = [] { const char* e = getenv("FMGPU_EXACT_VARIANT"); return e ? atoi(e) : 2; }();   // dev knob
     timer.start();
     uint32_t kq_words = 0, kq_max = 0, kq_nib = x->bwt.sigma <= 15 ? 1u : 0u;
-    const bool accel = (x->bwt.kblk || x->bwt.slut || x->bwt.walkj) && variant != 0;
+    const bool accel = x->bwt.kblk || x->bwt.slut || x->bwt.walkj;
     if (accel) {                                                 // LDS staging needs the longest query of the batch
         uint32_t mn = 0;
         if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &kq_max, &mn))) return rc;
@@ -1587,17 +1540,11 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
                                                                     (uint64_t*)slen.dev, dsteps, kq_words, kq_nib, kq_max);
             return 0;
         });
-    } else if (x->bwt.search_family() == FAM_A && variant >= 1) {
+    } else if (x->bwt.search_family() == FAM_A) {
         auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
-        auto launch = [&](auto occ) {
-            using O = decltype(occ);
-            constexpr int SG = std::is_same_v<O, OccA<5>> ? 5 : 0;
-            if (variant == 1) k_exact_a<SG, 1><<<grid, block, 0, stream>>>(occ, qb, qo, nq, n, ol, on, dsteps);
-            else if (variant == 2) k_exact_a<SG, 2><<<grid, block, 0, stream>>>(occ, qb, qo, nq, n, ol, on, dsteps);
-            else k_exact_a2<SG><<<dim3((unsigned)(((nq + 1) / 2 + 255) / 256)), block, 0, stream>>>(occ, qb, qo, nq, n, ol, on, dsteps);
-        };
-        if (x->bwt.sigma == 5) launch(OccA<5>{x->bwt.va}); else launch(OccA<0>{x->bwt.va});
-    } else if (x->bwt.search_family() == FAM_WAVELET && variant != 0) {
+        if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, 0, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
+        else k_exact_a<0><<<grid, block, 0, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
+    } else if (x->bwt.search_family() == FAM_WAVELET) {
         uint32_t mx = 0, mn = 0;
         if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) return rc;
         uint32_t qw = (mx + 3) / 4;
