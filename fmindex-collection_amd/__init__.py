@@ -16,7 +16,7 @@ from . import capi
 from .capi import FmgpuError, DeviceBuffer, LAYOUTS, UINT64_MAX, HIT_DTYPE
 from . import search_scheme  # noqa: F401
 
-__all__ = ["FMIndex", "BiFMIndex", "search_no_errors", "search_backtracking", "search_ng26", "search", "LocateLinear",
+__all__ = ["FMIndex", "BiFMIndex", "search_no_errors", "search_backtracking", "search_ng26", "search", "search_n", "search_best", "LocateLinear",
            "search_scheme", "FmgpuError", "DeviceBuffer", "flatten", "device_count"]
 
 
@@ -320,18 +320,9 @@ class search_ng26:
         return (hits, st) if want_stats else hits
 
 
-def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False, edit=False):
-    """fmc::search<EditDistance> / search_n (search/search.h:26-46; edit=False: Hamming, edit=True: edit distance, the reference's
-    default): errors == 0 -> search_no_errors, else search_ng26 with
-    h2(errors+2, 0, errors) and a uniform partition.  The reference's convenience overload additionally applies
-    limitToHamming to the un-expanded scheme (search/CachedSearchScheme.h:26-30), which loses hits (SURVEY.md §0.3);
-    compat_auto_scheme=True reproduces exactly that."""
-    if errors == 0:
-        lb, ln = search_no_errors.search(index, queries)
-        keep = np.nonzero(ln)[0]
-        hits = np.zeros(keep.size, dtype=HIT_DTYPE)
-        hits["qidx"], hits["lb"], hits["len"] = keep, lb[keep], ln[keep]
-        return hits
+def _auto_scheme_search(index, queries, errors, n, edit, compat_auto_scheme):
+    """search_ng26::search<Edit>(index, queries, maxErrors, delegate, n) (search/SearchNg26.h:436-444): per query length the cached scheme
+    h2(maxErrors + (length == 2 ? 1 : 2), 0, maxErrors) (CachedSearchScheme.h:16-36) with a uniform partition"""
     qbuf, qoff, nq = _queries(queries)
     if not isinstance(qoff, np.ndarray):                      # the facade splits the batch by length on the host
         qoff = qoff.to_array(np.uint64, nq + 1) if isinstance(qoff, DeviceBuffer) else np.asarray(qoff)
@@ -340,7 +331,6 @@ def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False, edit=
     lens = np.diff(qoff.astype(np.int64))
 
     def scheme_for(short):
-        # getCachedSearchScheme<false>(0, k, shortLen = (length == 2)): search/SearchNg26.h:436-444, CachedSearchScheme.h:16-36
         sc = search_scheme.h2(errors + (1 if short else 2), 0, errors)
         return search_scheme.limitToHamming(sc) if (compat_auto_scheme and not edit) else sc
 
@@ -356,6 +346,58 @@ def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False, edit=
             hits = hits.copy()
             hits["qidx"] = sel.astype(np.uint64)[hits["qidx"].astype(np.int64)]
         parts.append(hits)
+    if not parts:
+        return np.zeros(0, dtype=HIT_DTYPE)
+    hits = np.concatenate(parts)
+    return hits[np.lexsort((hits["seq"], hits["qidx"]))]
+
+
+def search(index, queries, errors, n=UINT64_MAX, compat_auto_scheme=False, edit=False):
+    """fmc::search<EditDistance> (search/search.h:26-35; edit=False: Hamming, edit=True: edit distance, the reference's default):
+    errors == 0 -> search_no_errors, else search_ng26 with h2(errors+2, 0, errors) and a uniform partition.  For Hamming distance the
+    reference's convenience overload additionally applies limitToHamming to the un-expanded scheme (search/CachedSearchScheme.h:26-30),
+    which loses hits; compat_auto_scheme=True reproduces exactly that."""
+    if errors == 0:
+        lb, ln = search_no_errors.search(index, queries)
+        keep = np.nonzero(ln)[0]
+        hits = np.zeros(keep.size, dtype=HIT_DTYPE)
+        hits["qidx"], hits["lb"], hits["len"] = keep, lb[keep], ln[keep]
+        return hits
+    return _auto_scheme_search(index, queries, errors, n, edit, compat_auto_scheme)
+
+
+def search_n(index, queries, errors, n, edit=True, compat_auto_scheme=False):
+    """fmc::search_n<EditDistance> (search/search.h:38-46): at most n rows per query, always through search_ng26 (also for errors == 0)"""
+    return _auto_scheme_search(index, queries, errors, n, edit, compat_auto_scheme)
+
+
+def search_best(index, queries, max_errors, n=UINT64_MAX, edit=True, schemes=None):
+    """search_ng26::search_best (search/SearchNg26.h:447-487).
+    schemes=None: the convenience overload (:476-487) — the whole batch is searched with 0, 1, ... max_errors - 1 errors (the loop ends
+    BEFORE max_errors, as in the reference) and stops at the first error count for which ANY query reports a hit.
+    schemes=[(scheme, partition), ...]: the explicit overload (:447-473) — per query the first scheme that reports anything wins."""
+    if schemes is None:
+        for k in range(int(max_errors)):
+            hits = _auto_scheme_search(index, queries, k, n, edit, False)
+            if len(hits):
+                return hits
+        return np.zeros(0, dtype=HIT_DTYPE)
+    qbuf, qoff, nq = _queries(queries)
+    if not isinstance(qoff, np.ndarray):
+        qoff = qoff.to_array(np.uint64, nq + 1) if isinstance(qoff, DeviceBuffer) else np.asarray(qoff)
+    if not isinstance(qbuf, np.ndarray):
+        qbuf = qbuf.to_array(np.uint8, int(qoff[-1]))
+    todo = np.arange(nq)
+    parts = []
+    for sch, part in schemes:
+        if todo.size == 0:
+            break
+        qb, qo = flatten([qbuf[int(qoff[i]): int(qoff[i + 1])] for i in todo])
+        hits = search_ng26.search(index, (qb, qo), sch, part, n, edit=edit).copy()
+        found = np.unique(hits["qidx"].astype(np.int64))
+        hits["qidx"] = todo.astype(np.uint64)[hits["qidx"].astype(np.int64)]
+        parts.append(hits)
+        todo = np.delete(todo, found)
     if not parts:
         return np.zeros(0, dtype=HIT_DTYPE)
     hits = np.concatenate(parts)

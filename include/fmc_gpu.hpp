@@ -422,6 +422,36 @@ void search(Index const& index, Queries const& queries, size_t maxErrors, Delega
     }
     detail::report(index, all, delegate);
 }
+// search_best<Edit>(index, queries, {(scheme, partition), ...}, delegate, n) — search/SearchNg26.h:447-473: per query the first scheme
+// that reports anything wins
+template <bool Edit = true, typename Index, typename Queries, typename Delegate>
+void search_best(Index const& index, Queries const& queries, std::vector<std::tuple<search_scheme::Scheme, std::vector<size_t>>> const& schemes,
+                 Delegate&& delegate, size_t n = std::numeric_limits<size_t>::max()) {
+    std::vector<uint64_t> todo;
+    for (size_t i = 0; i < queries.size(); ++i) todo.push_back(i);
+    std::vector<fmgpu_hit> all;
+    for (auto const& [scheme, partition] : schemes) {
+        if (todo.empty()) break;
+        std::vector<uint8_t> buf; std::vector<uint64_t> off{0};
+        for (auto qi : todo) { auto const& q = queries[qi]; buf.insert(buf.end(), q.begin(), q.end()); off.push_back(buf.size()); }
+        auto hits = detail2::run<Edit>(index, buf, off, scheme, partition, n, &todo);
+        std::vector<uint8_t> found(queries.size(), 0);
+        for (auto const& h : hits) found[h.qidx] = 1;
+        all.insert(all.end(), hits.begin(), hits.end());
+        std::vector<uint64_t> rest;
+        for (auto qi : todo) if (!found[qi]) rest.push_back(qi);
+        todo.swap(rest);
+    }
+    detail::report(index, all, delegate);
+}
+// search_best<Edit>(index, queries, maxErrors, delegate, n) — search/SearchNg26.h:476-487: the whole batch with 0, 1, ... maxErrors - 1
+// errors (the reference's loop ends before maxErrors), stopping at the first error count for which any query reports a hit
+template <bool Edit = true, typename Index, typename Queries, typename Delegate>
+void search_best(Index const& index, Queries const& queries, size_t maxErrors, Delegate&& delegate, size_t n = std::numeric_limits<size_t>::max()) {
+    bool found = false;
+    for (size_t i = 0; i < maxErrors && !found; ++i)
+        search<Edit>(index, queries, i, [&](size_t qidx, auto cursor, size_t e) { if (cursor.count() == 0) return; found = true; delegate(qidx, cursor, e); }, n);
+}
 }  // namespace search_ng26
 
 // fmc::search<EditDistance>(index, queries, errors, delegate(qidx, cursor, errors)) — search/search.h:26-35

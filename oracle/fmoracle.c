@@ -1095,6 +1095,7 @@ uint64_t ora_search_ng26_hamming(const ora_index* x, const uint8_t* qbuf, const 
             uint64_t before = e.count, part_buf[64];
             uint64_t m = qoff[q + 1] - qoff[q];
             const uint64_t* part = partition;
+            if (m < (uint64_t)nparts) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length; such a query is skipped */
             if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
             e.qidx = q; e.quota = max_hits_per_query;
             for (int si = 0; si < nsearch; ++si) {               /* search_impl, :369-391 */
@@ -1112,6 +1113,7 @@ uint64_t ora_search_ng26_hamming(const ora_index* x, const uint8_t* qbuf, const 
             uint64_t part_buf[64];
             uint64_t m = qoff[q + 1] - qoff[q];
             const uint64_t* part = partition;
+            if (m < (uint64_t)nparts) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length; such a query is skipped */
             if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
             for (int si = 0; si < nsearch; ++si) {
                 ng_search s = {x, qbuf + qoff[q], m, nparts, pi + si * nparts, l + si * nparts, u + si * nparts, part, &e};
@@ -1281,6 +1283,7 @@ uint64_t ora_search_ng26(const ora_index* x, int edit, const uint8_t* qbuf, cons
             uint64_t before = e.count, part_buf[64];
             uint64_t m = qoff[q + 1] - qoff[q];
             const uint64_t* part = partition;
+            if (m < (uint64_t)nparts) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length; such a query is skipped */
             if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
             e.qidx = q; e.quota = max_hits_per_query;
             for (int si = 0; si < nsearch; ++si) {
@@ -1297,6 +1300,7 @@ uint64_t ora_search_ng26(const ora_index* x, int edit, const uint8_t* qbuf, cons
             uint64_t part_buf[64];
             uint64_t m = qoff[q + 1] - qoff[q];
             const uint64_t* part = partition;
+            if (m < (uint64_t)nparts) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length; such a query is skipped */
             if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
             for (int si = 0; si < nsearch; ++si) {
                 nge_search s = {{x, qbuf + qoff[q], m, nparts, pi + si * nparts, l + si * nparts, u + si * nparts, part, &e}, edit};

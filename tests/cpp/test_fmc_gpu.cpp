@@ -82,6 +82,11 @@ int main() {
         fmc::search</*EditDistance=*/true>(index, queries, /*maxErrors*/ 1, locate_all);
         std::sort(results.begin(), results.end());
         CHECK((results == Results{{0, 0, 3}, {0, 0, 3}, {0, 1, 7}, {0, 1, 7}, {1, 0, 7}, {1, 0, 7}, {1, 1, 3}, {1, 1, 3}}));
+        results.clear();                                   // search_best: nothing at 0 errors, and the loop ends before maxErrors = 1 ...
+        fmc::search_ng26::search_best(index, queries, /*maxErrors*/ 1, locate_all);
+        CHECK(results.empty());
+        fmc::search_ng26::search_best(index, queries, /*maxErrors*/ 2, locate_all);     // ... so 2 is needed to see the 1-error hits
+        CHECK(results.size() == 8);
         results.clear();
         fmc::search_n</*EditDistance=*/true>(index, queries, /*maxErrors*/ 1, /*n*/ 3, locate_all);
         std::sort(results.begin(), results.end());

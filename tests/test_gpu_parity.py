@@ -399,6 +399,54 @@ def test_edit_distance_matches_the_cpu_walk(layout, sigma, k):
     assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch), ox.search_ng26(qbuf, qoff, sch)[0])
 
 
+@pytest.mark.parametrize("edit", [False, True])
+def test_search_n_and_search_best(edit):
+    """fmc::search_n (search/search.h:38-46) and search_ng26::search_best (SearchNg26.h:447-487): the host-side drivers around the search
+    kernels — per-length cached schemes, the convenience overload's loop over 0 .. maxErrors-1 that stops once any query has a hit, the
+    explicit overload's per-query first-scheme-wins"""
+    rng = np.random.default_rng(17)
+    base = rng.integers(1, 5, size=900, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[300:600]]), rng.integers(1, 5, size=300, dtype=np.uint8)]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 2, True)
+    gx = gpu_index(ox)
+    queries = [q for q in mutated_queries(seqs, 120, 6, 30, 2, seed=23)] + [np.array([1, 2], dtype=np.uint8), np.array([4, 4], dtype=np.uint8)]
+    qbuf, qoff = fm.flatten(queries)
+
+    def oracle_auto(k, n):                                        # SearchNg26.h:436-444 with the oracle
+        out = []
+        for short in (False, True):
+            sel = [i for i, q in enumerate(queries) if (len(q) == 2) == short]
+            if not sel:
+                continue
+            qb, qo = fm.flatten([queries[i] for i in sel])
+            h = ox.search_ng26(qb, qo, fo.scheme_h2(k + (1 if short else 2), 0, k), max_hits=n, edit=edit)[0].copy()
+            h["qidx"] = np.array(sel, dtype=np.uint64)[h["qidx"].astype(np.int64)]
+            out.append(h)
+        h = np.concatenate(out)
+        return h[np.argsort(h["qidx"], kind="stable")]             # the oracle emits in callback order: a stable sort keeps it inside a query
+
+    for k, n in ((0, 2), (1, 3), (2, fm.UINT64_MAX)):
+        assert same_hits(fm.search_n(gx, (qbuf, qoff), k, n, edit=edit), oracle_auto(k, n)), (k, n)
+    want = None
+    for k in range(2):
+        want = oracle_auto(k, 5)
+        if len(want):
+            break
+    assert same_hits(fm.search_best(gx, (qbuf, qoff), 2, n=5, edit=edit), want)
+    # explicit scheme list: exact first, then one error for the queries that found nothing
+    lists = [(fm.search_scheme.h2(2, 0, 0), None), (fm.search_scheme.h2(3, 0, 1), None)]
+    keep = [i for i, q in enumerate(queries) if len(q) >= 3]
+    kb, ko = fm.flatten([queries[i] for i in keep])
+    got = fm.search_best(gx, (kb, ko), 1, edit=edit, schemes=lists)
+    h0 = ox.search_ng26(kb, ko, fo.scheme_h2(2, 0, 0), edit=edit)[0]
+    rest = [i for i in range(len(keep)) if i not in set(h0["qidx"].tolist())]
+    rb, ro = fm.flatten([queries[keep[i]] for i in rest])
+    h1 = ox.search_ng26(rb, ro, fo.scheme_h2(3, 0, 1), edit=edit)[0].copy()
+    h1["qidx"] = np.array(rest, dtype=np.uint64)[h1["qidx"].astype(np.int64)]
+    want = np.concatenate([h0, h1]); want = want[np.argsort(want["qidx"], kind="stable")]
+    assert same_hits(got, want) and len(h1) > 0 and len(h0) > 0
+
+
 @pytest.mark.parametrize("bidir", [False, True])
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_backtracking(bidir, k):
