@@ -605,7 +605,9 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
     uint32_t e = 0, part = 0, qL = 0, qR = 0, pev = 0, tail = 0, sp = 0, resume = kNoResume;
     uint32_t side = 0;                      // lastRank[left] | lastRank[right] << 8 | lastQRank[left] << 16 | lastQRank[right] << 24
     uint32_t info = 0;                      // LInfo | RInfo << 2
-    idx_t cached_lf = 0;
+    idx_t cached_lf = 0, cached_lf2 = 0xffffffffu;   // a resumed one-row frame: LF of its row, LF of that row (if a child reported it)
+    bool lf_known = false; idx_t lf_val = 0;         // LF of the NEXT node's row is already known (same row after an insertion, or reported)
+    uint32_t report_slot = kNoResume;                // frame whose deletion child will stand on this node's row: tell it this node's LF
     bool right = true;
     const uint8_t *pi = s_pi, *L = s_l, *U = s_u;
     auto part_len = [&](uint32_t p) -> uint32_t { return sch.uniform ? pbase + (p < prem ? 1u : 0u) : s_part[p]; };
@@ -651,8 +653,14 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
         idx_t lfa[MAXSIG], lfb[MAXSIG];
         const bool via_lf = lfv.fw != nullptr && cur.len == 1;      // one row: its only child comes from the LF table
         idx_t lf1 = cached_lf;                                      // a resumed one-row node brings its LF value along in the frame
-        if (via_lf) { if (resume == kNoResume) lf1 = (right ? lfv.rv : lfv.fw)[a]; }
-        else occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
+        if (via_lf) {
+            if (resume == kNoResume) {
+                lf1 = lf_known ? lf_val : (right ? lfv.rv : lfv.fw)[a];
+                if (report_slot != kNoResume)                       // (the waiting deletion child of the parent starts from this same row)
+                    reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + report_slot))[2] = lf1;
+            }
+        } else occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
+        lf_known = false; report_slot = kNoResume;
         const uint32_t c = qstage_get(qst, qs, right ? qR : qL);
         SymSet<MAXSIG> alive;
         if (via_lf) { alive.clear(); alive.insert(symbol_of_lf_lds(s_C, sigma, lf1)); }
@@ -718,19 +726,23 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             // one 32-byte record per frame; a lane's frames are consecutive in memory: a DFS pushes and pops them in order, so four share a
             // 128-byte line (lanes of a wave sit at different depths — interleaving them by lane would touch one line per frame)
             uint4* f = reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
-            const uint64_t w2 = (uint64_t)(nxt | (info << 16)) | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
+            const uint64_t w2 = (uint64_t)(nxt | (info << 16) | ((via_lf ? 1u : 0u) << 20)) | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
                                 ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
-            f[0] = make_uint4(cur.lb, cur.lbRev, cur.len, (pev & 0xffffu) | ((qR & 0xffffu) << 16));
+            // one-row frames (len = 1): the third word holds LF(LF(row)) once the first child on that row has loaded it
+            f[0] = make_uint4(cur.lb, cur.lbRev, via_lf ? 0xffffffffu : cur.len, (pev & 0xffffu) | ((qR & 0xffffu) << 16));
             f[1] = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), side, lf1);
+            if (via_lf && nxt == 2u && (kind == 0u || kind == 1u)) report_slot = sp;
             ++sp;
         }
         resume = kNoResume;
         bool back = kind == 4u, to_next = false;
         if (kind != 4u) {
             if (kind != 3u) {
-                if (via_lf) cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
-                else cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
-            }
+                if (via_lf) {
+                    cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
+                    if (kind == 2u && resuming && cached_lf2 != 0xffffffffu) { lf_known = true; lf_val = cached_lf2; }   // reported by the first child on that row
+                } else cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+            } else if (via_lf) { lf_known = true; lf_val = lf1; }    // insertion: the next node stands on the same row
             if (kind != 0u) e += 1;
             const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
             if (kind == 0u) {                                       // in the exact tail the values written last survive (:236-237)
@@ -766,7 +778,9 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
                 }
                 back = true;
             } else {
-                right = pi[part - 1] < pi[part];
+                const bool nr = pi[part - 1] < pi[part];
+                if (nr != right) { lf_known = false; report_slot = kNoResume; }   // the other index: another LF table
+                right = nr;
             }
         }
         if (back) {
@@ -775,8 +789,11 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             const uint4* f = reinterpret_cast<const uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
             const uint4 a0 = f[0], a1 = f[1];
             const uint64_t w2 = (uint64_t)a1.x | ((uint64_t)a1.y << 32);
-            cur.lb = a0.x; cur.lbRev = a0.y; cur.len = a0.z; pev = a0.w & 0xffffu; qR = a0.w >> 16;
+            const bool one_row = ((uint32_t)w2 >> 20) & 1u;
+            cur.lb = a0.x; cur.lbRev = a0.y; cur.len = one_row ? 1u : a0.z; cached_lf2 = one_row ? a0.z : 0xffffffffu;
+            pev = a0.w & 0xffffu; qR = a0.w >> 16;
             resume = (uint32_t)w2 & 0xffffu; info = ((uint32_t)w2 >> 16) & 15u; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
+            lf_known = false; report_slot = kNoResume;
             right = (w2 >> 47) & 1u;
             qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
             side = a1.z; cached_lf = a1.w;
