@@ -56,6 +56,7 @@ def parse():
                     "protein: 1 = block-table expansion of the wavelet (default), 0 = search the wavelet lines themselves")
     ap.add_argument("--no-search-accel", action="store_true", help="k2: no prefix / walk tables (fmgpu_index_accelerate_search)")
     ap.add_argument("--no-exact-tables", action="store_true", help="exact / protein: only the k-step table (no suffix-interval table, no walk table)")
+    ap.add_argument("--trim", type=int, default=0, help="dev: every read loses 0..TRIM symbols at its end (a ragged batch)")
     ap.add_argument("--edit", action="store_true", help="k2: edit distance (search_ng26<Edit = true>) instead of Hamming distance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -133,8 +134,13 @@ def main():
         pos = torch.randint(0, L, (sel.numel(),), generator=gq, device=dev)
         shift = torch.randint(1, sigma - 1, (sel.numel(),), generator=gq, device=dev, dtype=torch.uint8)
         reads[sel, pos] = (reads[sel, pos] - 1 + shift) % (sigma - 1) + 1
-    qbuf = reads.reshape(-1)
-    qoff = (torch.arange(nq + 1, device=dev, dtype=torch.int64) * L)
+    if args.trim > 0:
+        lens = L - torch.randint(0, args.trim + 1, (nq,), generator=gq, device=dev, dtype=torch.int64)
+        qbuf = reads[ar[None, :] < lens[:, None]].contiguous()
+        qoff = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(lens, 0)])
+    else:
+        qbuf = reads.reshape(-1)
+        qoff = (torch.arange(nq + 1, device=dev, dtype=torch.int64) * L)
     torch.cuda.synchronize()
 
     # ---------------------------------------------------------------- index construction on the GPU (not timed as a step)

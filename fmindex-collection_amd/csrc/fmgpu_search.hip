@@ -20,6 +20,8 @@
 #include <tuple>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 namespace fmgpu {
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -974,7 +976,7 @@ template <int SIGMA, int MAXSIG>
 __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
-                                                                          uint32_t qwords, uint32_t qnib, int dev_flags) {
+                                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap) {
     // Wave-synchronous rounds.  A wave pays for every slow path any of its 64 lanes takes, so nothing with a dependent
     // memory round trip is lane-private: the 64 lanes fetch and stage their next queries TOGETHER (one atomicAdd per wave,
     // query words issued back to back), start every search of the scheme TOGETHER (so the few wide-interval steps at a
@@ -1002,11 +1004,12 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
         if (lane == 0) base = atomicAdd(&ctr->next, 64ull);
         base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
         if (base >= nq) break;
-        const uint64_t q = base + lane;
-        const bool active = q < nq && n != 0;
-        const uint64_t qo = q < nq ? qoff[q] : 0;
+        const bool present = base + lane < nq;                      // nq = queries of this launch; qmap (if any) names them within the batch
+        const uint64_t q = present ? (qmap ? (uint64_t)qmap[base + lane] : base + lane) : 0;
+        const bool active = present && n != 0;
+        const uint64_t qo = present ? qoff[q] : 0;
         const uint8_t* qs = qbuf + qo;
-        qstage_load_sync(qst, qbuf, qo, m, sigma, q < nq, m);
+        qstage_load_sync(qst, qbuf, qo, m, sigma, present, m);
 
         uint64_t quota = max_hits; uint32_t seq = 0, nh = 0;
         bool query_over = !active;
@@ -1457,6 +1460,12 @@ static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, uin
     return true;
 }
 
+// (length, query number) pairs for the length buckets of a ragged batch
+__global__ __launch_bounds__(256) void k_len_pairs(const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t* __restrict__ len, uint32_t* __restrict__ idx) {
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) { len[q] = (uint32_t)(qoff[q + 1] - qoff[q]); idx[q] = (uint32_t)q; }
+}
+
 struct DfsWorkspace {
     uint64_t* planes = nullptr; Counters* ctr = nullptr; StackView view{};
     unsigned grid = 0;
@@ -1669,33 +1678,92 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     const idx_t n = (idx_t)x->bwt.n;
     dim3 grid(ws.grid), block(256);
     // fast path: equal-length batch on a Format-A BiFMIndex with LF tables
-    std::vector<uint32_t> step_tab;
-    uint32_t lut_ok = 0;
     // 16-symbol walk: 2-bit symbols, queries staged in LDS as nibbles
     const bool use_wj = !(sd.dev_flags & 32) && x->bwt.walkj && x->rev.walkj && x->bwt.walk_bits == 2 && x->rev.walk_bits == 2 && qnib && qwords;
-    const bool fast = scheme_mode && !edit && x->bwt.search_family() == FAM_A && x->bwt.lf_table && x->rev.lf_table && minlen == maxlen &&
-                      x->bwt.sigma <= 32 && !(sd.dev_flags & 2) && build_step_table(sd, maxlen, (sd.dev_flags & 4) ? 0 : x->lut_len, use_wj ? 16u : 0u, step_tab, lut_ok);
+    const bool fast_ok = scheme_mode && !edit && x->bwt.search_family() == FAM_A && x->bwt.lf_table && x->rev.lf_table && x->bwt.sigma <= 32 && !(sd.dev_flags & 2);
+    const uint32_t lutL = (sd.dev_flags & 4) ? 0 : x->lut_len;
+    // one launch of the table-driven kernel per query length: an equal-length batch is one bucket; a ragged batch is sorted by length on the
+    // device (the kernel reads its queries through the sorted index) as long as the buckets stay large enough to be worth a launch each
+    struct Bucket { uint32_t m; uint64_t first, count; std::vector<uint32_t> tab; uint32_t lut_ok; };
+    std::vector<Bucket> buckets;
+    uint32_t* d_qmap = nullptr;
+    bool fast = false;
+    if (fast_ok && minlen == maxlen) {
+        Bucket b{maxlen, 0, nq, {}, 0};
+        fast = build_step_table(sd, maxlen, lutL, use_wj ? 16u : 0u, b.tab, b.lut_ok);
+        if (fast) buckets.push_back(std::move(b));
+    } else if (fast_ok && nq >= (1u << 16) && nq < 0x7fffffffull && !(sd.dev_flags & 64)) {
+        uint32_t *klen = nullptr, *kidx = nullptr, *slen = nullptr, *runs = nullptr;
+        void* tmp = nullptr; size_t tmp_bytes = 0, tmp2 = 0;
+        const uint32_t max_runs = maxlen - minlen + 1;
+        auto drop = [&] { for (void* p : {(void*)klen, (void*)kidx, (void*)slen, (void*)runs, tmp}) if (p) (void)hipFree(p); };
+        hipError_t he = hipMalloc((void**)&klen, nq * 4);
+        if (he == hipSuccess) he = hipMalloc((void**)&kidx, nq * 4);
+        if (he == hipSuccess) he = hipMalloc((void**)&slen, nq * 4);
+        if (he == hipSuccess) he = hipMalloc((void**)&d_qmap, nq * 4);
+        if (he == hipSuccess) he = hipMalloc((void**)&runs, ((size_t)max_runs * 2 + 1) * 4);
+        if (he == hipSuccess) {
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, klen, slen, kidx, d_qmap, (int)nq, 0, 16, stream);
+            (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp2, slen, runs, runs + max_runs, runs + 2 * max_runs, (int)nq, stream);
+            he = hipMalloc(&tmp, std::max(tmp_bytes, tmp2));
+        }
+        if (he != hipSuccess) { drop(); if (d_qmap) (void)hipFree(d_qmap); return hip_fail(he, "hipMalloc(length buckets)"); }
+        k_len_pairs<<<dim3((unsigned)((nq + 255) / 256)), 256, 0, stream>>>((const uint64_t*)soff.dev, nq, klen, kidx);
+        size_t tb = std::max(tmp_bytes, tmp2);
+        he = hipcub::DeviceRadixSort::SortPairs(tmp, tb, klen, slen, kidx, d_qmap, (int)nq, 0, 16, stream);
+        tb = std::max(tmp_bytes, tmp2);
+        if (he == hipSuccess) he = hipcub::DeviceRunLengthEncode::Encode(tmp, tb, slen, runs, runs + max_runs, runs + 2 * max_runs, (int)nq, stream);
+        std::vector<uint32_t> hruns((size_t)max_runs * 2 + 1);
+        if (he == hipSuccess) he = hipMemcpyAsync(hruns.data(), runs, hruns.size() * 4, hipMemcpyDeviceToHost, stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(stream);
+        drop();
+        if (he != hipSuccess) { (void)hipFree(d_qmap); return hip_fail(he, "length buckets"); }
+        const uint32_t nruns = hruns[(size_t)max_runs * 2];
+        fast = nruns > 0 && nq / nruns >= 4096;                    // buckets of a few thousand queries at least (a launch and a step table each)
+        uint64_t first = 0;
+        for (uint32_t r = 0; r < nruns && fast; ++r) {
+            const uint32_t m = hruns[r]; const uint64_t cnt = hruns[max_runs + r];
+            // expand.h:325-327 precondition; an explicit partition must cover the query exactly; other lengths are skipped as in k_scheme
+            if (m >= (uint32_t)sd.P && (sd.uniform || m == sd.psum) && n != 0) {
+                Bucket b{m, first, cnt, {}, 0};
+                fast = build_step_table(sd, m, lutL, use_wj ? 16u : 0u, b.tab, b.lut_ok);
+                if (fast) buckets.push_back(std::move(b));
+            }
+            first += cnt;
+        }
+        if (!fast) { buckets.clear(); (void)hipFree(d_qmap); d_qmap = nullptr; }
+    }
     uint32_t* d_steps = nullptr;
+    size_t steps_words = 0;
     if (fast) {
-        FM_HIP(hipMalloc((void**)&d_steps, step_tab.size() * 4));
-        FM_HIP(hipMemcpyAsync(d_steps, step_tab.data(), step_tab.size() * 4, hipMemcpyHostToDevice, stream));
+        for (const Bucket& b : buckets) steps_words += b.tab.size();
+        hipError_t he = hipMalloc((void**)&d_steps, std::max<size_t>(steps_words, 1) * 4);
+        if (he != hipSuccess) { if (d_qmap) (void)hipFree(d_qmap); return hip_fail(he, "hipMalloc(step tables)"); }
+        size_t at = 0;
+        for (const Bucket& b : buckets) { (void)hipMemcpyAsync(d_steps + at, b.tab.data(), b.tab.size() * 4, hipMemcpyHostToDevice, stream); at += b.tab.size(); }
     }
     timer.start();
     if (fast) {
-        FastArgs fa{};
-        fa.lf_fw = x->bwt.lf_table; fa.lf_rv = x->rev.lf_table; fa.steps = d_steps; fa.S = (uint32_t)sd.S; fa.m = maxlen;
-        if (!(sd.dev_flags & 8)) { fa.w3_fw = x->bwt.walk3; fa.w3_rv = x->rev.walk3; }
-        if (use_wj) { fa.wj_fw = x->bwt.walkj; fa.wj_rv = x->rev.walkj; }
-        fa.lut = lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = lut_ok;
-        for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
-        const size_t lds_fast = lds_bytes + step_tab.size() * 4 + (size_t)kHitBuf * 5 * 256 * 4;
-        FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));       // the fast kernel hands out 64-query rounds from 0
-        if (x->bwt.sigma == 5)
-            k_scheme_fast<5, 5><<<grid, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                   nq, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags);
-        else
-            k_scheme_fast<0, 32><<<grid, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                    nq, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags);
+        size_t at = 0;
+        for (const Bucket& b : buckets) {
+            FastArgs fa{};
+            fa.lf_fw = x->bwt.lf_table; fa.lf_rv = x->rev.lf_table; fa.steps = d_steps + at; fa.S = (uint32_t)sd.S; fa.m = b.m;
+            at += b.tab.size();
+            if (!(sd.dev_flags & 8)) { fa.w3_fw = x->bwt.walk3; fa.w3_rv = x->rev.walk3; }
+            if (use_wj) { fa.wj_fw = x->bwt.walkj; fa.wj_rv = x->rev.walkj; }
+            fa.lut = b.lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = b.lut_ok;
+            for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
+            const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (size_t)kHitBuf * 5 * 256 * 4;
+            FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));   // the fast kernel hands out 64-query rounds from 0
+            const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ws.grid, (b.count + 255) / 256)));
+            const uint32_t* qm = d_qmap ? d_qmap + b.first : nullptr;
+            if (x->bwt.sigma == 5)
+                k_scheme_fast<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                    b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
+            else
+                k_scheme_fast<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
+        }
     } else if (scheme_mode) {
         const DevString& rv = x->rev;
         LfView lfv{nullptr, nullptr, nullptr};
@@ -1730,6 +1798,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (le == hipSuccess) le = hipMemcpyAsync(&hc, ws.ctr, sizeof hc, hipMemcpyDeviceToHost, stream);
     if (le == hipSuccess) le = hipStreamSynchronize(stream);
     if (d_steps) (void)hipFree(d_steps);
+    if (d_qmap) (void)hipFree(d_qmap);
     if (le != hipSuccess) return hip_fail(le, "search kernel");
     *out_count = hc.hits;
     if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); }

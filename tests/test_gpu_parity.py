@@ -234,6 +234,44 @@ def test_scheme_search_equal_length_fast_path(k, length):
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, fm.search_scheme.h2(k + 2, 0, k))[0])
 
 
+def test_scheme_search_ragged_batch_in_length_buckets():
+    """a large ragged batch is sorted by length on the device and runs the table-driven kernel once per length: same records, order and
+    node count as the CPU walk and as the general kernel; queries shorter than the number of parts are skipped in both"""
+    seqs = repeat_text(77, n=8000)
+    ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
+    gx = gpu_index(ox)
+    gx.accelerate_search(4, 3)
+    rng = np.random.default_rng(5)
+    queries = []
+    s0 = seqs[0]
+    for i in range(70_000):
+        m = int(rng.integers(24, 32)) if i % 1000 else 2          # a few too-short ones
+        p = int(rng.integers(0, len(s0) - m)); q = s0[p: p + m].copy()
+        if i % 3: q[int(rng.integers(0, m))] = rng.integers(1, 5)
+        queries.append(q)
+    qbuf, qoff = fm.flatten(queries)
+    sch = fm.search_scheme.h2(3, 0, 1)
+    hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 22)
+    keep = [i for i, q in enumerate(queries) if len(q) >= 3]
+    kb, ko = fm.flatten([queries[i] for i in keep])
+    ohits, _, nodes = ox.search_ng26(kb, ko, sch, cap=1 << 22)
+    ohits = ohits.copy(); ohits["qidx"] = np.array(keep, dtype=np.uint64)[ohits["qidx"].astype(np.int64)]
+    assert same_hits(hits, ohits) and st.lf_steps == nodes
+    os.environ["FMGPU_DEV_FLAGS"] = "64"                      # no length buckets: the general kernel
+    try:
+        hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 22)
+    finally:
+        del os.environ["FMGPU_DEV_FLAGS"]
+    assert hits2.tobytes() == hits.tobytes() and st2.lf_steps == nodes
+    assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=1, capacity=1 << 22), ox_n1(ox, kb, ko, sch, keep))
+
+
+def ox_n1(ox, kb, ko, sch, keep):
+    h = ox.search_ng26(kb, ko, sch, max_hits=1, cap=1 << 22)[0].copy()
+    h["qidx"] = np.array(keep, dtype=np.uint64)[h["qidx"].astype(np.int64)]
+    return h
+
+
 def test_scheme_search_variants():
     seqs = repeat_text(20)
     ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
