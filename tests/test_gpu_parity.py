@@ -165,6 +165,32 @@ def test_exact_search_with_kstep_accelerator(layout, sigma, kstep):
     assert np.array_equal(lb2, lb) and np.array_equal(ln2, ln)
 
 
+@pytest.mark.parametrize("layout,sigma", [("IB16", 256), ("IB16", 21), ("EPRV5", 6), ("FBV_512_64K", 255)])
+def test_exact_search_tables_other_alphabets(layout, sigma):
+    """interval table and walk table with symbols wider than 2 bits (walk length 32 / bit_width(sigma-2): 4 symbols at sigma = 256)"""
+    rng = np.random.default_rng(sigma)
+    hi = min(sigma, 9)
+    base = rng.integers(1, hi, size=2500, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[500:900]]), rng.integers(1, sigma, size=600, dtype=np.uint8)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 8, False)
+    gx = gpu_index(ox)
+    queries = []
+    for i in range(600):
+        s = seqs[i % 2]; m = int(rng.integers(1, 70)); p = int(rng.integers(0, len(s) - m)); q = s[p: p + m].copy()
+        if i % 4 == 0:
+            q[int(rng.integers(0, m))] = rng.integers(1, sigma)
+        queries.append(q)
+    queries += [[], [0], [sigma - 1] * 5]
+    qbuf, qoff = fm.flatten(queries)
+    olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
+    for kstep, lut_len, walk in ((1, 2, True), (1, 0, True), (1, 1, False), (2 if sigma <= 6 else 1, 2, True)):
+        gx.accelerate(kstep, lut_len=lut_len, walk=walk)
+        lb, ln, st = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+        assert np.array_equal(lb, olb) and np.array_equal(ln, oln) and st.lf_steps == int(ost.sum()), (kstep, lut_len, walk)
+    with pytest.raises(fm.FmgpuError):
+        gx.accelerate(1, lut_len=32 if sigma > 6 else 33)         # table too large / out of range
+
+
 def test_exact_search_tiny_indices():
     for seqs in ([[1]], [[]], [[1], [1], [2, 1]], [[3] * 70]):
         ox = fo.OraIndex.build("IB16", 5, seqs, 1, True)
