@@ -579,7 +579,7 @@ constexpr int kEditWaves = 4;         // waves per SIMD the register allocation 
 template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_edit(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
                                                      const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
-                                                     fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv, uint32_t maxm) {
+                                                     fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv, uint32_t maxm, const uint4* __restrict__ lut, uint32_t lutL) {
     extern __shared__ uint32_t s_query[];
     const QStage qst{s_query, qwords, qnib};
     __shared__ uint8_t s_pi[kMaxSearches * kMaxParts], s_l[kMaxSearches * kMaxParts], s_u[kMaxSearches * kMaxParts];
@@ -649,6 +649,23 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             pev = part_len(pi[0]);
             right = true;
             need_search = false;
+            if (lut && U[0] == 0 && pev > lutL && n > 1) {          // an always-exact first part starts from the prefix table (fmgpu_index_accelerate_search)
+                uint32_t code = 0, mul = 1; bool valid = true;
+                for (uint32_t t = 0; t < lutL; ++t) {
+                    const uint32_t c = qstage_get(qst, qs, qR + t);
+                    valid = valid && c >= 1 && c < sigma;
+                    code += (c - 1) * mul; mul *= sigma - 1;
+                }
+                if (valid) {
+                    const uint4 en = lut[code];
+                    nodes += en.w;                                  // the extensions the reference performs before the interval is empty (:225-250)
+                    if (en.z == 0) { need_search = true; continue; }
+                    cur = Cur{en.x, en.y, en.z};
+                    qR += lutL; tail = pev - lutL;                  // the rest of the part is an exact tail
+                    const uint32_t lastc = qstage_get(qst, qs, qR - 1u);
+                    side = (lastc << 8) | (lastc << 24);           // lastRank / lastQRank of the right side (:236-237 at the end of the tail anyway)
+                }
+            }
         }
         const Occ& occ = right ? rv : fw;
         const idx_t a = right ? cur.lbRev : cur.lb;
@@ -1777,7 +1794,8 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             (void)hipMemsetAsync(&ws.ctr->next, 0, 8, stream);         // queries are handed out from 0, one reservation per wave
             if (edit) {
                 k_scheme_edit<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
-                                                                                  max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, maxlen);
+                                                                                  max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, maxlen,
+                                                                                  (sd.dev_flags & 4) ? nullptr : x->lut, x->lut_len);
                 return 0;
             }
             k_scheme<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,

@@ -461,6 +461,12 @@ def test_edit_distance_matches_the_cpu_walk(layout, sigma, k):
     assert same_hits(fm.search_ng26.search(gx, (sb, so), sch, partition=part, edit=True), ox.search_ng26(sb, so, sch, partition=part, edit=True)[0])
     # Edit = false through the same entry point still takes the Hamming kernels
     assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch), ox.search_ng26(qbuf, qoff, sch)[0])
+    if sigma <= 8:                                            # with the prefix table the always-exact first part starts from its entry
+        gx.accelerate_search(3, 1)
+        for sch2 in (sch, fm.search_scheme.pigeon_opt(0, k)):
+            hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch2, want_stats=True, edit=True)
+            ohits, _, nodes = ox.search_ng26(qbuf, qoff, sch2, edit=True)
+            assert same_hits(hits, ohits) and st.lf_steps == nodes
 
 
 @pytest.mark.parametrize("edit", [False, True])
