@@ -1242,6 +1242,215 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
 }
 
+// ---- search_ng26 Edit = true, table-driven ------------------------------------------------------------------------------------------
+// k_scheme_edit's node logic in k_scheme_fast's frame: rounds of 64 equal-length queries per wave, the searches of the scheme started by all
+// lanes together (so the wide first steps of a search coincide and the per-lane slow paths — query fetch, search set-up — are wave-wide
+// phases), the scheme expanded into the per-step table (a step = one query symbol consumed: deletions stay on their step), hits kept in LDS
+// and written out by the wave.  In the flat kernel a wave executes the union of what its 64 lanes are doing; measured lane utilisation ~11 %.
+template <int SIGMA, int MAXSIG>
+__global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
+                                                          const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
+                                                          fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
+                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap) {
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
+    const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
+    uint32_t* s_hb = s_steps + 2u * S * stride;                     // kWaveHitWords
+    const QStage qst{s_dyn, qwords, qnib};
+    for (uint32_t i = threadIdx.x; i < 2u * S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
+    __syncthreads();
+
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sigma = fw.sigma(), R = sigma - 1;
+    const uint32_t INS = 2u * sigma - 1u;
+    uint4* const frames = reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u));   // this lane's frames, 32 bytes each
+    uint32_t nodes = 0, nh = 0;
+    for (;;) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->next, 64ull);
+        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+        if (base >= nq) break;
+        const bool present = base + lane < nq;
+        const uint64_t q = present ? (qmap ? (uint64_t)qmap[base + lane] : base + lane) : 0;
+        const uint64_t qo = present ? qoff[q] : 0;
+        const uint8_t* qs = qbuf + qo;
+        qstage_load_sync(qst, qbuf, qo, m, sigma, present, m);
+
+        uint64_t quota = max_hits; uint32_t seq = 0;
+        bool query_over = !(present && n != 0);
+        for (uint32_t si = 0; si < S; ++si) {                       // search_impl (SearchNg26.h:385-390), all lanes in step
+            const uint32_t* tab = s_steps + si * stride;
+            bool done = query_over;
+            Cur cur{0, 0, n};                                       // run(): :62-79
+            uint32_t e = 0, j = 0, sp = 0, resume = kNoResume, side = 0, info = 0;
+            bool in_tail = false, lf_known = false;
+            idx_t lf_val = 0, cached_lf = 0, cached_lf2 = 0xffffffffu;
+            uint32_t report_slot = kNoResume;
+            if (fa.lut && ((fa.lut_ok >> si) & 1u) && n > 1) {      // the always-exact first part starts from the prefix table
+                uint32_t code = 0, mul = 1; bool valid = !done;
+                for (uint32_t t = 0; t < fa.lutL; ++t) {
+                    uint32_t c = qstage_get(qst, qs, tab[t] & 0xffffu);
+                    valid = valid && c >= 1 && c < sigma;
+                    code += (c - 1) * mul; mul *= R;
+                }
+                if (valid) {
+                    const uint4 en = fa.lut[code];
+                    cur = Cur{en.x, en.y, en.z};
+                    nodes += en.w;
+                    j = fa.lutL; in_tail = true;
+                    const uint32_t lastc = qstage_get(qst, qs, tab[fa.lutL - 1u] & 0xffffu);
+                    side = (lastc << 8) | (lastc << 24);
+                    if (en.z == 0) done = true;
+                }
+            }
+            for (;;) {
+                // wave-synchronous: write the buffered hits out when some lane's buffer is full
+                const uint64_t busy = __ballot(!done);
+                if (__ballot(nh == kWaveHitBuf) != 0ull || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
+                if (!busy) break;
+                if (done) continue;
+                const uint32_t ent = tab[j];
+                const bool right = (ent >> 16) & 1u;
+                const uint32_t minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
+                const bool lastp = (ent >> 17) & 1u;
+                const uint32_t c = qstage_get(qst, qs, ent & 0xffffu);
+                const bool multi = cur.len > 1, resuming = resume != kNoResume;
+                const idx_t a = right ? cur.lbRev : cur.lb;
+                const uint32_t d = right ? 1u : 0u;
+                const uint32_t T = (info >> (2u * d)) & 3u;
+                const uint32_t lastR = (side >> (8u * d)) & 255u, lastQ = (side >> (16u + 8u * d)) & 255u;
+                const bool Deletion = T != 1u && T != 2u, Insertion = T != 1u && T != 3u;                      // :146-147
+                const bool mOK = minE <= e && e <= maxE && (T != 2u || c != lastQ) && (T != 3u || c != lastR);    // :160-163
+                const bool iOK = minE <= e + 1 && e + 1 <= maxE;
+                const bool xOK = e + 1 <= maxE;
+                // ---- memory phase
+                idx_t lfa[MAXSIG], lfb[MAXSIG];
+                SymSet<MAXSIG> alive;
+                idx_t lf1 = cached_lf;
+                if (multi) {
+                    const OccA<SIGMA>& occ = right ? rv : fw;
+                    occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
+                    alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+                } else {
+                    if (!resuming) {
+                        lf1 = lf_known ? lf_val : (right ? fa.lf_rv : fa.lf_fw)[a];
+                        if (report_slot != kNoResume) reinterpret_cast<uint32_t*>(frames + 2u * report_slot)[2] = lf1;
+                    }
+                    alive.clear(); alive.insert(symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, lf1));
+                }
+                lf_known = false; report_slot = kNoResume;
+                const bool c_alive = alive.test(c);
+                // ---- child selection (numbering as in k_scheme_edit)
+                const uint32_t start = resuming ? resume : 0u;
+                uint32_t kind = 4u, take = c, nxt = kNoResume;
+                bool start_tail = false;
+                if (in_tail) { if (c_alive) kind = 0u; }
+                else if (multi) {
+                    if (!xOK) { if (!resuming && mOK && c_alive) { kind = 0u; start_tail = true; } }
+                    else {
+                        SymSet<MAXSIG> dels = alive; dels.remove(0); if (!Deletion) dels.clear();
+                        SymSet<MAXSIG> subs = alive; subs.remove(0); subs.remove(c); if (!iOK) subs.clear();
+                        const bool insOK = Insertion && iOK;
+                        auto child_from = [&](uint32_t s0) -> uint32_t {
+                            if (s0 == 0u && mOK && c_alive) return 0u;
+                            SymSet<MAXSIG> dd = dels, ss = subs;
+                            dd.clear_below(s0 <= 1u ? 1u : (s0 + 2u) >> 1);
+                            ss.clear_below(s0 <= 2u ? 1u : (s0 + 1u) >> 1);
+                            uint32_t best = kNoResume;
+                            if (dd.any()) best = 2u * dd.first() - 1u;
+                            if (ss.any()) { uint32_t v = 2u * ss.first(); if (v < best) best = v; }
+                            if (best == kNoResume && insOK && s0 <= INS) best = INS;
+                            return best;
+                        };
+                        const uint32_t idx = child_from(start);
+                        if (idx != kNoResume) {
+                            if (idx == 0u) kind = 0u;
+                            else if (idx == INS) kind = 3u;
+                            else { kind = (idx & 1u) ? 2u : 1u; take = (idx + 1u) >> 1; }
+                            if (idx != INS) nxt = child_from(idx + 1u);
+                        }
+                    }
+                } else {
+                    const uint32_t b = alive.first();
+                    const bool valid = b >= 1u;
+                    const bool same = valid && b == c;
+                    const bool en0 = Insertion && iOK;
+                    const bool en1 = same ? mOK : (valid && xOK && iOK);
+                    const bool en2 = Deletion && valid && xOK;
+                    uint32_t idx = kNoResume;
+                    if (start <= 0u && en0) idx = 0u; else if (start <= 1u && en1) idx = 1u; else if (start <= 2u && en2) idx = 2u;
+                    if (idx == 0u) { kind = 3u; nxt = en1 ? 1u : (en2 ? 2u : kNoResume); }
+                    else if (idx == 1u) {
+                        take = b;
+                        if (same) { kind = 0u; start_tail = !xOK; nxt = (en2 && xOK) ? 2u : kNoResume; }
+                        else { kind = 1u; nxt = en2 ? 2u : kNoResume; }
+                    } else if (idx == 2u) { kind = 2u; take = b; }
+                }
+                nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + (start_tail ? 1u : 0u))));
+                if (kind != 4u && nxt != kNoResume) {               // keep the parent: its remaining children start at nxt
+                    uint4* f = frames + 2u * sp;
+                    f[0] = make_uint4(cur.lb, cur.lbRev, multi ? cur.len : 0xffffffffu, (j & 0xffffu) | ((e & 0xffu) << 16) | ((multi ? 0u : 1u) << 24) | (info << 25));
+                    f[1] = make_uint4(nxt, side, lf1, 0u);
+                    if (!multi && nxt == 2u && (kind == 0u || kind == 1u)) report_slot = sp;
+                    ++sp;
+                }
+                resume = kNoResume;
+                bool back = kind == 4u;
+                if (kind != 4u) {
+                    if (kind != 3u) {
+                        if (multi) cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+                        else {
+                            cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
+                            if (kind == 2u && resuming && cached_lf2 != 0xffffffffu) { lf_known = true; lf_val = cached_lf2; }
+                        }
+                    } else if (!multi) { lf_known = true; lf_val = lf1; }
+                    if (kind != 0u) e += 1;
+                    const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
+                    if (kind == 0u) { side = (side & rmask & qmask) | (c << (8u * d)) | (c << (16u + 8u * d)); info = info & imask; }
+                    else if (kind == 1u) { side = (side & rmask & qmask) | (take << (8u * d)) | (c << (16u + 8u * d)); info = (info & imask) | (1u << (2u * d)); }
+                    else if (kind == 2u) { side = (side & rmask) | (take << (8u * d)); info = (info & imask) | (3u << (2u * d)); }
+                    else { side = (side & qmask) | (c << (16u + 8u * d)); info = (info & imask) | (2u << (2u * d)); }
+                    if (kind != 2u) {                               // one query symbol consumed: the next step of the table
+                        in_tail = !lastp && (in_tail || start_tail);
+                        ++j;
+                        if (j < m && (((tab[j] >> 16) & 1u) != (right ? 1u : 0u))) { lf_known = false; report_slot = kNoResume; }   // the other index from here on
+                    }
+                }
+                bool search_over = false;
+                if (!back && j == m) {                              // search_next at part == P (:101-108)
+                    const uint32_t fin = tab[m];
+                    const uint32_t li = info & 3u, ri = (info >> 2) & 3u;
+                    if ((li == 0u || li == 2u) && (ri == 0u || ri == 2u) && ((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x3fu)) {
+                        Cur r = cur;
+                        if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
+                        quota -= r.len;
+                        if (dev_flags & 1) ++seq; else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
+                        if (quota == 0) { search_over = true; query_over = true; }
+                    }
+                    back = !search_over;
+                }
+                if (back) {
+                    if (sp == 0) search_over = true;
+                    else {
+                        --sp;
+                        const uint4* f = frames + 2u * sp;
+                        const uint4 a0 = f[0], a1 = f[1];
+                        const bool one_row = (a0.w >> 24) & 1u;
+                        cur.lb = a0.x; cur.lbRev = a0.y; cur.len = one_row ? 1u : a0.z; cached_lf2 = one_row ? a0.z : 0xffffffffu;
+                        j = a0.w & 0xffffu; e = (a0.w >> 16) & 0xffu; info = (a0.w >> 25) & 15u;
+                        resume = a1.x; side = a1.y; cached_lf = a1.z;
+                        in_tail = false; lf_known = false; report_slot = kNoResume;
+                    }
+                }
+                if (search_over) done = true;
+            }
+        }
+    }
+    uint32_t tot = wave_sum(nodes);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
+}
+
 // ---- search_backtracking ----------------------------------------------------------------------------------------
 template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
@@ -1696,8 +1905,8 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     dim3 grid(ws.grid), block(256);
     // fast path: equal-length batch on a Format-A BiFMIndex with LF tables
     // 16-symbol walk: 2-bit symbols, queries staged in LDS as nibbles
-    const bool use_wj = !(sd.dev_flags & 32) && x->bwt.walkj && x->rev.walkj && x->bwt.walk_bits == 2 && x->rev.walk_bits == 2 && qnib && qwords;
-    const bool fast_ok = scheme_mode && !edit && x->bwt.search_family() == FAM_A && x->bwt.lf_table && x->rev.lf_table && x->bwt.sigma <= 32 && !(sd.dev_flags & 2);
+    const bool use_wj = !edit && !(sd.dev_flags & 32) && x->bwt.walkj && x->rev.walkj && x->bwt.walk_bits == 2 && x->rev.walk_bits == 2 && qnib && qwords;
+    const bool fast_ok = scheme_mode && x->bwt.search_family() == FAM_A && x->bwt.lf_table && x->rev.lf_table && x->bwt.sigma <= 32 && !(sd.dev_flags & 2);
     const uint32_t lutL = (sd.dev_flags & 4) ? 0 : x->lut_len;
     // one launch of the table-driven kernel per query length: an equal-length batch is one bucket; a ragged batch is sorted by length on the
     // device (the kernel reads its queries through the sorted index) as long as the buckets stay large enough to be worth a launch each
@@ -1770,11 +1979,18 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             if (use_wj) { fa.wj_fw = x->bwt.walkj; fa.wj_rv = x->rev.walkj; }
             fa.lut = b.lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = b.lut_ok;
             for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
-            const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (size_t)kHitBuf * 5 * 256 * 4;
+            const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (edit ? (size_t)kWaveHitWords * 4 : (size_t)kHitBuf * 5 * 256 * 4);
             FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));   // the fast kernel hands out 64-query rounds from 0
             const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ws.grid, (b.count + 255) / 256)));
             const uint32_t* qm = d_qmap ? d_qmap + b.first : nullptr;
-            if (x->bwt.sigma == 5)
+            if (edit) {
+                if (x->bwt.sigma == 5)
+                    k_scheme_fast_edit<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
+                else
+                    k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                              b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
+            } else if (x->bwt.sigma == 5)
                 k_scheme_fast<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
             else

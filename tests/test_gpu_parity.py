@@ -469,6 +469,45 @@ def test_edit_distance_matches_the_cpu_walk(layout, sigma, k):
             assert same_hits(hits, ohits) and st.lf_steps == nodes
 
 
+@pytest.mark.parametrize("k,length,sigma", [(1, 20, 5), (2, 31, 5), (2, 101, 5), (3, 40, 5), (1, 30, 28), (2, 24, 6)])
+def test_edit_distance_equal_length_fast_path(k, length, sigma):
+    """equal-length batches take the table-driven edit-distance kernel (k_scheme_fast_edit): same cursors, errors, callback order and
+    extension counts as the CPU walk, with and without the prefix table, with search_n clipping, and equal to the general kernel"""
+    rng = np.random.default_rng(100 + k + length)
+    hi = min(sigma, 8)
+    base = rng.integers(1, hi, size=2000, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[300:900]]), rng.integers(1, hi, size=500, dtype=np.uint8)]
+    ox = fo.OraIndex.build("IB16", sigma, seqs, 4, True)
+    gx = gpu_index(ox)
+    queries = []
+    for i in range(700 if k < 3 else 150):
+        p = int(rng.integers(0, len(seqs[0]) - length - 4)); q = list(seqs[0][p: p + length + 3])
+        for _ in range(int(rng.integers(0, k + 2))):
+            op = int(rng.integers(0, 3)); jj = int(rng.integers(0, len(q)))
+            if op == 0: q[jj] = int(rng.integers(1, hi))
+            elif op == 1: q.insert(jj, int(rng.integers(1, hi)))
+            else: del q[jj]
+        queries.append(np.array(q[:length], dtype=np.uint8))
+    assert len({len(q) for q in queries}) == 1
+    qbuf, qoff = fm.flatten(queries)
+    for accel in (None, (3, 1)):
+        if accel is not None:
+            gx.accelerate_search(*accel)
+        for sch in (fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k), fm.search_scheme.backtracking(2, 0, k)):
+            hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 21)
+            ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)
+            assert same_hits(hits, ohits) and st.lf_steps == nodes and len(ohits) > 0, (accel, k, length)
+        sch = fm.search_scheme.h2(k + 2, 0, k)
+        for n in (1, 4):
+            assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=n, edit=True), ox.search_ng26(qbuf, qoff, sch, max_hits=n, edit=True)[0])
+    os.environ["FMGPU_DEV_FLAGS"] = "2"                       # the general kernel
+    try:
+        hits2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, edit=True, capacity=1 << 21)
+    finally:
+        del os.environ["FMGPU_DEV_FLAGS"]
+    assert same_hits(hits2, ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)[0])
+
+
 @pytest.mark.parametrize("edit", [False, True])
 def test_search_n_and_search_best(edit):
     """fmc::search_n (search/search.h:38-46) and search_ng26::search_best (SearchNg26.h:447-487): the host-side drivers around the search
