@@ -287,7 +287,7 @@ def main():
         "gbp_per_s": qps * L / 1e9,
         "hits": hits,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": (("k_exact_a" if args.no_exact_tables else "k_exact_kstep") if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if args.kstep > 1 else "k_exact_a") if not bidir else ("k_scheme_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
+                     "traffic": traffic, "kernel": (("k_exact_a" if args.no_exact_tables else "k_exact_kstep") if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if args.kstep > 1 else "k_exact_a") if not bidir else ("k_scheme_fast_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
                      "units_per_launch": steps_per_launch, "bytes_per_unit": unit_bytes,
                      "unit": "GB/s", "note": NOTE_PROTEIN if protein else NOTE_DNA},
     }
