@@ -56,6 +56,8 @@ def parse():
                     "protein: 1 = block-table expansion of the wavelet (default), 0 = search the wavelet lines themselves")
     ap.add_argument("--no-search-accel", action="store_true", help="k2: no prefix / walk tables (fmgpu_index_accelerate_search)")
     ap.add_argument("--no-exact-tables", action="store_true", help="exact / protein: only the k-step table (no suffix-interval table, no walk table)")
+    ap.add_argument("--lut-len", type=int, default=0, help="exact / protein: symbols of the interval table (0 = 15 bp / 6 aa)")
+    ap.add_argument("--prefix-len", type=int, default=15, help="k2: symbols of the prefix table (fmgpu_index_accelerate_search)")
     ap.add_argument("--trim", type=int, default=0, help="dev: every read loses 0..TRIM symbols at its end (a ragged batch)")
     ap.add_argument("--edit", action="store_true", help="k2: edit distance (search_ng26<Edit = true>) instead of Hamming distance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -154,10 +156,10 @@ def main():
     if not bidir and (args.kstep > 1 or (protein and args.kstep == 1)):
         if args.no_exact_tables:
             index.accelerate(args.kstep)
-        else:                                                   # + interval table of the last 12 bp / 4 aa, + per-row LF^J walk table (J = 16 bp / 6 aa)
-            index.accelerate(args.kstep, lut_len=4 if protein else 12, walk=True)
+        else:                                                   # + interval table of the last 15 bp / 6 aa, + per-row LF^J walk table (J = 16 bp / 6 aa)
+            index.accelerate(args.kstep, lut_len=args.lut_len or (6 if protein else 15), walk=True)
     if bidir and not args.no_search_accel:
-        index.accelerate_search(11, 3)
+        index.accelerate_search(args.prefix_len, 3)
     build_s = time.time() - t0
     if not want_cpu:
         del text
@@ -280,9 +282,9 @@ def main():
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "protein_exact" if protein else "grch38_%s" % ("exact" if not bidir else ("k2_edit" if args.edit else "k2")), "text_symbols": total, "sequences": len(lengths),
                    "sigma": sigma, "layout": "Wavelet" if protein else "InterleavedBitvector16", "queries_per_gpu": nq, "read_len": L,
-                   "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale, "kstep_table": (args.kstep if not bidir else 1),
+                   "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale, "prefix_table_symbols": (args.prefix_len if bidir and not args.no_search_accel else None), "kstep_table": (args.kstep if not bidir else 1),
                    "device_table": ("block table expanded from the wavelet" if args.kstep else "wavelet lines") if protein else "block table",
-                   "exact_tables": None if (bidir or args.no_exact_tables or (protein and not args.kstep)) else {"suffix_interval_symbols": 4 if protein else 12, "walk_symbols_per_load": 6 if protein else 16},
+                   "exact_tables": None if (bidir or args.no_exact_tables or (protein and not args.kstep)) else {"suffix_interval_symbols": args.lut_len or (6 if protein else 15), "walk_symbols_per_load": 6 if protein else 16},
                    "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
         "gbp_per_s": qps * L / 1e9,
         "hits": hits,

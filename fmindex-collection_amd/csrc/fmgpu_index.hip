@@ -720,7 +720,7 @@ int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len
     const uint32_t sigma = (uint32_t)s.sigma, R = sigma - 1;
     if (lut_len > 0) {
         uint64_t entries = 1;
-        for (int t = 0; t < lut_len; ++t) { entries *= R; if (entries > (1ull << 28)) return fail(FMGPU_ERR_UNSUPPORTED, "suffix table would exceed 2^28 entries"); }
+        for (int t = 0; t < lut_len; ++t) { entries *= R; if (entries > (1ull << 30)) return fail(FMGPU_ERR_UNSUPPORTED, "suffix table would exceed 2^30 entries"); }
         FM_HIP(hipMalloc((void**)&s.slut, entries * 8));
         dim3 grid((unsigned)((entries + 255) / 256)), block(256);
         switch (s.search_family()) {
@@ -782,7 +782,7 @@ int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t w
     if (prefix_len > 0) {
         const uint32_t R = (uint32_t)x->bwt.sigma - 1;
         uint64_t entries = 1;
-        for (int t = 0; t < prefix_len; ++t) { entries *= R; if (entries > (1ull << 26)) return fail(FMGPU_ERR_UNSUPPORTED, "prefix table would exceed 2^26 entries"); }
+        for (int t = 0; t < prefix_len; ++t) { entries *= R; if (entries > (1ull << 30)) return fail(FMGPU_ERR_UNSUPPORTED, "prefix table would exceed 2^30 entries"); }
         FM_HIP(hipMalloc((void**)&x->lut, entries * 16));
         dim3 grid((unsigned)((entries + 255) / 256)), block(256);
         const DevString& r = x->rev;
