@@ -149,7 +149,7 @@ int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layo
  * one-line-per-LF-step block format the InterleavedBitvector* layouts are held in (12 * sigma / 64 bytes per row and direction; a
  * Wavelet step otherwise touches bit_width(sigma-1) lines); every search kernel then reads that table, fmgpu_string_query keeps
  * answering from the native layout.  kstep = 0 removes the k-step table and the expansion. */
-int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep);
+int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep);   /* (all fmgpu_index_accelerate* calls modify the handle: not concurrently with searches on it) */
 
 /* fmgpu_index_accelerate plus two more optional tables for fmgpu_search_exact (results unchanged):
  *   lut_len > 0: the interval of every string of `lut_len` symbols ((sigma-1)^lut_len entries of 8 bytes; DNA, 12 symbols: 134 MB) — a query
