@@ -1572,13 +1572,54 @@ __global__ __launch_bounds__(256) void k_locate(Occ occ, const idx_t* __restrict
 }
 
 // ------------------------------------------------------------------ host launchers
-struct EventTimer {
+// per host thread and device: small device buffers and events that every call needs (allocating and freeing them per call costs more
+// than the bookkeeping they serve — hipFree synchronises the device).  `ctr` serves calls that report stats (they synchronise before
+// returning, so it is idle between calls), `sink` the others (never read).
+struct CallScratch {
+    unsigned long long* ctr = nullptr; unsigned long long* sink = nullptr; unsigned long long* len2 = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr; int dev = -1;
+};
+static int call_scratch(CallScratch** out) {
+    static thread_local CallScratch sc;
+    int dev = 0;
+    FM_HIP(hipGetDevice(&dev));
+    if (sc.dev != dev) {                                          // first use on this device (objects of an earlier device are left to the process)
+        sc = CallScratch{}; sc.dev = dev;
+        FM_HIP(hipMalloc((void**)&sc.ctr, kCounterStripes * 8));
+        FM_HIP(hipMalloc((void**)&sc.sink, kCounterStripes * 8));
+        FM_HIP(hipMalloc((void**)&sc.len2, 16));
+        FM_HIP(hipEventCreate(&sc.ev_a));
+        FM_HIP(hipEventCreate(&sc.ev_b));
+    }
+    *out = &sc;
+    return 0;
+}
+static int step_counters(bool want, hipStream_t stream, unsigned long long** out) {
+    CallScratch* sc = nullptr;
+    int rc = call_scratch(&sc); if (rc) return rc;
+    if (want) FM_HIP(hipMemsetAsync(sc->ctr, 0, kCounterStripes * 8, stream));
+    *out = want ? sc->ctr : sc->sink;
+    return 0;
+}
+static int read_step_counters(const unsigned long long* dev, hipStream_t stream, unsigned long long* total) {
+    unsigned long long h[kCounterStripes];
+    FM_HIP(hipMemcpyAsync(h, dev, sizeof h, hipMemcpyDeviceToHost, stream));
+    FM_HIP(hipStreamSynchronize(stream));
+    unsigned long long t = 0;
+    for (unsigned long long v : h) t += v;
+    *total = t;
+    return 0;
+}
+
+struct EventTimer {       // the thread's cached event pair (one timed call at a time per host thread)
     hipEvent_t a = nullptr, b = nullptr; hipStream_t s; bool on;
-    EventTimer(hipStream_t s_, bool on_) : s(s_), on(on_) { if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); } }
+    EventTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
+        CallScratch* sc = nullptr;
+        if (on && call_scratch(&sc) == 0) { a = sc->ev_a; b = sc->ev_b; } else on = false;
+    }
     void start() { if (on) (void)hipEventRecord(a, s); }
     void stop() { if (on) (void)hipEventRecord(b, s); }
     float ms() { float v = 0; if (on) { (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&v, a, b); } return v; }
-    ~EventTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 };
 
 
@@ -1614,17 +1655,17 @@ __global__ __launch_bounds__(256) void k_len_range(const uint64_t* __restrict__ 
     if ((threadIdx.x & 63u) == 0) { atomicMax(out, v); atomicMin(out + 1, w); }
 }
 
+__global__ void k_len_init(unsigned long long* d) { d[0] = 0ull; d[1] = ~0ull; }
 static int query_len_range(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out_max, uint32_t* out_min) {
-    unsigned long long* d = nullptr;
-    FM_HIP(hipMalloc((void**)&d, 16));
-    unsigned long long init[2] = {0ull, ~0ull};
-    FM_HIP(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, stream));
+    CallScratch* sc = nullptr;
+    int rc = call_scratch(&sc); if (rc) return rc;
+    unsigned long long* d = sc->len2;
+    k_len_init<<<1, 1, 0, stream>>>(d);
     unsigned blocks = (unsigned)std::min<uint64_t>((nq + 255) / 256, 1024);
     k_len_range<<<dim3(blocks), dim3(256), 0, stream>>>(dqoff, nq, d);
     unsigned long long h[2] = {0, 0};
     hipError_t e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return hip_fail(e, "k_len_range");
     *out_max = (uint32_t)std::min<unsigned long long>(h[0], 0xffffffffull);
     *out_min = (uint32_t)std::min<unsigned long long>(h[1], 0xffffffffull);
@@ -1721,33 +1762,6 @@ struct DfsWorkspace {
 
 using namespace fmgpu;
 
-namespace {
-// per host thread and device: one zero-on-demand counter block for calls that report stats (they synchronise before returning, so it
-// is idle between calls) and one sink for calls that do not (never read)
-struct StepScratch { unsigned long long* ctr = nullptr; unsigned long long* sink = nullptr; int dev = -1; };
-int step_counters(bool want, hipStream_t stream, unsigned long long** out) {
-    static thread_local StepScratch sc;
-    int dev = 0;
-    FM_HIP(hipGetDevice(&dev));
-    if (sc.dev != dev) {                                          // first use on this device (blocks of an earlier device are left to the process)
-        sc.ctr = sc.sink = nullptr; sc.dev = dev;
-        FM_HIP(hipMalloc((void**)&sc.ctr, kCounterStripes * 8));
-        FM_HIP(hipMalloc((void**)&sc.sink, kCounterStripes * 8));
-    }
-    if (want) FM_HIP(hipMemsetAsync(sc.ctr, 0, kCounterStripes * 8, stream));
-    *out = want ? sc.ctr : sc.sink;
-    return 0;
-}
-int read_step_counters(const unsigned long long* dev, hipStream_t stream, unsigned long long* total) {
-    unsigned long long h[kCounterStripes];
-    FM_HIP(hipMemcpyAsync(h, dev, sizeof h, hipMemcpyDeviceToHost, stream));
-    FM_HIP(hipStreamSynchronize(stream));
-    unsigned long long t = 0;
-    for (unsigned long long v : h) t += v;
-    *total = t;
-    return 0;
-}
-}  // namespace
 
 extern "C" {
 
