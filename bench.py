@@ -293,6 +293,9 @@ def main():
                      "units_per_launch": steps_per_launch, "bytes_per_unit": unit_bytes,
                      "unit": "GB/s", "note": NOTE_PROTEIN if protein else NOTE_DNA},
     }
+    if traffic is not None:                                   # the PMC-measured bytes of the same launch against the same peak
+        result["roofline"]["traffic_rate"] = {"achieved": traffic / (k_ms * 1e-3) / 1e9, "unit": "GB/s", "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "what": "measured HBM bytes per launch (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE) / this run's kernel time"}
     if lines is not None:
         result["roofline"]["line_rate"] = {"achieved_G_per_s": lines / (k_ms * 1e-3) / 1e9, "ceiling_G_per_s": ceiling,
                                            "frac": lines / (k_ms * 1e-3) / 1e9 / ceiling,
