@@ -217,7 +217,24 @@ def main():
                 payload = packed[b].view(torch.uint8)
             if via_host:
                 payload = payload.cpu()
-            pending[b] = dist.gather(payload, [g[: payload.numel()] for g in gathered[b]] if rank == 0 else None, dst=0, async_op=True)
+            pending[b] = exchange(payload, b)
+
+    xch = {"mode": "gather", "bufs": [None, None]}
+
+    def exchange(payload, b):
+        """SA intervals / hit records to rank 0.  torch.distributed.gather (grouped send/recv in RCCL) is the exchange the path needs; should this
+        build refuse it, every rank switches to all_gather_into_tensor — more bytes over xGMI, same information on rank 0"""
+        if xch["mode"] == "gather":
+            try:
+                return dist.gather(payload, [g[: payload.numel()] for g in gathered[b]] if rank == 0 else None, dst=0, async_op=True)
+            except (RuntimeError, NotImplementedError, ValueError) as ex:
+                xch["mode"] = "all_gather"
+                if rank == 0:
+                    print("bench.py: dist.gather unavailable (%s); using all_gather_into_tensor" % ex, file=sys.stderr, flush=True)
+        need = world * payload.numel()
+        if xch["bufs"][b] is None or xch["bufs"][b].numel() < need:
+            xch["bufs"][b] = torch.empty(need, dtype=torch.uint8, device=payload.device)
+        return dist.all_gather_into_tensor(xch["bufs"][b][:need], payload, async_op=True)
 
     def drain():
         for b in range(2):
