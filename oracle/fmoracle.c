@@ -1087,6 +1087,8 @@ uint64_t ora_search_ng26_hamming(const ora_index* x, const uint8_t* qbuf, const 
                                  const uint64_t* partition, uint64_t max_hits_per_query,
                                  ora_hit* out, uint64_t cap, uint64_t* out_qcount, uint64_t* out_nodes, int nthreads) {
     if (!x->bidirectional || nq == 0 || max_hits_per_query == 0) { if (out_nodes) *out_nodes = 0; return 0; }   /* SearchNg26.h:408-409 */
+    uint64_t psum = 0;
+    if (partition) for (int p = 0; p < nparts; ++p) psum += partition[p];
     int T = nthreads > 0 ? nthreads : 1;
     uint64_t total = 0, total_nodes = 0;
     if (T == 1) {
@@ -1095,7 +1097,7 @@ uint64_t ora_search_ng26_hamming(const ora_index* x, const uint8_t* qbuf, const 
             uint64_t before = e.count, part_buf[64];
             uint64_t m = qoff[q + 1] - qoff[q];
             const uint64_t* part = partition;
-            if (m < (uint64_t)nparts) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length; such a query is skipped */
+            if (m < (uint64_t)nparts || (partition && m != psum)) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length, and an explicit partition must add up to the query: such a query is skipped */
             if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
             e.qidx = q; e.quota = max_hits_per_query;
             for (int si = 0; si < nsearch; ++si) {               /* search_impl, :369-391 */
@@ -1113,7 +1115,7 @@ uint64_t ora_search_ng26_hamming(const ora_index* x, const uint8_t* qbuf, const 
             uint64_t part_buf[64];
             uint64_t m = qoff[q + 1] - qoff[q];
             const uint64_t* part = partition;
-            if (m < (uint64_t)nparts) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length; such a query is skipped */
+            if (m < (uint64_t)nparts || (partition && m != psum)) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length, and an explicit partition must add up to the query: such a query is skipped */
             if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
             for (int si = 0; si < nsearch; ++si) {
                 ng_search s = {x, qbuf + qoff[q], m, nparts, pi + si * nparts, l + si * nparts, u + si * nparts, part, &e};
@@ -1275,6 +1277,8 @@ uint64_t ora_search_ng26(const ora_index* x, int edit, const uint8_t* qbuf, cons
                          const uint64_t* partition, uint64_t max_hits_per_query,
                          ora_hit* out, uint64_t cap, uint64_t* out_qcount, uint64_t* out_nodes, int nthreads) {
     if (!x->bidirectional || nq == 0 || max_hits_per_query == 0) { if (out_nodes) *out_nodes = 0; return 0; }
+    uint64_t psum = 0;
+    if (partition) for (int p = 0; p < nparts; ++p) psum += partition[p];
     int T = nthreads > 0 ? nthreads : 1;
     uint64_t total = 0, total_nodes = 0;
     if (T == 1) {
@@ -1283,7 +1287,7 @@ uint64_t ora_search_ng26(const ora_index* x, int edit, const uint8_t* qbuf, cons
             uint64_t before = e.count, part_buf[64];
             uint64_t m = qoff[q + 1] - qoff[q];
             const uint64_t* part = partition;
-            if (m < (uint64_t)nparts) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length; such a query is skipped */
+            if (m < (uint64_t)nparts || (partition && m != psum)) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length, and an explicit partition must add up to the query: such a query is skipped */
             if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
             e.qidx = q; e.quota = max_hits_per_query;
             for (int si = 0; si < nsearch; ++si) {
@@ -1300,7 +1304,7 @@ uint64_t ora_search_ng26(const ora_index* x, int edit, const uint8_t* qbuf, cons
             uint64_t part_buf[64];
             uint64_t m = qoff[q + 1] - qoff[q];
             const uint64_t* part = partition;
-            if (m < (uint64_t)nparts) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length; such a query is skipped */
+            if (m < (uint64_t)nparts || (partition && m != psum)) { if (out_qcount) out_qcount[q] = 0; continue; }   /* expand.h:325-327 asserts parts <= length, and an explicit partition must add up to the query: such a query is skipped */
             if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
             for (int si = 0; si < nsearch; ++si) {
                 nge_search s = {{x, qbuf + qoff[q], m, nparts, pi + si * nparts, l + si * nparts, u + si * nparts, part, &e}, edit};

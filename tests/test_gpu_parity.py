@@ -508,6 +508,44 @@ def test_edit_distance_equal_length_fast_path(k, length, sigma):
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)[0])
 
 
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_randomised_schemes_partitions_and_tables(seed):
+    """random texts, read lengths, schemes (h2 / pigeon / backtracking / expanded), explicit partitions with tiny parts (several part ends
+    inside one 16-symbol stretch) and accelerator combinations: Hamming and edit distance equal the CPU walk record by record"""
+    rng = np.random.default_rng(1000 + seed)
+    sigma = int(rng.choice([4, 5, 5, 6]))
+    base = rng.integers(1, sigma, size=int(rng.integers(1500, 4000)), dtype=np.uint8)
+    seqs = [np.concatenate([base, base[200:900], rng.integers(1, sigma, size=400, dtype=np.uint8)]), base[100:700][::-1].copy()]
+    ox = fo.OraIndex.build("IB16", sigma, seqs, 4, True)
+    gx = gpu_index(ox)
+    gx.accelerate_search(int(rng.integers(0, 6)), int(rng.integers(0, 4)))
+    L = int(rng.integers(18, 90))
+    k = int(rng.integers(1, 4))
+    queries = []
+    for i in range(400):
+        s = seqs[0]; p = int(rng.integers(0, len(s) - L - 9)); q = list(s[p: p + L + 8])
+        for _ in range(int(rng.integers(0, k + 2))):
+            op = int(rng.integers(0, 4)); jj = int(rng.integers(0, len(q)))
+            if op <= 1: q[jj] = int(rng.integers(1, sigma))
+            elif op == 2: q.insert(jj, int(rng.integers(1, sigma)))
+            else: del q[jj]
+        queries.append(np.array(q[:L] if seed % 4 else q[: L - (i % 3)], dtype=np.uint8))      # every fourth configuration is a ragged batch
+    qbuf, qoff = fm.flatten(queries)
+    gens = [fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k), fm.search_scheme.backtracking(int(rng.integers(1, 5)), 0, k),
+            fm.search_scheme.h2(k + 3, 0, k), fm.search_scheme.h2(k + 2, 1, k)]
+    sch = gens[int(rng.integers(0, len(gens)))]
+    P = sch[0].shape[1]
+    partition = None
+    if rng.integers(0, 2):                                     # explicit partition, often with very short parts
+        cuts = np.sort(rng.choice(np.arange(1, L), size=P - 1, replace=False)) if P > 1 else np.array([], dtype=np.int64)
+        partition = np.diff(np.concatenate([[0], cuts, [L]])).astype(np.uint64)
+    n = fm.UINT64_MAX if rng.integers(0, 3) else int(rng.integers(1, 4))
+    for edit in (False, True):
+        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, partition=partition, n=n, want_stats=True, edit=edit, capacity=1 << 21)
+        ohits, _, nodes = ox.search_ng26(qbuf, qoff, sch, partition=partition, max_hits=n, edit=edit, cap=1 << 21)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes, (seed, sigma, L, k, edit, None if partition is None else partition.tolist())
+
+
 @pytest.mark.parametrize("edit", [False, True])
 def test_search_n_and_search_best(edit):
     """fmc::search_n (search/search.h:38-46) and search_ng26::search_best (SearchNg26.h:447-487): the host-side drivers around the search
