@@ -715,6 +715,43 @@ def test_gpu_builder_equals_reference_construction(name, bidir):
         assert [(int(a), int(b), int(c)) for a, b, c in zip(seq, pos, steps)] == [ox.locate(int(r)) for r in rows]
 
 
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_gpu_builder_randomised(seed):
+    """random collections — 1 to 40 sequences, empty ones, long runs, tandem repeats, duplicated sequences (ties that only the delimiter
+    order resolves), alphabets 2 .. 7, several sampling rates — against the oracle's construction: BWT, bwtRev, C, SparseArray arrays, locate"""
+    rng = np.random.default_rng(500 + seed)
+    sigma = int(rng.integers(2, 8))
+    seqs = []
+    for _ in range(int(rng.integers(1, 41))):
+        kind = int(rng.integers(0, 6))
+        m = int(rng.integers(0, 400))
+        if kind == 0 or sigma == 2: q = np.ones(m, dtype=np.uint8)
+        elif kind == 1: q = np.tile(rng.integers(1, sigma, size=int(rng.integers(1, 6)), dtype=np.uint8), m // 3 + 1)[:m]
+        elif kind == 2 and seqs: q = seqs[int(rng.integers(0, len(seqs)))].copy()
+        elif kind == 3 and seqs: base = seqs[int(rng.integers(0, len(seqs)))]; q = base[: len(base) // 2].copy()
+        else: q = rng.integers(1, sigma, size=m, dtype=np.uint8)
+        seqs.append(q.astype(np.uint8))
+    rate = int(rng.choice([1, 2, 5, 16, 64]))
+    bidir = bool(rng.integers(0, 2))
+    gx = (fm.BiFMIndex if bidir else fm.FMIndex).from_sequences(seqs, sigma, "IB16", rate, keep_host=True)
+    ox = fo.OraIndex.build("IB16", sigma, seqs, rate, bidir)
+    n = ox.n
+    assert gx.n == n
+    assert np.array_equal(gx.built_array(0), np.array([ox.bwt_string().symbol(i) for i in range(n)], dtype=np.uint8)), (seed, sigma, len(seqs))
+    if bidir:
+        assert np.array_equal(gx.built_array(1), np.array([ox.bwt_string(rev=True).symbol(i) for i in range(n)], dtype=np.uint8))
+    assert np.array_equal(gx.built_array(2, np.uint64), ox.C)
+    sp = ox.sparse()
+    assert np.array_equal(gx.built_array(3, np.uint64), sp["l0"]) and np.array_equal(gx.built_array(4, np.uint16), sp["l1"])
+    assert np.array_equal(gx.built_array(5, np.uint64), sp["bits"])
+    assert np.array_equal(gx.built_array(6, np.uint64), sp["fields"][0]["data"]) and np.array_equal(gx.built_array(7, np.uint64), sp["fields"][1]["data"])
+    want = [int(sp["fields"][f][k]) for f in (0, 1) for k in ("bitCount", "bits", "largestValue", "commonDivisor")]
+    assert gx.built_array(8, np.uint64).tolist() == want
+    rows = np.arange(0, n, max(1, n // 300), dtype=np.uint64)
+    seq, pos, steps = gx.locate(rows)
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(seq, pos, steps)] == [ox.locate(int(r)) for r in rows]
+
+
 def test_gpu_builder_other_alphabets_and_errors():
     for sigma, n in ((28, 2000), (4, 500), (256, 700)):
         seqs = [make_text(n, sigma, seed=sigma), make_text(n // 3, sigma, seed=sigma + 1)]
