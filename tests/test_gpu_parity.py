@@ -191,6 +191,45 @@ def test_exact_search_tables_other_alphabets(layout, sigma):
         gx.accelerate(1, lut_len=32 if sigma > 6 else 33)         # table too large / out of range
 
 
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_exact_search_randomised_layouts_and_tables(seed):
+    """random layout, alphabet, text, table combination and ragged queries (with symbols outside the alphabet and delimiters): cursors and
+    step counts of the exact search equal the CPU walk"""
+    rng = np.random.default_rng(900 + seed)
+    layout = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
+    sigma = int(rng.choice([3, 4, 5, 5, 6, 8, 21, 28]))
+    hi = min(sigma, 9)
+    base = rng.integers(1, hi, size=int(rng.integers(300, 3000)), dtype=np.uint8)
+    seqs = [np.concatenate([base, base[50:250]]), rng.integers(1, sigma, size=int(rng.integers(1, 500)), dtype=np.uint8)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 4, False)
+    gx = gpu_index(ox)
+    R = sigma - 1
+    kstep = int(rng.integers(1, 5))
+    while kstep > 1 and R ** kstep > 255:
+        kstep -= 1
+    lut_len = int(rng.integers(0, 6))
+    while lut_len > 0 and R ** lut_len > (1 << 22):
+        lut_len -= 1
+    gx.accelerate(kstep, lut_len=lut_len, walk=bool(rng.integers(0, 2)))
+    queries = []
+    for i in range(500):
+        s = seqs[i % 2]; m = int(rng.integers(1, min(90, len(s)))); p = int(rng.integers(0, len(s) - m + 1)); q = s[p: p + m].copy()
+        r = int(rng.integers(0, 10))
+        if r == 0: q[int(rng.integers(0, m))] = rng.integers(1, sigma)
+        elif r == 1: q[int(rng.integers(0, m))] = 0
+        elif r == 2: q[int(rng.integers(0, m))] = min(255, sigma + int(rng.integers(0, 3)))
+        queries.append(q)
+    queries.append(np.array([], dtype=np.uint8))
+    qbuf, qoff = fm.flatten(queries)
+    lb, ln, st = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+    valid = [i for i, q in enumerate(queries) if all(c < sigma for c in q)]
+    vb, vo = fm.flatten([queries[i] for i in valid])
+    olb, oln, ost = ox.search_exact(vb, vo, want_steps=True)
+    assert np.array_equal(lb[valid], olb) and np.array_equal(ln[valid], oln), (seed, layout, sigma, kstep, lut_len)
+    invalid = [i for i in range(len(queries)) if i not in set(valid)]
+    assert not ln[invalid].any()                               # a symbol outside the alphabet cannot occur
+
+
 def test_exact_search_tiny_indices():
     for seqs in ([[1]], [[]], [[1], [1], [2, 1]], [[3] * 70]):
         ox = fo.OraIndex.build("IB16", 5, seqs, 1, True)
