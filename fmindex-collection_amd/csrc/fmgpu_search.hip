@@ -1,16 +1,18 @@
 // fmgpu_search.hip — the hot path: one query per lane.
 //
-//  k_exact         search_no_errors::search            (search/SearchNoErrors.h:12-26)
-//  k_scheme        search_ng26::search<Edit=false>     (search/SearchNg26.h:18-433, Hamming reduction: SURVEY.md appendix A)
-//  k_backtracking  search_backtracking::search         (search/Backtracking.h:42-102)
-//  k_locate        FMIndex::locate / BiFMIndex::locate (fmindex/FMIndex.h:113-124)
+//  k_exact_kstep       search_no_errors::search, table-driven: interval table, k-symbol-step table, LF^J walk table (search/SearchNoErrors.h:12-86)
+//  k_exact_a / _w / k_exact   the same without tables: Format A blocks / wavelet lines / any layout
+//  k_scheme_fast       search_ng26::search<Edit=false> on equal-length (or length-bucketed) batches: per-step table, prefix table,
+//                      LF..LF^3 and LF^16 walk tables, searches of a scheme started wave-synchronously (search/SearchNg26.h:18-433)
+//  k_scheme_fast_edit  search_ng26::search<Edit=true>, the same frame with the insertion / deletion branches (:146-218, :286-362)
+//  k_scheme, k_scheme_edit   the general forms (ragged small batches, explicit partitions, every layout): flat state machines
+//  k_backtracking      search_backtracking::search         (search/Backtracking.h:42-102)
+//  k_locate, k_locate_tab    FMIndex::locate / BiFMIndex::locate (fmindex/FMIndex.h:113-124), LF walk or per-row answer table
 //
-// The two DFS kernels are flat state machines: every loop iteration performs exactly one memory phase per lane
-// (the occurrence-table blocks at both interval ends, Occ::all2) followed by register-only control logic, so lanes
-// that sit in different branches of the reference's recursion (extend-all node, exact tail, single-row fast path,
-// resumed sibling) still issue their gathers together.  Pending siblings of a branching node live in a per-lane
-// stack in HBM (one frame per query position at most, lane-interleaved), and are re-derived from the parent
-// cursor when popped; children with an empty interval are never pushed (the reference returns from them at once).
+// The general DFS kernels are flat state machines: every loop iteration performs exactly one memory phase per lane (the occurrence-table
+// blocks at both interval ends, Occ::all2, or one LF-table load for a one-row cursor) followed by register-only control logic.  Pending
+// siblings of a branching node live in a per-lane stack in HBM and are re-derived from the parent cursor when popped; children with an empty
+// interval are never pushed (the reference returns from them at once).  Queries are handed out and hit records written by whole waves.
 #include "fmgpu_common.h"
 
 #include <algorithm>
@@ -140,7 +142,7 @@ struct Counters { unsigned long long hits, nodes, next; };
 
 
 // lane-interleaved frame stack: frame d of lane g at word (d * nlanes + g) of three u64 planes
-struct StackView { uint64_t *p0, *p1, *p2, *p3; uint64_t nlanes; uint32_t depth; uint32_t batch; };   // p3: edit-distance kernel only
+struct StackView { uint64_t *p0, *p1, *p2, *p3; uint64_t nlanes; uint32_t depth; };   // frame planes (the edit-distance kernels use the block as 32-byte records)
 
 struct Cur { idx_t lb, lbRev, len; };
 
@@ -1749,8 +1751,7 @@ struct DfsWorkspace {
         FM_HIP(hipMalloc((void**)&planes, words * 8 * (size_t)nplanes));
         view.p0 = planes; view.p1 = planes + words; view.p2 = planes + 2 * words; view.p3 = nplanes > 3 ? planes + 3 * words : nullptr;
         FM_HIP(hipMalloc((void**)&ctr, sizeof(Counters)));
-        view.batch = nq >= view.nlanes * 8ull ? 4u : 1u;                    // queries per hand-out
-        Counters init{0, 0, view.nlanes * (uint64_t)view.batch};           // next: the first batch of every lane is static
+        Counters init{0, 0, 0};                                             // next: the query hand-out counter of the scheme kernels
         FM_HIP(hipMemcpyAsync(ctr, &init, sizeof(Counters), hipMemcpyHostToDevice, stream));
         FM_HIP(hipStreamSynchronize(stream));
         return 0;
