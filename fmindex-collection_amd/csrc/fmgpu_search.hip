@@ -989,6 +989,25 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
 }
 
+// the 16 query symbols of a stretch as a 32-bit code (2 bits per symbol, the symbol consumed first in the low bits), from the nibble staging:
+// pos = query position of the stretch's first step, right = positions ascend.  valid = all 16 symbols are in 1 .. 4.
+__device__ __forceinline__ uint32_t query_code16(const QStage& qst, uint32_t pos, bool right, bool& valid) {
+    const uint32_t p0 = right ? pos : pos - 15u;                 // lowest query position of the stretch
+    const uint32_t w0 = qst.lds[(p0 >> 3) * 256u + threadIdx.x], w1 = qst.lds[((p0 >> 3) + 1u) * 256u + threadIdx.x];
+    const uint32_t w2 = (p0 & 7u) ? qst.lds[((p0 >> 3) + 2u) * 256u + threadIdx.x] : 0u;
+    const uint32_t sh = 4u * (p0 & 7u);
+    uint64_t x = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh;
+    if (sh) x |= (uint64_t)w2 << (64u - sh);
+    const uint64_t v = x - 0x1111111111111111ull;                // nibbles 1..4 -> 0..3
+    valid = ((v & ~x & 0x8888888888888888ull) == 0ull) && ((v & 0xccccccccccccccccull) == 0ull);
+    uint64_t t = v & 0x3333333333333333ull;
+    t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full; t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
+    t = (t | (t >> 8)) & 0x0000ffff0000ffffull; t = (t | (t >> 16)) & 0x00000000ffffffffull;
+    uint32_t qc = (uint32_t)t;                                   // symbol at position p0 + k in bits 2k
+    if (!right) { qc = __brev(qc); qc = ((qc >> 1) & 0x55555555u) | ((qc & 0x55555555u) << 1); }   // ... at position pos - k
+    return qc;
+}
+
 constexpr uint32_t kHitBuf = 2;      // hits buffered per lane and round in LDS; further hits of the same query are emitted directly
 
 template <int SIGMA, int MAXSIG>
@@ -1106,20 +1125,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                         const uint2 we = wj[a];
                         if (we.x != 0xffffffffu) {
                             walked = true;
-                            const uint32_t pos = ent & 0xffffu;
-                            const uint32_t p0 = right ? pos : pos - 15u;                 // lowest query position of the stretch
-                            const uint32_t w0 = qst.lds[(p0 >> 3) * 256u + threadIdx.x], w1 = qst.lds[((p0 >> 3) + 1u) * 256u + threadIdx.x];
-                            const uint32_t w2 = (p0 & 7u) ? qst.lds[((p0 >> 3) + 2u) * 256u + threadIdx.x] : 0u;
-                            const uint32_t sh = 4u * (p0 & 7u);
-                            uint64_t x = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh;
-                            if (sh) x |= (uint64_t)w2 << (64u - sh);
-                            const uint64_t v = x - 0x1111111111111111ull;                // nibbles 1..4 -> 0..3
-                            const bool qvalid = ((v & ~x & 0x8888888888888888ull) == 0ull) && ((v & 0xccccccccccccccccull) == 0ull);
-                            uint64_t t = v & 0x3333333333333333ull;
-                            t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full; t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
-                            t = (t | (t >> 8)) & 0x0000ffff0000ffffull; t = (t | (t >> 16)) & 0x00000000ffffffffull;
-                            uint32_t qc = (uint32_t)t;                                   // symbol at position p0 + k in bits 2k
-                            if (!right) { qc = __brev(qc); qc = ((qc >> 1) & 0x55555555u) | ((qc & 0x55555555u) << 1); }   // ... at position pos - k
+                            bool qvalid = false;
+                            const uint32_t qc = query_code16(qst, ent & 0xffffu, right, qvalid);
                             const uint32_t sw = s_stretch[si * stride + j];
                             const uint32_t tb = sw & 31u, hi1 = (sw >> 5) & 63u, hi2 = (sw >> 11) & 63u, lo = (sw >> 17) & 31u;
                             if (qvalid && qc == we.y && ((sw >> 22) & 1u) && lo <= e && e <= hi1) {
