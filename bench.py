@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-search-accel", action="store_true", help="k2: no prefix / walk tables (fmgpu_index_accelerate_search)")
     ap.add_argument("--no-exact-tables", action="store_true", help="exact / protein: only the k-step table (no suffix-interval table, no walk table)")
     ap.add_argument("--lut-len", type=int, default=0, help="exact / protein: symbols of the interval table (0 = 15 bp / 6 aa)")
+    ap.add_argument("--walk", type=int, default=2, help="exact / protein: 1 = LF^J walk table, 2 = LF^J and LF^2J")
     ap.add_argument("--prefix-len", type=int, default=15, help="k2: symbols of the prefix table (fmgpu_index_accelerate_search)")
     ap.add_argument("--trim", type=int, default=0, help="dev: every read loses 0..TRIM symbols at its end (a ragged batch)")
     ap.add_argument("--edit", action="store_true", help="k2: edit distance (search_ng26<Edit = true>) instead of Hamming distance")
@@ -157,7 +158,7 @@ def main():
         if args.no_exact_tables:
             index.accelerate(args.kstep)
         else:                                                   # + interval table of the last 15 bp / 6 aa, + per-row LF^J walk table (J = 16 bp / 6 aa)
-            index.accelerate(args.kstep, lut_len=args.lut_len or (6 if protein else 15), walk=True)
+            index.accelerate(args.kstep, lut_len=args.lut_len or (6 if protein else 15), walk=args.walk)
     if bidir and not args.no_search_accel:
         index.accelerate_search(args.prefix_len, 3)
     build_s = time.time() - t0
@@ -301,7 +302,7 @@ def main():
                    "sigma": sigma, "layout": "Wavelet" if protein else "InterleavedBitvector16", "queries_per_gpu": nq, "read_len": L,
                    "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale, "prefix_table_symbols": (args.prefix_len if bidir and not args.no_search_accel else None), "kstep_table": (args.kstep if not bidir else 1),
                    "device_table": ("block table expanded from the wavelet" if args.kstep else "wavelet lines") if protein else "block table",
-                   "exact_tables": None if (bidir or args.no_exact_tables or (protein and not args.kstep)) else {"suffix_interval_symbols": args.lut_len or (6 if protein else 15), "walk_symbols_per_load": 6 if protein else 16},
+                   "exact_tables": None if (bidir or args.no_exact_tables or (protein and not args.kstep)) else {"suffix_interval_symbols": args.lut_len or (6 if protein else 15), "walk_symbols_per_load": (6 if protein else 16) * (2 if args.walk >= 2 else 1)},
                    "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
         "gbp_per_s": qps * L / 1e9,
         "hits": hits,

@@ -205,7 +205,7 @@ class FMIndex:
     def accelerate(self, kstep=3, lut_len=0, walk=False):
         """add (kstep >= 2) or drop (0) the multi-symbol-step table used by exact search; lut_len > 0 adds the table of the
         intervals of all strings of that many symbols, walk=True the per-row LF^J + symbols table; results are unchanged"""
-        capi.check(capi.lib().fmgpu_index_accelerate_exact(self._h, kstep, lut_len, 1 if walk else 0))
+        capi.check(capi.lib().fmgpu_index_accelerate_exact(self._h, kstep, lut_len, int(walk)))      # walk: False / True (LF^J) / 2 (LF^J and LF^2J)
         n, sigma, layout, bidir, dbytes = C.c_uint64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()
         capi.check(capi.lib().fmgpu_index_info(self._h, C.byref(n), C.byref(sigma), C.byref(layout), C.byref(bidir), C.byref(dbytes)))
         self.device_bytes = dbytes.value

@@ -367,6 +367,8 @@ struct DevString {
     //   walkj[row] = {LF^J(row), sum (s_t - 1) << (walk_bits * t)} with s_1.. the symbols met (s_0 = BWT symbol of row), or {~0, 0} if a delimiter is met
     uint2* slut = nullptr; uint32_t slut_len = 0; uint64_t slut_entries = 0;
     uint2* walkj = nullptr; uint32_t walk_J = 0, walk_bits = 0;
+    //   walk2j[3*row ..] = {LF^(2J)(row), code of symbols 0 .. J-1, code of symbols J .. 2J-1} (walk = 2 in fmgpu_index_accelerate_exact), or {~0, 0, 0}
+    uint32_t* walk2j = nullptr;
     // Format A shadow of a Format R / W string (fmgpu_index_accelerate, kstep >= 1): the searches then read `va` (one line per
     // LF step instead of bitct lines); fmgpu_string_query keeps answering from the native format.
     void* shadow = nullptr; size_t shadow_bytes = 0;

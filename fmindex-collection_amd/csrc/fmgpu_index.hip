@@ -280,6 +280,8 @@ void free_string(DevString& s) {
     s.shadow = nullptr; s.shadow_bytes = 0;
     if (s.slut) (void)hipFree(s.slut);
     if (s.walkj) (void)hipFree(s.walkj);
+    if (s.walk2j) (void)hipFree(s.walk2j);
+    s.walk2j = nullptr;
     s.slut = nullptr; s.walkj = nullptr; s.slut_len = 0; s.slut_entries = 0; s.walk_J = 0;
     s.blk = s.aux = nullptr; s.lf_table = nullptr; s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0; s.walk3 = nullptr;
 }
@@ -510,6 +512,15 @@ __global__ __launch_bounds__(256) void k_walkj(const idx_t* __restrict__ lf, con
     }
     out[i] = ok ? make_uint2(r, code) : make_uint2(0xffffffffu, 0u);
 }
+// 2J steps = two J-step entries chained
+__global__ __launch_bounds__(256) void k_walk2j(const uint2* __restrict__ wj, uint64_t n, uint32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 a = wj[i];
+    uint32_t r = 0xffffffffu, c0 = 0, c1 = 0;
+    if (a.x != 0xffffffffu) { const uint2 b = wj[a.x]; if (b.x != 0xffffffffu) { r = b.x; c0 = a.y; c1 = b.y; } }
+    out[3 * i] = r; out[3 * i + 1] = c0; out[3 * i + 2] = c1;
+}
 // bidirectional interval of every string w of L symbols in [1, sigma): extendRight symbol by symbol (fmindex/BiFMIndexCursor.h:121-128)
 template <class Occ>
 __global__ __launch_bounds__(256) void k_prefix_lut(Occ rv, uint64_t entries, uint32_t L, uint32_t R, idx_t n, uint4* __restrict__ lut) {
@@ -716,6 +727,7 @@ int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len
     const uint64_t n = s.n;
     if (s.slut) { (void)hipFree(s.slut); x->device_bytes -= s.slut_entries * 8; s.slut = nullptr; s.slut_len = 0; s.slut_entries = 0; }
     if (s.walkj) { (void)hipFree(s.walkj); x->device_bytes -= n * 8; s.walkj = nullptr; s.walk_J = 0; }
+    if (s.walk2j) { (void)hipFree(s.walk2j); x->device_bytes -= n * 12; s.walk2j = nullptr; }
     if (n == 0) return 0;
     const uint32_t sigma = (uint32_t)s.sigma, R = sigma - 1;
     if (lut_len > 0) {
@@ -745,6 +757,12 @@ int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len
         FM_HIP(hipDeviceSynchronize());
         s.walk_J = J; s.walk_bits = bits;
         x->device_bytes += n * 8;
+        if (walk >= 2) {
+            FM_HIP(hipMalloc((void**)&s.walk2j, n * 12 + 16));
+            k_walk2j<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s.walkj, n, s.walk2j);
+            FM_HIP(hipDeviceSynchronize());
+            x->device_bytes += n * 12;
+        }
     }
     return 0;
 }

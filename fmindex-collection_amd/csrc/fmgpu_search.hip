@@ -902,6 +902,7 @@ struct ExactAccel {
     const uint8_t* kblk; uint32_t K, ncodes;        // k-symbol-step table (or null)
     const uint2* slut; uint32_t lutL;               // interval of the query's last lutL symbols (or null)
     const uint2* walk; uint32_t J, wbits;           // per row LF^J + the J symbols met (or null)
+    const uint32_t* walk2;                          // per row LF^(2J) + the 2J symbols met as two codes (or null)
 };
 
 template <class Occ>
@@ -942,6 +943,16 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
         // context table.  A step that would empty the interval (or meets an odd symbol) ends the phase WITHOUT touching the cursor:
         // its single-step walk is left to the tail phase, where the lanes of the wave are convergent again.
         for (;;) {
+            if (ac.walk2 && len == 1 && m - done >= 2u * ac.J) {  // 2J symbols with one 12-byte load
+                bool v0 = false, v1 = false;
+                const uint32_t q0 = code_of(done, ac.J, ac.wbits, v0), q1 = code_of(done + ac.J, ac.J, ac.wbits, v1);
+                if (!(v0 && v1)) break;
+                const uint32_t* p = ac.walk2 + 3u * (size_t)lb;
+                const uint32_t r = p[0], c0 = p[1], c1 = p[2];
+                if (r == 0xffffffffu || c0 != q0 || c1 != q1) break;
+                lb = r; done += 2u * ac.J; steps += 2u * ac.J;
+                continue;
+            }
             if (ac.walk && len == 1 && m - done >= ac.J) {
                 bool v = false;
                 const uint32_t qc = code_of(done, ac.J, ac.wbits, v);
@@ -1807,7 +1818,7 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     }
     if (accel) {
         const DevString& bs = x->bwt;
-        ExactAccel ac{bs.kblk, bs.kstep, bs.kcodes, bs.slut, bs.slut_len, bs.walkj, bs.walk_J, bs.walk_bits};
+        ExactAccel ac{bs.kblk, bs.kstep, bs.kcodes, bs.slut, bs.slut_len, bs.walkj, bs.walk_J, bs.walk_bits, bs.walk2j};
         rc = dispatch_occ(bs, [&](auto occ, auto) {
             k_exact_kstep<decltype(occ)><<<grid, block, (size_t)kq_words * 1024, stream>>>(occ, ac, (uint32_t)bs.sigma - 1,
                                                                     (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev,

@@ -155,7 +155,8 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep);   /* (all fmgpu_inde
  *   lut_len > 0: the interval of every string of `lut_len` symbols ((sigma-1)^lut_len entries of 8 bytes; DNA, 12 symbols: 134 MB) — a query
  *                starts from the entry of its last lut_len symbols instead of lut_len wide-interval steps;
  *   walk != 0:   per row LF^J and the J symbols met on the way, J = 32 / bit_width(sigma-2) (DNA: 16 symbols, protein: 6; 8 bytes per row):
- *                once the interval is one row, J query symbols are checked and consumed with one load. */
+ *                once the interval is one row, J query symbols are checked and consumed with one load;
+ *   walk >= 2:   additionally LF^(2J) and the 2J symbols (12 bytes per row): 32 bp / 12 aa per load while that many symbols remain. */
 int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk);
 
 /* Optional accelerators for fmgpu_search_scheme on a BiFMIndex (results unchanged):

@@ -156,7 +156,7 @@ def test_exact_search_with_kstep_accelerator(layout, sigma, kstep):
     olb, oln, ost = ox.search_exact(vb, vo, want_steps=True)
     assert np.array_equal(lb[valid], olb) and np.array_equal(ln[valid], oln)
     assert ln[-1] == 0
-    for lut_len, walk, ks in ((4, False, kstep), (0, True, kstep), (5, True, kstep), (3, True, 1), (2, False, 1)):   # suffix table / walk table, with and without the k-step table
+    for lut_len, walk, ks in ((4, False, kstep), (0, True, kstep), (5, True, kstep), (3, True, 1), (2, False, 1), (4, 2, kstep), (0, 2, 1)):   # suffix table / walk table, with and without the k-step table
         gx.accelerate(ks, lut_len=lut_len, walk=walk)
         lb3, ln3, st3 = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
         assert np.array_equal(lb3, lb) and np.array_equal(ln3, ln) and st3.lf_steps == st.lf_steps, (lut_len, walk, ks)
@@ -183,7 +183,7 @@ def test_exact_search_tables_other_alphabets(layout, sigma):
     queries += [[], [0], [sigma - 1] * 5]
     qbuf, qoff = fm.flatten(queries)
     olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
-    for kstep, lut_len, walk in ((1, 2, True), (1, 0, True), (1, 1, False), (2 if sigma <= 6 else 1, 2, True)):
+    for kstep, lut_len, walk in ((1, 2, True), (1, 0, True), (1, 1, False), (2 if sigma <= 6 else 1, 2, True), (1, 1, 2)):
         gx.accelerate(kstep, lut_len=lut_len, walk=walk)
         lb, ln, st = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
         assert np.array_equal(lb, olb) and np.array_equal(ln, oln) and st.lf_steps == int(ost.sum()), (kstep, lut_len, walk)
@@ -210,7 +210,7 @@ def test_exact_search_randomised_layouts_and_tables(seed):
     lut_len = int(rng.integers(0, 6))
     while lut_len > 0 and R ** lut_len > (1 << 22):
         lut_len -= 1
-    gx.accelerate(kstep, lut_len=lut_len, walk=bool(rng.integers(0, 2)))
+    gx.accelerate(kstep, lut_len=lut_len, walk=int(rng.integers(0, 3)))
     queries = []
     for i in range(500):
         s = seqs[i % 2]; m = int(rng.integers(1, min(90, len(s)))); p = int(rng.integers(0, len(s) - m + 1)); q = s[p: p + m].copy()
@@ -933,7 +933,7 @@ def test_full_size_properties():
     miss_lb = lbv.clone()                                      # cursor of the step that emptied the interval: part of the result
     # ---- the optional tables do not change a single cursor at this size (rows close to 2^32 exercise the 32-bit row arithmetic)
     reads[:, 50] = (reads[:, 50] + 2) % 4 + 1                  # undo the substitution ((x % 4 + 1) is a 4-cycle: three more steps)
-    for tables in ((3, 0, False), (3, 12, True), (1, 10, True)):
+    for tables in ((3, 0, False), (3, 12, True), (1, 10, True), (3, 15, 2)):
         gx.accelerate(tables[0], lut_len=tables[1], walk=tables[2])
         fm.search_no_errors.search(gx, (V(reads), V(qoff)), out=(V(lbv), V(lnv)))
         torch.cuda.synchronize()
