@@ -301,6 +301,16 @@ __device__ __forceinline__ uint32_t symbol_of_lf_lds(const idx_t* sC, uint32_t s
     return lo;
 }
 
+// eight query bytes -> eight nibbles (a byte >= sigma, sigma <= 15, becomes 15 = "not a symbol"), with word operations
+__device__ __forceinline__ uint32_t pack_nibbles8(uint64_t x, uint32_t sigma) {
+    const uint64_t k1 = 0x0101010101010101ull;
+    const uint64_t t = (((x & (0x7full * k1)) + (uint64_t)(0x80u - sigma) * k1) | x) & (0x80ull * k1);   // bit 7 of a byte set <=> byte >= sigma
+    uint64_t y = (x | ((t >> 7) * 0xffull)) & (0x0full * k1);
+    y = (y | (y >> 4)) & 0x00ff00ff00ff00ffull;
+    y = (y | (y >> 8)) & 0x0000ffff0000ffffull;
+    y = (y | (y >> 16)) & 0x00000000ffffffffull;
+    return (uint32_t)y;
+}
 // ---- per-lane query staging in LDS ------------------------------------------------------------------------------
 // A DFS visits a few hundred nodes per query; reading the query symbol of every node from global memory costs a
 // second random line per node (half a million lanes' query lines do not survive in L2).  Each lane therefore copies
@@ -325,10 +335,7 @@ __device__ __forceinline__ void qstage_load(const QStage& st, const uint8_t* qbu
         uint64_t x = mis ? ((lo >> (8u * mis)) | (hi << (64u - 8u * mis))) : lo;   // query bytes 8k .. 8k+7
         lo = hi;
         if (st.nib) {
-            uint32_t w = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 8; ++j) { uint32_t b = (uint32_t)(x >> (8u * j)) & 0xffu; w |= (b >= sigma || b > 14u ? 15u : b) << (4u * j); }
-            st.lds[wi * 256u + threadIdx.x] = w; ++wi;
+            st.lds[wi * 256u + threadIdx.x] = pack_nibbles8(x, sigma); ++wi;
         } else {
             st.lds[wi * 256u + threadIdx.x] = (uint32_t)x; ++wi;
             if ((k * 8u + 4u) < m) { st.lds[wi * 256u + threadIdx.x] = (uint32_t)(x >> 32); ++wi; }
@@ -878,10 +885,7 @@ __device__ __forceinline__ void qstage_load_sync(const QStage& st, const uint8_t
             const uint32_t p0 = (widx - 1u) * 8u;                   // first query position in x
             if (active && p0 < m) {
                 if (st.nib) {
-                    uint32_t w = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) { uint32_t bb = (uint32_t)(x >> (8u * j)) & 0xffu; w |= (bb >= sigma || bb > 14u ? 15u : bb) << (4u * j); }
-                    st.lds[wi * 256u + threadIdx.x] = w; ++wi;
+                    st.lds[wi * 256u + threadIdx.x] = pack_nibbles8(x, sigma); ++wi;
                 } else {
                     st.lds[wi * 256u + threadIdx.x] = (uint32_t)x; ++wi;
                     if (p0 + 4u < m) { st.lds[wi * 256u + threadIdx.x] = (uint32_t)(x >> 32); ++wi; }
@@ -898,6 +902,25 @@ __device__ __forceinline__ void qstage_load_sync(const QStage& st, const uint8_t
 // and step count are exactly those of search/SearchNoErrors.h:12-26.  The query is staged in LDS up front (one query per
 // lane: the staging is wave-synchronous by construction); the next chunk's context code is fetched from LDS while the
 // table entries of the current chunk are in flight, and both interval ends are loaded together.
+// the 16 query symbols of a stretch as a 32-bit code (2 bits per symbol, the symbol consumed first in the low bits), from the nibble staging:
+// pos = query position of the stretch's first step, right = positions ascend.  valid = all 16 symbols are in 1 .. 4.
+__device__ __forceinline__ uint32_t query_code16(const QStage& qst, uint32_t pos, bool right, bool& valid) {
+    const uint32_t p0 = right ? pos : pos - 15u;                 // lowest query position of the stretch
+    const uint32_t w0 = qst.lds[(p0 >> 3) * 256u + threadIdx.x], w1 = qst.lds[((p0 >> 3) + 1u) * 256u + threadIdx.x];
+    const uint32_t w2 = (p0 & 7u) ? qst.lds[((p0 >> 3) + 2u) * 256u + threadIdx.x] : 0u;
+    const uint32_t sh = 4u * (p0 & 7u);
+    uint64_t x = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh;
+    if (sh) x |= (uint64_t)w2 << (64u - sh);
+    const uint64_t v = x - 0x1111111111111111ull;                // nibbles 1..4 -> 0..3
+    valid = ((v & ~x & 0x8888888888888888ull) == 0ull) && ((v & 0xccccccccccccccccull) == 0ull);
+    uint64_t t = v & 0x3333333333333333ull;
+    t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full; t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
+    t = (t | (t >> 8)) & 0x0000ffff0000ffffull; t = (t | (t >> 16)) & 0x00000000ffffffffull;
+    uint32_t qc = (uint32_t)t;                                   // symbol at position p0 + k in bits 2k
+    if (!right) { qc = __brev(qc); qc = ((qc >> 1) & 0x55555555u) | ((qc & 0x55555555u) << 1); }   // ... at position pos - k
+    return qc;
+}
+
 struct ExactAccel {
     const uint8_t* kblk; uint32_t K, ncodes;        // k-symbol-step table (or null)
     const uint2* slut; uint32_t lutL;               // interval of the query's last lutL symbols (or null)
@@ -936,16 +959,23 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
         };
         if (ac.slut && n > 1) {                                  // the last lutL symbols at once; an empty entry is walked step by step instead
             bool v = false;                                      // (the reference's cursor and step count at the failing step are part of the result)
-            const uint32_t code = code_of(0, ac.lutL, 0, v);
+            uint32_t code;
+            if (qst.words && qst.nib && R == 4u && ac.lutL <= 16u && m >= 16u) {       // radix 4 = 2 bits per symbol: the word-level code, cut to lutL symbols
+                code = query_code16(qst, m - 1u, false, v);
+                if (ac.lutL < 16u) code &= (1u << (2u * ac.lutL)) - 1u;
+                if (!v) code = code_of(0, ac.lutL, 0, v);       // (an odd symbol among the 16: decide on the lutL symbols alone)
+            } else code = code_of(0, ac.lutL, 0, v);
             if (v) { const uint2 en = ac.slut[code]; if (en.y != 0) { lb = en.x; len = en.y; done = ac.lutL; steps = ac.lutL; } }
         }
         // main phase: one table load per iteration.  One row left: J symbols per load from the walk table; otherwise K symbols from the
         // context table.  A step that would empty the interval (or meets an odd symbol) ends the phase WITHOUT touching the cursor:
         // its single-step walk is left to the tail phase, where the lanes of the wave are convergent again.
         for (;;) {
+            const bool nib16 = qst.words && qst.nib && ac.wbits == 2u && ac.J == 16u;     // DNA: 16 staged nibbles -> one 32-bit code with a few word operations
             if (ac.walk2 && len == 1 && m - done >= 2u * ac.J) {  // 2J symbols with one 12-byte load
                 bool v0 = false, v1 = false;
-                const uint32_t q0 = code_of(done, ac.J, ac.wbits, v0), q1 = code_of(done + ac.J, ac.J, ac.wbits, v1);
+                const uint32_t q0 = nib16 ? query_code16(qst, m - 1u - done, false, v0) : code_of(done, ac.J, ac.wbits, v0);
+                const uint32_t q1 = nib16 ? query_code16(qst, m - 17u - done, false, v1) : code_of(done + ac.J, ac.J, ac.wbits, v1);
                 if (!(v0 && v1)) break;
                 const uint32_t* p = ac.walk2 + 3u * (size_t)lb;
                 const uint32_t r = p[0], c0 = p[1], c1 = p[2];
@@ -955,7 +985,7 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
             }
             if (ac.walk && len == 1 && m - done >= ac.J) {
                 bool v = false;
-                const uint32_t qc = code_of(done, ac.J, ac.wbits, v);
+                const uint32_t qc = nib16 ? query_code16(qst, m - 1u - done, false, v) : code_of(done, ac.J, ac.wbits, v);
                 if (!v) break;
                 const uint2 en = ac.walk[lb];
                 if (en.x == 0xffffffffu || en.y != qc) break;
@@ -998,25 +1028,6 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
     }
     uint32_t tot = wave_sum(steps);
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
-}
-
-// the 16 query symbols of a stretch as a 32-bit code (2 bits per symbol, the symbol consumed first in the low bits), from the nibble staging:
-// pos = query position of the stretch's first step, right = positions ascend.  valid = all 16 symbols are in 1 .. 4.
-__device__ __forceinline__ uint32_t query_code16(const QStage& qst, uint32_t pos, bool right, bool& valid) {
-    const uint32_t p0 = right ? pos : pos - 15u;                 // lowest query position of the stretch
-    const uint32_t w0 = qst.lds[(p0 >> 3) * 256u + threadIdx.x], w1 = qst.lds[((p0 >> 3) + 1u) * 256u + threadIdx.x];
-    const uint32_t w2 = (p0 & 7u) ? qst.lds[((p0 >> 3) + 2u) * 256u + threadIdx.x] : 0u;
-    const uint32_t sh = 4u * (p0 & 7u);
-    uint64_t x = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh;
-    if (sh) x |= (uint64_t)w2 << (64u - sh);
-    const uint64_t v = x - 0x1111111111111111ull;                // nibbles 1..4 -> 0..3
-    valid = ((v & ~x & 0x8888888888888888ull) == 0ull) && ((v & 0xccccccccccccccccull) == 0ull);
-    uint64_t t = v & 0x3333333333333333ull;
-    t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full; t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
-    t = (t | (t >> 8)) & 0x0000ffff0000ffffull; t = (t | (t >> 16)) & 0x00000000ffffffffull;
-    uint32_t qc = (uint32_t)t;                                   // symbol at position p0 + k in bits 2k
-    if (!right) { qc = __brev(qc); qc = ((qc >> 1) & 0x55555555u) | ((qc & 0x55555555u) << 1); }   // ... at position pos - k
-    return qc;
 }
 
 constexpr uint32_t kHitBuf = 2;      // hits buffered per lane and round in LDS; further hits of the same query are emitted directly
