@@ -282,10 +282,10 @@ def _run_hits(call, capacity):
             capacity = int(cnt.value)
             continue
         capi.check(rc)
-        hits = out[: cnt.value]
-        # the reference invokes the delegate in ascending qidx, inside a query in DFS order: (qidx, seq) restores it
-        order = np.lexsort((hits["seq"], hits["qidx"]))
-        return hits[order], st
+        hits = np.ascontiguousarray(out[: cnt.value])
+        # the reference invokes the delegate in ascending qidx, inside a query in DFS order: (qidx, seq) restores it (sorted on the device)
+        capi.check(capi.lib().fmgpu_hits_sort(capi.ptr(hits), hits.size, None))
+        return hits, st
 
 
 class search_backtracking:

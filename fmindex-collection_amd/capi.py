@@ -89,7 +89,7 @@ EXPORTS = [
     "fmgpu_search_exact", "fmgpu_search_scheme", "fmgpu_search_backtracking", "fmgpu_locate",
     "fmgpu_malloc", "fmgpu_free", "fmgpu_memcpy_h2d", "fmgpu_memcpy_d2h", "fmgpu_synchronize",
     "fmgpu_build_index", "fmgpu_built_free", "fmgpu_built_get", "fmgpu_index_accelerate", "fmgpu_index_accelerate_search",
-    "fmgpu_index_accelerate_exact", "fmgpu_index_accelerate_locate",
+    "fmgpu_index_accelerate_exact", "fmgpu_index_accelerate_locate", "fmgpu_hits_sort",
 ]
 
 _lib = None
@@ -120,6 +120,8 @@ def lib():
                                C.POINTER(Stats), C.c_void_p]
     if hasattr(L, "fmgpu_index_accelerate"):
         L.fmgpu_index_accelerate.argtypes = [C.c_void_p, C.c_int32]
+    if hasattr(L, "fmgpu_hits_sort"):
+        L.fmgpu_hits_sort.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     if hasattr(L, "fmgpu_index_accelerate_locate"):
         L.fmgpu_index_accelerate_locate.argtypes = [C.c_void_p, C.c_int32]
     if hasattr(L, "fmgpu_index_accelerate_exact"):

@@ -2187,4 +2187,60 @@ int fmgpu_index_accelerate_locate(fmgpu_index_t h, int32_t enable) {
     return 0;
 }
 
+// ---- hit records in the reference's callback order -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hit_keys(const fmgpu_hit* __restrict__ h, uint64_t count, uint64_t* __restrict__ key_q, uint32_t* __restrict__ key_s,
+                                                  uint32_t* __restrict__ idx) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) { key_q[t] = h[t].qidx; key_s[t] = h[t].seq; idx[t] = (uint32_t)t; }
+}
+__global__ __launch_bounds__(256) void k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ perm, uint64_t count, uint64_t* __restrict__ dst) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) dst[t] = src[perm[t]];
+}
+__global__ __launch_bounds__(256) void k_gather_hits(const fmgpu_hit* __restrict__ src, const uint32_t* __restrict__ perm, uint64_t count, fmgpu_hit* __restrict__ dst) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) dst[t] = src[perm[t]];
+}
+
+int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream_) {
+    if (count <= 1) return 0;
+    if (!hits) return fail(FMGPU_ERR_INVALID, "hits is null");
+    if (count >= 0x7fffffffull) return fail(FMGPU_ERR_UNSUPPORTED, "more than 2^31 - 1 records");
+    hipStream_t stream = (hipStream_t)stream_;
+    Staged sh;
+    int rc = sh.out(hits, count * sizeof(fmgpu_hit), stream); if (rc) return rc;            // in and out: host records are copied in first
+    if (sh.writeback) FM_HIP(hipMemcpyAsync(sh.dev, hits, count * sizeof(fmgpu_hit), hipMemcpyHostToDevice, stream));
+    // stable LSD order: by seq first, then by qidx
+    uint64_t *kq = nullptr, *kq2 = nullptr; uint32_t *ks = nullptr, *ks2 = nullptr, *ix = nullptr, *ix2 = nullptr; fmgpu_hit* tmp_h = nullptr; void* tmp = nullptr;
+    auto drop = [&] { for (void* p : {(void*)kq, (void*)kq2, (void*)ks, (void*)ks2, (void*)ix, (void*)ix2, (void*)tmp_h, tmp}) if (p) (void)hipFree(p); };
+    hipError_t e = hipMalloc((void**)&kq, count * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&kq2, count * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&ks, count * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ks2, count * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix, count * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix2, count * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&tmp_h, count * sizeof(fmgpu_hit));
+    size_t b1 = 0, b2 = 0;
+    if (e == hipSuccess) {
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b1, ks, ks2, ix, ix2, (int)count, 0, 32, stream);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b2, kq, kq2, ix2, ix, (int)count, 0, 64, stream);
+        e = hipMalloc(&tmp, std::max(b1, b2));
+    }
+    if (e != hipSuccess) { drop(); return hip_fail(e, "hipMalloc(hit sort)"); }
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    const fmgpu_hit* dh = (const fmgpu_hit*)sh.dev;
+    k_hit_keys<<<grid, block, 0, stream>>>(dh, count, kq, ks, ix);
+    size_t tb = std::max(b1, b2);
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, ks, ks2, ix, ix2, (int)count, 0, 32, stream);          // ix2: order by seq
+    k_gather_u64<<<grid, block, 0, stream>>>(kq, ix2, count, kq2);                                         // qidx in that order
+    tb = std::max(b1, b2);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, kq2, kq, ix2, ix, (int)count, 0, 64, stream);   // stable by qidx: ix = final order
+    k_gather_hits<<<grid, block, 0, stream>>>(dh, ix, count, tmp_h);
+    if (e == hipSuccess) e = hipMemcpyAsync(sh.dev, tmp_h, count * sizeof(fmgpu_hit), hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    drop();
+    if (e != hipSuccess) return hip_fail(e, "hit sort");
+    return sh.finish();
+}
+
 }  // extern "C"

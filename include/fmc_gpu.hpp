@@ -313,7 +313,7 @@ inline auto h2(size_t N, size_t minK, size_t K) -> Scheme {   // generator/h2.h:
 namespace detail {
 template <typename Index, typename Delegate>
 void report(Index const& index, std::vector<fmgpu_hit>& hits, Delegate&& delegate) {
-    std::sort(hits.begin(), hits.end(), [](fmgpu_hit const& a, fmgpu_hit const& b) { return std::tie(a.qidx, a.seq) < std::tie(b.qidx, b.seq); });
+    check(fmgpu_hits_sort(hits.data(), hits.size(), nullptr));    // (qidx, seq): the reference's callback order, sorted on the device
     using cursor_t = select_cursor_t<Index>;
     for (auto const& h : hits) {
         cursor_t cur{};

@@ -198,6 +198,11 @@ int fmgpu_search_backtracking(fmgpu_index_t h, const uint8_t* qbuf, const uint64
 int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count,
                  uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps, fmgpu_stats* stats, void* stream);
 
+/* Puts `count` hit records (host or device memory) into the reference's callback order — ascending qidx, inside a query the order the
+ * delegate is called in (search/SearchNg26.h:385-390; fmgpu_hit::seq) — with a stable device radix sort.  The search kernels emit records
+ * in no particular order. */
+int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream);
+
 /* GPU index construction from sequences — replaces FMIndex(Sequences, samplingRate, threads) (fmindex/FMIndex.h:58-104) and
  * BiFMIndex(Sequences, samplingRate, threads) (fmindex/BiFMIndex.h:107-167), i.e. libsais (utils.h:97-129) + the String /
  * SparseArray constructors.  Sequence i = seqs[seq_off[i] .. seq_off[i+1]); a 0 delimiter follows every sequence
