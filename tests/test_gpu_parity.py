@@ -191,7 +191,7 @@ def test_exact_search_tables_other_alphabets(layout, sigma):
         gx.accelerate(1, lut_len=32 if sigma > 6 else 33)         # table too large / out of range
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(24)) + [462, 772])
 def test_exact_search_randomised_layouts_and_tables(seed):
     """random layout, alphabet, text, table combination and ragged queries (with symbols outside the alphabet and delimiters): cursors and
     step counts of the exact search equal the CPU walk"""
@@ -202,6 +202,12 @@ def test_exact_search_randomised_layouts_and_tables(seed):
     base = rng.integers(1, hi, size=int(rng.integers(300, 3000)), dtype=np.uint8)
     seqs = [np.concatenate([base, base[50:250]]), rng.integers(1, sigma, size=int(rng.integers(1, 500)), dtype=np.uint8)]
     ox = fo.OraIndex.build(layout, sigma, seqs, 4, False)
+    if int(ox.C[-1]) != ox.n:
+        # the reference's own defect: rank(n, c) double-counts when n is a multiple of the super-block period of InterleavedEPR* / EPRV3_*
+        # (DESIGN.md §2), and computeC (utils.h:199-206) reads exactly that — such a reference index has a corrupt C; it is refused
+        with pytest.raises(fm.FmgpuError):
+            gpu_index(ox)
+        return
     gx = gpu_index(ox)
     R = sigma - 1
     kstep = int(rng.integers(1, 5))
@@ -213,7 +219,7 @@ def test_exact_search_randomised_layouts_and_tables(seed):
     gx.accelerate(kstep, lut_len=lut_len, walk=int(rng.integers(0, 3)))
     queries = []
     for i in range(500):
-        s = seqs[i % 2]; m = int(rng.integers(1, min(90, len(s)))); p = int(rng.integers(0, len(s) - m + 1)); q = s[p: p + m].copy()
+        s = seqs[i % 2]; m = int(rng.integers(1, max(2, min(90, len(s))))); p = int(rng.integers(0, len(s) - m + 1)); q = s[p: p + m].copy()
         r = int(rng.integers(0, 10))
         if r == 0: q[int(rng.integers(0, m))] = rng.integers(1, sigma)
         elif r == 1: q[int(rng.integers(0, m))] = 0
