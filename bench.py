@@ -158,7 +158,7 @@ def main():
     index = cls.from_sequences((_Dev(text), _Dev(seq_off)), sigma, layout, 16, keep_host=want_cpu)
     if args.kstep < 0:
         args.kstep = 1 if protein else 3
-    if not bidir and (args.kstep > 1 or (protein and args.kstep == 1)):
+    if not bidir and args.kstep >= 1 and (not args.no_exact_tables or args.kstep > 1 or protein):
         if args.no_exact_tables:
             index.accelerate(args.kstep)
         else:                                                   # + interval table of the last 15 bp / 6 aa, + per-row LF^J walk table (J = 16 bp / 6 aa)
@@ -311,7 +311,7 @@ def main():
         "gbp_per_s": qps * L / 1e9,
         "hits": hits,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": (("k_exact_a" if args.no_exact_tables else "k_exact_kstep") if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if args.kstep > 1 else "k_exact_a") if not bidir else ("k_scheme_fast_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
+                     "traffic": traffic, "kernel": (("k_exact_a" if args.no_exact_tables else "k_exact_kstep") if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if (args.kstep > 1 or not args.no_exact_tables) else "k_exact_a") if not bidir else ("k_scheme_fast_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
                      "units_per_launch": steps_per_launch, "bytes_per_unit": unit_bytes,
                      "unit": "GB/s", "note": NOTE_PROTEIN if protein else NOTE_DNA},
     }
