@@ -15,7 +15,7 @@ batch (weak scaling: per-GPU work fixed), and the resulting SA intervals are gat
 the timed region — the path's only exchange step.  Result buffers are double-buffered so that the gather of step i
 crosses xGMI while the kernel of step i+1 runs; the last gather is drained before the closing barrier.
 
-At N = 1 the default run appends `secondary`: the k = 2 workload measured in a child process after the exact index has been released
+At N = 1 the default run appends `secondary`: the k = 2 workload measured in a child process before this one touches the GPU
 (BASELINE.json's metric names exact AND k = 2; `value` stays the exact figure).
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (executed LF steps x
@@ -78,6 +78,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    secondary = None
+    if world == 1 and args.workload == "exact" and not args.no_secondary and args.scale == 1.0 and args.nq == 10_000_000 and args.trim == 0:
+        # the metric's second half — k = 2 Hamming on the same text — in a child process of its own, BEFORE this process touches the GPU (the two
+        # indices do not fit the HBM together, and a GPU-initialised process must not start other programs); never part of `value`
+        import subprocess
+        try:
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "k2", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                    "--no-cpu-baseline"] + (["--read-len", str(args.read_len)] if args.read_len else []),
+                                   capture_output=True, text=True, timeout=600)
+            line = [l for l in child.stdout.splitlines() if l.startswith("{")]
+            if child.returncode == 0 and line:
+                k2 = json.loads(line[-1])
+                secondary = {k: k2[k] for k in ("metric", "value", "unit", "ms_per_step", "gbp_per_s", "hits", "config", "roofline") if k in k2}
+            else:
+                secondary = {"error": (child.stderr or child.stdout)[-400:]}
+        except Exception as ex:                                  # the primary measurement stands on its own
+            secondary = {"error": repr(ex)}
     import numpy as np
     import torch
     import fmindex_collection_amd as fm
@@ -324,24 +341,8 @@ def main():
                                            "what": "L2->fabric 128-byte line requests per second (TCC_EA0_RDREQ) vs the measured ceiling for dependent random line reads"}
     if want_cpu:
         result["cpu_baseline"] = cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, args.cpu_sample, out_lb, out_len, layout, sigma, args.edit)
-    if world == 1 and args.workload == "exact" and not args.no_secondary and args.scale == 1.0 and nq == 10_000_000 and args.trim == 0:
-        # the metric's second half — k = 2 Hamming on the same text, in a child process once this one has released its HBM (never part of `value`)
-        import subprocess
-        index.close()
-        outs = hits_bufs = reads = qbuf = qoff = starts = text = out_lb = out_len = packed = None     # noqa: F841 — release the HBM they hold
-        state.clear()
-        torch.cuda.empty_cache()
-        try:
-            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "k2", "--steps", str(args.steps), "--warmup", str(args.warmup),
-                                    "--no-cpu-baseline", "--read-len", str(L)], capture_output=True, text=True, timeout=600)
-            line = [l for l in child.stdout.splitlines() if l.startswith("{")]
-            if child.returncode == 0 and line:
-                k2 = json.loads(line[-1])
-                result["secondary"] = {k: k2[k] for k in ("metric", "value", "unit", "ms_per_step", "gbp_per_s", "hits", "config", "roofline") if k in k2}
-            else:
-                result["secondary"] = {"error": (child.stderr or child.stdout)[-400:]}
-        except Exception as ex:                                  # the primary measurement stands on its own
-            result["secondary"] = {"error": repr(ex)}
+    if secondary is not None:
+        result["secondary"] = secondary
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
