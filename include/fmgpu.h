@@ -133,7 +133,8 @@ typedef struct fmgpu_stats {
 int         fmgpu_abi_version(void);
 const char* fmgpu_last_error(void);
 int         fmgpu_device_count(int* count);
-int         fmgpu_set_device(int device);
+int         fmgpu_set_device(int device);   /* hipSetDevice for the calling thread.  A handle lives on the device that was current when it was created;
+                                               calls on it must be made with that device current (one process per GPU needs a single call at start-up) */
 
 /* index upload: copies (and re-lays out for HBM) the arrays; the caller keeps ownership of host memory.
  * replaces: FMIndex(span bwt, SparseArray) fmindex/FMIndex.h:30-34, BiFMIndex(...) fmindex/BiFMIndex.h:40-51 */
