@@ -378,6 +378,9 @@ struct DevString {
 // builds s.shadow / s.va from the string's own symbols; defined in fmgpu_build.hip
 int build_format_a_shadow(DevString& s, const idx_t* dC, hipStream_t stream);
 
+// 0 if the calling thread's current device is the one the handle lives on; defined in fmgpu_index.hip
+int on_handle_device(const struct Index* x);
+
 // fills s.lf_table from the device string (all layouts); defined in fmgpu_index.hip
 int build_lf_table(DevString& s, hipStream_t stream);
 void free_string(DevString& s);

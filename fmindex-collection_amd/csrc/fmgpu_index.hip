@@ -270,6 +270,13 @@ static int upload(const void* host, size_t bytes, void** dev) {
     return 0;
 }
 
+int on_handle_device(const Index* x) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return fail(FMGPU_ERR_NO_DEVICE, "no HIP device visible — the product path has no CPU fallback"); }
+    if (dev != x->device) return fail(FMGPU_ERR_INVALID, "the handle lives on device " + std::to_string(x->device) + ", the calling thread's current device is " + std::to_string(dev));
+    return 0;
+}
+
 void free_string(DevString& s) {
     if (s.blk) (void)hipFree(s.blk);
     if (s.aux) (void)hipFree(s.aux);
@@ -691,6 +698,7 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
 int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
     DevString& s = x->bwt;
     if (kstep < 0 || kstep > 8) return fail(FMGPU_ERR_INVALID, "kstep must be in [0, 8]");
     x->device_bytes -= s.kblk_bytes;
@@ -720,6 +728,7 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
 int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
     if (lut_len < 0 || lut_len > 32) return fail(FMGPU_ERR_INVALID, "lut_len must be in [0, 32]");
     int rc = fmgpu_index_accelerate(h, kstep);
     if (rc) return rc;
@@ -770,6 +779,7 @@ int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len
 int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t walk) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
     if (!x->bidirectional) return fail(FMGPU_ERR_INVALID, "search accelerators need a BiFMIndex");
     if (prefix_len < 0 || prefix_len > 32) return fail(FMGPU_ERR_INVALID, "prefix_len must be in [0, 32]");
     const uint64_t n = x->bwt.n;
@@ -835,6 +845,7 @@ int fmgpu_string_query(fmgpu_index_t h, int which, const uint64_t* idx, const ui
                        uint64_t count, uint64_t* out, void* stream_) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
     if (which != 0 && !(which == 1 && x->bidirectional)) return fail(FMGPU_ERR_INVALID, "which must be 0 (bwt) or 1 (bwtRev of a BiFMIndex)");
     if (count == 0) return 0;
     if (!idx || !out) return fail(FMGPU_ERR_INVALID, "idx / out is null");

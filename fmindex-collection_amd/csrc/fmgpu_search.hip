@@ -1799,6 +1799,7 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
                        uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats, void* stream_) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
     if (stats) *stats = fmgpu_stats{0, 0, 0.f};
     if (nq == 0) return 0;
     if (!qbuf || !qoff || !out_lb || !out_len) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out_lb / out_len is null");
@@ -2092,6 +2093,7 @@ int fmgpu_search_scheme(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
                         uint64_t max_hits_per_query, fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, void* stream) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
     return run_dfs(x, true, qbuf, qoff, nq, scheme, max_hits_per_query, 0, out, capacity, out_count, stats, (hipStream_t)stream);
 }
 
@@ -2099,6 +2101,7 @@ int fmgpu_search_backtracking(fmgpu_index_t h, const uint8_t* qbuf, const uint64
                               fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, void* stream) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
     if (max_errors > 254) return fail(FMGPU_ERR_INVALID, "max_errors > 254");
     return run_dfs(x, false, qbuf, qoff, nq, nullptr, ~0ull, (uint32_t)max_errors, out, capacity, out_count, stats, (hipStream_t)stream);
 }
@@ -2107,6 +2110,7 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
                  fmgpu_stats* stats, void* stream_) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
     if (!x->has_sa) return fail(FMGPU_ERR_INVALID, "index was created without an annotated (sampled suffix) array");
     if (stats) *stats = fmgpu_stats{0, 0, 0.f};
     if (count == 0) return 0;
@@ -2161,6 +2165,7 @@ __global__ __launch_bounds__(256) void k_iota64(uint64_t* __restrict__ out, uint
 int fmgpu_index_accelerate_locate(fmgpu_index_t h, int32_t enable) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
     const uint64_t n = x->bwt.n;
     if (x->loc_tab) { (void)hipFree(x->loc_tab); x->loc_tab = nullptr; x->device_bytes -= n * 12; }
     if (!enable || n == 0) return 0;
