@@ -865,6 +865,7 @@ __device__ __forceinline__ uint32_t symbol_of_lf(const FastArgs& fa, const idx_t
 
 // wave-synchronous staging of one query per lane: all loads of a chunk are issued before the first is consumed
 __device__ __forceinline__ void qstage_load_sync(const QStage& st, const uint8_t* qbuf, uint64_t off, uint32_t m, uint32_t sigma, bool active, uint32_t maxm) {
+    if (!st.words) return;                                         // staging disabled (very long queries): qstage_get reads global memory
     const uint64_t addr = (uint64_t)qbuf + off;
     const uint32_t mis = (uint32_t)(addr & 7ull);
     const uint64_t* base = reinterpret_cast<const uint64_t*>(addr - mis);

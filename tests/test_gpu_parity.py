@@ -236,6 +236,38 @@ def test_exact_search_randomised_layouts_and_tables(seed):
     assert not ln[invalid].any()                               # a symbol outside the alphabet cannot occur
 
 
+def test_queries_too_long_for_lds_staging():
+    """queries beyond the LDS staging budget (48 KB per block: > 384 DNA symbols, > 192 symbols of a larger alphabet) are read from global
+    memory by the same kernels: exact search with every table, the table-driven k-mismatch and edit-distance kernels, the general ones"""
+    rng = np.random.default_rng(3)
+    for sigma, L in ((5, 700), (28, 300)):
+        hi = min(sigma, 9)
+        base = rng.integers(1, hi, size=6000, dtype=np.uint8)
+        seqs = [np.concatenate([base, base[1000:3000]]), rng.integers(1, hi, size=900, dtype=np.uint8)]
+        ox = fo.OraIndex.build("IB16", sigma, seqs, 8, True)
+        gx = gpu_index(ox)
+        gx.accelerate(3 if sigma == 5 else 1, lut_len=4, walk=2).accelerate_search(4, 3)
+        queries = []
+        for i in range(120):
+            p = int(rng.integers(0, len(seqs[0]) - L)); q = seqs[0][p: p + L].copy()
+            for _ in range(i % 3):
+                q[int(rng.integers(0, L))] = rng.integers(1, hi)
+            queries.append(q)
+        qbuf, qoff = fm.flatten(queries)
+        lb, ln, st = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+        olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
+        assert np.array_equal(lb, olb) and np.array_equal(ln, oln) and st.lf_steps == int(ost.sum())
+        sch = fm.search_scheme.h2(4, 0, 2)
+        for edit in (False, True):
+            hits, st = fm.search_ng26.search(gx, (qbuf[: qoff[30]], qoff[:31]) if edit else (qbuf, qoff), sch, want_stats=True, edit=edit, capacity=1 << 20)
+            ohits, _, nodes = ox.search_ng26(qbuf[: qoff[30]], qoff[:31], sch, edit=True, cap=1 << 20) if edit else ox.search_ng26(qbuf, qoff, sch, cap=1 << 20)
+            assert same_hits(hits, ohits) and st.lf_steps == nodes, (sigma, edit)
+        ragged = [q[: L - (i % 5)] for i, q in enumerate(queries[:40])]
+        rb, ro = fm.flatten(ragged)
+        assert same_hits(fm.search_ng26.search(gx, (rb, ro), sch, capacity=1 << 20), ox.search_ng26(rb, ro, sch, cap=1 << 20)[0])
+        assert same_hits(fm.search_backtracking.search(gx, (rb[: ro[10]], ro[:11]), 1), ox.search_backtracking(rb[: ro[10]], ro[:11], 1)[0])
+
+
 def test_exact_search_tiny_indices():
     for seqs in ([[1]], [[]], [[1], [1], [2, 1]], [[3] * 70]):
         ox = fo.OraIndex.build("IB16", 5, seqs, 1, True)
