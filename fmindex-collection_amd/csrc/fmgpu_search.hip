@@ -1924,7 +1924,12 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (maxlen > 0xfffeu) return fail(FMGPU_ERR_UNSUPPORTED, "queries longer than 65534 symbols");
     static std::mutex occ_mu; static std::map<std::tuple<int, int, int, size_t>, int> occ_cache;
     int bpc = 8;
-    const size_t occ_lds = (size_t)((x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4)) * 1024 > 48 * 1024 ? 0 : (size_t)((x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4)) * 1024;
+    // LDS budget of a 256-lane block of the DFS kernels: 64 KB in all — the staged queries (1 KB per word and block) beside the kernels' own
+    // tables and hit buffers (<= 17 KB static in the general kernels; per-step tables + hit buffers in the table-driven ones, reserved below)
+    const size_t stage_words = x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4;
+    const size_t tables_lds = scheme_mode ? (size_t)2 * (size_t)std::max(sd.S, 1) * ((size_t)maxlen + 1) * 4 + (size_t)kWaveHitWords * 4 : 0;
+    const size_t stage_budget = (size_t)64 * 1024 - std::max<size_t>(17 * 1024, std::min<size_t>(tables_lds, 47 * 1024));
+    const size_t occ_lds = stage_words * 1024 > stage_budget ? 0 : stage_words * 1024;
     const auto occ_key = std::make_tuple(x->bwt.search_family(), x->bwt.sigma, (int)scheme_mode + (edit ? 2 : 0), occ_lds);
     bool occ_known = false;
     { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(occ_key); if (it != occ_cache.end()) { bpc = it->second; occ_known = true; } }
@@ -1941,7 +1946,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     // query staging: 8 (nibbles) or 4 (bytes) symbols per LDS word, 256 lanes per block; above 48 KB the kernels read global memory
     const uint32_t qnib = x->bwt.sigma <= 15 ? 1u : 0u;
     uint32_t qwords = qnib ? (maxlen + 7) / 8 : (maxlen + 3) / 4;
-    if ((size_t)qwords * 1024 > 48 * 1024) qwords = 0;
+    if ((size_t)qwords * 1024 > stage_budget) qwords = 0;
     const size_t lds_bytes = (size_t)qwords * 1024;
     DfsWorkspace ws;
     // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound

@@ -240,7 +240,7 @@ def test_queries_too_long_for_lds_staging():
     """queries beyond the LDS staging budget (48 KB per block: > 384 DNA symbols, > 192 symbols of a larger alphabet) are read from global
     memory by the same kernels: exact search with every table, the table-driven k-mismatch and edit-distance kernels, the general ones"""
     rng = np.random.default_rng(3)
-    for sigma, L in ((5, 700), (28, 300)):
+    for sigma, L in ((5, 700), (28, 300), (5, 300), (5, 336), (5, 380), (28, 170)):       # around the budget as well
         hi = min(sigma, 9)
         base = rng.integers(1, hi, size=6000, dtype=np.uint8)
         seqs = [np.concatenate([base, base[1000:3000]]), rng.integers(1, hi, size=900, dtype=np.uint8)]
