@@ -262,6 +262,10 @@ def test_queries_too_long_for_lds_staging():
             hits, st = fm.search_ng26.search(gx, (qbuf[: qoff[30]], qoff[:31]) if edit else (qbuf, qoff), sch, want_stats=True, edit=edit, capacity=1 << 20)
             ohits, _, nodes = ox.search_ng26(qbuf[: qoff[30]], qoff[:31], sch, edit=True, cap=1 << 20) if edit else ox.search_ng26(qbuf, qoff, sch, cap=1 << 20)
             assert same_hits(hits, ohits) and st.lf_steps == nodes, (sigma, edit)
+        for other in ("WAVELET", "EPR16", "EPRV2_16"):                 # the kernels of the other device formats, without tables
+            oy = fo.OraIndex.build(other, sigma, seqs, 8, False)
+            lb2, ln2 = fm.search_no_errors.search(gpu_index(oy), (qbuf, qoff))
+            assert np.array_equal(lb2, olb) and np.array_equal(ln2, oln), other
         ragged = [q[: L - (i % 5)] for i, q in enumerate(queries[:40])]
         rb, ro = fm.flatten(ragged)
         assert same_hits(fm.search_ng26.search(gx, (rb, ro), sch, capacity=1 << 20), ox.search_ng26(rb, ro, sch, cap=1 << 20)[0])
