@@ -54,3 +54,21 @@ def test_two_rank_sharded_search_and_gather():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
         assert os.path.exists(os.path.join(d, "ok"))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 control flow (per-rank batches, double-buffered asynchronous exchange, barrier + max-over-ranks timing, one JSON line
+    from rank 0) with two ranks sharing the one GPU of the test box; the collective travels over gloo here, over RCCL in the driver's run"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--workload", "k2"]):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.02",
+                            "--nq", "200000", "--dist-backend", "gloo", "--all-ranks-device0"] + extra, capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert r.returncode == 0 and len(lines) == 1, r.stdout[-500:] + r.stderr[-1500:]
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and "cpu_baseline" not in out and "secondary" not in out
