@@ -931,6 +931,42 @@ void ora_search_exact(const ora_index* x, const uint8_t* qbuf, const uint64_t* q
     }
 }
 
+/* search/SearchNoErrors.h:28-86: up to `batch` cursors advanced round-robin, one symbol each per pass (the reference's way of keeping several
+ * independent cache misses in flight); a query leaves the batch when its interval is empty or it is finished.  Same results as above. */
+void ora_search_exact_batched(const ora_index* x, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                              uint64_t* out_lb, uint64_t* out_len, int batch, int nthreads) {
+    if (batch < 1) batch = 32;
+    if (batch > 256) batch = 256;
+    int T = nthreads > 0 ? nthreads : 1;
+    const uint64_t chunk = 4096;
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(T)
+    for (int64_t c0 = 0; c0 < (int64_t)((nq + chunk - 1) / chunk); ++c0) {
+        const uint64_t first = (uint64_t)c0 * chunk, last = first + chunk < nq ? first + chunk : nq;
+        uint64_t qi[256], lb[256], len[256], st[256];
+        int live = 0;
+        uint64_t next = first;
+        for (;;) {
+            while (live < batch && next < last) { qi[live] = next; lb[live] = 0; len[live] = x->n; st[live] = 0; ++live; ++next; }   /* fillBatch */
+            if (live == 0) break;
+            for (int k = 0; k < live; ++k) {                        /* doBatchJump: one extendLeft per cursor */
+                const uint64_t q = qi[k], m = qoff[q + 1] - qoff[q];
+                if (st[k] < m) {
+                    const uint64_t r = qbuf[qoff[q] + m - st[k] - 1];
+                    const uint64_t a = ora_rank(x->bwt, lb[k], r), b = ora_rank(x->bwt, lb[k] + len[k], r);
+                    lb[k] = a + x->C[r]; len[k] = b - a; ++st[k];
+                }
+            }
+            int w = 0;
+            for (int k = 0; k < live; ++k) {                        /* remove_if: empty or finished */
+                const uint64_t q = qi[k], m = qoff[q + 1] - qoff[q];
+                if (len[k] == 0 || st[k] == m) { out_lb[q] = lb[k]; out_len[q] = len[k]; }
+                else { qi[w] = qi[k]; lb[w] = lb[k]; len[w] = len[k]; st[w] = st[k]; ++w; }
+            }
+            live = w;
+        }
+    }
+}
+
 typedef struct emit_ctx { ora_hit* out; uint64_t cap, count, qidx, nodes; uint64_t quota; } emit_ctx;
 static void emit(emit_ctx* e, ora_cursor c, uint64_t errors) {
     if (e->count < e->cap) {

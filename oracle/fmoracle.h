@@ -131,6 +131,9 @@ typedef struct ora_hit { uint64_t qidx, lb, lb_rev, len, errors; } ora_hit;
 /* search/SearchNoErrors.h:12-26 per query; out_steps (optional) = executed extensions */
 void ora_search_exact(const ora_index* x, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                       uint64_t* out_lb, uint64_t* out_len, uint64_t* out_steps, int nthreads);
+/* the batched form, search/SearchNoErrors.h:28-86 (BatchSize cursors advanced round-robin); same results */
+void     ora_search_exact_batched(const ora_index* x, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                                  uint64_t* out_lb, uint64_t* out_len, int batch, int nthreads);
 
 /* search/Backtracking.h:42-102 — hits in the reference's callback order; returns total count (may exceed cap) */
 uint64_t ora_search_backtracking(const ora_index* x, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,

@@ -122,6 +122,7 @@ def lib():
         L.ora_search_ng26_hamming.argtypes = [C.POINTER(IndexStruct), u8p, u64p, C.c_uint64, C.c_int, C.c_int,
                                               u64p, u64p, u64p, u64p, C.c_uint64, C.c_void_p, C.c_uint64,
                                               u64p, u64p, C.c_int]
+        L.ora_search_exact_batched.argtypes = [C.POINTER(IndexStruct), u8p, u64p, C.c_uint64, u64p, u64p, C.c_int, C.c_int]
         L.ora_search_ng26.restype = C.c_uint64
         L.ora_search_ng26.argtypes = [C.POINTER(IndexStruct), C.c_int, u8p, u64p, C.c_uint64, C.c_int, C.c_int,
                                       u64p, u64p, u64p, u64p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, u64p, C.c_int]
@@ -351,6 +352,13 @@ class OraIndex:
         st = np.zeros(nq, dtype=np.uint64) if want_steps else None
         lib().ora_search_exact(self.p, _p8(qbuf), _p64(qoff), nq, _p64(lb), _p64(ln), _p64(st), nthreads)
         return (lb, ln, st) if want_steps else (lb, ln)
+
+    def search_exact_batched(self, qbuf, qoff, batch=32, nthreads=1):
+        nq = len(qoff) - 1
+        lb = np.zeros(nq, dtype=np.uint64)
+        ln = np.zeros(nq, dtype=np.uint64)
+        lib().ora_search_exact_batched(self.p, _p8(qbuf), _p64(qoff), nq, _p64(lb), _p64(ln), batch, nthreads)
+        return lb, ln
 
     def search_backtracking(self, qbuf, qoff, k, cap=1 << 20):
         nq = len(qoff) - 1

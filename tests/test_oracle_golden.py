@@ -301,6 +301,26 @@ def test_exact_intervals_match_text_scan(layout):
         assert found == sorted(int(p) for p in pos)
 
 
+@pytest.mark.parametrize("layout,batch,threads", [("IB16", 32, 1), ("WAVELET", 7, 3), ("EPRV5", 1, 2), ("IB16", 300, 2)])
+def test_batched_exact_search_equals_one_at_a_time(layout, batch, threads):
+    """search/SearchNoErrors.h:28-86 (round-robin over a batch of cursors) answers what :12-26 answers, ragged and empty queries included"""
+    rng = np.random.default_rng(77)
+    text = rng.integers(1, 5, size=30000, dtype=np.uint8)
+    x = fo.OraIndex.build(layout, 5, [text], 8, False)
+    queries = []
+    for i in range(9000):
+        m = int(rng.integers(0, 60))
+        s = int(rng.integers(0, len(text) - 60))
+        q = text[s: s + m].copy()
+        if m and i % 3 == 0:
+            q[int(rng.integers(0, m))] = rng.integers(1, 5)
+        queries.append(q)
+    qbuf, qoff = fo.flatten_queries(queries)
+    lb, ln = x.search_exact(qbuf, qoff)
+    blb, bln = x.search_exact_batched(qbuf, qoff, batch, threads)
+    assert np.array_equal(ln, bln) and np.array_equal(lb, blb)
+
+
 @pytest.mark.parametrize("k", [1, 2, 3])
 def test_ng26_equals_backtracking_equals_text_scan(k):
     """h2(k+2, 0, k) with a uniform partition is complete and non-redundant: same multiset as naive backtracking and as a
