@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--walk", type=int, default=2, help="exact / protein: 1 = LF^J walk table, 2 = LF^J and LF^2J")
     ap.add_argument("--prefix-len", type=int, default=15, help="k2: symbols of the prefix table (fmgpu_index_accelerate_search)")
     ap.add_argument("--trim", type=int, default=0, help="dev: every read loses 0..TRIM symbols at its end (a ragged batch)")
+    ap.add_argument("--ng21", action="store_true", help="k2: search_ng21 over expand(h2(4,0,2), read length) (edit distance; the reference's older algorithm) — a side measurement")
     ap.add_argument("--edit", action="store_true", help="k2: edit distance (search_ng26<Edit = true>) instead of Hamming distance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="default run at N = 1: do not append the k = 2 measurement (BASELINE's metric names exact AND k = 2)")
@@ -75,6 +76,9 @@ def parse():
 
 def main():
     args = parse()
+    if args.ng21:                                             # a side measurement: no CPU leg (the restatement of search_ng21 is single-threaded), no second workload
+        args.no_cpu_baseline = True
+        args.no_secondary = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,7 +194,18 @@ def main():
     # results are double-buffered: the gather of step i travels over xGMI while the kernel of step i+1 runs
     outs = [torch.empty(2 * nq, dtype=torch.int64, device=dev) for _ in range(2 if world > 1 else 1)]   # [lb | len], one buffer so that the gather sends it as is
     scheme = fm.search_scheme.h2(4, 0, 2)
-    hit_cap = (16 if args.edit else 4) * nq
+    hit_cap = (16 if (args.edit or args.ng21) else 4) * nq
+    ex21 = None
+    if args.ng21:
+        import numpy as np
+        if args.trim > 0 or not bidir:
+            raise SystemExit("--ng21 needs --workload k2 and equal-length reads")
+        args.edit = True
+        arrs = tuple(np.ascontiguousarray(a, dtype=np.uint64) for a in fm.search_scheme.expand(scheme, L))
+        ex = capi.ExpandedScheme()
+        ex.n_searches, ex.length = arrs[0].shape
+        ex.pi, ex.l, ex.u = (a.ctypes.data_as(capi.u64p) for a in arrs)
+        ex21 = (ex, arrs)
     hits_bufs = [torch.empty(hit_cap * 40, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)] if bidir else None
     via_host = world > 1 and args.dist_backend == "gloo"
     count_dev = torch.zeros(1, dtype=torch.int64, device="cpu" if via_host else dev)
@@ -217,6 +232,11 @@ def main():
             capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
                                                      C.c_void_p(out[:nq].data_ptr()), C.c_void_p(out[nq:].data_ptr()),
                                                      C.byref(stats), None))
+        elif args.ng21:
+            cnt = C.c_uint64()
+            capi.check(capi.lib().fmgpu_search_ng21(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
+                                                    C.byref(ex21[0]), capi.UINT64_MAX, C.c_void_p(hits_bufs[b].data_ptr()), hit_cap,
+                                                    C.byref(cnt), C.byref(stats), None))
         else:
             sc = _scheme_struct(capi, scheme)
             sc[0].edit = 1 if args.edit else 0
@@ -302,7 +322,7 @@ def main():
         if protein:
             key = "protein_exact_wavelet_lines" if not args.kstep else ("protein_exact_block_table_only" if args.no_exact_tables else "protein_exact")
         elif bidir:
-            key = "grch38_k2_edit" if args.edit else "grch38_k2"
+            key = "grch38_k2_ng21" if args.ng21 else "grch38_k2_edit" if args.edit else "grch38_k2"
         elif args.no_exact_tables:
             key = "grch38_exact_kstep3_only" if args.kstep == 3 else "grch38_exact_kstep%d" % args.kstep
         else:
@@ -315,11 +335,11 @@ def main():
         traffic, lines = None, None
     result = {
         "metric": ("queries/sec (sigma=28 protein index, 10M x 40aa, exact, Wavelet)" if protein else
-                   "queries/sec (GRCh38-sized index, 10M x 101bp, %s)" % ("exact" if not bidir else ("k=2 edit distance, h2(4,0,2)" if args.edit else "k=2 Hamming, h2(4,0,2)"))),
+                   "queries/sec (GRCh38-sized index, 10M x 101bp, %s)" % ("exact" if not bidir else ("k=2 edit distance, search_ng21 over expand(h2(4,0,2))" if args.ng21 else "k=2 edit distance, h2(4,0,2)" if args.edit else "k=2 Hamming, h2(4,0,2)"))),
         "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "protein_exact" if protein else "grch38_%s" % ("exact" if not bidir else ("k2_edit" if args.edit else "k2")), "text_symbols": total, "sequences": len(lengths),
+        "config": {"workload": "protein_exact" if protein else "grch38_%s" % ("exact" if not bidir else ("k2_ng21" if args.ng21 else "k2_edit" if args.edit else "k2")), "text_symbols": total, "sequences": len(lengths),
                    "sigma": sigma, "layout": "Wavelet" if protein else "InterleavedBitvector16", "queries_per_gpu": nq, "read_len": L,
                    "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale, "prefix_table_symbols": (args.prefix_len if bidir and not args.no_search_accel else None), "kstep_table": (args.kstep if not bidir else 1),
                    "device_table": ("block table expanded from the wavelet" if args.kstep else "wavelet lines") if protein else "block table",
@@ -328,7 +348,7 @@ def main():
         "gbp_per_s": qps * L / 1e9,
         "hits": hits,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": (("k_exact_a" if args.no_exact_tables else "k_exact_kstep") if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if (args.kstep > 1 or not args.no_exact_tables) else "k_exact_a") if not bidir else ("k_scheme_fast_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
+                     "traffic": traffic, "kernel": (("k_exact_a" if args.no_exact_tables else "k_exact_kstep") if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if (args.kstep > 1 or not args.no_exact_tables) else "k_exact_a") if not bidir else ("k_ng21" if args.ng21 else "k_scheme_fast_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
                      "units_per_launch": steps_per_launch, "bytes_per_unit": unit_bytes,
                      "unit": "GB/s", "note": NOTE_PROTEIN if protein else NOTE_DNA},
     }

@@ -16,7 +16,7 @@ from . import capi
 from .capi import FmgpuError, DeviceBuffer, LAYOUTS, UINT64_MAX, HIT_DTYPE
 from . import search_scheme  # noqa: F401
 
-__all__ = ["FMIndex", "BiFMIndex", "search_no_errors", "search_backtracking", "search_ng26", "search", "search_n", "search_best", "LocateLinear",
+__all__ = ["FMIndex", "BiFMIndex", "search_no_errors", "search_backtracking", "search_ng26", "search_ng21", "search", "search_n", "search_best", "LocateLinear",
            "search_scheme", "FmgpuError", "DeviceBuffer", "flatten", "device_count"]
 
 
@@ -318,6 +318,59 @@ class search_ng26:
         hits, st = _run_hits(lambda out, c, cnt, st: capi.lib().fmgpu_search_scheme(
             index._h, capi.ptr(qbuf), capi.ptr(qoff), nq, C.byref(sc), n, capi.ptr(out), c, C.byref(cnt), C.byref(st), None), cap)
         return (hits, st) if want_stats else hits
+
+
+class search_ng21:
+    """search/SearchNg21.h: edit-distance search over an EXPANDED scheme — search_scheme.expand(scheme, query length), one {pi, l, u} entry
+    per query symbol, so all queries of a call have that length (the reference indexes query[pi[k]] without a check)"""
+
+    @staticmethod
+    def search(index, queries, scheme, capacity=None, want_stats=False, n=UINT64_MAX):
+        """search_ng21::search (:205-217); scheme = (pi, l, u) arrays [searches][query length]"""
+        qbuf, qoff, nq = _queries(queries)
+        pi, l, u = (_u64(x) for x in scheme)
+        sc = capi.ExpandedScheme()
+        sc.n_searches, sc.length = (pi.shape if pi.ndim == 2 else (0, 0))
+        sc.pi, sc.l, sc.u = (x.ctypes.data_as(capi.u64p) for x in (pi, l, u))
+        cap = capacity if capacity is not None else max(1024, 4 * nq)
+        hits, st = _run_hits(lambda out, c, cnt, st: capi.lib().fmgpu_search_ng21(
+            index._h, capi.ptr(qbuf), capi.ptr(qoff), nq, C.byref(sc), n, capi.ptr(out), c, C.byref(cnt), C.byref(st), None), cap)
+        return (hits, st) if want_stats else hits
+
+    @staticmethod
+    def search_n(index, queries, scheme, n, capacity=None, want_stats=False):
+        """search_ng21::search_n (:220-240): at most n rows per query, the last cursor clipped"""
+        return search_ng21.search(index, queries, scheme, capacity, want_stats, n)
+
+    @staticmethod
+    def search_best(index, queries, schemes, n=UINT64_MAX):
+        """search_ng21::search_best (:242-264): per query the first scheme of the list that reports any row"""
+        qbuf, qoff, nq = _queries(queries)
+        if not isinstance(qoff, np.ndarray):
+            qoff = qoff.to_array(np.uint64, nq + 1) if isinstance(qoff, DeviceBuffer) else np.asarray(qoff)
+        if not isinstance(qbuf, np.ndarray):
+            qbuf = qbuf.to_array(np.uint8, int(qoff[-1]))
+        todo = np.arange(nq)
+        parts = []
+        for rank, sch in enumerate(schemes):
+            if todo.size == 0:
+                break
+            qb, qo = flatten([qbuf[int(qoff[i]): int(qoff[i + 1])] for i in todo])
+            hits = search_ng21.search(index, (qb, qo), sch, n=n).copy()
+            rows = np.bincount(hits["qidx"].astype(np.int64), weights=hits["len"].astype(np.float64), minlength=todo.size)
+            hits["qidx"] = todo.astype(np.uint64)[hits["qidx"].astype(np.int64)]
+            parts.append((rank, hits))
+            todo = todo[rows == 0]                                    # `if (ct > 0) break;` (:261)
+        if not parts:
+            return np.zeros(0, dtype=HIT_DTYPE)
+        hits = np.concatenate([h for _, h in parts])
+        order = np.concatenate([np.full(len(h), r) for r, h in parts])
+        return hits[np.lexsort((hits["seq"], order, hits["qidx"]))]
+
+    @staticmethod
+    def search_best_n(index, queries, schemes, n):
+        """search_ng21::search_best_n (:267-293)"""
+        return search_ng21.search_best(index, queries, schemes, n)
 
 
 def _auto_scheme_search(index, queries, errors, n, edit, compat_auto_scheme):

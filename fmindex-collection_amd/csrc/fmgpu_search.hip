@@ -832,6 +832,182 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
 }
 
+// ---- search_ng21 (search/SearchNg21.h:26-156) -------------------------------------------------------------------
+// Edit-distance search over an EXPANDED scheme: one table word per (search, step) = query position | l << 16 | u << 23 | right << 30
+// (search_scheme/expand.h:146-165, prepare_reorder :184-200).  Differences from search_ng26<Edit = true> that decide the results: the lower
+// bound applies at every step, deletion and substitution children exist only for symbols 1..sigma-1 other than the query's, one lastRank
+// for both sides, the previous STEP's query symbol in place of lastQRank, no one-row path.  Children of a node are numbered in the
+// reference's call order: 0 match, 2i-1 deletion of i, 2i substitution by i, 2*sigma-1 insertion.  Same wave-synchronous head, hit buffers and
+// 32-byte lane-major frames as k_scheme_edit.
+template <class Occ, int MAXSIG>
+__global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_ng21(Occ fw, Occ rv, const uint32_t* __restrict__ tab, uint32_t S, uint32_t M,
+                                                     const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
+                                                     fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib,
+                                                     LfView lfv, uint32_t tab_lds, const uint4* __restrict__ lut, uint32_t lutL) {
+    extern __shared__ uint32_t s_query[];
+    const QStage qst{s_query, qwords, qnib};
+    __shared__ uint32_t s_hb[kWaveHitWords];
+    __shared__ idx_t s_C[257];
+    if (lfv.fw) for (uint32_t i = threadIdx.x; i <= fw.sigma(); i += blockDim.x) s_C[i] = lfv.C[i];
+    if (tab_lds) {                                                  // the step table sits behind the staged queries
+        uint32_t* st = s_query + (size_t)qwords * 256u;
+        for (uint32_t i = threadIdx.x; i < S * M; i += blockDim.x) st[i] = tab[i];
+        tab = st;
+    }
+    __syncthreads();
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sigma = fw.sigma();
+    const uint32_t INS = 2u * sigma - 1u;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t nodes = 0, nh = 0;
+    uint64_t q = 0, quota = 0;
+    uint32_t si = 0, seq = 0;
+    bool idle = false, have_query = false, fresh = false, need_search = true;
+    const uint8_t* qs = qbuf;
+    const uint32_t* T = tab;
+    Cur cur{0, 0, 0};
+    uint32_t e = 0, k = 0, sp = 0, resume = kNoResume, lastRank = 0, info = 0;     // info: LInfo | RInfo << 2 (0 M, 1 S, 2 I, 3 D)
+    idx_t cached_lf = 0;                                            // a resumed one-row frame brings the LF value of its row along
+    for (;;) {
+        const bool want_q = !idle && need_search && !(have_query && si + 1 < S && quota != 0);   // search_reordered, :168-181: the next search unless the delegate said stop
+        const uint64_t got = wave_hand_out(want_q, ctr, lane);
+        if (want_q) {
+            q = got;
+            have_query = false;
+            if (q >= nq) idle = true;
+            else {
+                const uint64_t qo = qoff[q];
+                qs = qbuf + qo;
+                if ((uint32_t)(qoff[q + 1] - qo) >= M && n != 0) { have_query = true; fresh = true; }   // (a shorter query is read out of bounds by the reference)
+            }
+        }
+        const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(!idle);
+        if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
+        if (!busy) break;
+        if (idle) continue;
+        if (need_search) {
+            if (!have_query) continue;
+            if (fresh) { fresh = false; si = 0; quota = max_hits; seq = 0; qstage_load(qst, qbuf, qoff[q], M, sigma); }
+            else ++si;
+            T = tab + (size_t)si * M;
+            cur = Cur{0, 0, n};                                    // run(): :43-48
+            e = 0; k = 0; sp = 0; resume = kNoResume; lastRank = 0; info = 0;
+            need_search = false;
+            if (lut && (T[0] >> 31)) {                              // the first lutL steps are exact, rightwards and adjacent: start from the prefix table
+                const uint32_t p0 = T[0] & 0xffffu;
+                uint32_t code = 0, mul = 1, c = 0; bool valid = true;
+                for (uint32_t t = 0; t < lutL; ++t) {
+                    c = qstage_get(qst, qs, p0 + t);
+                    valid = valid && c >= 1 && c < sigma;
+                    code += (c - 1) * mul; mul *= sigma - 1;
+                }
+                if (valid) {
+                    const uint4 en = lut[code];
+                    nodes += en.w;                                  // the extensions performed before the interval is empty (:146-148 per step)
+                    if (en.z == 0) { need_search = true; continue; }
+                    cur = Cur{en.x, en.y, en.z};
+                    k = lutL; lastRank = c;
+                }
+            }
+        }
+        const uint32_t tw = T[k];
+        const bool right = (tw >> 30) & 1u;
+        const uint32_t Lk = (tw >> 16) & 127u, Uk = (tw >> 23) & 127u;
+        const uint32_t c = qstage_get(qst, qs, tw & 0xffffu);
+        const uint32_t d = right ? 1u : 0u;
+        const uint32_t TI = (info >> (2u * d)) & 3u;
+        const bool Deletion = TI == 0u || TI == 3u, Insertion = TI == 0u || TI == 2u;                       // :91-92
+        const bool resuming = resume != kNoResume;
+        bool mOK = Lk <= e && e <= Uk && (TI != 3u || c != lastRank);                                        // :105-107
+        if (mOK && TI == 2u) mOK = c != qstage_get(qst, qs, T[k - 1u] & 0xffffu);                           // (TI = I only after a step)
+        const bool xOK = Lk <= e + 1u && e + 1u <= Uk;                                                      // :108
+        uint32_t kind = 4u, take = c, nxt = kNoResume;          // kind: 0 match, 1 substitution, 2 deletion, 3 insertion, 4 nothing left
+        idx_t lfa[MAXSIG], lfb[MAXSIG];
+        const bool via_lf = lfv.fw != nullptr && cur.len == 1;      // one row: its only child comes from the LF table (one 4-byte load)
+        idx_t lf1 = cached_lf;
+        if (xOK || (mOK && !resuming)) {
+            const Occ& occ = right ? rv : fw;
+            const idx_t a = right ? cur.lbRev : cur.lb;
+            SymSet<MAXSIG> alive;
+            if (via_lf) {
+                if (!resuming) lf1 = (right ? lfv.rv : lfv.fw)[a];
+                alive.clear(); alive.insert(symbol_of_lf_lds(s_C, sigma, lf1));
+            } else {
+                occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
+                alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+            }
+            if (!resuming) ++nodes;                                 // one extend call per node (:111 or :146)
+            if (!xOK) { if (alive.test(c)) kind = 0u; }
+            else {
+                SymSet<MAXSIG> subs = alive; subs.remove(0); subs.remove(c);
+                SymSet<MAXSIG> dels = subs; if (!Deletion) dels.clear();
+                const bool c_alive = alive.test(c);
+                auto child_from = [&](uint32_t s0) -> uint32_t {    // number of the first existing child >= s0
+                    if (s0 == 0u && mOK && c_alive) return 0u;
+                    SymSet<MAXSIG> dd = dels, ss = subs;
+                    dd.clear_below(s0 <= 1u ? 1u : (s0 + 2u) >> 1);  // 2i - 1 >= s0
+                    ss.clear_below(s0 <= 2u ? 1u : (s0 + 1u) >> 1);  // 2i     >= s0
+                    uint32_t best = kNoResume;
+                    if (dd.any()) best = 2u * dd.first() - 1u;
+                    if (ss.any()) { uint32_t v = 2u * ss.first(); if (v < best) best = v; }
+                    if (best == kNoResume && Insertion && s0 <= INS) best = INS;
+                    return best;
+                };
+                const uint32_t idx = child_from(resuming ? resume : 0u);
+                if (idx != kNoResume) {
+                    if (idx == 0u) kind = 0u;
+                    else if (idx == INS) kind = 3u;
+                    else { kind = (idx & 1u) ? 2u : 1u; take = (idx + 1u) >> 1; }
+                    if (idx != INS) nxt = child_from(idx + 1u);
+                }
+            }
+        }
+        if (kind != 4u && nxt != kNoResume) {                       // keep the parent: its remaining children start at nxt
+            uint4* f = reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
+            f[0] = make_uint4(cur.lb, cur.lbRev, cur.len, k);
+            f[1] = make_uint4(nxt, e | (info << 8) | (lastRank << 16), lf1, 0u);
+            ++sp;
+        }
+        resume = kNoResume;
+        bool back = kind == 4u;
+        if (kind != 4u) {
+            if (kind != 3u) {
+                if (via_lf) cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
+                else cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+            }
+            const uint32_t imask = ~(3u << (2u * d));
+            if (kind == 0u) { info = info & imask; lastRank = c; }
+            else {
+                e += 1u;
+                info = (info & imask) | ((kind == 1u ? 1u : (kind == 2u ? 3u : 2u)) << (2u * d));
+                if (kind != 3u) lastRank = take;
+            }
+            if (kind != 2u) ++k;
+            if (k == M) {                                           // search_next, :73-78
+                const uint32_t li = info & 3u, ri = (info >> 2) & 3u;
+                if ((li == 0u || li == 2u) && (ri == 0u || ri == 2u)) {
+                    Cur r = cur;
+                    if ((uint64_t)r.len > quota) r.len = (idx_t)quota;       // search_n, :229-235
+                    quota -= r.len;
+                    wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
+                    if (quota == 0) { need_search = true; continue; }
+                }
+                back = true;
+            }
+        }
+        if (back) {
+            if (sp == 0) { need_search = true; continue; }
+            --sp;
+            const uint4* f = reinterpret_cast<const uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
+            const uint4 a0 = f[0], a1 = f[1];
+            cur = Cur{a0.x, a0.y, a0.z}; k = a0.w;
+            resume = a1.x; e = a1.y & 255u; info = (a1.y >> 8) & 15u; lastRank = (a1.y >> 16) & 255u; cached_lf = a1.z;
+        }
+    }
+    uint32_t tot = wave_sum(nodes);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
+}
+
 // ---- search_ng26 Hamming, fast path ------------------------------------------------------------------------------
 // For a batch of equal-length queries on a Format-A BiFMIndex the host expands the scheme once into a per-step table
 // (query position, direction, error window [minE, maxE] of the step, "last character of its part"; SearchNg26.h:160-168:
@@ -2110,6 +2286,111 @@ int fmgpu_search_backtracking(fmgpu_index_t h, const uint8_t* qbuf, const uint64
     if (int drc = on_handle_device(x)) return drc;
     if (max_errors > 254) return fail(FMGPU_ERR_INVALID, "max_errors > 254");
     return run_dfs(x, false, qbuf, qoff, nq, nullptr, ~0ull, (uint32_t)max_errors, out, capacity, out_count, stats, (hipStream_t)stream);
+}
+
+int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_expanded_scheme* scheme,
+                      uint64_t max_hits_per_query, fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, void* stream_) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (stats) *stats = fmgpu_stats{0, 0, 0.f};
+    if (out_count) *out_count = 0;
+    if (!x->bidirectional) return fail(FMGPU_ERR_INVALID, "search_ng21 needs a BiFMIndex (bwt_rev)");
+    if (!scheme) return fail(FMGPU_ERR_INVALID, "scheme is null");
+    if (scheme->n_searches < 0 || scheme->n_searches > 4096) return fail(FMGPU_ERR_UNSUPPORTED, "more than 4096 searches");
+    if (nq == 0 || scheme->n_searches == 0) return 0;                                  // SearchNg21.h:205
+    if (!qbuf || !qoff || (!out && capacity) || !out_count) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out / out_count is null");
+    if (!scheme->pi || !scheme->l || !scheme->u) return fail(FMGPU_ERR_INVALID, "scheme arrays are null");
+    const uint64_t M = scheme->length;
+    if (M == 0 || M > 0xfffeu) return fail(FMGPU_ERR_INVALID, "expanded scheme length must be in [1, 65534]");
+    const uint32_t S = (uint32_t)scheme->n_searches;
+    std::vector<uint32_t> tab((size_t)S * M);
+    uint32_t max_u = 0;
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint64_t *pi = scheme->pi + (size_t)s * M, *l = scheme->l + (size_t)s * M, *u = scheme->u + (size_t)s * M;
+        uint64_t lo = pi[0], hi = pi[0];
+        for (uint64_t k = 0; k < M; ++k) {
+            if (pi[k] >= M) return fail(FMGPU_ERR_INVALID, "scheme pi entry out of range");
+            if (l[k] > 127 || u[k] > 127) return fail(FMGPU_ERR_UNSUPPORTED, "error bounds above 127");
+            if (k) {        // the cursor only grows at its two ends (search_scheme/isValid.h:18-33)
+                if (pi[k] == hi + 1) hi = pi[k]; else if (pi[k] + 1 == lo) lo = pi[k]; else return fail(FMGPU_ERR_INVALID, "scheme pi is not contiguous");
+            }
+            const bool right = k == 0 ? (M < 2 || pi[0] < pi[1]) : pi[k - 1] < pi[k];                    // prepare_reorder, :184-200
+            tab[(size_t)s * M + k] = (uint32_t)pi[k] | ((uint32_t)l[k] << 16) | ((uint32_t)u[k] << 23) | ((right ? 1u : 0u) << 30);
+            max_u = std::max<uint32_t>(max_u, (uint32_t)u[k]);
+        }
+        // bit 31 of a search's first word: its first lut_len steps are error-free, rightwards and adjacent, so the prefix table
+        // (fmgpu_index_accelerate_search) holds the cursor they lead to
+        const uint32_t LL = x->lut ? x->lut_len : 0;
+        bool ok = LL > 0 && M > LL && x->bwt.n > 1;
+        for (uint64_t k = 0; ok && k < LL; ++k) ok = u[k] == 0 && l[k] == 0 && pi[k] == pi[0] + k;
+        if (ok) tab[(size_t)s * M] |= 1u << 31;
+    }
+    Staged soff, sbuf, sout;
+    int rc;
+    if ((rc = soff.in(qoff, (nq + 1) * 8, stream))) return rc;
+    uint64_t total = 0;
+    if (is_device_pointer(qoff)) { FM_HIP(hipMemcpyAsync(&total, qoff + nq, 8, hipMemcpyDeviceToHost, stream)); FM_HIP(hipStreamSynchronize(stream)); }
+    else total = qoff[nq];
+    if ((rc = sbuf.in(qbuf, total, stream))) return rc;
+    if ((rc = sout.out(out, capacity * sizeof(fmgpu_hit), stream))) return rc;
+    const uint32_t qnib = x->bwt.sigma <= 15 ? 1u : 0u;
+    uint32_t qwords = qnib ? ((uint32_t)M + 7) / 8 : ((uint32_t)M + 3) / 4;
+    if ((size_t)qwords * 1024 > 48 * 1024) qwords = 0;             // 64 KB of LDS per block, 14 KB of hit buffers: very long queries stay in global memory
+    const uint32_t tab_lds = (size_t)qwords * 1024 + tab.size() * 4 <= 44 * 1024 ? 1u : 0u;   // step table behind the staged queries if both fit
+    const size_t lds_bytes = (size_t)qwords * 1024 + (tab_lds ? tab.size() * 4 : 0);
+    LfView lfv{nullptr, nullptr, nullptr};
+    if (x->bwt.lf_table && x->rev.lf_table) lfv = LfView{x->bwt.lf_table, x->rev.lf_table, x->dC};
+    static std::mutex occ_mu; static std::map<std::tuple<int, int, size_t>, int> occ_cache;
+    int bpc = 4;
+    const auto occ_key = std::make_tuple(x->bwt.search_family(), x->bwt.sigma, lds_bytes);
+    bool occ_known = false;
+    { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(occ_key); if (it != occ_cache.end()) { bpc = it->second; occ_known = true; } }
+    if (!occ_known) {
+        dispatch_occ(x->bwt, [&](auto occ, auto ms) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ng21<decltype(occ), decltype(ms)::value>, 256, lds_bytes) == hipSuccess && nb > 0) bpc = nb;
+            else (void)hipGetLastError();
+            return 0;
+        });
+        std::lock_guard<std::mutex> g(occ_mu); occ_cache[occ_key] = bpc;
+    }
+    DfsWorkspace ws;
+    if ((rc = ws.init((uint32_t)M + max_u + 2, nq, bpc, stream, 4))) return rc;       // deletions lengthen the path beyond the query by at most the largest upper bound
+    uint32_t* d_tab = nullptr;
+    FM_HIP(hipMalloc((void**)&d_tab, tab.size() * 4));
+    hipError_t le = hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, stream);
+    EventTimer timer(stream, stats != nullptr);
+    const idx_t n = (idx_t)x->bwt.n;
+    timer.start();
+    if (le == hipSuccess) rc = dispatch_occ(x->bwt, [&](auto occ, auto ms) {
+        using O = decltype(occ);
+        const DevString& rv = x->rev;
+        O r{};
+        if constexpr (std::is_same_v<O, OccA<5>> || std::is_same_v<O, OccA<0>>) r = O{rv.va};
+        else if constexpr (std::is_same_v<O, OccW>) r = O{rv.vw};
+        else r = O{rv.vr};
+        k_ng21<O, decltype(ms)::value><<<dim3(ws.grid), dim3(256), lds_bytes, stream>>>(occ, r, d_tab, S, (uint32_t)M, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                                   nq, n, max_hits_per_query, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, tab_lds, x->lut, x->lut_len);
+        return 0;
+    });
+    timer.stop();
+    if (le == hipSuccess) le = hipGetLastError();
+    Counters hc{};
+    if (le == hipSuccess) le = hipMemcpyAsync(&hc, ws.ctr, sizeof hc, hipMemcpyDeviceToHost, stream);
+    if (le == hipSuccess) le = hipStreamSynchronize(stream);
+    (void)hipFree(d_tab);
+    if (le != hipSuccess) return hip_fail(le, "search_ng21 kernel");
+    if (rc) return rc;
+    *out_count = hc.hits;
+    if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); }
+    if (hc.hits > capacity) {
+        if (sout.writeback) { sout.bytes = capacity * sizeof(fmgpu_hit); (void)sout.finish(); }
+        return fail(FMGPU_ERR_CAPACITY, "result buffer holds " + std::to_string(capacity) + " records, " + std::to_string(hc.hits) + " produced");
+    }
+    if (sout.writeback) sout.bytes = hc.hits * sizeof(fmgpu_hit);
+    return sout.finish();
 }
 
 int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps,

@@ -454,6 +454,77 @@ void search_best(Index const& index, Queries const& queries, size_t maxErrors, D
 }
 }  // namespace search_ng26
 
+// search/SearchNg21.h: edit-distance search over an EXPANDED scheme (search_scheme::expand(scheme, query length): one {pi, l, u} entry per
+// query symbol), so the queries of a call have that length; shorter ones — which the reference would read out of bounds — report nothing.
+namespace search_ng21 {
+namespace detail2 {
+template <typename Index>
+std::vector<fmgpu_hit> run(Index const& index, std::vector<uint8_t> const& buf, std::vector<uint64_t> const& off, search_scheme::Scheme const& scheme,
+                           size_t n, std::vector<uint64_t> const* qmap) {
+    size_t nq = off.size() - 1;
+    if (scheme.empty() || nq == 0) return {};                                         // :205
+    size_t M = scheme[0].pi.size();
+    std::vector<uint64_t> pi, l, u;
+    for (auto const& s : scheme) {
+        if (s.pi.size() != M || s.l.size() != M || s.u.size() != M) throw std::runtime_error("fmindex-collection (gpu): searches of an expanded scheme must have the same length");
+        pi.insert(pi.end(), s.pi.begin(), s.pi.end()); l.insert(l.end(), s.l.begin(), s.l.end()); u.insert(u.end(), s.u.begin(), s.u.end());
+    }
+    fmgpu_expanded_scheme sc{static_cast<int32_t>(scheme.size()), 0, M, pi.data(), l.data(), u.data()};
+    auto hits = detail::run_hits(nq, [&](fmgpu_hit* out, uint64_t cap, uint64_t* count) {
+        return fmgpu_search_ng21(index.handle, buf.data(), off.data(), nq, &sc, n, out, cap, count, nullptr, nullptr);
+    });
+    if (qmap) for (auto& h : hits) h.qidx = (*qmap)[h.qidx];
+    return hits;
+}
+template <typename Index, typename Queries, typename Delegate>
+void best(Index const& index, Queries const& queries, std::vector<search_scheme::Scheme> const& schemes, size_t n, Delegate&& delegate) {
+    std::vector<uint64_t> todo;
+    for (size_t i = 0; i < queries.size(); ++i) todo.push_back(i);
+    std::vector<fmgpu_hit> all;
+    for (auto const& scheme : schemes) {
+        if (todo.empty()) break;
+        std::vector<uint8_t> buf; std::vector<uint64_t> off{0};
+        for (auto qi : todo) { auto const& q = queries[qi]; buf.insert(buf.end(), q.begin(), q.end()); off.push_back(buf.size()); }
+        auto hits = run(index, buf, off, scheme, n, &todo);
+        std::vector<uint8_t> found(queries.size(), 0);
+        for (auto const& h : hits) if (h.len) found[h.qidx] = 1;                      // `if (ct > 0) break;` (:261, :290)
+        all.insert(all.end(), hits.begin(), hits.end());
+        std::vector<uint64_t> rest;
+        for (auto qi : todo) if (!found[qi]) rest.push_back(qi);
+        todo.swap(rest);
+    }
+    detail::report(index, all, delegate);
+}
+}  // namespace detail2
+
+// search(index, queries, search_scheme, delegate(qidx, cursor, errors)) — :205-217
+template <typename Index, typename Queries, typename Delegate>
+void search(Index const& index, Queries const& queries, search_scheme::Scheme const& scheme, Delegate&& delegate) {
+    std::vector<uint8_t> buf; std::vector<uint64_t> off;
+    detail::flatten(queries, buf, off);
+    auto hits = detail2::run(index, buf, off, scheme, std::numeric_limits<size_t>::max(), nullptr);
+    detail::report(index, hits, delegate);
+}
+// search_n(index, queries, search_scheme, n, delegate) — :220-240: at most n rows per query, the last cursor clipped
+template <typename Index, typename Queries, typename Delegate>
+void search_n(Index const& index, Queries const& queries, search_scheme::Scheme const& scheme, size_t n, Delegate&& delegate) {
+    std::vector<uint8_t> buf; std::vector<uint64_t> off;
+    detail::flatten(queries, buf, off);
+    auto hits = detail2::run(index, buf, off, scheme, n, nullptr);
+    detail::report(index, hits, delegate);
+}
+// search_best(index, queries, search_schemes, delegate) — :242-264: per query the first scheme of the list that reports any row
+template <typename Index, typename Queries, typename Delegate>
+void search_best(Index const& index, Queries const& queries, std::vector<search_scheme::Scheme> const& schemes, Delegate&& delegate) {
+    detail2::best(index, queries, schemes, std::numeric_limits<size_t>::max(), std::forward<Delegate>(delegate));
+}
+// search_best_n(index, queries, search_schemes, n, delegate) — :267-293
+template <typename Index, typename Queries, typename Delegate>
+void search_best_n(Index const& index, Queries const& queries, std::vector<search_scheme::Scheme> const& schemes, size_t n, Delegate&& delegate) {
+    detail2::best(index, queries, schemes, n, std::forward<Delegate>(delegate));
+}
+}  // namespace search_ng21
+
 // fmc::search<EditDistance>(index, queries, errors, delegate(qidx, cursor, errors)) — search/search.h:26-35
 template <bool EditDistance, typename Index, typename Queries, typename Delegate>
 void search(Index const& index, Queries const& queries, size_t errors, Delegate&& delegate) {

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FMGPU_ABI_VERSION 2
+#define FMGPU_ABI_VERSION 3
 
 typedef enum fmgpu_status {
     FMGPU_OK = 0,
@@ -124,6 +124,14 @@ typedef struct fmgpu_scheme {
     int32_t reserved;
 } fmgpu_scheme;
 
+/* an EXPANDED scheme, one {pi, l, u} entry per query symbol (search_scheme/expand.h:146-165), flattened [search][length]:
+ * what search_ng21 walks (search/SearchNg21.h:184-200 prepare_reorder) */
+typedef struct fmgpu_expanded_scheme {
+    int32_t  n_searches, reserved;
+    uint64_t length;             /* entries per search = symbols of a query that are searched */
+    const uint64_t* pi; const uint64_t* l; const uint64_t* u;
+} fmgpu_expanded_scheme;
+
 typedef struct fmgpu_stats {
     uint64_t lf_steps;       /* exact search: executed extensions;  k-mismatch: visited nodes (cursor extensions) */
     uint64_t hits;           /* records produced */
@@ -188,6 +196,15 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
 int fmgpu_search_scheme(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                         const fmgpu_scheme* scheme, uint64_t max_hits_per_query,
                         fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, void* stream);
+
+/* search_ng21::search(index, queries, search_scheme, delegate) and search_n(..., n, delegate) (search/SearchNg21.h:205-240):
+ * edit-distance search over an expanded scheme; BiFMIndex only.  max_hits_per_query = n (UINT64_MAX = search).  Queries shorter than
+ * scheme->length (which the reference would read out of bounds) produce nothing; of longer ones the first `length` symbols' positions
+ * pi[] are searched, as in the reference.  Records as for fmgpu_search_scheme; errors <= 127.  search_best / search_best_n
+ * (:242-293) are host loops over this call (first scheme of a list with any hit), see the host mirrors. */
+int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                      const fmgpu_expanded_scheme* scheme, uint64_t max_hits_per_query,
+                      fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, void* stream);
 
 /* search_backtracking::search(index, queries, maxErrors, delegate) (search/Backtracking.h:85-89); FMIndex or BiFMIndex */
 int fmgpu_search_backtracking(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,

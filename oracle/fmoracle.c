@@ -1354,6 +1354,84 @@ uint64_t ora_search_ng26(const ora_index* x, int edit, const uint8_t* qbuf, cons
     return total;
 }
 
+/* ---- search_ng21 (search/SearchNg21.h:26-156): edit-distance search over an EXPANDED scheme (one {pi, l, u} entry per query symbol,
+ * search_scheme/expand.h:146-165).  No count()==1 path, one lastRank for both sides, the previous block's symbol instead of lastQRank,
+ * the lower bound applied at every symbol, substitution / deletion children only for symbols 1..Sigma-1 other than the query's. ------- */
+typedef struct n21_search {
+    const ora_index* x; const uint8_t* q; uint64_t len;
+    const uint64_t *pi, *l, *u;
+    emit_ctx* e;
+} n21_search;
+static int n21_right(const n21_search* s, uint64_t k) {           /* prepare_reorder, :184-200 (a one-symbol search reads pi[1]: taken as Right here) */
+    if (k == 0) return s->len < 2 || s->pi[0] < s->pi[1];
+    return s->pi[k - 1] < s->pi[k];
+}
+static int n21_report(const n21_search* s, ora_cursor cur, uint64_t e) {   /* search_n, :223-240 (search: quota = UINT64_MAX, never full) */
+    emit_ctx* c = s->e;
+    if (cur.len > c->quota) cur.len = c->quota;
+    c->quota -= cur.len;
+    emit(c, cur, e);
+    return c->quota == 0;
+}
+static int n21_next(const n21_search* s, ora_cursor cur, uint64_t e, uint64_t k, uint64_t lastRank, char LInfo, char RInfo) {   /* search_next + search_next_dir, :68-153 */
+    if (cur.len == 0) return 0;
+    if (k == s->len) {
+        if ((LInfo == 'M' || LInfo == 'I') && (RInfo == 'M' || RInfo == 'I')) return n21_report(s, cur, e);
+        return 0;
+    }
+    const int Right = n21_right(s, k);
+    const char TInfo = Right ? RInfo : LInfo;
+    const int Deletion = TInfo == 'M' || TInfo == 'D', Insertion = TInfo == 'M' || TInfo == 'I';
+    const uint64_t symb = s->q[s->pi[k]];
+    const int matchAllowed = s->l[k] <= e && e <= s->u[k]
+                             && (TInfo != 'I' || symb != s->q[s->pi[k - 1]])
+                             && (TInfo != 'D' || symb != lastRank);
+    const int mismatchAllowed = s->l[k] <= e + 1 && e + 1 <= s->u[k];
+    #define N21_L(op) (Right ? LInfo : (op))
+    #define N21_R(op) (Right ? (op) : RInfo)
+    if (mismatchAllowed) {
+        ora_cursor kids[256];
+        if (Right) ora_extend_right_all(s->x, cur, kids); else ora_extend_left_all(s->x, cur, kids);
+        s->e->nodes++;
+        if (matchAllowed && n21_next(s, kids[symb], e, k + 1, symb, N21_L('M'), N21_R('M'))) return 1;
+        for (uint64_t i = 1; i < (uint64_t)s->x->sigma; ++i) {   /* :122-143, the two loops around symb */
+            if (i == symb) continue;
+            if (Deletion && n21_next(s, kids[i], e + 1, k, i, N21_L('D'), N21_R('D'))) return 1;
+            if (n21_next(s, kids[i], e + 1, k + 1, i, N21_L('S'), N21_R('S'))) return 1;
+        }
+        if (Insertion && n21_next(s, cur, e + 1, k + 1, lastRank, N21_L('I'), N21_R('I'))) return 1;
+    } else if (matchAllowed) {
+        ora_cursor c = Right ? ora_extend_right(s->x, cur, symb) : ora_extend_left(s->x, cur, symb);
+        s->e->nodes++;
+        if (n21_next(s, c, e, k + 1, symb, N21_L('M'), N21_R('M'))) return 1;
+    }
+    #undef N21_L
+    #undef N21_R
+    return 0;
+}
+/* search / search_n, :205-240: pi, l, u hold nsearch rows of `len` entries (the expanded scheme); a query shorter than `len` would be read
+ * out of bounds by the reference and is skipped; hits carry the query index, in callback order */
+uint64_t ora_search_ng21(const ora_index* x, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                         int nsearch, uint64_t len, const uint64_t* pi, const uint64_t* l, const uint64_t* u,
+                         uint64_t max_hits_per_query, ora_hit* out, uint64_t cap, uint64_t* out_qcount, uint64_t* out_nodes) {
+    if (out_nodes) *out_nodes = 0;
+    if (!x->bidirectional || nq == 0 || nsearch <= 0) return 0;
+    emit_ctx e = {out, cap, 0, 0, 0, 0};
+    for (uint64_t q = 0; q < nq; ++q) {
+        const uint64_t before = e.count, m = qoff[q + 1] - qoff[q];
+        if (out_qcount) out_qcount[q] = 0;
+        if (m < len) continue;
+        e.qidx = q; e.quota = max_hits_per_query;
+        for (int si = 0; si < nsearch; ++si) {
+            n21_search s = {x, qbuf + qoff[q], len, pi + (uint64_t)si * len, l + (uint64_t)si * len, u + (uint64_t)si * len, &e};
+            if (n21_next(&s, ora_cursor_init(x), 0, 0, 0, 'M', 'M')) break;
+        }
+        if (out_qcount) out_qcount[q] = e.count - before;
+    }
+    if (out_nodes) *out_nodes = e.nodes;
+    return e.count;
+}
+
 /* =====================================================================================
  * search schemes
  * ===================================================================================== */

@@ -159,6 +159,10 @@ int  ora_scheme_h2(uint64_t N, uint64_t minK, uint64_t K, uint64_t* pi, uint64_t
 int  ora_scheme_pigeon_opt(uint64_t minK, uint64_t K, uint64_t* pi, uint64_t* l, uint64_t* u);              /* generator/pigeon.h:54-102; parts = K+1 */
 int  ora_scheme_pigeon_trivial(uint64_t minK, uint64_t K, uint64_t* pi, uint64_t* l, uint64_t* u);          /* generator/pigeon.h:14-52 */
 int  ora_scheme_backtracking(uint64_t N, uint64_t minK, uint64_t K, uint64_t* pi, uint64_t* l, uint64_t* u); /* generator/backtracking.h:14-21 */
+/* search/SearchNg21.h:205-240 (search, search_n) over an expanded scheme: nsearch rows of `len` entries */
+uint64_t ora_search_ng21(const ora_index* x, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                         int nsearch, uint64_t len, const uint64_t* pi, const uint64_t* l, const uint64_t* u,
+                         uint64_t max_hits_per_query, ora_hit* out, uint64_t cap, uint64_t* out_qcount, uint64_t* out_nodes);
 void ora_uniform_partition(uint64_t parts, uint64_t total, uint64_t* out);                                    /* search_scheme/expand.h:324-343 */
 /* search_scheme/expand.h:146-165: expands every search to newLen parts, drops invalid ones; returns #searches kept */
 int  ora_scheme_expand(int nsearch, uint64_t parts, const uint64_t* pi, const uint64_t* l, const uint64_t* u,

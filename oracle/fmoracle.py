@@ -123,6 +123,9 @@ def lib():
                                               u64p, u64p, u64p, u64p, C.c_uint64, C.c_void_p, C.c_uint64,
                                               u64p, u64p, C.c_int]
         L.ora_search_exact_batched.argtypes = [C.POINTER(IndexStruct), u8p, u64p, C.c_uint64, u64p, u64p, C.c_int, C.c_int]
+        L.ora_search_ng21.restype = C.c_uint64
+        L.ora_search_ng21.argtypes = [C.POINTER(IndexStruct), u8p, u64p, C.c_uint64, C.c_int, C.c_uint64, u64p, u64p, u64p,
+                                      C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.POINTER(C.c_uint64)]
         L.ora_search_ng26.restype = C.c_uint64
         L.ora_search_ng26.argtypes = [C.POINTER(IndexStruct), C.c_int, u8p, u64p, C.c_uint64, C.c_int, C.c_int,
                                       u64p, u64p, u64p, u64p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, u64p, C.c_int]
@@ -404,6 +407,42 @@ class OraIndex:
         if nthreads == 1 and n > cap:
             return self._search_ng26_full(qbuf, qoff, scheme, partition, max_hits, int(n), 1, edit)
         return out[: n if nthreads == 1 else 0], qcount, nodes.value
+
+
+    def search_ng21(self, qbuf, qoff, expanded, max_hits=UINT64_MAX, cap=1 << 20):
+        """search_ng21::search / search_n over an expanded scheme (pi, l, u of shape [searches, query length])"""
+        pi, l, u = expanded
+        nsearch, length = pi.shape if pi.ndim == 2 else (0, 0)
+        nq = len(qoff) - 1
+        out = np.zeros(cap, dtype=HIT_DTYPE)
+        qcount = np.zeros(nq, dtype=np.uint64)
+        nodes = C.c_uint64()
+        n = lib().ora_search_ng21(self.p, _p8(qbuf), _p64(qoff), nq, nsearch, length, _p64(as_u64(pi)), _p64(as_u64(l)), _p64(as_u64(u)),
+                                  max_hits, out.ctypes.data, cap, _p64(qcount), C.byref(nodes))
+        if n > cap:
+            return self.search_ng21(qbuf, qoff, expanded, max_hits, cap=int(n))
+        return out[:n], qcount, nodes.value
+
+    def search_ng21_best(self, qbuf, qoff, expanded_list, max_hits=UINT64_MAX):
+        """search_best / search_best_n, SearchNg21.h:242-293: per query the first scheme of the list with any hit"""
+        nq = len(qoff) - 1
+        parts, nodes = [], 0
+        todo = np.arange(nq)
+        for ex in expanded_list:
+            if len(todo) == 0:
+                break
+            sub_off = np.zeros(len(todo) + 1, dtype=np.uint64)
+            lens = (qoff[1:] - qoff[:-1])[todo]
+            sub_off[1:] = np.cumsum(lens)
+            sub_buf = np.concatenate([qbuf[int(qoff[q]): int(qoff[q + 1])] for q in todo]) if len(todo) else np.zeros(0, np.uint8)
+            hits, qcount, nd = self.search_ng21(np.ascontiguousarray(sub_buf, dtype=np.uint8), sub_off, ex, max_hits)
+            nodes += nd
+            hits = hits.copy()
+            hits["qidx"] = todo[hits["qidx"].astype(np.int64)]
+            parts.append(hits)
+            todo = todo[qcount == 0]
+        allh = np.concatenate(parts) if parts else np.zeros(0, dtype=HIT_DTYPE)
+        return allh[np.argsort(allh["qidx"], kind="stable")], nodes
 
 
 class _BorrowedString(OraString):

@@ -91,6 +91,26 @@ int main() {
         fmc::search_n</*EditDistance=*/true>(index, queries, /*maxErrors*/ 1, /*n*/ 3, locate_all);
         std::sort(results.begin(), results.end());
         CHECK((results == Results{{0, 0, 3}, {0, 1, 7}, {0, 1, 7}, {1, 0, 7}, {1, 0, 7}, {1, 1, 3}}));
+        // search_ng21 over expanded schemes: checkSearches.cpp "search ng21, all search" / "all search_n" / "all search_best" / "all search_best_n"
+        auto ex = [&](size_t minK, size_t maxK) { return ss::expand(ss::generator::pigeon_opt(minK, maxK), queries[0].size()); };
+        auto all8 = Results{{0, 0, 3}, {0, 0, 3}, {0, 1, 7}, {0, 1, 7}, {1, 0, 7}, {1, 0, 7}, {1, 1, 3}, {1, 1, 3}};
+        auto top3 = Results{{0, 0, 3}, {0, 1, 7}, {0, 1, 7}, {1, 0, 7}, {1, 0, 7}, {1, 1, 3}};
+        results.clear();
+        fmc::search_ng21::search(index, queries, ex(0, 1), locate_all);
+        std::sort(results.begin(), results.end());
+        CHECK(results == all8);
+        results.clear();
+        fmc::search_ng21::search_n(index, queries, ex(0, 1), 3, locate_all);
+        std::sort(results.begin(), results.end());
+        CHECK(results == top3);
+        results.clear();
+        fmc::search_ng21::search_best(index, queries, std::vector{ex(0, 0), ex(1, 1), ex(2, 2)}, locate_all);
+        std::sort(results.begin(), results.end());
+        CHECK(results == all8);
+        results.clear();
+        fmc::search_ng21::search_best_n(index, queries, std::vector{ex(0, 0), ex(1, 1)}, 3, locate_all);
+        std::sort(results.begin(), results.end());
+        CHECK(results == top3);
     }
     {   // "backtracking with errors": FMIndex<256>
         auto index = fmc::FMIndex<256>{input, 1, 1};

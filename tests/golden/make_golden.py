@@ -125,6 +125,12 @@ def reference_tests():
                             "ng26_pigeon_opt_n3": {"queries": [[Cc, Cc], [B, B]], "n": 3, "expected": expected_of("search ng26, all search_n")},
                             "facade_k1": {"queries": [[Cc, Cc], [B, B]], "expected": expected_of("search, all search, no search scheme", live)},
                             "facade_k1_n3": {"queries": [[Cc, Cc], [B, B]], "n": 3, "expected": expected_of("search, all search_n, no search scheme", live)}}
+    # --- search_ng21 (always edit distance) over expanded pigeon_opt schemes
+    out["searches_ng21"] = {"source": "search/checkSearches.cpp:422-525", "sigma": 256, "sampling_rate": 1, "input": inp, "queries": [[Cc, Cc], [B, B]],
+                            "search": {"scheme": [0, 1], "expected": expected_of("search ng21, all search")},
+                            "search_n": {"scheme": [0, 1], "n": 3, "expected": expected_of("search ng21, all search_n")},
+                            "search_best": {"schemes": [[0, 0], [1, 1], [2, 2]], "expected": expected_of("search ng21, all search_best")},
+                            "search_best_n": {"schemes": [[0, 0], [1, 1]], "n": 3, "expected": expected_of("search ng21, all search_best_n")}}
     src = open(f"{TESTS}/search/checkSearchBacktracking.cpp").read()
     i = src.index("searching with collection and backtracking")
     bexp, p = _list_after(src, "auto expected = std::vector<uint8_t>{", i)

@@ -589,6 +589,137 @@ def test_edit_distance_equal_length_fast_path(k, length, sigma):
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)[0])
 
 
+# ------------------------------------------------------------------------------------------------ search_ng21 (expanded schemes)
+def test_ng21_reference_vectors():
+    """search/checkSearches.cpp:422-525: the located multisets the reference's tests expect from search_ng21::search / search_n /
+    search_best / search_best_n over expand(pigeon_opt(..), 2)"""
+    g = REF["searches_ng21"]
+    ox = fo.OraIndex.build("IB16", g["sigma"], g["input"], g["sampling_rate"], True)
+    gx = gpu_index(ox)
+    m = len(g["queries"][0])
+    ex = lambda a: fm.search_scheme.expand(fm.search_scheme.pigeon_opt(*a), m)
+
+    def located(hits):
+        owner, seq, pos, steps = fm.LocateLinear(gx, hits["lb"], hits["len"])()
+        return sorted([int(hits["qidx"][o]), int(a), int(b + s)] for o, a, b, s in zip(owner, seq, pos, steps))
+
+    assert located(fm.search_ng21.search(gx, g["queries"], ex(g["search"]["scheme"]))) == g["search"]["expected"]
+    assert located(fm.search_ng21.search_n(gx, g["queries"], ex(g["search_n"]["scheme"]), g["search_n"]["n"])) == g["search_n"]["expected"]
+    assert located(fm.search_ng21.search_best(gx, g["queries"], [ex(a) for a in g["search_best"]["schemes"]])) == g["search_best"]["expected"]
+    assert located(fm.search_ng21.search_best_n(gx, g["queries"], [ex(a) for a in g["search_best_n"]["schemes"]], g["search_best_n"]["n"])) == g["search_best_n"]["expected"]
+
+
+@pytest.mark.parametrize("layout,sigma,k,length", [("IB16", 5, 1, 20), ("IB16", 5, 2, 31), ("IB16", 5, 3, 18), ("WAVELET", 28, 1, 24), ("EPRV2_16", 5, 2, 27),
+                                                   ("IB16", 256, 1, 16), ("EPR16", 6, 2, 22), ("FBV_512_64K", 5, 2, 40), ("IB16", 5, 2, 101)])
+def test_ng21_matches_the_cpu_walk(layout, sigma, k, length):
+    """search_ng21: same cursors, error counts, callback order and number of extensions as the CPU restatement — several expanded schemes,
+    search_n clipping, search_best over 0..k errors, queries longer than the scheme (prefix searched) and shorter (skipped)"""
+    rng = np.random.default_rng(300 + sigma + k + length)
+    hi = min(sigma, 8)
+    base = rng.integers(1, hi, size=1500, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[300:800]]), rng.integers(1, hi, size=400, dtype=np.uint8)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 4, True)
+    gx = gpu_index(ox)
+    queries = []
+    for i in range(400 if k < 3 else 100):
+        p = int(rng.integers(0, len(seqs[0]) - length - 4)); q = list(seqs[0][p: p + length + 3])
+        for _ in range(int(rng.integers(0, k + 2))):
+            op = int(rng.integers(0, 3)); jj = int(rng.integers(0, len(q)))
+            if op == 0: q[jj] = int(rng.integers(1, hi))
+            elif op == 1: q.insert(jj, int(rng.integers(1, hi)))
+            else: del q[jj]
+        queries.append(np.array(q[:length], dtype=np.uint8))
+    qbuf, qoff = fm.flatten(queries)
+    schemes = [fm.search_scheme.expand(sc, length) for sc in (fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k), fm.search_scheme.backtracking(1, 0, k))]
+    total = 0
+    for ex in schemes:
+        hits, st = fm.search_ng21.search(gx, (qbuf, qoff), ex, want_stats=True, capacity=1 << 21)
+        ohits, qc, nodes = ox.search_ng21(qbuf, qoff, ex, cap=1 << 21)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes, (layout, k)
+        total += len(ohits)
+    assert total > 0
+    for n in (1, 3):
+        assert same_hits(fm.search_ng21.search_n(gx, (qbuf, qoff), schemes[0], n), ox.search_ng21(qbuf, qoff, schemes[0], max_hits=n)[0])
+    best = [fm.search_scheme.expand(fm.search_scheme.pigeon_opt(e, e), length) for e in range(k + 1)]
+    for n in (fm.UINT64_MAX, 2):
+        got = fm.search_ng21.search_best(gx, (qbuf, qoff), best, n)
+        want, _ = ox.search_ng21_best(qbuf, qoff, best, max_hits=n)
+        assert all(np.array_equal(got[f], want[f]) for f in ("qidx", "lb", "lb_rev", "len", "errors"))
+    ragged = [np.concatenate([queries[0], queries[1][:5]]), queries[2][: length - 1], queries[3], np.zeros(0, dtype=np.uint8)]
+    rb, ro = fm.flatten(ragged)
+    assert same_hits(fm.search_ng21.search(gx, (rb, ro), schemes[0]), ox.search_ng21(rb, ro, schemes[0])[0])
+    if sigma <= 8:                                            # with LF tables a one-row cursor takes its child from one 4-byte load
+        gx.accelerate_search(3, 1)
+        for ex in schemes:
+            hits, st = fm.search_ng21.search(gx, (qbuf, qoff), ex, want_stats=True, capacity=1 << 21)
+            ohits, qc, nodes = ox.search_ng21(qbuf, qoff, ex, cap=1 << 21)
+            assert same_hits(hits, ohits) and st.lf_steps == nodes, (layout, k)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_ng21_randomised_expanded_schemes(seed):
+    """hand-made expanded schemes — a random walk of the cursor's two ends, arbitrary (also decreasing) per-symbol bounds, several searches —
+    equal the CPU walk record by record"""
+    rng = np.random.default_rng(5000 + seed)
+    sigma = int(rng.choice([4, 5, 6]))
+    length = int(rng.integers(6, 30))
+    base = rng.integers(1, sigma, size=int(rng.integers(600, 1500)), dtype=np.uint8)
+    seqs = [np.concatenate([base, base[100:400]]), base[50:350][::-1].copy()]
+    ox = fo.OraIndex.build(str(rng.choice(["IB16", "EPRV2_16", "IBP16"])), sigma, seqs, 4, True)
+    gx = gpu_index(ox)
+    K = int(rng.integers(1, 4))
+    rows = []
+    for _ in range(int(rng.integers(1, 5))):
+        lo = hi = int(rng.integers(0, length)); pi = [lo]
+        while len(pi) < length:
+            if lo > 0 and (hi == length - 1 or rng.random() < 0.5): lo -= 1; pi.append(lo)
+            else: hi += 1; pi.append(hi)
+        u = np.minimum(K, np.sort(rng.integers(0, K + 2, size=length)))
+        if rng.random() < 0.3: u[int(rng.integers(0, length))] = int(rng.integers(0, K + 1))      # a bound that drops again
+        l = np.minimum(u, np.sort(rng.integers(0, K + 1, size=length)) * (rng.random(length) < 0.5))
+        rows.append((pi, l, u))
+    ex = tuple(np.array([r[j] for r in rows], dtype=np.uint64) for j in range(3))
+    queries = []
+    for i in range(200):
+        p = int(rng.integers(0, len(seqs[0]) - length - 4)); q = list(seqs[0][p: p + length + 3])
+        for _ in range(int(rng.integers(0, K + 1))):
+            op = int(rng.integers(0, 3)); jj = int(rng.integers(0, len(q)))
+            if op == 0: q[jj] = int(rng.integers(1, sigma))
+            elif op == 1: q.insert(jj, int(rng.integers(1, sigma)))
+            else: del q[jj]
+        queries.append(np.array(q[:length], dtype=np.uint8))
+    qbuf, qoff = fm.flatten(queries)
+    for n in (fm.UINT64_MAX, 2, fm.UINT64_MAX):
+        hits, st = fm.search_ng21.search(gx, (qbuf, qoff), ex, want_stats=True, capacity=1 << 21, n=n)
+        ohits, _, nodes = ox.search_ng21(qbuf, qoff, ex, max_hits=n, cap=1 << 21)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes, seed
+        if n == 2:
+            gx.accelerate_search(int(rng.integers(2, 5)), 1)  # the third pass runs with LF tables
+
+
+def test_ng21_argument_errors():
+    rng = np.random.default_rng(9)
+    text = rng.integers(1, 5, size=500, dtype=np.uint8)
+    bx = gpu_index(fo.OraIndex.build("IB16", 5, [text], 4, True))
+    ux = gpu_index(fo.OraIndex.build("IB16", 5, [text], 4, False))
+    ex = fm.search_scheme.expand(fm.search_scheme.pigeon_opt(0, 1), 10)
+    q = [text[5:15]]
+    with pytest.raises(fm.FmgpuError):
+        fm.search_ng21.search(ux, q, ex)                               # needs a BiFMIndex
+    pi, l, u = (np.array(a, dtype=np.uint64).copy() for a in ex)
+    bad = pi.copy(); bad[0, 0] = 10
+    with pytest.raises(fm.FmgpuError):
+        fm.search_ng21.search(bx, q, (bad, l, u))
+    gap = pi.copy(); gap[0, [1, 2]] = gap[0, [2, 1]]
+    with pytest.raises(fm.FmgpuError):
+        fm.search_ng21.search(bx, q, (gap, l, u))                      # the cursor cannot jump over a symbol
+    big = u.copy(); big[0, -1] = 200
+    with pytest.raises(fm.FmgpuError):
+        fm.search_ng21.search(bx, q, (pi, l, big))
+    empty = tuple(np.zeros((0, 10), dtype=np.uint64) for _ in range(3))
+    assert len(fm.search_ng21.search(bx, q, empty)) == 0                # SearchNg21.h:205: an empty scheme reports nothing
+
+
 @pytest.mark.parametrize("seed", list(range(40)))
 def test_randomised_schemes_partitions_and_tables(seed):
     """random texts, read lengths, schemes (h2 / pigeon / backtracking / expanded), explicit partitions with tiny parts (several part ends

@@ -371,6 +371,63 @@ def test_edit_distance_fixtures():
         assert _located(x, hits) == c["expected"], key
 
 
+def test_ng21_fixtures():
+    """search/checkSearches.cpp:422-525: search_ng21::search / search_n / search_best / search_best_n over expand(pigeon_opt(..), 2)"""
+    g = REF["searches_ng21"]
+    x = fo.OraIndex.build("IB16", g["sigma"], g["input"], g["sampling_rate"], True)
+    qbuf, qoff = fo.flatten_queries(g["queries"])
+    m = len(g["queries"][0])
+    ex = lambda a: fo.scheme_expand(fo.scheme_pigeon_opt(*a), m)
+    hits, _, _ = x.search_ng21(qbuf, qoff, ex(g["search"]["scheme"]))
+    assert _located(x, hits) == g["search"]["expected"]
+    hits, _, _ = x.search_ng21(qbuf, qoff, ex(g["search_n"]["scheme"]), max_hits=g["search_n"]["n"])
+    assert _located(x, hits) == g["search_n"]["expected"]
+    hits, _ = x.search_ng21_best(qbuf, qoff, [ex(a) for a in g["search_best"]["schemes"]])
+    assert _located(x, hits) == g["search_best"]["expected"]
+    hits, _ = x.search_ng21_best(qbuf, qoff, [ex(a) for a in g["search_best_n"]["schemes"]], max_hits=g["search_best_n"]["n"])
+    assert _located(x, hits) == g["search_best_n"]["expected"]
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_ng21_sound_and_covering(k):
+    """search_ng21 reports cursors of alignments with at most k edits: every reported occurrence is within its error count of the query,
+    and every text substring within edit distance k has a reported occurrence starting at most k positions away (it prunes equivalent
+    alignments like search_ng26<Edit = true>, SearchNg21.h:97-98)"""
+    rng = np.random.default_rng(70 + k)
+    seqs = [rng.integers(1, 5, size=260, dtype=np.uint8), rng.integers(1, 5, size=120, dtype=np.uint8)]
+    text = _concat(seqs)
+    x = fo.OraIndex.build("IB16", 5, seqs, 1, True)
+    starts = np.cumsum([0] + [len(s) + 1 for s in seqs])
+    m = 12
+    queries = []
+    for i in range(25):
+        p = int(rng.integers(0, len(seqs[0]) - m - 2)); q = list(seqs[0][p: p + m + 2])
+        for _ in range(int(rng.integers(0, k + 1))):
+            op = int(rng.integers(0, 3)); at = int(rng.integers(1, m - 1))
+            if op == 0: q[at] = int(rng.integers(1, 5))
+            elif op == 1: del q[at]
+            else: q.insert(at, int(rng.integers(1, 5)))
+        queries.append(np.array(q[:m], dtype=np.uint8))
+    qbuf, qoff = fo.flatten_queries(queries)
+    hits, _, _ = x.search_ng21(qbuf, qoff, fo.scheme_expand(fo.scheme_pigeon_opt(0, k), m))
+    found = {}
+    for h in hits:
+        for r in range(int(h["lb"]), int(h["lb"] + h["len"])):
+            s_, p_, o_ = x.locate(r)
+            at = int(starts[s_]) + p_ + o_
+            e = int(h["errors"])
+            assert e <= k
+            assert any(at + ln <= len(text) and 0 not in text[at: at + ln] and _edit_distance(list(queries[int(h["qidx"])]), list(text[at: at + ln])) <= e
+                       for ln in range(max(1, m - e), m + e + 1)), (h, at)
+            found.setdefault(int(h["qidx"]), set()).add(at)
+    for qi, q in enumerate(queries):
+        for at in range(len(text)):
+            for ln in range(m - k, m + k + 1):
+                sub = text[at: at + ln]
+                if len(sub) == ln and 0 not in sub and _edit_distance(list(q), list(sub)) <= k:
+                    assert any(abs(at - f) <= k for f in found.get(qi, ())), (qi, at, ln)
+
+
 @pytest.mark.parametrize("k", [1, 2, 3])
 def test_ng26_full_state_machine_equals_hamming_reduction(k):
     """the line-by-line restatement (nge_*, Edit = false) and the Hamming reduction of SURVEY appendix A (ng_*) agree hit by hit,
