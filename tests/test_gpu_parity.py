@@ -589,6 +589,86 @@ def test_edit_distance_equal_length_fast_path(k, length, sigma):
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)[0])
 
 
+# ------------------------------------------------------------------------------------------------ concurrency (threads, streams)
+def test_concurrent_host_threads_on_one_handle():
+    """the reference is re-entrant on a const index; so is the C-ABI: four host threads run exact, k-mismatch, edit-distance, search_ng21
+    and locate calls on the same handle at the same time (ctypes releases the GIL during a call) and every result equals the oracle's"""
+    import threading
+    rng = np.random.default_rng(21)
+    base = rng.integers(1, 5, size=6000, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[1000:3000]]), rng.integers(1, 5, size=1500, dtype=np.uint8)]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
+    gx = gpu_index(ox)
+    gx.accelerate(3, lut_len=5, walk=True).accelerate_search(4, 3)
+    sch = fm.search_scheme.h2(3, 0, 1)
+    work = []
+    for t in range(4):
+        r = np.random.default_rng(100 + t)
+        reads = []
+        for i in range(600):
+            p = int(r.integers(0, len(seqs[0]) - 40)); q = seqs[0][p: p + 36].copy()
+            if i % 2: q[int(r.integers(0, 36))] = r.integers(1, 5)
+            reads.append(q)
+        qbuf, qoff = fm.flatten(reads)
+        rows = r.integers(0, ox.n, size=500).astype(np.uint64)
+        ex = fm.search_scheme.expand(fm.search_scheme.pigeon_opt(0, 1), 36)
+        want = (ox.search_exact(qbuf, qoff), ox.search_ng26(qbuf, qoff, sch)[0], ox.search_ng26(qbuf, qoff, sch, edit=True)[0],
+                ox.search_ng21(qbuf, qoff, ex)[0], [ox.locate(int(x)) for x in rows])
+        work.append((qbuf, qoff, rows, ex, want))
+    errors = []
+
+    def run(t):
+        try:
+            qbuf, qoff, rows, ex, want = work[t]
+            for rep in range(6):
+                lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
+                assert np.array_equal(lb, want[0][0]) and np.array_equal(ln, want[0][1])
+                assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch), want[1])
+                assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, edit=True), want[2])
+                assert same_hits(fm.search_ng21.search(gx, (qbuf, qoff), ex), want[3])
+                seq, pos, steps = gx.locate(rows)
+                assert [(int(a), int(b), int(c)) for a, b, c in zip(seq, pos, steps)] == [tuple(int(v) for v in w) for w in want[4]]
+        except BaseException as e:                            # noqa: BLE001 — reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errors, errors
+
+
+def test_calls_on_caller_streams_with_device_buffers():
+    """queries and results in HBM, two caller-owned HIP streams in flight at once: each call's result is complete once ITS stream is synchronised
+    (streams from the HIP runtime libfmgpu.so itself is linked against — a second runtime in the process would not see its device)"""
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(22)
+    text = rng.integers(1, 5, size=50000, dtype=np.uint8)
+    ox = fo.OraIndex.build("IB16", 5, [text], 8, False)
+    gx = gpu_index(ox)
+    L = capi.lib()
+    jobs = []
+    for k in range(2):
+        st = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(st)) == 0
+        reads = sample_reads(text, 20000, 60, seed=30 + k, mutate=1)
+        qbuf, qoff = fm.flatten(reads)
+        nq = len(reads)
+        dq, do = fm.DeviceBuffer.from_array(qbuf), fm.DeviceBuffer.from_array(qoff.astype(np.uint64))
+        dl, dn = fm.DeviceBuffer.from_array(np.full(nq, 2**64 - 1, dtype=np.uint64)), fm.DeviceBuffer.from_array(np.full(nq, 2**64 - 1, dtype=np.uint64))
+        jobs.append((st, dq, do, dl, dn, ox.search_exact(qbuf, qoff), nq))
+    for rep in range(3):
+        for st, dq, do, dl, dn, want, nq in jobs:
+            capi.check(L.fmgpu_search_exact(gx._h, C.c_void_p(dq.ptr), C.c_void_p(do.ptr), nq, C.c_void_p(dl.ptr), C.c_void_p(dn.ptr), None, st))
+        for st, dq, do, dl, dn, want, nq in jobs:
+            assert hip.hipStreamSynchronize(st) == 0
+            assert np.array_equal(dl.to_array(np.uint64, nq), want[0]) and np.array_equal(dn.to_array(np.uint64, nq), want[1])
+    for st, *_ in jobs:
+        hip.hipStreamDestroy(st)
+
+
 # ------------------------------------------------------------------------------------------------ search_ng21 (expanded schemes)
 def test_ng21_reference_vectors():
     """search/checkSearches.cpp:422-525: the located multisets the reference's tests expect from search_ng21::search / search_n /
