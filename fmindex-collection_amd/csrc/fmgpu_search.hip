@@ -1785,6 +1785,7 @@ __global__ __launch_bounds__(256) void k_locate(Occ occ, const idx_t* __restrict
 // returning, so it is idle between calls), `sink` the others (never read).
 struct CallScratch {
     unsigned long long* ctr = nullptr; unsigned long long* sink = nullptr; unsigned long long* len2 = nullptr;
+    unsigned long long* pinned = nullptr;                         // host side of the small read-backs (a pageable target costs a staging copy each)
     hipEvent_t ev_a = nullptr, ev_b = nullptr; int dev = -1;
 };
 static int call_scratch(CallScratch** out) {
@@ -1795,7 +1796,8 @@ static int call_scratch(CallScratch** out) {
         sc = CallScratch{}; sc.dev = dev;
         FM_HIP(hipMalloc((void**)&sc.ctr, kCounterStripes * 8));
         FM_HIP(hipMalloc((void**)&sc.sink, kCounterStripes * 8));
-        FM_HIP(hipMalloc((void**)&sc.len2, 16));
+        FM_HIP(hipMalloc((void**)&sc.len2, (2 * 1024 + 1) * 8));
+        FM_HIP(hipHostMalloc((void**)&sc.pinned, (2 * 1024 + 1) * 8, hipHostMallocDefault));
         FM_HIP(hipEventCreate(&sc.ev_a));
         FM_HIP(hipEventCreate(&sc.ev_b));
     }
@@ -1810,11 +1812,13 @@ static int step_counters(bool want, hipStream_t stream, unsigned long long** out
     return 0;
 }
 static int read_step_counters(const unsigned long long* dev, hipStream_t stream, unsigned long long* total) {
-    unsigned long long h[kCounterStripes];
-    FM_HIP(hipMemcpyAsync(h, dev, sizeof h, hipMemcpyDeviceToHost, stream));
+    CallScratch* sc = nullptr;
+    int rc = call_scratch(&sc); if (rc) return rc;
+    unsigned long long* h = sc->pinned;
+    FM_HIP(hipMemcpyAsync(h, dev, kCounterStripes * 8, hipMemcpyDeviceToHost, stream));
     FM_HIP(hipStreamSynchronize(stream));
     unsigned long long t = 0;
-    for (unsigned long long v : h) t += v;
+    for (unsigned k = 0; k < kCounterStripes; ++k) t += h[k];
     *total = t;
     return 0;
 }
@@ -1850,9 +1854,12 @@ static int dispatch_occ(const DevString& s, F&& f) {
     }
 }
 
-// longest and shortest query: a tiny reduction kernel (queries may live in HBM)
+// longest and shortest query and the total symbol count of a batch whose offsets live in HBM: one reduction kernel, one small copy,
+// one synchronisation (per-block partial results reduced on the host: no atomics, nothing to initialise)
+constexpr unsigned kLenBlocks = 1024;
 __global__ __launch_bounds__(256) void k_len_range(const uint64_t* __restrict__ qoff, uint64_t nq, unsigned long long* __restrict__ out) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long s_v[4], s_w[4];
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v = 0, w = ~0ull;
     for (uint64_t q = t; q < nq; q += (uint64_t)gridDim.x * blockDim.x) { unsigned long long l = qoff[q + 1] - qoff[q]; v = l > v ? l : v; w = l < w ? l : w; }
 #pragma unroll
@@ -1860,24 +1867,34 @@ __global__ __launch_bounds__(256) void k_len_range(const uint64_t* __restrict__ 
         unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v;
         unsigned long long p = __shfl_xor(w, off, 64); w = p < w ? p : w;
     }
-    if ((threadIdx.x & 63u) == 0) { atomicMax(out, v); atomicMin(out + 1, w); }
+    if ((threadIdx.x & 63u) == 0) { s_v[threadIdx.x >> 6] = v; s_w[threadIdx.x >> 6] = w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { v = s_v[i] > v ? s_v[i] : v; w = s_w[i] < w ? s_w[i] : w; }
+        out[2 * blockIdx.x] = v; out[2 * blockIdx.x + 1] = w;
+        if (blockIdx.x == 0) out[2 * gridDim.x] = qoff[nq];
+    }
 }
 
-__global__ void k_len_init(unsigned long long* d) { d[0] = 0ull; d[1] = ~0ull; }
-static int query_len_range(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out_max, uint32_t* out_min) {
+static int query_shape(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out_max, uint32_t* out_min, uint64_t* out_total) {
     CallScratch* sc = nullptr;
     int rc = call_scratch(&sc); if (rc) return rc;
     unsigned long long* d = sc->len2;
-    k_len_init<<<1, 1, 0, stream>>>(d);
-    unsigned blocks = (unsigned)std::min<uint64_t>((nq + 255) / 256, 1024);
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + 255) / 256, kLenBlocks));
     k_len_range<<<dim3(blocks), dim3(256), 0, stream>>>(dqoff, nq, d);
-    unsigned long long h[2] = {0, 0};
-    hipError_t e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, stream);
+    unsigned long long* h = sc->pinned;
+    hipError_t e = hipMemcpyAsync(h, d, ((size_t)2 * blocks + 1) * 8, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return hip_fail(e, "k_len_range");
-    *out_max = (uint32_t)std::min<unsigned long long>(h[0], 0xffffffffull);
-    *out_min = (uint32_t)std::min<unsigned long long>(h[1], 0xffffffffull);
+    unsigned long long mx = 0, mn = ~0ull;
+    for (unsigned b = 0; b < blocks; ++b) { mx = std::max(mx, h[2 * b]); mn = std::min(mn, h[2 * b + 1]); }
+    *out_max = (uint32_t)std::min<unsigned long long>(mx, 0xffffffffull);
+    *out_min = (uint32_t)std::min<unsigned long long>(mn, 0xffffffffull);
+    if (out_total) *out_total = h[2 * blocks];
     return 0;
+}
+static int query_len_range(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out_max, uint32_t* out_min) {
+    return query_shape(dqoff, nq, stream, out_max, out_min, nullptr);
 }
 
 // expands a scheme for queries of length m into the fast kernel's per-step table (see k_scheme_fast); false if it does not fit.
@@ -1985,7 +2002,9 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     int rc;
     if ((rc = soff.in(qoff, (nq + 1) * 8, stream))) return rc;
     uint64_t total = 0;
-    if (is_device_pointer(qoff)) { FM_HIP(hipMemcpyAsync(&total, qoff + nq, 8, hipMemcpyDeviceToHost, stream)); FM_HIP(hipStreamSynchronize(stream)); }
+    uint32_t shape_max = 0, shape_min = 0;
+    bool have_shape = false;                                     // offsets in HBM: total and length range come back in one copy
+    if (is_device_pointer(qoff)) { if ((rc = query_shape((const uint64_t*)soff.dev, nq, stream, &shape_max, &shape_min, &total))) return rc; have_shape = true; }
     else total = qoff[nq];
     if ((rc = sbuf.in(qbuf, total, stream))) return rc;
     if ((rc = slb.out(out_lb, nq * 8, stream))) return rc;
@@ -2000,7 +2019,8 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     const bool accel = x->bwt.kblk || x->bwt.slut || x->bwt.walkj;
     if (accel) {                                                 // LDS staging needs the longest query of the batch
         uint32_t mn = 0;
-        if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &kq_max, &mn))) return rc;
+        if (have_shape) kq_max = shape_max;
+        else if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &kq_max, &mn))) return rc;
         kq_words = kq_nib ? (kq_max + 7) / 8 : (kq_max + 3) / 4;
         if ((size_t)kq_words * 1024 > 48 * 1024) kq_words = 0;  // very long queries: read them from global memory
         timer.start();
@@ -2019,8 +2039,8 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
         if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, 0, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         else k_exact_a<0><<<grid, block, 0, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
     } else if (x->bwt.search_family() == FAM_WAVELET) {
-        uint32_t mx = 0, mn = 0;
-        if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) return rc;
+        uint32_t mx = shape_max, mn = 0;
+        if (!have_shape && (rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) return rc;
         uint32_t qw = (mx + 3) / 4;
         if ((size_t)qw * 1024 > 48 * 1024) qw = 0;
         timer.start();
@@ -2091,12 +2111,13 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     int rc;
     if ((rc = soff.in(qoff, (nq + 1) * 8, stream))) return rc;
     uint64_t total = 0;
-    if (is_device_pointer(qoff)) { FM_HIP(hipMemcpyAsync(&total, qoff + nq, 8, hipMemcpyDeviceToHost, stream)); FM_HIP(hipStreamSynchronize(stream)); }
+    uint32_t maxlen = 0, minlen = 0;
+    const bool have_shape = is_device_pointer(qoff);             // offsets in HBM: total and length range come back in one copy
+    if (have_shape) { if ((rc = query_shape((const uint64_t*)soff.dev, nq, stream, &maxlen, &minlen, &total))) return rc; }
     else total = qoff[nq];
     if ((rc = sbuf.in(qbuf, total, stream))) return rc;
     if ((rc = sout.out(out, capacity * sizeof(fmgpu_hit), stream))) return rc;
-    uint32_t maxlen = 0, minlen = 0;
-    if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &maxlen, &minlen))) return rc;
+    if (!have_shape && (rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &maxlen, &minlen))) return rc;
     if (maxlen > 0xfffeu) return fail(FMGPU_ERR_UNSUPPORTED, "queries longer than 65534 symbols");
     static std::mutex occ_mu; static std::map<std::tuple<int, int, int, size_t>, int> occ_cache;
     int bpc = 8;
