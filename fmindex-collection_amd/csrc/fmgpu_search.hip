@@ -1786,6 +1786,8 @@ __global__ __launch_bounds__(256) void k_locate(Occ occ, const idx_t* __restrict
 struct CallScratch {
     unsigned long long* ctr = nullptr; unsigned long long* sink = nullptr; unsigned long long* len2 = nullptr;
     unsigned long long* pinned = nullptr;                         // host side of the small read-backs (a pageable target costs a staging copy each)
+    void* frames = nullptr; size_t frames_bytes = 0;              // frame stacks of the DFS kernels, kept between calls up to kFrameCache bytes
+    void* dfs_ctr = nullptr;                                      // their Counters (a DFS call synchronises before it returns: one at a time per thread)
     hipEvent_t ev_a = nullptr, ev_b = nullptr; int dev = -1;
 };
 static int call_scratch(CallScratch** out) {
@@ -1793,11 +1795,13 @@ static int call_scratch(CallScratch** out) {
     int dev = 0;
     FM_HIP(hipGetDevice(&dev));
     if (sc.dev != dev) {                                          // first use on this device (objects of an earlier device are left to the process)
+        if (sc.frames) (void)hipFree(sc.frames);                   // (the frame stacks are the one object worth returning)
         sc = CallScratch{}; sc.dev = dev;
         FM_HIP(hipMalloc((void**)&sc.ctr, kCounterStripes * 8));
         FM_HIP(hipMalloc((void**)&sc.sink, kCounterStripes * 8));
         FM_HIP(hipMalloc((void**)&sc.len2, (2 * 1024 + 1) * 8));
         FM_HIP(hipHostMalloc((void**)&sc.pinned, (2 * 1024 + 1) * 8, hipHostMallocDefault));
+        FM_HIP(hipMalloc(&sc.dfs_ctr, 64));
         FM_HIP(hipEventCreate(&sc.ev_a));
         FM_HIP(hipEventCreate(&sc.ev_b));
     }
@@ -1958,11 +1962,15 @@ __global__ __launch_bounds__(256) void k_len_pairs(const uint64_t* __restrict__ 
     if (q < nq) { len[q] = (uint32_t)(qoff[q + 1] - qoff[q]); idx[q] = (uint32_t)q; }
 }
 
+constexpr size_t kFrameCache = (size_t)2 << 30;
 struct DfsWorkspace {
     uint64_t* planes = nullptr; Counters* ctr = nullptr; StackView view{};
     unsigned grid = 0;
+    bool own_planes = false;
     // blocks_per_cu: resident 256-lane blocks of the kernel that will run (the lanes walk the batch with a static stride, so
-    // every block must be resident from the start or the late ones form a tail)
+    // every block must be resident from the start or the late ones form a tail).
+    // The frame stacks (~1 GB for a full-chip launch over 101-symbol reads) stay with the calling host thread between calls: allocating and
+    // freeing them per call costs ~0.2 ms (hipFree synchronises the device), 2-3 % of a 10 M-read k = 2 call.
     int init(uint32_t depth, uint64_t nq, int blocks_per_cu, hipStream_t stream, int nplanes = 3) {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
@@ -1971,15 +1979,26 @@ struct DfsWorkspace {
         grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (nq + 255) / 256));
         view.nlanes = (uint64_t)grid * 256; view.depth = depth;
         uint64_t words = view.nlanes * ((uint64_t)depth + 1);
-        FM_HIP(hipMalloc((void**)&planes, words * 8 * (size_t)nplanes));
+        const size_t need = words * 8 * (size_t)nplanes;
+        CallScratch* sc = nullptr;
+        int rc = call_scratch(&sc); if (rc) return rc;
+        if (need <= kFrameCache) {
+            if (sc->frames_bytes < need) {
+                if (sc->frames) { (void)hipFree(sc->frames); sc->frames = nullptr; sc->frames_bytes = 0; }
+                FM_HIP(hipMalloc(&sc->frames, need));
+                sc->frames_bytes = need;
+            }
+            planes = (uint64_t*)sc->frames;
+        } else {
+            FM_HIP(hipMalloc((void**)&planes, need));
+            own_planes = true;
+        }
         view.p0 = planes; view.p1 = planes + words; view.p2 = planes + 2 * words; view.p3 = nplanes > 3 ? planes + 3 * words : nullptr;
-        FM_HIP(hipMalloc((void**)&ctr, sizeof(Counters)));
-        Counters init{0, 0, 0};                                             // next: the query hand-out counter of the scheme kernels
-        FM_HIP(hipMemcpyAsync(ctr, &init, sizeof(Counters), hipMemcpyHostToDevice, stream));
-        FM_HIP(hipStreamSynchronize(stream));
+        ctr = (Counters*)sc->dfs_ctr;
+        FM_HIP(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));            // next: the query hand-out counter of the scheme kernels
         return 0;
     }
-    ~DfsWorkspace() { if (planes) (void)hipFree(planes); if (ctr) (void)hipFree(ctr); }
+    ~DfsWorkspace() { if (planes && own_planes) (void)hipFree(planes); }
 };
 
 }  // namespace fmgpu
