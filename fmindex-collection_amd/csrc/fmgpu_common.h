@@ -127,6 +127,24 @@ struct OccA {
         symb = c;
         return e.cnt + popc64(e.bits & lowmask(bit));
     }
+    // all2 in two halves for SIGMA <= 5 (one 64-byte block per end): the loads alone, so that a caller can issue them next to other lanes'
+    // loads of a divergent wave before anything is consumed, and the arithmetic
+    __device__ __forceinline__ void load2(idx_t a, idx_t b, uint32_t* da, uint32_t* db) const {
+        const uint4* pa = reinterpret_cast<const uint4*>(v.blk + (size_t)(a >> 6) * 64u);
+        const uint4* pb = reinterpret_cast<const uint4*>(v.blk + (size_t)(b >> 6) * 64u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { uint4 t = pa[k]; da[4 * k] = t.x; da[4 * k + 1] = t.y; da[4 * k + 2] = t.z; da[4 * k + 3] = t.w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { uint4 t = pb[k]; db[4 * k] = t.x; db[4 * k + 1] = t.y; db[4 * k + 2] = t.z; db[4 * k + 3] = t.w; }
+    }
+    __device__ __forceinline__ void all2_of(const uint32_t* da, const uint32_t* db, idx_t a, idx_t b, idx_t* lfa, idx_t* lfb) const {
+        const uint64_t ma = lowmask(a & 63u), mb = lowmask(b & 63u);
+#pragma unroll
+        for (uint32_t c = 0; c < (uint32_t)(SIGMA > 0 ? SIGMA : 1); ++c) {
+            lfa[c] = da[3 * c] + popc64(((uint64_t)da[3 * c + 1] | ((uint64_t)da[3 * c + 2] << 32)) & ma);
+            lfb[c] = db[3 * c] + popc64(((uint64_t)db[3 * c + 1] | ((uint64_t)db[3 * c + 2] << 32)) & mb);
+        }
+    }
     template <int MS>
     __device__ __forceinline__ void all2(idx_t a, idx_t b, idx_t* lfa, idx_t* lfb) const {
         const uint32_t s = sigma();

@@ -305,7 +305,7 @@ int build_lf_table(DevString& s, hipStream_t stream) {
     const char* e = getenv("FMGPU_LF_TABLE");
     if (e && atoi(e) == 0) return 0;
     if (s.n == 0) return 0;
-    FM_HIP(hipMalloc((void**)&s.lf_table, s.n * sizeof(idx_t)));
+    FM_HIP(hipMalloc((void**)&s.lf_table, s.n * sizeof(idx_t) + 16));   // (+16: k_scheme_fast reads 16 bytes at a row)
     dim3 grid((unsigned)((s.n + 255) / 256)), block(256);
     switch (s.family) {
     case FAM_A:

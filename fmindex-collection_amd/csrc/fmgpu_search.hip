@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
 constexpr uint32_t kHitBuf = 2;      // hits buffered per lane and round in LDS; further hits of the same query are emitted directly
 
 template <int SIGMA, int MAXSIG>
-__global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
+__global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
                                                                           uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap) {
@@ -1278,13 +1278,39 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                 const bool multi = cur.len > 1;
                 const idx_t a = right ? cur.lbRev : cur.lb;
                 bool back = false;
+                // ---- memory phase: the lanes of a wave sit in different kinds of nodes; every lane issues its loads here, before any lane
+                // consumes one, so that an iteration costs one round trip and not one per kind of node present in the wave
+                // (ONE unconditional 16-byte load per lane — the first quarter of a multi-row lane's block, or a one-row lane's walk / LF^1..3 /
+                // LF entry, all dword-aligned, the tables carry 16 bytes of slack — and the rest of the two blocks right behind it)
+                constexpr bool kSplit = SIGMA > 0 && SIGMA <= 5;
+                const uint2* wj = right ? fa.wj_rv : fa.wj_fw;
+                const idx_t* w3 = right ? fa.w3_rv : fa.w3_fw;
+                const bool use_wj = !multi && wj && ((ent >> 29) & 1u);
+                const uint8_t* blk = (right ? rv : fw).v.blk;
+                const uint8_t* p0 = (multi && kSplit) ? blk + (size_t)(a >> 6) * 64u
+                                  : use_wj ? reinterpret_cast<const uint8_t*>(wj + a)
+                                  : w3 ? reinterpret_cast<const uint8_t*>(w3 + 3u * (size_t)a)
+                                  : reinterpret_cast<const uint8_t*>((right ? fa.lf_rv : fa.lf_fw) + a);
+                const uint4 r0 = *reinterpret_cast<const uint4*>(p0);
+                uint4 r1, r2, r3, s0, s1, s2, s3;
+                if (multi && kSplit) {
+                    const uint4* pa = reinterpret_cast<const uint4*>(p0);
+                    const uint4* pb = reinterpret_cast<const uint4*>(blk + (size_t)((a + cur.len) >> 6) * 64u);
+                    r1 = pa[1]; r2 = pa[2]; r3 = pa[3]; s0 = pb[0]; s1 = pb[1]; s2 = pb[2]; s3 = pb[3];
+                }
+                const uint2 we = make_uint2(r0.x, r0.y);
+                idx_t t0 = r0.x, t1 = r0.y, t2 = r0.z;
                 if (multi) {
                     // ---- extend-all node (search_next_dir, :143-224) or exact-tail step over several rows
                     const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
                     const bool lastp = (ent >> 17) & 1u;
                     idx_t lfa[MAXSIG], lfb[MAXSIG];
                     const OccA<SIGMA>& occ = right ? rv : fw;
-                    occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
+                    if constexpr (kSplit) {
+                        const uint32_t da[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+                        const uint32_t db[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+                        occ.all2_of(da, db, a, a + cur.len, lfa, lfb);
+                    } else occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
                     const SymSet<MAXSIG> alive = alive_set<MAXSIG>(lfa, lfb, sigma);
                     const uint32_t c = qstage_get(qst, qs, pos);
                     const bool c_alive = alive.test(c);
@@ -1316,28 +1342,56 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                     } else back = true;
                 } else {
                     // ---- single row (search_next_dir_single, :251-365): the only child is the BWT symbol of the row; up to `run` steps per load
-                    const uint2* wj = right ? fa.wj_rv : fa.wj_fw;
                     bool walked = false;
-                    if (wj && ((ent >> 29) & 1u)) {
+                    if (use_wj) {
                         // 16 steps in one go: the walk table gives LF^16 and the 16 symbols met; they are compared with the query's 16 symbols as
                         // two 32-bit codes.  All equal and one window check for the whole stretch: done; otherwise step by step from registers.
-                        const uint2 we = wj[a];
                         if (we.x != 0xffffffffu) {
                             walked = true;
                             bool qvalid = false;
                             const uint32_t qc = query_code16(qst, ent & 0xffffu, right, qvalid);
                             const uint32_t sw = s_stretch[si * stride + j];
                             const uint32_t tb = sw & 31u, hi1 = (sw >> 5) & 63u, hi2 = (sw >> 11) & 63u, lo = (sw >> 17) & 31u;
-                            if (qvalid && qc == we.y && ((sw >> 22) & 1u) && lo <= e && e <= hi1) {
-                                // every step is a match inside its window; extensions as the reference counts them: one per step plus one where an
-                                // exact tail starts (no error left in the part and not in a tail yet), :310-314
-                                uint32_t bonus = (!in_tail && e == hi1) ? 1u : 0u;
-                                bool it = tb < 16u ? false : (in_tail || e == hi1);
-                                if (tb < 15u) { bonus += (e == hi2) ? 1u : 0u; it = e == hi2; }
-                                nodes += 16u + bonus;
-                                in_tail = it;
-                                if (right) cur.lbRev = we.x; else cur.lb = we.x;
-                                j += 16u;
+                            if (qvalid && ((sw >> 22) & 1u)) {
+                                // A stretch with at most one part end (at offset tb; 16: none), walked run by run instead of step by step: a run of
+                                // matching symbols, then the differing symbol that ends it.  Steps up to tb have the window [.., hi1], later ones
+                                // [.., hi2]; the lower bound lo binds at step tb only.  Extensions are counted as the reference performs them: one
+                                // per step, one more where an exact tail starts (a match with no error left and not in a tail yet, :310-314), and
+                                // the step at which a branch ends is its last.  A wave spends as many rounds here as its lane with the most
+                                // differing symbols (a branch survives at most hi2 - e of them), not 16.
+                                const uint32_t diff = qc ^ we.y;
+                                const uint32_t mm = (diff | (diff >> 1)) & 0x55555555u;          // bit 2k: step k differs
+                                uint32_t x = 0;
+                                bool dead = false;
+                                while (!dead && x < 16u) {
+                                    const uint32_t rest = mm >> (2u * x);
+                                    const uint32_t p = rest ? x + (((uint32_t)__ffs((int)rest) - 1u) >> 1) : 16u;   // next differing step
+                                    uint32_t xb = x;
+                                    if (x < p && x <= tb) {                                      // matching steps up to the part end
+                                        if (e > hi1 || (x == tb && e < lo)) { nodes += 1u; dead = true; }
+                                        else {
+                                            const uint32_t bonus = (!in_tail && e == hi1) ? 1u : 0u;
+                                            in_tail = in_tail || e == hi1;
+                                            if (tb < p) {
+                                                if (tb > x && e < lo) { nodes += (tb - x) + bonus + 1u; dead = true; }
+                                                else { nodes += (tb + 1u - x) + bonus; in_tail = false; xb = tb + 1u; }
+                                            } else { nodes += (p - x) + bonus; xb = p; }
+                                        }
+                                    }
+                                    if (!dead && xb < p) {                                       // matching steps behind the part end
+                                        if (e > hi2) { nodes += 1u; dead = true; }
+                                        else { nodes += (p - xb) + ((!in_tail && e == hi2) ? 1u : 0u); in_tail = in_tail || e == hi2; }
+                                    }
+                                    if (!dead && p < 16u) {                                      // the differing step: a substitution or the end
+                                        nodes += 1u;
+                                        const uint32_t maxp = p <= tb ? hi1 : hi2, minp = p == tb ? lo : 0u;
+                                        if (minp <= e + 1u && e + 1u <= maxp) { e += 1u; in_tail = p != tb && in_tail; }
+                                        else dead = true;
+                                    }
+                                    x = p + 1u;
+                                }
+                                if (dead) back = true;
+                                else { if (right) cur.lbRev = we.x; else cur.lb = we.x; j += 16u; }
                             } else {
                                 bool dead = false;
                                 for (uint32_t kk = 0; kk < 16u && !dead; ++kk) {
@@ -1362,11 +1416,11 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 6 : 1) void k_scheme_fast(OccA<SI
                         }
                     }
                     if (!walked) {
-                    const idx_t* w3 = right ? fa.w3_rv : fa.w3_fw;
                     const uint32_t run = w3 ? (ent >> 30) : 1u;    // consecutive steps in this direction (<= 3), never past the query end
-                    idx_t t0, t1 = 0, t2 = 0;
-                    if (w3) { const idx_t* p = w3 + 3u * (size_t)a; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
-                    else t0 = (right ? fa.lf_rv : fa.lf_fw)[a];
+                    if (use_wj) {                                   // (a walk entry that crosses a delimiter: the steps one load later)
+                        if (w3) { const idx_t* p = w3 + 3u * (size_t)a; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
+                        else t0 = (right ? fa.lf_rv : fa.lf_fw)[a];
+                    }
                     idx_t tk = t0, last = t0;
                     uint32_t k = 0;
                     bool dead = false;
