@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--walk", type=int, default=2, help="exact / protein: 1 = LF^J walk table, 2 = LF^J and LF^2J")
     ap.add_argument("--prefix-len", type=int, default=15, help="k2: symbols of the prefix table (fmgpu_index_accelerate_search)")
     ap.add_argument("--trim", type=int, default=0, help="dev: every read loses 0..TRIM symbols at its end (a ragged batch)")
+    ap.add_argument("--sub-every", type=int, default=10, help="exact / protein: every n-th read carries one substitution (default 10 = SURVEY 8d; 0 = none; a dev knob)")
     ap.add_argument("--ng21", action="store_true", help="k2: search_ng21 over expand(h2(4,0,2), read length) (edit distance; the reference's older algorithm) — a side measurement")
     ap.add_argument("--edit", action="store_true", help="k2: edit distance (search_ng26<Edit = true>) instead of Hamming distance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,7 +153,7 @@ def main():
         hi = min(nq, lo + (1 << 20))
         reads[lo:hi] = text[starts[lo:hi, None] + ar[None, :]]
     if args.workload != "k2":                                 # 10 % of the reads carry one substitution (early exits)
-        rows = torch.arange(0, nq, 10, device=dev)
+        rows = torch.arange(0, nq, args.sub_every, device=dev) if args.sub_every > 0 else torch.arange(0, 0, device=dev)
         nsub = torch.ones_like(rows)
     else:                                                     # 0 / 1 / 2 substitutions in ratio 1:1:1
         rows = torch.arange(0, nq, device=dev)
