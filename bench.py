@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--walk", type=int, default=2, help="exact / protein: 1 = LF^J walk table, 2 = LF^J and LF^2J")
     ap.add_argument("--prefix-len", type=int, default=15, help="k2: symbols of the prefix table (fmgpu_index_accelerate_search)")
     ap.add_argument("--trim", type=int, default=0, help="dev: every read loses 0..TRIM symbols at its end (a ragged batch)")
+    ap.add_argument("--single-rank-collectives", action="store_true", help="rehearsal only: run the N > 1 code path (process group, asynchronous gather, barrier) with one rank")
     ap.add_argument("--sub-every", type=int, default=10, help="exact / protein: every n-th read carries one substitution (default 10 = SURVEY 8d; 0 = none; a dev knob)")
     ap.add_argument("--ng21", action="store_true", help="k2: search_ng21 over expand(h2(4,0,2), read length) (edit distance; the reference's older algorithm) — a side measurement")
     ap.add_argument("--edit", action="store_true", help="k2: edit distance (search_ng26<Edit = true>) instead of Hamming distance")
@@ -113,7 +114,8 @@ def main():
     capi.check(capi.lib().fmgpu_set_device(local_rank))
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.single_rank_collectives         # (dev: the N > 1 control flow and its RCCL calls with a group of one rank)
+    if multi:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -193,7 +195,7 @@ def main():
     torch.cuda.empty_cache()
 
     # results are double-buffered: the gather of step i travels over xGMI while the kernel of step i+1 runs
-    outs = [torch.empty(2 * nq, dtype=torch.int64, device=dev) for _ in range(2 if world > 1 else 1)]   # [lb | len], one buffer so that the gather sends it as is
+    outs = [torch.empty(2 * nq, dtype=torch.int64, device=dev) for _ in range(2 if multi else 1)]   # [lb | len], one buffer so that the gather sends it as is
     scheme = fm.search_scheme.h2(4, 0, 2)
     hit_cap = (16 if (args.edit or args.ng21) else 4) * nq
     ex21 = None
@@ -207,13 +209,16 @@ def main():
         ex.n_searches, ex.length = arrs[0].shape
         ex.pi, ex.l, ex.u = (a.ctypes.data_as(capi.u64p) for a in arrs)
         ex21 = (ex, arrs)
-    hits_bufs = [torch.empty(hit_cap * 40, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)] if bidir else None
-    via_host = world > 1 and args.dist_backend == "gloo"
+    hits_bufs = [torch.empty(hit_cap * 40, dtype=torch.uint8, device=dev) for _ in range(2 if multi else 1)] if bidir else None
+    via_host = multi and args.dist_backend == "gloo"
     count_dev = torch.zeros(1, dtype=torch.int64, device="cpu" if via_host else dev)
-    packed = [torch.empty(nq, dtype=torch.int64, device=dev) for _ in range(2)] if (world > 1 and not bidir) else None
+    packed = [torch.empty(nq, dtype=torch.int64, device=dev) for _ in range(2)] if (multi and not bidir) else None
+    # k = 2: a hit travels as 16 bytes — qidx:32 | lb:32, len:32 | errors:8 | seq:24 (rows and batch sizes are < 2^32; lbRev stays on the rank that
+    # found the hit: it only serves further extension) — instead of the 40-byte record of the C-ABI
+    packed_hits = [torch.empty((2 * nq, 2), dtype=torch.int64, device=dev) for _ in range(2)] if (multi and bidir) else None
     gathered = None
-    if world > 1 and rank == 0:                               # k=2 messages are sized per step (largest hit count over the ranks), at most 2*nq records
-        full = 2 * nq * (40 if bidir else 8)
+    if multi and rank == 0:                               # k=2 messages are sized per step (largest hit count over the ranks), at most 2*nq records
+        full = 2 * nq * (16 if bidir else 8)
         gathered = [[torch.empty(full, dtype=torch.uint8, device="cpu" if via_host else dev) for _ in range(world)] for _ in range(2)]
 
     import ctypes as C
@@ -247,19 +252,24 @@ def main():
                                                       C.byref(cnt), C.byref(stats), None))
         kernel_ms.append(stats.kernel_ms)
         units.append(stats.lf_steps)
-        if world > 1:                                          # the path's one exchange: SA intervals to rank 0 over RCCL/xGMI
+        if multi:                                          # the path's one exchange: SA intervals to rank 0 over RCCL/xGMI
             if bidir:
                 count_dev.fill_(int(cnt.value))
                 dist.all_reduce(count_dev, op=dist.ReduceOp.MAX)
                 m = (int(count_dev.item()) + 65535) // 65536 * 65536
                 if m > 2 * nq:
                     raise SystemExit("more than 2 hits per read on average: raise the gather buffers")
-                payload = hits_bufs[b][: m * 40]
+                rec = hits_bufs[b][: m * 40].view(torch.int64).view(m, 5)
+                ph = packed_hits[b][:m]
+                torch.bitwise_or(rec[:, 0], rec[:, 1] << 32, out=ph[:, 0])
+                torch.bitwise_or(rec[:, 3], ((rec[:, 4] & 0xff) << 32) | ((rec[:, 4] >> 32) << 40), out=ph[:, 1])
+                payload = ph.view(torch.uint8).view(-1)
             else:                                              # (lb, len) as one 64-bit word per read: rows are < 2^32, 80 MB per rank instead of 160
                 torch.bitwise_or(out[:nq] << 32, out[nq:], out=packed[b])
                 payload = packed[b].view(torch.uint8)
             if via_host:
                 payload = payload.cpu()
+            state["payload"], state["b"] = payload, b
             pending[b] = exchange(payload, b)
 
     xch = {"mode": "gather", "bufs": [None, None]}
@@ -288,24 +298,39 @@ def main():
         step()
     drain()
     kernel_ms.clear(); units.clear()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    gather_ok = None
+    if multi:                                             # outside the timed region: rank 0 holds what every rank sent in the last step
+        pl = state["payload"]
+        chk = pl.view(torch.int64).sum().reshape(1).to(count_dev.device)
+        sums = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(sums, chk)
+        if rank == 0:
+            b = state["b"]
+            if xch["mode"] == "gather":
+                got = [gathered[b][r][: pl.numel()].view(torch.int64).sum().item() for r in range(world)]
+            else:
+                got = [xch["bufs"][b][r * pl.numel(): (r + 1) * pl.numel()].view(torch.int64).sum().item() for r in range(world)]
+            gather_ok = got == [int(x.item()) for x in sums]
+            if not gather_ok:
+                raise SystemExit("bench.py: the gathered intervals on rank 0 differ from what the ranks sent")
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
     ms_per_step = elapsed / args.steps * 1e3
@@ -348,6 +373,8 @@ def main():
                    "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
         "gbp_per_s": qps * L / 1e9,
         "hits": hits,
+        **({"exchange": {"collective": xch["mode"], "bytes_per_rank_and_step": int(state["payload"].numel()), "verified_on_rank0": gather_ok,
+                         "record": "16 B per hit (qidx:32 | lb:32, len:32 | errors:8 | seq:24)" if bidir else "8 B per read (lb:32 | len:32)"}} if multi else {}),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": (("k_exact_a" if args.no_exact_tables else "k_exact_kstep") if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if (args.kstep > 1 or not args.no_exact_tables) else "k_exact_a") if not bidir else ("k_ng21" if args.ng21 else "k_scheme_fast_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
                      "units_per_launch": steps_per_launch, "bytes_per_unit": unit_bytes,
@@ -365,7 +392,7 @@ def main():
     if secondary is not None:
         result["secondary"] = secondary
     print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

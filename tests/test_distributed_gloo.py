@@ -72,3 +72,4 @@ def test_bench_two_ranks_on_one_gpu():
         assert r.returncode == 0 and len(lines) == 1, r.stdout[-500:] + r.stderr[-1500:]
         out = json.loads(lines[0])
         assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and "cpu_baseline" not in out and "secondary" not in out
+        assert out["exchange"]["verified_on_rank0"] is True and out["exchange"]["bytes_per_rank_and_step"] > 0   # rank 0 received what both ranks sent
