@@ -1843,14 +1843,19 @@ struct CallScratch {
     void* frames = nullptr; size_t frames_bytes = 0;              // frame stacks of the DFS kernels, kept between calls up to kFrameCache bytes
     void* dfs_ctr = nullptr;                                      // their Counters (a DFS call synchronises before it returns: one at a time per thread)
     hipEvent_t ev_a = nullptr, ev_b = nullptr; int dev = -1;
+    CallScratch() = default;
+    CallScratch(const CallScratch&) = default;
+    CallScratch& operator=(const CallScratch&) = default;
+    ~CallScratch() { if (frames) (void)hipFree(frames); }          // a host thread that ends returns its frame stacks (the small objects stay with the process)
 };
 static int call_scratch(CallScratch** out) {
     static thread_local CallScratch sc;
     int dev = 0;
     FM_HIP(hipGetDevice(&dev));
     if (sc.dev != dev) {                                          // first use on this device (objects of an earlier device are left to the process)
-        if (sc.frames) (void)hipFree(sc.frames);                   // (the frame stacks are the one object worth returning)
-        sc = CallScratch{}; sc.dev = dev;
+        if (sc.frames) { (void)hipFree(sc.frames); sc.frames = nullptr; }   // (the frame stacks are the one object worth returning)
+        { CallScratch fresh; sc = fresh; }
+        sc.dev = dev;
         FM_HIP(hipMalloc((void**)&sc.ctr, kCounterStripes * 8));
         FM_HIP(hipMalloc((void**)&sc.sink, kCounterStripes * 8));
         FM_HIP(hipMalloc((void**)&sc.len2, (2 * 1024 + 1) * 8));
