@@ -234,7 +234,10 @@ def main():
             pending[b].wait(); pending[b] = None
         out = outs[b]
         state["out"] = out
-        if not bidir:
+        if not bidir and multi:                               # N > 1: the kernel writes the 8-byte transport word (lb << 32 | len) itself
+            capi.check(capi.lib().fmgpu_search_exact_packed(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
+                                                            C.c_void_p(packed[b].data_ptr()), C.byref(stats), None))
+        elif not bidir:
             capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
                                                      C.c_void_p(out[:nq].data_ptr()), C.c_void_p(out[nq:].data_ptr()),
                                                      C.byref(stats), None))
@@ -265,7 +268,6 @@ def main():
                 torch.bitwise_or(rec[:, 3], ((rec[:, 4] & 0xff) << 32) | ((rec[:, 4] >> 32) << 40), out=ph[:, 1])
                 payload = ph.view(torch.uint8).view(-1)
             else:                                              # (lb, len) as one 64-bit word per read: rows are < 2^32, 80 MB per rank instead of 160
-                torch.bitwise_or(out[:nq] << 32, out[nq:], out=packed[b])
                 payload = packed[b].view(torch.uint8)
             if via_host:
                 payload = payload.cpu()
@@ -341,6 +343,9 @@ def main():
     alg_bytes = steps_per_launch * unit_bytes
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     out_lb, out_len = state["out"][:nq], state["out"][nq:]
+    if multi and not bidir:                                   # the last step's transport words, taken apart again
+        w = packed[state["b"]]
+        out_lb, out_len = (w >> 32) & 0xffffffff, w & 0xffffffff
     hits = int((out_len > 0).sum().item()) if not bidir else int(stats.hits)
     traffic, lines = None, None                               # HBM bytes / line requests per launch from the committed PMC passes
     try:

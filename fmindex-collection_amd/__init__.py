@@ -272,6 +272,17 @@ class search_no_errors:
         return (lb, ln, st) if want_stats else (lb, ln)
 
 
+    @staticmethod
+    def search_packed(index, queries, out=None, want_stats=False):
+        """the same cursors as one word per query, lb << 32 | len (the form a rank's intervals are gathered in)"""
+        qbuf, qoff, nq = _queries(queries)
+        word = np.empty(nq, dtype=np.uint64) if out is None else out
+        st = capi.Stats()
+        capi.check(capi.lib().fmgpu_search_exact_packed(index._h, capi.ptr(qbuf), capi.ptr(qoff), nq, capi.ptr(word),
+                                                        C.byref(st) if want_stats else None, None))
+        return (word, st) if want_stats else word
+
+
 def _run_hits(call, capacity):
     while True:
         out = np.zeros(max(capacity, 1), dtype=HIT_DTYPE)

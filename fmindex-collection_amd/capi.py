@@ -90,7 +90,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "fmgpu_abi_version", "fmgpu_last_error", "fmgpu_device_count", "fmgpu_set_device",
     "fmgpu_index_create", "fmgpu_index_destroy", "fmgpu_index_info", "fmgpu_string_query",
-    "fmgpu_search_exact", "fmgpu_search_scheme", "fmgpu_search_ng21", "fmgpu_search_backtracking", "fmgpu_locate",
+    "fmgpu_search_exact", "fmgpu_search_exact_packed", "fmgpu_search_scheme", "fmgpu_search_ng21", "fmgpu_search_backtracking", "fmgpu_locate",
     "fmgpu_malloc", "fmgpu_free", "fmgpu_memcpy_h2d", "fmgpu_memcpy_d2h", "fmgpu_synchronize",
     "fmgpu_build_index", "fmgpu_built_free", "fmgpu_built_get", "fmgpu_index_accelerate", "fmgpu_index_accelerate_search",
     "fmgpu_index_accelerate_exact", "fmgpu_index_accelerate_locate", "fmgpu_hits_sort",
@@ -118,6 +118,8 @@ def lib():
                                      C.POINTER(Stats), C.c_void_p]
     L.fmgpu_search_scheme.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Scheme), C.c_uint64,
                                       C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats), C.c_void_p]
+    if hasattr(L, "fmgpu_search_exact_packed"):
+        L.fmgpu_search_exact_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Stats), C.c_void_p]
     if hasattr(L, "fmgpu_search_ng21"):
         L.fmgpu_search_ng21.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(ExpandedScheme), C.c_uint64,
                                         C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats), C.c_void_p]

@@ -26,6 +26,13 @@
 
 namespace fmgpu {
 
+// the cursor of query q: two 64-bit arrays as the reference's cursor fields, or (out_len == nullptr) one word lb << 32 | len — the transport
+// form of fmgpu_search_exact_packed (rows are < 2^32)
+__device__ __forceinline__ void store_interval(uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len, uint64_t q, idx_t lb, idx_t len) {
+    if (out_len) { out_lb[q] = lb; out_len[q] = len; }
+    else out_lb[q] = ((uint64_t)lb << 32) | (uint64_t)len;
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void k_exact(Occ occ, const uint8_t* __restric
             lb = ra; len = rb - ra;
             if (len == 0) break;
         }
-        out_lb[q] = lb; out_len[q] = len;
+        store_interval(out_lb, out_len, q, lb, len);
     }
     uint32_t tot = wave_sum(steps);
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
                 if (len == 0) break;
             }
         }
-        out_lb[q] = lb; out_len[q] = len;
+        store_interval(out_lb, out_len, q, lb, len);
     }
     uint32_t tot = wave_sum(steps);
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256) void k_exact_w(ViewW v, const uint8_t* __restr
             a += s_C[c]; b += s_C[c];
             if (a == b) break;
         }
-        out_lb[q] = a; out_len[q] = b - a;
+        store_interval(out_lb, out_len, q, a, b - a);
     }
     uint32_t tot = wave_sum(steps);
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
@@ -1201,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
             occ.lf2(lb, lb + len, c, ra, rb);
             lb = ra; len = rb - ra;
         }
-        out_lb[q] = lb; out_len[q] = len;
+        store_interval(out_lb, out_len, q, lb, len);
     }
     uint32_t tot = wave_sum(steps);
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
@@ -2067,14 +2074,14 @@ using namespace fmgpu;
 
 extern "C" {
 
-int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
-                       uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats, void* stream_) {
+static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                        uint64_t* out_lb, uint64_t* out_len, bool packed, fmgpu_stats* stats, void* stream_) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
     if (int drc = on_handle_device(x)) return drc;
     if (stats) *stats = fmgpu_stats{0, 0, 0.f};
     if (nq == 0) return 0;
-    if (!qbuf || !qoff || !out_lb || !out_len) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out_lb / out_len is null");
+    if (!qbuf || !qoff || !out_lb || (!out_len && !packed)) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out_lb / out_len is null");
     hipStream_t stream = (hipStream_t)stream_;
     Staged soff, sbuf, slb, slen;
     int rc;
@@ -2086,7 +2093,7 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
     else total = qoff[nq];
     if ((rc = sbuf.in(qbuf, total, stream))) return rc;
     if ((rc = slb.out(out_lb, nq * 8, stream))) return rc;
-    if ((rc = slen.out(out_len, nq * 8, stream))) return rc;
+    if (out_len && (rc = slen.out(out_len, nq * 8, stream))) return rc;   // (packed form: slen.dev stays null and the kernels write one word per query)
     unsigned long long* dsteps = nullptr;
     if ((rc = step_counters(stats != nullptr, stream, &dsteps))) return rc;
     EventTimer timer(stream, stats != nullptr);
@@ -2140,9 +2147,19 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
         stats->lf_steps = hs; stats->hits = nq; stats->kernel_ms = timer.ms();
     }
     if ((rc = slb.finish())) return rc;
-    if ((rc = slen.finish())) return rc;
+    if (out_len && (rc = slen.finish())) return rc;
     if (stats || slb.owned || slen.owned) (void)hipStreamSynchronize(stream);
     return 0;
+}
+
+int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                       uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats, void* stream) {
+    return search_exact(h, qbuf, qoff, nq, out_lb, out_len, false, stats, stream);
+}
+
+int fmgpu_search_exact_packed(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                              uint64_t* out_interval, fmgpu_stats* stats, void* stream) {
+    return search_exact(h, qbuf, qoff, nq, out_interval, nullptr, true, stats, stream);
 }
 
 static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme,

@@ -190,6 +190,11 @@ int fmgpu_string_query(fmgpu_index_t h, int which, const uint64_t* idx, const ui
 int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                        uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats, void* stream);
 
+/* the same search, each cursor as ONE word  lb << 32 | len  (rows are < 2^32 in this build): the 8-byte-per-read form in which a rank's
+ * intervals travel to the gathering rank ("only an RCCL gather of the resulting SA intervals") */
+int fmgpu_search_exact_packed(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
+                              uint64_t* out_interval, fmgpu_stats* stats, void* stream);
+
 /* search_ng26::search<Edit=false>(index, queries, scheme, partition, delegate, n) (search/SearchNg26.h:426-433);
  * BiFMIndex only.  max_hits_per_query = n (UINT64_MAX = unlimited).  Records are appended in no particular order across
  * queries; (qidx, seq) restores the reference's callback order.  *out_count = records produced (also when > capacity). */

@@ -589,6 +589,22 @@ def test_edit_distance_equal_length_fast_path(k, length, sigma):
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)[0])
 
 
+@pytest.mark.parametrize("layout,sigma,tables", [("IB16", 5, False), ("IB16", 5, True), ("WAVELET", 28, False), ("EPR16", 5, False), ("IB16", 256, False)])
+def test_packed_exact_intervals(layout, sigma, tables):
+    """fmgpu_search_exact_packed: one word lb << 32 | len per query, equal to the two-array form on every kernel variant"""
+    rng = np.random.default_rng(sigma)
+    text = rng.integers(1, min(sigma, 8), size=40000, dtype=np.uint8)
+    ox = fo.OraIndex.build(layout, sigma, [text], 8, False)
+    gx = gpu_index(ox)
+    if tables:
+        gx.accelerate(3, lut_len=5, walk=2)
+    reads = sample_reads(text, 5000, 70, seed=4, mutate=1) + [np.zeros(0, dtype=np.uint8)]
+    qbuf, qoff = fm.flatten(reads)
+    lb, ln = ox.search_exact(qbuf, qoff)
+    word, st = fm.search_no_errors.search_packed(gx, (qbuf, qoff), want_stats=True)
+    assert np.array_equal(word, (lb << np.uint64(32)) | ln) and st.lf_steps > 0
+
+
 # ------------------------------------------------------------------------------------------------ concurrency (SURVEY 8b: threads, streams)
 def test_concurrent_host_threads_on_one_handle():
     """the reference is re-entrant on a const index; so is the C-ABI: four host threads run exact, k-mismatch, edit-distance, search_ng21
