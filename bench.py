@@ -262,11 +262,8 @@ def main():
                 m = (int(count_dev.item()) + 65535) // 65536 * 65536
                 if m > 2 * nq:
                     raise SystemExit("more than 2 hits per read on average: raise the gather buffers")
-                rec = hits_bufs[b][: m * 40].view(torch.int64).view(m, 5)
-                ph = packed_hits[b][:m]
-                torch.bitwise_or(rec[:, 0], rec[:, 1] << 32, out=ph[:, 0])
-                torch.bitwise_or(rec[:, 3], ((rec[:, 4] & 0xff) << 32) | ((rec[:, 4] >> 32) << 40), out=ph[:, 1])
-                payload = ph.view(torch.uint8).view(-1)
+                capi.check(capi.lib().fmgpu_hits_pack16(C.c_void_p(hits_bufs[b].data_ptr()), int(cnt.value), C.c_void_p(packed_hits[b].data_ptr()), None))
+                payload = packed_hits[b][:m].view(torch.uint8).view(-1)
             else:                                              # (lb, len) as one 64-bit word per read: rows are < 2^32, 80 MB per rank instead of 160
                 payload = packed[b].view(torch.uint8)
             if via_host:

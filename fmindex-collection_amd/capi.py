@@ -93,7 +93,7 @@ EXPORTS = [
     "fmgpu_search_exact", "fmgpu_search_exact_packed", "fmgpu_search_scheme", "fmgpu_search_ng21", "fmgpu_search_backtracking", "fmgpu_locate",
     "fmgpu_malloc", "fmgpu_free", "fmgpu_memcpy_h2d", "fmgpu_memcpy_d2h", "fmgpu_synchronize",
     "fmgpu_build_index", "fmgpu_built_free", "fmgpu_built_get", "fmgpu_index_accelerate", "fmgpu_index_accelerate_search",
-    "fmgpu_index_accelerate_exact", "fmgpu_index_accelerate_locate", "fmgpu_hits_sort",
+    "fmgpu_index_accelerate_exact", "fmgpu_index_accelerate_locate", "fmgpu_hits_sort", "fmgpu_hits_pack16",
 ]
 
 _lib = None
@@ -129,6 +129,8 @@ def lib():
                                C.POINTER(Stats), C.c_void_p]
     if hasattr(L, "fmgpu_index_accelerate"):
         L.fmgpu_index_accelerate.argtypes = [C.c_void_p, C.c_int32]
+    if hasattr(L, "fmgpu_hits_pack16"):
+        L.fmgpu_hits_pack16.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     if hasattr(L, "fmgpu_hits_sort"):
         L.fmgpu_hits_sort.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     if hasattr(L, "fmgpu_index_accelerate_locate"):

@@ -2610,6 +2610,28 @@ __global__ __launch_bounds__(256) void k_gather_hits(const fmgpu_hit* __restrict
     if (t < count) dst[t] = src[perm[t]];
 }
 
+// 16-byte transport form of a hit: word 0 = qidx:32 | lb:32, word 1 = len:32 | errors:8 | seq:24
+__global__ __launch_bounds__(256) void k_hits_pack16(const fmgpu_hit* __restrict__ h, uint64_t count, ulonglong2* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const fmgpu_hit r = h[t];
+    out[t] = make_ulonglong2((r.qidx & 0xffffffffull) | (r.lb << 32),
+                             (r.len & 0xffffffffull) | ((uint64_t)(r.errors & 0xffu) << 32) | ((uint64_t)(r.seq & 0xffffffu) << 40));
+}
+
+int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream_) {
+    if (count == 0) return 0;
+    if (!hits || !out) return fail(FMGPU_ERR_INVALID, "hits / out is null");
+    hipStream_t stream = (hipStream_t)stream_;
+    Staged sh, so;
+    int rc = sh.in(hits, count * sizeof(fmgpu_hit), stream); if (rc) return rc;
+    if ((rc = so.out(out, count * 16, stream))) return rc;
+    k_hits_pack16<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream>>>((const fmgpu_hit*)sh.dev, count, (ulonglong2*)so.dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "k_hits_pack16");
+    return so.finish();
+}
+
 int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream_) {
     if (count <= 1) return 0;
     if (!hits) return fail(FMGPU_ERR_INVALID, "hits is null");

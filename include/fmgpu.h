@@ -221,6 +221,11 @@ int fmgpu_search_backtracking(fmgpu_index_t h, const uint8_t* qbuf, const uint64
 int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count,
                  uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps, fmgpu_stats* stats, void* stream);
 
+/* the 16-byte transport form of hit records (what a rank sends to the gathering rank): out[2k] = qidx:32 | lb:32,
+ * out[2k+1] = len:32 | errors:8 | seq:24; lb_rev is dropped (it only serves further extension of the cursor).  Needs qidx, lb, len < 2^32,
+ * errors < 256, seq < 2^24 — all true for this build's indices and for batches below 2^32 queries. */
+int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
+
 /* Puts `count` hit records (host or device memory) into the reference's callback order — ascending qidx, inside a query the order the
  * delegate is called in (search/SearchNg26.h:385-390; fmgpu_hit::seq) — with a stable device radix sort.  The search kernels emit records
  * in no particular order. */

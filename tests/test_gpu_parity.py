@@ -605,6 +605,25 @@ def test_packed_exact_intervals(layout, sigma, tables):
     assert np.array_equal(word, (lb << np.uint64(32)) | ln) and st.lf_steps > 0
 
 
+def test_hit_records_pack16():
+    """fmgpu_hits_pack16: the 16-byte transport form of the 40-byte hit record, host and device buffers"""
+    rng = np.random.default_rng(3)
+    n = 5000
+    hits = np.zeros(n, dtype=fm.HIT_DTYPE)
+    hits["qidx"] = rng.integers(0, 2**32, size=n); hits["lb"] = rng.integers(0, 2**32, size=n); hits["lb_rev"] = rng.integers(0, 2**32, size=n)
+    hits["len"] = rng.integers(0, 2**32, size=n); hits["errors"] = rng.integers(0, 256, size=n); hits["seq"] = rng.integers(0, 2**24, size=n)
+    want = np.empty((n, 2), dtype=np.uint64)
+    want[:, 0] = hits["qidx"] | (hits["lb"] << np.uint64(32))
+    want[:, 1] = hits["len"] | (hits["errors"].astype(np.uint64) << np.uint64(32)) | (hits["seq"].astype(np.uint64) << np.uint64(40))
+    out = np.zeros((n, 2), dtype=np.uint64)
+    capi.check(capi.lib().fmgpu_hits_pack16(capi.ptr(hits), n, capi.ptr(out), None))
+    assert np.array_equal(out, want)
+    dh, do = fm.DeviceBuffer.from_array(hits), fm.DeviceBuffer(n * 16)
+    capi.check(capi.lib().fmgpu_hits_pack16(C.c_void_p(dh.ptr), n, C.c_void_p(do.ptr), None))
+    capi.check(capi.lib().fmgpu_synchronize(None))
+    assert np.array_equal(do.to_array(np.uint64, 2 * n).reshape(n, 2), want)
+
+
 # ------------------------------------------------------------------------------------------------ concurrency (SURVEY 8b: threads, streams)
 def test_concurrent_host_threads_on_one_handle():
     """the reference is re-entrant on a const index; so is the C-ABI: four host threads run exact, k-mismatch, edit-distance, search_ng21
