@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfmgpu.so")
+LIB_PATH = os.environ.get("FMGPU_LIBRARY") or os.path.join(HERE, "libfmgpu.so")   # (FMGPU_LIBRARY: another build of the same ABI, e.g. a tuning variant)
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)
