@@ -1151,32 +1151,34 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
             } else code = code_of(0, ac.lutL, 0, v);
             if (v) { const uint2 en = ac.slut[code]; if (en.y != 0) { lb = en.x; len = en.y; done = ac.lutL; steps = ac.lutL; } }
         }
-        // main phase: one table load per iteration.  One row left: J symbols per load from the walk table; otherwise K symbols from the
+        // main phase: one table load per iteration.  One row left: J (or 2J) symbols per load from the walk tables; otherwise K symbols from the
         // context table.  A step that would empty the interval (or meets an odd symbol) ends the phase WITHOUT touching the cursor:
         // its single-step walk is left to the tail phase, where the lanes of the wave are convergent again.
+        // The lanes of a wave sit in different kinds of steps, so an iteration first decides every lane's kind and address (registers and LDS
+        // only), then issues ONE 16-byte load for all of them (every table entry is dword-aligned and the tables carry 16 bytes of slack),
+        // and only then looks at what came back: one memory round trip per iteration instead of one per kind of step present in the wave.
+        const bool nib16 = qst.words && qst.nib && ac.wbits == 2u && ac.J == 16u;         // DNA: 16 staged nibbles -> one 32-bit code with a few word operations
         for (;;) {
-            const bool nib16 = qst.words && qst.nib && ac.wbits == 2u && ac.J == 16u;     // DNA: 16 staged nibbles -> one 32-bit code with a few word operations
-            if (ac.walk2 && len == 1 && m - done >= 2u * ac.J) {  // 2J symbols with one 12-byte load
+            uint32_t kind = 0, q0 = 0, q1 = 0;                  // 1: 2J symbols, 2: J symbols, 3: K symbols from the context table
+            const uint8_t* p0 = nullptr;
+            const idx_t a = lb, b = lb + len;
+            if (ac.walk2 && len == 1 && m - done >= 2u * ac.J) {
                 bool v0 = false, v1 = false;
-                const uint32_t q0 = nib16 ? query_code16(qst, m - 1u - done, false, v0) : code_of(done, ac.J, ac.wbits, v0);
-                const uint32_t q1 = nib16 ? query_code16(qst, m - 17u - done, false, v1) : code_of(done + ac.J, ac.J, ac.wbits, v1);
+                q0 = nib16 ? query_code16(qst, m - 1u - done, false, v0) : code_of(done, ac.J, ac.wbits, v0);
+                q1 = nib16 ? query_code16(qst, m - 17u - done, false, v1) : code_of(done + ac.J, ac.J, ac.wbits, v1);
                 if (!(v0 && v1)) break;
-                const uint32_t* p = ac.walk2 + 3u * (size_t)lb;
-                const uint32_t r = p[0], c0 = p[1], c1 = p[2];
-                if (r == 0xffffffffu || c0 != q0 || c1 != q1) break;
-                lb = r; done += 2u * ac.J; steps += 2u * ac.J;
-                continue;
-            }
-            if (ac.walk && len == 1 && m - done >= ac.J) {
+                kind = 1; p0 = reinterpret_cast<const uint8_t*>(ac.walk2 + 3u * (size_t)lb);
+            } else if (ac.walk && len == 1 && m - done >= ac.J) {
                 bool v = false;
-                const uint32_t qc = nib16 ? query_code16(qst, m - 1u - done, false, v) : code_of(done, ac.J, ac.wbits, v);
+                q0 = nib16 ? query_code16(qst, m - 1u - done, false, v) : code_of(done, ac.J, ac.wbits, v);
                 if (!v) break;
-                const uint2 en = ac.walk[lb];
-                if (en.x == 0xffffffffu || en.y != qc) break;
-                lb = en.x; done += ac.J; steps += ac.J;
-                continue;
-            }
-            if (!ac.kblk) {                                      // no context table: one symbol per iteration from the occurrence table itself
+                kind = 2; p0 = reinterpret_cast<const uint8_t*>(ac.walk + lb);
+            } else if (ac.kblk) {
+                bool valid = false;
+                const uint32_t code = code_of(done, K, 0, valid);
+                if (!valid) break;
+                kind = 3; p0 = ac.kblk + (size_t)code * 16u + (size_t)(a >> 6) * ((size_t)ncodes * 16u);      // same 12-byte entry shape as Format A
+            } else {                                             // no context table: one symbol per iteration from the occurrence table itself
                 if (done >= m) break;
                 const uint32_t c = qstage_get(qst, sq, m - 1 - done);
                 if (c >= sigma) break;
@@ -1186,17 +1188,21 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
                 lb = ra; len = rb - ra; ++steps; ++done;
                 continue;
             }
-            bool valid = false;
-            const uint32_t code = code_of(done, K, 0, valid);
-            if (!valid) break;
-            const idx_t a = lb, b = lb + len;
-            EntryA ea = load_entry_a(ac.kblk + (size_t)code * 16u, ncodes * 16u, a, 0);       // same 12-byte entry shape as Format A
-            EntryA eb = ea;
-            if ((a >> 6) != (b >> 6)) eb = load_entry_a(ac.kblk + (size_t)code * 16u, ncodes * 16u, b, 0);
-            idx_t ra = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
-            idx_t rb = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
-            if (rb == ra) break;
-            lb = ra; len = rb - ra; steps += K; done += K;
+            const uint4 r0 = *reinterpret_cast<const uint4*>(p0);
+            uint4 r1 = r0;
+            if (kind == 3u && (a >> 6) != (b >> 6)) r1 = *reinterpret_cast<const uint4*>(p0 + ((size_t)(b >> 6) - (size_t)(a >> 6)) * ((size_t)ncodes * 16u));
+            if (kind == 1u) {
+                if (r0.x == 0xffffffffu || r0.y != q0 || r0.z != q1) break;
+                lb = r0.x; done += 2u * ac.J; steps += 2u * ac.J;
+            } else if (kind == 2u) {
+                if (r0.x == 0xffffffffu || r0.y != q0) break;
+                lb = r0.x; done += ac.J; steps += ac.J;
+            } else {
+                const idx_t ra = r0.x + popc64(((uint64_t)r0.y | ((uint64_t)r0.z << 32)) & lowmask(a & 63u));
+                const idx_t rb = r1.x + popc64(((uint64_t)r1.y | ((uint64_t)r1.z << 32)) & lowmask(b & 63u));
+                if (rb == ra) break;
+                lb = ra; len = rb - ra; steps += K; done += K;
+            }
         }
         // tail phase: single steps — the step that failed in a table (until the interval is empty), the symbols after an odd one,
         // or the left-over symbols
