@@ -1158,11 +1158,20 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
         // only), then issues ONE 16-byte load for all of them (every table entry is dword-aligned and the tables carry 16 bytes of slack),
         // and only then looks at what came back: one memory round trip per iteration instead of one per kind of step present in the wave.
         const bool nib16 = qst.words && qst.nib && ac.wbits == 2u && ac.J == 16u;         // DNA: 16 staged nibbles -> one 32-bit code with a few word operations
+        // A walk entry whose symbols differ from the query's tells where: the symbols before that place are matches and still go K at a time
+        // through the context table (walks switched off up to `limit`); only the differing step itself and < K symbols before it are single steps.
+        bool walks = true; uint32_t limit = 0;
         for (;;) {
             uint32_t kind = 0, q0 = 0, q1 = 0;                  // 1: 2J symbols, 2: J symbols, 3: K symbols from the context table
             const uint8_t* p0 = nullptr;
             const idx_t a = lb, b = lb + len;
-            if (ac.walk2 && len == 1 && m - done >= 2u * ac.J) {
+            if (!walks) {
+                bool valid = false;
+                if (!ac.kblk || done + K > limit) break;
+                const uint32_t code = code_of(done, K, 0, valid);
+                if (!valid) break;
+                kind = 3; p0 = ac.kblk + (size_t)code * 16u + (size_t)(a >> 6) * ((size_t)ncodes * 16u);
+            } else if (ac.walk2 && len == 1 && m - done >= 2u * ac.J) {
                 bool v0 = false, v1 = false;
                 q0 = nib16 ? query_code16(qst, m - 1u - done, false, v0) : code_of(done, ac.J, ac.wbits, v0);
                 q1 = nib16 ? query_code16(qst, m - 17u - done, false, v1) : code_of(done + ac.J, ac.J, ac.wbits, v1);
@@ -1192,10 +1201,16 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
             uint4 r1 = r0;
             if (kind == 3u && (a >> 6) != (b >> 6)) r1 = *reinterpret_cast<const uint4*>(p0 + ((size_t)(b >> 6) - (size_t)(a >> 6)) * ((size_t)ncodes * 16u));
             if (kind == 1u) {
-                if (r0.x == 0xffffffffu || r0.y != q0 || r0.z != q1) break;
+                if (r0.x == 0xffffffffu) break;
+                if (r0.y != q0 || r0.z != q1) {                  // symbols matching before the first differing one
+                    const uint32_t same = r0.y != q0 ? ((uint32_t)__ffs((int)(r0.y ^ q0)) - 1u) / ac.wbits : ac.J + ((uint32_t)__ffs((int)(r0.z ^ q1)) - 1u) / ac.wbits;
+                    walks = false; limit = done + same;
+                    continue;
+                }
                 lb = r0.x; done += 2u * ac.J; steps += 2u * ac.J;
             } else if (kind == 2u) {
-                if (r0.x == 0xffffffffu || r0.y != q0) break;
+                if (r0.x == 0xffffffffu) break;
+                if (r0.y != q0) { walks = false; limit = done + ((uint32_t)__ffs((int)(r0.y ^ q0)) - 1u) / ac.wbits; continue; }
                 lb = r0.x; done += ac.J; steps += ac.J;
             } else {
                 const idx_t ra = r0.x + popc64(((uint64_t)r0.y | ((uint64_t)r0.z << 32)) & lowmask(a & 63u));
