@@ -3,7 +3,8 @@ import csv, glob, collections, json, sys
 d, pat, out = sys.argv[1], sys.argv[2], sys.argv[3]
 res = {"source": d, "kernel_filter": pat, "kernel_stats": [], "counters_per_launch": {}}
 for f in glob.glob(d + "/trace/*/*_kernel_stats.csv"):
-    for r in list(csv.DictReader(open(f)))[:12]:
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:12] + [r for r in rows[12:] if pat in r["Name"]]:
         res["kernel_stats"].append({"name": r["Name"][:110], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                                     "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6, "pct": float(r["Percentage"])})
 for f in sorted(glob.glob(d + "/pmc_*/*/*_counter_collection.csv")):
