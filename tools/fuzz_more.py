@@ -13,4 +13,15 @@ for seed in range(12, 120):
         t.test_ng21_randomised_expanded_schemes(seed)
     except AssertionError as e:
         bad.append(("ng21", seed, str(e)[:200])); print("FAIL ng21", seed, flush=True)
+for name in ("test_exact_search_randomised_layouts_and_tables",):
+    fn = getattr(t, name, None)
+    if fn is None: continue
+    for seed in range(100, 700):
+        try:
+            fn(seed)
+        except AssertionError as e:
+            bad.append((name, seed, str(e)[:200])); print("FAIL", name, seed, flush=True)
+        except Exception as e:
+            bad.append((name, seed, repr(e)[:200])); print("ERR", name, seed, repr(e)[:200], flush=True)
+        if seed % 50 == 0: print(name, seed, flush=True)
 print("done, failures:", bad)
