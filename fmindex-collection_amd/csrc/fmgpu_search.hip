@@ -1254,9 +1254,10 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
     const uint32_t* s_stretch = s_steps + S * stride;               // stretch words of the run16 steps
-    uint32_t* s_hits = s_steps + 2u * S * stride;                   // [kHitBuf][5][256]: lb, lbRev, len, e, seq
+    const uint32_t* s_stretch3 = s_steps + 2u * S * stride;         // ... and of the <= 3 steps of a `run`
+    uint32_t* s_hits = s_steps + 3u * S * stride;                   // [kHitBuf][5][256]: lb, lbRev, len, e, seq
     const QStage qst{s_dyn, qwords, qnib};
-    for (uint32_t i = threadIdx.x; i < 2u * S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
+    for (uint32_t i = threadIdx.x; i < 3u * S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
     __syncthreads();
 
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1369,112 +1370,132 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         ++j;
                     } else back = true;
                 } else {
-                    // ---- single row (search_next_dir_single, :251-365): the only child is the BWT symbol of the row; up to `run` steps per load
-                    bool walked = false;
-                    if (use_wj) {
-                        // 16 steps in one go: the walk table gives LF^16 and the 16 symbols met; they are compared with the query's 16 symbols as
-                        // two 32-bit codes.  All equal and one window check for the whole stretch: done; otherwise step by step from registers.
-                        if (we.x != 0xffffffffu) {
-                            walked = true;
-                            bool qvalid = false;
-                            const uint32_t qc = query_code16(qst, ent & 0xffffu, right, qvalid);
-                            const uint32_t sw = s_stretch[si * stride + j];
-                            const uint32_t tb = sw & 31u, hi1 = (sw >> 5) & 63u, hi2 = (sw >> 11) & 63u, lo = (sw >> 17) & 31u;
-                            if (qvalid && ((sw >> 22) & 1u)) {
-                                // A stretch with at most one part end (at offset tb; 16: none), walked run by run instead of step by step: a run of
-                                // matching symbols, then the differing symbol that ends it.  Steps up to tb have the window [.., hi1], later ones
-                                // [.., hi2]; the lower bound lo binds at step tb only.  Extensions are counted as the reference performs them: one
-                                // per step, one more where an exact tail starts (a match with no error left and not in a tail yet, :310-314), and
-                                // the step at which a branch ends is its last.  A wave spends as many rounds here as its lane with the most
-                                // differing symbols (a branch survives at most hi2 - e of them), not 16.
-                                const uint32_t diff = qc ^ we.y;
-                                const uint32_t mm = (diff | (diff >> 1)) & 0x55555555u;          // bit 2k: step k differs
-                                uint32_t x = 0;
-                                bool dead = false;
-                                while (!dead && x < 16u) {
-                                    const uint32_t rest = mm >> (2u * x);
-                                    const uint32_t p = rest ? x + (((uint32_t)__ffs((int)rest) - 1u) >> 1) : 16u;   // next differing step
-                                    uint32_t xb = x;
-                                    if (x < p && x <= tb) {                                      // matching steps up to the part end
-                                        if (e > hi1 || (x == tb && e < lo)) { nodes += 1u; dead = true; }
-                                        else {
-                                            const uint32_t bonus = (!in_tail && e == hi1) ? 1u : 0u;
-                                            in_tail = in_tail || e == hi1;
-                                            if (tb < p) {
-                                                if (tb > x && e < lo) { nodes += (tb - x) + bonus + 1u; dead = true; }
-                                                else { nodes += (tb + 1u - x) + bonus; in_tail = false; xb = tb + 1u; }
-                                            } else { nodes += (p - x) + bonus; xb = p; }
-                                        }
-                                    }
-                                    if (!dead && xb < p) {                                       // matching steps behind the part end
-                                        if (e > hi2) { nodes += 1u; dead = true; }
-                                        else { nodes += (p - xb) + ((!in_tail && e == hi2) ? 1u : 0u); in_tail = in_tail || e == hi2; }
-                                    }
-                                    if (!dead && p < 16u) {                                      // the differing step: a substitution or the end
-                                        nodes += 1u;
-                                        const uint32_t maxp = p <= tb ? hi1 : hi2, minp = p == tb ? lo : 0u;
-                                        if (minp <= e + 1u && e + 1u <= maxp) { e += 1u; in_tail = p != tb && in_tail; }
-                                        else dead = true;
-                                    }
-                                    x = p + 1u;
-                                }
-                                if (dead) back = true;
-                                else { if (right) cur.lbRev = we.x; else cur.lb = we.x; j += 16u; }
-                            } else {
-                                bool dead = false;
-                                for (uint32_t kk = 0; kk < 16u && !dead; ++kk) {
-                                    const uint32_t en = tab[j + kk];
-                                    const uint32_t minE = (en >> 18) & 0x1fu, maxE = (en >> 23) & 0x3fu;
-                                    const bool lastp = (en >> 17) & 1u;
-                                    const uint32_t b = ((we.y >> (2u * kk)) & 3u) + 1u;
-                                    const uint32_t c = qstage_get(qst, qs, en & 0xffffu);
-                                    const bool mOK = minE <= e && e <= maxE;
-                                    const bool sOK = minE <= e + 1 && e + 1 <= maxE;
-                                    const bool xOK = e + 1 <= maxE;
-                                    const bool is_match = b == c && mOK;
-                                    nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
-                                    if (b == c) { if (!mOK) dead = true; }
-                                    else if (sOK) e += 1;
-                                    else dead = true;
-                                    if (!dead) in_tail = !lastp && (in_tail || (is_match && !xOK));
-                                }
-                                if (dead) back = true;
-                                else { if (right) cur.lbRev = we.x; else cur.lb = we.x; j += 16u; }
+                    // ---- single row (search_next_dir_single, :251-365): the only child is the BWT symbol of the row.  A stretch of n steps in one
+                    // direction — 16 from a walk entry, or up to three from the LF / LF^2 / LF^3 values — is described by the steps at which the
+                    // row's symbols differ from the query's (mm, bit 2k = step k), its stretch word (windows) and the row it leads to, and then
+                    // walked run by run by ONE piece of code for both kinds.
+                    bool walked = false, have = false, del_after = false;
+                    uint32_t n = 0, mm = 0, sword = 0;
+                    idx_t target = 0;
+                    if (use_wj && we.x != 0xffffffffu) {
+                        walked = true;
+                        bool qvalid = false;
+                        const uint32_t qc = query_code16(qst, ent & 0xffffu, right, qvalid);
+                        const uint32_t sw = s_stretch[si * stride + j];
+                        if (qvalid && ((sw >> 22) & 1u)) {
+                            const uint32_t diff = qc ^ we.y;
+                            have = true; n = 16u; mm = (diff | (diff >> 1)) & 0x55555555u; sword = sw; target = we.x;
+                        } else {                                     // an odd query symbol or two part ends inside: step by step
+                            bool dead = false;
+                            for (uint32_t kk = 0; kk < 16u && !dead; ++kk) {
+                                const uint32_t en = tab[j + kk];
+                                const uint32_t minE = (en >> 18) & 0x1fu, maxE = (en >> 23) & 0x3fu;
+                                const bool lastp = (en >> 17) & 1u;
+                                const uint32_t b = ((we.y >> (2u * kk)) & 3u) + 1u;
+                                const uint32_t c = qstage_get(qst, qs, en & 0xffffu);
+                                const bool mOK = minE <= e && e <= maxE;
+                                const bool sOK = minE <= e + 1 && e + 1 <= maxE;
+                                const bool xOK = e + 1 <= maxE;
+                                const bool is_match = b == c && mOK;
+                                nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
+                                if (b == c) { if (!mOK) dead = true; }
+                                else if (sOK) e += 1;
+                                else dead = true;
+                                if (!dead) in_tail = !lastp && (in_tail || (is_match && !xOK));
                             }
+                            if (dead) back = true;
+                            else { if (right) cur.lbRev = we.x; else cur.lb = we.x; j += 16u; }
                         }
                     }
                     if (!walked) {
-                    const uint32_t run = w3 ? (ent >> 30) : 1u;    // consecutive steps in this direction (<= 3), never past the query end
-                    if (use_wj) {                                   // (a walk entry that crosses a delimiter: the steps one load later)
-                        if (w3) { const idx_t* p = w3 + 3u * (size_t)a; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
-                        else t0 = (right ? fa.lf_rv : fa.lf_fw)[a];
-                    }
-                    idx_t tk = t0, last = t0;
-                    uint32_t k = 0;
-                    bool dead = false;
+                        const uint32_t run = w3 ? (ent >> 30) : 1u;    // consecutive steps in this direction (<= 3), never past the query end
+                        if (use_wj) {                                   // (a walk entry that crosses a delimiter: the steps one load later)
+                            if (w3) { const idx_t* p = w3 + 3u * (size_t)a; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
+                            else t0 = (right ? fa.lf_rv : fa.lf_fw)[a];
+                        }
+                        const uint32_t sw3 = s_stretch3[si * stride + j];
+                        if ((sw3 >> 22) & 1u) {
+                            // the row's next symbols against the query's; a delimiter row ends the branch at its step (:295-297), after the steps before it
+                            uint32_t nn = run;
 #pragma unroll
-                    for (uint32_t kk = 0; kk < 3; ++kk) {
-                        if (kk < run && !dead) {
-                            const uint32_t en = kk == 0 ? ent : tab[j + kk];
-                            const uint32_t pos = en & 0xffffu, minE = (en >> 18) & 0x1fu, maxE = (en >> 23) & 0x3fu;
-                            const bool lastp = (en >> 17) & 1u;
-                            tk = kk == 0 ? t0 : (kk == 1 ? t1 : t2);
-                            const uint32_t b = symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, tk);
-                            const uint32_t c = qstage_get(qst, qs, pos);
-                            const bool mOK = minE <= e && e <= maxE;
-                            const bool sOK = minE <= e + 1 && e + 1 <= maxE;
-                            const bool xOK = e + 1 <= maxE;
-                            const bool is_match = b >= 1 && b == c && mOK;
-                            nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
-                            if (b < 1) dead = true;                 // :295-297: a delimiter row ends the walk
-                            else if (b == c) { if (!mOK) dead = true; }
-                            else if (sOK) e += 1;
-                            else dead = true;
-                            if (!dead) { in_tail = !lastp && (in_tail || (is_match && !xOK)); last = tk; ++k; }
+                            for (uint32_t kk = 0; kk < 3; ++kk) {
+                                if (kk < nn) {
+                                    const idx_t tk = kk == 0 ? t0 : (kk == 1 ? t1 : t2);
+                                    const uint32_t bsym = symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, tk);
+                                    const uint32_t c = qstage_get(qst, qs, (kk == 0 ? ent : tab[j + kk]) & 0xffffu);
+                                    if (bsym < 1u) { nn = kk; del_after = true; }
+                                    else { if (bsym != c) mm |= 1u << (2u * kk); target = tk; }
+                                }
+                            }
+                            have = true; n = nn; sword = sw3;
+                        } else {
+                            idx_t tk = t0, last = t0;
+                            uint32_t k = 0;
+                            bool dead = false;
+#pragma unroll
+                            for (uint32_t kk = 0; kk < 3; ++kk) {
+                                if (kk < run && !dead) {
+                                    const uint32_t en = kk == 0 ? ent : tab[j + kk];
+                                    const uint32_t pos = en & 0xffffu, minE = (en >> 18) & 0x1fu, maxE = (en >> 23) & 0x3fu;
+                                    const bool lastp = (en >> 17) & 1u;
+                                    tk = kk == 0 ? t0 : (kk == 1 ? t1 : t2);
+                                    const uint32_t b = symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, tk);
+                                    const uint32_t c = qstage_get(qst, qs, pos);
+                                    const bool mOK = minE <= e && e <= maxE;
+                                    const bool sOK = minE <= e + 1 && e + 1 <= maxE;
+                                    const bool xOK = e + 1 <= maxE;
+                                    const bool is_match = b >= 1 && b == c && mOK;
+                                    nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
+                                    if (b < 1) dead = true;                 // :295-297: a delimiter row ends the walk
+                                    else if (b == c) { if (!mOK) dead = true; }
+                                    else if (sOK) e += 1;
+                                    else dead = true;
+                                    if (!dead) { in_tail = !lastp && (in_tail || (is_match && !xOK)); last = tk; ++k; }
+                                }
+                            }
+                            if (dead) back = true;
+                            else { if (right) cur.lbRev = last; else cur.lb = last; j += k; }   // one row: the other side's prefix count is 0
                         }
                     }
-                    if (dead) back = true;
-                    else { if (right) cur.lbRev = last; else cur.lb = last; j += k; }   // one row: the other side's prefix count is 0
+                    if (have) {
+                        // Steps up to the part end inside the stretch (offset tb; n: none) have the window [.., hi1], later ones [.., hi2]; the lower
+                        // bound lo binds at step tb only.  Extensions are counted as the reference performs them: one per step, one more where an
+                        // exact tail starts (a match with no error left and not in a tail yet, :310-314), and the step at which a branch ends is
+                        // its last.  A wave spends as many rounds here as its lane with the most differing symbols, not n.
+                        const uint32_t tb = sword & 31u, hi1 = (sword >> 5) & 63u, hi2 = (sword >> 11) & 63u, lo = (sword >> 17) & 31u;
+                        uint32_t x = 0;
+                        bool dead = false;
+                        while (!dead && x < n) {
+                            const uint32_t rest = mm >> (2u * x);
+                            uint32_t p = rest ? x + (((uint32_t)__ffs((int)rest) - 1u) >> 1) : n;      // next differing step
+                            p = p < n ? p : n;
+                            uint32_t xb = x;
+                            if (x < p && x <= tb) {                                              // matching steps up to the part end
+                                if (e > hi1 || (x == tb && e < lo)) { nodes += 1u; dead = true; }
+                                else {
+                                    const uint32_t bonus = (!in_tail && e == hi1) ? 1u : 0u;
+                                    in_tail = in_tail || e == hi1;
+                                    if (tb < p) {
+                                        if (tb > x && e < lo) { nodes += (tb - x) + bonus + 1u; dead = true; }
+                                        else { nodes += (tb + 1u - x) + bonus; in_tail = false; xb = tb + 1u; }
+                                    } else { nodes += (p - x) + bonus; xb = p; }
+                                }
+                            }
+                            if (!dead && xb < p) {                                               // matching steps behind the part end
+                                if (e > hi2) { nodes += 1u; dead = true; }
+                                else { nodes += (p - xb) + ((!in_tail && e == hi2) ? 1u : 0u); in_tail = in_tail || e == hi2; }
+                            }
+                            if (!dead && p < n) {                                                // the differing step: a substitution or the end
+                                nodes += 1u;
+                                const uint32_t maxp = p <= tb ? hi1 : hi2, minp = p == tb ? lo : 0u;
+                                if (minp <= e + 1u && e + 1u <= maxp) { e += 1u; in_tail = p != tb && in_tail; }
+                                else dead = true;
+                            }
+                            x = p + 1u;
+                        }
+                        if (!dead && del_after) { nodes += 1u; dead = true; }
+                        if (dead) back = true;
+                        else if (n) { if (right) cur.lbRev = target; else cur.lb = target; j += n; }
                     }
                 }
                 bool search_over = false;
@@ -1993,17 +2014,18 @@ static int query_len_range(const uint64_t* dqoff, uint64_t nq, hipStream_t strea
 static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, uint32_t J, std::vector<uint32_t>& tab, uint32_t& lut_ok) {
     const uint32_t S = (uint32_t)sd.S, P = (uint32_t)sd.P;
     lut_ok = 0;
-    if (m < P || m > 0xfffeu || (uint64_t)S * (m + 1) > 4096) return false;
+    if (m < P || m > 0xfffeu || (uint64_t)S * (m + 1) > 2730) return false;     // three tables of S * (m + 1) words in LDS: 32 KB at most
     std::vector<uint32_t> plen(P);
     uint32_t sum = 0;
     for (uint32_t p = 0; p < P; ++p) { plen[p] = sd.uniform ? m / P + (p < m % P ? 1u : 0u) : sd.partition[p]; sum += plen[p]; }
     if (sum != m) return false;
     const size_t half = (size_t)S * (m + 1);
-    tab.assign(2 * half, 0);
+    tab.assign(3 * half, 0);
     for (uint32_t s = 0; s < S; ++s) {
         const uint8_t* pi = sd.pi + s * kMaxParts; const uint8_t* L = sd.l + s * kMaxParts; const uint8_t* U = sd.u + s * kMaxParts;
         uint32_t* T = tab.data() + (size_t)s * (m + 1);
         uint32_t* T2 = tab.data() + half + (size_t)s * (m + 1);
+        uint32_t* T3 = tab.data() + 2 * half + (size_t)s * (m + 1);
         uint32_t start = 0;
         for (uint32_t i = 0; i < pi[0]; ++i) start += plen[i];
         uint32_t qR = start, qL = start - 1, j = 0;              // SearchNg26.h:62-79
@@ -2023,6 +2045,13 @@ static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, uin
             uint32_t run = 1;
             while (run < 3 && k + run < m && ((T[k + run] >> 16) & 1u) == ((T[k] >> 16) & 1u)) ++run;
             T[k] |= run << 30;
+            {   // the stretch word of these `run` steps (same fields as for 16; tb = run if no part ends inside)
+                uint32_t tb = run, ends = 0, lo = 0;
+                for (uint32_t t = 0; t < run; ++t)
+                    if ((T[k + t] >> 17) & 1u) { if (!ends) tb = t; ++ends; lo = std::max(lo, (T[k + t] >> 18) & 0x1fu); }
+                const uint32_t hi1 = (T[k] >> 23) & 0x3fu, hi2 = tb + 1 < run ? (T[k + tb + 1] >> 23) & 0x3fu : hi1;
+                T3[k] = tb | (hi1 << 5) | (hi2 << 11) | (lo << 17) | ((ends <= 1 ? 1u : 0u) << 22);
+            }
             // run16: J steps in this direction from k on.  Their stretch word: tb = offset of the first part end inside the stretch (J if none),
             // hi1 / hi2 = upper bound before / after it, lo = the largest lower bound that applies inside, simple = at most one part end
             if (J && J <= 31 && k + J <= m) {
@@ -2240,7 +2269,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     // LDS budget of a 256-lane block of the DFS kernels: 64 KB in all — the staged queries (1 KB per word and block) beside the kernels' own
     // tables and hit buffers (<= 17 KB static in the general kernels; per-step tables + hit buffers in the table-driven ones, reserved below)
     const size_t stage_words = x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4;
-    const size_t tables_lds = scheme_mode ? (size_t)2 * (size_t)std::max(sd.S, 1) * ((size_t)maxlen + 1) * 4 + (size_t)kWaveHitWords * 4 : 0;
+    const size_t tables_lds = scheme_mode ? (size_t)3 * (size_t)std::max(sd.S, 1) * ((size_t)maxlen + 1) * 4 + (size_t)kWaveHitWords * 4 : 0;
     const size_t stage_budget = (size_t)64 * 1024 - std::max<size_t>(17 * 1024, std::min<size_t>(tables_lds, 47 * 1024));
     const size_t occ_lds = stage_words * 1024 > stage_budget ? 0 : stage_words * 1024;
     const auto occ_key = std::make_tuple(x->bwt.search_family(), x->bwt.sigma, (int)scheme_mode + (edit ? 2 : 0), occ_lds);
