@@ -2471,6 +2471,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     const uint64_t M = scheme->length;
     if (M == 0 || M > 0xfffeu) return fail(FMGPU_ERR_INVALID, "expanded scheme length must be in [1, 65534]");
     const uint32_t S = (uint32_t)scheme->n_searches;
+    if ((uint64_t)S * M > (1ull << 24)) return fail(FMGPU_ERR_UNSUPPORTED, "expanded scheme with more than 2^24 entries");
     std::vector<uint32_t> tab((size_t)S * M);
     uint32_t max_u = 0;
     for (uint32_t s = 0; s < S; ++s) {
