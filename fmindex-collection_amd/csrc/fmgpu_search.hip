@@ -2291,11 +2291,9 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if ((size_t)qwords * 1024 > stage_budget) qwords = 0;
     const size_t lds_bytes = (size_t)qwords * 1024;
     DfsWorkspace ws;
-    // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
-    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? 4 : 3))) return rc;
     EventTimer timer(stream, stats != nullptr);
     const idx_t n = (idx_t)x->bwt.n;
-    dim3 grid(ws.grid), block(256);
+    const dim3 block(256);
     // fast path: equal-length batch on a Format-A BiFMIndex with LF tables
     // 16-symbol walk: 2-bit symbols, queries staged in LDS as nibbles
     const bool use_wj = !edit && !(sd.dev_flags & 32) && x->bwt.walkj && x->rev.walkj && x->bwt.walk_bits == 2 && x->rev.walk_bits == 2 && qnib && qwords;
@@ -2352,6 +2350,27 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         }
         if (!fast) { buckets.clear(); (void)hipFree(d_qmap); d_qmap = nullptr; }
     }
+    // the workspace is sized for the kernel that will run: the table-driven edit-distance kernel keeps 5 blocks per CU resident where the
+    // general one (launch bounds for 4) keeps 4 — a grid of 4 leaves a fifth of its wave slots empty (84.5 -> 77.3 ms per 4 M reads)
+    if (fast && edit) {
+        size_t max_tab = 0;
+        for (const Bucket& b : buckets) max_tab = std::max(max_tab, b.tab.size());
+        const size_t lds_fast = lds_bytes + max_tab * 4 + (size_t)kWaveHitWords * 4;
+        const auto key = std::make_tuple(-1, x->bwt.sigma, 3, lds_fast);
+        bool known = false;
+        { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(key); if (it != occ_cache.end()) { bpc = it->second; known = true; } }
+        if (!known) {
+            int nb = 0;
+            hipError_t oe = x->bwt.sigma == 5 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scheme_fast_edit<5, 5>, 256, lds_fast)
+                                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scheme_fast_edit<0, 32>, 256, lds_fast);
+            if (oe == hipSuccess && nb > 0) bpc = nb; else (void)hipGetLastError();
+            std::lock_guard<std::mutex> g(occ_mu); occ_cache[key] = bpc;
+        }
+    }
+    { const char* ev = getenv("FMGPU_DEV_BPC"); if (ev && atoi(ev) > 0) bpc = atoi(ev); }   // dev knob: resident blocks per CU the grid is sized for
+    // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
+    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? 4 : 3))) { if (d_qmap) (void)hipFree(d_qmap); return rc; }
+    const dim3 grid(ws.grid);
     uint32_t* d_steps = nullptr;
     size_t steps_words = 0;
     if (fast) {
