@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
 // reference's call order: 0 match, 2i-1 deletion of i, 2i substitution by i, 2*sigma-1 insertion.  Same wave-synchronous head, hit buffers and
 // 32-byte lane-major frames as k_scheme_edit.
 template <class Occ, int MAXSIG>
-__global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_ng21(Occ fw, Occ rv, const uint32_t* __restrict__ tab, uint32_t S, uint32_t M,
+__global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ rv, const uint32_t* __restrict__ tab, uint32_t S, uint32_t M,
                                                      const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                      fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib,
                                                      LfView lfv, uint32_t tab_lds, const uint4* __restrict__ lut, uint32_t lutL) {
