@@ -390,7 +390,10 @@ def main():
                                            "frac": lines / (k_ms * 1e-3) / 1e9 / ceiling,
                                            "what": "L2->fabric 128-byte line requests per second (TCC_EA0_RDREQ) vs the measured ceiling for dependent random line reads"}
     if want_cpu:
-        result["cpu_baseline"] = cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, args.cpu_sample, out_lb, out_len, layout, sigma, args.edit)
+        hit_q = None
+        if bidir and not multi:                               # query numbers of the last step's hit records: their counts per query are compared with the CPU walk's
+            hit_q = hits_bufs[0][: int(stats.hits) * 40].view(torch.int64).view(-1, 5)[:, 0]
+        result["cpu_baseline"] = cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, args.cpu_sample, out_lb, out_len, layout, sigma, args.edit, hit_q)
     if secondary is not None:
         result["secondary"] = secondary
     print(json.dumps(result), flush=True)
@@ -417,7 +420,7 @@ def _scheme_struct(capi, scheme):
     return sc, (pi, l, u)
 
 
-def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_len, layout="IB16", sigma=5, edit=False):
+def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_len, layout="IB16", sigma=5, edit=False, hit_q=None):
     """the CPU restatement (oracle/) on the host cores, bounded sample of the same reads; also a parity spot-check"""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -450,15 +453,19 @@ def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_le
         lb, ln = r
         ok = bool(np.array_equal(lb, out_lb[:sample].cpu().numpy().astype(np.uint64)) and
                   np.array_equal(ln, out_len[:sample].cpu().numpy().astype(np.uint64)))
+    elif hit_q is not None:                                   # per-query record counts on the sample (hit-by-hit parity: tests/test_gpu_parity.py)
+        import torch
+        mine = torch.bincount(hit_q[hit_q < sample], minlength=sample).cpu().numpy().astype(np.uint64)
+        ok = bool(np.array_equal(mine, np.asarray(r[1][:sample], dtype=np.uint64)))
     else:
-        ok = None                                             # (hit-by-hit parity of k-mismatch search is covered by tests/test_gpu_parity.py)
+        ok = None
     one = max(1000, min(sample, int(sample / dt * 3.0 / cores)))          # ~3 s on one thread (single-thread figure beside all cores)
     _, dt1 = run(one, threads=1)
     out = {"value": sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",
            "single_thread": {"value": one / dt1, "unit": "queries/s", "sample": "the first %d reads, one thread" % one},
            "sample": "the first %d reads of the same batch, OpenMP over queries on all host cores%s; index rebuilt on the host from the "
                      "GPU-built BWT in %.0f s" % (sample, "" if bidir else ", 32 cursors interleaved per thread (SearchNoErrors.h:28-86)", build),
-           "seconds": dt, "gpu_results_match_on_sample": ok}
+           "seconds": dt, "gpu_results_match_on_sample": ok}   # exact: every (lb, len); k = 2: the number of records per query
     if not bidir:                                             # the one-query-at-a-time form beside it, on a sample a fifth the size
         few = max(1000, sample // 5)
         _, dts = run(few, batched=False)
