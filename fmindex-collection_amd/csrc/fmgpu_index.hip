@@ -487,17 +487,17 @@ __global__ __launch_bounds__(256) void k_walk3(const idx_t* __restrict__ lf, uin
 // suffix table for exact search: the interval of the L symbols c_0 (consumed first = the query's last symbol), c_1, ...
 template <class Occ>
 __global__ __launch_bounds__(256) void k_suffix_lut(Occ occ, uint64_t entries, uint32_t L, uint32_t R, idx_t n, uint2* __restrict__ lut) {
-    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= entries) return;
-    idx_t lb = 0, len = n;
-    uint64_t rest = w;
-    for (uint32_t t = 0; t < L && len != 0; ++t) {
-        uint32_t c = (uint32_t)(rest % R) + 1; rest /= R;
-        idx_t ra, rb;
-        occ.lf2(lb, lb + len, c, ra, rb);
-        lb = ra; len = rb - ra;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < entries; w += (uint64_t)gridDim.x * blockDim.x) {   // (2^32 entries: more than one launch's threads)
+        idx_t lb = 0, len = n;
+        uint64_t rest = w;
+        for (uint32_t t = 0; t < L && len != 0; ++t) {
+            uint32_t c = (uint32_t)(rest % R) + 1; rest /= R;
+            idx_t ra, rb;
+            occ.lf2(lb, lb + len, c, ra, rb);
+            lb = ra; len = rb - ra;
+        }
+        lut[w] = make_uint2(lb, len);
     }
-    lut[w] = make_uint2(lb, len);
 }
 // J LF steps from every row, remembering the symbols met
 __global__ __launch_bounds__(256) void k_walkj(const idx_t* __restrict__ lf, const idx_t* __restrict__ C, uint32_t sigma, uint64_t n, uint32_t J, uint32_t bits,
@@ -741,9 +741,9 @@ int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len
     const uint32_t sigma = (uint32_t)s.sigma, R = sigma - 1;
     if (lut_len > 0) {
         uint64_t entries = 1;
-        for (int t = 0; t < lut_len; ++t) { entries *= R; if (entries > (1ull << 30)) return fail(FMGPU_ERR_UNSUPPORTED, "suffix table would exceed 2^30 entries"); }
+        for (int t = 0; t < lut_len; ++t) { entries *= R; if (entries > (1ull << 32)) return fail(FMGPU_ERR_UNSUPPORTED, "suffix table would exceed 2^32 entries"); }
         FM_HIP(hipMalloc((void**)&s.slut, entries * 8));
-        dim3 grid((unsigned)((entries + 255) / 256)), block(256);
+        dim3 grid((unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22)), block(256);
         switch (s.search_family()) {
         case FAM_A:
             if (s.sigma == 5) k_suffix_lut<OccA<5>><<<grid, block>>>(OccA<5>{s.va}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut);
