@@ -294,6 +294,11 @@ def test_plumbing_config0():
     olb, oln = ox.search_exact(qbuf, qoff, nthreads=4)
     assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
     assert int((ln > 0).sum()) >= 5000
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "config0_intervals.npy"))      # computed with the real reference's rank
+    assert np.array_equal(lb, want[:, 0]) and np.array_equal(ln, want[:, 1])
+    gx.accelerate(3, lut_len=8, walk=2)
+    lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
+    assert np.array_equal(lb, want[:, 0]) and np.array_equal(ln, want[:, 1])
 
 
 # ------------------------------------------------------------------------------------------------ k-mismatch

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import fmoracle as fo
-from tests.util import make_text, occurrences
+from tests.util import make_text, occurrences, sample_reads
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 REF = json.load(open(os.path.join(GOLD, "reference_tests.json")))
@@ -369,6 +369,20 @@ def test_edit_distance_fixtures():
         qbuf, qoff = fo.flatten_queries(c["queries"])
         hits, _, _ = x.search_ng26(qbuf, qoff, sch, max_hits=c.get("n", fo.UINT64_MAX), edit=True)
         assert _located(x, hits) == c["expected"], key
+
+
+def test_config0_intervals_from_the_real_reference_rank():
+    """BASELINE.json configs[0] (1 MB random DNA, 10k x 31 bp exact, InterleavedBitvector16): tests/golden/config0_intervals.npy was computed with
+    the real reference's rank function (tests/golden/make_golden.py::config0_intervals); the restatement's search must reproduce it"""
+    want = np.load(os.path.join(GOLD, "config0_intervals.npy"))
+    text = make_text(1_000_000, 5, seed=42)
+    x = fo.OraIndex.build("IB16", 5, [text], 16, False)
+    qbuf, qoff = fo.flatten_queries(sample_reads(text, 10_000, 31, seed=1, mutate=1))
+    lb, ln = x.search_exact(qbuf, qoff, nthreads=4)
+    assert np.array_equal(ln, want[:, 1]) and np.array_equal(lb, want[:, 0])
+    blb, bln = x.search_exact_batched(qbuf, qoff, 32, 4)
+    assert np.array_equal(bln, want[:, 1]) and np.array_equal(blb, want[:, 0])
+    assert int((want[:, 1] > 0).sum()) >= 5000
 
 
 def test_ng21_fixtures():
