@@ -6,7 +6,8 @@
                          text is kept, only numbers.
   ref_strings.json       vectors produced by the REAL reference headers (oracle/_ref/libfmref.so): rank / prefix_rank /
                          symbol tables and layout checksums of the occurrence-table types on seeded texts.
-  config0_intervals.npy  BASELINE configs[0]: (lb, len) of 10k x 31 bp exact searches on 1 MB of DNA, computed with the REAL reference's rank.
+  ref_search_intervals.npz  (lb, len) of exact searches — BASELINE configs[0] (1 MB of DNA, 10k x 31 bp, InterleavedBitvector16), a small
+                         FMIndex<28, Wavelet> case and EPR / EPRV2 / EPRV5 / Prefix16 cases — computed with the REAL reference's rank.
   ref_schemes.json       search-scheme tables produced by the real reference (h2, pigeon_opt, backtracking, expand,
                          limitToHamming, isValid, isComplete, nodeCount, createUniformPartition).
 
@@ -219,37 +220,49 @@ def ref_vectors():
     return strings, schemes
 
 
-def config0_intervals():
-    """BASELINE.json configs[0] (1 MB random DNA, 10k x 31 bp exact, FMIndex<5, InterleavedBitvector16>): the (lb, len) of every read, computed
-    with the REAL reference's InterleavedBitvector16<5>::rank (oracle/_ref/libfmref.so) — backward search as FMIndexCursor::extendLeft does it
-    (fmindex/FMIndexCursor.h:33-37) over the BWT of the text, early exit on an empty interval like search/SearchNoErrors.h:12-26.  The suffix
-    order (hence the BWT) is a property of the text, so any correct suffix sorter gives the reference's; here the restatement's."""
+REF_SEARCH_CASES = {    # name: (layout, sigma, text symbols, text seed, reads, read length)
+    "config0_ib16": ("IB16", 5, 1_000_000, 42, 10_000, 31),          # BASELINE.json configs[0]
+    "protein_wavelet": ("WAVELET", 28, 300_000, 7, 3_000, 40),        # configs[4] in small: FMIndex<28, Wavelet>, 40 aa
+    "epr16": ("EPR16", 5, 200_000, 8, 2_000, 31),
+    "eprv2_16": ("EPRV2_16", 5, 200_000, 9, 2_000, 31),
+    "eprv5": ("EPRV5", 5, 200_000, 10, 2_000, 31),
+    "ibp16": ("IBP16", 5, 200_000, 11, 2_000, 31),
+}
+
+
+def ref_search_intervals():
+    """exact-search intervals computed with the REAL reference's rank functions (oracle/_ref/libfmref.so): backward search as
+    FMIndexCursor::extendLeft does it (fmindex/FMIndexCursor.h:33-37) over the BWT of the text, early exit on an empty interval like
+    search/SearchNoErrors.h:12-26.  The suffix order (hence the BWT) is a property of the text, so any correct suffix sorter gives the
+    reference's; here the restatement's.  (lb, len) per read; texts / reads = tests.util.make_text / sample_reads(seed=1, mutate=1)."""
     import fmoracle as fo
     from tests.util import make_text, sample_reads
-    text = make_text(1_000_000, 5, seed=42)
-    ox = fo.OraIndex.build("IB16", 5, [text], 16, False)
-    bs = ox.bwt_string()
-    n = bs.size()
-    bwt = np.fromiter((bs.symbol(i) for i in range(n)), dtype=np.uint8, count=n)
-    ref = fo.RefString("IB16", 5, bwt)
-    counts = np.bincount(bwt, minlength=5)
-    Cc = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    reads = sample_reads(text, 10_000, 31, seed=1, mutate=1)
-    out = np.zeros((len(reads), 2), dtype=np.uint32)
-    for q, r in enumerate(reads):
-        lb, ln = 0, n
-        for c in r[::-1]:
-            a, b = ref.rank(lb, int(c)), ref.rank(lb + ln, int(c))
-            lb, ln = int(Cc[c]) + a, b - a
-            if ln == 0:
-                break
-        out[q] = (lb, ln)
-    np.save(os.path.join(HERE, "config0_intervals.npy"), out)
+    out = {}
+    for name, (layout, sigma, tn, seed, nreads, rl) in REF_SEARCH_CASES.items():
+        text = make_text(tn, sigma, seed=seed)
+        ox = fo.OraIndex.build("IB16", sigma, [text], 16, False)
+        bs = ox.bwt_string()
+        n = bs.size()
+        bwt = np.fromiter((bs.symbol(i) for i in range(n)), dtype=np.uint8, count=n)
+        ref = fo.RefString(layout, sigma, bwt)
+        Cc = np.concatenate([[0], np.cumsum(np.bincount(bwt, minlength=sigma))]).astype(np.int64)
+        reads = sample_reads(text, nreads, rl, seed=1, mutate=1, sigma=sigma)
+        res = np.zeros((len(reads), 2), dtype=np.uint32)
+        for q, r in enumerate(reads):
+            lb, ln = 0, n
+            for c in r[::-1]:
+                a, b = ref.rank(lb, int(c)), ref.rank(lb + ln, int(c))
+                lb, ln = int(Cc[c]) + a, b - a
+                if ln == 0:
+                    break
+            res[q] = (lb, ln)
+        out[name] = res
+    np.savez_compressed(os.path.join(HERE, "ref_search_intervals.npz"), **out)
     return out
 
 
 def main():
-    config0_intervals()
+    ref_search_intervals()
     with open(os.path.join(HERE, "reference_tests.json"), "w") as f:
         json.dump(reference_tests(), f, separators=(",", ":"))
     strings, schemes = ref_vectors()

@@ -294,11 +294,23 @@ def test_plumbing_config0():
     olb, oln = ox.search_exact(qbuf, qoff, nthreads=4)
     assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
     assert int((ln > 0).sum()) >= 5000
-    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "config0_intervals.npy"))      # computed with the real reference's rank
-    assert np.array_equal(lb, want[:, 0]) and np.array_equal(ln, want[:, 1])
-    gx.accelerate(3, lut_len=8, walk=2)
-    lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
-    assert np.array_equal(lb, want[:, 0]) and np.array_equal(ln, want[:, 1])
+
+
+@pytest.mark.parametrize("name", ["config0_ib16", "protein_wavelet", "epr16", "eprv2_16", "eprv5", "ibp16"])
+def test_search_intervals_from_the_real_reference_rank(name):
+    """tests/golden/ref_search_intervals.npz — (lb, len) computed by backward search over the REAL reference's rank functions
+    (make_golden.py::ref_search_intervals; config0_ib16 = BASELINE.json configs[0]) — reproduced by the HIP path, plain and with the tables"""
+    from tests.golden.make_golden import REF_SEARCH_CASES
+    layout, sigma, tn, seed, nreads, rl = REF_SEARCH_CASES[name]
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_search_intervals.npz"))[name]
+    text = make_text(tn, sigma, seed=seed)
+    gx = gpu_index(fo.OraIndex.build(layout, sigma, [text], 16, False))
+    qbuf, qoff = fm.flatten(sample_reads(text, nreads, rl, seed=1, mutate=1, sigma=sigma))
+    for tables in (False, True):
+        if tables:
+            gx.accelerate(3 if sigma == 5 else 1, lut_len=8 if sigma == 5 else 3, walk=2)
+        lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
+        assert np.array_equal(lb, want[:, 0]) and np.array_equal(ln, want[:, 1]), (name, tables)
 
 
 # ------------------------------------------------------------------------------------------------ k-mismatch
