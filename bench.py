@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--no-exact-tables", action="store_true", help="exact / protein: only the k-step table (no suffix-interval table, no walk table)")
     ap.add_argument("--lut-len", type=int, default=0, help="exact / protein: symbols of the interval table (0 = 15 bp / 6 aa)")
     ap.add_argument("--walk", type=int, default=2, help="exact / protein: 1 = LF^J walk table, 2 = LF^J and LF^2J")
-    ap.add_argument("--prefix-len", type=int, default=15, help="k2: symbols of the prefix table (fmgpu_index_accelerate_search)")
+    ap.add_argument("--prefix-len", type=int, default=16, help="k2: symbols of the prefix table (fmgpu_index_accelerate_search)")
     ap.add_argument("--trim", type=int, default=0, help="dev: every read loses 0..TRIM symbols at its end (a ragged batch)")
     ap.add_argument("--single-rank-collectives", action="store_true", help="rehearsal only: run the N > 1 code path (process group, asynchronous gather, barrier) with one rank")
     ap.add_argument("--sub-every", type=int, default=10, help="exact / protein: every n-th read carries one substitution (default 10 = SURVEY 8d; 0 = none; a dev knob)")

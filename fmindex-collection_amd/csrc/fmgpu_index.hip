@@ -531,24 +531,24 @@ __global__ __launch_bounds__(256) void k_walk2j(const uint2* __restrict__ wj, ui
 // bidirectional interval of every string w of L symbols in [1, sigma): extendRight symbol by symbol (fmindex/BiFMIndexCursor.h:121-128)
 template <class Occ>
 __global__ __launch_bounds__(256) void k_prefix_lut(Occ rv, uint64_t entries, uint32_t L, uint32_t R, idx_t n, uint4* __restrict__ lut) {
-    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= entries) return;
-    idx_t lb = 0, lbRev = 0, len = n;
-    uint32_t used = 0;
-    uint64_t rest = w;
     const uint32_t sigma = rv.sigma();
-    for (uint32_t t = 0; t < L && len != 0; ++t) {
-        uint32_t c = (uint32_t)(rest % R) + 1; rest /= R;
-        idx_t pre = 0, ra = 0, rb = 0;
-        for (uint32_t d = 0; d <= c && d < sigma; ++d) {
-            idx_t x, y;
-            rv.lf2(lbRev, lbRev + len, d, x, y);
-            if (d < c) pre += y - x; else { ra = x; rb = y; }
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < entries; w += (uint64_t)gridDim.x * blockDim.x) {   // (2^32 entries: more than one launch's threads)
+        idx_t lb = 0, lbRev = 0, len = n;
+        uint32_t used = 0;
+        uint64_t rest = w;
+        for (uint32_t t = 0; t < L && len != 0; ++t) {
+            uint32_t c = (uint32_t)(rest % R) + 1; rest /= R;
+            idx_t pre = 0, ra = 0, rb = 0;
+            for (uint32_t d = 0; d <= c && d < sigma; ++d) {
+                idx_t x, y;
+                rv.lf2(lbRev, lbRev + len, d, x, y);
+                if (d < c) pre += y - x; else { ra = x; rb = y; }
+            }
+            lb += pre; lbRev = ra; len = rb - ra;
+            ++used;
         }
-        lb += pre; lbRev = ra; len = rb - ra;
-        ++used;
+        lut[w] = make_uint4(lb, lbRev, len, used);
     }
-    lut[w] = make_uint4(lb, lbRev, len, used);
 }
 
 }  // namespace fmgpu
@@ -810,9 +810,9 @@ int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t w
     if (prefix_len > 0) {
         const uint32_t R = (uint32_t)x->bwt.sigma - 1;
         uint64_t entries = 1;
-        for (int t = 0; t < prefix_len; ++t) { entries *= R; if (entries > (1ull << 30)) return fail(FMGPU_ERR_UNSUPPORTED, "prefix table would exceed 2^30 entries"); }
+        for (int t = 0; t < prefix_len; ++t) { entries *= R; if (entries > (1ull << 32)) return fail(FMGPU_ERR_UNSUPPORTED, "prefix table would exceed 2^32 entries"); }
         FM_HIP(hipMalloc((void**)&x->lut, entries * 16));
-        dim3 grid((unsigned)((entries + 255) / 256)), block(256);
+        dim3 grid((unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22)), block(256);
         const DevString& r = x->rev;
         switch (r.family) {
         case FAM_A:

@@ -170,7 +170,7 @@ int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len
 
 /* Optional accelerators for fmgpu_search_scheme on a BiFMIndex (results unchanged):
  *   prefix_len > 0: table of the bidirectional SA interval of every string of `prefix_len` symbols ((sigma-1)^prefix_len entries of 16 bytes; DNA,
- *                   11 symbols: 67 MB) — the always-exact first part of a search (u[0] = 0, search_scheme/generator/h2.h) starts from its entry;
+ *                   11 symbols: 67 MB; 16 symbols: 69 GB, at most 2^32 entries) — the always-exact first part of a search (u[0] = 0, search_scheme/generator/h2.h) starts from its entry;
  *   walk & 1:       per row and direction LF, LF^2, LF^3 (12 bytes): a cursor of one row advances up to three symbols per load;
  *   walk & 2:       per row and direction LF^J and the J symbols met (8 bytes, J = 32 / bit_width(sigma-2)): with 2-bit symbols (sigma <= 5) a
  *                   one-row cursor advances 16 symbols per load wherever 16 steps of a search go in one direction. */
