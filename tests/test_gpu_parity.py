@@ -1289,7 +1289,7 @@ def test_full_size_k2_tables_agree():
         return hits, st.lf_steps
     base, nodes = run()
     assert len(base) >= nq - 100 and int(base["errors"].max()) == 2
-    for accel in ((11, 1), (0, 2), (11, 3)):
+    for accel in ((11, 1), (0, 2), (11, 3), (16, 3)):                       # (16 symbols: 2^32 prefix-table entries, the bench default)
         gx.accelerate_search(*accel)
         hits, nn = run()
         assert nn == nodes and hits.tobytes() == base.tobytes(), accel
