@@ -188,7 +188,14 @@ def main():
         else:                                                   # + interval table of the last 15 bp / 6 aa, + per-row LF^J walk table (J = 16 bp / 6 aa)
             index.accelerate(args.kstep, lut_len=args.lut_len or (6 if protein else 15), walk=args.walk)
     if bidir and not args.no_search_accel:
-        index.accelerate_search(args.prefix_len, 3)
+        try:
+            index.accelerate_search(args.prefix_len, 3)
+        except fm.FmgpuError as ex:                            # (the 16-symbol table is 69 GB: should the card be short of memory, one symbol less)
+            if args.prefix_len < 16:
+                raise
+            print("bench.py: %s; retrying with a 15-symbol prefix table" % ex, file=sys.stderr, flush=True)
+            args.prefix_len = 15
+            index.accelerate_search(args.prefix_len, 3)
     build_s = time.time() - t0
     if not want_cpu:
         del text
