@@ -83,7 +83,8 @@ class ExpandedScheme(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("lf_steps", C.c_uint64), ("hits", C.c_uint64), ("kernel_ms", C.c_float)]
+    _fields_ = [("lf_steps", C.c_uint64), ("hits", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32),
+                ("table_bytes", C.c_uint64), ("table_accesses", C.c_uint64)]
 
 
 # every symbol include/fmgpu.h declares (tests check that the library exports all of them)
@@ -94,6 +95,7 @@ EXPORTS = [
     "fmgpu_malloc", "fmgpu_free", "fmgpu_memcpy_h2d", "fmgpu_memcpy_d2h", "fmgpu_synchronize",
     "fmgpu_build_index", "fmgpu_built_free", "fmgpu_built_get", "fmgpu_index_accelerate", "fmgpu_index_accelerate_search",
     "fmgpu_index_accelerate_exact", "fmgpu_index_accelerate_locate", "fmgpu_hits_sort", "fmgpu_hits_pack16",
+    "fmgpu_index_row_bits", "fmgpu_index_accelerate_lf", "fmgpu_search_exact_depth", "fmgpu_cursor_extend",
 ]
 
 _lib = None
@@ -139,6 +141,10 @@ def lib():
         L.fmgpu_index_accelerate_exact.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     if hasattr(L, "fmgpu_index_accelerate_search"):
         L.fmgpu_index_accelerate_search.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.fmgpu_index_row_bits.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.fmgpu_index_accelerate_lf.argtypes = [C.c_void_p, C.c_int32]
+    L.fmgpu_search_exact_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.fmgpu_cursor_extend.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.fmgpu_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
     L.fmgpu_free.argtypes = [C.c_void_p]
     L.fmgpu_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]

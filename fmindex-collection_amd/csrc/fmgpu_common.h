@@ -1,7 +1,12 @@
 // fmgpu_common.h — internal to libfmgpu.so: device formats, occurrence-table accessors, host helpers.
 //
-// Device formats (HBM layout).  Row indices are 32-bit on the device (n < 2^32 - 64);
-// the ABI speaks uint64_t like the reference's size_t.
+// Row width.  Every translation unit with kernels is compiled twice: FMGPU_WIDE=0 (namespace fmgpu32, idx_t = uint32_t, n < 2^32 - 64 rows,
+// all accelerator tables) and FMGPU_WIDE=1 (namespace fmgpu64, idx_t = uint64_t, n < 2^40 rows: the plain occurrence tables, exact search,
+// search_ng26<Hamming>, search_backtracking, locate, construction).  The reference is size_t throughout and switches to a 64-bit suffix array at
+// n >= 2^31 (utils.h:243-247).  fmgpu_abi.hip holds the extern "C" entry points and picks the namespace from the handle (IndexHeader::wide).
+// The ABI speaks uint64_t like the reference's size_t either way.
+//
+// Device formats (HBM layout).
 //
 //  Format A  ("LF-ready interleaved bitvectors", built from the reference's InterleavedBitvector* /
 //             InterleavedBitvectorPrefix* arrays by k_convert_ib):
@@ -10,17 +15,25 @@
 //         u64 bits  = bit k set  <=>  s[64B + k] == c           (row p <-> bit p&63 of block p>>6)
 //     sigma <= 5: bstride = 64 (one HBM line per block, 4 spare bytes); otherwise bstride = 12*sigma.
 //     LF(i, c) = cnt + popc(bits & lowmask(i & 63)),  rank(i, c) = LF(i, c) - C[c].
+//     Wide rows: cnt is relative to the block's super-block (2^30 rows); super[(i >> 30) * sigma + c] (u64, a few hundred bytes, cache
+//     resident) holds the rest:  LF(i, c) = super + cnt + popc(...).
 //     The reference stores u16 counts relative to a 65 536-row super-block plus a u64 super-block table
 //     (string/InterleavedBitvector.h:13-60) and shifts rows by one bit (row p <-> bit (p+1)&63 of block
 //     (p+1)>>6); both are normalised away at upload, results are identical.
 //
 //  Format R  (reference layout as is — InterleavedEPR*, InterleavedEPRV2*): blocks + superBlocks copied verbatim.
 //
-//  Format W  (wavelet; built from Wavelet::bitvector[*] at upload, or on the device by the builder): every node is an array
-//     of 64-byte lines { u64 hdr0 = ones before the line (within the node); u64 hdr1 = cum[1..5], 9 bits each, cum[k] = ones
-//     in bits[0..k); u64 bits[6] } (384 payload bits per line); nodes are concatenated, line offset of node k in node_base[k].
-//     One node-rank = one line, fetched with two loads (header + the word that holds the position); the reference touches
-//     three arrays (bitvector/Bitvector.h:147-166).
+//  Format W  (the reference's binary wavelet tree, one 64-byte line per 384 node bits; built from Wavelet::bitvector[*] at upload and only
+//     kept until Format M has been derived from it): { u64 hdr0 = ones before the line (within the node); u64 hdr1 = cum[1..5], 9 bits each;
+//     u64 bits[6] }; nodes concatenated, line offset of node k in node_base[k].
+//
+//  Format M  (multi-ary wavelet tree — what a Wavelet string is searched in): the bit_width(sigma-1) symbol bits are cut from the top into
+//     digits of 3, 3, 2 bits (5 bits: 3 + 2; the reference's own two-level form is string/MultiaryWavelet.h:27-33).  Level l has one node
+//     per value of the digits above it, holding the level's digit of every symbol with that prefix in text order.  A node is an array of
+//     blocks of 64 positions:  { u32 cnt[2^d] = occurrences of each digit value before the block (within the node; wide rows: relative to
+//     the 2^30-position super-block);  u64 plane[d] = bit k of the digit of the 64 positions }  — 64 bytes for d = 3, 32 for d = 2, 16 for
+//     d = 1: one memory line per node rank, two (sigma = 28) instead of five dependent lines per LF step and end.
+//     rank_v(i) = cnt[v] + popc(AND_k (plane[k] ^ ~bit_k(v)) & lowmask(i & 63)).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -29,13 +42,130 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/fmgpu.h"
 
+#ifndef FMGPU_WIDE
+#define FMGPU_WIDE 0
+#endif
+#if FMGPU_WIDE
+#define FMGPU_NS fmgpu64
+#else
+#define FMGPU_NS fmgpu32
+#endif
+
+// ====================================================================================================================== shared (width-independent)
 namespace fmgpu {
 
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+const char* last_error_cstr();
+
+#define FM_HIP(call)                                                   \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return ::fmgpu::hip_fail(e_, #call);     \
+    } while (0)
+
+// after a `<<<>>>`: a rejected launch configuration is reported by hipGetLastError only (hipDeviceSynchronize stays silent)
+#define FM_LAUNCHED(what)                                              \
+    do {                                                               \
+        hipError_t e_ = hipGetLastError();                             \
+        if (e_ != hipSuccess) return ::fmgpu::hip_fail(e_, what);      \
+    } while (0)
+
+bool is_device_pointer(const void* p);
+
+// grid of 256-thread blocks covering `threads` threads.  A kernel whose domain may exceed the grid limit runs a grid-stride loop and passes the
+// number of blocks it wants at most; every other launch fails with FMGPU_ERR_UNSUPPORTED instead of being rejected by the runtime.
+constexpr uint64_t kMaxGridBlocks = 0x7fffffffull;
+inline int grid_of(uint64_t threads, dim3* out, uint64_t cap_blocks = 0) {
+    uint64_t blocks = (threads + 255) / 256;
+    if (blocks == 0) blocks = 1;
+    if (cap_blocks) blocks = blocks < cap_blocks ? blocks : cap_blocks;
+    if (blocks > kMaxGridBlocks) return fail(FMGPU_ERR_UNSUPPORTED, "a launch of " + std::to_string(threads) + " threads exceeds the grid limit");
+    *out = dim3((unsigned)blocks);
+    return 0;
+}
+#define FM_GRID(var, threads)       dim3 var; do { int rc_ = ::fmgpu::grid_of((threads), &var); if (rc_) return rc_; } while (0)
+
+struct DBuf {    // RAII device allocation
+    void* p = nullptr; size_t bytes = 0;
+    int alloc(size_t b) {
+        release(); bytes = b ? b : 8;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            p = nullptr; bytes = 0; (void)hipGetLastError();
+            return fail(e == hipErrorOutOfMemory ? FMGPU_ERR_NOMEM : FMGPU_ERR_HIP, "hipMalloc(" + std::to_string(b) + " bytes): " + hipGetErrorString(e));
+        }
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void* take() { void* q = p; p = nullptr; bytes = 0; return q; }     // hands the allocation over (to a handle)
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    ~DBuf() { release(); }
+    DBuf() = default;
+    DBuf(const DBuf&) = delete; DBuf& operator=(const DBuf&) = delete;
+};
+
+// A temporary device mirror of a caller buffer: device pointers are used in place, host pointers are staged.
+struct Staged {
+    void* dev = nullptr;
+    void* host = nullptr;
+    size_t bytes = 0;
+    bool owned = false, writeback = false;
+    hipStream_t stream = nullptr;
+    int in(const void* p, size_t nbytes, hipStream_t s);      // read-only input
+    int out(void* p, size_t nbytes, hipStream_t s);           // output (copied back by finish())
+    int finish();                                             // D2H of outputs (synchronises when anything was staged)
+    ~Staged();
+};
+
+struct Built {   // host copies of construction by-products (fmgpu_build_index with keep_host)
+    std::vector<std::vector<uint8_t>> part;
+};
+
+// first member of both widths' Index: what the extern "C" layer needs to route a handle
+constexpr uint32_t kIndexMagic = 0x464d4758u;   // "FMGX"
+struct IndexHeader { uint32_t magic = kIndexMagic; int32_t wide = 0; int32_t device = 0; };
+
+// rows below this are indexed with 32-bit device tables (FMGPU_FORCE_WIDE=1 sends every new index to the 64-bit build: a test knob)
+constexpr uint64_t kNarrowLimit = 0xffffffffull - 64;
+constexpr uint64_t kWideLimit = 1ull << 40;
+bool want_wide(uint64_t n);
+
+// per host thread and device: small device buffers and events that every search call needs (allocating and freeing them per call costs more
+// than the bookkeeping they serve — hipFree synchronises the device).  `ctr` serves calls that report stats (they synchronise before
+// returning, so it is idle between calls), `sink` the others (never read).
+constexpr uint32_t kCounterStripes = 64;      // step counters of the one-thread-per-query kernels are striped (a single word would serialise one atomic per wave)
+constexpr uint32_t kCounterKinds = 3;         // [0] steps, [1] table bytes, [2] table accesses — kCounterStripes words each
+struct CallScratch {
+    unsigned long long* ctr = nullptr; unsigned long long* sink = nullptr; unsigned long long* len2 = nullptr;
+    unsigned long long* pinned = nullptr;                         // host side of the small read-backs (a pageable target costs a staging copy each)
+    void* frames = nullptr; size_t frames_bytes = 0;              // frame stacks of the DFS kernels, kept between calls up to kFrameCache bytes
+    void* dfs_ctr = nullptr;                                      // their Counters (a DFS call synchronises before it returns: one at a time per thread)
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    void drop();
+};
+int call_scratch(CallScratch** out);          // the calling thread's scratch for its current device (created on first use; all-or-nothing)
+
+}  // namespace fmgpu
+
+// ====================================================================================================================== per row width
+namespace FMGPU_NS {
+using namespace fmgpu;
+
+#if FMGPU_WIDE
+using idx_t = uint64_t;
+#else
 using idx_t = uint32_t;
+#endif
+constexpr bool kWide = FMGPU_WIDE != 0;
+constexpr uint32_t kSuperShift = 30;          // wide rows: counts are kept relative to super-blocks of 2^30 rows / node positions
+constexpr idx_t kNoRow = ~(idx_t)0;
 
 enum Family : int { FAM_A = 0, FAM_EPR = 1, FAM_EPRV2 = 2, FAM_WAVELET = 3 };
 
@@ -45,6 +175,7 @@ struct ViewA {            // Format A
     uint32_t bstride;
     uint32_t sigma;
     const idx_t* C;       // sigma+1 entries (device)
+    const uint64_t* super;// wide rows only: [row >> 30][sigma]
 };
 
 struct ViewR {            // Format R (EPR / EPRV2 reference layout)
@@ -58,27 +189,63 @@ struct ViewR {            // Format R (EPR / EPRV2 reference layout)
     uint64_t maskEven, bitMask;
 };
 
-struct ViewW {            // Format W
+struct ViewW {            // Format W (transient)
     const uint64_t* lines;      // 8 u64 per line
     const uint32_t* node_base;  // line offset per node
     const idx_t* C;
     uint32_t sigma, bitct;
 };
 
+constexpr int kMaxLevelsM = 3;
+constexpr int kMaxNodesM = 1 + 8 + 64;
+struct LevelM { uint32_t bits, shift, stride, first_node; };     // digit = (c >> shift) & ((1 << bits) - 1); node = first_node + (c >> (shift + bits))
+struct ViewM {            // Format M
+    const uint8_t* data;
+    const uint64_t* node_off;   // byte offset of every node's block array (kMaxNodesM entries at most)
+    const idx_t* C;
+    uint32_t sigma, bitct, nlevels, nnodes;
+    LevelM lv[kMaxLevelsM];
+    const uint64_t* super;      // wide rows only: counts of the super-blocks, [node_super[node] + (pos >> 30)][8]
+    const uint32_t* node_super; // wide rows only: first super-block row of every node
+};
+// digits of a symbol of `bitct` bits, from the top
+inline void digits_of(uint32_t bitct, uint32_t* d, uint32_t* n) {
+    static const uint8_t tab[9][3] = {{1, 0, 0}, {1, 0, 0}, {2, 0, 0}, {3, 0, 0}, {2, 2, 0}, {3, 2, 0}, {3, 3, 0}, {3, 2, 2}, {3, 3, 2}};
+    *n = 0;
+    for (int k = 0; k < 3; ++k) if (tab[bitct][k]) d[(*n)++] = tab[bitct][k];
+}
+
 // ------------------------------------------------------------------ small device helpers
 __device__ __forceinline__ uint64_t lowmask(uint32_t k) { return (1ull << k) - 1ull; }   // k in [0, 63]
 __device__ __forceinline__ uint32_t popc64(uint64_t v) { return (uint32_t)__popcll(v); }
 
-struct EntryA { uint32_t cnt; uint64_t bits; };
+struct EntryA { idx_t cnt; uint64_t bits; };
 
-__device__ __forceinline__ EntryA load_entry_a(const uint8_t* blk, uint32_t bstride, idx_t i, uint32_t c) {
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(blk + (size_t)(i >> 6) * bstride + c * 12u);
+__device__ __forceinline__ EntryA load_entry_a(const ViewA& v, idx_t i, uint32_t c) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(v.blk + (size_t)(i >> 6) * v.bstride + c * 12u);
     EntryA e;
     uint32_t a = p[0], b = p[1], d = p[2];
     e.cnt = a;
+    if constexpr (kWide) e.cnt += v.super[(size_t)(i >> kSuperShift) * v.sigma + c];
     e.bits = (uint64_t)b | ((uint64_t)d << 32);
     return e;
 }
+
+// Format A entry writer shared by the converters and the builder: `total` = C[c] + occurrences before the block, `base` = the same for the first
+// block of the block's super-block (wide rows: the entry keeps total - base, the first block of a super-block publishes base)
+__device__ __forceinline__ void put_entry_count_a(uint8_t* out, uint64_t* super, uint64_t B, uint32_t c, uint32_t sigma, uint32_t bstride, uint64_t total, uint64_t base) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + B * bstride + 12ull * c);
+    if constexpr (kWide) {
+        o[0] = (uint32_t)(total - base);
+        if ((B & ((1ull << (kSuperShift - 6)) - 1ull)) == 0) super[(B >> (kSuperShift - 6)) * sigma + c] = total;
+    } else o[0] = (uint32_t)total;
+}
+__device__ __forceinline__ void put_entry_a(uint8_t* out, uint64_t* super, uint64_t B, uint32_t c, uint32_t sigma, uint32_t bstride, uint64_t total, uint64_t base, uint64_t bits) {
+    put_entry_count_a(out, super, B, c, sigma, bstride, total, base);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + B * bstride + 12ull * c);
+    o[1] = (uint32_t)bits; o[2] = (uint32_t)(bits >> 32);
+}
+__device__ __forceinline__ uint64_t super_first_block(uint64_t B) { return (B >> (kSuperShift - 6)) << (kSuperShift - 6); }
 
 // ------------------------------------------------------------------ occurrence-table accessors
 // Every Occ exposes:
@@ -93,14 +260,14 @@ struct OccA {
     __device__ __forceinline__ uint32_t sigma() const { return SIGMA > 0 ? (uint32_t)SIGMA : v.sigma; }
 
     __device__ __forceinline__ void lf2(idx_t a, idx_t b, uint32_t c, idx_t& ra, idx_t& rb) const {
-        EntryA ea = load_entry_a(v.blk, v.bstride, a, c);
-        EntryA eb = load_entry_a(v.blk, v.bstride, b, c);
-        ra = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
-        rb = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
+        EntryA ea = load_entry_a(v, a, c);
+        EntryA eb = load_entry_a(v, b, c);
+        ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
+        rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
     }
     __device__ __forceinline__ idx_t lf(idx_t i, uint32_t c) const {
-        EntryA e = load_entry_a(v.blk, v.bstride, i, c);
-        return e.cnt + popc64(e.bits & lowmask(i & 63u));
+        EntryA e = load_entry_a(v, i, c);
+        return e.cnt + popc64(e.bits & lowmask((uint32_t)i & 63u));
     }
     __device__ __forceinline__ idx_t rank(idx_t i, uint32_t c) const { return lf(i, c) - v.C[c]; }
     __device__ __forceinline__ idx_t prefix_rank(idx_t i, uint32_t c) const {
@@ -110,9 +277,9 @@ struct OccA {
     }
     __device__ __forceinline__ uint32_t symbol(idx_t i) const {
         const uint32_t s = sigma();
-        uint32_t bit = i & 63u;
+        uint32_t bit = (uint32_t)i & 63u;
         for (uint32_t c = 0; c + 1 < s; ++c) {
-            EntryA e = load_entry_a(v.blk, v.bstride, i, c);
+            EntryA e = load_entry_a(v, i, c);
             if ((e.bits >> bit) & 1ull) return c;
         }
         return s - 1;
@@ -120,10 +287,10 @@ struct OccA {
     // symbol and LF of that symbol from one pass over the block (locate)
     __device__ __forceinline__ idx_t lf_symbol(idx_t i, uint32_t& symb) const {
         const uint32_t s = sigma();
-        uint32_t bit = i & 63u;
+        uint32_t bit = (uint32_t)i & 63u;
         uint32_t c = 0;
-        EntryA e = load_entry_a(v.blk, v.bstride, i, 0);
-        while (c + 1 < s && !((e.bits >> bit) & 1ull)) { ++c; e = load_entry_a(v.blk, v.bstride, i, c); }
+        EntryA e = load_entry_a(v, i, 0);
+        while (c + 1 < s && !((e.bits >> bit) & 1ull)) { ++c; e = load_entry_a(v, i, c); }
         symb = c;
         return e.cnt + popc64(e.bits & lowmask(bit));
     }
@@ -138,52 +305,45 @@ struct OccA {
         for (int k = 0; k < 4; ++k) { uint4 t = pb[k]; db[4 * k] = t.x; db[4 * k + 1] = t.y; db[4 * k + 2] = t.z; db[4 * k + 3] = t.w; }
     }
     __device__ __forceinline__ void all2_of(const uint32_t* da, const uint32_t* db, idx_t a, idx_t b, idx_t* lfa, idx_t* lfb) const {
-        const uint64_t ma = lowmask(a & 63u), mb = lowmask(b & 63u);
+        const uint64_t ma = lowmask((uint32_t)a & 63u), mb = lowmask((uint32_t)b & 63u);
+        constexpr uint32_t S = (uint32_t)(SIGMA > 0 ? SIGMA : 1);
 #pragma unroll
-        for (uint32_t c = 0; c < (uint32_t)(SIGMA > 0 ? SIGMA : 1); ++c) {
+        for (uint32_t c = 0; c < S; ++c) {
             lfa[c] = da[3 * c] + popc64(((uint64_t)da[3 * c + 1] | ((uint64_t)da[3 * c + 2] << 32)) & ma);
             lfb[c] = db[3 * c] + popc64(((uint64_t)db[3 * c + 1] | ((uint64_t)db[3 * c + 2] << 32)) & mb);
+            if constexpr (kWide) {
+                lfa[c] += v.super[(size_t)(a >> kSuperShift) * S + c];
+                lfb[c] += v.super[(size_t)(b >> kSuperShift) * S + c];
+            }
         }
     }
     template <int MS>
     __device__ __forceinline__ void all2(idx_t a, idx_t b, idx_t* lfa, idx_t* lfb) const {
         const uint32_t s = sigma();
         if (SIGMA > 0 && SIGMA <= 5) {
-            // 64-byte block = one line: fetch it whole (4 x dwordx4); both ends usually share the block once the
-            // interval is short, then the second fetch is skipped
-            // both ends' loads are issued back to back (one round trip); a wave holds 64 out-of-phase lanes, so "rare"
-            // second fetches would otherwise be paid by the whole wave in nearly every iteration
+            // 64-byte block = one line: fetch it whole (4 x dwordx4); both ends' loads are issued back to back (one round trip): a wave holds 64
+            // out-of-phase lanes, so "rare" second fetches would otherwise be paid by the whole wave in nearly every iteration
             uint32_t da[16], db[16];
-            const uint4* pa = reinterpret_cast<const uint4*>(v.blk + (size_t)(a >> 6) * 64u);
-            const uint4* pb = reinterpret_cast<const uint4*>(v.blk + (size_t)(b >> 6) * 64u);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { uint4 t = pa[k]; da[4 * k] = t.x; da[4 * k + 1] = t.y; da[4 * k + 2] = t.z; da[4 * k + 3] = t.w; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { uint4 t = pb[k]; db[4 * k] = t.x; db[4 * k + 1] = t.y; db[4 * k + 2] = t.z; db[4 * k + 3] = t.w; }
-            const uint64_t ma = lowmask(a & 63u), mb = lowmask(b & 63u);
-#pragma unroll
-            for (uint32_t c = 0; c < (uint32_t)SIGMA; ++c) {
-                lfa[c] = da[3 * c] + popc64(((uint64_t)da[3 * c + 1] | ((uint64_t)da[3 * c + 2] << 32)) & ma);
-                lfb[c] = db[3 * c] + popc64(((uint64_t)db[3 * c + 1] | ((uint64_t)db[3 * c + 2] << 32)) & mb);
-            }
+            load2(a, b, da, db);
+            all2_of(da, db, a, b, lfa, lfb);
             return;
         }
         if (MS <= 32) {
 #pragma unroll
             for (uint32_t c = 0; c < (uint32_t)MS; ++c) {
                 if (c < s) {
-                    EntryA ea = load_entry_a(v.blk, v.bstride, a, c);
-                    EntryA eb = load_entry_a(v.blk, v.bstride, b, c);
-                    lfa[c] = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
-                    lfb[c] = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
+                    EntryA ea = load_entry_a(v, a, c);
+                    EntryA eb = load_entry_a(v, b, c);
+                    lfa[c] = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
+                    lfb[c] = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
                 }
             }
         } else {
             for (uint32_t c = 0; c < s; ++c) {
-                EntryA ea = load_entry_a(v.blk, v.bstride, a, c);
-                EntryA eb = load_entry_a(v.blk, v.bstride, b, c);
-                lfa[c] = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
-                lfb[c] = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
+                EntryA ea = load_entry_a(v, a, c);
+                EntryA eb = load_entry_a(v, b, c);
+                lfa[c] = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
+                lfb[c] = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
             }
         }
     }
@@ -223,8 +383,8 @@ struct OccR {
         return te | to;
     }
     __device__ __forceinline__ void split(idx_t i, size_t& b, size_t& sb, uint32_t& bit) const {
-        if (V2) { b = i >> 6; sb = v.period_shift >= 32 ? 0 : (i >> v.period_shift); bit = i & 63u; }
-        else    { b = i / v.rows; sb = i / v.period; bit = i % v.rows; }
+        if (V2) { b = (size_t)(i >> 6); sb = v.period_shift >= 32 ? (size_t)((uint64_t)i >> 32) : (size_t)(i >> v.period_shift); bit = (uint32_t)i & 63u; }
+        else    { b = (size_t)(i / v.rows); sb = (size_t)(i / v.period); bit = (uint32_t)(i % v.rows); }
     }
     __device__ __forceinline__ idx_t rank(idx_t i, uint32_t c) const {
         size_t b, sb; uint32_t bit; split(i, b, sb, bit);
@@ -266,59 +426,20 @@ struct OccR {
     }
 };
 
-// Format W: string/Wavelet.h:77-141 over one-line node ranks
+// Format W: string/Wavelet.h:77-102 over one-line node ranks (only used to read the symbols back when Format M is derived from uploaded node arrays)
 struct OccW {
     ViewW v;
-    static constexpr int kMaxSigma = 256;
-    __device__ __forceinline__ uint32_t sigma() const { return v.sigma; }
-
     __device__ __forceinline__ idx_t node_rank(uint32_t id, idx_t i, uint32_t* bit_out) const {
-        const uint32_t line = i / 384u, r = i - line * 384u;
+        const idx_t line = i / 384u; const uint32_t r = (uint32_t)(i - line * 384u);
         const uint32_t k = r >> 6, part = r & 63u;
-        const uint64_t* L = v.lines + ((size_t)v.node_base[id] + line) * 8u;
+        const uint64_t* L = v.lines + ((size_t)v.node_base[id] + (size_t)line) * 8u;
         const uint64_t h0 = L[0], h1 = L[1];
         const uint64_t w = L[2 + k];
         const uint32_t cum = k ? (uint32_t)(h1 >> (9u * (k - 1u))) & 0x1ffu : 0u;
         if (bit_out) *bit_out = (uint32_t)((w >> part) & 1ull);
         return (idx_t)h0 + cum + popc64(w & lowmask(part));
     }
-    __device__ __forceinline__ idx_t rank(idx_t i, uint32_t c) const {
-        for (uint32_t b = 0; b < v.bitct; ++b) {
-            uint32_t bitId = v.bitct - b - 1;
-            uint32_t bit = (c >> bitId) & 1u;
-            uint32_t id = ((1u << b) - 1u) + (c >> (bitId + 1));
-            idx_t r = node_rank(id, i, nullptr);
-            i = bit ? r : i - r;
-        }
-        return i;
-    }
-    __device__ __forceinline__ idx_t lf(idx_t i, uint32_t c) const { return rank(i, c) + v.C[c]; }
-    __device__ __forceinline__ void lf2(idx_t a, idx_t b, uint32_t c, idx_t& ra, idx_t& rb) const {
-        // both ends descend the same node path: interleave the two dependent chains
-        for (uint32_t lv = 0; lv < v.bitct; ++lv) {
-            uint32_t bitId = v.bitct - lv - 1;
-            uint32_t bit = (c >> bitId) & 1u;
-            uint32_t id = ((1u << lv) - 1u) + (c >> (bitId + 1));
-            idx_t x = node_rank(id, a, nullptr), y = node_rank(id, b, nullptr);
-            a = bit ? x : a - x;
-            b = bit ? y : b - y;
-        }
-        ra = a + v.C[c]; rb = b + v.C[c];
-    }
-    __device__ __forceinline__ idx_t prefix_rank(idx_t i, uint32_t c) const {
-        if (c == 0) return 0;
-        c -= 1;
-        idx_t a = 0;
-        for (uint32_t b = 0; b < v.bitct; ++b) {
-            uint32_t bitId = v.bitct - b - 1;
-            uint32_t bit = (c >> bitId) & 1u;
-            uint32_t id = ((1u << b) - 1u) + (c >> (bitId + 1));
-            idx_t r = node_rank(id, i, nullptr);
-            if (!bit) i = i - r; else { a += i - r; i = r; }
-        }
-        return a + i;
-    }
-    __device__ __forceinline__ idx_t lf_symbol(idx_t i, uint32_t& symb) const {
+    __device__ __forceinline__ uint32_t symbol(idx_t i) const {
         uint32_t s = 0;
         for (uint32_t b = 0; b < v.bitct; ++b) {
             uint32_t id = ((1u << b) - 1u) + s;
@@ -326,6 +447,78 @@ struct OccW {
             idx_t r = node_rank(id, i, &bit);
             s = (s << 1) | bit;
             i = bit ? r : i - r;
+        }
+        return s;
+    }
+};
+
+// Format M: the multi-ary wavelet tree
+struct OccM {
+    ViewM v;
+    static constexpr int kMaxSigma = 256;
+    __device__ __forceinline__ uint32_t sigma() const { return v.sigma; }
+
+    __device__ __forceinline__ const uint8_t* block(const LevelM& L, uint32_t node, idx_t i) const {
+        return v.data + v.node_off[node] + (size_t)(i >> 6) * L.stride;
+    }
+    static __device__ __forceinline__ uint64_t match(const uint64_t* pl, uint32_t bits, uint32_t val) {
+        uint64_t m = ~0ull;
+        for (uint32_t k = 0; k < bits; ++k) m &= pl[k] ^ (0ull - (uint64_t)((~val >> k) & 1u));
+        return m;
+    }
+    __device__ __forceinline__ idx_t super_of(uint32_t node, idx_t i, uint32_t val) const {
+        if constexpr (kWide) return (idx_t)v.super[((size_t)v.node_super[node] + (size_t)(i >> kSuperShift)) * 8u + val];
+        else return 0;
+    }
+    __device__ __forceinline__ idx_t node_rank(const LevelM& L, uint32_t node, idx_t i, uint32_t val) const {
+        const uint8_t* b = block(L, node, i);
+        const uint32_t cnt = reinterpret_cast<const uint32_t*>(b)[val];
+        const uint64_t* pl = reinterpret_cast<const uint64_t*>(b + (4u << L.bits));
+        return super_of(node, i, val) + cnt + popc64(match(pl, L.bits, val) & lowmask((uint32_t)i & 63u));
+    }
+    __device__ __forceinline__ idx_t rank(idx_t i, uint32_t c) const {
+        for (uint32_t l = 0; l < v.nlevels; ++l) {
+            const LevelM L = v.lv[l];
+            i = node_rank(L, L.first_node + (c >> (L.shift + L.bits)), i, (c >> L.shift) & ((1u << L.bits) - 1u));
+        }
+        return i;
+    }
+    __device__ __forceinline__ idx_t lf(idx_t i, uint32_t c) const { return rank(i, c) + v.C[c]; }
+    __device__ __forceinline__ void lf2(idx_t a, idx_t b, uint32_t c, idx_t& ra, idx_t& rb) const {
+        for (uint32_t l = 0; l < v.nlevels; ++l) {        // both ends descend the same node path: the two dependent chains interleave
+            const LevelM L = v.lv[l];
+            const uint32_t node = L.first_node + (c >> (L.shift + L.bits)), val = (c >> L.shift) & ((1u << L.bits) - 1u);
+            const idx_t x = node_rank(L, node, a, val), y = node_rank(L, node, b, val);
+            a = x; b = y;
+        }
+        ra = a + v.C[c]; rb = b + v.C[c];
+    }
+    __device__ __forceinline__ idx_t prefix_rank(idx_t i, uint32_t c) const {     // symbols < c among the first i
+        idx_t acc = 0;
+        if (c >= (1u << v.bitct)) return i;                                       // (c == 2^bitct == sigma: every symbol is smaller)
+        for (uint32_t l = 0; l < v.nlevels; ++l) {
+            const LevelM L = v.lv[l];
+            const uint32_t node = L.first_node + (c >> (L.shift + L.bits)), val = (c >> L.shift) & ((1u << L.bits) - 1u);
+            for (uint32_t u = 0; u < val; ++u) acc += node_rank(L, node, i, u);   // same prefix, smaller digit (one block: the same line)
+            i = node_rank(L, node, i, val);
+        }
+        return acc;
+    }
+    __device__ __forceinline__ idx_t lf_symbol(idx_t i, uint32_t& symb) const {
+        uint32_t s = 0;
+        for (uint32_t l = 0; l < v.nlevels; ++l) {
+            const LevelM L = v.lv[l];
+            const uint32_t node = L.first_node + s;
+            const uint8_t* b = block(L, node, i);
+            const uint64_t* pl = reinterpret_cast<const uint64_t*>(b + (4u << L.bits));
+            uint64_t p[3] = {0, 0, 0};
+            for (uint32_t k = 0; k < L.bits; ++k) p[k] = pl[k];
+            const uint32_t bit = (uint32_t)i & 63u;
+            uint32_t val = 0;
+            for (uint32_t k = 0; k < L.bits; ++k) val |= (uint32_t)((p[k] >> bit) & 1ull) << k;
+            const uint32_t cnt = reinterpret_cast<const uint32_t*>(b)[val];
+            i = super_of(node, i, val) + cnt + popc64(match(p, L.bits, val) & lowmask(bit));
+            s = (s << L.bits) | val;
         }
         symb = s;
         return i + v.C[s];
@@ -344,9 +537,9 @@ struct ViewSA {
     uint32_t bits0, bits1; uint64_t div0, div1;
 };
 
-__device__ __forceinline__ bool sa_present(const ViewSA& s, idx_t i) { return (s.bits[i >> 6] >> (i & 63u)) & 1ull; }
+__device__ __forceinline__ bool sa_present(const ViewSA& s, idx_t i) { return (s.bits[i >> 6] >> ((uint32_t)i & 63u)) & 1ull; }
 __device__ __forceinline__ uint64_t sa_rank(const ViewSA& s, idx_t i) {   // bitvector/Bitvector2L.h:123-142
-    uint32_t bitId = i & 511u;
+    uint32_t bitId = (uint32_t)i & 511u;
     const uint64_t* w = s.bits + (size_t)(i >> 9) * 8u;
     uint32_t cnt = 0;
     for (uint32_t k = 0; k < (bitId >> 6); ++k) cnt += popc64(w[k]);
@@ -367,12 +560,14 @@ __device__ __forceinline__ uint64_t dense_access(const uint64_t* data, uint32_t 
 struct DevString {
     int layout = 0, family = 0, sigma = 0, bitct = 0;
     uint64_t n = 0;
-    void* blk = nullptr;       // Format A blocks / Format R blocks / Format W lines
-    void* aux = nullptr;       // Format R superBlocks / Format W node_base
-    size_t blk_bytes = 0, aux_bytes = 0;
-    ViewA va{}; ViewR vr{}; ViewW vw{};
+    void* blk = nullptr;       // Format A blocks / Format R blocks / Format M node blocks
+    void* aux = nullptr;       // Format R superBlocks / Format M node offsets (wide: + node_super + super rows)
+    void* sup = nullptr;       // wide Format A: super-block counts
+    size_t blk_bytes = 0, aux_bytes = 0, sup_bytes = 0;
+    ViewA va{}; ViewR vr{}; ViewM vm{};
     // explicit LF mapping: lf_table[i] = C[s[i]] + rank(i, s[i])  (n entries; the symbol is recovered from C).
-    // 4 bytes per row buy one-load single-row DFS nodes and one-load locate steps; skipped with FMGPU_LF_TABLE=0.
+    // One word per row buys one-load single-row DFS nodes and one-load locate steps; fmgpu_index_accelerate_lf drops / adds it
+    // (FMGPU_LF_TABLE=0: not built at creation).
     idx_t* lf_table = nullptr;
     // multi-symbol-step table (fmgpu_index_accelerate): block B, context w at  kblk + (B * kcodes + w) * 16 :
     //   { u32 cnt = LF_k(64B, w); u32 bits_lo; u32 bits_hi; u32 0 }   (bit r: the kstep symbols preceding suffix 64B+r spell w;
@@ -387,26 +582,30 @@ struct DevString {
     uint2* walkj = nullptr; uint32_t walk_J = 0, walk_bits = 0;
     //   walk2j[3*row ..] = {LF^(2J)(row), code of symbols 0 .. J-1, code of symbols J .. 2J-1} (walk = 2 in fmgpu_index_accelerate_exact), or {~0, 0, 0}
     uint32_t* walk2j = nullptr;
-    // Format A shadow of a Format R / W string (fmgpu_index_accelerate, kstep >= 1): the searches then read `va` (one line per
-    // LF step instead of bitct lines); fmgpu_string_query keeps answering from the native format.
+    // Format A shadow of a Format R / M string (fmgpu_index_accelerate, kstep >= 1): the searches then read `va` (one line per
+    // LF step instead of one per level); fmgpu_string_query keeps answering from the native format.
     void* shadow = nullptr; size_t shadow_bytes = 0;
+    void* shadow_sup = nullptr;
     int search_family() const { return shadow ? (int)FAM_A : family; }
 };
 
 // builds s.shadow / s.va from the string's own symbols; defined in fmgpu_build.hip
 int build_format_a_shadow(DevString& s, const idx_t* dC, hipStream_t stream);
+// Format M from a device array of symbols (string/Wavelet.h:61-71 restated as bulk passes); defined in fmgpu_build.hip
+int make_format_m(const uint8_t* symbols, uint64_t n, uint32_t sigma, const idx_t* dC, DevString& s, int layout, hipStream_t stream);
 
+struct Index;
 // 0 if the calling thread's current device is the one the handle lives on; defined in fmgpu_index.hip
-int on_handle_device(const struct Index* x);
+int on_handle_device(const Index* x);
 
 // fills s.lf_table from the device string (all layouts); defined in fmgpu_index.hip
 int build_lf_table(DevString& s, hipStream_t stream);
 void free_string(DevString& s);
 
 struct Index {
+    IndexHeader hdr;
     DevString bwt, rev;
     bool bidirectional = false, has_sa = false;
-    int device = 0;
     idx_t* dC = nullptr;
     uint64_t hC[258] = {0};
     // sampled SA
@@ -417,31 +616,35 @@ struct Index {
     size_t device_bytes = 0;
     // prefix table (fmgpu_index_accelerate_search): lut[code(w)] = { lb, lbRev, len, symbols consumed before the interval emptied (or L) }
     uint4* lut = nullptr; uint32_t lut_len = 0; uint64_t lut_entries = 0;
+    Index() { hdr.wide = kWide ? 1 : 0; }
 };
 
-void set_error(const std::string& msg);
-int fail(int code, const std::string& msg);
-int hip_fail(hipError_t e, const char* what);
+template <class F>
+static int dispatch_native(const DevString& s, F&& f) {      // the string's own format (fmgpu_string_query, table builders)
+    switch (s.family) {
+    case FAM_A:
+        if (s.sigma == 5) return f(OccA<5>{s.va}, std::integral_constant<int, 5>{});
+        if (s.sigma <= 32) return f(OccA<0>{s.va}, std::integral_constant<int, 32>{});
+        return f(OccA<0>{s.va}, std::integral_constant<int, 256>{});
+    case FAM_EPR:
+        if (s.sigma <= 32) return f(OccR<false>{s.vr}, std::integral_constant<int, 32>{});
+        return f(OccR<false>{s.vr}, std::integral_constant<int, 256>{});
+    case FAM_EPRV2:
+        if (s.sigma <= 32) return f(OccR<true>{s.vr}, std::integral_constant<int, 32>{});
+        return f(OccR<true>{s.vr}, std::integral_constant<int, 256>{});
+    default:
+        if (s.sigma <= 32) return f(OccM{s.vm}, std::integral_constant<int, 32>{});
+        return f(OccM{s.vm}, std::integral_constant<int, 256>{});
+    }
+}
+template <class F>
+static int dispatch_occ(const DevString& s, F&& f) {         // what the searches read (the Format A shadow if there is one)
+    if (s.shadow) {
+        if (s.sigma == 5) return f(OccA<5>{s.va}, std::integral_constant<int, 5>{});
+        if (s.sigma <= 32) return f(OccA<0>{s.va}, std::integral_constant<int, 32>{});
+        return f(OccA<0>{s.va}, std::integral_constant<int, 256>{});
+    }
+    return dispatch_native(s, std::forward<F>(f));
+}
 
-#define FM_HIP(call)                                                   \
-    do {                                                               \
-        hipError_t e_ = (call);                                        \
-        if (e_ != hipSuccess) return ::fmgpu::hip_fail(e_, #call);     \
-    } while (0)
-
-bool is_device_pointer(const void* p);
-
-// A temporary device mirror of a caller buffer: device pointers are used in place, host pointers are staged.
-struct Staged {
-    void* dev = nullptr;
-    void* host = nullptr;
-    size_t bytes = 0;
-    bool owned = false, writeback = false;
-    hipStream_t stream = nullptr;
-    int in(const void* p, size_t nbytes, hipStream_t s);      // read-only input
-    int out(void* p, size_t nbytes, hipStream_t s);           // output (copied back by finish())
-    int finish();                                             // D2H of outputs (synchronises when anything was staged)
-    ~Staged();
-};
-
-}  // namespace fmgpu
+}  // namespace FMGPU_NS

@@ -1,4 +1,4 @@
-// fmgpu_index.hip — error handling, staging helpers, index upload / re-layout, String_c batch queries.
+// fmgpu_index.hip — index upload / re-layout, optional accelerator tables, String_c batch queries, cursor steps.  Compiled once per row width.
 #include "fmgpu_common.h"
 
 #include <algorithm>
@@ -6,55 +6,9 @@
 #include <memory>
 #include <new>
 
-namespace fmgpu {
+#include <hipcub/hipcub.hpp>
 
-static thread_local std::string g_last_error;
-
-void set_error(const std::string& msg) { g_last_error = msg; }
-int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
-int hip_fail(hipError_t e, const char* what) {
-    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
-    (void)hipGetLastError();
-    return FMGPU_ERR_HIP;
-}
-
-bool is_device_pointer(const void* p) {
-    if (!p) return false;
-    hipPointerAttribute_t a;
-    std::memset(&a, 0, sizeof a);
-    hipError_t e = hipPointerGetAttributes(&a, p);
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
-}
-
-int Staged::in(const void* p, size_t nbytes, hipStream_t s) {
-    stream = s; bytes = nbytes;
-    if (nbytes == 0) { dev = nullptr; return 0; }
-    if (is_device_pointer(p)) { dev = const_cast<void*>(p); return 0; }
-    FM_HIP(hipMalloc(&dev, nbytes));
-    owned = true;
-    FM_HIP(hipMemcpyAsync(dev, p, nbytes, hipMemcpyHostToDevice, s));
-    return 0;
-}
-int Staged::out(void* p, size_t nbytes, hipStream_t s) {
-    stream = s; bytes = nbytes;
-    if (nbytes == 0) { dev = nullptr; return 0; }
-    if (is_device_pointer(p)) { dev = p; return 0; }
-    FM_HIP(hipMalloc(&dev, nbytes));
-    owned = true; writeback = true; host = p;
-    return 0;
-}
-int Staged::finish() {
-    if (writeback && bytes) {
-        FM_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
-        FM_HIP(hipStreamSynchronize(stream));
-        writeback = false;
-    }
-    return 0;
-}
-Staged::~Staged() {
-    if (owned && dev) { (void)hipStreamSynchronize(stream); (void)hipFree(dev); }
-}
+namespace FMGPU_NS {
 
 // ------------------------------------------------------------------ layout parameters (mirror of the reference's struct layouts)
 struct RefLayout {
@@ -97,7 +51,7 @@ static int ref_layout(int layout, int sigma, RefLayout& L) {
 // thread = (device block B, symbol c).  Reference row p lives at bit (p+1)&63 of block (p+1)>>6
 // (string/InterleavedBitvector.h:64-94); prefix layout stores s[j] <= c (InterleavedBitvectorPrefix.h:86-100).
 __global__ __launch_bounds__(256) void k_convert_ib(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ super,
-                                                    const idx_t* __restrict__ C, uint8_t* __restrict__ out,
+                                                    const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t* __restrict__ out_super,
                                                     uint64_t nblocks, uint32_t sigma, uint32_t bt, uint32_t bits_off,
                                                     uint32_t stride, uint64_t period, uint32_t bstride, int prefix) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,23 +67,55 @@ __global__ __launch_bounds__(256) void k_convert_ib(const uint8_t* __restrict__ 
     auto word_of = [&](uint64_t b, uint32_t s) -> uint64_t {
         return *reinterpret_cast<const uint64_t*>(raw + b * stride + bits_off + 8ull * s);
     };
-    uint64_t sb = (64ull * B) / period;
-    uint64_t w = word_of(B, c), cnt = count_of(B, c) + super[sb * sigma + c];
-    uint64_t wn = B + 1 < nblocks ? word_of(B + 1, c) : 0;
-    if (prefix && c > 0) {   // cumulative planes -> exclusive planes
-        uint64_t wl = word_of(B, c - 1);
-        uint64_t wln = B + 1 < nblocks ? word_of(B + 1, c - 1) : 0;
-        uint64_t bmask = bt == 2 ? 0xffffull : (bt == 1 ? 0xffull : 0xffffffffull);
-        cnt = ((count_of(B, c) - count_of(B, c - 1)) & bmask) + super[sb * sigma + c] - super[sb * sigma + c - 1];
-        w &= ~wl; wn &= ~wln;
-    }
-    uint64_t bits = (w >> 1) | ((wn & 1ull) << 63);
-    uint32_t total = (uint32_t)(cnt + (w & 1ull)) + C[c];
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + B * bstride + 12ull * c);
-    o[0] = total; o[1] = (uint32_t)bits; o[2] = (uint32_t)(bits >> 32);
+    auto eval = [&](uint64_t b, uint64_t* bits_out) -> uint64_t {       // C[c] + occurrences of c in rows [0, 64 b)
+        uint64_t sb = (64ull * b) / period;
+        uint64_t w = word_of(b, c), cnt = count_of(b, c) + super[sb * sigma + c];
+        uint64_t wn = b + 1 < nblocks ? word_of(b + 1, c) : 0;
+        if (prefix && c > 0) {   // cumulative planes -> exclusive planes
+            uint64_t wl = word_of(b, c - 1);
+            uint64_t wln = b + 1 < nblocks ? word_of(b + 1, c - 1) : 0;
+            uint64_t bmask = bt == 2 ? 0xffffull : (bt == 1 ? 0xffull : 0xffffffffull);
+            cnt = ((count_of(b, c) - count_of(b, c - 1)) & bmask) + super[sb * sigma + c] - super[sb * sigma + c - 1];
+            w &= ~wl; wn &= ~wln;
+        }
+        if (bits_out) *bits_out = (w >> 1) | ((wn & 1ull) << 63);
+        return cnt + (w & 1ull) + C[c];
+    };
+    uint64_t bits = 0;
+    const uint64_t total = eval(B, &bits);
+    const uint64_t base = kWide ? eval(super_first_block(B), nullptr) : 0;
+    put_entry_a(out, out_super, B, c, sigma, bstride, total, base, bits);
 }
 
-static int upload(const void* host, size_t bytes, void** dev);
+static int upload(const void* host, size_t bytes, void** dev) {
+    *dev = nullptr;
+    if (bytes == 0) bytes = 8;
+    FM_HIP(hipMalloc(dev, bytes));
+    if (host) {
+        hipError_t e = hipMemcpy(*dev, host, bytes, hipMemcpyDefault);
+        if (e != hipSuccess) { (void)hipFree(*dev); *dev = nullptr; return hip_fail(e, "hipMemcpy(upload)"); }
+    }
+    return 0;
+}
+
+// allocates the Format A block table (+ the wide super table) of a string of n rows
+static int alloc_format_a(DevString& s, uint64_t n, uint32_t sigma, const idx_t* dC) {
+    const uint64_t nblocks = n / 64 + 1;
+    const uint32_t bstride = sigma <= 5 ? 64u : 12u * sigma;
+    DBuf blk, sup;
+    int rc;
+    if ((rc = blk.alloc(nblocks * bstride + 64))) return rc;
+    FM_HIP(hipMemset(blk.p, 0, blk.bytes));
+    if (kWide) {
+        if ((rc = sup.alloc(((n >> kSuperShift) + 1) * sigma * 8))) return rc;
+        FM_HIP(hipMemset(sup.p, 0, sup.bytes));
+    }
+    s.blk_bytes = blk.bytes; s.blk = blk.take();
+    s.sup_bytes = kWide ? sup.bytes : 0; s.sup = sup.take();
+    s.family = FAM_A;
+    s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC, (const uint64_t*)s.sup};
+    return 0;
+}
 
 // EPRV3 / EPRV4 / EPRV5 / InterleavedEPRV7 -> Format A.  thread = (block B, symbol c): the symbol-match mask of the bit planes
 // (EPRV3.h:55-68) becomes the entry's bitmap (position p <-> bit p & 63, as in Format A), the counters of every level that
@@ -139,27 +125,31 @@ struct HierView {
     const uint8_t* lev[3]; uint32_t lev_w[3], lev_shift[3], lev_stride[3], lev_off[3]; int nlev;
     const uint64_t* super; uint32_t sshift;
 };
-__global__ __launch_bounds__(256) void k_convert_hier(HierView v, const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t nblocks, uint64_t n,
-                                                      uint32_t sigma, uint32_t bitct, uint32_t bstride) {
+__global__ __launch_bounds__(256) void k_convert_hier(HierView v, const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t* __restrict__ out_super,
+                                                      uint64_t nblocks, uint64_t n, uint32_t sigma, uint32_t bitct, uint32_t bstride) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nblocks * sigma) return;
-    uint64_t B = t / sigma, row = B * 64;
+    const uint64_t B = t / sigma;
     uint32_t c = (uint32_t)(t % sigma);
+    auto eval = [&](uint64_t b) -> uint64_t {
+        const uint64_t row = b * 64;
+        uint64_t cnt = v.super[(row >> v.sshift) * sigma + c];
+        for (int L = 0; L < v.nlev; ++L) {
+            const uint8_t* p = v.lev[L] + (row >> v.lev_shift[L]) * v.lev_stride[L] + v.lev_off[L] + (uint64_t)c * v.lev_w[L];
+            if (v.lev_w[L] == 1) cnt += *p;
+            else if (v.lev_w[L] == 2) { uint16_t x; memcpy(&x, p, 2); cnt += x; }
+            else { uint32_t x; memcpy(&x, p, 4); cnt += x; }
+        }
+        return cnt + C[c];
+    };
+    const uint64_t row = B * 64;
     uint64_t m = ~0ull;
     for (uint32_t i = 0; i < bitct; ++i) {
         uint64_t w; memcpy(&w, v.bits + B * v.bits_stride + 8ull * i, 8);            // V7's packed structs are not 8-byte aligned
         m &= w ^ (0ull - (uint64_t)((~c >> i) & 1u));
     }
     if (n - row < 64) m &= (1ull << (n - row)) - 1ull;                                 // rows past the end read as symbol 0 in the planes
-    uint64_t cnt = v.super[(row >> v.sshift) * sigma + c];
-    for (int L = 0; L < v.nlev; ++L) {
-        const uint8_t* p = v.lev[L] + (row >> v.lev_shift[L]) * v.lev_stride[L] + v.lev_off[L] + (uint64_t)c * v.lev_w[L];
-        if (v.lev_w[L] == 1) cnt += *p;
-        else if (v.lev_w[L] == 2) { uint16_t x; memcpy(&x, p, 2); cnt += x; }
-        else { uint32_t x; memcpy(&x, p, 4); cnt += x; }
-    }
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + B * bstride + 12ull * c);
-    o[0] = (uint32_t)cnt + C[c]; o[1] = (uint32_t)m; o[2] = (uint32_t)(m >> 32);
+    put_entry_a(out, out_super, B, c, sigma, bstride, eval(B), kWide ? eval(super_first_block(B)) : 0, m);
 }
 
 static int create_hier(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
@@ -193,44 +183,50 @@ static int create_hier(const fmgpu_string_desc& d, const idx_t* dC, DevString& s
         rc = upload(d.levels[L], need, &held[2 + L]); if (rc) { drop(); return rc; }
         v.lev[L] = (const uint8_t*)held[2 + L];
     }
-    const uint32_t bstride = sigma <= 5 ? 64u : 12u * sigma;
-    s.blk_bytes = nblocks * bstride + 64;
-    hipError_t e = hipMalloc(&s.blk, s.blk_bytes);
-    if (e != hipSuccess) { drop(); return hip_fail(e, "hipMalloc(format A)"); }
-    (void)hipMemset(s.blk, 0, s.blk_bytes);
-    const uint64_t threads = nblocks * sigma;
-    k_convert_hier<<<dim3((unsigned)((threads + 255) / 256)), dim3(256)>>>(v, dC, (uint8_t*)s.blk, nblocks, d.n, sigma, bitct, bstride);
-    e = hipDeviceSynchronize();
+    if ((rc = alloc_format_a(s, d.n, sigma, dC))) { drop(); return rc; }
+    dim3 grid;
+    if ((rc = grid_of(nblocks * sigma, &grid))) { drop(); return rc; }
+    k_convert_hier<<<grid, dim3(256)>>>(v, dC, (uint8_t*)s.blk, (uint64_t*)s.sup, nblocks, d.n, sigma, bitct, s.va.bstride);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     drop();
     if (e != hipSuccess) return hip_fail(e, "k_convert_hier");
-    s.family = FAM_A; s.bitct = (int)bitct;
-    s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC};
+    s.bitct = (int)bitct;
     return 0;
 }
 
 // FlattenedBitvectors2L<sigma, l1_bits, 65536> -> Format A (FlattenedBitvectors2L.h:209-224): thread = (64-row block B, symbol c)
 __global__ __launch_bounds__(256) void k_convert_fbv(const uint8_t* __restrict__ bits, const uint64_t* __restrict__ l0, const uint16_t* __restrict__ l1,
-                                                     const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t nblocks, uint64_t n,
+                                                     const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t* __restrict__ out_super, uint64_t nblocks, uint64_t n,
                                                      uint32_t sigma, uint32_t bitct, uint32_t l1_bits, uint32_t bstride) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nblocks * sigma) return;
-    const uint64_t B = t / sigma, row = B * 64, blk = row / l1_bits, sb = row >> 16;
-    const uint32_t c = (uint32_t)(t % sigma), w = (uint32_t)((row % l1_bits) / 64), sig1 = sigma + 1;
-    const uint8_t* base = bits + blk * ((uint64_t)bitct * l1_bits / 8);
-    auto have = [&](uint32_t word) -> uint64_t {
-        uint64_t m = ~0ull;
-        for (uint32_t i = 0; i < bitct; ++i) {
-            uint64_t v = *reinterpret_cast<const uint64_t*>(base + (uint64_t)i * (l1_bits / 8) + 8ull * word);
-            m &= v ^ (0ull - (uint64_t)((~c >> i) & 1u));
+    const uint64_t B = t / sigma;
+    const uint32_t c = (uint32_t)(t % sigma), sig1 = sigma + 1;
+    auto eval = [&](uint64_t b, uint64_t* bits_out) -> uint64_t {
+        const uint64_t row = b * 64, blk = row / l1_bits, sb = row >> 16;
+        const uint32_t w = (uint32_t)((row % l1_bits) / 64);
+        const uint8_t* base = bits + blk * ((uint64_t)bitct * l1_bits / 8);
+        auto have = [&](uint32_t word) -> uint64_t {
+            uint64_t m = ~0ull;
+            for (uint32_t i = 0; i < bitct; ++i) {
+                uint64_t v = *reinterpret_cast<const uint64_t*>(base + (uint64_t)i * (l1_bits / 8) + 8ull * word);
+                m &= v ^ (0ull - (uint64_t)((~c >> i) & 1u));
+            }
+            return m;
+        };
+        uint64_t cnt = l0[sb * sig1 + c + 1] - l0[sb * sig1 + c] + (uint64_t)l1[blk * sig1 + c + 1] - (uint64_t)l1[blk * sig1 + c];
+        for (uint32_t j = 0; j < w; ++j) cnt += (uint64_t)__popcll(have(j));
+        if (bits_out) {
+            uint64_t m = have(w);
+            if (n - row < 64) m &= (1ull << (n - row)) - 1ull;
+            *bits_out = m;
         }
-        return m;
+        return cnt + C[c];
     };
-    uint64_t cnt = l0[sb * sig1 + c + 1] - l0[sb * sig1 + c] + (uint64_t)l1[blk * sig1 + c + 1] - (uint64_t)l1[blk * sig1 + c];
-    for (uint32_t j = 0; j < w; ++j) cnt += (uint64_t)__popcll(have(j));
-    uint64_t m = have(w);
-    if (n - row < 64) m &= (1ull << (n - row)) - 1ull;
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + B * bstride + 12ull * c);
-    o[0] = (uint32_t)cnt + C[c]; o[1] = (uint32_t)m; o[2] = (uint32_t)(m >> 32);
+    uint64_t m = 0;
+    const uint64_t total = eval(B, &m);
+    put_entry_a(out, out_super, B, c, sigma, bstride, total, kWide ? eval(super_first_block(B), nullptr) : 0, m);
 }
 
 static int create_fbv(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
@@ -246,84 +242,64 @@ static int create_fbv(const fmgpu_string_desc& d, const idx_t* dC, DevString& s)
     int rc = upload(d.blocks, nl1 * stride, &db); if (rc) { drop(); return rc; }
     rc = upload(d.super_blocks, nsuper * (sigma + 1) * 8, &d0); if (rc) { drop(); return rc; }
     rc = upload(d.levels[0], nl1 * (sigma + 1) * 2, &d1); if (rc) { drop(); return rc; }
-    const uint32_t bstride = sigma <= 5 ? 64u : 12u * sigma;
-    s.blk_bytes = nblocks * bstride + 64;
-    hipError_t e = hipMalloc(&s.blk, s.blk_bytes);
-    if (e != hipSuccess) { drop(); return hip_fail(e, "hipMalloc(format A)"); }
-    (void)hipMemset(s.blk, 0, s.blk_bytes);
-    const uint64_t threads = nblocks * sigma;
-    k_convert_fbv<<<dim3((unsigned)((threads + 255) / 256)), dim3(256)>>>((const uint8_t*)db, (const uint64_t*)d0, (const uint16_t*)d1, dC, (uint8_t*)s.blk,
-                                                                            nblocks, d.n, sigma, bitct, l1_bits, bstride);
-    e = hipDeviceSynchronize();
+    if ((rc = alloc_format_a(s, d.n, sigma, dC))) { drop(); return rc; }
+    dim3 grid;
+    if ((rc = grid_of(nblocks * sigma, &grid))) { drop(); return rc; }
+    k_convert_fbv<<<grid, dim3(256)>>>((const uint8_t*)db, (const uint64_t*)d0, (const uint16_t*)d1, dC, (uint8_t*)s.blk, (uint64_t*)s.sup,
+                                       nblocks, d.n, sigma, bitct, l1_bits, s.va.bstride);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     drop();
     if (e != hipSuccess) return hip_fail(e, "k_convert_fbv");
-    s.family = FAM_A; s.bitct = (int)bitct;
-    s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC};
-    return 0;
-}
-
-static int upload(const void* host, size_t bytes, void** dev) {
-    *dev = nullptr;
-    if (bytes == 0) bytes = 8;
-    FM_HIP(hipMalloc(dev, bytes));
-    if (host) FM_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyDefault));
+    s.bitct = (int)bitct;
     return 0;
 }
 
 int on_handle_device(const Index* x) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return fail(FMGPU_ERR_NO_DEVICE, "no HIP device visible — the product path has no CPU fallback"); }
-    if (dev != x->device) return fail(FMGPU_ERR_INVALID, "the handle lives on device " + std::to_string(x->device) + ", the calling thread's current device is " + std::to_string(dev));
+    if (dev != x->hdr.device) return fail(FMGPU_ERR_INVALID, "the handle lives on device " + std::to_string(x->hdr.device) + ", the calling thread's current device is " + std::to_string(dev));
     return 0;
 }
 
 void free_string(DevString& s) {
-    if (s.blk) (void)hipFree(s.blk);
-    if (s.aux) (void)hipFree(s.aux);
-    if (s.lf_table) (void)hipFree(s.lf_table);
-    if (s.kblk) (void)hipFree(s.kblk);
-    if (s.walk3) (void)hipFree(s.walk3);
-    if (s.shadow) (void)hipFree(s.shadow);
-    s.shadow = nullptr; s.shadow_bytes = 0;
-    if (s.slut) (void)hipFree(s.slut);
-    if (s.walkj) (void)hipFree(s.walkj);
-    if (s.walk2j) (void)hipFree(s.walk2j);
-    s.walk2j = nullptr;
-    s.slut = nullptr; s.walkj = nullptr; s.slut_len = 0; s.slut_entries = 0; s.walk_J = 0;
-    s.blk = s.aux = nullptr; s.lf_table = nullptr; s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0; s.walk3 = nullptr;
+    for (void* p : {s.blk, s.aux, s.sup, (void*)s.lf_table, (void*)s.kblk, (void*)s.walk3, s.shadow, s.shadow_sup, (void*)s.slut, (void*)s.walkj, (void*)s.walk2j})
+        if (p) (void)hipFree(p);
+    s = DevString{};
 }
 
 template <class Occ>
 __global__ __launch_bounds__(256) void k_lf_table(Occ occ, uint64_t n, idx_t* __restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c;
-    out[i] = occ.lf_symbol((idx_t)i, c);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t c;
+        out[i] = occ.lf_symbol((idx_t)i, c);
+    }
 }
 
 int build_lf_table(DevString& s, hipStream_t stream) {
-    const char* e = getenv("FMGPU_LF_TABLE");
-    if (e && atoi(e) == 0) return 0;
-    if (s.n == 0) return 0;
-    FM_HIP(hipMalloc((void**)&s.lf_table, s.n * sizeof(idx_t) + 16));   // (+16: k_scheme_fast reads 16 bytes at a row)
-    dim3 grid((unsigned)((s.n + 255) / 256)), block(256);
-    switch (s.family) {
-    case FAM_A:
-        if (s.sigma == 5) k_lf_table<OccA<5>><<<grid, block, 0, stream>>>(OccA<5>{s.va}, s.n, s.lf_table);
-        else k_lf_table<OccA<0>><<<grid, block, 0, stream>>>(OccA<0>{s.va}, s.n, s.lf_table);
-        break;
-    case FAM_EPR:   k_lf_table<OccR<false>><<<grid, block, 0, stream>>>(OccR<false>{s.vr}, s.n, s.lf_table); break;
-    case FAM_EPRV2: k_lf_table<OccR<true>><<<grid, block, 0, stream>>>(OccR<true>{s.vr}, s.n, s.lf_table); break;
-    default:        k_lf_table<OccW><<<grid, block, 0, stream>>>(OccW{s.vw}, s.n, s.lf_table); break;
-    }
-    FM_HIP(hipGetLastError());
+    if (s.n == 0 || s.lf_table) return 0;
+    DBuf t; int rc;
+    if ((rc = t.alloc(s.n * sizeof(idx_t) + 16))) return rc;   // (+16: k_scheme_fast reads 16 bytes at a row)
+    dim3 grid;
+    if ((rc = grid_of(s.n, &grid, 1u << 22))) return rc;
+    rc = dispatch_native(s, [&](auto occ, auto) {
+        k_lf_table<decltype(occ)><<<grid, dim3(256), 0, stream>>>(occ, s.n, t.as<idx_t>());
+        return 0;
+    });
+    FM_LAUNCHED("k_lf_table");
     FM_HIP(hipStreamSynchronize(stream));
+    s.lf_table = (idx_t*)t.take();
     return 0;
+}
+
+template <class Occ>
+__global__ __launch_bounds__(256) void k_symbols_w(OccW occ, uint64_t n, uint8_t* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint8_t)occ.symbol((idx_t)i);
 }
 
 static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
     if (d.sigma < 2 || d.sigma > 256) return fail(FMGPU_ERR_INVALID, "sigma must be in [2, 256]");
-    if (d.n >= 0xffffffffull - 64) return fail(FMGPU_ERR_UNSUPPORTED, "this build indexes fewer than 2^32 - 64 rows per string");
+    if (!kWide && d.n >= kNarrowLimit) return fail(FMGPU_ERR_UNSUPPORTED, "the 32-bit-row build indexes fewer than 2^32 - 64 rows per string");
     if (d.layout >= FMGPU_EPRV3_8 && d.layout <= FMGPU_IEPRV7) {
         s.layout = d.layout; s.sigma = d.sigma; s.n = d.n;
         return create_hier(d, dC, s);
@@ -345,20 +321,16 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
         void *raw = nullptr, *sup = nullptr;
         int rc = upload(d.blocks, d.blocks_bytes, &raw); if (rc) return rc;
         rc = upload(d.super_blocks, nsuper * sigma * 8, &sup); if (rc) { (void)hipFree(raw); return rc; }
-        uint32_t bstride = sigma <= 5 ? 64u : 12u * sigma;
-        s.blk_bytes = nblocks * bstride + 64;
-        hipError_t e = hipMalloc(&s.blk, s.blk_bytes);
-        if (e != hipSuccess) { (void)hipFree(raw); (void)hipFree(sup); return hip_fail(e, "hipMalloc(format A)"); }
-        (void)hipMemset(s.blk, 0, s.blk_bytes);
-        uint64_t threads = nblocks * sigma;
-        k_convert_ib<<<dim3((unsigned)((threads + 255) / 256)), dim3(256)>>>(
-            (const uint8_t*)raw, (const uint64_t*)sup, dC, (uint8_t*)s.blk, nblocks, sigma, L.bt, L.bits_off, L.stride,
-            L.period, bstride, L.family == 1 ? 1 : 0);
-        e = hipDeviceSynchronize();
-        (void)hipFree(raw); (void)hipFree(sup);
+        auto drop = [&] { (void)hipFree(raw); (void)hipFree(sup); };
+        if ((rc = alloc_format_a(s, d.n, sigma, dC))) { drop(); return rc; }
+        dim3 grid;
+        if ((rc = grid_of(nblocks * sigma, &grid))) { drop(); return rc; }
+        k_convert_ib<<<grid, dim3(256)>>>((const uint8_t*)raw, (const uint64_t*)sup, dC, (uint8_t*)s.blk, (uint64_t*)s.sup, nblocks, sigma, L.bt, L.bits_off, L.stride,
+                                          L.period, s.va.bstride, L.family == 1 ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        drop();
         if (e != hipSuccess) return hip_fail(e, "k_convert_ib");
-        s.family = FAM_A;
-        s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC};
         return 0;
     }
     if (L.family == 2 || L.family == 3) {   // EPR / EPRV2: reference layout verbatim
@@ -381,7 +353,8 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
         s.vr = v;
         return 0;
     }
-    // wavelet -> Format W
+    // Wavelet: the node bitvectors (bitvector/Bitvector.h:31-34) are laid out as Format W lines on the host, the symbols are read back from them on
+    // the device (string/Wavelet.h:77-102) and the multi-ary tree (Format M) is built from those; the lines are dropped again
     uint64_t nnodes = 1; while (nnodes < sigma) nnodes <<= 1;
     if (!d.nodes || d.n_nodes != nnodes) return fail(FMGPU_ERR_INVALID, "wavelet needs bit_ceil(sigma) node descriptors");
     std::vector<uint32_t> base(nnodes, 0);
@@ -392,6 +365,7 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
         if (d.nodes[k].n_bits < d.nodes[k].total_length / 64 + 1) return fail(FMGPU_ERR_INVALID, "wavelet node bits array too short");
         if (total_lines >= 0xffffffffull) return fail(FMGPU_ERR_UNSUPPORTED, "wavelet too large for 32-bit line offsets");
     }
+    if (d.nodes[0].total_length != d.n) return fail(FMGPU_ERR_INVALID, "wavelet root node length differs from n");
     std::unique_ptr<uint64_t[]> lines(new (std::nothrow) uint64_t[total_lines * 8]());
     if (!lines) return fail(FMGPU_ERR_NOMEM, "host staging for wavelet lines");
     for (uint64_t k = 0; k < nnodes; ++k) {
@@ -412,51 +386,60 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
             ones += cum;
         }
     }
-    int rc = upload(lines.get(), total_lines * 64, &s.blk); if (rc) return rc;
-    rc = upload(base.data(), nnodes * 4, &s.aux); if (rc) return rc;
-    s.blk_bytes = total_lines * 64; s.aux_bytes = nnodes * 4;
-    s.family = FAM_WAVELET;
-    s.vw = ViewW{(const uint64_t*)s.blk, (const uint32_t*)s.aux, dC, sigma, L.bitct};
-    return 0;
+    DBuf dl, db, sym;
+    int rc;
+    if ((rc = dl.alloc(total_lines * 64)) || (rc = db.alloc(nnodes * 4)) || (rc = sym.alloc(d.n + 64))) return rc;
+    FM_HIP(hipMemcpy(dl.p, lines.get(), total_lines * 64, hipMemcpyHostToDevice));
+    FM_HIP(hipMemcpy(db.p, base.data(), nnodes * 4, hipMemcpyHostToDevice));
+    lines.reset();
+    if (d.n) {
+        dim3 grid;
+        if ((rc = grid_of(d.n, &grid, 1u << 22))) return rc;
+        k_symbols_w<OccW><<<grid, dim3(256)>>>(OccW{ViewW{dl.as<uint64_t>(), db.as<uint32_t>(), dC, sigma, L.bitct}}, d.n, sym.as<uint8_t>());
+        FM_LAUNCHED("k_symbols_w");
+        FM_HIP(hipDeviceSynchronize());
+    }
+    dl.release(); db.release();
+    return make_format_m(sym.as<uint8_t>(), d.n, sigma, dC, s, d.layout, nullptr);
 }
 
+#if !FMGPU_WIDE
 // ------------------------------------------------------------------ multi-symbol-step table
 // context code of row j: walk K LF steps from j collecting the BWT symbols s_1 (immediately before the suffix), s_2, ...;
 // w = s_K ... s_1 in text order, code = sum (s_t - 1) * R^(t-1) with R = sigma - 1; 255 if a delimiter is met.
 template <class Occ>
-__global__ __launch_bounds__(256) void k_kstep_codes(Occ occ, const idx_t* __restrict__ lf_table, uint64_t n, uint32_t K, uint32_t R, uint8_t* __restrict__ code) {
-    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    idx_t row = (idx_t)j;
-    uint32_t c = 0, mul = 1; bool ok = true;
-    for (uint32_t t = 0; t < K; ++t) {
-        uint32_t s;
-        row = occ.lf_symbol(row, s);
-        if (s == 0) { ok = false; break; }
-        c += (s - 1) * mul; mul *= R;
+__global__ __launch_bounds__(256) void k_kstep_codes(Occ occ, uint64_t n, uint32_t K, uint32_t R, uint8_t* __restrict__ code) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        idx_t row = (idx_t)j;
+        uint32_t c = 0, mul = 1; bool ok = true;
+        for (uint32_t t = 0; t < K; ++t) {
+            uint32_t s;
+            row = occ.lf_symbol(row, s);
+            if (s == 0) { ok = false; break; }
+            c += (s - 1) * mul; mul *= R;
+        }
+        code[j] = ok ? (uint8_t)c : (uint8_t)255;
     }
-    (void)lf_table;
-    code[j] = ok ? (uint8_t)c : (uint8_t)255;
 }
 // one wave per 64-row block: plane bits by ballot; per-block counts into cnt[w * nblocks + B]
 __global__ __launch_bounds__(256) void k_kstep_bits(const uint8_t* __restrict__ code, uint64_t n, uint64_t nblocks, uint32_t ncodes,
                                                     uint8_t* __restrict__ kblk, uint32_t* __restrict__ cnt) {
-    uint64_t B = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t lane = threadIdx.x & 63u;
-    if (B >= nblocks) return;
-    uint64_t row = B * 64 + lane;
-    uint32_t s = row < n ? code[row] : 0xffffffffu;
-    for (uint32_t c0 = 0; c0 < ncodes; c0 += 64) {
-        uint64_t mine = 0;
-        for (uint32_t c = c0; c < ncodes && c < c0 + 64; ++c) {
-            uint64_t bits = __ballot(s == c);
-            if (lane == c - c0) mine = bits;
-        }
-        uint32_t c = c0 + lane;
-        if (c < ncodes) {
-            uint32_t* o = reinterpret_cast<uint32_t*>(kblk + (B * ncodes + c) * 16ull);
-            o[1] = (uint32_t)mine; o[2] = (uint32_t)(mine >> 32); o[3] = 0;
-            cnt[(uint64_t)c * nblocks + B] = (uint32_t)__popcll(mine);
+    for (uint64_t B = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; B < nblocks; B += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
+        uint64_t row = B * 64 + lane;
+        uint32_t s = row < n ? code[row] : 0xffffffffu;
+        for (uint32_t c0 = 0; c0 < ncodes; c0 += 64) {
+            uint64_t mine = 0;
+            for (uint32_t c = c0; c < ncodes && c < c0 + 64; ++c) {
+                uint64_t bits = __ballot(s == c);
+                if (lane == c - c0) mine = bits;
+            }
+            uint32_t c = c0 + lane;
+            if (c < ncodes) {
+                uint32_t* o = reinterpret_cast<uint32_t*>(kblk + (B * ncodes + c) * 16ull);
+                o[1] = (uint32_t)mine; o[2] = (uint32_t)(mine >> 32); o[3] = 0;
+                cnt[(uint64_t)c * nblocks + B] = (uint32_t)__popcll(mine);
+            }
         }
     }
 }
@@ -471,18 +454,19 @@ __global__ void k_kstep_base(Occ occ, uint32_t K, uint32_t R, uint32_t ncodes, i
 }
 __global__ __launch_bounds__(256) void k_kstep_counts(const uint32_t* __restrict__ cnt, const idx_t* __restrict__ base, uint64_t nblocks, uint32_t ncodes,
                                                       uint8_t* __restrict__ kblk) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblocks * ncodes) return;
-    uint64_t B = t % nblocks; uint32_t c = (uint32_t)(t / nblocks);
-    *reinterpret_cast<uint32_t*>(kblk + (B * ncodes + c) * 16ull) = cnt[t] + base[c];
+    const uint64_t total = nblocks * ncodes;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t B = t % nblocks; uint32_t c = (uint32_t)(t / nblocks);
+        *reinterpret_cast<uint32_t*>(kblk + (B * ncodes + c) * 16ull) = cnt[t] + base[c];
+    }
 }
 
 // ------------------------------------------------------------------ search accelerators (prefix table, walk table)
 __global__ __launch_bounds__(256) void k_walk3(const idx_t* __restrict__ lf, uint64_t n, idx_t* __restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    idx_t a = lf[i], b = lf[a], c = lf[b];
-    out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        idx_t a = lf[i], b = lf[a], c = lf[b];
+        out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
+    }
 }
 // suffix table for exact search: the interval of the L symbols c_0 (consumed first = the query's last symbol), c_1, ...
 template <class Occ>
@@ -505,28 +489,28 @@ __global__ __launch_bounds__(256) void k_walkj(const idx_t* __restrict__ lf, con
     __shared__ idx_t sC[257];
     for (uint32_t i = threadIdx.x; i <= sigma; i += blockDim.x) sC[i] = C[i];
     __syncthreads();
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    idx_t r = (idx_t)i;
-    uint32_t code = 0; bool ok = true;
-    for (uint32_t t = 0; t < J; ++t) {
-        idx_t nr = lf[r];
-        uint32_t lo = 0, hi = sigma;                   // symbol of the step: C[s] <= LF < C[s+1]
-        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sC[mid] <= nr) lo = mid; else hi = mid; }
-        if (lo == 0) { ok = false; break; }
-        code |= (lo - 1u) << (bits * t);
-        r = nr;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        idx_t r = (idx_t)i;
+        uint32_t code = 0; bool ok = true;
+        for (uint32_t t = 0; t < J; ++t) {
+            idx_t nr = lf[r];
+            uint32_t lo = 0, hi = sigma;                   // symbol of the step: C[s] <= LF < C[s+1]
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sC[mid] <= nr) lo = mid; else hi = mid; }
+            if (lo == 0) { ok = false; break; }
+            code |= (lo - 1u) << (bits * t);
+            r = nr;
+        }
+        out[i] = ok ? make_uint2(r, code) : make_uint2(0xffffffffu, 0u);
     }
-    out[i] = ok ? make_uint2(r, code) : make_uint2(0xffffffffu, 0u);
 }
 // 2J steps = two J-step entries chained
 __global__ __launch_bounds__(256) void k_walk2j(const uint2* __restrict__ wj, uint64_t n, uint32_t* __restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint2 a = wj[i];
-    uint32_t r = 0xffffffffu, c0 = 0, c1 = 0;
-    if (a.x != 0xffffffffu) { const uint2 b = wj[a.x]; if (b.x != 0xffffffffu) { r = b.x; c0 = a.y; c1 = b.y; } }
-    out[3 * i] = r; out[3 * i + 1] = c0; out[3 * i + 2] = c1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 a = wj[i];
+        uint32_t r = 0xffffffffu, c0 = 0, c1 = 0;
+        if (a.x != 0xffffffffu) { const uint2 b = wj[a.x]; if (b.x != 0xffffffffu) { r = b.x; c0 = a.y; c1 = b.y; } }
+        out[3 * i] = r; out[3 * i + 1] = c0; out[3 * i + 2] = c1;
+    }
 }
 // bidirectional interval of every string w of L symbols in [1, sigma): extendRight symbol by symbol (fmindex/BiFMIndexCursor.h:121-128)
 template <class Occ>
@@ -551,12 +535,9 @@ __global__ __launch_bounds__(256) void k_prefix_lut(Occ rv, uint64_t entries, ui
     }
 }
 
-}  // namespace fmgpu
+constexpr uint64_t kTableGridCap = 1u << 22;      // blocks of the grid-stride table builders
 
-#include <hipcub/hipcub.hpp>
-
-namespace fmgpu {
-
+// the table is built into local allocations and installed in the handle only after every launch and the final synchronisation have succeeded
 template <class Occ>
 static int accelerate_with(DevString& s, Occ occ, uint32_t K) {
     const uint32_t R = (uint32_t)s.sigma - 1;
@@ -564,76 +545,108 @@ static int accelerate_with(DevString& s, Occ occ, uint32_t K) {
     for (uint32_t t = 0; t < K; ++t) { nc *= R; if (nc > 255) return fail(FMGPU_ERR_UNSUPPORTED, "(sigma-1)^kstep must be <= 255"); }
     const uint32_t ncodes = (uint32_t)nc;
     const uint64_t n = s.n, nblocks = n / 64 + 1;
-    uint8_t* code = nullptr; uint32_t* cnt = nullptr; idx_t* base = nullptr; uint8_t* kblk = nullptr; void* tmp = nullptr;
-    auto cleanup = [&]() { for (void* p : {(void*)code, (void*)cnt, (void*)base, tmp}) if (p) (void)hipFree(p); };
-    hipError_t e;
-    if ((e = hipMalloc((void**)&code, n + 64)) != hipSuccess || (e = hipMalloc((void**)&cnt, (size_t)ncodes * nblocks * 4)) != hipSuccess ||
-        (e = hipMalloc((void**)&base, ncodes * sizeof(idx_t))) != hipSuccess || (e = hipMalloc((void**)&kblk, (size_t)nblocks * ncodes * 16 + 128)) != hipSuccess) {
-        cleanup(); if (kblk) (void)hipFree(kblk); return hip_fail(e, "hipMalloc(k-step table)");
-    }
-    k_kstep_codes<Occ><<<dim3((unsigned)((n + 255) / 256)), 256>>>(occ, s.lf_table, n, K, R, code);
-    k_kstep_bits<<<dim3((unsigned)((nblocks * 64 + 255) / 256)), 256>>>(code, n, nblocks, ncodes, kblk, cnt);
-    k_kstep_base<Occ><<<dim3((ncodes + 63) / 64), 64>>>(occ, K, R, ncodes, base);
+    DBuf code, cnt, base, kblk, tmp;
+    int rc;
+    if ((rc = code.alloc(n + 64)) || (rc = cnt.alloc((size_t)ncodes * nblocks * 4)) || (rc = base.alloc(ncodes * sizeof(idx_t))) ||
+        (rc = kblk.alloc((size_t)nblocks * ncodes * 16 + 128))) return rc;
+    dim3 g_rows, g_waves, g_all;
+    if ((rc = grid_of(n, &g_rows, kTableGridCap)) || (rc = grid_of(nblocks * 64, &g_waves, kTableGridCap)) || (rc = grid_of(nblocks * ncodes, &g_all, kTableGridCap))) return rc;
+    k_kstep_codes<Occ><<<g_rows, 256>>>(occ, n, K, R, code.as<uint8_t>());
+    FM_LAUNCHED("k_kstep_codes");
+    k_kstep_bits<<<g_waves, 256>>>(code.as<uint8_t>(), n, nblocks, ncodes, kblk.as<uint8_t>(), cnt.as<uint32_t>());
+    FM_LAUNCHED("k_kstep_bits");
+    k_kstep_base<Occ><<<dim3((ncodes + 63) / 64), 64>>>(occ, K, R, ncodes, base.as<idx_t>());
+    FM_LAUNCHED("k_kstep_base");
     size_t tb = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt, cnt, (size_t)nblocks);
-    if ((e = hipMalloc(&tmp, tb ? tb : 8)) != hipSuccess) { cleanup(); (void)hipFree(kblk); return hip_fail(e, "hipMalloc(scan)"); }
+    FM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, cnt.as<uint32_t>(), cnt.as<uint32_t>(), (size_t)nblocks));
+    if ((rc = tmp.alloc(tb ? tb : 8))) return rc;
     for (uint32_t c = 0; c < ncodes; ++c) {
-        uint32_t* p = cnt + (uint64_t)c * nblocks;
+        uint32_t* p = cnt.as<uint32_t>() + (uint64_t)c * nblocks;
         size_t b2 = tb;
-        if ((e = hipcub::DeviceScan::ExclusiveSum(tmp, b2, p, p, (size_t)nblocks)) != hipSuccess) { cleanup(); (void)hipFree(kblk); return hip_fail(e, "ExclusiveSum"); }
+        FM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, b2, p, p, (size_t)nblocks));
     }
-    k_kstep_counts<<<dim3((unsigned)((nblocks * ncodes + 255) / 256)), 256>>>(cnt, base, nblocks, ncodes, kblk);
-    e = hipDeviceSynchronize();
-    cleanup();
-    if (e != hipSuccess) { (void)hipFree(kblk); return hip_fail(e, "k-step table kernels"); }
+    k_kstep_counts<<<g_all, 256>>>(cnt.as<uint32_t>(), base.as<idx_t>(), nblocks, ncodes, kblk.as<uint8_t>());
+    FM_LAUNCHED("k_kstep_counts");
+    FM_HIP(hipDeviceSynchronize());
     if (s.kblk) (void)hipFree(s.kblk);
-    s.kblk = kblk; s.kstep = K; s.kcodes = ncodes; s.kblk_bytes = (size_t)nblocks * ncodes * 16 + 128;
+    s.kblk_bytes = kblk.bytes; s.kblk = (uint8_t*)kblk.take(); s.kstep = K; s.kcodes = ncodes;
     return 0;
 }
+#endif  // !FMGPU_WIDE
 
 // ------------------------------------------------------------------ String_c batch kernel
 template <class Occ>
 __global__ __launch_bounds__(256) void k_string_query(Occ occ, const uint64_t* __restrict__ idx, const uint8_t* __restrict__ symb,
-                                                      const uint8_t* __restrict__ what, uint64_t count, uint64_t* __restrict__ out) {
+                                                      const uint8_t* __restrict__ what, uint64_t count, uint64_t n, uint64_t* __restrict__ out) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
-    idx_t i = (idx_t)idx[t];
     uint32_t c = symb ? symb[t] : 0;
     uint32_t w = what ? what[t] : 0;
-    uint64_t r;
-    if (w == 0) r = occ.rank(i, c);
-    else if (w == 1) r = occ.prefix_rank(i, c);
-    else r = occ.symbol(i);
+    const uint64_t i64 = idx[t];
+    uint64_t r = ~0ull;                                   // (a position the reference would read out of bounds)
+    if (i64 <= n && (w != 2 || i64 < n) && (w == 2 || c < occ.sigma() || (w == 1 && c == occ.sigma()))) {
+        const idx_t i = (idx_t)i64;
+        if (w == 0) r = occ.rank(i, c);
+        else if (w == 1) r = c == occ.sigma() ? (uint64_t)i : (uint64_t)occ.prefix_rank(i, c);
+        else r = occ.symbol(i);
+    }
     out[t] = r;
 }
 
-}  // namespace fmgpu
-
-using namespace fmgpu;
-
-extern "C" {
-
-int fmgpu_abi_version(void) { return FMGPU_ABI_VERSION; }
-const char* fmgpu_last_error(void) { return g_last_error.c_str(); }
-
-int fmgpu_device_count(int* count) {
-    if (!count) return fail(FMGPU_ERR_INVALID, "count is null");
-    int c = 0;
-    hipError_t e = hipGetDeviceCount(&c);
-    if (e != hipSuccess) { (void)hipGetLastError(); *count = 0; return fail(FMGPU_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
-    *count = c;
-    return 0;
+// ------------------------------------------------------------------ cursor steps (fmindex/BiFMIndexCursor.h:58-128, fmindex/FMIndexCursor.h:33-53)
+// one thread per cursor: extendLeft(c) / extendRight(c) (symb != null) or extendLeft() / extendRight() over all symbols (sigma outputs per cursor)
+template <class Occ, int MAXSIG>
+__global__ __launch_bounds__(256) void k_cursor_extend(Occ fw, Occ rv, bool bidir, int right, uint64_t count, const uint64_t* __restrict__ lb, const uint64_t* __restrict__ lb_rev,
+                                                       const uint64_t* __restrict__ len, const uint8_t* __restrict__ symb, uint64_t n,
+                                                       uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_lb_rev, uint64_t* __restrict__ out_len) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t sigma = fw.sigma();
+    const uint64_t a0 = lb[t], r0 = lb_rev ? lb_rev[t] : 0, l0 = len[t];
+    const bool valid = a0 <= n && l0 <= n - a0 && r0 <= n && l0 <= n - r0;
+    const Occ& occ = right ? rv : fw;
+    const idx_t a = (idx_t)(right ? r0 : a0), b = (idx_t)(a + l0);
+    if (symb) {
+        const uint32_t c = symb[t];
+        uint64_t nlb = 0, nrev = 0, nlen = 0;
+        if (valid && c < sigma) {
+            idx_t ra, rb, pre = 0;
+            occ.lf2(a, b, c, ra, rb);
+            if (bidir) pre = occ.prefix_rank(b, c) - occ.prefix_rank(a, c);
+            nlen = rb - ra;
+            if (right) { nrev = ra; nlb = a0 + pre; } else { nlb = ra; nrev = bidir ? r0 + pre : 0; }
+        }
+        out_lb[t] = nlb; if (out_lb_rev) out_lb_rev[t] = nrev; out_len[t] = nlen;
+        return;
+    }
+    idx_t pre = 0;
+    for (uint32_t c = 0; c < sigma; ++c) {
+        uint64_t nlb = 0, nrev = 0, nlen = 0;
+        if (valid) {
+            idx_t ra, rb;
+            occ.lf2(a, b, c, ra, rb);
+            nlen = rb - ra;
+            if (right) { nrev = ra; nlb = a0 + pre; } else { nlb = ra; nrev = bidir ? r0 + pre : 0; }
+            pre += rb - ra;
+        }
+        out_lb[t * sigma + c] = nlb; if (out_lb_rev) out_lb_rev[t * sigma + c] = nrev; out_len[t * sigma + c] = nlen;
+    }
 }
-int fmgpu_set_device(int device) { FM_HIP(hipSetDevice(device)); return 0; }
+
+namespace api {
+#include "fmgpu_api_decl.h"
 
 int fmgpu_index_destroy(fmgpu_index_t h) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return 0;
     free_string(x->bwt); free_string(x->rev);
     for (void* p : {(void*)x->dC, x->sa_l0, x->sa_l1, x->sa_bits, x->sa_f0, x->sa_f1, (void*)x->lut, (void*)x->loc_tab}) if (p) (void)hipFree(p);
+    x->hdr.magic = 0;
     delete x;
     return 0;
 }
+
+static bool lf_table_wanted() { const char* e = getenv("FMGPU_LF_TABLE"); return !(e && atoi(e) == 0); }
 
 int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
     if (!desc || !out) return fail(FMGPU_ERR_INVALID, "desc / out is null");
@@ -645,22 +658,24 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
         return fail(FMGPU_ERR_INVALID, "bwt don't have the same size: " + std::to_string(desc->bwt.n) + " " + std::to_string(desc->bwt_rev->n));   // fmindex/BiFMIndex.h:48-50
     std::unique_ptr<Index> x(new (std::nothrow) Index());
     if (!x) return fail(FMGPU_ERR_NOMEM, "host allocation");
-    (void)hipGetDevice(&x->device);
+    (void)hipGetDevice(&x->hdr.device);
     const int sigma = desc->bwt.sigma;
     if (sigma < 2 || sigma > 256) return fail(FMGPU_ERR_INVALID, "sigma must be in [2, 256]");
-    std::vector<idx_t> c32(sigma + 1);
+    std::vector<idx_t> cdev(sigma + 1);
     for (int i = 0; i <= sigma; ++i) {
         if (desc->C[i] > desc->bwt.n) return fail(FMGPU_ERR_INVALID, "C[] entry exceeds n");
-        x->hC[i] = desc->C[i]; c32[i] = (idx_t)desc->C[i];
+        x->hC[i] = desc->C[i]; cdev[i] = (idx_t)desc->C[i];
     }
-    int rc = upload(c32.data(), (sigma + 1) * sizeof(idx_t), (void**)&x->dC);
-    auto bail = [&](int code) { fmgpu_index_destroy(reinterpret_cast<fmgpu_index_t>(x.release())); return code; };
+    int rc = upload(cdev.data(), (sigma + 1) * sizeof(idx_t), (void**)&x->dC);
+    auto bail = [&](int code) { api::fmgpu_index_destroy(reinterpret_cast<fmgpu_index_t>(x.release())); return code; };
     if (rc) return bail(rc);
     rc = create_string(desc->bwt, x->dC, x->bwt); if (rc) return bail(rc);
     if (desc->bwt_rev) { rc = create_string(*desc->bwt_rev, x->dC, x->rev); if (rc) return bail(rc); x->bidirectional = true; }
-    rc = build_lf_table(x->bwt, nullptr); if (rc) return bail(rc);
-    if (x->bidirectional) { rc = build_lf_table(x->rev, nullptr); if (rc) return bail(rc); }
-    x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->rev.blk_bytes + x->rev.aux_bytes +
+    if (lf_table_wanted()) {
+        rc = build_lf_table(x->bwt, nullptr); if (rc) return bail(rc);
+        if (x->bidirectional) { rc = build_lf_table(x->rev, nullptr); if (rc) return bail(rc); }
+    }
+    x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->bwt.sup_bytes + x->rev.blk_bytes + x->rev.aux_bytes + x->rev.sup_bytes +
                       (x->bwt.lf_table ? x->bwt.n * sizeof(idx_t) : 0) + (x->rev.lf_table ? x->rev.n * sizeof(idx_t) : 0);
     if (const fmgpu_sparse_array_desc* sa = desc->annotated_array) {
         if (sa->n != desc->bwt.n) return bail(fail(FMGPU_ERR_INVALID, "annotated_array.n != bwt.n"));
@@ -695,6 +710,56 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
     return 0;
 }
 
+int fmgpu_index_accelerate_lf(fmgpu_index_t h, int32_t enable) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
+    for (DevString* s : {&x->bwt, &x->rev}) {
+        if (s->n == 0) continue;
+        if (!enable) {
+            if (s->walk3 || s->walkj || s->walk2j) return fail(FMGPU_ERR_INVALID, "the walk tables are built on the LF table: drop them first (fmgpu_index_accelerate_exact / _search with walk = 0)");
+            if (s->lf_table) { (void)hipFree(s->lf_table); s->lf_table = nullptr; x->device_bytes -= s->n * sizeof(idx_t); }
+        } else if (!s->lf_table) {
+            int rc = build_lf_table(*s, nullptr); if (rc) return rc;
+            x->device_bytes += s->n * sizeof(idx_t);
+        }
+    }
+    return 0;
+}
+
+#if FMGPU_WIDE
+static int no_wide(const char* what) { return fail(FMGPU_ERR_UNSUPPORTED, std::string(what) + " is not available for indices of 2^32 rows or more (64-bit-row build): searches run on the plain occurrence tables"); }
+int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (kstep < 0 || kstep > 8) return fail(FMGPU_ERR_INVALID, "kstep must be in [0, 8]");
+    if (kstep <= 1) {                                      // Format A expansion of EPR / Wavelet strings (kstep = 1), or dropping it (0): available
+        if (int drc = on_handle_device(x)) return drc;
+        if (kstep == 0) {
+            for (DevString* t : {&x->bwt, &x->rev}) if (t->shadow) { (void)hipFree(t->shadow); if (t->shadow_sup) (void)hipFree(t->shadow_sup); x->device_bytes -= t->shadow_bytes; t->shadow = t->shadow_sup = nullptr; t->shadow_bytes = 0; t->va = ViewA{}; }
+            return 0;
+        }
+        for (DevString* t : {&x->bwt, &x->rev}) {
+            if (t->n == 0 || t->family == FAM_A || t->shadow) continue;
+            int rc = build_format_a_shadow(*t, x->dC, nullptr); if (rc) return rc;
+            x->device_bytes += t->shadow_bytes;
+        }
+        return 0;
+    }
+    return no_wide("the multi-symbol-step table");
+}
+int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk) {
+    if (lut_len < 0 || lut_len > 32) return fail(FMGPU_ERR_INVALID, "lut_len must be in [0, 32]");
+    if (kstep > 1 || lut_len > 0 || walk) return no_wide("the exact-search tables");
+    return api::fmgpu_index_accelerate(h, kstep);
+}
+int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t walk) {
+    if (!h) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (prefix_len < 0 || prefix_len > 32) return fail(FMGPU_ERR_INVALID, "prefix_len must be in [0, 32]");
+    if (prefix_len > 0 || walk) return no_wide("the prefix / walk tables");
+    return 0;
+}
+#else
 int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
@@ -715,12 +780,7 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
         x->device_bytes += t->shadow_bytes;
     }
     if (kstep <= 1) return 0;
-    switch (s.search_family()) {
-    case FAM_A:     rc = s.sigma == 5 ? accelerate_with(s, OccA<5>{s.va}, (uint32_t)kstep) : accelerate_with(s, OccA<0>{s.va}, (uint32_t)kstep); break;
-    case FAM_EPR:   rc = accelerate_with(s, OccR<false>{s.vr}, (uint32_t)kstep); break;
-    case FAM_EPRV2: rc = accelerate_with(s, OccR<true>{s.vr}, (uint32_t)kstep); break;
-    default:        rc = accelerate_with(s, OccW{s.vw}, (uint32_t)kstep); break;
-    }
+    rc = dispatch_occ(s, [&](auto occ, auto) { return accelerate_with(s, occ, (uint32_t)kstep); });
     if (rc == 0) x->device_bytes += s.kblk_bytes;
     return rc;
 }
@@ -730,46 +790,53 @@ int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
     if (int drc = on_handle_device(x)) return drc;
     if (lut_len < 0 || lut_len > 32) return fail(FMGPU_ERR_INVALID, "lut_len must be in [0, 32]");
-    int rc = fmgpu_index_accelerate(h, kstep);
+    int rc = api::fmgpu_index_accelerate(h, kstep);
     if (rc) return rc;
     DevString& s = x->bwt;
     const uint64_t n = s.n;
     if (s.slut) { (void)hipFree(s.slut); x->device_bytes -= s.slut_entries * 8; s.slut = nullptr; s.slut_len = 0; s.slut_entries = 0; }
-    if (s.walkj) { (void)hipFree(s.walkj); x->device_bytes -= n * 8; s.walkj = nullptr; s.walk_J = 0; }
     if (s.walk2j) { (void)hipFree(s.walk2j); x->device_bytes -= n * 12; s.walk2j = nullptr; }
+    if (s.walkj && !walk) { (void)hipFree(s.walkj); x->device_bytes -= n * 8; s.walkj = nullptr; s.walk_J = 0; }
     if (n == 0) return 0;
     const uint32_t sigma = (uint32_t)s.sigma, R = sigma - 1;
     if (lut_len > 0) {
         uint64_t entries = 1;
         for (int t = 0; t < lut_len; ++t) { entries *= R; if (entries > (1ull << 32)) return fail(FMGPU_ERR_UNSUPPORTED, "suffix table would exceed 2^32 entries"); }
-        FM_HIP(hipMalloc((void**)&s.slut, entries * 8));
-        dim3 grid((unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22)), block(256);
-        switch (s.search_family()) {
-        case FAM_A:
-            if (s.sigma == 5) k_suffix_lut<OccA<5>><<<grid, block>>>(OccA<5>{s.va}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut);
-            else k_suffix_lut<OccA<0>><<<grid, block>>>(OccA<0>{s.va}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut);
-            break;
-        case FAM_EPR:   k_suffix_lut<OccR<false>><<<grid, block>>>(OccR<false>{s.vr}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut); break;
-        case FAM_EPRV2: k_suffix_lut<OccR<true>><<<grid, block>>>(OccR<true>{s.vr}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut); break;
-        default:        k_suffix_lut<OccW><<<grid, block>>>(OccW{s.vw}, entries, (uint32_t)lut_len, R, (idx_t)n, s.slut); break;
-        }
+        DBuf lut;
+        if ((rc = lut.alloc(entries * 8))) return rc;
+        dim3 grid;
+        if ((rc = grid_of(entries, &grid, kTableGridCap))) return rc;
+        rc = dispatch_occ(s, [&](auto occ, auto) {
+            k_suffix_lut<decltype(occ)><<<grid, dim3(256)>>>(occ, entries, (uint32_t)lut_len, R, (idx_t)n, lut.as<uint2>());
+            return 0;
+        });
+        FM_LAUNCHED("k_suffix_lut");
         FM_HIP(hipDeviceSynchronize());
-        s.slut_len = (uint32_t)lut_len; s.slut_entries = entries;
+        s.slut = (uint2*)lut.take(); s.slut_len = (uint32_t)lut_len; s.slut_entries = entries;
         x->device_bytes += entries * 8;
     }
     if (walk) {
-        if (!s.lf_table) return fail(FMGPU_ERR_INVALID, "the walk table needs the LF table (FMGPU_LF_TABLE=0 was set)");
+        if (!s.lf_table) { if ((rc = build_lf_table(s, nullptr))) return rc; x->device_bytes += n * sizeof(idx_t); }
         uint32_t bits = 1; while ((1u << bits) < R) ++bits;               // symbols 1 .. sigma-1 stored as 0 .. sigma-2
         const uint32_t J = 32u / bits;
-        FM_HIP(hipMalloc((void**)&s.walkj, n * 8 + 16));
-        k_walkj<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s.lf_table, x->dC, sigma, n, J, bits, s.walkj);
-        FM_HIP(hipDeviceSynchronize());
-        s.walk_J = J; s.walk_bits = bits;
-        x->device_bytes += n * 8;
-        if (walk >= 2) {
-            FM_HIP(hipMalloc((void**)&s.walk2j, n * 12 + 16));
-            k_walk2j<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s.walkj, n, s.walk2j);
+        dim3 grid;
+        if ((rc = grid_of(n, &grid, kTableGridCap))) return rc;
+        if (!s.walkj) {
+            DBuf wj;
+            if ((rc = wj.alloc(n * 8 + 16))) return rc;
+            k_walkj<<<grid, 256>>>(s.lf_table, x->dC, sigma, n, J, bits, wj.as<uint2>());
+            FM_LAUNCHED("k_walkj");
             FM_HIP(hipDeviceSynchronize());
+            s.walkj = (uint2*)wj.take(); s.walk_J = J; s.walk_bits = bits;
+            x->device_bytes += n * 8;
+        }
+        if (walk >= 2) {
+            DBuf w2;
+            if ((rc = w2.alloc(n * 12 + 16))) return rc;
+            k_walk2j<<<grid, 256>>>(s.walkj, n, w2.as<uint32_t>());
+            FM_LAUNCHED("k_walk2j");
+            FM_HIP(hipDeviceSynchronize());
+            s.walk2j = (uint32_t*)w2.take();
             x->device_bytes += n * 12;
         }
     }
@@ -788,47 +855,54 @@ int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t w
     for (DevString* s : {&x->bwt, &x->rev}) if (s->walk3) { (void)hipFree(s->walk3); s->walk3 = nullptr; x->device_bytes -= n * 12; }
     if (x->rev.walkj) { (void)hipFree(x->rev.walkj); x->rev.walkj = nullptr; x->rev.walk_J = 0; x->device_bytes -= n * 8; }
     if (n == 0) return 0;
+    int rc;
     if (walk) {
         const uint32_t sigma = (uint32_t)x->bwt.sigma;
         uint32_t bits = 1; while ((1u << bits) < sigma - 1) ++bits;
+        dim3 grid;
+        if ((rc = grid_of(n, &grid, kTableGridCap))) return rc;
         for (DevString* s : {&x->bwt, &x->rev}) {
-            if (!s->lf_table) return fail(FMGPU_ERR_INVALID, "walk tables need the LF tables (FMGPU_LF_TABLE=0 was set)");
+            if (!s->lf_table) { if ((rc = build_lf_table(*s, nullptr))) return rc; x->device_bytes += n * sizeof(idx_t); }
             if (walk & 1) {
-                FM_HIP(hipMalloc((void**)&s->walk3, n * 12 + 16));
-                k_walk3<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s->lf_table, n, s->walk3);
+                DBuf w3;
+                if ((rc = w3.alloc(n * 12 + 16))) return rc;
+                k_walk3<<<grid, 256>>>(s->lf_table, n, w3.as<idx_t>());
+                FM_LAUNCHED("k_walk3");
+                FM_HIP(hipDeviceSynchronize());
+                s->walk3 = (idx_t*)w3.take();
                 x->device_bytes += n * 12;
             }
             if ((walk & 2) && !s->walkj) {                          // (the forward one may exist already: fmgpu_index_accelerate_exact)
-                FM_HIP(hipMalloc((void**)&s->walkj, n * 8 + 16));
-                k_walkj<<<dim3((unsigned)((n + 255) / 256)), 256>>>(s->lf_table, x->dC, sigma, n, 32u / bits, bits, s->walkj);
-                s->walk_J = 32u / bits; s->walk_bits = bits;
+                DBuf wj;
+                if ((rc = wj.alloc(n * 8 + 16))) return rc;
+                k_walkj<<<grid, 256>>>(s->lf_table, x->dC, sigma, n, 32u / bits, bits, wj.as<uint2>());
+                FM_LAUNCHED("k_walkj");
+                FM_HIP(hipDeviceSynchronize());
+                s->walkj = (uint2*)wj.take(); s->walk_J = 32u / bits; s->walk_bits = bits;
                 x->device_bytes += n * 8;
             }
         }
-        FM_HIP(hipDeviceSynchronize());
     }
     if (prefix_len > 0) {
         const uint32_t R = (uint32_t)x->bwt.sigma - 1;
         uint64_t entries = 1;
         for (int t = 0; t < prefix_len; ++t) { entries *= R; if (entries > (1ull << 32)) return fail(FMGPU_ERR_UNSUPPORTED, "prefix table would exceed 2^32 entries"); }
-        FM_HIP(hipMalloc((void**)&x->lut, entries * 16));
-        dim3 grid((unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22)), block(256);
-        const DevString& r = x->rev;
-        switch (r.family) {
-        case FAM_A:
-            if (r.sigma == 5) k_prefix_lut<OccA<5>><<<grid, block>>>(OccA<5>{r.va}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut);
-            else k_prefix_lut<OccA<0>><<<grid, block>>>(OccA<0>{r.va}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut);
-            break;
-        case FAM_EPR:   k_prefix_lut<OccR<false>><<<grid, block>>>(OccR<false>{r.vr}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut); break;
-        case FAM_EPRV2: k_prefix_lut<OccR<true>><<<grid, block>>>(OccR<true>{r.vr}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut); break;
-        default:        k_prefix_lut<OccW><<<grid, block>>>(OccW{r.vw}, entries, (uint32_t)prefix_len, R, (idx_t)n, x->lut); break;
-        }
+        DBuf lut;
+        if ((rc = lut.alloc(entries * 16))) return rc;
+        dim3 grid;
+        if ((rc = grid_of(entries, &grid, kTableGridCap))) return rc;
+        rc = dispatch_native(x->rev, [&](auto occ, auto) {
+            k_prefix_lut<decltype(occ)><<<grid, dim3(256)>>>(occ, entries, (uint32_t)prefix_len, R, (idx_t)n, lut.as<uint4>());
+            return 0;
+        });
+        FM_LAUNCHED("k_prefix_lut");
         FM_HIP(hipDeviceSynchronize());
-        x->lut_len = (uint32_t)prefix_len; x->lut_entries = entries;
+        x->lut = (uint4*)lut.take(); x->lut_len = (uint32_t)prefix_len; x->lut_entries = entries;
         x->device_bytes += entries * 16;
     }
     return 0;
 }
+#endif  // FMGPU_WIDE
 
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes) {
     Index* x = reinterpret_cast<Index*>(h);
@@ -857,25 +931,48 @@ int fmgpu_string_query(fmgpu_index_t h, int which, const uint64_t* idx, const ui
     if ((rc = ssym.in(symb, symb ? count : 0, stream))) return rc;
     if ((rc = swhat.in(what, what ? count : 0, stream))) return rc;
     if ((rc = sout.out(out, count * 8, stream))) return rc;
-    dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    FM_GRID(grid, count);
     auto a = (const uint64_t*)sidx.dev; auto b = (const uint8_t*)ssym.dev; auto c = (const uint8_t*)swhat.dev; auto o = (uint64_t*)sout.dev;
-    switch (s.family) {
-    case FAM_A:
-        if (s.sigma == 5) k_string_query<OccA<5>><<<grid, block, 0, stream>>>(OccA<5>{s.va}, a, b, c, count, o);
-        else k_string_query<OccA<0>><<<grid, block, 0, stream>>>(OccA<0>{s.va}, a, b, c, count, o);
-        break;
-    case FAM_EPR:     k_string_query<OccR<false>><<<grid, block, 0, stream>>>(OccR<false>{s.vr}, a, b, c, count, o); break;
-    case FAM_EPRV2:   k_string_query<OccR<true>><<<grid, block, 0, stream>>>(OccR<true>{s.vr}, a, b, c, count, o); break;
-    default:          k_string_query<OccW><<<grid, block, 0, stream>>>(OccW{s.vw}, a, b, c, count, o); break;
-    }
-    FM_HIP(hipGetLastError());
+    rc = dispatch_native(s, [&](auto occ, auto) {
+        k_string_query<decltype(occ)><<<grid, dim3(256), 0, stream>>>(occ, a, b, c, count, s.n, o);
+        return 0;
+    });
+    FM_LAUNCHED("k_string_query");
     return sout.finish();
 }
 
-int fmgpu_malloc(void** ptr, uint64_t bytes) { if (!ptr) return fail(FMGPU_ERR_INVALID, "ptr is null"); FM_HIP(hipMalloc(ptr, bytes ? bytes : 8)); return 0; }
-int fmgpu_free(void* ptr) { if (ptr) FM_HIP(hipFree(ptr)); return 0; }
-int fmgpu_memcpy_h2d(void* dst, const void* src, uint64_t bytes) { if (bytes) FM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
-int fmgpu_memcpy_d2h(void* dst, const void* src, uint64_t bytes) { if (bytes) FM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
-int fmgpu_synchronize(void* stream) { FM_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int fmgpu_cursor_extend(fmgpu_index_t h, int32_t direction, uint64_t count, const uint64_t* lb, const uint64_t* lb_rev, const uint64_t* len, const uint8_t* symb,
+                        uint64_t* out_lb, uint64_t* out_lb_rev, uint64_t* out_len, void* stream_) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
+    if (direction != 0 && direction != 1) return fail(FMGPU_ERR_INVALID, "direction must be 0 (extendLeft) or 1 (extendRight)");
+    if (direction == 1 && !x->bidirectional) return fail(FMGPU_ERR_INVALID, "extendRight needs a BiFMIndex");
+    if (count == 0) return 0;
+    if (!lb || !len || !out_lb || !out_len || (x->bidirectional && (!lb_rev || !out_lb_rev))) return fail(FMGPU_ERR_INVALID, "cursor arrays are null");
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint64_t fan = symb ? 1 : (uint64_t)x->bwt.sigma;
+    Staged slb, srev, slen, ssym, olb, orev, olen;
+    int rc;
+    if ((rc = slb.in(lb, count * 8, stream)) || (rc = srev.in(lb_rev, lb_rev ? count * 8 : 0, stream)) || (rc = slen.in(len, count * 8, stream)) ||
+        (rc = ssym.in(symb, symb ? count : 0, stream)) || (rc = olb.out(out_lb, count * fan * 8, stream)) ||
+        (rc = orev.out(out_lb_rev, out_lb_rev ? count * fan * 8 : 0, stream)) || (rc = olen.out(out_len, count * fan * 8, stream))) return rc;
+    FM_GRID(grid, count);
+    const DevString& fw = x->bwt; const DevString& rv = x->bidirectional ? x->rev : x->bwt;
+    rc = dispatch_native(fw, [&](auto occ, auto ms) {
+        using O = decltype(occ);
+        O r = occ;
+        if constexpr (std::is_same_v<O, OccA<5>> || std::is_same_v<O, OccA<0>>) r = O{rv.va};
+        else if constexpr (std::is_same_v<O, OccM>) r = O{rv.vm};
+        else r = O{rv.vr};
+        k_cursor_extend<O, decltype(ms)::value><<<grid, dim3(256), 0, stream>>>(occ, r, x->bidirectional, direction, count, (const uint64_t*)slb.dev, (const uint64_t*)srev.dev,
+                                                                               (const uint64_t*)slen.dev, (const uint8_t*)ssym.dev, fw.n, (uint64_t*)olb.dev, (uint64_t*)orev.dev, (uint64_t*)olen.dev);
+        return 0;
+    });
+    FM_LAUNCHED("k_cursor_extend");
+    if ((rc = olb.finish()) || (rc = orev.finish()) || (rc = olen.finish())) return rc;
+    return 0;
+}
 
-}  // extern "C"
+}  // namespace api
+}  // namespace FMGPU_NS

@@ -24,12 +24,12 @@
 
 #include <hipcub/hipcub.hpp>
 
-namespace fmgpu {
+namespace FMGPU_NS {
 
 // the cursor of query q: two 64-bit arrays as the reference's cursor fields, or (out_len == nullptr) one word lb << 32 | len — the transport
-// form of fmgpu_search_exact_packed (rows are < 2^32)
+// form of fmgpu_search_exact_packed (32-bit rows only)
 __device__ __forceinline__ void store_interval(uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len, uint64_t q, idx_t lb, idx_t len) {
-    if (out_len) { out_lb[q] = lb; out_len[q] = len; }
+    if (kWide || out_len) { out_lb[q] = lb; out_len[q] = len; }
     else out_lb[q] = ((uint64_t)lb << 32) | (uint64_t)len;
 }
 
@@ -38,10 +38,23 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
 
-// step counters of the one-thread-per-query kernels: striped over kCounterStripes words (a single word would serialise one
-// atomic per wave — 156 k of them for 10 M queries — behind each other)
-constexpr uint32_t kCounterStripes = 64;
+// counters of the one-thread-per-query kernels: [0] executed steps, [1] table bytes consumed, [2] table accesses (fmgpu_stats), each striped
+// over kCounterStripes words (a single word would serialise one atomic per wave — 156 k of them for 10 M queries — behind each other)
+__device__ __forceinline__ void add_counters(unsigned long long* __restrict__ ctr, uint32_t steps, uint32_t bytes, uint32_t accesses) {
+    const uint32_t ts = wave_sum(steps), tb = wave_sum(bytes), ta = wave_sum(accesses);
+    if ((threadIdx.x & 63u) == 0 && ts) {
+        const uint32_t stripe = blockIdx.x & (kCounterStripes - 1u);
+        atomicAdd(&ctr[stripe], (unsigned long long)ts);
+        atomicAdd(&ctr[kCounterStripes + stripe], (unsigned long long)tb);
+        atomicAdd(&ctr[2u * kCounterStripes + stripe], (unsigned long long)ta);
+    }
+}
 
 // ------------------------------------------------------------------ exact search
 template <class Occ>
@@ -67,8 +80,32 @@ __global__ __launch_bounds__(256) void k_exact(Occ occ, const uint8_t* __restric
         }
         store_interval(out_lb, out_len, q, lb, len);
     }
-    uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
+    add_counters(steps_total, steps, 0u, 0u);
+}
+
+// symbols a query consumes until its interval is a single row (or empty): out[q] = that count, or its length + 1 if the interval still
+// holds several rows at the end — the quantity that decides how much of a read the one-row walk tables can serve (bench.py reports its distribution)
+template <class Occ>
+__global__ __launch_bounds__(256) void k_exact_depth(Occ occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
+                                                     uint32_t* __restrict__ out) {
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    uint64_t o = qoff[q];
+    uint32_t m = (uint32_t)(qoff[q + 1] - o);
+    const uint8_t* s = qbuf + o;
+    const uint32_t sigma = occ.sigma();
+    idx_t lb = 0, len = n;
+    uint32_t depth = m + 1, done = 0;
+    for (uint32_t i = m; i-- > 0 && len > 1;) {
+        uint32_t c = s[i];
+        ++done;
+        if (c >= sigma) { len = 0; break; }
+        idx_t ra, rb;
+        occ.lf2(lb, lb + len, c, ra, rb);
+        lb = ra; len = rb - ra;
+    }
+    if (len <= 1) depth = done;
+    out[q] = depth;
 }
 
 // ---- exact search on Format A without accelerator tables --------------------------------------------------------
@@ -104,7 +141,7 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                  unsigned long long* __restrict__ steps_total) {
     uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0;
+    uint32_t steps = 0, acc = 0;
     if (q < nq) {
         uint64_t o = qoff[q];
         uint32_t m = (uint32_t)(qoff[q + 1] - o);
@@ -117,19 +154,19 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
                 ++steps;
                 if (c >= sigma) { lb = 0; len = 0; break; }
                 const idx_t a = lb, b = lb + len;
-                EntryA ea = load_entry_a(occ.v.blk, occ.v.bstride, a, c);
+                EntryA ea = load_entry_a(occ.v, a, c);
                 EntryA eb = ea;
-                if ((a >> 6) != (b >> 6)) eb = load_entry_a(occ.v.blk, occ.v.bstride, b, c);
-                idx_t ra = ea.cnt + popc64(ea.bits & lowmask(a & 63u));
-                idx_t rb = eb.cnt + popc64(eb.bits & lowmask(b & 63u));
+                ++acc;
+                if ((a >> 6) != (b >> 6)) { eb = load_entry_a(occ.v, b, c); ++acc; }
+                idx_t ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
+                idx_t rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
                 lb = ra; len = rb - ra;
                 if (len == 0) break;
             }
         }
         store_interval(out_lb, out_len, q, lb, len);
     }
-    uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
+    add_counters(steps_total, steps, 12u * acc, acc);
 }
 
 // ------------------------------------------------------------------ DFS machinery
@@ -145,7 +182,7 @@ struct SchemeDev {             // flattened [search][part]; values fit a byte (e
     int dev_flags;                   // dev knobs: 1 = count hits per lane only (no records)
 };
 
-struct Counters { unsigned long long hits, nodes, next; };
+struct Counters { unsigned long long hits, nodes, next, table_bytes, table_accesses; };
 
 
 // lane-interleaved frame stack: frame d of lane g at word (d * nlanes + g) of three u64 planes
@@ -261,7 +298,8 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
 // the whole wave is done): queries are handed out with one reservation for all lanes that want one, hits are kept in LDS
 // (kWaveHitBuf per lane) and written out by the whole wave with one reservation as soon as some lane's buffer is full.
 constexpr uint32_t kWaveHitBuf = 2;
-constexpr uint32_t kWaveHitWords = kWaveHitBuf * 7u * 256u;       // [slot][qidx lo, qidx hi, lb, lbRev, len, e, seq][thread]
+constexpr uint32_t kHitWords = kWide ? 10u : 7u;                  // [qidx lo, qidx hi, lb, lbRev, len, e, seq (, high words of lb, lbRev, len)]
+constexpr uint32_t kWaveHitWords = kWaveHitBuf * kHitWords * 256u;   // [slot][word][thread]
 
 __device__ __forceinline__ uint64_t wave_hand_out(bool want, Counters* ctr, uint32_t lane) {     // all lanes call; valid for lanes with `want`
     const uint64_t wm = __ballot(want);
@@ -274,8 +312,9 @@ __device__ __forceinline__ uint64_t wave_hand_out(bool want, Counters* ctr, uint
 }
 __device__ __forceinline__ void wave_keep_hit(uint32_t* s_hb, uint32_t& nh, fmgpu_hit* out, uint64_t cap, Counters* ctr, uint64_t q, Cur r, uint32_t e, uint32_t seq) {
     if (nh < kWaveHitBuf) {
-        uint32_t* h = s_hb + (size_t)nh * 7u * 256u + threadIdx.x;
-        h[0] = (uint32_t)q; h[256] = (uint32_t)(q >> 32); h[512] = r.lb; h[768] = r.lbRev; h[1024] = r.len; h[1280] = e; h[1536] = seq;
+        uint32_t* h = s_hb + (size_t)nh * kHitWords * 256u + threadIdx.x;
+        h[0] = (uint32_t)q; h[256] = (uint32_t)(q >> 32); h[512] = (uint32_t)r.lb; h[768] = (uint32_t)r.lbRev; h[1024] = (uint32_t)r.len; h[1280] = e; h[1536] = seq;
+        if constexpr (kWide) { h[1792] = (uint32_t)((uint64_t)r.lb >> 32); h[2048] = (uint32_t)((uint64_t)r.lbRev >> 32); h[2304] = (uint32_t)((uint64_t)r.len >> 32); }
         ++nh;
     } else emit_hit(out, cap, ctr, q, r, e, seq);                  // (cannot happen while the wave flushes whenever a buffer is full)
 }
@@ -286,11 +325,12 @@ __device__ __forceinline__ void wave_flush_hits(const uint32_t* s_hb, uint32_t& 
     if (lane == 0 && total) slot = atomicAdd(&ctr->hits, (unsigned long long)total);
     slot = ((unsigned long long)__shfl((uint32_t)(slot >> 32), 0, 64) << 32) | __shfl((uint32_t)slot, 0, 64);
     for (uint32_t k = 0; k < nh; ++k) {
-        const uint32_t* h = s_hb + (size_t)k * 7u * 256u + threadIdx.x;
+        const uint32_t* h = s_hb + (size_t)k * kHitWords * 256u + threadIdx.x;
         const unsigned long long at = slot + before + k;
         if (at < cap) {
             fmgpu_hit rec;
             rec.qidx = (uint64_t)h[0] | ((uint64_t)h[256] << 32); rec.lb = h[512]; rec.lb_rev = h[768]; rec.len = h[1024];
+            if constexpr (kWide) { rec.lb |= (uint64_t)h[1792] << 32; rec.lb_rev |= (uint64_t)h[2048] << 32; rec.len |= (uint64_t)h[2304] << 32; }
             rec.errors = h[1280]; rec.seq = h[1536];
             out[at] = rec;
         }
@@ -356,24 +396,67 @@ __device__ __forceinline__ uint32_t qstage_get(const QStage& st, const uint8_t* 
     return (st.lds[(p >> 2) * 256u + threadIdx.x] >> ((p & 3u) * 8u)) & 255u;
 }
 
-// ---- exact search over Format W (wavelet) -----------------------------------------------------------------------
-// One LF step = bitct dependent node-ranks (string/Wavelet.h:104-119), each one 64-byte line: header + the payload word that
-// holds the position.  Both interval ends walk the same node path; once the interval is short they sit in the same line
-// (and mostly the same word), so the second end re-uses the first end's loads.  The query is staged in LDS, the node
-// offsets and C[] too, so that the only global loads of a step are the line reads on the dependent chain.
-__global__ __launch_bounds__(256) void k_exact_w(ViewW v, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
+// ---- exact search over Format M (multi-ary wavelet tree) -----------------------------------------------------------
+// One LF step = one node rank per level (string/Wavelet.h:104-119 with the levels fused into digits of 3 / 2 bits): per level and interval end one
+// block of 64 positions = one memory line — the count of the digit value before the block and the digit's bit planes.  Both ends walk the same
+// node path; once the interval is short they sit in the same block and the second end re-uses the first end's loads.  The query is staged in
+// LDS, the node offsets and C[] too, so that the only global loads of a step are the block reads on the dependent chain.
+template <int D>
+__device__ __forceinline__ void load_block_m(const uint8_t* blk, uint32_t val, uint32_t& cnt, uint64_t (&pl)[3]) {
+    cnt = reinterpret_cast<const uint32_t*>(blk)[val];
+    if constexpr (D == 3) {
+        const uint4 x = *reinterpret_cast<const uint4*>(blk + 32); const uint2 y = *reinterpret_cast<const uint2*>(blk + 48);
+        pl[0] = (uint64_t)x.x | ((uint64_t)x.y << 32); pl[1] = (uint64_t)x.z | ((uint64_t)x.w << 32); pl[2] = (uint64_t)y.x | ((uint64_t)y.y << 32);
+    } else if constexpr (D == 2) {
+        const uint4 x = *reinterpret_cast<const uint4*>(blk + 16);
+        pl[0] = (uint64_t)x.x | ((uint64_t)x.y << 32); pl[1] = (uint64_t)x.z | ((uint64_t)x.w << 32); pl[2] = 0;
+    } else {
+        const uint2 x = *reinterpret_cast<const uint2*>(blk + 8);
+        pl[0] = (uint64_t)x.x | ((uint64_t)x.y << 32); pl[1] = 0; pl[2] = 0;
+    }
+}
+template <int D>
+__device__ __forceinline__ uint64_t match_m(const uint64_t (&pl)[3], uint32_t val) {
+    uint64_t m = pl[0] ^ (0ull - (uint64_t)(~val & 1u));
+    if constexpr (D >= 2) m &= pl[1] ^ (0ull - (uint64_t)((~val >> 1) & 1u));
+    if constexpr (D >= 3) m &= pl[2] ^ (0ull - (uint64_t)((~val >> 2) & 1u));
+    return m;
+}
+// one level of the descent for both interval ends
+template <int D, int SHIFT, int FIRST>
+__device__ __forceinline__ void level_m(const ViewM& v, const uint64_t* s_off, uint32_t c, idx_t& a, idx_t& b, uint32_t& bytes, uint32_t& acc) {
+    constexpr uint32_t stride = D == 3 ? 64u : (D == 2 ? 32u : 16u);
+    const uint32_t val = (c >> SHIFT) & ((1u << D) - 1u), node = (uint32_t)FIRST + (c >> (SHIFT + D));
+    const uint8_t* nb = v.data + s_off[node];
+    uint32_t ca, cb; uint64_t pa[3], pb[3];
+    load_block_m<D>(nb + (size_t)(a >> 6) * stride, val, ca, pa);
+    bytes += 4u + 8u * D; ++acc;
+    if ((a >> 6) != (b >> 6)) { load_block_m<D>(nb + (size_t)(b >> 6) * stride, val, cb, pb); bytes += 4u + 8u * D; ++acc; }
+    else { cb = ca; pb[0] = pa[0]; pb[1] = pa[1]; pb[2] = pa[2]; }
+    idx_t xa = ca + popc64(match_m<D>(pa, val) & lowmask((uint32_t)a & 63u));
+    idx_t xb = cb + popc64(match_m<D>(pb, val) & lowmask((uint32_t)b & 63u));
+    if constexpr (kWide) {
+        const size_t row = v.node_super[node];
+        xa += (idx_t)v.super[(row + (size_t)(a >> kSuperShift)) * 8u + val];
+        xb += (idx_t)v.super[(row + (size_t)(b >> kSuperShift)) * 8u + val];
+    }
+    a = xa; b = xb;
+}
+template <int D0, int D1, int D2>
+__global__ __launch_bounds__(256) void k_exact_m(ViewM v, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
                                                  uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len, unsigned long long* __restrict__ steps_total,
                                                  uint32_t qwords) {
     extern __shared__ uint32_t s_query[];
-    __shared__ uint32_t s_nb[256];
+    __shared__ uint64_t s_off[kMaxNodesM];
     __shared__ idx_t s_C[257];
-    const uint32_t sigma = v.sigma, bits = v.bitct;
-    for (uint32_t i = threadIdx.x; i < (1u << bits); i += blockDim.x) s_nb[i] = v.node_base[i];
+    const uint32_t sigma = v.sigma;
+    for (uint32_t i = threadIdx.x; i < v.nnodes; i += blockDim.x) s_off[i] = v.node_off[i];
     for (uint32_t i = threadIdx.x; i <= sigma; i += blockDim.x) s_C[i] = v.C[i];
     __syncthreads();
+    constexpr int BITCT = D0 + D1 + D2;
     const QStage qst{s_query, qwords, 0u};
     uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0;
+    uint32_t steps = 0, bytes = 0, acc = 0;
     if (q < nq) {
         uint64_t o = qoff[q];
         uint32_t m = (uint32_t)(qoff[q + 1] - o);
@@ -384,33 +467,15 @@ __global__ __launch_bounds__(256) void k_exact_w(ViewW v, const uint8_t* __restr
             uint32_t c = qstage_get(qst, qs, i);
             ++steps;
             if (c >= sigma) { a = b = 0; break; }
-            for (uint32_t lv = 0; lv < bits; ++lv) {
-                const uint32_t bitId = bits - lv - 1u;
-                const uint32_t bit = (c >> bitId) & 1u;
-                const uint32_t id = ((1u << lv) - 1u) + (c >> (bitId + 1u));
-                const uint64_t* node = v.lines + (size_t)s_nb[id] * 8u;
-                const uint32_t la = a / 384u, ra = a - la * 384u, ka = ra >> 6;
-                const uint32_t lb = b / 384u, rb = b - lb * 384u, kb = rb >> 6;
-                const uint64_t* pa = node + (size_t)la * 8u;
-                const uint64_t* pb = node + (size_t)lb * 8u;
-                uint64_t ha0 = pa[0], ha1 = pa[1], wa = pa[2 + ka];
-                uint64_t hb0 = ha0, hb1 = ha1, wb = wa;
-                if (lb != la) { hb0 = pb[0]; hb1 = pb[1]; }
-                if (lb != la || kb != ka) wb = pb[2 + kb];
-                const uint32_t ca = ka ? (uint32_t)(ha1 >> (9u * (ka - 1u))) & 0x1ffu : 0u;
-                const uint32_t cb = kb ? (uint32_t)(hb1 >> (9u * (kb - 1u))) & 0x1ffu : 0u;
-                const idx_t xa = (idx_t)ha0 + ca + popc64(wa & lowmask(ra & 63u));
-                const idx_t xb = (idx_t)hb0 + cb + popc64(wb & lowmask(rb & 63u));
-                a = bit ? xa : a - xa;
-                b = bit ? xb : b - xb;
-            }
+            level_m<D0, BITCT - D0, 0>(v, s_off, c, a, b, bytes, acc);
+            if constexpr (D1 > 0) level_m<D1, BITCT - D0 - D1, 1>(v, s_off, c, a, b, bytes, acc);
+            if constexpr (D2 > 0) level_m<D2, 0, 1 + (1 << D0)>(v, s_off, c, a, b, bytes, acc);
             a += s_C[c]; b += s_C[c];
             if (a == b) break;
         }
         store_interval(out_lb, out_len, q, a, b - a);
     }
-    uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
+    add_counters(steps_total, steps, bytes, acc);
 }
 
 // ---- search_ng26 Hamming --------------------------------------------------------------------------------------
@@ -432,6 +497,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
     const uint32_t sigma = fw.sigma();
     const uint32_t P = (uint32_t)sch.P, S = (uint32_t)sch.S;
     uint32_t nodes = 0;
+    uint64_t tbytes = 0; uint32_t tacc = 0;                         // table bytes consumed / table accesses issued (fmgpu_stats; blocks, LF entries, frames)
 
     // One flat loop over (query, search, node): a lane that finishes a search starts its next search — or its next
     // query — in the same iteration the other lanes of the wave spend on a node, so the wave never waits for its
@@ -498,8 +564,12 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
         idx_t lfa[MAXSIG], lfb[MAXSIG];
         const bool via_lf = lfv.fw != nullptr && cur.len == 1;      // one row: its only child comes from the LF table
         idx_t lf1 = 0;
-        if (via_lf) lf1 = (right ? lfv.rv : lfv.fw)[a];
-        else occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);       // the memory phase
+        if (via_lf) { lf1 = (right ? lfv.rv : lfv.fw)[a]; tbytes += (uint32_t)sizeof(idx_t); ++tacc; }
+        else {
+            occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);        // the memory phase
+            const bool same = (a >> 6) == ((a + cur.len) >> 6);
+            tbytes += (MAXSIG <= 5 ? 64u : 12u * sigma) * (same ? 1u : 2u); tacc += same ? 1u : 2u;
+        }
         const uint32_t c = qstage_get(qst, qs, right ? qR : qL);
         SymSet<MAXSIG> alive;
         if (via_lf) { alive.clear(); alive.insert(symbol_of_lf_lds(s_C, sigma, lf1)); }
@@ -534,13 +604,20 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
         // before deciding, :267-277, and once more per exact-tail step)
         nodes += in_tail ? 1u : multi ? ((!resuming && (xOK || mOK)) ? 1u : 0u) : (1u + ((take_match && !xOK) ? 1u : 0u));
         if (ok && multi && !in_tail && subs.any()) {               // (re-)push the parent: its remaining siblings start at subs.first()
-            uint64_t w0 = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
-            uint64_t w1 = (uint64_t)cur.len | ((uint64_t)(pev & 0xffffu) << 32) | ((uint64_t)(qR & 0xffffu) << 48);
-            uint64_t w2 = (uint64_t)subs.first() | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
-                          ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
+            uint64_t w0, w1, w2;
+            if constexpr (kWide) {                                 // rows of up to 40 bits: one cursor field per word
+                w0 = (uint64_t)cur.lb | ((uint64_t)(pev & 0xffffu) << 40) | ((uint64_t)(e & 0xffu) << 56);
+                w1 = (uint64_t)cur.lbRev | ((uint64_t)(qR & 0xffffu) << 40) | ((uint64_t)(subs.first() & 0xffu) << 56);
+                w2 = (uint64_t)cur.len | ((uint64_t)((qL + 1u) & 0xffffu) << 40) | ((uint64_t)(part & 0x7fu) << 56) | ((uint64_t)(right ? 1u : 0u) << 63);
+            } else {
+                w0 = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
+                w1 = (uint64_t)cur.len | ((uint64_t)(pev & 0xffffu) << 32) | ((uint64_t)(qR & 0xffffu) << 48);
+                w2 = (uint64_t)subs.first() | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
+                     ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
+            }
             uint64_t o = (uint64_t)sp * stk.nlanes + gid;
             stk.p0[o] = w0; stk.p1[o] = w1; stk.p2[o] = w2;
-            ++sp;
+            ++sp; tbytes += 24u; ++tacc;
         }
         resume = kNoResume;
         bool back = !ok, to_next = false;
@@ -572,18 +649,31 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
             --sp;
             uint64_t o = (uint64_t)sp * stk.nlanes + gid;
             uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o];
-            cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32);
-            cur.len = (idx_t)w1; pev = (uint32_t)(w1 >> 32) & 0xffffu; qR = (uint32_t)(w1 >> 48) & 0xffffu;
-            resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
-            right = (w2 >> 47) & 1u;
-            qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
+            tbytes += 24u; ++tacc;
+            if constexpr (kWide) {
+                const uint64_t m40 = (1ull << 40) - 1ull;
+                cur.lb = (idx_t)(w0 & m40); pev = (uint32_t)(w0 >> 40) & 0xffffu; e = (uint32_t)(w0 >> 56) & 0xffu;
+                cur.lbRev = (idx_t)(w1 & m40); qR = (uint32_t)(w1 >> 40) & 0xffffu; resume = (uint32_t)(w1 >> 56) & 0xffu;
+                cur.len = (idx_t)(w2 & m40); qL = ((uint32_t)(w2 >> 40) & 0xffffu) - 1u; part = (uint32_t)(w2 >> 56) & 0x7fu; right = (w2 >> 63) & 1u;
+            } else {
+                cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32);
+                cur.len = (idx_t)w1; pev = (uint32_t)(w1 >> 32) & 0xffffu; qR = (uint32_t)(w1 >> 48) & 0xffffu;
+                resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
+                right = (w2 >> 47) & 1u;
+                qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
+            }
             tail = 0;
         }
     }
     uint32_t tot = wave_sum(nodes);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
+    const unsigned long long tb = wave_sum64(tbytes); const uint32_t ta = wave_sum(tacc);
+    if ((threadIdx.x & 63u) == 0 && tot) {
+        atomicAdd(&ctr->nodes, (unsigned long long)tot);
+        atomicAdd(&ctr->table_bytes, tb); atomicAdd(&ctr->table_accesses, (unsigned long long)ta);
+    }
 }
 
+#if !FMGPU_WIDE   // ======== 32-bit rows only: edit distance, search_ng21 and every table-driven kernel (frames, tables and transport words hold 32-bit rows)
 // ---- search_ng26, Edit = true (SearchNg26.h:143-224, :251-365 with insertions and deletions) ------------------------------------
 // Same flat (query, search, node) loop and frame stack as k_scheme; a node's children are numbered in the reference's call order
 //   several rows:  0 match | 2i-1 deletion of index symbol i | 2i substitution by i  (i = 1 .. sigma-1) | 2*sigma-1 insertion
@@ -1127,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
     const uint32_t sigma = occ.sigma();
     const uint32_t K = ac.K, ncodes = ac.ncodes;
     qstage_load_sync(qst, qbuf, o, m, sigma, active && m != 0, maxm);
-    uint32_t steps = 0;
+    uint32_t steps = 0, tbytes = 0, tacc = 0;          // executed extensions; table bytes consumed / table accesses issued (fmgpu_stats)
     if (active) {
         idx_t lb = 0, len = n;
         uint32_t done = 0;                                       // symbols consumed (from the right end)
@@ -1149,7 +1239,7 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
                 if (ac.lutL < 16u) code &= (1u << (2u * ac.lutL)) - 1u;
                 if (!v) code = code_of(0, ac.lutL, 0, v);       // (an odd symbol among the 16: decide on the lutL symbols alone)
             } else code = code_of(0, ac.lutL, 0, v);
-            if (v) { const uint2 en = ac.slut[code]; if (en.y != 0) { lb = en.x; len = en.y; done = ac.lutL; steps = ac.lutL; } }
+            if (v) { const uint2 en = ac.slut[code]; tbytes += 8u; ++tacc; if (en.y != 0) { lb = en.x; len = en.y; done = ac.lutL; steps = ac.lutL; } }
         }
         // main phase: one table load per iteration.  One row left: J (or 2J) symbols per load from the walk tables; otherwise K symbols from the
         // context table.  A step that would empty the interval (or meets an odd symbol) ends the phase WITHOUT touching the cursor:
@@ -1193,13 +1283,15 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
                 if (c >= sigma) break;
                 idx_t ra, rb;
                 occ.lf2(lb, lb + len, c, ra, rb);
+                tbytes += 24u; tacc += 2u;
                 if (rb == ra) break;
                 lb = ra; len = rb - ra; ++steps; ++done;
                 continue;
             }
             const uint4 r0 = *reinterpret_cast<const uint4*>(p0);
             uint4 r1 = r0;
-            if (kind == 3u && (a >> 6) != (b >> 6)) r1 = *reinterpret_cast<const uint4*>(p0 + ((size_t)(b >> 6) - (size_t)(a >> 6)) * ((size_t)ncodes * 16u));
+            tbytes += kind == 2u ? 8u : 12u; ++tacc;
+            if (kind == 3u && (a >> 6) != (b >> 6)) { r1 = *reinterpret_cast<const uint4*>(p0 + ((size_t)(b >> 6) - (size_t)(a >> 6)) * ((size_t)ncodes * 16u)); tbytes += 12u; ++tacc; }
             if (kind == 1u) {
                 if (r0.x == 0xffffffffu) break;
                 if (r0.y != q0 || r0.z != q1) {                  // symbols matching before the first differing one
@@ -1227,12 +1319,12 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
             if (c >= sigma) { lb = 0; len = 0; break; }
             idx_t ra, rb;
             occ.lf2(lb, lb + len, c, ra, rb);
+            tbytes += 24u; tacc += 2u;
             lb = ra; len = rb - ra;
         }
         store_interval(out_lb, out_len, q, lb, len);
     }
-    uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
+    add_counters(steps_total, steps, tbytes, tacc);
 }
 
 constexpr uint32_t kHitBuf = 2;      // hits buffered per lane and round in LDS; further hits of the same query are emitted directly
@@ -1264,6 +1356,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sigma = fw.sigma(), R = sigma - 1;
     uint32_t nodes = 0;
+    uint64_t tbytes = 0; uint32_t tacc = 0;                         // table bytes consumed / table accesses issued (fmgpu_stats)
     for (;;) {
         // ---- round start: 64 consecutive queries for this wave
         unsigned long long base = 0;
@@ -1294,6 +1387,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 }
                 if (valid) {
                     const uint4 en = fa.lut[code];
+                    tbytes += 16u; ++tacc;
                     cur = Cur{en.x, en.y, en.z};
                     nodes += en.w;                                  // the extensions the reference performs before the interval is empty (:225-250)
                     j = fa.lutL; in_tail = true;
@@ -1316,7 +1410,9 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 const idx_t* w3 = right ? fa.w3_rv : fa.w3_fw;
                 const bool use_wj = !multi && wj && ((ent >> 29) & 1u);
                 const uint8_t* blk = (right ? rv : fw).v.blk;
-                const uint8_t* p0 = (multi && kSplit) ? blk + (size_t)(a >> 6) * 64u
+                // the plain index (no LF tables: the ~6 GB configuration): a one-row node reads its 64-byte block and takes the row's symbol and LF from it
+                const bool from_block = kSplit && !multi && fa.lf_fw == nullptr;
+                const uint8_t* p0 = ((multi && kSplit) || from_block) ? blk + (size_t)(a >> 6) * 64u
                                   : use_wj ? reinterpret_cast<const uint8_t*>(wj + a)
                                   : w3 ? reinterpret_cast<const uint8_t*>(w3 + 3u * (size_t)a)
                                   : reinterpret_cast<const uint8_t*>((right ? fa.lf_rv : fa.lf_fw) + a);
@@ -1326,9 +1422,26 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     const uint4* pa = reinterpret_cast<const uint4*>(p0);
                     const uint4* pb = reinterpret_cast<const uint4*>(blk + (size_t)((a + cur.len) >> 6) * 64u);
                     r1 = pa[1]; r2 = pa[2]; r3 = pa[3]; s0 = pb[0]; s1 = pb[1]; s2 = pb[2]; s3 = pb[3];
-                }
+                    const bool same = (a >> 6) == ((a + cur.len) >> 6);
+                    tbytes += same ? 64u : 128u; tacc += same ? 1u : 2u;
+                } else if (multi) { tbytes += 24u * sigma; tacc += 2u; }
+                else { tbytes += from_block ? 64u : use_wj ? 8u : w3 ? 12u : 4u; ++tacc; }
                 const uint2 we = make_uint2(r0.x, r0.y);
                 idx_t t0 = r0.x, t1 = r0.y, t2 = r0.z;
+                if constexpr (kSplit) {
+                    if (from_block) {
+                        const uint4* pa = reinterpret_cast<const uint4*>(p0);
+                        r1 = pa[1]; r2 = pa[2]; r3 = pa[3];
+                        const uint32_t da[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+                        const uint32_t bit = a & 63u;
+                        t0 = 0;
+#pragma unroll
+                        for (uint32_t cc = 0; cc < (uint32_t)SIGMA; ++cc) {
+                            const uint64_t bits = (uint64_t)da[3 * cc + 1] | ((uint64_t)da[3 * cc + 2] << 32);
+                            if ((bits >> bit) & 1ull) t0 = da[3 * cc] + popc64(bits & lowmask(bit));
+                        }
+                    }
+                }
                 if (multi) {
                     // ---- extend-all node (search_next_dir, :143-224) or exact-tail step over several rows
                     const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
@@ -1360,7 +1473,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         uint64_t o = (uint64_t)sp * stk.nlanes + gid;
                         stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
                         stk.p1[o] = (uint64_t)cur.len | ((uint64_t)(j & 0xffffu) << 32) | ((uint64_t)(e & 0xffu) << 48) | ((uint64_t)(subs.first() & 0xffu) << 56);
-                        ++sp;
+                        ++sp; tbytes += 16u; ++tacc;
                     }
                     resume = kNoResume;
                     if (take_match || take_sub) {
@@ -1410,8 +1523,9 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     if (!walked) {
                         const uint32_t run = w3 ? (ent >> 30) : 1u;    // consecutive steps in this direction (<= 3), never past the query end
                         if (use_wj) {                                   // (a walk entry that crosses a delimiter: the steps one load later)
-                            if (w3) { const idx_t* p = w3 + 3u * (size_t)a; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
-                            else t0 = (right ? fa.lf_rv : fa.lf_fw)[a];
+                            if (w3) { const idx_t* p = w3 + 3u * (size_t)a; t0 = p[0]; t1 = p[1]; t2 = p[2]; tbytes += 12u; }
+                            else { t0 = (right ? fa.lf_rv : fa.lf_fw)[a]; tbytes += 4u; }
+                            ++tacc;
                         }
                         const uint32_t sw3 = s_stretch3[si * stride + j];
                         if ((sw3 >> 22) & 1u) {
@@ -1522,6 +1636,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         --sp;
                         uint64_t o = (uint64_t)sp * stk.nlanes + gid;
                         uint64_t w0 = stk.p0[o], w1 = stk.p1[o];
+                        tbytes += 16u; ++tacc;
                         cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32); cur.len = (idx_t)w1;
                         j = (uint32_t)(w1 >> 32) & 0xffffu; e = (uint32_t)(w1 >> 48) & 0xffu; resume = (uint32_t)(w1 >> 56) & 0xffu;
                         in_tail = false;
@@ -1548,9 +1663,14 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 }
             }
         } else if (nh) atomicAdd(&ctr->hits, (unsigned long long)nh);
+        tbytes += 40u * nh; tacc += nh;                            // the hit records written
     }
     uint32_t tot = wave_sum(nodes);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
+    const unsigned long long tb = wave_sum64(tbytes); const uint32_t ta = wave_sum(tacc);
+    if ((threadIdx.x & 63u) == 0 && tot) {
+        atomicAdd(&ctr->nodes, (unsigned long long)tot);
+        atomicAdd(&ctr->table_bytes, tb); atomicAdd(&ctr->table_accesses, (unsigned long long)ta);
+    }
 }
 
 // ---- search_ng26 Edit = true, table-driven ------------------------------------------------------------------------------------------
@@ -1762,6 +1882,8 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
 }
 
+#endif  // !FMGPU_WIDE
+
 // ---- search_backtracking ----------------------------------------------------------------------------------------
 template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
@@ -1801,9 +1923,16 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
                     subs.remove(s);
                     if (subs.any() || match) {                       // something is still pending at this node
                         uint64_t o = (uint64_t)sp * stk.nlanes + gid;
-                        stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
-                        stk.p1[o] = (uint64_t)cur.len | ((uint64_t)i << 32);
-                        stk.p2[o] = (uint64_t)(subs.any() ? subs.first() : 256u) | ((uint64_t)e << 32);
+                        const uint32_t nxt = subs.any() ? subs.first() : 256u;
+                        if constexpr (kWide) {
+                            stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)i << 40);
+                            stk.p1[o] = (uint64_t)cur.lbRev | ((uint64_t)e << 40);
+                            stk.p2[o] = (uint64_t)cur.len | ((uint64_t)nxt << 40);
+                        } else {
+                            stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
+                            stk.p1[o] = (uint64_t)cur.len | ((uint64_t)i << 32);
+                            stk.p2[o] = (uint64_t)nxt | ((uint64_t)e << 32);
+                        }
                         ++sp;
                     }
                     cur = kid_of<MAXSIG>(lfa, lfb, cur, s, false, sigma);
@@ -1823,8 +1952,14 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
             --sp;
             uint64_t o = (uint64_t)sp * stk.nlanes + gid;
             uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o];
-            cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32); cur.len = (idx_t)w1; i = (uint32_t)(w1 >> 32);
-            resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32);
+            if constexpr (kWide) {
+                const uint64_t m40 = (1ull << 40) - 1ull;
+                cur.lb = (idx_t)(w0 & m40); i = (uint32_t)(w0 >> 40); cur.lbRev = (idx_t)(w1 & m40); e = (uint32_t)(w1 >> 40);
+                cur.len = (idx_t)(w2 & m40); resume = (uint32_t)(w2 >> 40);
+            } else {
+                cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32); cur.len = (idx_t)w1; i = (uint32_t)(w1 >> 32);
+                resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32);
+            }
         }
     }
     uint32_t tot = wave_sum(nodes);
@@ -1832,6 +1967,7 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
 }
 
 // ------------------------------------------------------------------ locate
+#if !FMGPU_WIDE
 // with the per-row answer table (fmgpu_index_accelerate_locate): one 12-byte load per row
 __global__ __launch_bounds__(256) void k_locate_tab(const uint32_t* __restrict__ tab, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
                                                     uint64_t* __restrict__ out_seq, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_steps,
@@ -1847,10 +1983,10 @@ __global__ __launch_bounds__(256) void k_locate_tab(const uint32_t* __restrict__
         }
         out_seq[t] = seq; out_pos[t] = pos; out_steps[t] = st;
     }
-    uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
+    add_counters(steps_total, steps, 0u, 0u);
 }
 
+#endif
 constexpr uint32_t kLocateStepCap = 1u << 24;   // a valid index reaches a sampled row long before; bounds a corrupt one
 
 template <class Occ>
@@ -1878,60 +2014,29 @@ __global__ __launch_bounds__(256) void k_locate(Occ occ, const idx_t* __restrict
         }
         out_seq[t] = seq; out_pos[t] = pos; out_steps[t] = st;
     }
-    uint32_t tot = wave_sum(steps);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&steps_total[blockIdx.x & (kCounterStripes - 1u)], (unsigned long long)tot);
+    add_counters(steps_total, steps, 0u, 0u);
 }
 
 // ------------------------------------------------------------------ host launchers
-// per host thread and device: small device buffers and events that every call needs (allocating and freeing them per call costs more
-// than the bookkeeping they serve — hipFree synchronises the device).  `ctr` serves calls that report stats (they synchronise before
-// returning, so it is idle between calls), `sink` the others (never read).
-struct CallScratch {
-    unsigned long long* ctr = nullptr; unsigned long long* sink = nullptr; unsigned long long* len2 = nullptr;
-    unsigned long long* pinned = nullptr;                         // host side of the small read-backs (a pageable target costs a staging copy each)
-    void* frames = nullptr; size_t frames_bytes = 0;              // frame stacks of the DFS kernels, kept between calls up to kFrameCache bytes
-    void* dfs_ctr = nullptr;                                      // their Counters (a DFS call synchronises before it returns: one at a time per thread)
-    hipEvent_t ev_a = nullptr, ev_b = nullptr; int dev = -1;
-    CallScratch() = default;
-    CallScratch(const CallScratch&) = default;
-    CallScratch& operator=(const CallScratch&) = default;
-    ~CallScratch() { if (frames) (void)hipFree(frames); }          // a host thread that ends returns its frame stacks (the small objects stay with the process)
-};
-static int call_scratch(CallScratch** out) {
-    static thread_local CallScratch sc;
-    int dev = 0;
-    FM_HIP(hipGetDevice(&dev));
-    if (sc.dev != dev) {                                          // first use on this device (objects of an earlier device are left to the process)
-        if (sc.frames) { (void)hipFree(sc.frames); sc.frames = nullptr; }   // (the frame stacks are the one object worth returning)
-        { CallScratch fresh; sc = fresh; }
-        sc.dev = dev;
-        FM_HIP(hipMalloc((void**)&sc.ctr, kCounterStripes * 8));
-        FM_HIP(hipMalloc((void**)&sc.sink, kCounterStripes * 8));
-        FM_HIP(hipMalloc((void**)&sc.len2, (2 * 1024 + 1) * 8));
-        FM_HIP(hipHostMalloc((void**)&sc.pinned, (2 * 1024 + 1) * 8, hipHostMallocDefault));
-        FM_HIP(hipMalloc(&sc.dfs_ctr, 64));
-        FM_HIP(hipEventCreate(&sc.ev_a));
-        FM_HIP(hipEventCreate(&sc.ev_b));
-    }
-    *out = &sc;
-    return 0;
-}
 static int step_counters(bool want, hipStream_t stream, unsigned long long** out) {
     CallScratch* sc = nullptr;
     int rc = call_scratch(&sc); if (rc) return rc;
-    if (want) FM_HIP(hipMemsetAsync(sc->ctr, 0, kCounterStripes * 8, stream));
+    if (want) FM_HIP(hipMemsetAsync(sc->ctr, 0, (size_t)kCounterStripes * kCounterKinds * 8, stream));
     *out = want ? sc->ctr : sc->sink;
     return 0;
 }
-static int read_step_counters(const unsigned long long* dev, hipStream_t stream, unsigned long long* total) {
+// totals[0] executed steps, [1] table bytes, [2] table accesses
+static int read_step_counters(const unsigned long long* dev, hipStream_t stream, unsigned long long* totals) {
     CallScratch* sc = nullptr;
     int rc = call_scratch(&sc); if (rc) return rc;
     unsigned long long* h = sc->pinned;
-    FM_HIP(hipMemcpyAsync(h, dev, kCounterStripes * 8, hipMemcpyDeviceToHost, stream));
+    FM_HIP(hipMemcpyAsync(h, dev, (size_t)kCounterStripes * kCounterKinds * 8, hipMemcpyDeviceToHost, stream));
     FM_HIP(hipStreamSynchronize(stream));
-    unsigned long long t = 0;
-    for (unsigned k = 0; k < kCounterStripes; ++k) t += h[k];
-    *total = t;
+    for (unsigned kind = 0; kind < kCounterKinds; ++kind) {
+        unsigned long long t = 0;
+        for (unsigned k = 0; k < kCounterStripes; ++k) t += h[kind * kCounterStripes + k];
+        totals[kind] = t;
+    }
     return 0;
 }
 
@@ -1945,26 +2050,6 @@ struct EventTimer {       // the thread's cached event pair (one timed call at a
     void stop() { if (on) (void)hipEventRecord(b, s); }
     float ms() { float v = 0; if (on) { (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&v, a, b); } return v; }
 };
-
-
-template <class F>
-static int dispatch_occ(const DevString& s, F&& f) {
-    switch (s.search_family()) {
-    case FAM_A:
-        if (s.sigma == 5) return f(OccA<5>{s.va}, std::integral_constant<int, 5>{});
-        if (s.sigma <= 32) return f(OccA<0>{s.va}, std::integral_constant<int, 32>{});
-        return f(OccA<0>{s.va}, std::integral_constant<int, 256>{});
-    case FAM_EPR:
-        if (s.sigma <= 32) return f(OccR<false>{s.vr}, std::integral_constant<int, 32>{});
-        return f(OccR<false>{s.vr}, std::integral_constant<int, 256>{});
-    case FAM_EPRV2:
-        if (s.sigma <= 32) return f(OccR<true>{s.vr}, std::integral_constant<int, 32>{});
-        return f(OccR<true>{s.vr}, std::integral_constant<int, 256>{});
-    default:
-        if (s.sigma <= 32) return f(OccW{s.vw}, std::integral_constant<int, 32>{});
-        return f(OccW{s.vw}, std::integral_constant<int, 256>{});
-    }
-}
 
 // longest and shortest query and the total symbol count of a batch whose offsets live in HBM: one reduction kernel, one small copy,
 // one synchronisation (per-block partial results reduced on the host: no atomics, nothing to initialise)
@@ -2117,12 +2202,10 @@ struct DfsWorkspace {
     ~DfsWorkspace() { if (planes && own_planes) (void)hipFree(planes); }
 };
 
-}  // namespace fmgpu
-
-using namespace fmgpu;
-
-
-extern "C" {
+namespace api {
+#include "fmgpu_api_decl.h"
+int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
+int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream);
 
 static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                         uint64_t* out_lb, uint64_t* out_len, bool packed, fmgpu_stats* stats, void* stream_) {
@@ -2132,6 +2215,7 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
     if (stats) *stats = fmgpu_stats{0, 0, 0.f};
     if (nq == 0) return 0;
     if (!qbuf || !qoff || !out_lb || (!out_len && !packed)) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out_lb / out_len is null");
+    if (kWide && packed) return fail(FMGPU_ERR_UNSUPPORTED, "the one-word interval form (lb << 32 | len) needs rows below 2^32; use fmgpu_search_exact");
     hipStream_t stream = (hipStream_t)stream_;
     Staged soff, sbuf, slb, slen;
     int rc;
@@ -2147,9 +2231,11 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
     unsigned long long* dsteps = nullptr;
     if ((rc = step_counters(stats != nullptr, stream, &dsteps))) return rc;
     EventTimer timer(stream, stats != nullptr);
-    dim3 grid((unsigned)((nq + 255) / 256)), block(256);
+    FM_GRID(grid, nq);
+    const dim3 block(256);
     const idx_t n = (idx_t)x->bwt.n;
     timer.start();
+#if !FMGPU_WIDE
     uint32_t kq_words = 0, kq_max = 0, kq_nib = x->bwt.sigma <= 15 ? 1u : 0u;
     const bool accel = x->bwt.kblk || x->bwt.slut || x->bwt.walkj;
     if (accel) {                                                 // LDS staging needs the longest query of the batch
@@ -2169,7 +2255,9 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
                                                                     (uint64_t*)slen.dev, dsteps, kq_words, kq_nib, kq_max);
             return 0;
         });
-    } else if (x->bwt.search_family() == FAM_A) {
+    } else
+#endif
+    if (x->bwt.search_family() == FAM_A) {
         auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
         if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, 0, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         else k_exact_a<0><<<grid, block, 0, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
@@ -2179,8 +2267,19 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         uint32_t qw = (mx + 3) / 4;
         if ((size_t)qw * 1024 > 48 * 1024) qw = 0;
         timer.start();
-        k_exact_w<<<grid, block, (size_t)qw * 1024, stream>>>(x->bwt.vw, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
-                                                               (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps, qw);
+        const ViewM& vm = x->bwt.vm;
+        auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
+        const size_t lds = (size_t)qw * 1024;
+        switch (vm.bitct) {                                      // the digits of digits_of() as template arguments
+        case 1: k_exact_m<1, 0, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 2: k_exact_m<2, 0, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 3: k_exact_m<3, 0, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 4: k_exact_m<2, 2, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 5: k_exact_m<3, 2, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 6: k_exact_m<3, 3, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 7: k_exact_m<3, 2, 2><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        default: k_exact_m<3, 3, 2><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        }
     } else {
         rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
             k_exact<decltype(occ)><<<grid, block, 0, stream>>>(occ, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
@@ -2192,9 +2291,10 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_exact launch");
     if (stats) {
-        unsigned long long hs = 0;
-        if ((rc = read_step_counters(dsteps, stream, &hs))) return rc;
-        stats->lf_steps = hs; stats->hits = nq; stats->kernel_ms = timer.ms();
+        unsigned long long hs[kCounterKinds] = {0, 0, 0};
+        if ((rc = read_step_counters(dsteps, stream, hs))) return rc;
+        stats->lf_steps = hs[0]; stats->hits = nq; stats->kernel_ms = timer.ms();
+        stats->table_bytes = hs[1]; stats->table_accesses = hs[2];
     }
     if ((rc = slb.finish())) return rc;
     if (out_len && (rc = slen.finish())) return rc;
@@ -2210,6 +2310,29 @@ int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qof
 int fmgpu_search_exact_packed(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                               uint64_t* out_interval, fmgpu_stats* stats, void* stream) {
     return search_exact(h, qbuf, qoff, nq, out_interval, nullptr, true, stats, stream);
+}
+
+int fmgpu_search_exact_depth(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, uint32_t* out_depth, void* stream_) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
+    if (nq == 0) return 0;
+    if (!qbuf || !qoff || !out_depth) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out_depth is null");
+    hipStream_t stream = (hipStream_t)stream_;
+    Staged soff, sbuf, sout;
+    int rc;
+    if ((rc = soff.in(qoff, (nq + 1) * 8, stream))) return rc;
+    uint64_t total = 0;
+    if (is_device_pointer(qoff)) { FM_HIP(hipMemcpyAsync(&total, qoff + nq, 8, hipMemcpyDeviceToHost, stream)); FM_HIP(hipStreamSynchronize(stream)); }
+    else total = qoff[nq];
+    if ((rc = sbuf.in(qbuf, total, stream)) || (rc = sout.out(out_depth, nq * 4, stream))) return rc;
+    FM_GRID(grid, nq);
+    rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
+        k_exact_depth<decltype(occ)><<<grid, dim3(256), 0, stream>>>(occ, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, (idx_t)x->bwt.n, (uint32_t*)sout.dev);
+        return 0;
+    });
+    FM_LAUNCHED("k_exact_depth");
+    return sout.finish();
 }
 
 static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme,
@@ -2229,6 +2352,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         if (max_hits == 0 || scheme->n_searches == 0) return 0;                       // SearchNg26.h:408-409
         sd.S = scheme->n_searches; sd.P = scheme->n_parts; sd.uniform = scheme->partition ? 0 : 1;
         edit = scheme->edit != 0;
+        if (kWide && edit) return fail(FMGPU_ERR_UNSUPPORTED, "edit-distance search is not available for indices of 2^32 rows or more (64-bit-row build)");
         { const char* e = getenv("FMGPU_DEV_FLAGS"); sd.dev_flags = e ? atoi(e) : 0; }
         for (int s = 0; s < sd.S; ++s) {
             uint32_t seen = 0;
@@ -2270,7 +2394,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     // tables and hit buffers (<= 17 KB static in the general kernels; per-step tables + hit buffers in the table-driven ones, reserved below)
     const size_t stage_words = x->bwt.sigma <= 15 ? (maxlen + 7) / 8 : (maxlen + 3) / 4;
     const size_t tables_lds = scheme_mode ? (size_t)3 * (size_t)std::max(sd.S, 1) * ((size_t)maxlen + 1) * 4 + (size_t)kWaveHitWords * 4 : 0;
-    const size_t stage_budget = (size_t)64 * 1024 - std::max<size_t>(17 * 1024, std::min<size_t>(tables_lds, 47 * 1024));
+    const size_t stage_budget = (size_t)64 * 1024 - std::max<size_t>((kWide ? 24 : 17) * 1024, std::min<size_t>(tables_lds, 47 * 1024));
     const size_t occ_lds = stage_words * 1024 > stage_budget ? 0 : stage_words * 1024;
     const auto occ_key = std::make_tuple(x->bwt.search_family(), x->bwt.sigma, (int)scheme_mode + (edit ? 2 : 0), occ_lds);
     bool occ_known = false;
@@ -2279,8 +2403,10 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         auto occ_of = [&](auto kernel) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, occ_lds) == hipSuccess && nb > 0) bpc = nb; else (void)hipGetLastError(); };
         dispatch_occ(x->bwt, [&](auto occ, auto ms) {
             using O = decltype(occ);
-            if (scheme_mode && edit) occ_of(k_scheme_edit<O, decltype(ms)::value>);
-            else if (scheme_mode) occ_of(k_scheme<O, decltype(ms)::value>); else occ_of(k_backtracking<O, decltype(ms)::value>);
+#if !FMGPU_WIDE
+            if (scheme_mode && edit) occ_of(k_scheme_edit<O, decltype(ms)::value>); else
+#endif
+            if (scheme_mode) occ_of(k_scheme<O, decltype(ms)::value>); else occ_of(k_backtracking<O, decltype(ms)::value>);
             return 0;
         });
         std::lock_guard<std::mutex> g(occ_mu); occ_cache[occ_key] = bpc;
@@ -2294,17 +2420,20 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     EventTimer timer(stream, stats != nullptr);
     const idx_t n = (idx_t)x->bwt.n;
     const dim3 block(256);
-    // fast path: equal-length batch on a Format-A BiFMIndex with LF tables
+    uint32_t* d_qmap = nullptr;
+    uint32_t* d_steps = nullptr;
+    bool fast = false;
+#if !FMGPU_WIDE
+    // fast path: equal-length batch on a Format-A BiFMIndex — with LF tables, or (Hamming, sigma <= 5) on the blocks alone
     // 16-symbol walk: 2-bit symbols, queries staged in LDS as nibbles
-    const bool use_wj = !edit && !(sd.dev_flags & 32) && x->bwt.walkj && x->rev.walkj && x->bwt.walk_bits == 2 && x->rev.walk_bits == 2 && qnib && qwords;
-    const bool fast_ok = scheme_mode && x->bwt.search_family() == FAM_A && x->bwt.lf_table && x->rev.lf_table && x->bwt.sigma <= 32 && !(sd.dev_flags & 2);
+    const bool have_lf = x->bwt.lf_table && x->rev.lf_table;
+    const bool use_wj = !edit && !(sd.dev_flags & 32) && have_lf && x->bwt.walkj && x->rev.walkj && x->bwt.walk_bits == 2 && x->rev.walk_bits == 2 && qnib && qwords;
+    const bool fast_ok = scheme_mode && x->bwt.search_family() == FAM_A && (have_lf || (!edit && x->bwt.sigma == 5)) && x->bwt.sigma <= 32 && !(sd.dev_flags & 2);
     const uint32_t lutL = (sd.dev_flags & 4) ? 0 : x->lut_len;
     // one launch of the table-driven kernel per query length: an equal-length batch is one bucket; a ragged batch is sorted by length on the
     // device (the kernel reads its queries through the sorted index) as long as the buckets stay large enough to be worth a launch each
     struct Bucket { uint32_t m; uint64_t first, count; std::vector<uint32_t> tab; uint32_t lut_ok; };
     std::vector<Bucket> buckets;
-    uint32_t* d_qmap = nullptr;
-    bool fast = false;
     if (fast_ok && minlen == maxlen) {
         Bucket b{maxlen, 0, nq, {}, 0};
         fast = build_step_table(sd, maxlen, lutL, use_wj ? 16u : 0u, b.tab, b.lut_ok);
@@ -2367,11 +2496,12 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             std::lock_guard<std::mutex> g(occ_mu); occ_cache[key] = bpc;
         }
     }
+#endif  // !FMGPU_WIDE
     { const char* ev = getenv("FMGPU_DEV_BPC"); if (ev && atoi(ev) > 0) bpc = atoi(ev); }   // dev knob: resident blocks per CU the grid is sized for
     // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
     if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? 4 : 3))) { if (d_qmap) (void)hipFree(d_qmap); return rc; }
     const dim3 grid(ws.grid);
-    uint32_t* d_steps = nullptr;
+#if !FMGPU_WIDE
     size_t steps_words = 0;
     if (fast) {
         for (const Bucket& b : buckets) steps_words += b.tab.size();
@@ -2380,14 +2510,17 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         size_t at = 0;
         for (const Bucket& b : buckets) { (void)hipMemcpyAsync(d_steps + at, b.tab.data(), b.tab.size() * 4, hipMemcpyHostToDevice, stream); at += b.tab.size(); }
     }
+#endif
     timer.start();
+#if !FMGPU_WIDE
     if (fast) {
         size_t at = 0;
         for (const Bucket& b : buckets) {
             FastArgs fa{};
-            fa.lf_fw = x->bwt.lf_table; fa.lf_rv = x->rev.lf_table; fa.steps = d_steps + at; fa.S = (uint32_t)sd.S; fa.m = b.m;
+            if (have_lf) { fa.lf_fw = x->bwt.lf_table; fa.lf_rv = x->rev.lf_table; }
+            fa.steps = d_steps + at; fa.S = (uint32_t)sd.S; fa.m = b.m;
             at += b.tab.size();
-            if (!(sd.dev_flags & 8)) { fa.w3_fw = x->bwt.walk3; fa.w3_rv = x->rev.walk3; }
+            if (have_lf && !(sd.dev_flags & 8)) { fa.w3_fw = x->bwt.walk3; fa.w3_rv = x->rev.walk3; }
             if (use_wj) { fa.wj_fw = x->bwt.walkj; fa.wj_rv = x->rev.walkj; }
             fa.lut = b.lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = b.lut_ok;
             for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
@@ -2409,7 +2542,9 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                 k_scheme_fast<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                      b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
         }
-    } else if (scheme_mode) {
+    } else
+#endif
+    if (scheme_mode) {
         const DevString& rv = x->rev;
         LfView lfv{nullptr, nullptr, nullptr};
         if (x->bwt.lf_table && rv.lf_table && !(sd.dev_flags & 16)) lfv = LfView{x->bwt.lf_table, rv.lf_table, x->dC};
@@ -2417,15 +2552,17 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             using O = decltype(occ);
             O r{};
             if constexpr (std::is_same_v<O, OccA<5>> || std::is_same_v<O, OccA<0>>) r = O{rv.va};
-            else if constexpr (std::is_same_v<O, OccW>) r = O{rv.vw};
+            else if constexpr (std::is_same_v<O, OccM>) r = O{rv.vm};
             else r = O{rv.vr};
             (void)hipMemsetAsync(&ws.ctr->next, 0, 8, stream);         // queries are handed out from 0, one reservation per wave
+#if !FMGPU_WIDE
             if (edit) {
                 k_scheme_edit<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
                                                                                   max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, maxlen,
                                                                                   (sd.dev_flags & 4) ? nullptr : x->lut, x->lut_len);
                 return 0;
             }
+#endif
             k_scheme<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
                                                                          max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv);
             return 0;
@@ -2447,7 +2584,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (d_qmap) (void)hipFree(d_qmap);
     if (le != hipSuccess) return hip_fail(le, "search kernel");
     *out_count = hc.hits;
-    if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); }
+    if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); stats->table_bytes = hc.table_bytes; stats->table_accesses = hc.table_accesses; }
     if (hc.hits > capacity) {
         if (sout.writeback) { sout.bytes = capacity * sizeof(fmgpu_hit); (void)sout.finish(); }
         return fail(FMGPU_ERR_CAPACITY, "result buffer holds " + std::to_string(capacity) + " records, " + std::to_string(hc.hits) + " produced");
@@ -2477,6 +2614,10 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
                       uint64_t max_hits_per_query, fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, void* stream_) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+#if FMGPU_WIDE
+    (void)qbuf; (void)qoff; (void)nq; (void)scheme; (void)max_hits_per_query; (void)out; (void)capacity; (void)out_count; (void)stats; (void)stream_;
+    return fail(FMGPU_ERR_UNSUPPORTED, "search_ng21 (edit distance) is not available for indices of 2^32 rows or more (64-bit-row build)");
+#else
     if (int drc = on_handle_device(x)) return drc;
     hipStream_t stream = (hipStream_t)stream_;
     if (stats) *stats = fmgpu_stats{0, 0, 0.f};
@@ -2555,7 +2696,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
         const DevString& rv = x->rev;
         O r{};
         if constexpr (std::is_same_v<O, OccA<5>> || std::is_same_v<O, OccA<0>>) r = O{rv.va};
-        else if constexpr (std::is_same_v<O, OccW>) r = O{rv.vw};
+        else if constexpr (std::is_same_v<O, OccM>) r = O{rv.vm};
         else r = O{rv.vr};
         k_ng21<O, decltype(ms)::value><<<dim3(ws.grid), dim3(256), lds_bytes, stream>>>(occ, r, d_tab, S, (uint32_t)M, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                                    nq, n, max_hits_per_query, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, tab_lds, x->lut, x->lut_len);
@@ -2577,6 +2718,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     }
     if (sout.writeback) sout.bytes = hc.hits * sizeof(fmgpu_hit);
     return sout.finish();
+#endif
 }
 
 int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps,
@@ -2598,12 +2740,16 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
     unsigned long long* dsteps = nullptr;
     if ((rc = step_counters(stats != nullptr, stream, &dsteps))) return rc;
     EventTimer timer(stream, stats != nullptr);
-    dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    FM_GRID(grid, count);
+    const dim3 block(256);
     const idx_t n = (idx_t)x->bwt.n;
     timer.start();
+#if !FMGPU_WIDE
     if (x->loc_tab)
         k_locate_tab<<<grid, block, 0, stream>>>(x->loc_tab, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
-    else rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
+    else
+#endif
+    rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
         k_locate<decltype(occ)><<<grid, block, 0, stream>>>(occ, x->bwt.lf_table, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev,
                                                            (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
         return 0;
@@ -2612,15 +2758,22 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_locate launch");
     if (stats) {
-        unsigned long long hs = 0;
-        if ((rc = read_step_counters(dsteps, stream, &hs))) return rc;
-        stats->lf_steps = hs; stats->hits = count; stats->kernel_ms = timer.ms();
+        unsigned long long hs[kCounterKinds] = {0, 0, 0};
+        if ((rc = read_step_counters(dsteps, stream, hs))) return rc;
+        stats->lf_steps = hs[0]; stats->hits = count; stats->kernel_ms = timer.ms();
     }
     rc = sseq.finish(); if (!rc) rc = spos.finish(); if (!rc) rc = sst.finish();
     if (stats || sseq.owned || spos.owned || sst.owned) (void)hipStreamSynchronize(stream);
     return rc;
 }
 
+#if FMGPU_WIDE
+int fmgpu_index_accelerate_locate(fmgpu_index_t h, int32_t enable) {
+    if (!h) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (!enable) return 0;
+    return fail(FMGPU_ERR_UNSUPPORTED, "the locate answer table is not available for indices of 2^32 rows or more (64-bit-row build)");
+}
+#else
 // answer table for locate: every row is located once, the triples are kept (12 bytes per row)
 __global__ __launch_bounds__(256) void k_pack_locate(const uint64_t* __restrict__ seq, const uint64_t* __restrict__ pos, const uint64_t* __restrict__ st, uint64_t first,
                                                      uint64_t count, uint32_t* __restrict__ tab) {
@@ -2643,28 +2796,27 @@ int fmgpu_index_accelerate_locate(fmgpu_index_t h, int32_t enable) {
     if (x->loc_tab) { (void)hipFree(x->loc_tab); x->loc_tab = nullptr; x->device_bytes -= n * 12; }
     if (!enable || n == 0) return 0;
     if (!x->has_sa) return fail(FMGPU_ERR_INVALID, "index was created without an annotated (sampled suffix) array");
-    uint32_t* tab = nullptr;
-    FM_HIP(hipMalloc((void**)&tab, n * 12 + 16));
+    DBuf tab, staging;
+    int rc;
     const uint64_t chunk = 1ull << 26;
-    uint64_t* buf = nullptr;                                       // rows | seq | pos | steps of one chunk
-    hipError_t e = hipMalloc((void**)&buf, chunk * 8 * 4);
-    if (e != hipSuccess) { (void)hipFree(tab); return hip_fail(e, "hipMalloc(locate staging)"); }
-    int rc = 0;
-    for (uint64_t first = 0; first < n && rc == 0; first += chunk) {
+    if ((rc = tab.alloc(n * 12 + 16)) || (rc = staging.alloc(chunk * 8 * 4))) return rc;
+    uint64_t* buf = staging.as<uint64_t>();                        // rows | seq | pos | steps of one chunk
+    for (uint64_t first = 0; first < n; first += chunk) {
         const uint64_t cnt = std::min(chunk, n - first);
         k_iota64<<<dim3((unsigned)((cnt + 255) / 256)), 256>>>(buf, first, cnt);
-        rc = fmgpu_locate(h, buf, cnt, buf + chunk, buf + 2 * chunk, buf + 3 * chunk, nullptr, nullptr);
-        if (rc == 0) k_pack_locate<<<dim3((unsigned)((cnt + 255) / 256)), 256>>>(buf + chunk, buf + 2 * chunk, buf + 3 * chunk, first, cnt, tab);
+        FM_LAUNCHED("k_iota64");
+        if ((rc = api::fmgpu_locate(h, buf, cnt, buf + chunk, buf + 2 * chunk, buf + 3 * chunk, nullptr, nullptr))) return rc;
+        k_pack_locate<<<dim3((unsigned)((cnt + 255) / 256)), 256>>>(buf + chunk, buf + 2 * chunk, buf + 3 * chunk, first, cnt, tab.as<uint32_t>());
+        FM_LAUNCHED("k_pack_locate");
     }
-    e = hipDeviceSynchronize();
-    (void)hipFree(buf);
-    if (rc == 0 && e != hipSuccess) rc = hip_fail(e, "locate table");
-    if (rc) { (void)hipFree(tab); return rc; }
-    x->loc_tab = tab;
+    FM_HIP(hipDeviceSynchronize());
+    x->loc_tab = (uint32_t*)tab.take();
     x->device_bytes += n * 12;
     return 0;
 }
+#endif  // FMGPU_WIDE
 
+#if !FMGPU_WIDE   // (fmgpu_hit holds 64-bit fields: the record helpers are width-independent and live in the 32-bit-row build)
 // ---- hit records in the reference's callback order -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hit_keys(const fmgpu_hit* __restrict__ h, uint64_t count, uint64_t* __restrict__ key_q, uint32_t* __restrict__ key_s,
                                                   uint32_t* __restrict__ idx) {
@@ -2680,11 +2832,12 @@ __global__ __launch_bounds__(256) void k_gather_hits(const fmgpu_hit* __restrict
     if (t < count) dst[t] = src[perm[t]];
 }
 
-// 16-byte transport form of a hit: word 0 = qidx:32 | lb:32, word 1 = len:32 | errors:8 | seq:24
-__global__ __launch_bounds__(256) void k_hits_pack16(const fmgpu_hit* __restrict__ h, uint64_t count, ulonglong2* __restrict__ out) {
+// 16-byte transport form of a hit: word 0 = qidx:32 | lb:32, word 1 = len:32 | errors:8 | seq:24; a record that does not fit raises *bad
+__global__ __launch_bounds__(256) void k_hits_pack16(const fmgpu_hit* __restrict__ h, uint64_t count, ulonglong2* __restrict__ out, unsigned int* __restrict__ bad) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const fmgpu_hit r = h[t];
+    if ((r.qidx | r.lb | r.len) >> 32 || r.errors > 0xffu || r.seq > 0xffffffu) atomicOr(bad, 1u);
     out[t] = make_ulonglong2((r.qidx & 0xffffffffull) | (r.lb << 32),
                              (r.len & 0xffffffffull) | ((uint64_t)(r.errors & 0xffu) << 32) | ((uint64_t)(r.seq & 0xffffffu) << 40));
 }
@@ -2696,9 +2849,17 @@ int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void
     Staged sh, so;
     int rc = sh.in(hits, count * sizeof(fmgpu_hit), stream); if (rc) return rc;
     if ((rc = so.out(out, count * 16, stream))) return rc;
-    k_hits_pack16<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream>>>((const fmgpu_hit*)sh.dev, count, (ulonglong2*)so.dev);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "k_hits_pack16");
+    CallScratch* sc = nullptr;
+    if ((rc = call_scratch(&sc))) return rc;
+    unsigned int* bad = reinterpret_cast<unsigned int*>(sc->len2);      // (a word of the thread's scratch; the read-back below orders this call's use of it)
+    FM_HIP(hipMemsetAsync(bad, 0, 4, stream));
+    FM_GRID(grid, count);
+    k_hits_pack16<<<grid, dim3(256), 0, stream>>>((const fmgpu_hit*)sh.dev, count, (ulonglong2*)so.dev, bad);
+    FM_LAUNCHED("k_hits_pack16");
+    unsigned int* hbad = reinterpret_cast<unsigned int*>(sc->pinned);
+    FM_HIP(hipMemcpyAsync(hbad, bad, 4, hipMemcpyDeviceToHost, stream));
+    FM_HIP(hipStreamSynchronize(stream));
+    if (*hbad) return fail(FMGPU_ERR_UNSUPPORTED, "a hit record does not fit the 16-byte transport form (qidx, lb, len < 2^32, errors < 256, seq < 2^24)");
     return so.finish();
 }
 
@@ -2743,4 +2904,7 @@ int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream_) {
     return sh.finish();
 }
 
-}  // extern "C"
+#endif  // !FMGPU_WIDE
+
+}  // namespace api
+}  // namespace FMGPU_NS

@@ -20,6 +20,10 @@
  *     threads (each call brings its own stream / buffers).
  *   - symbols are ranks in [0, sigma) exactly as in the reference (0 = sequence delimiter);
  *     row indices, interval bounds and counts are uint64_t like the reference's size_t.
+ *   - row width: an index of fewer than 2^32 - 64 rows is held in 32-bit device tables and may use every optional accelerator table below;
+ *     a larger one (up to 2^40 rows; the reference switches to a 64-bit suffix array at 2^31 rows, utils.h:243-247) is held in 64-bit-row
+ *     tables: construction, exact search, search_ng26<Hamming>, search_backtracking, locate, cursor steps and String_c queries work on it,
+ *     the accelerator tables, edit distance and the one-word transport forms return FMGPU_ERR_UNSUPPORTED (fmgpu_index_row_bits tells which).
  */
 #ifndef FMGPU_H
 #define FMGPU_H
@@ -31,12 +35,12 @@
 extern "C" {
 #endif
 
-#define FMGPU_ABI_VERSION 3
+#define FMGPU_ABI_VERSION 4
 
 typedef enum fmgpu_status {
     FMGPU_OK = 0,
     FMGPU_ERR_INVALID = -1,      /* bad argument (null pointer, sigma out of range, sizes that do not match the layout) */
-    FMGPU_ERR_UNSUPPORTED = -2,  /* valid request this build cannot serve (e.g. n >= 2^32 rows) */
+    FMGPU_ERR_UNSUPPORTED = -2,  /* valid request this build cannot serve (e.g. an accelerator table on a 64-bit-row index, n >= 2^40 rows) */
     FMGPU_ERR_HIP = -3,          /* a HIP runtime call failed; message holds hipGetErrorString */
     FMGPU_ERR_NO_DEVICE = -4,    /* no gfx950 device visible */
     FMGPU_ERR_CAPACITY = -5,     /* result buffer too small; *out_count holds the required record count */
@@ -136,6 +140,13 @@ typedef struct fmgpu_stats {
     uint64_t lf_steps;       /* exact search: executed extensions;  k-mismatch: visited nodes (cursor extensions) */
     uint64_t hits;           /* records produced */
     float    kernel_ms;      /* duration of the dominant kernel, measured with hipEvents on `stream` (0 if not requested) */
+    uint32_t reserved;
+    /* what the dominant kernel actually asked of the memory system on the index tables, counted by the kernel itself (0 for kernels that do
+     * not count): table_bytes = sum over issued table loads of the entry bytes consumed (a 12-byte block entry, an 8-byte walk entry, a
+     * 64-byte block of an extend-all, a 16-byte frame ...), table_accesses = number of such accesses that can each touch a different
+     * memory line (two loads into the same 64-byte block count once).  Query and result traffic is coalesced and not included. */
+    uint64_t table_bytes;
+    uint64_t table_accesses;
 } fmgpu_stats;
 
 int         fmgpu_abi_version(void);
@@ -149,6 +160,13 @@ int         fmgpu_set_device(int device);   /* hipSetDevice for the calling thre
 int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out);
 int fmgpu_index_destroy(fmgpu_index_t h);
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes);
+int fmgpu_index_row_bits(fmgpu_index_t h, int32_t* bits);   /* 32 or 64: the width of the device tables this index is held in */
+
+/* The explicit LF mapping (one word per row and direction: LF(row) = C[s] + rank(row, s) of the row's own symbol s): one-load one-row
+ * search nodes and locate steps, and what the walk tables are built from.  Built at creation unless FMGPU_LF_TABLE=0 is set in the
+ * environment; enable = 0 drops it (the walk tables must have been dropped before), enable != 0 builds it.  Without it the index is the
+ * bit-packed occurrence table alone (GRCh38: 3.1 GB per direction).  Results are unchanged. */
+int fmgpu_index_accelerate_lf(fmgpu_index_t h, int32_t enable);
 
 /* Optional accelerator for fmgpu_search_exact: a k-symbol-step occurrence table (one table entry advances a cursor by `kstep`
  * symbols, so a query touches 1/kstep as many HBM lines).  Built on the device from the index itself; needs
@@ -190,10 +208,23 @@ int fmgpu_string_query(fmgpu_index_t h, int which, const uint64_t* idx, const ui
 int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                        uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats, void* stream);
 
-/* the same search, each cursor as ONE word  lb << 32 | len  (rows are < 2^32 in this build): the 8-byte-per-read form in which a rank's
+/* the same search, each cursor as ONE word  lb << 32 | len  (32-bit-row indices only): the 8-byte-per-read form in which a rank's
  * intervals travel to the gathering rank ("only an RCCL gather of the resulting SA intervals") */
 int fmgpu_search_exact_packed(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                               uint64_t* out_interval, fmgpu_stats* stats, void* stream);
+
+/* A profile of the same search: out_depth[q] = query symbols consumed until the cursor holds at most one row (0 rows included), or
+ * length + 1 if it still holds several rows at the end.  (Tells how much of a batch the one-row walk tables can serve; bench.py reports
+ * the distribution for each text.) */
+int fmgpu_search_exact_depth(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, uint32_t* out_depth, void* stream);
+
+/* Cursor steps, batched: FMIndexCursor / BiFMIndexCursor::extendLeft(symb), extendRight(symb) (fmindex/FMIndexCursor.h:33-37,
+ * fmindex/BiFMIndexCursor.h:113-128) for `count` cursors {lb, lb_rev, len}, or — symb == NULL — extendLeft() / extendRight() over all
+ * symbols (FMIndexCursor.h:38-53, BiFMIndexCursor.h:58-82): then every cursor yields sigma cursors, out[i * sigma + c].
+ * direction 0 = left, 1 = right (BiFMIndex only).  lb_rev / out_lb_rev may be NULL for a unidirectional FMIndex.
+ * symbolLeft / symbolRight of a cursor (BiFMIndexCursor.h:180-190) are fmgpu_string_query(what = 2) on bwt at lb / on bwtRev at lb_rev. */
+int fmgpu_cursor_extend(fmgpu_index_t h, int32_t direction, uint64_t count, const uint64_t* lb, const uint64_t* lb_rev, const uint64_t* len,
+                        const uint8_t* symb, uint64_t* out_lb, uint64_t* out_lb_rev, uint64_t* out_len, void* stream);
 
 /* search_ng26::search<Edit=false>(index, queries, scheme, partition, delegate, n) (search/SearchNg26.h:426-433);
  * BiFMIndex only.  max_hits_per_query = n (UINT64_MAX = unlimited).  Records are appended in no particular order across
@@ -223,7 +254,8 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count,
 
 /* the 16-byte transport form of hit records (what a rank sends to the gathering rank): out[2k] = qidx:32 | lb:32,
  * out[2k+1] = len:32 | errors:8 | seq:24; lb_rev is dropped (it only serves further extension of the cursor).  Needs qidx, lb, len < 2^32,
- * errors < 256, seq < 2^24 — all true for this build's indices and for batches below 2^32 queries. */
+ * errors < 256, seq < 2^24; a record that does not fit makes the call return FMGPU_ERR_UNSUPPORTED (checked on the device; the call
+ * synchronises `stream`). */
 int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
 
 /* Puts `count` hit records (host or device memory) into the reference's callback order — ascending qidx, inside a query the order the

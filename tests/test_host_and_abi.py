@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.fmgpu_abi_version() == 3
+    assert L.fmgpu_abi_version() == 4
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
