@@ -185,6 +185,41 @@ class FMIndex:
     def size(self):
         return self.n
 
+    @property
+    def row_bits(self):
+        """32 or 64: the width of the device tables the index is held in (include/fmgpu.h, "row width")"""
+        b = C.c_int32()
+        capi.check(capi.lib().fmgpu_index_row_bits(self._h, C.byref(b)))
+        return b.value
+
+    def _refresh_bytes(self):
+        dbytes = C.c_uint64()
+        capi.check(capi.lib().fmgpu_index_info(self._h, None, None, None, None, C.byref(dbytes)))
+        self.device_bytes = dbytes.value
+        return self
+
+    def accelerate_lf(self, enable=True):
+        """build / drop the explicit LF tables (one word per row and direction); without them the index is the bit-packed occurrence table alone"""
+        capi.check(capi.lib().fmgpu_index_accelerate_lf(self._h, 1 if enable else 0))
+        return self._refresh_bytes()
+
+    # -------------------------------------------------------------- cursor steps (fmindex/FMIndexCursor.h:33-53, fmindex/BiFMIndexCursor.h:58-128)
+    def extend(self, lb, lb_rev, length, symb=None, right=False):
+        """extendLeft / extendRight of a batch of cursors.  symb = one symbol per cursor -> (lb, lb_rev, len) arrays of the same shape;
+        symb = None -> extendLeft() / extendRight() over all symbols: arrays of shape (count, Sigma)"""
+        lb, length = _u64(lb).reshape(-1), _u64(length).reshape(-1)
+        rev = _u64(lb_rev).reshape(-1) if lb_rev is not None else None
+        fan = 1 if symb is not None else self.Sigma
+        sy = None if symb is None else np.ascontiguousarray(np.broadcast_to(np.asarray(symb, dtype=np.uint8), lb.shape))
+        olb, olen = np.empty(lb.size * fan, dtype=np.uint64), np.empty(lb.size * fan, dtype=np.uint64)
+        orev = np.empty(lb.size * fan, dtype=np.uint64) if rev is not None else None
+        capi.check(capi.lib().fmgpu_cursor_extend(self._h, 1 if right else 0, lb.size, capi.ptr(lb), capi.ptr(rev), capi.ptr(length), capi.ptr(sy),
+                                                  capi.ptr(olb), capi.ptr(orev), capi.ptr(olen), None))
+        if fan > 1:
+            olb, olen = olb.reshape(-1, fan), olen.reshape(-1, fan)
+            orev = None if orev is None else orev.reshape(-1, fan)
+        return olb, orev, olen
+
     def accelerate_search(self, prefix_len=11, walk=True):
         """BiFMIndex: prefix table for the exact first part of a search + walk tables (walk: True / 1 = LF, LF^2, LF^3 per row; 2 = LF^16 with
         the 16 symbols met; 3 = both); results are unchanged"""
@@ -271,6 +306,14 @@ class search_no_errors:
                                                  C.byref(st) if want_stats else None, None))
         return (lb, ln, st) if want_stats else (lb, ln)
 
+
+    @staticmethod
+    def depth(index, queries):
+        """per query: symbols consumed until the cursor holds at most one row (length + 1: still several rows at the end)"""
+        qbuf, qoff, nq = _queries(queries)
+        out = np.empty(nq, dtype=np.uint32)
+        capi.check(capi.lib().fmgpu_search_exact_depth(index._h, capi.ptr(qbuf), capi.ptr(qoff), nq, capi.ptr(out), None))
+        return out
 
     @staticmethod
     def search_packed(index, queries, out=None, want_stats=False):

@@ -1,0 +1,140 @@
+"""The 64-bit-row build of the kernels (indices of 2^32 rows or more; the reference switches to libsais64 at 2^31 rows, utils.h:243-247),
+exercised on small inputs: FMGPU_FORCE_WIDE=1 routes a new index to it whatever its size, so every kernel of that build is compared with
+the oracle exactly like its 32-bit twin.  The test at real size (n > 2^32) is test_gpu_parity.py::test_rows_beyond_2_32."""
+import contextlib
+import os
+
+import numpy as np
+import pytest
+
+import fmoracle as fo
+import fmindex_collection_amd as fm
+from fmindex_collection_amd import capi
+from tests.util import make_text, sample_reads, oracle_arrays, string_arrays
+from tests.test_gpu_parity import LAYOUTS, same_hits, repeat_text, mutated_queries
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def force_wide():
+    old = os.environ.get("FMGPU_FORCE_WIDE")
+    os.environ["FMGPU_FORCE_WIDE"] = "1"
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop("FMGPU_FORCE_WIDE", None)
+        else:
+            os.environ["FMGPU_FORCE_WIDE"] = old
+
+
+def wide_index(ox):
+    cls = fm.BiFMIndex if ox.bidirectional else fm.FMIndex
+    with force_wide():
+        gx = cls.from_reference_arrays(**oracle_arrays(ox))
+    assert gx.row_bits == 64
+    return gx
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("sigma", [5, 28, 255])
+def test_wide_string_concept(layout, sigma):
+    for n in (1, 64, 65, 300, 1300) if sigma != 255 else (65, 300):
+        text = make_text(n, sigma, seed=n + sigma, lo=0)
+        s = fo.OraString(layout, sigma, text)
+        C_arr = np.array([int(np.count_nonzero(text < c)) for c in range(sigma + 1)], dtype=np.uint64)
+        with force_wide():
+            gx = fm.FMIndex.from_reference_arrays(bwt=string_arrays(s), C_array=C_arr)
+        assert gx.row_bits == 64
+        ork, opr = s.rank_table()
+        idx = np.repeat(np.arange(n + 1, dtype=np.uint64), sigma)
+        sym = np.tile(np.arange(sigma, dtype=np.uint8), n + 1)
+        assert np.array_equal(gx.rank(idx, sym).reshape(n + 1, sigma), ork), (layout, sigma, n)
+        assert np.array_equal(gx.prefix_rank(idx, sym).reshape(n + 1, sigma), opr), (layout, sigma, n)
+        assert np.array_equal(gx.symbol(np.arange(n, dtype=np.uint64)), text.astype(np.uint64))
+
+
+@pytest.mark.parametrize("layout,sigma", [("IB16", 5), ("IBP16", 5), ("EPR16", 5), ("EPRV2_16", 5), ("WAVELET", 5), ("WAVELET", 28), ("WAVELET", 256), ("IB16", 28), ("EPRV5", 6), ("FBV_512_64K", 21)])
+def test_wide_exact_search_and_locate(layout, sigma):
+    text = make_text(40_000, sigma, seed=3)
+    ox = fo.OraIndex.build(layout, sigma, [text[:25_000], text[25_000:]], 8, False)
+    gx = wide_index(ox)
+    reads = sample_reads(text, 3000, 24, seed=9, mutate=1, sigma=sigma)
+    qbuf, qoff = fm.flatten(reads)
+    lb, ln, st = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+    olb, oln = ox.search_exact(qbuf, qoff)
+    assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
+    rows = np.concatenate([lb[ln > 0][:500], np.arange(0, 400, dtype=np.uint64)])
+    seq, pos, steps = gx.locate(rows)
+    for k in range(0, rows.size, 7):
+        assert (seq[k], pos[k], steps[k]) == ox.locate(int(rows[k]))
+    # what only the 32-bit-row build offers says so instead of misbehaving
+    for call in (lambda: gx.accelerate(3), lambda: gx.accelerate(1, lut_len=4), lambda: gx.accelerate_locate(),
+                 lambda: fm.search_no_errors.search_packed(gx, (qbuf, qoff))):
+        with pytest.raises(fm.FmgpuError) as ei:
+            call()
+        assert ei.value.code == capi.FMGPU_ERR_UNSUPPORTED
+    if layout not in ("IB16", "IBP16", "IB16A", "FBV_512_64K", "EPRV5"):       # Format A expansion of the other layouts works in both builds
+        gx.accelerate(1)
+        lb2, ln2 = fm.search_no_errors.search(gx, (qbuf, qoff))
+        assert np.array_equal(lb2, olb) and np.array_equal(ln2, oln)
+
+
+@pytest.mark.parametrize("layout,sigma,k", [("IB16", 5, 1), ("IB16", 5, 2), ("EPRV2_16", 5, 2), ("WAVELET", 28, 1), ("IB16", 256, 1), ("IB8", 6, 2)])
+@pytest.mark.parametrize("lf", [True, False])
+def test_wide_k_mismatch_and_backtracking(layout, sigma, k, lf):
+    seqs = repeat_text(4) if sigma == 5 else [make_text(2500, sigma, seed=8), make_text(700, sigma, seed=9)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 4, True)
+    gx = wide_index(ox)
+    if not lf:
+        gx.accelerate_lf(False)
+    queries = mutated_queries(seqs, 300, 12, 40, k, seed=21, sigma=sigma)
+    qbuf, qoff = fm.flatten(queries)
+    sch = fm.search_scheme.h2(k + 2, 0, k)
+    hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True)
+    ohits, _, onodes = ox.search_ng26(qbuf, qoff, sch)
+    assert same_hits(hits, ohits) and st.lf_steps == onodes
+    few = fm.flatten(queries[:60])
+    bh = fm.search_backtracking.search(gx, few, k)
+    obh = ox.search_backtracking(few[0], few[1], k)[0]
+    assert same_hits(bh, obh)
+    with pytest.raises(fm.FmgpuError) as ei:
+        fm.search_ng26.search(gx, few, sch, edit=True)
+    assert ei.value.code == capi.FMGPU_ERR_UNSUPPORTED
+    # cursor steps
+    lb0, rev0, len0 = hits["lb"][:50], hits["lb_rev"][:50], hits["len"][:50]
+    for right in (False, True):
+        olb, orev, olen = gx.extend(lb0, rev0, len0, None, right=right)
+        for i in range(0, len(lb0), 5):
+            cur = fo.Cursor(int(lb0[i]), int(rev0[i]), int(len0[i]))
+            exp = ox.extend_right_all(cur) if right else ox.extend_left_all(cur)
+            assert [tuple(map(int, t)) for t in zip(olb[i], orev[i], olen[i])] == [(c.lb, c.lb_rev, c.len) for c in exp]
+
+
+@pytest.mark.parametrize("bidir", [False, True])
+@pytest.mark.parametrize("layout,sigma", [("IB16", 5), ("WAVELET", 28), ("IB16", 256)])
+def test_wide_gpu_builder(layout, sigma, bidir):
+    seqs = repeat_text(7, 2400) if sigma == 5 else [make_text(1800, sigma, seed=2), make_text(333, sigma, seed=3), np.zeros(0, dtype=np.uint8)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 4, bidir)
+    cls = fm.BiFMIndex if bidir else fm.FMIndex
+    with force_wide():
+        gx = cls.from_sequences(seqs, sigma, layout, 4, keep_host=True)
+    assert gx.row_bits == 64
+    n = ox.n
+    assert gx.n == n
+    assert np.array_equal(gx.built_array(0), np.array([ox.bwt_string().symbol(i) for i in range(n)], dtype=np.uint8))
+    if bidir:
+        assert np.array_equal(gx.built_array(1), np.array([ox.bwt_string(rev=True).symbol(i) for i in range(n)], dtype=np.uint8))
+    sp = ox.sparse()
+    assert np.array_equal(gx.built_array(3, np.uint64), sp["l0"]) and np.array_equal(gx.built_array(4, np.uint16), sp["l1"])
+    assert np.array_equal(gx.built_array(5, np.uint64), sp["bits"])
+    assert np.array_equal(gx.built_array(6, np.uint64), sp["fields"][0]["data"]) and np.array_equal(gx.built_array(7, np.uint64), sp["fields"][1]["data"])
+    qbuf, qoff = fm.flatten(mutated_queries([s for s in seqs if len(s) > 50], 400, 8, 30, 1, seed=5, sigma=sigma))
+    lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
+    olb, oln = ox.search_exact(qbuf, qoff)
+    assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
+    rows = np.arange(0, min(gx.n, 1500), dtype=np.uint64)
+    seq, pos, steps = gx.locate(rows)
+    for r in range(0, rows.size, 11):
+        assert (seq[r], pos[r], steps[r]) == ox.locate(int(r))
