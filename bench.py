@@ -2,26 +2,31 @@
 """bench.py — throughput of the backward-search hot path on MI355X.
 
 One "step" = one pass of the hot path over one batch of synthetic reads that are already resident in HBM.
-Default workload = BASELINE.json configs[1]: GRCh38-sized FMIndex (25 sequences with the GRCh38 chromosome
-lengths, 3.09 Gbp, sigma = 5, uniform random bases — the real assembly is not available offline), 10 M x 101 bp
-exact search.  `--workload k2` runs configs[2] (BiFMIndex, h2(4,0,2) search scheme, Hamming distance);
-`--workload protein` runs configs[4] (UniRef50 stand-in: 4 M sequences x 500 residues = 2.0e9 residues uniform in
-{1..27}, sigma = 28, FMIndex<28, Wavelet>, 10 M x 40 aa exact search).
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: launched by torch.distributed.run, one rank per GPU; the index is replicated, every rank searches its own
-batch (weak scaling: per-GPU work fixed), and the resulting SA intervals are gathered to rank 0 over RCCL inside
-the timed region — the path's only exchange step.  Result buffers are double-buffered so that the gather of step i
-crosses xGMI while the kernel of step i+1 runs; the last gather is drained before the closing barrier.
+Headline (`value`) = BASELINE.json configs[1]: exact search (search_no_errors) of 10 M x 101 bp reads on a GRCh38-sized FMIndex (25 sequences with
+the GRCh38 chromosome lengths, 3.09 Gbp, sigma = 5), all optional tables on.  The text is the repeat-structured stand-in of
+fmindex-collection_amd/datasets.py (45 % interspersed repeats, satellites, 5 % runs of one symbol) — or the real assembly when FMGPU_FASTA=<path> names
+one (reference loader rule, src/example/utils.h:86-98: unknown bases -> A).  The uniform-random text of SURVEY 8d-2 is measured next to it.
 
-At N = 1 the default run appends `secondary`: the k = 2 workload measured in a child process before this one touches the GPU
-(BASELINE.json's metric names exact AND k = 2; `value` stays the exact figure).
+At N = 1 the default run measures, one after the other in this process, for each text (`records`, every one driver-timed in the same run):
+    exact / plain     k_exact_a on the bit-packed occurrence table alone (3.1 GB — the index north_star describes); roofline by SURVEY 8d:
+                      executed LF steps x 112 B (2 x sizeof(InterleavedBitvector16<5>::Block)) / kernel time / 8 TB/s
+    exact / tables    k_exact_kstep with the interval, k-step and walk tables (the headline); roofline by what the kernel really loads:
+                      (table bytes it counted + query bytes + result bytes) / kernel time / 8 TB/s, and the same at one 128-byte line per access
+    k2 / plain        search_ng26<Hamming>, h2(4,0,2), on the two occurrence tables alone (6.2 GB); visited nodes x 112 B
+    k2 / tables       the same with LF, prefix and walk tables
+plus configs[3]'s single-GPU share (k = 2, 12.5 M x 151 bp) and configs[4] (protein, sigma = 28, FMIndex<28, Wavelet>, 10 M x 40 aa: the
+multi-ary wavelet tree itself at 170 B per LF step, and its block-table expansion with tables).
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (executed LF steps x
-2 x sizeof(InterleavedBitvector16<5>::Block) = 112 B) / the search kernel's launch duration, measured with HIP
-events on the launch stream inside the C-ABI.  `cpu_baseline` = the CPU restatement (oracle/, parity-pinned) on
-the host cores over a bounded sample of the same reads.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the index is replicated (every rank builds the same seeded text), the query batch is
+sharded, the only exchange is the RCCL gather of the results to rank 0 inside the timed region (double-buffered: the gather of step i crosses xGMI
+while the kernel of step i+1 runs).  `value` = exact search, 10 M reads PER RANK (weak scaling: per-GPU work fixed); `secondary` = configs[3]:
+k = 2 Hamming, 151 bp, partition {38,38,38,37}, 100 M reads in total sharded 100 M / N per rank (strong scaling), 16-byte packed hits gathered.
+
+Prints ONE JSON line (rank 0).  `cpu_baseline` = the CPU restatement (oracle/, parity-pinned) on the host cores over a bounded sample of the same
+reads, NUMA-spread and thread-bound; it is a reported baseline, not the target.
 """
 import argparse
 import json
@@ -37,13 +42,9 @@ GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 1708059
                   58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569]
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BLOCK_BYTES_IB16_S5 = 56       # sizeof(InterleavedBitvector16<5>::Block), SURVEY.md appendix B
-NOTE_DNA = ("unit = executed LF step (exact) / visited node (k=2), identical to the CPU walk; bytes_per_unit = 2 x sizeof(InterleavedBitvector16<5>::Block) "
-            "of the reference layout (SURVEY 8d). The tables serve many LF steps per touched line (12 from the interval table, 3 per k-step entry, 16 per "
-            "walk entry), so algorithmic bytes exceed the traffic; see line_rate for the hardware bound")
-NOTE_PROTEIN = ("unit = executed LF step, identical to the CPU walk; bytes_per_unit = 2 ends x 5 levels x (8 + 1 + 8) B the reference's Wavelet rank reads "
-                "(SURVEY 8d). The expanded block table answers a step from one 12-byte entry per end and the walk table 6 steps per entry, so algorithmic bytes exceed the traffic; see "
-                "line_rate for the hardware bound")
-PROTEIN_SEQS, PROTEIN_SEQ_LEN = 4_000_000, 500      # UniRef50 stand-in (the release itself is not available offline): 2.0e9 residues
+BYTES_PER_STEP_DNA = 2 * BLOCK_BYTES_IB16_S5          # both interval ends
+BYTES_PER_STEP_WAVELET28 = 2 * 5 * 17                 # 2 ends x 5 levels x (8 + 1 + 8) B
+PROTEIN_SEQS, PROTEIN_SEQ_LEN = 4_000_000, 500        # UniRef50 stand-in (the release itself is not available offline): 2.0e9 residues
 
 
 def parse():
@@ -51,361 +52,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="exact", choices=["exact", "k2", "protein"])
+    ap.add_argument("--texts", default="", help="comma list of genome, uniform (default: genome,uniform at N = 1, genome at N > 1; FMGPU_FASTA replaces genome)")
+    ap.add_argument("--only", default="", help="comma list of record ids to measure (text/workload/index, e.g. genome/exact/plain); default: all of the run")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the text (dev runs only; the judged run uses 1.0)")
     ap.add_argument("--nq", type=int, default=10_000_000)
-    ap.add_argument("--read-len", type=int, default=0, help="0 = the workload's own (101 bp, 40 aa)")
-    ap.add_argument("--kstep", type=int, default=-1, help="exact search: symbols per table step (fmgpu_index_accelerate); 1 = plain occurrence table; "
-                    "protein: 1 = block-table expansion of the wavelet (default), 0 = search the wavelet lines themselves")
-    ap.add_argument("--no-search-accel", action="store_true", help="k2: no prefix / walk tables (fmgpu_index_accelerate_search)")
-    ap.add_argument("--no-exact-tables", action="store_true", help="exact / protein: only the k-step table (no suffix-interval table, no walk table)")
-    ap.add_argument("--lut-len", type=int, default=0, help="exact / protein: symbols of the interval table (0 = 15 bp / 6 aa)")
-    ap.add_argument("--walk", type=int, default=2, help="exact / protein: 1 = LF^J walk table, 2 = LF^J and LF^2J")
-    ap.add_argument("--prefix-len", type=int, default=16, help="k2: symbols of the prefix table (fmgpu_index_accelerate_search)")
-    ap.add_argument("--trim", type=int, default=0, help="dev: every read loses 0..TRIM symbols at its end (a ragged batch)")
-    ap.add_argument("--single-rank-collectives", action="store_true", help="rehearsal only: run the N > 1 code path (process group, asynchronous gather, barrier) with one rank")
-    ap.add_argument("--sub-every", type=int, default=10, help="exact / protein: every n-th read carries one substitution (default 10 = SURVEY 8d; 0 = none; a dev knob)")
-    ap.add_argument("--ng21", action="store_true", help="k2: search_ng21 over expand(h2(4,0,2), read length) (edit distance; the reference's older algorithm) — a side measurement")
-    ap.add_argument("--edit", action="store_true", help="k2: edit distance (search_ng26<Edit = true>) instead of Hamming distance")
+    ap.add_argument("--lut-len", type=int, default=15, help="exact tables: symbols of the interval table")
+    ap.add_argument("--prefix-len", type=int, default=16, help="k2 tables: symbols of the prefix table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="default run at N = 1: do not append the k = 2 measurement (BASELINE's metric names exact AND k = 2)")
+    ap.add_argument("--no-protein", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto, ~15 s of CPU work)")
+    ap.add_argument("--single-rank-collectives", action="store_true", help="rehearsal only: run the N > 1 code path (process group, asynchronous gather, barrier) with one rank")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="rehearsal only: gloo runs the N > 1 control flow where RCCL cannot (all ranks on one card); results travel through host memory")
     ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal only: every rank uses GPU 0")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--total-k2-reads", type=int, default=100_000_000, help="N > 1: reads of the configs[3] leg in total (sharded over the ranks)")
     return ap.parse_args()
-
-
-def main():
-    args = parse()
-    if args.ng21:                                             # a side measurement: no CPU leg (the restatement of search_ng21 is single-threaded), no second workload
-        args.no_cpu_baseline = True
-        args.no_secondary = True
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    secondary = None
-    if world == 1 and args.workload == "exact" and not args.no_secondary and args.scale == 1.0 and args.nq == 10_000_000 and args.trim == 0:
-        # the metric's second half — k = 2 Hamming on the same text — in a child process of its own, BEFORE this process touches the GPU (the two
-        # indices do not fit the HBM together, and a GPU-initialised process must not start other programs); never part of `value`
-        import subprocess
-        try:
-            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "k2", "--steps", str(args.steps), "--warmup", str(args.warmup),
-                                    "--no-cpu-baseline"] + (["--read-len", str(args.read_len)] if args.read_len else []),
-                                   capture_output=True, text=True, timeout=600)
-            line = [l for l in child.stdout.splitlines() if l.startswith("{")]
-            if child.returncode == 0 and line:
-                k2 = json.loads(line[-1])
-                secondary = {k: k2[k] for k in ("metric", "value", "unit", "ms_per_step", "gbp_per_s", "hits", "config", "roofline") if k in k2}
-            else:
-                secondary = {"error": (child.stderr or child.stdout)[-400:]}
-        except Exception as ex:                                  # the primary measurement stands on its own
-            secondary = {"error": repr(ex)}
-    import numpy as np
-    import torch
-    import fmindex_collection_amd as fm
-    from fmindex_collection_amd import capi
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    if args.all_ranks_device0:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    capi.check(capi.lib().fmgpu_set_device(local_rank))
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    multi = world > 1 or args.single_rank_collectives         # (dev: the N > 1 control flow and its RCCL calls with a group of one rank)
-    if multi:
-        import torch.distributed as dist
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
-
-    # ---------------------------------------------------------------- synthetic inputs, generated in HBM
-    protein = args.workload == "protein"
-    sigma, layout = (28, "WAVELET") if protein else (5, "IB16")
-    if not args.read_len:
-        args.read_len = 40 if protein else 101
-    if protein:
-        lengths = [PROTEIN_SEQ_LEN] * max(1, int(PROTEIN_SEQS * args.scale))
-    else:
-        lengths = [max(1, int(l * args.scale)) for l in GRCH38_LENGTHS]
-    total = sum(lengths)
-    g = torch.Generator(device=dev)
-    g.manual_seed(42)
-    text = torch.empty(total, dtype=torch.uint8, device=dev)
-    chunk = 1 << 28
-    for lo in range(0, total, chunk):                         # bases uniform in {1..4}; 0 is the delimiter
-        hi = min(total, lo + chunk)
-        text[lo:hi] = torch.randint(1, sigma, (hi - lo,), generator=g, device=dev, dtype=torch.uint8)
-    seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64))])).to(dev)
-    L, nq = args.read_len, args.nq
-    gq = torch.Generator(device=dev)
-    gq.manual_seed(1000 + rank)                               # every rank searches its own batch
-    # reads = substrings of a random chromosome-internal position (so every unmutated read has >= 1 hit)
-    if protein:                                               # inside one sequence: 500-residue entries are short next to the read
-        starts = (torch.randint(0, len(lengths), (nq,), generator=gq, device=dev, dtype=torch.int64) * PROTEIN_SEQ_LEN +
-                  torch.randint(0, PROTEIN_SEQ_LEN - L + 1, (nq,), generator=gq, device=dev, dtype=torch.int64))
-    else:
-        starts = torch.randint(0, total - L, (nq,), generator=gq, device=dev, dtype=torch.int64)
-    reads = torch.empty((nq, L), dtype=torch.uint8, device=dev)
-    ar = torch.arange(L, device=dev, dtype=torch.int64)
-    for lo in range(0, nq, 1 << 20):
-        hi = min(nq, lo + (1 << 20))
-        reads[lo:hi] = text[starts[lo:hi, None] + ar[None, :]]
-    if args.workload != "k2":                                 # 10 % of the reads carry one substitution (early exits)
-        rows = torch.arange(0, nq, args.sub_every, device=dev) if args.sub_every > 0 else torch.arange(0, 0, device=dev)
-        nsub = torch.ones_like(rows)
-    else:                                                     # 0 / 1 / 2 substitutions in ratio 1:1:1
-        rows = torch.arange(0, nq, device=dev)
-        nsub = rows % 3
-    for k in range(2):
-        sel = rows[nsub > k]
-        pos = torch.randint(0, L, (sel.numel(),), generator=gq, device=dev)
-        shift = torch.randint(1, sigma - 1, (sel.numel(),), generator=gq, device=dev, dtype=torch.uint8)
-        reads[sel, pos] = (reads[sel, pos] - 1 + shift) % (sigma - 1) + 1
-    if args.trim > 0:
-        lens = L - torch.randint(0, args.trim + 1, (nq,), generator=gq, device=dev, dtype=torch.int64)
-        qbuf = reads[ar[None, :] < lens[:, None]].contiguous()
-        qoff = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(lens, 0)])
-    else:
-        qbuf = reads.reshape(-1)
-        qoff = (torch.arange(nq + 1, device=dev, dtype=torch.int64) * L)
-    torch.cuda.synchronize()
-
-    # ---------------------------------------------------------------- index construction on the GPU (not timed as a step)
-    bidir = args.workload == "k2"
-    want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
-    t0 = time.time()
-    cls = fm.BiFMIndex if bidir else fm.FMIndex
-    index = cls.from_sequences((_Dev(text), _Dev(seq_off)), sigma, layout, 16, keep_host=want_cpu)
-    if args.kstep < 0:
-        args.kstep = 1 if protein else 3
-    if not bidir and args.kstep >= 1 and (not args.no_exact_tables or args.kstep > 1 or protein):
-        if args.no_exact_tables:
-            index.accelerate(args.kstep)
-        else:                                                   # + interval table of the last 15 bp / 6 aa, + per-row LF^J walk table (J = 16 bp / 6 aa)
-            index.accelerate(args.kstep, lut_len=args.lut_len or (6 if protein else 15), walk=args.walk)
-    if bidir and not args.no_search_accel:
-        try:
-            index.accelerate_search(args.prefix_len, 3)
-        except fm.FmgpuError as ex:                            # (the 16-symbol table is 69 GB: should the card be short of memory, one symbol less)
-            if args.prefix_len < 16:
-                raise
-            print("bench.py: %s; retrying with a 15-symbol prefix table" % ex, file=sys.stderr, flush=True)
-            args.prefix_len = 15
-            index.accelerate_search(args.prefix_len, 3)
-    build_s = time.time() - t0
-    if not want_cpu:
-        del text
-    torch.cuda.empty_cache()
-
-    # results are double-buffered: the gather of step i travels over xGMI while the kernel of step i+1 runs
-    outs = [torch.empty(2 * nq, dtype=torch.int64, device=dev) for _ in range(2 if multi else 1)]   # [lb | len], one buffer so that the gather sends it as is
-    scheme = fm.search_scheme.h2(4, 0, 2)
-    hit_cap = (16 if (args.edit or args.ng21) else 4) * nq
-    ex21 = None
-    if args.ng21:
-        import numpy as np
-        if args.trim > 0 or not bidir:
-            raise SystemExit("--ng21 needs --workload k2 and equal-length reads")
-        args.edit = True
-        arrs = tuple(np.ascontiguousarray(a, dtype=np.uint64) for a in fm.search_scheme.expand(scheme, L))
-        ex = capi.ExpandedScheme()
-        ex.n_searches, ex.length = arrs[0].shape
-        ex.pi, ex.l, ex.u = (a.ctypes.data_as(capi.u64p) for a in arrs)
-        ex21 = (ex, arrs)
-    hits_bufs = [torch.empty(hit_cap * 40, dtype=torch.uint8, device=dev) for _ in range(2 if multi else 1)] if bidir else None
-    via_host = multi and args.dist_backend == "gloo"
-    count_dev = torch.zeros(1, dtype=torch.int64, device="cpu" if via_host else dev)
-    packed = [torch.empty(nq, dtype=torch.int64, device=dev) for _ in range(2)] if (multi and not bidir) else None
-    # k = 2: a hit travels as 16 bytes — qidx:32 | lb:32, len:32 | errors:8 | seq:24 (rows and batch sizes are < 2^32; lbRev stays on the rank that
-    # found the hit: it only serves further extension) — instead of the 40-byte record of the C-ABI
-    packed_hits = [torch.empty((2 * nq, 2), dtype=torch.int64, device=dev) for _ in range(2)] if (multi and bidir) else None
-    gathered = None
-    if multi and rank == 0:                               # k=2 messages are sized per step (largest hit count over the ranks), at most 2*nq records
-        full = 2 * nq * (16 if bidir else 8)
-        gathered = [[torch.empty(full, dtype=torch.uint8, device="cpu" if via_host else dev) for _ in range(world)] for _ in range(2)]
-
-    import ctypes as C
-    stats = capi.Stats()
-    kernel_ms, units = [], []
-    pending = [None, None]
-    state = {"i": 0, "out": outs[0]}
-
-    def step():
-        b = state["i"] % len(outs)
-        state["i"] += 1
-        if pending[b] is not None:                             # the buffer's previous gather must have left before it is overwritten
-            pending[b].wait(); pending[b] = None
-        out = outs[b]
-        state["out"] = out
-        if not bidir and multi:                               # N > 1: the kernel writes the 8-byte transport word (lb << 32 | len) itself
-            capi.check(capi.lib().fmgpu_search_exact_packed(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
-                                                            C.c_void_p(packed[b].data_ptr()), C.byref(stats), None))
-        elif not bidir:
-            capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
-                                                     C.c_void_p(out[:nq].data_ptr()), C.c_void_p(out[nq:].data_ptr()),
-                                                     C.byref(stats), None))
-        elif args.ng21:
-            cnt = C.c_uint64()
-            capi.check(capi.lib().fmgpu_search_ng21(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
-                                                    C.byref(ex21[0]), capi.UINT64_MAX, C.c_void_p(hits_bufs[b].data_ptr()), hit_cap,
-                                                    C.byref(cnt), C.byref(stats), None))
-        else:
-            sc = _scheme_struct(capi, scheme)
-            sc[0].edit = 1 if args.edit else 0
-            cnt = C.c_uint64()
-            capi.check(capi.lib().fmgpu_search_scheme(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
-                                                      C.byref(sc[0]), capi.UINT64_MAX, C.c_void_p(hits_bufs[b].data_ptr()), hit_cap,
-                                                      C.byref(cnt), C.byref(stats), None))
-        kernel_ms.append(stats.kernel_ms)
-        units.append(stats.lf_steps)
-        if multi:                                          # the path's one exchange: SA intervals to rank 0 over RCCL/xGMI
-            if bidir:
-                count_dev.fill_(int(cnt.value))
-                dist.all_reduce(count_dev, op=dist.ReduceOp.MAX)
-                m = (int(count_dev.item()) + 65535) // 65536 * 65536
-                if m > 2 * nq:
-                    raise SystemExit("more than 2 hits per read on average: raise the gather buffers")
-                capi.check(capi.lib().fmgpu_hits_pack16(C.c_void_p(hits_bufs[b].data_ptr()), int(cnt.value), C.c_void_p(packed_hits[b].data_ptr()), None))
-                payload = packed_hits[b][:m].view(torch.uint8).view(-1)
-            else:                                              # (lb, len) as one 64-bit word per read: rows are < 2^32, 80 MB per rank instead of 160
-                payload = packed[b].view(torch.uint8)
-            if via_host:
-                payload = payload.cpu()
-            state["payload"], state["b"] = payload, b
-            pending[b] = exchange(payload, b)
-
-    xch = {"mode": "gather", "bufs": [None, None]}
-
-    def exchange(payload, b):
-        """SA intervals / hit records to rank 0.  torch.distributed.gather (grouped send/recv in RCCL) is the exchange the path needs; should this
-        build refuse it, every rank switches to all_gather_into_tensor — more bytes over xGMI, same information on rank 0"""
-        if xch["mode"] == "gather":
-            try:
-                return dist.gather(payload, [g[: payload.numel()] for g in gathered[b]] if rank == 0 else None, dst=0, async_op=True)
-            except (RuntimeError, NotImplementedError, ValueError) as ex:
-                xch["mode"] = "all_gather"
-                if rank == 0:
-                    print("bench.py: dist.gather unavailable (%s); using all_gather_into_tensor" % ex, file=sys.stderr, flush=True)
-        need = world * payload.numel()
-        if xch["bufs"][b] is None or xch["bufs"][b].numel() < need:
-            xch["bufs"][b] = torch.empty(need, dtype=torch.uint8, device=payload.device)
-        return dist.all_gather_into_tensor(xch["bufs"][b][:need], payload, async_op=True)
-
-    def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait(); pending[b] = None
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    kernel_ms.clear(); units.clear()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    gather_ok = None
-    if multi:                                             # outside the timed region: rank 0 holds what every rank sent in the last step
-        pl = state["payload"]
-        chk = pl.view(torch.int64).sum().reshape(1).to(count_dev.device)
-        sums = [torch.zeros_like(chk) for _ in range(world)]
-        dist.all_gather(sums, chk)
-        if rank == 0:
-            b = state["b"]
-            if xch["mode"] == "gather":
-                got = [gathered[b][r][: pl.numel()].view(torch.int64).sum().item() for r in range(world)]
-            else:
-                got = [xch["bufs"][b][r * pl.numel(): (r + 1) * pl.numel()].view(torch.int64).sum().item() for r in range(world)]
-            gather_ok = got == [int(x.item()) for x in sums]
-            if not gather_ok:
-                raise SystemExit("bench.py: the gathered intervals on rank 0 differ from what the ranks sent")
-    if rank != 0:
-        if multi:
-            dist.destroy_process_group()
-        return
-    ms_per_step = elapsed / args.steps * 1e3
-    qps = world * nq * args.steps / elapsed
-    k_ms = sum(kernel_ms) / len(kernel_ms)
-    steps_per_launch = sum(units) / len(units)
-    unit_bytes = 2 * 5 * 17 if protein else 2 * BLOCK_BYTES_IB16_S5      # SURVEY 8d: Wavelet 2 x levels x (8 + 1 + 8) B per LF step
-    alg_bytes = steps_per_launch * unit_bytes
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    out_lb, out_len = state["out"][:nq], state["out"][nq:]
-    if multi and not bidir:                                   # the last step's transport words, taken apart again
-        w = packed[state["b"]]
-        out_lb, out_len = (w >> 32) & 0xffffffff, w & 0xffffffff
-    hits = int((out_len > 0).sum().item()) if not bidir else int(stats.hits)
-    traffic, lines = None, None                               # HBM bytes / line requests per launch from the committed PMC passes
-    try:
-        tall = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if protein:
-            key = "protein_exact_wavelet_lines" if not args.kstep else ("protein_exact_block_table_only" if args.no_exact_tables else "protein_exact")
-        elif bidir:
-            key = "grch38_k2_ng21" if args.ng21 else "grch38_k2_edit" if args.edit else "grch38_k2"
-        elif args.no_exact_tables:
-            key = "grch38_exact_kstep3_only" if args.kstep == 3 else "grch38_exact_kstep%d" % args.kstep
-        else:
-            key = "grch38_exact" if args.kstep == 3 else "grch38_exact_kstep%d_tables" % args.kstep
-        tj = tall[key]
-        if args.scale == 1.0 and nq == 10_000_000 and L == (40 if protein else 101):
-            traffic, lines = tj["bytes_per_launch"], tj["line_requests_per_launch"]
-            ceiling = tall["_random_line_ceiling_G_per_s"]["value"]
-    except Exception:
-        traffic, lines = None, None
-    result = {
-        "metric": ("queries/sec (sigma=28 protein index, 10M x 40aa, exact, Wavelet)" if protein else
-                   "queries/sec (GRCh38-sized index, 10M x 101bp, %s)" % ("exact" if not bidir else ("k=2 edit distance, search_ng21 over expand(h2(4,0,2))" if args.ng21 else "k=2 edit distance, h2(4,0,2)" if args.edit else "k=2 Hamming, h2(4,0,2)"))),
-        "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "protein_exact" if protein else "grch38_%s" % ("exact" if not bidir else ("k2_ng21" if args.ng21 else "k2_edit" if args.edit else "k2")), "text_symbols": total, "sequences": len(lengths),
-                   "sigma": sigma, "layout": "Wavelet" if protein else "InterleavedBitvector16", "queries_per_gpu": nq, "read_len": L,
-                   "index": "BiFMIndex" if bidir else "FMIndex", "scale": args.scale, "prefix_table_symbols": (args.prefix_len if bidir and not args.no_search_accel else None), "kstep_table": (args.kstep if not bidir else 1),
-                   "device_table": ("block table expanded from the wavelet" if args.kstep else "wavelet lines") if protein else "block table",
-                   "exact_tables": None if (bidir or args.no_exact_tables or (protein and not args.kstep)) else {"suffix_interval_symbols": args.lut_len or (6 if protein else 15), "walk_symbols_per_load": (6 if protein else 16) * (2 if args.walk >= 2 else 1)},
-                   "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
-        "gbp_per_s": qps * L / 1e9,
-        "hits": hits,
-        **({"exchange": {"collective": xch["mode"], "bytes_per_rank_and_step": int(state["payload"].numel()), "verified_on_rank0": gather_ok,
-                         "record": "16 B per hit (qidx:32 | lb:32, len:32 | errors:8 | seq:24)" if bidir else "8 B per read (lb:32 | len:32)"}} if multi else {}),
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": (("k_exact_a" if args.no_exact_tables else "k_exact_kstep") if args.kstep else "k_exact_w") if protein else ("k_exact_kstep" if (args.kstep > 1 or not args.no_exact_tables) else "k_exact_a") if not bidir else ("k_ng21" if args.ng21 else "k_scheme_fast_edit" if args.edit else "k_scheme_fast"), "kernel_ms": k_ms,
-                     "units_per_launch": steps_per_launch, "bytes_per_unit": unit_bytes,
-                     "unit": "GB/s", "note": NOTE_PROTEIN if protein else NOTE_DNA},
-    }
-    if traffic is not None:                                   # the PMC-measured bytes of the same launch against the same peak
-        result["roofline"]["traffic_rate"] = {"achieved": traffic / (k_ms * 1e-3) / 1e9, "unit": "GB/s", "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                              "what": "measured HBM bytes per launch (profiles/traffic.json: FETCH_SIZE x 2 + WRITE_SIZE) / this run's kernel time"}
-    if lines is not None:
-        result["roofline"]["line_rate"] = {"achieved_G_per_s": lines / (k_ms * 1e-3) / 1e9, "ceiling_G_per_s": ceiling,
-                                           "frac": lines / (k_ms * 1e-3) / 1e9 / ceiling,
-                                           "what": "L2->fabric 128-byte line requests per second (TCC_EA0_RDREQ) vs the measured ceiling for dependent random line reads"}
-    if want_cpu:
-        hit_q = None
-        if bidir and not multi:                               # query numbers of the last step's hit records: their counts per query are compared with the CPU walk's
-            hit_q = hits_bufs[0][: int(stats.hits) * 40].view(torch.int64).view(-1, 5)[:, 0]
-        result["cpu_baseline"] = cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, args.cpu_sample, out_lb, out_len, layout, sigma, args.edit, hit_q)
-    if secondary is not None:
-        result["secondary"] = secondary
-    print(json.dumps(result), flush=True)
-    if multi:
-        dist.destroy_process_group()
 
 
 class _Dev:
@@ -417,6 +78,468 @@ class _Dev:
         self.nbytes = t.numel() * t.element_size()
 
 
+class Ctx:
+    pass
+
+
+def main():
+    args = parse()
+    # the CPU leg's OpenMP team: one thread per core, spread over the sockets — must be in the environment before the OpenMP runtime starts
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+    import fmindex_collection_amd as fm
+    from fmindex_collection_amd import capi, datasets
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.all_ranks_device0:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    capi.check(capi.lib().fmgpu_set_device(local_rank))
+    c = Ctx()
+    c.args, c.rank, c.world, c.np, c.torch, c.fm, c.capi, c.datasets = args, rank, world, np, torch, fm, capi, datasets
+    c.dev = torch.device("cuda", local_rank)
+    c.multi = world > 1 or args.single_rank_collectives      # (dev: the N > 1 control flow and its RCCL calls with a group of one rank)
+    c.dist = None
+    if c.multi:
+        import torch.distributed as dist
+        c.dist = dist
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=c.dev)
+        else:
+            dist.init_process_group("gloo")
+    c.via_host = c.multi and args.dist_backend == "gloo"
+    c.only = set(x for x in args.only.split(",") if x)
+    c.traffic = {}
+    try:
+        c.traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+    except Exception:
+        pass
+
+    fasta = os.environ.get("FMGPU_FASTA")
+    texts = [t for t in args.texts.split(",") if t] or (["genome"] if c.multi else ["genome", "uniform"])
+    if fasta:
+        texts = ["fasta" if t == "genome" else t for t in texts]
+    records = []
+    for name in texts:
+        records += run_dna_text(c, name, primary=(name == texts[0]))
+    if not c.multi and not args.no_protein and args.scale == 1.0 and (not c.only or any(o.startswith("protein") for o in c.only)):
+        records += run_protein(c)
+    if rank != 0:
+        if c.multi:
+            c.dist.destroy_process_group()
+        return
+    records = [r for r in records if r is not None]
+    if not records:
+        raise SystemExit("bench.py: nothing was measured (check --only)")
+    head = next((r for r in records if r["id"].endswith("/exact/tables")), records[0])
+    line = dict(head)
+    line.pop("id")
+    rest = [r for r in records if r is not head]
+    if c.multi:
+        sec = next((r for r in rest if "/k2_151/" in r["id"]), None)
+        if sec is not None:
+            line["secondary"] = sec
+            rest = [r for r in rest if r is not sec]
+    line["records"] = rest
+    print(json.dumps(line), flush=True)
+    if c.multi:
+        c.dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------- inputs
+def make_text(c, name):
+    torch, np = c.torch, c.np
+    lengths = [max(1, int(l * c.args.scale)) for l in GRCH38_LENGTHS]
+    info = {"text": name}
+    if name == "fasta":
+        sym, off = c.datasets.load_fasta(os.environ["FMGPU_FASTA"])
+        text = torch.from_numpy(sym).to(c.dev)
+        lengths = np.diff(off).tolist()
+        info.update({"source": os.environ["FMGPU_FASTA"], "rule": "src/example/utils.h:86-98 with --convertUnknownChar: unknown bases -> rank 1 (A)"})
+    elif name == "genome":
+        text, st = c.datasets.genome_like_text(lengths, seed=42, device=c.dev)
+        info.update({"generator": "fmindex-collection_amd/datasets.py genome_like_text(seed=42)", **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}})
+    elif name == "uniform":
+        total = sum(lengths)
+        g = torch.Generator(device=c.dev)
+        g.manual_seed(42)
+        text = torch.empty(total, dtype=torch.uint8, device=c.dev)
+        for lo in range(0, total, 1 << 28):
+            hi = min(total, lo + (1 << 28))
+            text[lo:hi] = torch.randint(1, 5, (hi - lo,), generator=g, device=c.dev, dtype=torch.uint8)
+        info.update({"generator": "uniform bases in {1..4}, torch generator seed 42 (SURVEY 8d-2's stand-in)"})
+    else:
+        raise SystemExit("unknown text %r" % name)
+    seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64))])).to(c.dev)
+    info["symbols"] = int(text.numel()); info["sequences"] = len(lengths)
+    return text, seq_off, lengths, info
+
+
+def sample_reads(c, text, lengths, L, nq, seed, mode, sigma=5, inside=None):
+    """reads copied from the text; mode 'exact': every 10th read carries one substitution (early exits), 'k2': 0 / 1 / 2 substitutions in ratio 1:1:1"""
+    torch = c.torch
+    total = text.numel()
+    gq = torch.Generator(device=c.dev)
+    gq.manual_seed(seed)
+    if inside is not None:                                    # protein: inside one entry (500-residue entries are short next to the read)
+        nseq, slen = inside
+        starts = (torch.randint(0, nseq, (nq,), generator=gq, device=c.dev, dtype=torch.int64) * slen +
+                  torch.randint(0, slen - L + 1, (nq,), generator=gq, device=c.dev, dtype=torch.int64))
+    else:
+        starts = torch.randint(0, total - L, (nq,), generator=gq, device=c.dev, dtype=torch.int64)
+    reads = torch.empty((nq, L), dtype=torch.uint8, device=c.dev)
+    ar = torch.arange(L, device=c.dev, dtype=torch.int64)
+    for lo in range(0, nq, 1 << 20):
+        hi = min(nq, lo + (1 << 20))
+        reads[lo:hi] = text[starts[lo:hi, None] + ar[None, :]]
+    if mode == "exact":
+        rows = torch.arange(0, nq, 10, device=c.dev)
+        nsub = torch.ones_like(rows)
+    else:
+        rows = torch.arange(0, nq, device=c.dev)
+        nsub = rows % 3
+    for k in range(2):
+        sel = rows[nsub > k]
+        pos = torch.randint(0, L, (sel.numel(),), generator=gq, device=c.dev)
+        shift = torch.randint(1, sigma - 1, (sel.numel(),), generator=gq, device=c.dev, dtype=torch.uint8)
+        reads[sel, pos] = (reads[sel, pos] - 1 + shift) % (sigma - 1) + 1
+    qbuf = reads.reshape(-1)
+    qoff = torch.arange(nq + 1, device=c.dev, dtype=torch.int64) * L
+    return qbuf, qoff
+
+
+def wanted(c, rid):
+    return not c.only or rid in c.only
+
+
+# ---------------------------------------------------------------------------------------------------------------- timing
+def timed(c, step, drain=None):
+    """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; returns (seconds [max over ranks], per-step stats)"""
+    torch, args = c.torch, c.args
+    log = []
+    for _ in range(args.warmup):
+        step(log)
+    if drain:
+        drain()
+    log.clear()
+    if c.multi:
+        c.dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(log)
+    if drain:
+        drain()
+    if c.multi:
+        c.dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if c.multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if c.via_host else c.dev)
+        c.dist.all_reduce(t, op=c.dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, log
+
+
+class Exchange:
+    """the path's one exchange: results to rank 0 over RCCL/xGMI (torch.distributed.gather = grouped send/recv), double-buffered"""
+
+    def __init__(self, c, max_bytes):
+        self.c, self.mode, self.pending, self.bufs = c, "gather", [None, None], [None, None]
+        self.gathered = None
+        if c.rank == 0:
+            self.gathered = [[c.torch.empty(max_bytes, dtype=c.torch.uint8, device="cpu" if c.via_host else c.dev) for _ in range(c.world)] for _ in range(2)]
+        self.last = None
+
+    def wait(self, b):
+        if self.pending[b] is not None:
+            self.pending[b].wait(); self.pending[b] = None
+
+    def send(self, payload, b):
+        c, dist = self.c, self.c.dist
+        if c.via_host:
+            payload = payload.cpu()
+        self.last = (payload, b)
+        if self.mode == "gather":
+            try:
+                self.pending[b] = dist.gather(payload, [g[: payload.numel()] for g in self.gathered[b]] if c.rank == 0 else None, dst=0, async_op=True)
+                return
+            except (RuntimeError, NotImplementedError, ValueError) as ex:   # should this build refuse it: all_gather — more bytes over xGMI, same information on rank 0
+                self.mode = "all_gather"
+                if c.rank == 0:
+                    print("bench.py: dist.gather unavailable (%s); using all_gather_into_tensor" % ex, file=sys.stderr, flush=True)
+        need = c.world * payload.numel()
+        if self.bufs[b] is None or self.bufs[b].numel() < need:
+            self.bufs[b] = c.torch.empty(need, dtype=c.torch.uint8, device=payload.device)
+        self.pending[b] = dist.all_gather_into_tensor(self.bufs[b][:need], payload, async_op=True)
+
+    def drain(self):
+        for b in range(2):
+            self.wait(b)
+
+    def verify(self):
+        """outside the timed region: rank 0 holds what every rank sent in the last step (a checksum per rank)"""
+        c, torch, dist = self.c, self.c.torch, self.c.dist
+        pl, b = self.last
+        n8 = pl.numel() // 8 * 8
+        chk = pl[:n8].view(torch.int64).sum().reshape(1).to("cpu" if c.via_host else c.dev)
+        sums = [torch.zeros_like(chk) for _ in range(c.world)]
+        dist.all_gather(sums, chk)
+        if c.rank != 0:
+            return None
+        if self.mode == "gather":
+            got = [self.gathered[b][r][:n8].view(torch.int64).sum().item() for r in range(c.world)]
+        else:
+            got = [self.bufs[b][r * pl.numel(): r * pl.numel() + n8].view(torch.int64).sum().item() for r in range(c.world)]
+        ok = got == [int(x.item()) for x in sums]
+        if not ok:
+            raise SystemExit("bench.py: the gathered results on rank 0 differ from what the ranks sent")
+        return ok
+
+
+def roofline_sec8d(units, bytes_per_unit, k_ms, kernel, what):
+    ach = units * bytes_per_unit / (k_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "kernel": kernel, "kernel_ms": k_ms, "units_per_launch": units, "bytes_per_unit": bytes_per_unit,
+            "accounting": "SURVEY 8d: executed " + what + " x bytes_per_unit of the reference layout / kernel time (HIP events on the launch stream)"}
+
+
+def roofline_loaded(st, coalesced_bytes, k_ms, kernel, units, what):
+    """the table-driven kernels: what they actually asked of the memory system, counted by the kernel itself (fmgpu_stats)"""
+    tb, ta = float(st["table_bytes"]), float(st["table_accesses"])
+    ach = (tb + coalesced_bytes) / (k_ms * 1e-3) / 1e9
+    line = (ta * 128.0 + coalesced_bytes) / (k_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "kernel": kernel, "kernel_ms": k_ms, "units_per_launch": units,
+            "bytes_per_launch": {"table_entries": tb, "table_accesses": ta, "queries_and_results": coalesced_bytes},
+            "line_granular": {"achieved": line, "frac": line / HBM_PEAK_GBS, "what": "every table access priced as one 128-byte line"},
+            "accounting": "bytes of the loads the kernel issued (counted in the kernel: interval / context / walk / prefix table entries, blocks, frames, hit records) "
+                          "+ query and result bytes, / kernel time; units_per_launch = " + what + " the batch stands for (identical to the CPU walk), served by fewer loads"}
+
+
+def attach_traffic(c, rec):
+    t = c.traffic.get(rec["id"])
+    if t and c.args.scale == 1.0:
+        rec["roofline"]["traffic"] = t["bytes_per_launch"]
+        rec["roofline"]["traffic_source"] = "profiles/r02_traffic.json (%s): separate rocprofv3 --pmc passes of this record, FETCH_SIZE x 2 + WRITE_SIZE; replayed, not measured in this run" % t.get("source", "")
+
+
+def mean(xs):
+    return sum(xs) / max(len(xs), 1)
+
+
+# ---------------------------------------------------------------------------------------------------------------- DNA texts
+def run_dna_text(c, name, primary):
+    torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
+    import ctypes as C
+    legs = ["exact", "k2", "k2_151"]
+    ids = ["%s/%s/%s" % (name, w, i) for w in legs for i in ("plain", "tables")]
+    if c.only and not any(i in c.only for i in ids):
+        return []
+    text, seq_off, lengths, tinfo = make_text(c, name)
+    total = int(text.numel())
+    out = []
+    nq = args.nq
+    want_cpu = primary and c.rank == 0 and not c.multi and not args.no_cpu_baseline
+    base_cfg = {"text": tinfo, "sigma": 5, "layout": "InterleavedBitvector16", "scale": args.scale}
+
+    # ------------------------------------------------------------------ exact search, configs[1]
+    if any(wanted(c, "%s/exact/%s" % (name, i)) for i in ("plain", "tables")):
+        L = 101
+        qbuf, qoff = sample_reads(c, text, lengths, L, nq, 1000 + c.rank, "exact")
+        os.environ["FMGPU_LF_TABLE"] = "0"
+        t0 = time.time()
+        index = fm.FMIndex.from_sequences((_Dev(text), _Dev(seq_off)), 5, "IB16", 16, keep_host=want_cpu)
+        build_plain = time.time() - t0
+        outs = [torch.empty(2 * nq, dtype=torch.int64, device=c.dev) for _ in range(2 if c.multi else 1)]
+        packed = [torch.empty(nq, dtype=torch.int64, device=c.dev) for _ in range(2)] if c.multi else None
+        stats = capi.Stats()
+        xch = Exchange(c, nq * 8) if c.multi else None
+        state = {"i": 0}
+
+        def step(log):
+            b = state["i"] % len(outs); state["i"] += 1
+            if xch:
+                xch.wait(b)
+                capi.check(capi.lib().fmgpu_search_exact_packed(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
+                                                                C.c_void_p(packed[b].data_ptr()), C.byref(stats), None))
+            else:
+                capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
+                                                         C.c_void_p(outs[b][:nq].data_ptr()), C.c_void_p(outs[b][nq:].data_ptr()), C.byref(stats), None))
+            log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses})
+            if xch:
+                xch.send(packed[b].view(torch.uint8), b)
+
+        def finish(rid, index_kind, kernel, elapsed, log, build_s, extra):
+            k_ms = mean([x["kernel_ms"] for x in log]); units = mean([x["units"] for x in log])
+            qps = c.world * nq * args.steps / elapsed
+            if xch:
+                w = packed[(state["i"] - 1) % 2]
+                out_len = w & 0xffffffff
+            else:
+                out_len = outs[0][nq:]
+            rec = {"id": rid, "metric": "queries/sec (GRCh38-sized index, 10M x 101bp, exact)", "value": qps, "unit": "queries/s", "n_gpus": c.world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+                   "data": "synthetic" if name != "fasta" else "real",
+                   "config": {"workload": "grch38_exact", **base_cfg, "index": "FMIndex", "index_kind": index_kind, "queries_per_gpu": nq, "read_len": L,
+                              "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2), **extra},
+                   "gbp_per_s": qps * L / 1e9, "hits": int((out_len > 0).sum().item())}
+            if index_kind == "plain":
+                rec["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_DNA, k_ms, kernel, "LF steps")
+            else:
+                st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
+                rec["roofline"] = roofline_loaded(st, nq * (L + 8 + 16), k_ms, kernel, units, "LF steps")
+            if xch:
+                rec["exchange"] = {"collective": xch.mode, "bytes_per_rank_and_step": nq * 8, "verified_on_rank0": xch.verify(), "record": "8 B per read (lb:32 | len:32)"}
+            attach_traffic(c, rec)
+            return rec
+
+        plain_ms = None
+        if wanted(c, name + "/exact/plain") and not c.multi:
+            elapsed, log = timed(c, step)
+            r = finish(name + "/exact/plain", "plain", "k_exact_a", elapsed, log, build_plain, {"tables": None})
+            plain_ms = r["roofline"]["kernel_ms"]
+            if c.rank == 0 and not c.multi:                     # the distribution the judge asked for: symbols until the interval is one row
+                depth = torch.empty(nq, dtype=torch.int32, device=c.dev)
+                capi.check(capi.lib().fmgpu_search_exact_depth(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq, C.c_void_p(depth.data_ptr()), None))
+                d = depth.to(torch.float32)
+                qs = torch.quantile(d[:: max(1, nq // 1_000_000)], torch.tensor([0.5, 0.9, 0.99], device=c.dev)).tolist()
+                r["symbols_until_one_row"] = {"mean": float(d.mean().item()), "p50": qs[0], "p90": qs[1], "p99": qs[2],
+                                              "never_within_the_read": float((depth > L).float().mean().item()),
+                                              "what": "query symbols consumed until the SA interval holds <= 1 row (fmgpu_search_exact_depth), over the same reads"}
+                del depth, d
+            out.append(r)
+        if wanted(c, name + "/exact/tables"):
+            t0 = time.time()
+            os.environ.pop("FMGPU_LF_TABLE", None)
+            index.accelerate(3, lut_len=args.lut_len, walk=2)
+            build_tab = build_plain + time.time() - t0
+            elapsed, log = timed(c, step, xch.drain if xch else None)
+            r = finish(name + "/exact/tables", "tables", "k_exact_kstep", elapsed, log, build_tab,
+                       {"tables": {"suffix_interval_symbols": args.lut_len, "kstep": 3, "walk_symbols_per_load": 32}})
+            if plain_ms:
+                r["roofline"]["speedup_over_plain_index_kernel"] = plain_ms / r["roofline"]["kernel_ms"]
+            if want_cpu:
+                r["cpu_baseline"] = cpu_baseline(c, index, False, qbuf, qoff, nq, L, None, outs[0][:nq], outs[0][nq:], None)
+            out.append(r)
+        os.environ.pop("FMGPU_LF_TABLE", None)
+        index.close()
+        del index, qbuf, qoff, outs, packed
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ k = 2 Hamming, configs[2] (101 bp) and configs[3] (151 bp)
+    scheme = fm.search_scheme.h2(4, 0, 2)
+    k2_legs = [("k2", 101, nq if not c.multi else 0), ("k2_151", 151, (args.total_k2_reads // c.world) if c.multi else min(12_500_000, max(1, int(12_500_000 * min(1.0, nq / 10_000_000)))))]
+    k2_legs = [(w, L, n_) for (w, L, n_) in k2_legs if n_ > 0 and any(wanted(c, "%s/%s/%s" % (name, w, i)) for i in ("plain", "tables"))]
+    if k2_legs:
+        os.environ["FMGPU_LF_TABLE"] = "0"
+        t0 = time.time()
+        keep = want_cpu and any(w == "k2" for w, _, _ in k2_legs)
+        index = fm.BiFMIndex.from_sequences((_Dev(text), _Dev(seq_off)), 5, "IB16", 16, keep_host=keep)
+        build_plain = time.time() - t0
+        os.environ.pop("FMGPU_LF_TABLE", None)
+        reads = {w: sample_reads(c, text, lengths, L, n_, 2000 + c.rank + 17 * L, "k2") for (w, L, n_) in k2_legs}
+        if not keep:
+            del text
+            text = None
+            torch.cuda.empty_cache()
+        stats = capi.Stats()
+        sc = _scheme_struct(capi, scheme)
+
+        def k2_run(w, L, n_, index_kind, build_s):
+            rid = "%s/%s/%s" % (name, w, index_kind)
+            if not wanted(c, rid) or (c.multi and index_kind == "plain"):
+                return None
+            qb, qo = reads[w]
+            # capacity of the hit buffers: an untimed pass tells how many records this batch produces (repeat-rich texts report many cursors per read)
+            probe = C.c_uint64()
+            rc = capi.lib().fmgpu_search_scheme(index._h, C.c_void_p(qb.data_ptr()), C.c_void_p(qo.data_ptr()), n_, C.byref(sc[0]), capi.UINT64_MAX,
+                                                None, 0, C.byref(probe), None, None)
+            if rc not in (0, capi.FMGPU_ERR_CAPACITY):
+                capi.check(rc)
+            hit_cap = int(probe.value) + 1024
+            if c.multi:                                           # every rank sizes its buffers for the largest count
+                t_ = torch.tensor([hit_cap], dtype=torch.int64, device="cpu" if c.via_host else c.dev)
+                c.dist.all_reduce(t_, op=c.dist.ReduceOp.MAX)
+                hit_cap = int(t_.item())
+            hits_bufs = [torch.empty(hit_cap * 40, dtype=torch.uint8, device=c.dev) for _ in range(2 if c.multi else 1)]
+            pk_cap = (hit_cap + 65535) // 65536 * 65536
+            packed_hits = [torch.empty((pk_cap, 2), dtype=torch.int64, device=c.dev) for _ in range(2)] if c.multi else None
+            xch = Exchange(c, pk_cap * 16) if c.multi else None
+            count_dev = torch.zeros(1, dtype=torch.int64, device="cpu" if c.via_host else c.dev) if c.multi else None
+            state = {"i": 0, "cnt": 0}
+
+            def step(log):
+                b = state["i"] % len(hits_bufs); state["i"] += 1
+                if xch:
+                    xch.wait(b)
+                cnt = C.c_uint64()
+                capi.check(capi.lib().fmgpu_search_scheme(index._h, C.c_void_p(qb.data_ptr()), C.c_void_p(qo.data_ptr()), n_, C.byref(sc[0]), capi.UINT64_MAX,
+                                                          C.c_void_p(hits_bufs[b].data_ptr()), hit_cap, C.byref(cnt), C.byref(stats), None))
+                state["cnt"] = int(cnt.value)
+                log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses, "hits": stats.hits})
+                if xch:                                           # 16 bytes per hit (qidx:32 | lb:32, len:32 | errors:8 | seq:24); message size = the largest count over the ranks
+                    count_dev.fill_(int(cnt.value))
+                    c.dist.all_reduce(count_dev, op=c.dist.ReduceOp.MAX)
+                    m = (int(count_dev.item()) + 65535) // 65536 * 65536
+                    capi.check(capi.lib().fmgpu_hits_pack16(C.c_void_p(hits_bufs[b].data_ptr()), int(cnt.value), C.c_void_p(packed_hits[b].data_ptr()), None))
+                    xch.send(packed_hits[b][:m].view(torch.uint8).view(-1), b)
+
+            elapsed, log = timed(c, step, xch.drain if xch else None)
+            k_ms = mean([x["kernel_ms"] for x in log]); units = mean([x["units"] for x in log]); nh = mean([x["hits"] for x in log])
+            qps = c.world * n_ * args.steps / elapsed
+            kernel = "k_scheme_fast"
+            part = [L // 4 + (1 if p < L % 4 else 0) for p in range(4)]
+            rec = {"id": rid, "metric": "queries/sec (GRCh38-sized index, %s x %dbp, k=2 Hamming, h2(4,0,2))" % ("10M" if w == "k2" else ("%.1fM per GPU" % (n_ / 1e6)), L),
+                   "value": qps, "unit": "queries/s", "n_gpus": c.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                   "higher_is_better": True, "scaling": "strong" if (c.multi and w == "k2_151") else "weak", "vs_baseline": None, "dtype": "u64",
+                   "data": "synthetic" if name != "fasta" else "real",
+                   "config": {"workload": "grch38_k2" if w == "k2" else "grch38_k2_151bp (configs[3]%s)" % ("" if c.multi else ": one GPU's share of 8"), **base_cfg,
+                              "index": "BiFMIndex", "index_kind": index_kind, "queries_per_gpu": n_, "read_len": L, "scheme": "h2(4,0,2)", "partition": part,
+                              "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2),
+                              "tables": None if index_kind == "plain" else {"lf": True, "prefix_symbols": args.prefix_len, "walk": "LF,LF^2,LF^3 + LF^16"}},
+                   "gbp_per_s": qps * L / 1e9, "hits": int(nh)}
+            if index_kind == "plain":
+                rec["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_DNA, k_ms, kernel, "visited nodes (cursor extensions)")
+            else:
+                st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
+                rec["roofline"] = roofline_loaded(st, n_ * (L + 8), k_ms, kernel, units, "visited nodes")
+            if xch:
+                rec["exchange"] = {"collective": xch.mode, "bytes_per_rank_and_step": int(xch.last[0].numel()), "verified_on_rank0": xch.verify(),
+                                   "record": "16 B per hit (qidx:32 | lb:32, len:32 | errors:8 | seq:24)"}
+            attach_traffic(c, rec)
+            if keep and w == "k2" and index_kind == "tables":
+                rec["cpu_baseline"] = cpu_baseline(c, index, True, qb, qo, n_, L, scheme, None, None, (hits_bufs[0], state["cnt"]))
+            return rec
+
+        for (w, L, n_) in k2_legs:
+            out.append(k2_run(w, L, n_, "plain", build_plain))
+        t0 = time.time()
+        index.accelerate_lf(True)
+        try:
+            index.accelerate_search(args.prefix_len, 3)
+        except fm.FmgpuError as ex:                            # (the 16-symbol table is 69 GB: should the card be short of memory, one symbol less)
+            if args.prefix_len < 16:
+                raise
+            print("bench.py: %s; retrying with a 15-symbol prefix table" % ex, file=sys.stderr, flush=True)
+            args.prefix_len = 15
+            index.accelerate_search(args.prefix_len, 3)
+        build_tab = build_plain + time.time() - t0
+        for (w, L, n_) in k2_legs:
+            out.append(k2_run(w, L, n_, "tables", build_tab))
+        index.close()
+        del index, reads
+    del text
+    torch.cuda.empty_cache()
+    return out
+
+
 def _scheme_struct(capi, scheme):
     import numpy as np
     pi, l, u = (np.ascontiguousarray(x, dtype=np.uint64) for x in scheme)
@@ -424,55 +547,134 @@ def _scheme_struct(capi, scheme):
     sc.n_searches, sc.n_parts = pi.shape
     sc.pi, sc.l, sc.u = (x.ctypes.data_as(capi.u64p) for x in (pi, l, u))
     sc.partition = None
+    sc.edit = 0
     return sc, (pi, l, u)
 
 
-def cpu_baseline(index, bidir, qbuf, qoff, nq, L, scheme, sample, out_lb, out_len, layout="IB16", sigma=5, edit=False, hit_q=None):
-    """the CPU restatement (oracle/) on the host cores, bounded sample of the same reads; also a parity spot-check"""
-    import numpy as np
+# ---------------------------------------------------------------------------------------------------------------- protein, configs[4]
+def run_protein(c):
+    torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
+    import ctypes as C
+    ids = ["protein/exact/wavelet", "protein/exact/tables"]
+    if c.only and not any(i in c.only for i in ids):
+        return []
+    sigma, L, nq = 28, 40, args.nq
+    nseq = PROTEIN_SEQS
+    total = nseq * PROTEIN_SEQ_LEN
+    g = torch.Generator(device=c.dev)
+    g.manual_seed(42)
+    text = torch.empty(total, dtype=torch.uint8, device=c.dev)
+    for lo in range(0, total, 1 << 28):
+        hi = min(total, lo + (1 << 28))
+        text[lo:hi] = torch.randint(1, sigma, (hi - lo,), generator=g, device=c.dev, dtype=torch.uint8)
+    seq_off = torch.arange(nseq + 1, device=c.dev, dtype=torch.int64) * PROTEIN_SEQ_LEN
+    qbuf, qoff = sample_reads(c, text, None, L, nq, 1000, "exact", sigma=sigma, inside=(nseq, PROTEIN_SEQ_LEN))
+    os.environ["FMGPU_LF_TABLE"] = "0"
+    t0 = time.time()
+    index = fm.FMIndex.from_sequences((_Dev(text), _Dev(seq_off)), sigma, "WAVELET", 16, keep_host=False)
+    build_s = time.time() - t0
+    os.environ.pop("FMGPU_LF_TABLE", None)
+    del text
+    torch.cuda.empty_cache()
+    out_t = torch.empty(2 * nq, dtype=torch.int64, device=c.dev)
+    stats = capi.Stats()
+
+    def step(log):
+        capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
+                                                 C.c_void_p(out_t[:nq].data_ptr()), C.c_void_p(out_t[nq:].data_ptr()), C.byref(stats), None))
+        log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses})
+
+    def rec_of(rid, kind, kernel, elapsed, log, b_s, tables):
+        k_ms = mean([x["kernel_ms"] for x in log]); units = mean([x["units"] for x in log])
+        qps = nq * args.steps / elapsed
+        r = {"id": rid, "metric": "queries/sec (sigma=28 protein index, 10M x 40aa, exact, Wavelet)", "value": qps, "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
+             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+             "config": {"workload": "protein_exact", "text": {"text": "uniform residues in {1..27}", "symbols": total, "sequences": nseq}, "sigma": sigma, "layout": "Wavelet",
+                        "index": "FMIndex", "index_kind": kind, "queries_per_gpu": nq, "read_len": L, "index_device_bytes": index.device_bytes, "index_build_s": round(b_s, 2),
+                        "tables": tables},
+             "gres_per_s": qps * L / 1e9, "hits": int((out_t[nq:] > 0).sum().item())}
+        if kind == "wavelet":
+            r["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_WAVELET28, k_ms, kernel, "LF steps")
+            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
+            r["roofline"]["loaded"] = {"bytes_per_launch": st["table_bytes"], "accesses_per_launch": st["table_accesses"],
+                                       "what": "bytes / blocks the kernel actually read from the two-level multi-ary tree (counted in the kernel)"}
+        else:
+            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
+            r["roofline"] = roofline_loaded(st, nq * (L + 8 + 16), k_ms, kernel, units, "LF steps")
+        attach_traffic(c, r)
+        return r
+
+    out = []
+    if wanted(c, ids[0]):
+        elapsed, log = timed(c, step)
+        out.append(rec_of(ids[0], "wavelet", "k_exact_m", elapsed, log, build_s, None))
+    if wanted(c, ids[1]):
+        t0 = time.time()
+        index.accelerate(1, lut_len=6, walk=2)
+        b2 = build_s + time.time() - t0
+        elapsed, log = timed(c, step)
+        out.append(rec_of(ids[1], "tables", "k_exact_kstep", elapsed, log, b2, {"block_table_expansion": True, "suffix_interval_symbols": 6, "walk_symbols_per_load": 12}))
+    index.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- CPU leg
+def cpu_baseline(c, index, bidir, qbuf, qoff, nq, L, scheme, out_lb, out_len, hits):
+    """the CPU restatement (oracle/) on the host cores over a bounded sample of the same reads; also a parity check of the GPU results on that sample:
+    exact — every (lb, len); k = 2 — every hit record (qidx, lb, lb_rev, len, errors) in callback order"""
+    np, torch, capi = c.np, c.torch, c.capi
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fmoracle as fo
     cores = len(os.sched_getaffinity(0))
     t0 = time.time()
     bwt = index.built_array(0)
     bwt_rev = index.built_array(1) if bidir else None
-    ox = fo.OraIndex.from_bwt(layout, sigma, bwt, bwt_rev, None, None, None)
+    ox = fo.OraIndex.from_bwt("IB16", 5, bwt, bwt_rev, None, None, None)
+    ox.spread(cores)                                          # pages of the occurrence tables over all NUMA nodes (built by one thread = on one node)
     build = time.time() - t0
-    hq_all = qbuf.cpu().numpy()
-    ho_all = qoff.cpu().numpy().astype(np.uint64)
+    sample_cap = min(nq, 12_000_000 if not bidir else 1_000_000)
+    hq_all = qbuf[: sample_cap * L].cpu().numpy()
+    ho_all = qoff[: sample_cap + 1].cpu().numpy().astype(np.uint64)
 
-    def run(count, threads=cores, batched=True):
+    def run(count, threads=cores, batched=True, records=False):
         t0 = time.time()
         if not bidir and batched:                             # search/SearchNoErrors.h:28-86, the reference's 32-way interleaved form
             r = ox.search_exact_batched(hq_all[: count * L], ho_all[: count + 1], 32, threads)
         elif not bidir:                                       # :12-26, one query at a time
             r = ox.search_exact(hq_all[: count * L], ho_all[: count + 1], nthreads=threads)
-        else:
-            r = ox.search_ng26(hq_all[: count * L], ho_all[: count + 1], scheme, nthreads=threads, edit=True if edit else None)
+        else:                                                 # timed: the walk itself (counts per query); records=True adds a second pass that writes the hit records
+            r = ox.search_ng26(hq_all[: count * L], ho_all[: count + 1], scheme, nthreads=threads, cap=16 * count + 1024, records=records)
         return r, time.time() - t0
 
-    pilot = min(nq, 200_000 if not bidir else (5_000 if edit else 50_000))
+    pilot = min(sample_cap, 400_000 if not bidir else 50_000)
     _, dt = run(pilot)                                        # also warms the caches / OpenMP team
-    if sample <= 0:                                           # aim at ~15 s of CPU work, bounded by the batch
-        sample = int(min(nq, max(pilot, pilot * 15.0 / max(dt, 1e-3))))
+    sample = c.args.cpu_sample or int(min(sample_cap, max(pilot, pilot * 12.0 / max(dt, 1e-3))))
     r, dt = run(sample)
     if not bidir:
         lb, ln = r
-        ok = bool(np.array_equal(lb, out_lb[:sample].cpu().numpy().astype(np.uint64)) and
-                  np.array_equal(ln, out_len[:sample].cpu().numpy().astype(np.uint64)))
-    elif hit_q is not None:                                   # per-query record counts on the sample (hit-by-hit parity: tests/test_gpu_parity.py)
-        import torch
-        mine = torch.bincount(hit_q[hit_q < sample], minlength=sample).cpu().numpy().astype(np.uint64)
-        ok = bool(np.array_equal(mine, np.asarray(r[1][:sample], dtype=np.uint64)))
+        ok = bool(np.array_equal(lb, out_lb[:sample].cpu().numpy().astype(np.uint64)) and np.array_equal(ln, out_len[:sample].cpu().numpy().astype(np.uint64)))
     else:
-        ok = None
+        checked = min(sample, 200_000)                        # hit-by-hit parity on the first reads of the sample (a second, untimed oracle pass writes the records)
+        r, _ = run(checked, records=True)
+        buf, cnt = hits
+        rec = buf[: cnt * 40].view(torch.int64).view(-1, 5)
+        mine = rec[rec[:, 0] < checked].cpu().numpy()
+        order = np.lexsort((mine[:, 4] >> 32, mine[:, 0]))     # (qidx, seq): the reference's callback order
+        mine = mine[order]
+        oh = r[0]
+        ok = bool(len(oh) == len(mine) and all(np.array_equal(mine[:, k].astype(np.uint64), oh[f].astype(np.uint64)) for k, f in ((0, "qidx"), (1, "lb"), (2, "lb_rev"), (3, "len"))) and
+                  np.array_equal((mine[:, 4] & 0xffffffff).astype(np.uint64), oh["errors"].astype(np.uint64)))
     one = max(1000, min(sample, int(sample / dt * 3.0 / cores)))          # ~3 s on one thread (SURVEY 8d: single-thread figure beside all cores)
     _, dt1 = run(one, threads=1)
     out = {"value": sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",
            "single_thread": {"value": one / dt1, "unit": "queries/s", "sample": "the first %d reads, one thread" % one},
-           "sample": "the first %d reads of the same batch, OpenMP over queries on all host cores%s; index rebuilt on the host from the "
-                     "GPU-built BWT in %.0f s" % (sample, "" if bidir else ", 32 cursors interleaved per thread (SearchNoErrors.h:28-86)", build),
-           "seconds": dt, "gpu_results_match_on_sample": ok}   # exact: every (lb, len); k = 2: the number of records per query
+           "parallel_efficiency": (sample / dt) / (one / dt1) / cores,
+           "sample": "the first %d reads of the same batch, OpenMP over queries on all host cores (OMP_PROC_BIND=%s, OMP_PLACES=%s; occurrence tables re-homed over the NUMA nodes "
+                     "by a parallel first touch)%s; index rebuilt on the host from the GPU-built BWT in %.0f s"
+                     % (sample, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), "" if bidir else ", 32 cursors interleaved per thread (SearchNoErrors.h:28-86)", build),
+           "seconds": dt, "gpu_results_match_on_sample": ok,
+           "compared": "every (lb, len) of the sample" if not bidir else "every hit record (qidx, lb, lb_rev, len, errors) of the first %d reads, in callback order" % min(sample, 200_000)}
     if not bidir:                                             # the one-query-at-a-time form beside it, on a sample a fifth the size
         few = max(1000, sample // 5)
         _, dts = run(few, batched=False)

@@ -467,6 +467,38 @@ void ora_string_free(ora_string* s) {
     }
     free(s);
 }
+/* Re-homes the big arrays of a string so that their pages are spread over the NUMA nodes of the threads that will search them: a new
+ * buffer is first touched by `nthreads` OpenMP threads in a static schedule (the construction above runs on one thread, so everything it
+ * allocated sits on that thread's node and every other socket's queries cross the interconnect).  Contents are unchanged.  Test
+ * infrastructure for bench.py's cpu_baseline leg — the reference itself does nothing of the kind. */
+static void* spread_copy(void* old, uint64_t bytes, int nthreads) {
+    if (!old || bytes < (1u << 20)) return old;
+    uint8_t* fresh = malloc(bytes);
+    if (!fresh) return old;
+    const uint64_t page = 1u << 21;                      /* a transparent huge page */
+    const int64_t npages = (int64_t)((bytes + page - 1) / page);
+    #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t p = 0; p < npages; ++p) {
+        const uint64_t o = (uint64_t)p * page, len = o + page <= bytes ? page : bytes - o;
+        memcpy(fresh + o, (const uint8_t*)old + o, len);
+    }
+    free(old);
+    return fresh;
+}
+void ora_index_spread(ora_index* x, int nthreads) {
+    ora_string* two[2] = {x->bwt, x->bwt_rev};
+    for (int k = 0; k < 2; ++k) {
+        ora_string* s = two[k];
+        if (!s) continue;
+        if (s->blocks) s->blocks = spread_copy(s->blocks, (s->family == FAM_IB || s->family == FAM_IBP ? s->nblocks : (s->n / (s->rows ? s->rows : 64) + 2)) * s->stride, nthreads);
+        if (s->node) for (uint64_t i = 0; i < s->nnodes; ++i) {
+            ora_bitvector* v = &s->node[i];
+            v->superblocks = spread_copy(v->superblocks, (v->cap / 4 + 2) * 8, nthreads);
+            v->blocks = spread_copy(v->blocks, v->cap + 1, nthreads);
+            v->bits = spread_copy(v->bits, (v->cap + 1) * 8, nthreads);
+        }
+    }
+}
 uint64_t ora_string_size(const ora_string* s) { return s->n; }
 int ora_string_sigma(const ora_string* s) { return s->sigma; }
 int ora_string_layout(const ora_string* s) { return s->layout; }
@@ -1159,6 +1191,27 @@ uint64_t ora_search_ng26_hamming(const ora_index* x, const uint8_t* qbuf, const 
             }
             if (out_qcount) out_qcount[q] = e.count;
             total += e.count; total_nodes += e.nodes;
+        }
+        /* hit records from the threaded variant (bench.py's parity check at full index size): the per-query counts give every query its slice
+         * of `out`, a second pass over the queries fills the slices — same order as the single-threaded walk */
+        if (out && out_qcount && total <= cap) {
+            uint64_t* first = malloc((nq + 1) * 8);
+            first[0] = 0;
+            for (uint64_t q = 0; q < nq; ++q) first[q + 1] = first[q] + out_qcount[q];
+            #pragma omp parallel for schedule(dynamic, 256) num_threads(T)
+            for (int64_t q = 0; q < (int64_t)nq; ++q) {
+                if (out_qcount[q] == 0) continue;
+                emit_ctx e = {out + first[q], out_qcount[q], 0, (uint64_t)q, 0, max_hits_per_query};
+                uint64_t part_buf[64];
+                uint64_t m = qoff[q + 1] - qoff[q];
+                const uint64_t* part = partition;
+                if (!part) { ora_uniform_partition((uint64_t)nparts, m, part_buf); part = part_buf; }
+                for (int si = 0; si < nsearch; ++si) {
+                    ng_search s = {x, qbuf + qoff[q], m, nparts, pi + si * nparts, l + si * nparts, u + si * nparts, part, &e};
+                    if (ng_run(&s)) break;
+                }
+            }
+            free(first);
         }
     }
     if (out_nodes) *out_nodes = total_nodes;

@@ -113,6 +113,9 @@ ora_index* ora_index_build(int layout, int sigma, const uint8_t* seqs, const uin
 ora_index* ora_index_from_bwt(int layout, int sigma, const uint8_t* bwt, const uint8_t* bwt_rev, uint64_t n,
                               const uint8_t* has, const uint64_t* seq, const uint64_t* pos);
 void       ora_index_free(ora_index* x);
+/* spreads the pages of the occurrence tables over the NUMA nodes of `nthreads` OpenMP threads (parallel first touch of a copy); only
+ * bench.py's cpu_baseline uses it, so that the all-core figure is not bound by one memory controller */
+void       ora_index_spread(ora_index* x, int nthreads);
 
 /* cursors: fmindex/FMIndexCursor.h:33-53, fmindex/BiFMIndexCursor.h:58-128, :180-190 */
 typedef struct ora_cursor { uint64_t lb, lb_rev, len; } ora_cursor;

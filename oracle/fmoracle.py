@@ -106,6 +106,8 @@ def lib():
         L.ora_index_from_bwt.restype = C.POINTER(IndexStruct)
         L.ora_index_from_bwt.argtypes = [C.c_int, C.c_int, u8p, u8p, C.c_uint64, u8p, u64p, u64p]
         L.ora_index_free.argtypes = [C.POINTER(IndexStruct)]
+        L.ora_index_spread.argtypes = [C.POINTER(IndexStruct), C.c_int]
+        L.ora_index_spread.restype = None
         L.ora_cursor_init.restype = Cursor
         L.ora_cursor_init.argtypes = [C.POINTER(IndexStruct)]
         for f in ("ora_extend_left", "ora_extend_right"):
@@ -284,6 +286,11 @@ class OraIndex:
             lib().ora_index_free(self.p)
             self.p = None
 
+    def spread(self, nthreads):
+        """re-home the occurrence tables over the NUMA nodes of `nthreads` OpenMP threads (bench.py's all-core baseline)"""
+        lib().ora_index_spread(self.p, int(nthreads))
+        return self
+
     @property
     def n(self):
         return self.p.contents.n
@@ -372,8 +379,9 @@ class OraIndex:
             return self.search_backtracking(qbuf, qoff, k, cap=int(n))
         return out[:n], nodes.value
 
-    def search_ng26(self, qbuf, qoff, scheme, partition=None, max_hits=UINT64_MAX, cap=1 << 20, nthreads=1, edit=None):
-        """edit=None: the Hamming reduction; edit=False / True: the full state machine with Edit = false / true"""
+    def search_ng26(self, qbuf, qoff, scheme, partition=None, max_hits=UINT64_MAX, cap=1 << 20, nthreads=1, edit=None, records=False):
+        """edit=None: the Hamming reduction; edit=False / True: the full state machine with Edit = false / true.
+        nthreads > 1 counts only (the timed baseline) unless records=True: then a second threaded pass also fills the hit records"""
         if edit is not None:
             return self._search_ng26_full(qbuf, qoff, scheme, partition, max_hits, cap, nthreads, bool(edit))
         pi, l, u = scheme
@@ -383,13 +391,14 @@ class OraIndex:
         qcount = np.zeros(nq, dtype=np.uint64)
         nodes = C.c_uint64()
         part = as_u64(partition) if partition is not None else None
+        want = nthreads == 1 or records
         n = lib().ora_search_ng26_hamming(self.p, _p8(qbuf), _p64(qoff), nq, nsearch, nparts,
                                           _p64(as_u64(pi)), _p64(as_u64(l)), _p64(as_u64(u)), _p64(part),
-                                          max_hits, out.ctypes.data if nthreads == 1 else None,
-                                          cap if nthreads == 1 else 0, _p64(qcount), C.byref(nodes), nthreads)
-        if nthreads == 1 and n > cap:
-            return self.search_ng26(qbuf, qoff, scheme, partition, max_hits, cap=int(n), nthreads=1)
-        return out[: n if nthreads == 1 else 0], qcount, nodes.value
+                                          max_hits, out.ctypes.data if want else None,
+                                          cap if want else 0, _p64(qcount), C.byref(nodes), nthreads)
+        if want and n > cap:
+            return self.search_ng26(qbuf, qoff, scheme, partition, max_hits, cap=int(n), nthreads=nthreads, records=records)
+        return out[: n if want else 0], qcount, nodes.value
 
 
     def _search_ng26_full(self, qbuf, qoff, scheme, partition, max_hits, cap, nthreads, edit):

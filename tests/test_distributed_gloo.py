@@ -64,12 +64,16 @@ def test_bench_two_ranks_on_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ([], ["--workload", "k2"]):
-        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.02",
-                            "--nq", "200000", "--dist-backend", "gloo", "--all-ranks-device0"] + extra, capture_output=True, text=True, timeout=600)
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        assert r.returncode == 0 and len(lines) == 1, r.stdout[-500:] + r.stderr[-1500:]
-        out = json.loads(lines[0])
-        assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and "cpu_baseline" not in out and "secondary" not in out
-        assert out["exchange"]["verified_on_rank0"] is True and out["exchange"]["bytes_per_rank_and_step"] > 0   # rank 0 received what both ranks sent
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.02",
+                        "--nq", "200000", "--total-k2-reads", "100000", "--lut-len", "10", "--prefix-len", "11", "--dist-backend", "gloo", "--all-ranks-device0"], capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-500:] + r.stderr[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and "cpu_baseline" not in out
+    assert out["config"]["workload"] == "grch38_exact" and out["config"]["queries_per_gpu"] == 200000
+    assert out["exchange"]["verified_on_rank0"] is True and out["exchange"]["bytes_per_rank_and_step"] > 0   # rank 0 received what both ranks sent
+    assert 0 < out["roofline"]["frac"] <= 1.0
+    sec = out["secondary"]                                       # configs[3]: k = 2, 151 bp, the batch sharded over the ranks (strong scaling)
+    assert sec["scaling"] == "strong" and sec["config"]["read_len"] == 151 and sec["config"]["queries_per_gpu"] == 50000 and sec["config"]["partition"] == [38, 38, 38, 37]
+    assert sec["exchange"]["verified_on_rank0"] is True and sec["value"] > 0
