@@ -178,6 +178,7 @@ def make_text(c, name):
         raise SystemExit("unknown text %r" % name)
     seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64))])).to(c.dev)
     info["symbols"] = int(text.numel()); info["sequences"] = len(lengths)
+    torch.cuda.synchronize()                                  # (the generator's kernels are not part of the index build time)
     return text, seq_off, lengths, info
 
 
@@ -353,6 +354,7 @@ def run_dna_text(c, name, primary):
     if any(wanted(c, "%s/exact/%s" % (name, i)) for i in ("plain", "tables")):
         L = 101
         qbuf, qoff = sample_reads(c, text, lengths, L, nq, 1000 + c.rank, "exact")
+        torch.cuda.synchronize()
         os.environ["FMGPU_LF_TABLE"] = "0"
         t0 = time.time()
         index = fm.FMIndex.from_sequences((_Dev(text), _Dev(seq_off)), 5, "IB16", 16, keep_host=want_cpu)
@@ -445,6 +447,7 @@ def run_dna_text(c, name, primary):
         build_plain = time.time() - t0
         os.environ.pop("FMGPU_LF_TABLE", None)
         reads = {w: sample_reads(c, text, lengths, L, n_, 2000 + c.rank + 17 * L, "k2") for (w, L, n_) in k2_legs}
+        torch.cuda.synchronize()
         if not keep:
             del text
             text = None

@@ -1327,27 +1327,29 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
     add_counters(steps_total, steps, tbytes, tacc);
 }
 
-constexpr uint32_t kHitBuf = 2;      // hits buffered per lane and round in LDS; further hits of the same query are emitted directly
+constexpr uint32_t kRefillLanes = 16; // lanes of a wave that must be out of work before the wave fetches and stages new queries together
 
 template <int SIGMA, int MAXSIG>
 __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
                                                                           uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap) {
-    // Wave-synchronous rounds.  A wave pays for every slow path any of its 64 lanes takes, so nothing with a dependent
-    // memory round trip is lane-private: the 64 lanes fetch and stage their next queries TOGETHER (one atomicAdd per wave,
-    // query words issued back to back), start every search of the scheme TOGETHER (so the few wide-interval steps at a
-    // search's start coincide; a round lasts as long as its slowest lane anyway), keep their hits in LDS and flush them
-    // together (one atomicAdd per wave).  Inside a search the loop performs one memory phase per iteration:
+    // One flat loop per lane over (query, search, node) with every slow path wave-synchronous.  A wave pays for every slow path any of its 64
+    // lanes takes, so nothing with a dependent memory round trip is lane-private: queries are fetched and staged TOGETHER — as soon as
+    // kRefillLanes lanes of the wave are out of work (one atomicAdd per refill, query words issued back to back) — and hits are kept in LDS
+    // and written out together (one atomicAdd per flush).  The work per read is heavy-tailed on a repeat-rich text (a read from a young repeat
+    // family or a satellite visits 10^4 - 10^5 nodes where the median read visits 200): in lock-step rounds of 64 reads nearly every round
+    // holds such a read and the other 63 lanes wait for it (measured: 10 % lane utilisation on the genome-like text); refilling lanes as
+    // they finish keeps them busy.  Every iteration performs ONE memory phase for whatever its lanes are doing:
+    //   search start     : the prefix table entry of the first L symbols of the always-exact first part;
     //   multi-row cursor : the 64-byte blocks at both ends (extend-all);
-    //   single-row cursor: ONE load of LF, LF^2, LF^3 and up to three steps from it (or one LF-table load and one step);
-    //   search start     : the prefix table entry of the first L symbols of the always-exact first part.
+    //   single-row cursor: ONE load of a walk entry / LF, LF^2, LF^3 / LF and up to 16 / 3 / 1 steps from it (or the row's block: plain index).
     extern __shared__ uint32_t s_dyn[];
     uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
     const uint32_t* s_stretch = s_steps + S * stride;               // stretch words of the run16 steps
     const uint32_t* s_stretch3 = s_steps + 2u * S * stride;         // ... and of the <= 3 steps of a `run`
-    uint32_t* s_hits = s_steps + 3u * S * stride;                   // [kHitBuf][5][256]: lb, lbRev, len, e, seq
+    uint32_t* s_hb = s_steps + 3u * S * stride;                     // kWaveHitWords: the wave's hit buffers (wave_keep_hit / wave_flush_hits)
     const QStage qst{s_dyn, qwords, qnib};
     for (uint32_t i = threadIdx.x; i < 3u * S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
     __syncthreads();
@@ -1357,50 +1359,58 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     const uint32_t sigma = fw.sigma(), R = sigma - 1;
     uint32_t nodes = 0;
     uint64_t tbytes = 0; uint32_t tacc = 0;                         // table bytes consumed / table accesses issued (fmgpu_stats)
+    const uint32_t refill_at = ((uint32_t)dev_flags >> 8) & 63u ? ((uint32_t)dev_flags >> 8) & 63u : kRefillLanes;   // (dev knob: bits 8..13)
+    uint32_t nh = 0, count_only = 0;
+    bool have = false, exhausted = n == 0, need_start = false, query_over = false;
+    uint64_t q = 0, quota = 0;
+    const uint8_t* qs = qbuf;
+    const uint32_t* tab = s_steps;
+    uint32_t seq = 0, si = 0;
+    Cur cur{0, 0, 0};                                               // state of the search in progress
+    uint32_t e = 0, j = 0, sp = 0, resume = kNoResume;
+    bool in_tail = false;
     for (;;) {
-        // ---- round start: 64 consecutive queries for this wave
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->next, 64ull);
-        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
-        if (base >= nq) break;
-        const bool present = base + lane < nq;                      // nq = queries of this launch; qmap (if any) names them within the batch
-        const uint64_t q = present ? (qmap ? (uint64_t)qmap[base + lane] : base + lane) : 0;
-        const bool active = present && n != 0;
-        const uint64_t qo = present ? qoff[q] : 0;
-        const uint8_t* qs = qbuf + qo;
-        qstage_load_sync(qst, qbuf, qo, m, sigma, present, m);
-
-        uint64_t quota = max_hits; uint32_t seq = 0, nh = 0;
-        bool query_over = !active;
-        for (uint32_t si = 0; si < S; ++si) {                       // search_impl (SearchNg26.h:385-390), all lanes in step
-            const uint32_t* tab = s_steps + si * stride;
-            bool done = query_over;
-            Cur cur{0, 0, n};                                       // run(): SearchNg26.h:62-79
-            uint32_t e = 0, j = 0, sp = 0, resume = kNoResume;
-            bool in_tail = false;
-            if (fa.lut && ((fa.lut_ok >> si) & 1u) && n > 1) {      // the exact first part starts from the prefix table
-                uint32_t code = 0, mul = 1; bool valid = !done;
-                for (uint32_t t = 0; t < fa.lutL; ++t) {
-                    uint32_t c = qstage_get(qst, qs, tab[t] & 0xffffu);
-                    valid = valid && c >= 1 && c < sigma;
-                    code += (c - 1) * mul; mul *= R;
-                }
-                if (valid) {
-                    const uint4 en = fa.lut[code];
-                    tbytes += 16u; ++tacc;
-                    cur = Cur{en.x, en.y, en.z};
-                    nodes += en.w;                                  // the extensions the reference performs before the interval is empty (:225-250)
-                    j = fa.lutL; in_tail = true;
-                    if (en.z == 0) done = true;
+        // ---- wave-synchronous part: every lane passes here in every iteration
+        const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
+        if (needm && ((uint32_t)__popcll(needm) >= refill_at || !busym)) {
+            const bool want = !have && !exhausted;
+            const uint64_t got = wave_hand_out(want, ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
+            bool fresh = false; uint64_t qo = 0;
+            if (want) {
+                if (got >= nq) exhausted = true;
+                else { q = qmap ? (uint64_t)qmap[got] : got; qo = qoff[q]; qs = qbuf + qo; fresh = true; }
+            }
+            qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
+            if (fresh) { have = true; si = 0; need_start = true; quota = max_hits; seq = 0; query_over = false; }
+        }
+        {
+            const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(have);
+            if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
+            if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
+        }
+        if (!have) continue;
+        {
+            bool lut_start = false; uint32_t lut_code = 0;
+            if (need_start) {                                       // search_impl (SearchNg26.h:385-390) -> run(): :62-79
+                need_start = false;
+                tab = s_steps + si * stride;
+                cur = Cur{0, 0, n}; e = 0; j = 0; sp = 0; resume = kNoResume; in_tail = false;
+                if (fa.lut && ((fa.lut_ok >> si) & 1u) && n > 1) {  // the exact first part starts from the prefix table
+                    uint32_t code = 0, mul = 1; bool valid = true;
+                    for (uint32_t t = 0; t < fa.lutL; ++t) {
+                        uint32_t c = qstage_get(qst, qs, tab[t] & 0xffffu);
+                        valid = valid && c >= 1 && c < sigma;
+                        code += (c - 1) * mul; mul *= R;
+                    }
+                    lut_start = valid; lut_code = code;
                 }
             }
-            while (__ballot(!done) != 0ull) {
-                if (done) continue;
+            {
                 const uint32_t ent = tab[j];
                 const bool right = (ent >> 16) & 1u;
-                const bool multi = cur.len > 1;
+                const bool multi = !lut_start && cur.len > 1;
                 const idx_t a = right ? cur.lbRev : cur.lb;
-                bool back = false;
+                bool back = false, search_over = false;
                 // ---- memory phase: the lanes of a wave sit in different kinds of nodes; every lane issues its loads here, before any lane
                 // consumes one, so that an iteration costs one round trip and not one per kind of node present in the wave
                 // (ONE unconditional 16-byte load per lane — the first quarter of a multi-row lane's block, or a one-row lane's walk / LF^1..3 /
@@ -1408,11 +1418,12 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 constexpr bool kSplit = SIGMA > 0 && SIGMA <= 5;
                 const uint2* wj = right ? fa.wj_rv : fa.wj_fw;
                 const idx_t* w3 = right ? fa.w3_rv : fa.w3_fw;
-                const bool use_wj = !multi && wj && ((ent >> 29) & 1u);
+                const bool use_wj = !lut_start && !multi && wj && ((ent >> 29) & 1u);
                 const uint8_t* blk = (right ? rv : fw).v.blk;
                 // the plain index (no LF tables: the ~6 GB configuration): a one-row node reads its 64-byte block and takes the row's symbol and LF from it
-                const bool from_block = kSplit && !multi && fa.lf_fw == nullptr;
-                const uint8_t* p0 = ((multi && kSplit) || from_block) ? blk + (size_t)(a >> 6) * 64u
+                const bool from_block = kSplit && !lut_start && !multi && fa.lf_fw == nullptr;
+                const uint8_t* p0 = lut_start ? reinterpret_cast<const uint8_t*>(fa.lut + lut_code)
+                                  : ((multi && kSplit) || from_block) ? blk + (size_t)(a >> 6) * 64u
                                   : use_wj ? reinterpret_cast<const uint8_t*>(wj + a)
                                   : w3 ? reinterpret_cast<const uint8_t*>(w3 + 3u * (size_t)a)
                                   : reinterpret_cast<const uint8_t*>((right ? fa.lf_rv : fa.lf_fw) + a);
@@ -1425,7 +1436,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     const bool same = (a >> 6) == ((a + cur.len) >> 6);
                     tbytes += same ? 64u : 128u; tacc += same ? 1u : 2u;
                 } else if (multi) { tbytes += 24u * sigma; tacc += 2u; }
-                else { tbytes += from_block ? 64u : use_wj ? 8u : w3 ? 12u : 4u; ++tacc; }
+                else { tbytes += lut_start ? 16u : from_block ? 64u : use_wj ? 8u : w3 ? 12u : 4u; ++tacc; }
                 const uint2 we = make_uint2(r0.x, r0.y);
                 idx_t t0 = r0.x, t1 = r0.y, t2 = r0.z;
                 if constexpr (kSplit) {
@@ -1442,7 +1453,12 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         }
                     }
                 }
-                if (multi) {
+                if (lut_start) {
+                    cur = Cur{r0.x, r0.y, r0.z};
+                    nodes += r0.w;                                  // the extensions the reference performs before the interval is empty (:225-250)
+                    j = fa.lutL; in_tail = true;
+                    if (r0.z == 0) search_over = true;
+                } else if (multi) {
                     // ---- extend-all node (search_next_dir, :143-224) or exact-tail step over several rows
                     const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
                     const bool lastp = (ent >> 17) & 1u;
@@ -1612,20 +1628,15 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         else if (n) { if (right) cur.lbRev = target; else cur.lb = target; j += n; }
                     }
                 }
-                bool search_over = false;
-                if (!back && j == m) {                              // search_next at part == P (:101-108)
+                if (!lut_start && !back && j == m) {                // search_next at part == P (:101-108)
                     const uint32_t fin = tab[m];
                     if (((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x3fu)) {
                         Cur r = cur;
                         if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
                         quota -= r.len;
-                        if (!(dev_flags & 1)) {
-                            if (nh < kHitBuf) {                    // buffered; written out at the end of the round
-                                uint32_t* h = s_hits + (size_t)nh * 5u * 256u + threadIdx.x;
-                                h[0] = r.lb; h[256] = r.lbRev; h[512] = r.len; h[768] = e; h[1024] = seq;
-                            } else emit_hit(out, cap, ctr, q, r, e, seq);
-                        }
-                        ++nh; ++seq;
+                        if (dev_flags & 1) ++count_only;
+                        else { wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq); tbytes += 40u; ++tacc; }
+                        ++seq;
                         if (quota == 0) { search_over = true; query_over = true; }   // delegate returned true: no further searches (:372-383)
                     }
                     back = !search_over;
@@ -1642,34 +1653,19 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         in_tail = false;
                     }
                 }
-                if (search_over) done = true;
-            }
-        }
-        // ---- round end: flush the buffered hits of the wave with one reservation
-        if (!(dev_flags & 1)) {
-            const uint32_t mine = nh < kHitBuf ? nh : kHitBuf;
-            const uint32_t before = wave_excl_scan(mine, lane);
-            const uint32_t total = __shfl(before + mine, 63, 64);
-            unsigned long long slot = 0;
-            if (lane == 0 && total) slot = atomicAdd(&ctr->hits, (unsigned long long)total);
-            slot = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(slot >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)slot);
-            for (uint32_t k = 0; k < mine; ++k) {
-                const uint32_t* h = s_hits + (size_t)k * 5u * 256u + threadIdx.x;
-                const unsigned long long at = slot + before + k;
-                if (at < cap) {
-                    fmgpu_hit rec;
-                    rec.qidx = q; rec.lb = h[0]; rec.lb_rev = h[256]; rec.len = h[512]; rec.errors = h[768]; rec.seq = h[1024];
-                    out[at] = rec;
+                if (search_over) {                                  // the next search of the scheme, or the lane is out of work
+                    ++si;
+                    if (si == S || query_over) have = false; else need_start = true;
                 }
             }
-        } else if (nh) atomicAdd(&ctr->hits, (unsigned long long)nh);
-        tbytes += 40u * nh; tacc += nh;                            // the hit records written
+        }
     }
     uint32_t tot = wave_sum(nodes);
-    const unsigned long long tb = wave_sum64(tbytes); const uint32_t ta = wave_sum(tacc);
-    if ((threadIdx.x & 63u) == 0 && tot) {
+    const unsigned long long tb = wave_sum64(tbytes); const uint32_t ta = wave_sum(tacc), co = wave_sum(count_only);
+    if ((threadIdx.x & 63u) == 0 && (tot || co)) {
         atomicAdd(&ctr->nodes, (unsigned long long)tot);
         atomicAdd(&ctr->table_bytes, tb); atomicAdd(&ctr->table_accesses, (unsigned long long)ta);
+        if (co) atomicAdd(&ctr->hits, (unsigned long long)co);
     }
 }
 
@@ -2524,7 +2520,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             if (use_wj) { fa.wj_fw = x->bwt.walkj; fa.wj_rv = x->rev.walkj; }
             fa.lut = b.lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = b.lut_ok;
             for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
-            const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (edit ? (size_t)kWaveHitWords * 4 : (size_t)kHitBuf * 5 * 256 * 4);
+            const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (size_t)kWaveHitWords * 4;
             FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));   // the fast kernel hands out 64-query rounds from 0
             const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ws.grid, (b.count + 255) / 256)));
             const uint32_t* qm = d_qmap ? d_qmap + b.first : nullptr;

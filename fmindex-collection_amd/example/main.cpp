@@ -1,4 +1,4 @@
-// The reference's `example` harness (src/example/main.cpp:21-275, argp.h:11-107, utils.h:27-105) on the GPU path:
+// The reference's `example` harness (src/example/main.cpp, with its command line and FASTA reader) on the GPU path — same behaviour, own code:
 // FASTA -> ranks, reverse complements, BiFMIndex<5, InterleavedBitvector16> at sampling rate 16, one search per k in
 // [min_k, max_k] with the chosen algorithm and search-scheme generator, LocateLinear of every reported cursor, the same
 // statistics line and the same `--save_output` file ("queryId seqId pos" per located row, in callback order).
@@ -13,10 +13,13 @@
 #include "../../include/fmc_gpu.hpp"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <filesystem>
 #include <fstream>
+#include <iterator>
+#include <cstdlib>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -25,135 +28,155 @@
 
 namespace {
 
-struct Config {                                                   // argp.h:11-36
-    std::string generator = "h2-k2";
-    bool generator_dyn = false;
-    size_t maxQueries{};
-    size_t readLength{};
-    std::string saveOutput;
-    size_t minK{0}, maxK{6}, k_stepSize{1};
-    bool reverse{true};
-    bool help{false};
-    bool convertUnknownChar{false};
+// ---- command line --------------------------------------------------------------------------------------------------------------
+// What the reference's example accepts (its argp.h), described as a table: flag, whether a value follows, what the value does.  Numbers are
+// read as floating point and truncated, so "--queries 1e5" works as it does there; a flag that needs a value but is the last token, and any
+// token that is no flag, is reported as "unknown commandline <token>".
+enum class HitMode { all, besthits };
+struct Options {
+    std::string referenceFasta, readsFasta, outputFile;
     std::vector<std::string> algorithms;
-    std::string queryPath{};
-    std::string indexPath{};
-    enum class Mode { All, BestHits };
-    Mode mode{Mode::All};
-    size_t maxHitsPerQuery{0};
+    std::string schemeName = "h2-k2";
+    bool schemeDyn = false;
+    size_t firstK = 0, lastK = 6, stepK = 1;
+    size_t readLimit = 0, trimTo = 0, hitsPerRead = 0;          // 0 = no limit
+    bool withReverseComplement = true, unknownToA = false, wantHelp = false;
+    HitMode hitMode = HitMode::all;
 };
 
-Config loadConfig(int argc, char const* const* argv) {            // argp.h:38-107
-    Config config;
-    for (int i{1}; i < argc; ++i) {
-        auto a = std::string{argv[i]};
-        bool more = i + 1 < argc;
-        if (a == "--query" && more) config.queryPath = argv[++i];
-        else if (a == "--index" && more) config.indexPath = argv[++i];
-        else if (a == "--algo" && more) config.algorithms.emplace_back(argv[++i]);
-        else if (a == "--ext" && more) ++i;
-        else if (a == "--gen" && more) {
-            config.generator = argv[++i];
-            if (config.generator.size() > 4 && config.generator.substr(config.generator.size() - 4) == "_dyn") {
-                config.generator = config.generator.substr(0, config.generator.size() - 4);
-                config.generator_dyn = true;
+size_t asCount(char const* text) { return static_cast<size_t>(std::strtod(text, nullptr)); }
+
+struct FlagRule {
+    char const* name;
+    bool takesValue;
+    void (*apply)(Options&, char const*);
+};
+FlagRule const kFlags[] = {
+    {"--index", true, [](Options& o, char const* v) { o.referenceFasta = v; }},
+    {"--query", true, [](Options& o, char const* v) { o.readsFasta = v; }},
+    {"--save_output", true, [](Options& o, char const* v) { o.outputFile = v; }},
+    {"--algo", true, [](Options& o, char const* v) { o.algorithms.emplace_back(v); }},
+    {"--gen", true, [](Options& o, char const* v) {
+         o.schemeName = v;
+         static std::string const suffix = "_dyn";
+         if (o.schemeName.size() > suffix.size() && o.schemeName.compare(o.schemeName.size() - suffix.size(), suffix.size(), suffix) == 0) {
+             o.schemeName.erase(o.schemeName.size() - suffix.size());
+             o.schemeDyn = true;
+         }
+     }},
+    {"--min_k", true, [](Options& o, char const* v) { o.firstK = asCount(v); }},
+    {"--max_k", true, [](Options& o, char const* v) { o.lastK = asCount(v); }},
+    {"--stepSize_k", true, [](Options& o, char const* v) { o.stepK = asCount(v); }},
+    {"--queries", true, [](Options& o, char const* v) { o.readLimit = asCount(v); }},
+    {"--read_length", true, [](Options& o, char const* v) { o.trimTo = asCount(v); }},
+    {"--maxhitperquery", true, [](Options& o, char const* v) { o.hitsPerRead = asCount(v); }},
+    {"--mode", true, [](Options& o, char const* v) {
+         std::string const m = v;
+         if (m == "all") o.hitMode = HitMode::all;
+         else if (m == "besthits") o.hitMode = HitMode::besthits;
+         else throw std::runtime_error("invalid mode \"" + m + "\", must be any of \"all\", \"besthits\"");
+     }},
+    {"--no-reverse", false, [](Options& o, char const*) { o.withReverseComplement = false; }},
+    {"--convertUnknownChar", false, [](Options& o, char const*) { o.unknownToA = true; }},
+    {"--help", false, [](Options& o, char const*) { o.wantHelp = true; }},
+    // accepted for compatibility; nothing to switch in this build (no index cache file, no host threads, one String type)
+    {"--ext", true, [](Options&, char const*) {}},
+    {"--threads", true, [](Options&, char const*) {}},
+    {"--partialBuildUp", false, [](Options&, char const*) {}},
+};
+
+Options parseCommandLine(int argc, char const* const* argv) {
+    Options o;
+    for (int at = 1; at < argc; ++at) {
+        std::string const token = argv[at];
+        FlagRule const* rule = nullptr;
+        for (auto const& f : kFlags) if (token == f.name) { rule = &f; break; }
+        if (!rule || (rule->takesValue && at + 1 >= argc)) throw std::runtime_error("unknown commandline " + token);
+        rule->apply(o, rule->takesValue ? argv[++at] : nullptr);
+    }
+    return o;
+}
+
+// ---- FASTA ------------------------------------------------------------------------------------------------------------------------
+// The reader the example uses, by its observable rules: the file must begin with '>'; a name line runs to the next newline; every other
+// byte of a record is a symbol — $ A C G T (either case) are ranks 0..4, N is rank 5 when the alphabet has six symbols, newlines are
+// dropped, any other byte is rank 1 (5 with six symbols) under --convertUnknownChar and an "unknown alphabet" error without it; a '>'
+// anywhere in the sequence part starts the next record; the very last byte of the file ends the last record and is never a symbol itself
+// (a file whose last line has no newline loses its last base); a name line that runs to the end of the file yields no record.
+enum ByteClass : uint8_t { kSymbol0 = 0, /* 1..5: that rank */ kSkip = 6, kOther = 7 };
+std::array<uint8_t, 256> byteClasses(size_t sigma) {
+    std::array<uint8_t, 256> t;
+    t.fill(kOther);
+    t[static_cast<unsigned char>('\n')] = kSkip;
+    t[static_cast<unsigned char>('$')] = 0;
+    char const* letters = "ACGT";
+    for (uint8_t r = 0; r < 4; ++r) {
+        t[static_cast<unsigned char>(letters[r])] = static_cast<uint8_t>(r + 1);
+        t[static_cast<unsigned char>(letters[r] - 'A' + 'a')] = static_cast<uint8_t>(r + 1);
+    }
+    if (sigma == 6) t[static_cast<unsigned char>('N')] = t[static_cast<unsigned char>('n')] = 5;
+    return t;
+}
+
+std::vector<std::vector<uint8_t>> readFasta(std::string const& path, size_t sigma, bool unknownToA) {
+    std::vector<std::vector<uint8_t>> records;
+    if (path.empty() || !std::filesystem::exists(path)) return records;
+    std::ifstream in{path, std::ios::binary};
+    std::vector<char> bytes{std::istreambuf_iterator<char>{in}, std::istreambuf_iterator<char>{}};
+    if (bytes.empty() || bytes[0] != '>') throw std::runtime_error("can't read fasta file");
+    auto const classes = byteClasses(sigma);
+    uint8_t const fallback = sigma == 6 ? 5 : 1;
+    size_t const size = bytes.size();
+    size_t at = 0;
+    while (at < size) {                                            // `at` stands on the '>' of a name line
+        while (at < size && bytes[at] != '\n') ++at;
+        ++at;                                                      // first byte of the sequence part
+        if (at >= size) break;
+        std::vector<uint8_t> ranks;
+        for (; at + 1 < size && bytes[at] != '>'; ++at) {
+            uint8_t const cls = classes[static_cast<unsigned char>(bytes[at])];
+            if (cls < kSkip) ranks.push_back(cls);
+            else if (cls == kOther) {
+                if (!unknownToA) throw std::runtime_error("unknown alphabet");
+                ranks.push_back(fallback);
             }
         }
-        else if (a == "--queries" && more) config.maxQueries = static_cast<size_t>(std::stod(argv[++i]));
-        else if (a == "--threads" && more) ++i;
-        else if (a == "--read_length" && more) config.readLength = static_cast<size_t>(std::stod(argv[++i]));
-        else if (a == "--save_output" && more) config.saveOutput = argv[++i];
-        else if (a == "--min_k" && more) config.minK = static_cast<size_t>(std::stod(argv[++i]));
-        else if (a == "--max_k" && more) config.maxK = static_cast<size_t>(std::stod(argv[++i]));
-        else if (a == "--stepSize_k" && more) config.k_stepSize = static_cast<size_t>(std::stod(argv[++i]));
-        else if (a == "--no-reverse") config.reverse = false;
-        else if (a == "--help") config.help = true;
-        else if (a == "--partialBuildUp") {}
-        else if (a == "--convertUnknownChar") config.convertUnknownChar = true;
-        else if (a == "--mode" && more) {
-            auto s = std::string{argv[++i]};
-            if (s == "all") config.mode = Config::Mode::All;
-            else if (s == "besthits") config.mode = Config::Mode::BestHits;
-            else throw std::runtime_error("invalid mode \"" + s + "\", must be any of \"all\", \"besthits\"");
-        }
-        else if (a == "--maxhitperquery" && more) config.maxHitsPerQuery = static_cast<size_t>(std::stod(argv[++i]));
-        else throw std::runtime_error("unknown commandline " + a);
+        records.push_back(std::move(ranks));
+        if (at + 1 >= size) break;                                 // stopped on the last byte of the file
     }
-    return config;
+    return records;
 }
 
-std::vector<uint8_t> readFile(std::string const& file) {
-    auto ifs = std::ifstream{file, std::ios::binary};
-    ifs.seekg(0, std::ios::end);
-    auto buffer = std::vector<uint8_t>(static_cast<size_t>(ifs.tellg()));
-    ifs.seekg(0, std::ios::beg);
-    ifs.read(reinterpret_cast<char*>(buffer.data()), static_cast<std::streamsize>(buffer.size()));
-    return buffer;
-}
-
-// utils.h:27-105: '>' lines are names, every other byte is a symbol ($ACGT -> 0..4, N -> 5 only for Sigma 6, newlines skipped, anything else
-// rank 1 under --convertUnknownChar or an error); a record ends at the next '>' or at the LAST byte of the file, which is never read as
-// a symbol (a file that does not end in a newline loses its last base, as in the reference).
-template <size_t Sigma>
-auto loadQueries(std::string const& path, bool reverse, bool convertUnknownChar) {
-    std::vector<std::vector<uint8_t>> queries;
-    std::vector<std::pair<std::string, bool>> queryInfos;
-    if (path.empty() || !std::filesystem::exists(path)) return std::make_tuple(queries, queryInfos);
-    auto b = readFile(path);
-    if (b.empty() || b[0] != '>') throw std::runtime_error("can't read fasta file");
-    auto ptr = b.data();
-    auto const end = b.data() + b.size();
-    std::vector<uint8_t> query;
-    bool inName = true;
-    while (ptr != end) {
-        if (inName) {
-            std::string name;
-            if (*ptr != '>') throw std::runtime_error("expected '>'");
-            ++ptr;
-            if (ptr != end && *ptr == ' ') ++ptr;
-            while (ptr != end && *ptr != '\n') { name += static_cast<char>(*ptr); ++ptr; }
-            if (ptr != end) ++ptr;
-            inName = false;
-            queryInfos.emplace_back(name, false);
-            if (reverse) queryInfos.emplace_back(name, true);
-        } else if (*ptr == '>' || (ptr + 1) == end) {
-            queries.push_back(query);
-            if (reverse) {
-                std::reverse(query.begin(), query.end());
-                for (auto& c : query) {
-                    if (c == 1) c = 4; else if (c == 2) c = 3; else if (c == 3) c = 2; else if (c == 4) c = 1;
-                }
-                queries.push_back(query);
-            }
-            query.clear();
-            inName = true;
-            if ((ptr + 1) == end) ++ptr;
-        } else {
-            auto ch = *ptr;
-            if (ch == '$') query.push_back(0);
-            else if (ch == 'A' || ch == 'a') query.push_back(1);
-            else if (ch == 'C' || ch == 'c') query.push_back(2);
-            else if (ch == 'G' || ch == 'g') query.push_back(3);
-            else if (ch == 'T' || ch == 't') query.push_back(4);
-            else if ((ch == 'N' || ch == 'n') && Sigma == 6) query.push_back(5);
-            else if (ch == '\n') {}
-            else if (convertUnknownChar) query.push_back(Sigma == 6 ? 5 : 1);
-            else throw std::runtime_error("unknown alphabet");
-            ++ptr;
-        }
+// every read followed by its reverse complement (A <-> T, C <-> G; other ranks stay)
+std::vector<std::vector<uint8_t>> withReverseComplements(std::vector<std::vector<uint8_t>> const& reads) {
+    static uint8_t const complement[6] = {0, 4, 3, 2, 1, 5};
+    std::vector<std::vector<uint8_t>> both;
+    both.reserve(2 * reads.size());
+    for (auto const& r : reads) {
+        both.push_back(r);
+        std::vector<uint8_t> rc(r.rbegin(), r.rend());
+        for (auto& c : rc) if (c < 6) c = complement[c];
+        both.push_back(std::move(rc));
     }
-    return std::make_tuple(queries, queryInfos);
+    return both;
 }
 
-fmc::search_scheme::Scheme generate(std::string const& name, size_t minK, size_t maxK) {   // generator/all.h:35-96, the entries this build has
+// ---- search-scheme generators by name (the ones this build has; the reference's list is search_scheme/generator/all.h:35-96) ----------------
+fmc::search_scheme::Scheme schemeByName(std::string const& name, size_t minErrors, size_t maxErrors) {
     namespace g = fmc::search_scheme::generator;
-    if (name == "backtracking") return g::backtracking(1, minK, maxK);
-    if (name == "pigeon") return g::pigeon_trivial(minK, maxK);
-    if (name == "pigeon_opt") return g::pigeon_opt(minK, maxK);
-    if (name == "h2-k1") return g::h2(maxK + 1, minK, maxK);
-    if (name == "h2-k2") return g::h2(maxK + 2, minK, maxK);
-    if (name == "h2-k3") return g::h2(maxK + 3, minK, maxK);
-    throw std::runtime_error("unknown search scheme generetaror \"" + name + "\"");
+    struct Entry { char const* name; fmc::search_scheme::Scheme (*make)(size_t, size_t); };
+    static Entry const table[] = {
+        {"backtracking", [](size_t lo, size_t hi) { return g::backtracking(1, lo, hi); }},
+        {"pigeon", [](size_t lo, size_t hi) { return g::pigeon_trivial(lo, hi); }},
+        {"pigeon_opt", [](size_t lo, size_t hi) { return g::pigeon_opt(lo, hi); }},
+        {"h2-k1", [](size_t lo, size_t hi) { return g::h2(hi + 1, lo, hi); }},
+        {"h2-k2", [](size_t lo, size_t hi) { return g::h2(hi + 2, lo, hi); }},
+        {"h2-k3", [](size_t lo, size_t hi) { return g::h2(hi + 3, lo, hi); }},
+    };
+    for (auto const& e : table) if (name == e.name) return e.make(minErrors, maxErrors);
+    std::string known;
+    for (auto const& e : table) known += std::string(known.empty() ? "" : ", ") + e.name;
+    throw std::runtime_error("unknown search scheme generator \"" + name + "\" (this build has: " + known + ")");
 }
 
 struct StopWatch {
@@ -170,8 +193,8 @@ struct StopWatch {
 
 int main(int argc, char const* const* argv) try {
     constexpr size_t Sigma = 5;
-    auto config = loadConfig(argc, argv);
-    if (config.help) {
+    auto config = parseCommandLine(argc, argv);
+    if (config.wantHelp) {
         std::printf("Usage:\n"
                     "./example --index somefile.fasta\n"
                     "   this will only build the index for somefile.fasta (on the GPU; nothing is written)\n"
@@ -191,8 +214,9 @@ int main(int argc, char const* const* argv) try {
                     "          --maxhitperquery <int> (some int, 0 = infinite hits)\n");
         return 0;
     }
-    if (config.generator_dyn) throw std::runtime_error("the _dyn generators (expandByWNC) are not part of this build");
-    auto const [queries, queryInfos] = loadQueries<Sigma>(config.queryPath, config.reverse, config.convertUnknownChar);
+    if (config.schemeDyn) throw std::runtime_error("the _dyn generators (expandByWNC) are not part of this build");
+    auto const forward = readFasta(config.readsFasta, Sigma, config.unknownToA);
+    auto const queries = config.withReverseComplement ? withReverseComplements(forward) : forward;
     if (!queries.empty()) {
         std::printf("loaded %zu queries (incl reverse complements)\n", queries.size());
         std::printf("%-15s: %10s  (%10s +%10s ) %10s    - results: %10s/%10s/%10s/%10s - mem: %13s\n", "name", "time_search + time_locate", "time_search",
@@ -205,8 +229,8 @@ int main(int argc, char const* const* argv) try {
     size_t samplingRate = 16;
     using Index = fmc::BiFMIndex<Sigma, fmc::string::InterleavedBitvector16>;
     auto index = [&]() {                                          // loadDenseIndex, utils.h:150-259 (always the build branch)
-        auto [ref, refInfo] = loadQueries<Sigma>(config.indexPath, false, config.convertUnknownChar);
-        if (ref.empty()) throw std::runtime_error("no sequences in --index " + config.indexPath);
+        auto ref = readFasta(config.referenceFasta, Sigma, config.unknownToA);
+        if (ref.empty()) throw std::runtime_error("no sequences in --index " + config.referenceFasta);
         return Index{ref, samplingRate, 1};
     }();
     std::printf("done\n");
@@ -216,16 +240,16 @@ int main(int argc, char const* const* argv) try {
         if (algorithm != "ng21" && algorithm != "ng26" && algorithm != "noerror")
             throw std::runtime_error("algorithm \"" + algorithm + "\" is not part of this build (available: ng21, ng26, noerror)");
         auto mut_queries = queries;
-        if (config.maxQueries != 0) mut_queries.resize(std::min(mut_queries.size(), config.maxQueries));
-        if (config.readLength != 0) for (auto& q : mut_queries) q.resize(std::min(config.readLength, q.size()));
+        if (config.readLimit != 0) mut_queries.resize(std::min(mut_queries.size(), config.readLimit));
+        if (config.trimTo != 0) for (auto& q : mut_queries) q.resize(std::min(config.trimTo, q.size()));
         if (mut_queries.empty()) continue;
 
-        for (size_t k{config.minK}; k <= config.maxK; k = k + config.k_stepSize) {
+        for (size_t k{config.firstK}; k <= config.lastK; k = k + config.stepK) {
             auto len = mut_queries[0].size();
-            auto oss = generate(config.generator, 0, k);
+            auto oss = schemeByName(config.schemeName, 0, k);
             auto search_scheme = fmc::search_scheme::expand(oss, len);
             auto search_schemes = std::vector<fmc::search_scheme::Scheme>{};
-            for (size_t j{0}; j <= k; ++j) search_schemes.emplace_back(fmc::search_scheme::expand(generate(config.generator, j, j), len));
+            for (size_t j{0}; j <= k; ++j) search_schemes.emplace_back(fmc::search_scheme::expand(schemeByName(config.schemeName, j, j), len));
 
             size_t resultCt{};
             StopWatch sw;
@@ -234,19 +258,19 @@ int main(int argc, char const* const* argv) try {
             auto res_cb = [&](size_t queryId, auto cursor, size_t errors) { resultCursors.emplace_back(queryId, cursor, errors); };
 
             if (algorithm == "ng21") {                            // main.cpp:176-185
-                if (config.mode == Config::Mode::All) {
-                    if (config.maxHitsPerQuery == 0) fmc::search_ng21::search(index, mut_queries, search_scheme, res_cb);
-                    else fmc::search_ng21::search_n(index, mut_queries, search_scheme, config.maxHitsPerQuery, res_cb);
+                if (config.hitMode == HitMode::all) {
+                    if (config.hitsPerRead == 0) fmc::search_ng21::search(index, mut_queries, search_scheme, res_cb);
+                    else fmc::search_ng21::search_n(index, mut_queries, search_scheme, config.hitsPerRead, res_cb);
                 } else {
-                    if (config.maxHitsPerQuery == 0) fmc::search_ng21::search_best(index, mut_queries, search_schemes, res_cb);
-                    else fmc::search_ng21::search_best_n(index, mut_queries, search_schemes, config.maxHitsPerQuery, res_cb);
+                    if (config.hitsPerRead == 0) fmc::search_ng21::search_best(index, mut_queries, search_schemes, res_cb);
+                    else fmc::search_ng21::search_best_n(index, mut_queries, search_schemes, config.hitsPerRead, res_cb);
                 }
             } else if (algorithm == "ng26") {
-                auto n = config.maxHitsPerQuery == 0 ? std::numeric_limits<size_t>::max() : config.maxHitsPerQuery;
-                if (config.mode == Config::Mode::All) fmc::search_ng26::search<true>(index, mut_queries, oss, {}, res_cb, n);
+                auto n = config.hitsPerRead == 0 ? std::numeric_limits<size_t>::max() : config.hitsPerRead;
+                if (config.hitMode == HitMode::all) fmc::search_ng26::search<true>(index, mut_queries, oss, {}, res_cb, n);
                 else {
                     auto list = std::vector<std::tuple<fmc::search_scheme::Scheme, std::vector<size_t>>>{};
-                    for (size_t j{0}; j <= k; ++j) list.emplace_back(generate(config.generator, j, j), std::vector<size_t>{});
+                    for (size_t j{0}; j <= k; ++j) list.emplace_back(schemeByName(config.schemeName, j, j), std::vector<size_t>{});
                     fmc::search_ng26::search_best<true>(index, mut_queries, list, res_cb, n);
                 }
             } else {                                              // noerror, main.cpp:213-215
@@ -282,9 +306,9 @@ int main(int argc, char const* const* argv) try {
             std::printf("%-15s %3zu: %10.3gs (%10.3gs+%10.3gs) %10.3gq/s - results: %10zu/%10zu/%10zu/%10zu - mem: %13zu\n", name.c_str(), k,
                         time_search + time_locate, time_search, time_locate, mut_queries.size() / (time_search + time_locate), resultCt, results.size(),
                         uniqueResults.size(), readIds.size(), size_t{0});
-            if (!config.saveOutput.empty()) {
-                auto ofs = std::fopen(config.saveOutput.c_str(), "w");
-                if (!ofs) throw std::runtime_error("cannot write " + config.saveOutput);
+            if (!config.outputFile.empty()) {
+                auto ofs = std::fopen(config.outputFile.c_str(), "w");
+                if (!ofs) throw std::runtime_error("cannot write " + config.outputFile);
                 for (auto const& [queryId, seqId, pos, e] : results) std::fprintf(ofs, "%zu %zu %zu\n", queryId, seqId, pos);
                 std::fclose(ofs);
             }

@@ -1,7 +1,8 @@
 // fmc_gpu.hpp — C++ host mirror of the reference's template API for the backward-search path, on top of the C-ABI
 // (include/fmgpu.h, libfmgpu.so).  Header-only, C++17.  Same names, argument meaning and error behaviour as
 // SGSSGene/fmindex-collection for: FMIndex / BiFMIndex (fmindex/FMIndex.h:14-134, fmindex/BiFMIndex.h:17-216), their cursors
-// (fmindex/FMIndexCursor.h, fmindex/BiFMIndexCursor.h: lb, lbRev, len, steps, count(), empty(), begin/end),
+// (fmindex/FMIndexCursor.h, fmindex/BiFMIndexCursor.h: lb, lbRev, len, steps, count(), empty(), begin/end, extendLeft / extendRight with and
+// without a symbol, symbolLeft / symbolRight), single_locate_step, fmc::Search{...}(),
 // search_no_errors::search (search/SearchNoErrors.h), search_backtracking::search (search/Backtracking.h),
 // search_ng26::search (search/SearchNg26.h:426-444), fmc::search<Edit> (search/search.h:26-35), LocateLinear (locate.h:14-57),
 // search_scheme::{Search, Scheme, generator::{h2, pigeon_opt, pigeon_trivial, backtracking}, createUniformPartition, expand,
@@ -106,6 +107,12 @@ struct GpuIndexBase {
         detail::check(fmgpu_locate(handle, &row, 1, &seq, &pos, &steps, nullptr, nullptr));
         return {static_cast<uint32_t>(seq), static_cast<uint32_t>(pos), static_cast<size_t>(steps)};
     }
+    // single_locate_step(idx) (fmindex/FMIndex.h:126-128): the sampled entry of row idx, if that row is sampled
+    auto single_locate_step(size_t idx) const -> std::optional<std::tuple<uint32_t, uint32_t>> {
+        auto [seq, pos, steps] = locate(idx);
+        if (steps != 0) return std::nullopt;
+        return std::tuple<uint32_t, uint32_t>{seq, pos};
+    }
     auto locate(std::vector<uint64_t> const& rows) const -> std::vector<LEntry> {
         std::vector<uint64_t> seq(rows.size()), pos(rows.size()), steps(rows.size());
         detail::check(fmgpu_locate(handle, rows.data(), rows.size(), seq.data(), pos.data(), steps.data(), nullptr, nullptr));
@@ -131,22 +138,74 @@ struct IntIterator {   // utils.h:656-669
     auto operator++() -> IntIterator& { ++i; return *this; }
     bool operator!=(IntIterator const& o) const { return i != o.i; }
 };
+namespace detail {
+// one cursor step on the device (fmgpu_cursor_extend): symb < 0 = every symbol
+inline void extend(fmgpu_index_t h, int direction, uint64_t lb, uint64_t lbRev, uint64_t len, int symb, bool bidir, uint64_t* olb, uint64_t* orev, uint64_t* olen) {
+    uint8_t c = static_cast<uint8_t>(symb < 0 ? 0 : symb);
+    check(fmgpu_cursor_extend(h, direction, 1, &lb, bidir ? &lbRev : nullptr, &len, symb < 0 ? nullptr : &c, olb, bidir ? orev : nullptr, olen, nullptr));
+}
+inline size_t symbol_at(fmgpu_index_t h, int which, uint64_t row) {
+    uint8_t what = 2; uint64_t out{};
+    check(fmgpu_string_query(h, which, &row, nullptr, &what, 1, &out, nullptr));
+    return static_cast<size_t>(out);
+}
+}  // namespace detail
+
+// Single cursor steps go through the batched device call one cursor at a time: they are here so that code written against the reference's cursor
+// API runs unchanged (tests, small tools); a search loop belongs into the batched search calls below.
 template <typename Index>
-struct FMIndexCursor {
+struct FMIndexCursor {   // fmindex/FMIndexCursor.h:12-63
     static constexpr size_t Sigma = Index::Sigma;
     Index const* index{};
     size_t lb{}, len{};
+    FMIndexCursor() = default;
+    explicit FMIndexCursor(Index const& idx) : index{&idx}, lb{0}, len{idx.size()} {}
+    FMIndexCursor(Index const& idx, size_t lb_, size_t len_) : index{&idx}, lb{lb_}, len{len_} {}
     bool empty() const { return len == 0; }
     size_t count() const { return len; }
+    auto extendLeft(size_t symb) const -> FMIndexCursor {                            // :33-37
+        uint64_t nlb{}, nlen{};
+        detail::extend(index->handle, 0, lb, 0, len, static_cast<int>(symb), false, &nlb, nullptr, &nlen);
+        return FMIndexCursor{*index, static_cast<size_t>(nlb), static_cast<size_t>(nlen)};
+    }
+    auto extendLeft() const -> std::array<FMIndexCursor, Sigma> {                    // :38-53
+        std::array<uint64_t, Sigma> nlb{}, nlen{};
+        detail::extend(index->handle, 0, lb, 0, len, -1, false, nlb.data(), nullptr, nlen.data());
+        std::array<FMIndexCursor, Sigma> out;
+        for (size_t c = 0; c < Sigma; ++c) out[c] = FMIndexCursor{*index, static_cast<size_t>(nlb[c]), static_cast<size_t>(nlen[c])};
+        return out;
+    }
 };
 template <typename Index>
-struct BiFMIndexCursor {
+struct BiFMIndexCursor {   // fmindex/BiFMIndexCursor.h:13-191
     static constexpr size_t Sigma = Index::Sigma;
     Index const* index{};
     size_t lb{}, lbRev{}, len{}, steps{};
+    BiFMIndexCursor() = default;
+    explicit BiFMIndexCursor(Index const& idx) : index{&idx}, lb{0}, lbRev{0}, len{idx.size()}, steps{0} {}
+    BiFMIndexCursor(Index const& idx, size_t lb_, size_t lbRev_, size_t len_, size_t steps_) : index{&idx}, lb{lb_}, lbRev{lbRev_}, len{len_}, steps{steps_} {}
     bool empty() const { return len == 0; }
     size_t count() const { return len; }
     bool operator==(BiFMIndexCursor const& o) const noexcept { return lb == o.lb && len == o.len; }
+    auto extendLeft(size_t symb) const -> BiFMIndexCursor { return step(0, symb); }   // :113-120
+    auto extendRight(size_t symb) const -> BiFMIndexCursor { return step(1, symb); }  // :121-128
+    auto extendLeft() const -> std::array<BiFMIndexCursor, Sigma> { return fan(0); }  // :58-69
+    auto extendRight() const -> std::array<BiFMIndexCursor, Sigma> { return fan(1); } // :71-82
+    auto symbolLeft() const -> size_t { return detail::symbol_at(index->handle, 0, lb); }      // :180-184
+    auto symbolRight() const -> size_t { return detail::symbol_at(index->handle, 1, lbRev); }  // :186-190
+private:
+    auto step(int direction, size_t symb) const -> BiFMIndexCursor {
+        uint64_t nlb{}, nrev{}, nlen{};
+        detail::extend(index->handle, direction, lb, lbRev, len, static_cast<int>(symb), true, &nlb, &nrev, &nlen);
+        return BiFMIndexCursor{*index, static_cast<size_t>(nlb), static_cast<size_t>(nrev), static_cast<size_t>(nlen), steps + 1};
+    }
+    auto fan(int direction) const -> std::array<BiFMIndexCursor, Sigma> {
+        std::array<uint64_t, Sigma> nlb{}, nrev{}, nlen{};
+        detail::extend(index->handle, direction, lb, lbRev, len, -1, true, nlb.data(), nrev.data(), nlen.data());
+        std::array<BiFMIndexCursor, Sigma> out;
+        for (size_t c = 0; c < Sigma; ++c) out[c] = BiFMIndexCursor{*index, static_cast<size_t>(nlb[c]), static_cast<size_t>(nrev[c]), static_cast<size_t>(nlen[c]), steps + 1};
+        return out;
+    }
 };
 template <typename C> auto begin(C const& c) -> decltype(IntIterator{c.lb}) { return IntIterator{c.lb}; }
 template <typename C> auto end(C const& c) -> decltype(IntIterator{c.lb + c.len}) { return IntIterator{c.lb + c.len}; }
@@ -550,5 +609,30 @@ struct LocateLinear {
     auto end() const { return entries.end(); }
 };
 template <typename Index, typename Cursor> LocateLinear(Index const&, Cursor const&) -> LocateLinear<Index, Cursor>;
+
+// fmc::Search{index, queries, editDistance, errors, maxResults, reportFunc}() — search/search.h:48-75: searches, locates every row of every
+// reported cursor and calls reportFunc(qidx, seqId, pos + offset, errors)
+template <typename index_t, typename queries_t, typename delegate_t>
+struct Search {
+    index_t const&        index;
+    queries_t const&      queries;
+    bool                  editDistance{true};
+    size_t                errors{0};
+    std::optional<size_t> maxResults{};
+    delegate_t const&     reportFunc;
+    void operator()() {
+        auto report = [&](size_t qidx, auto const& cursor, size_t e) {
+            for (auto [sid, spos, offset] : LocateLinear{index, cursor}) reportFunc(qidx, sid, spos + offset, e);
+        };
+        if (maxResults) {
+            if (editDistance) search_n<true>(index, queries, errors, *maxResults, report);
+            else search_n<false>(index, queries, errors, *maxResults, report);
+        } else {
+            if (editDistance) search<true>(index, queries, errors, report);
+            else search<false>(index, queries, errors, report);
+        }
+    }
+};
+template <typename I, typename Q, typename D> Search(I const&, Q const&, bool, size_t, std::optional<size_t>, D const&) -> Search<I, Q, D>;
 
 }  // namespace fmc

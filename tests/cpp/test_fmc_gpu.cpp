@@ -1,9 +1,10 @@
 // The reference's own tests for the path, re-stated against include/fmc_gpu.hpp (same calls, same expected values):
 // search/checkSearches.cpp:14-72, :104-117, :1173-1199; search/checkSearchBacktracking.cpp:42-102; fmindex/checkBiFMIndexCursor.cpp:12-30;
-// search_scheme/expand.cpp:11-60; search_scheme/checkGeneratorsIsComplete.cpp:48-60.  Needs a GPU; exit code 0 = all checks passed.
+// fmindex/checkBiFMIndexCursor.cpp:12-103; fmindex/checkFMIndexCursor.cpp:13-66; search_scheme/expand.cpp:11-60; search_scheme/checkGeneratorsIsComplete.cpp:48-60.  Needs a GPU; exit code 0 = all checks passed.
 #include "../../include/fmc_gpu.hpp"
 
 #include <cstdio>
+#include <optional>
 #include <tuple>
 #include <vector>
 
@@ -178,6 +179,63 @@ int main() {
                 if (sid == 0 && spos + offset == qidx * 49) { ++found; CHECK(errors == (qidx == 2 ? 1u : 0u)); }
         });
         CHECK(found == reads.size());
+    }
+    {   // fmindex/checkBiFMIndexCursor.cpp:12-103 and checkFMIndexCursor.cpp: single cursor steps through the mirror
+        auto data = std::vector<std::vector<uint8_t>>{std::vector<uint8_t>{1, 1, 1, 1, 2, 2, 2}};
+        using Index = fmc::BiFMIndex<256>;
+        auto index = Index{data, 1, 1};
+        auto cursor = fmc::BiFMIndexCursor{index};
+        CHECK(cursor.count() == index.size()); CHECK(!cursor.empty()); CHECK(cursor.lb == 0); CHECK(cursor.len == index.size());
+        size_t const want_count[4] = {1, 4, 3, 0}, want_lb[4] = {0, 1, 5, 8};
+        for (size_t c = 0; c < 4; ++c) {
+            auto l = cursor.extendLeft(c), r = cursor.extendRight(c);
+            CHECK(l.count() == want_count[c]); CHECK(l.lb == want_lb[c]);
+            CHECK(r.count() == want_count[c]); CHECK(r.lb == want_lb[c]);
+            CHECK(l.steps == 1); CHECK(r.steps == 1);
+        }
+        auto allL = cursor.extendLeft(), allR = cursor.extendRight();
+        for (size_t i = 0; i < 256; ++i) {
+            auto l = cursor.extendLeft(i), r = cursor.extendRight(i);
+            CHECK(l.index == allL[i].index); CHECK(l.lb == allL[i].lb); CHECK(l.len == allL[i].len); CHECK(l.lbRev == allL[i].lbRev);
+            CHECK(r.index == allR[i].index); CHECK(r.lb == allR[i].lb); CHECK(r.len == allR[i].len); CHECK(r.lbRev == allR[i].lbRev);
+        }
+        size_t seen = 0, sum = 0;
+        for (auto pos : cursor) { ++seen; sum += pos; }
+        CHECK(seen == 8); CHECK(sum == 28);
+        // a two-step walk: "21" occurs once (text 1111222$): left then right extension meet the same interval
+        auto a = cursor.extendLeft(2).extendLeft(1), b = cursor.extendRight(1).extendRight(2);
+        CHECK(a.count() == 1); CHECK(b.count() == 1); CHECK(a.lb == b.lb); CHECK(a.lbRev == b.lbRev); CHECK(a.steps == 2);
+        CHECK(a.symbolLeft() == 1); CHECK(a.symbolRight() == 2);                         // the symbols around the one occurrence of "12": 1 [12] 2
+        // unidirectional twin (fmindex/checkFMIndexCursor.cpp:13-66)
+        auto fidx = fmc::FMIndex<256>{data, 1, 1};
+        auto fc = fmc::FMIndexCursor{fidx};
+        for (size_t c = 0; c < 4; ++c) { auto l = fc.extendLeft(c); CHECK(l.count() == want_count[c]); CHECK(l.lb == want_lb[c]); }
+        auto fall = fc.extendLeft();
+        for (size_t i = 0; i < 256; ++i) { auto l = fc.extendLeft(i); CHECK(l.lb == fall[i].lb); CHECK(l.len == fall[i].len); }
+        // single_locate_step (fmindex/FMIndex.h:126-128): at sampling rate 1 every row is sampled and equals locate()
+        for (size_t i = 0; i < index.size(); ++i) {
+            auto one = index.single_locate_step(i);
+            auto [sid, spos, off] = index.locate(i);
+            CHECK(one.has_value()); CHECK(off == 0);
+            if (one) { CHECK(std::get<0>(*one) == sid); CHECK(std::get<1>(*one) == spos); }
+        }
+        auto sparse = Index{data, 4, 1};
+        size_t sampled = 0;
+        for (size_t i = 0; i < sparse.size(); ++i) if (sparse.single_locate_step(i)) ++sampled;
+        CHECK(sampled == 2);                                                          // positions 0 and 4 of the one 8-symbol sequence (delimiter included)
+    }
+    {   // fmc::Search{...}() (search/search.h:48-75) against the loop it stands for
+        auto index = fmc::BiFMIndex<256>{input, 1, 1};
+        auto viaStruct = Results{}, viaCalls = Results{};
+        auto rep = [&](size_t qidx, size_t sid, size_t pos, size_t errors) { (void)errors; viaStruct.emplace_back(qidx, sid, pos); };
+        fmc::Search{index, queries, /*editDistance*/ true, /*errors*/ size_t{1}, std::optional<size_t>{}, rep}();
+        fmc::search<true>(index, queries, 1, [&](auto qidx, auto cursor, auto) {
+            for (auto [sid, spos, offset] : fmc::LocateLinear{index, cursor}) viaCalls.emplace_back(qidx, sid, spos + offset);
+        });
+        CHECK(viaStruct == viaCalls); CHECK(viaStruct.size() == 8);
+        viaStruct.clear();
+        fmc::Search{index, queries, /*editDistance*/ false, size_t{1}, std::optional<size_t>{3}, rep}();
+        CHECK(viaStruct.size() == 6);
     }
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "all checks passed", failures);
     return failures ? 1 : 0;
