@@ -1327,7 +1327,11 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
     add_counters(steps_total, steps, tbytes, tacc);
 }
 
-constexpr uint32_t kRefillLanes = 16; // lanes of a wave that must be out of work before the wave fetches and stages new queries together
+// when a wave fetches and stages new queries (a wave-synchronous phase of ~15 loads and LDS stores per lane, paid by all 64 lanes): as soon as
+// kRefillLanes lanes are out of work, or kRefillWait iterations after the first one ran dry — on a uniform text the lanes of a wave finish within
+// a few iterations of each other and one refill serves them all (measured, 10 M reads with tables: refill at 4 / 8 / 16 / 32 / 63 idle lanes =
+// 26 / 17 / 10.7 / 7.7 / 6.4 ms); next to a heavy read the others are re-filled after a bounded wait
+constexpr uint32_t kRefillLanes = 48, kRefillWait = 32;
 
 template <int SIGMA, int MAXSIG>
 __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
@@ -1359,8 +1363,10 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     const uint32_t sigma = fw.sigma(), R = sigma - 1;
     uint32_t nodes = 0;
     uint64_t tbytes = 0; uint32_t tacc = 0;                         // table bytes consumed / table accesses issued (fmgpu_stats)
-    const uint32_t refill_at = ((uint32_t)dev_flags >> 8) & 63u ? ((uint32_t)dev_flags >> 8) & 63u : kRefillLanes;   // (dev knob: bits 8..13)
-    uint32_t nh = 0, count_only = 0;
+    const uint32_t refill_at = ((uint32_t)dev_flags >> 8) & 63u ? ((uint32_t)dev_flags >> 8) & 63u : kRefillLanes;   // (dev knobs: bits 8..13, 16..23)
+    const uint32_t refill_wait = ((uint32_t)dev_flags >> 16) & 255u ? ((uint32_t)dev_flags >> 16) & 255u : kRefillWait;
+    uint32_t dry_iters = 0;                                         // iterations since a lane of the wave ran out of work (wave-uniform)
+    uint32_t nh = 0, count_only = 0, nodes0 = 0;
     bool have = false, exhausted = n == 0, need_start = false, query_over = false;
     uint64_t q = 0, quota = 0;
     const uint8_t* qs = qbuf;
@@ -1372,7 +1378,9 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     for (;;) {
         // ---- wave-synchronous part: every lane passes here in every iteration
         const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
-        if (needm && ((uint32_t)__popcll(needm) >= refill_at || !busym)) {
+        dry_iters = needm ? dry_iters + 1u : 0u;
+        if (needm && ((uint32_t)__popcll(needm) >= refill_at || dry_iters > refill_wait || !busym)) {
+            dry_iters = 0;
             const bool want = !have && !exhausted;
             const uint64_t got = wave_hand_out(want, ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
             bool fresh = false; uint64_t qo = 0;
@@ -1381,7 +1389,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 else { q = qmap ? (uint64_t)qmap[got] : got; qo = qoff[q]; qs = qbuf + qo; fresh = true; }
             }
             qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
-            if (fresh) { have = true; si = 0; need_start = true; quota = max_hits; seq = 0; query_over = false; }
+            if (fresh) { have = true; si = 0; need_start = true; quota = max_hits; seq = 0; query_over = false; nodes0 = nodes; }
         }
         {
             const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(have);
@@ -1655,7 +1663,10 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 }
                 if (search_over) {                                  // the next search of the scheme, or the lane is out of work
                     ++si;
-                    if (si == S || query_over) have = false; else need_start = true;
+                    if (si == S || query_over) {
+                        have = false;
+                        if ((dev_flags & 129) == 129) reinterpret_cast<uint64_t*>(out)[q] = nodes - nodes0;   // dev: nodes per query instead of records (count-only mode)
+                    } else need_start = true;
                 }
             }
         }

@@ -787,45 +787,95 @@ int ora_sparse_value(const ora_sparse* s, uint64_t idx, uint64_t* seq, uint64_t*
  * suffix array (stands in for libsais: utils.h:97-129 — any correct suffix sorter gives
  * the same SA; order = plain byte string order, a proper prefix sorts first)
  * ===================================================================================== */
+/* Prefix doubling, refining only the groups that are still tied (Larsson & Sadakane's scheme with plain sorts): the first round orders all
+ * suffixes by their first 7 symbols (LSD radix sort on the packed key), every later round sorts each tied group by the rank of the suffix h
+ * positions on.  A long run of one symbol costs log2(run) rounds over ITS rows only. */
 typedef struct { uint64_t key; uint32_t idx; } sa_item;
-static int sa_item_cmp(const void* a, const void* b) {
-    const sa_item* x = a; const sa_item* y = b;
-    if (x->key != y->key) return x->key < y->key ? -1 : 1;
-    return 0;
+typedef struct { uint32_t key, idx; } sa_pair;
+typedef struct { uint32_t s, e; } sa_group;
+static int sa_pair_cmp(const void* a, const void* b) {
+    const sa_pair* x = a; const sa_pair* y = b;
+    return x->key < y->key ? -1 : (x->key > y->key ? 1 : 0);
+}
+static void sa_radix_sort(sa_item* it, sa_item* tmp, uint64_t n) {            /* stable, 16 bits per pass, keys below 2^63 */
+    uint64_t* count = malloc(65537 * 8);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 16 * pass;
+        memset(count, 0, 65537 * 8);
+        for (uint64_t i = 0; i < n; ++i) count[((it[i].key >> shift) & 0xffff) + 1]++;
+        if (count[1] == n) continue;                                          /* every key has a zero digit here */
+        for (int d = 0; d < 65536; ++d) count[d + 1] += count[d];
+        for (uint64_t i = 0; i < n; ++i) tmp[count[(it[i].key >> shift) & 0xffff]++] = it[i];
+        memcpy(it, tmp, n * sizeof *it);
+    }
+    free(count);
 }
 int ora_suffix_array(const uint8_t* text, uint64_t n, uint64_t* sa) {
     if (n == 0) return 0;
     if (n >= (1ull << 31)) return -1;
     sa_item* it = malloc(n * sizeof *it);
+    sa_item* tmp = malloc(n * sizeof *tmp);
     uint32_t* rank = malloc(n * 4);
     uint32_t* idx = malloc(n * 4);
-    /* initial key: first 7 symbols, 9 bits each (symbol+1, 0 = past the end) */
+    /* initial key: first 7 symbols, 9 bits each (symbol+1, 0 = past the end: a proper prefix sorts first) */
     uint64_t h = 7;
-    for (uint64_t i = 0; i < n; ++i) {
+    #pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
         uint64_t k = 0;
-        for (uint64_t j = 0; j < h; ++j) k = (k << 9) | (i + j < n ? (uint64_t)text[i + j] + 1 : 0);
+        for (uint64_t j = 0; j < h; ++j) k = (k << 9) | ((uint64_t)i + j < n ? (uint64_t)text[i + j] + 1 : 0);
         it[i].key = k; it[i].idx = (uint32_t)i;
     }
-    for (;;) {
-        qsort(it, n, sizeof *it, sa_item_cmp);
-        /* rank = index of first item with an equal key */
-        uint64_t distinct = 0, start = 0;
-        for (uint64_t i = 0; i < n; ++i) {
-            if (i == 0 || it[i].key != it[i - 1].key) { start = i; ++distinct; }
-            rank[it[i].idx] = (uint32_t)start;
-            idx[i] = it[i].idx;
+    sa_radix_sort(it, tmp, n);
+    free(tmp);
+    /* rank = index of the first item with an equal key; tied groups are collected */
+    uint64_t ngroups = 0, cap = 1024;
+    sa_group* groups = malloc(cap * sizeof *groups);
+    uint64_t start = 0;
+    for (uint64_t i = 0; i <= n; ++i) {
+        if (i == n || (i > 0 && it[i].key != it[i - 1].key)) {
+            if (i - start > 1) {
+                if (ngroups == cap) { cap *= 2; groups = realloc(groups, cap * sizeof *groups); }
+                groups[ngroups].s = (uint32_t)start; groups[ngroups].e = (uint32_t)i; ++ngroups;
+            }
+            start = i;
         }
-        if (distinct == n) break;
-        for (uint64_t i = 0; i < n; ++i) {
-            uint64_t p = idx[i];
-            uint64_t second = p + h < n ? (uint64_t)rank[p + h] + 1 : 0;
-            it[i].key = ((uint64_t)rank[p] << 32) | second;
-            it[i].idx = (uint32_t)p;
-        }
-        h *= 2;
+        if (i < n) { rank[it[i].idx] = (uint32_t)start; idx[i] = it[i].idx; }
     }
-    for (uint64_t i = 0; i < n; ++i) sa[i] = it[i].idx;
-    free(it); free(rank); free(idx);
+    free(it);
+    sa_pair* pr = malloc(n * sizeof *pr);
+    sa_group* next = malloc(cap * sizeof *next);
+    uint64_t next_cap = cap;
+    while (ngroups) {
+        /* keys from the ranks of the previous round (no rank is written before every key of this round is read) */
+        #pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t g = 0; g < (int64_t)ngroups; ++g)
+            for (uint32_t i = groups[g].s; i < groups[g].e; ++i) {
+                const uint64_t p = idx[i];
+                pr[i].key = p + h < n ? rank[p + h] + 1u : 0u;
+                pr[i].idx = (uint32_t)p;
+            }
+        #pragma omp parallel for schedule(dynamic, 16)
+        for (int64_t g = 0; g < (int64_t)ngroups; ++g) qsort(pr + groups[g].s, groups[g].e - groups[g].s, sizeof *pr, sa_pair_cmp);
+        uint64_t nn = 0;
+        for (uint64_t g = 0; g < ngroups; ++g) {
+            uint32_t st = groups[g].s;
+            for (uint32_t i = groups[g].s; i <= groups[g].e; ++i) {
+                if (i == groups[g].e || (i > groups[g].s && pr[i].key != pr[i - 1].key)) {
+                    if (i - st > 1) {
+                        if (nn == next_cap) { next_cap *= 2; next = realloc(next, next_cap * sizeof *next); }
+                        next[nn].s = st; next[nn].e = i; ++nn;
+                    }
+                    st = i;
+                }
+                if (i < groups[g].e) { idx[i] = pr[i].idx; rank[pr[i].idx] = st; }
+            }
+        }
+        sa_group* sw = groups; groups = next; next = sw;
+        uint64_t sc = cap; cap = next_cap; next_cap = sc;
+        ngroups = nn; h *= 2;
+    }
+    for (uint64_t i = 0; i < n; ++i) sa[i] = idx[i];
+    free(pr); free(rank); free(idx); free(groups); free(next);
     return 0;
 }
 void ora_bwt_from_sa(const uint8_t* text, uint64_t n, const uint64_t* sa, uint8_t* bwt) {   /* utils.h:145-163 */

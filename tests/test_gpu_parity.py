@@ -1255,47 +1255,149 @@ def test_full_size_properties():
     assert bool(torch.equal(seq, seq2) and torch.equal(pos, pos2) and torch.equal(steps, steps2))
 
 
-def test_full_size_k2_tables_agree():
-    """BASELINE.json configs[2] at full index size (3.09 Gbp BiFMIndex), 1 M reads: the table-driven kernel with every accelerator reports
-    the same hit records and node count as without any, and as the general kernel (the small-case parity against the CPU walk carries over)"""
+class _V:
+    def __init__(self, t):
+        self.t, self.ptr, self.nbytes = t, t.data_ptr(), t.numel() * t.element_size()
+
+
+def _oracle_from_built(gx, bidir, sigma=5, layout="IB16", threads=None):
+    """the CPU restatement over the GPU-built BWT(s): what bench.py's cpu_baseline does"""
+    ox = fo.OraIndex.from_bwt(layout, sigma, gx.built_array(0), gx.built_array(1) if bidir else None, None, None, None)
+    ox.spread(threads or len(os.sched_getaffinity(0)))
+    return ox
+
+
+def _sorted_records(hits):
+    return hits[np.lexsort((hits["seq"], hits["qidx"]))]
+
+
+def test_full_size_k2_records_equal_the_cpu_walk():
+    """BASELINE.json configs[2] and configs[3] at full index size (3.09 Gbp BiFMIndex) on the repeat-structured text: the oracle is built from the
+    GPU-built BWTs and every hit record (qidx, lb, lb_rev, len, errors, callback order) of 100 k reads at 101 bp and at 151 bp is compared with
+    the CPU walk — with the plain index (blocks only), with LF tables, and with every accelerator (16-symbol prefix table = 2^32 entries, rows
+    close to 2^32); node counts too.  The general kernel must agree as well."""
     torch = pytest.importorskip("torch")
+    from fmindex_collection_amd import datasets
+    import bench
     dev = torch.device("cuda", 0)
-    n, nq, L = 3_088_286_401, 1_000_000, 101
+    lengths = list(bench.GRCH38_LENGTHS)
+    text, stats = datasets.genome_like_text(lengths, seed=42, device=dev)
+    n = int(text.numel())
+    seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64))])).to(dev)
     g = torch.Generator(device=dev); g.manual_seed(11)
-    text = torch.empty(n, dtype=torch.uint8, device=dev)
-    for lo in range(0, n, 1 << 28):
-        hi = min(n, lo + (1 << 28))
-        text[lo:hi] = torch.randint(1, 5, (hi - lo,), generator=g, device=dev, dtype=torch.uint8)
-    starts = torch.randint(0, n - L, (nq,), generator=g, device=dev, dtype=torch.int64)
-    reads = text[starts[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
-    rows = torch.arange(nq, device=dev)
-    for k in range(2):                                         # 0 / 1 / 2 substitutions
-        sel = rows[rows % 3 > k]
-        p = torch.randint(0, L, (sel.numel(),), generator=g, device=dev)
-        reads[sel, p] = reads[sel, p] % 4 + 1
-    seq_off = torch.tensor([0, n], dtype=torch.int64, device=dev)
-
-    class V:
-        def __init__(self, t):
-            self.t, self.ptr, self.nbytes = t, t.data_ptr(), t.numel() * t.element_size()
-    gx = fm.BiFMIndex.from_sequences((V(text), V(seq_off)), 5, "IB16", 16)
+    batches = {}
+    for L, nq in ((101, 100_000), (151, 100_000)):
+        starts = torch.randint(0, n - L, (nq,), generator=g, device=dev, dtype=torch.int64)
+        reads = text[starts[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
+        rows = torch.arange(nq, device=dev)
+        for k in range(2):                                     # 0 / 1 / 2 substitutions
+            sel = rows[rows % 3 > k]
+            p = torch.randint(0, L, (sel.numel(),), generator=g, device=dev)
+            reads[sel, p] = reads[sel, p] % 4 + 1
+        batches[L] = (reads.reshape(-1).cpu().numpy(), (np.arange(nq + 1, dtype=np.uint64) * L))
+    os.environ["FMGPU_LF_TABLE"] = "0"
+    try:
+        gx = fm.BiFMIndex.from_sequences((_V(text), _V(seq_off)), 5, "IB16", 16, keep_host=True)
+    finally:
+        del os.environ["FMGPU_LF_TABLE"]
     del text
-    qoff = torch.arange(nq + 1, device=dev, dtype=torch.int64) * L
+    ox = _oracle_from_built(gx, True)
     sch = fm.search_scheme.h2(4, 0, 2)
-    hq, ho = reads.reshape(-1).cpu().numpy(), qoff.cpu().numpy().astype(np.uint64)
+    want = {}
+    for L, (hq, ho) in batches.items():
+        oh, _, onodes = ox.search_ng26(hq, ho, sch, nthreads=len(os.sched_getaffinity(0)), records=True, cap=1 << 22)
+        want[L] = (oh, onodes)
+        assert int(oh["errors"].max()) == 2 and len(oh) >= len(ho) - 1 - 100
 
-    def run():
-        hits, st = fm.search_ng26.search(gx, (hq, ho), sch, want_stats=True)
-        return hits, st.lf_steps
-    base, nodes = run()
-    assert len(base) >= nq - 100 and int(base["errors"].max()) == 2
-    for accel in ((11, 1), (0, 2), (11, 3), (16, 3)):                       # (16 symbols: 2^32 prefix-table entries, the bench default)
+    def check(tag):
+        for L, (hq, ho) in batches.items():
+            hits, st = fm.search_ng26.search(gx, (hq, ho), sch, want_stats=True)
+            oh, onodes = want[L]
+            assert st.lf_steps == onodes, (tag, L, st.lf_steps, onodes)
+            assert same_hits(hits, oh), (tag, L)
+    check("plain index")
+    gx.accelerate_lf(True)
+    check("LF tables")
+    for accel in ((11, 1), (0, 2), (16, 3)):
         gx.accelerate_search(*accel)
-        hits, nn = run()
-        assert nn == nodes and hits.tobytes() == base.tobytes(), accel
+        check(accel)
     os.environ["FMGPU_DEV_FLAGS"] = "2"                        # the general kernel
     try:
-        hits, nn = run()
+        check("general kernel")
     finally:
         del os.environ["FMGPU_DEV_FLAGS"]
-    assert nn == nodes and hits.tobytes() == base.tobytes()
+
+
+def test_gpu_builder_on_a_repeat_structured_text():
+    """fmgpu_build_index on 51 Mbp of the genome-like text (interspersed repeats, satellites, 2.5 % of it in one run of one symbol per sequence:
+    prefix doubling over long ties): the BWT and the located positions equal the oracle's suffix array, which is itself checked for sortedness
+    with the inverse-permutation criterion (suffix(a) < suffix(b) <=> (text[a], isa[a+1]) < (text[b], isa[b+1]))"""
+    torch = pytest.importorskip("torch")
+    from fmindex_collection_amd import datasets
+    import bench
+    lengths = [max(1, int(l * 0.0165)) for l in bench.GRCH38_LENGTHS]
+    text, stats = datasets.genome_like_text(lengths, seed=42, device=torch.device("cuda", 0))
+    assert 0.35 < stats["repeat_fraction_written"] < 0.5 and stats["run_fraction_written"] > 0.04
+    host = text.cpu().numpy()
+    seqs = np.split(host, np.cumsum(lengths)[:-1])
+    gx = fm.FMIndex.from_sequences(seqs, 5, "IB16", 16, keep_host=True)
+    # the text as the index sees it: every sequence followed by a delimiter (utils.h:382-411)
+    cat = np.concatenate([np.concatenate([s_, np.zeros(1, dtype=np.uint8)]) for s_ in seqs])
+    n = cat.size
+    assert gx.n == n
+    sa = np.empty(n, dtype=np.uint64)
+    assert fo.lib().ora_suffix_array(cat.ctypes.data_as(C.POINTER(C.c_uint8)), n, sa.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+    sai = sa.astype(np.int64)
+    isa = np.empty(n, dtype=np.int64); isa[sai] = np.arange(n)
+    a, b = sai[:-1], sai[1:]
+    nxa = np.where(a + 1 < n, isa[np.minimum(a + 1, n - 1)], -1); nxb = np.where(b + 1 < n, isa[np.minimum(b + 1, n - 1)], -1)
+    assert bool(((cat[a] < cat[b]) | ((cat[a] == cat[b]) & (nxa < nxb))).all())          # the oracle's suffix array is sorted
+    assert np.array_equal(gx.built_array(0), cat[(sai + n - 1) % n])                       # bwt[i] = text[(sa[i] + n - 1) % n], utils.h:145-163
+    rows = np.random.default_rng(3).integers(0, n, size=200_000).astype(np.uint64)
+    seq, pos, steps = gx.locate(rows)
+    starts = np.concatenate([[0], np.cumsum(np.asarray(lengths) + 1)])
+    assert np.array_equal(starts[seq.astype(np.int64)] + pos.astype(np.int64) + steps.astype(np.int64), sai[rows.astype(np.int64)])
+
+
+def test_rows_beyond_2_32():
+    """An index of 4.4e9 rows (64-bit-row build, real size): built on the GPU, the oracle is built from its BWTs; exact intervals, 1-mismatch hit
+    records and located positions of 10 k reads equal the CPU walk, and every sampled read locates back to where it was copied from."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    lengths = [3_000_000_000, 1_400_000_123]
+    n_sym = sum(lengths)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    text = torch.empty(n_sym, dtype=torch.uint8, device=dev)
+    for lo in range(0, n_sym, 1 << 28):
+        hi = min(n_sym, lo + (1 << 28))
+        text[lo:hi] = torch.randint(1, 5, (hi - lo,), generator=g, device=dev, dtype=torch.uint8)
+    L, nq = 60, 10_000
+    starts = torch.cat([torch.randint(0, lengths[0] - L, (nq // 2,), generator=g, device=dev, dtype=torch.int64),
+                        lengths[0] + torch.randint(0, lengths[1] - L, (nq // 2,), generator=g, device=dev, dtype=torch.int64)])
+    reads = text[starts[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
+    mut = torch.arange(0, nq, 4, device=dev)
+    reads[mut, 17] = reads[mut, 17] % 4 + 1                    # every fourth read carries one substitution
+    seq_off = torch.tensor([0, lengths[0], n_sym], dtype=torch.int64, device=dev)
+    gx = fm.BiFMIndex.from_sequences((_V(text), _V(seq_off)), 5, "IB16", 16, keep_host=True)
+    del text
+    torch.cuda.empty_cache()
+    assert gx.row_bits == 64 and gx.n == n_sym + 2 and gx.n > 2**32
+    ox = _oracle_from_built(gx, True)
+    hq, ho = reads.reshape(-1).cpu().numpy(), np.arange(nq + 1, dtype=np.uint64) * L
+    lb, ln = fm.search_no_errors.search(gx, (hq, ho))
+    olb, oln = ox.search_exact(hq, ho, nthreads=8)
+    assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
+    assert int(lb.max()) > 2**32 and int((ln > 0).sum()) == nq - len(mut)
+    hit = np.nonzero(ln == 1)[0]
+    seq, pos, steps = gx.locate(lb[hit])
+    st_host = starts.cpu().numpy()
+    want_seq = (st_host[hit] >= lengths[0]).astype(np.uint64)
+    assert np.array_equal(seq, want_seq) and np.array_equal(pos + steps, (st_host[hit] - want_seq.astype(np.int64) * lengths[0]).astype(np.uint64))
+    sch = fm.search_scheme.h2(3, 0, 1)
+    hits, st = fm.search_ng26.search(gx, (hq, ho), sch, want_stats=True)
+    oh, _, onodes = ox.search_ng26(hq, ho, sch, nthreads=8, records=True)
+    assert same_hits(hits, oh) and st.lf_steps == onodes and len(hits) >= nq
+    idx = np.array([0, 1, 2**32 - 1, 2**32, 2**32 + 12345, gx.n - 1, gx.n], dtype=np.uint64)
+    for c in range(5):
+        want = np.array([ox.bwt_string().rank(int(i), c) for i in idx], dtype=np.uint64)
+        assert np.array_equal(gx.rank(idx, c), want)
