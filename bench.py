@@ -23,7 +23,7 @@ multi-ary wavelet tree itself at 170 B per LF step, and its block-table expansio
 N > 1 (launched by torch.distributed.run, one rank per GPU): the index is replicated (every rank builds the same seeded text), the query batch is
 sharded, the only exchange is the RCCL gather of the results to rank 0 inside the timed region (double-buffered: the gather of step i crosses xGMI
 while the kernel of step i+1 runs).  `value` = exact search, 10 M reads PER RANK (weak scaling: per-GPU work fixed); `secondary` = configs[3]:
-k = 2 Hamming, 151 bp, partition {38,38,38,37}, 100 M reads in total sharded 100 M / N per rank (strong scaling), 16-byte packed hits gathered.
+k = 2 Hamming, 151 bp, partition {38,38,38,37}, 100 M reads in total sharded 100 M / N per rank (strong scaling), 24-byte packed hits gathered.
 
 Prints ONE JSON line (rank 0).  `cpu_baseline` = the CPU restatement (oracle/, parity-pinned) on the host cores over a bounded sample of the same
 reads, NUMA-spread and thread-bound; it is a reported baseline, not the target.
@@ -473,8 +473,8 @@ def run_dna_text(c, name, primary):
                 hit_cap = int(t_.item())
             hits_bufs = [torch.empty(hit_cap * 40, dtype=torch.uint8, device=c.dev) for _ in range(2 if c.multi else 1)]
             pk_cap = (hit_cap + 65535) // 65536 * 65536
-            packed_hits = [torch.empty((pk_cap, 2), dtype=torch.int64, device=c.dev) for _ in range(2)] if c.multi else None
-            xch = Exchange(c, pk_cap * 16) if c.multi else None
+            packed_hits = [torch.empty((pk_cap, 3), dtype=torch.int64, device=c.dev) for _ in range(2)] if c.multi else None
+            xch = Exchange(c, pk_cap * 24) if c.multi else None
             count_dev = torch.zeros(1, dtype=torch.int64, device="cpu" if c.via_host else c.dev) if c.multi else None
             state = {"i": 0, "cnt": 0}
 
@@ -487,11 +487,11 @@ def run_dna_text(c, name, primary):
                                                           C.c_void_p(hits_bufs[b].data_ptr()), hit_cap, C.byref(cnt), C.byref(stats), None))
                 state["cnt"] = int(cnt.value)
                 log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses, "hits": stats.hits})
-                if xch:                                           # 16 bytes per hit (qidx:32 | lb:32, len:32 | errors:8 | seq:24); message size = the largest count over the ranks
+                if xch:                                           # 24 bytes per hit (qidx:32 | lb:32, len:32 | errors + key:32, lb_rev:32 | key:32); message size = the largest count over the ranks
                     count_dev.fill_(int(cnt.value))
                     c.dist.all_reduce(count_dev, op=c.dist.ReduceOp.MAX)
                     m = (int(count_dev.item()) + 65535) // 65536 * 65536
-                    capi.check(capi.lib().fmgpu_hits_pack16(C.c_void_p(hits_bufs[b].data_ptr()), int(cnt.value), C.c_void_p(packed_hits[b].data_ptr()), None))
+                    capi.check(capi.lib().fmgpu_hits_pack24(C.c_void_p(hits_bufs[b].data_ptr()), int(cnt.value), C.c_void_p(packed_hits[b].data_ptr()), None))
                     xch.send(packed_hits[b][:m].view(torch.uint8).view(-1), b)
 
             elapsed, log = timed(c, step, xch.drain if xch else None)
@@ -515,7 +515,7 @@ def run_dna_text(c, name, primary):
                 rec["roofline"] = roofline_loaded(st, n_ * (L + 8), k_ms, kernel, units, "visited nodes")
             if xch:
                 rec["exchange"] = {"collective": xch.mode, "bytes_per_rank_and_step": int(xch.last[0].numel()), "verified_on_rank0": xch.verify(),
-                                   "record": "16 B per hit (qidx:32 | lb:32, len:32 | errors:8 | seq:24)"}
+                                   "record": "24 B per hit (qidx:32 | lb:32, len:32 | errors + order key:32, lb_rev:32 | order key:32)"}
             attach_traffic(c, rec)
             if keep and w == "k2" and index_kind == "tables":
                 rec["cpu_baseline"] = cpu_baseline(c, index, True, qb, qo, n_, L, scheme, None, None, (hits_bufs[0], state["cnt"]))
@@ -663,11 +663,12 @@ def cpu_baseline(c, index, bidir, qbuf, qoff, nq, L, scheme, out_lb, out_len, hi
         buf, cnt = hits
         rec = buf[: cnt * 40].view(torch.int64).view(-1, 5)
         mine = rec[rec[:, 0] < checked].cpu().numpy()
-        order = np.lexsort((mine[:, 4] >> 32, mine[:, 0]))     # (qidx, seq): the reference's callback order
+        e_key = mine[:, 4].astype(np.uint64)                   # errors:8 | key high:24 | seq (key low):32 -> (qidx, key) is the reference's callback order
+        order = np.lexsort(((((e_key >> np.uint64(8)) & np.uint64(0xffffff)) << np.uint64(32)) | (e_key >> np.uint64(32)), mine[:, 0]))
         mine = mine[order]
         oh = r[0]
         ok = bool(len(oh) == len(mine) and all(np.array_equal(mine[:, k].astype(np.uint64), oh[f].astype(np.uint64)) for k, f in ((0, "qidx"), (1, "lb"), (2, "lb_rev"), (3, "len"))) and
-                  np.array_equal((mine[:, 4] & 0xffffffff).astype(np.uint64), oh["errors"].astype(np.uint64)))
+                  np.array_equal((mine[:, 4] & 0xff).astype(np.uint64), oh["errors"].astype(np.uint64)))
     one = max(1000, min(sample, int(sample / dt * 3.0 / cores)))          # ~3 s on one thread (single-thread figure beside all cores)
     _, dt1 = run(one, threads=1)
     out = {"value": sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",

@@ -95,7 +95,7 @@ EXPORTS = [
     "fmgpu_malloc", "fmgpu_free", "fmgpu_memcpy_h2d", "fmgpu_memcpy_d2h", "fmgpu_synchronize",
     "fmgpu_build_index", "fmgpu_built_free", "fmgpu_built_get", "fmgpu_index_accelerate", "fmgpu_index_accelerate_search",
     "fmgpu_index_accelerate_exact", "fmgpu_index_accelerate_locate", "fmgpu_hits_sort", "fmgpu_hits_pack16",
-    "fmgpu_index_row_bits", "fmgpu_index_accelerate_lf", "fmgpu_search_exact_depth", "fmgpu_cursor_extend",
+    "fmgpu_index_row_bits", "fmgpu_index_accelerate_lf", "fmgpu_search_exact_depth", "fmgpu_cursor_extend", "fmgpu_hits_pack24",
 ]
 
 _lib = None
@@ -133,6 +133,7 @@ def lib():
         L.fmgpu_index_accelerate.argtypes = [C.c_void_p, C.c_int32]
     if hasattr(L, "fmgpu_hits_pack16"):
         L.fmgpu_hits_pack16.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.fmgpu_hits_pack24.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     if hasattr(L, "fmgpu_hits_sort"):
         L.fmgpu_hits_sort.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     if hasattr(L, "fmgpu_index_accelerate_locate"):

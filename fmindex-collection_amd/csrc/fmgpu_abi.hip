@@ -70,7 +70,7 @@ bool want_wide(uint64_t n) {
 // tables) leaves nothing half-initialised behind, and the next call simply tries again.  Keyed by device: a host thread that alternates
 // between handles on two devices re-uses both sets.  FMGPU_FAIL_SCRATCH=k (test knob) fails the k-th allocation of the next creation.
 void CallScratch::drop() {
-    for (void* p : {(void*)ctr, (void*)sink, (void*)len2, frames, dfs_ctr}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)ctr, (void*)sink, (void*)len2, frames, dfs_ctr, tasks}) if (p) (void)hipFree(p);
     if (pinned) (void)hipHostFree(pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
@@ -238,9 +238,11 @@ int fmgpu_synchronize(void* stream) { FM_HIP(hipStreamSynchronize((hipStream_t)s
 
 namespace fmgpu32 { namespace api {
 int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
+int fmgpu_hits_pack24(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
 int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream);
 } }
 extern "C" {
 int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream) { return fmgpu32::api::fmgpu_hits_pack16(hits, count, out, stream); }
+int fmgpu_hits_pack24(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream) { return fmgpu32::api::fmgpu_hits_pack24(hits, count, out, stream); }
 int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream) { return fmgpu32::api::fmgpu_hits_sort(hits, count, stream); }
 }

@@ -182,7 +182,35 @@ struct SchemeDev {             // flattened [search][part]; values fit a byte (e
     int dev_flags;                   // dev knobs: 1 = count hits per lane only (no records)
 };
 
-struct Counters { unsigned long long hits, nodes, next, table_bytes, table_accesses; };
+struct Counters { unsigned long long hits, nodes, next, table_bytes, table_accesses, tq_head, tq_tail; long long busy_waves; };
+
+// ---- work sharing between the lanes of k_scheme_fast ---------------------------------------------------------------------------------
+// The work of a k-mismatch search is heavy-tailed on a repeat-rich text: the median read visits ~200 nodes, a read from a satellite array
+// half a million (measured on the genome-like text: 0.02 % of the reads hold 13 % of all nodes), and a depth-first walk of one read by one
+// lane takes as long as its node count.  A lane that has spent kExportNodes nodes on its current read therefore hands the BOTTOM frame of its
+// stack — the untried siblings of its shallowest branching node, i.e. the largest piece of work it still owns — to a global task queue; any
+// lane that runs out of work takes tasks before it takes fresh reads.  A task is a self-contained resumed frame (read, search, cursor, step,
+// errors, next sibling, path key).  This needs an order of the hit records that does not depend on who found them: the path key below.
+struct Task {
+    uint64_t q_si;                 // read number (bits 0..47) | search (48..55) | valid (56..63), written last
+    uint32_t lb, lbRev, len;
+    uint32_t jer;                  // step j (bits 0..15) | errors e (16..23) | next sibling (24..31)
+    uint64_t key;
+};
+struct TaskQueue { Task* tasks; uint32_t cap; uint32_t export_nodes; };
+constexpr uint32_t kTaskCap = 1u << 21;
+constexpr uint32_t kExportNodes = 1024;
+
+// Path key: the callback order of the reference is the depth-first order in which every node tries its match child first and its substitution
+// children in ascending symbol order (SearchNg26.h:171-218).  For hits of one read that is the lexicographic order of
+//   (search, [m - step of the 1st substitution, its symbol], [m - step of the 2nd substitution, its symbol])   with "no substitution" = 0:
+// a later first substitution is met earlier on the way back up.  24 bits per substitution; the key travels in fmgpu_hit::seq (low 32 bits) and
+// the upper 24 bits of fmgpu_hit::errors until fmgpu_hits_sort orders the records by (qidx, key) and turns it into the dense callback index.
+__device__ __forceinline__ uint64_t key_with(uint64_t key, uint32_t e_before, uint32_t m, uint32_t step, uint32_t symb) {
+    if (e_before >= 2u) return key;
+    return key | ((uint64_t)(((m - step) << 8) | symb) << (24u * (1u - e_before)));
+}
+
 
 
 // lane-interleaved frame stack: frame d of lane g at word (d * nlanes + g) of three u64 planes
@@ -1337,7 +1365,7 @@ template <int SIGMA, int MAXSIG>
 __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
-                                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap) {
+                                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, TaskQueue tq, int use_key) {
     // One flat loop per lane over (query, search, node) with every slow path wave-synchronous.  A wave pays for every slow path any of its 64
     // lanes takes, so nothing with a dependent memory round trip is lane-private: queries are fetched and staged TOGETHER — as soon as
     // kRefillLanes lanes of the wave are out of work (one atomicAdd per refill, query words issued back to back) — and hits are kept in LDS
@@ -1367,6 +1395,10 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     const uint32_t refill_wait = ((uint32_t)dev_flags >> 16) & 255u ? ((uint32_t)dev_flags >> 16) & 255u : kRefillWait;
     uint32_t dry_iters = 0;                                         // iterations since a lane of the wave ran out of work (wave-uniform)
     uint32_t nh = 0, count_only = 0, nodes0 = 0;
+    const bool sharing = tq.tasks != nullptr;                       // work sharing through the task queue (unlimited hits, path keys)
+    bool wave_busy = true, is_task = false;
+    uint32_t sbase = 0, mark = 0;                                   // frames below sbase were handed out; nodes at the lane's last export
+    uint64_t pkey = 0;                                              // path key of the node the lane stands on
     bool have = false, exhausted = n == 0, need_start = false, query_over = false;
     uint64_t q = 0, quota = 0;
     const uint8_t* qs = qbuf;
@@ -1377,24 +1409,76 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     bool in_tail = false;
     for (;;) {
         // ---- wave-synchronous part: every lane passes here in every iteration
-        const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
+        const uint64_t needm = __ballot(!have && (!exhausted || sharing)), busym = __ballot(have);
         dry_iters = needm ? dry_iters + 1u : 0u;
         if (needm && ((uint32_t)__popcll(needm) >= refill_at || dry_iters > refill_wait || !busym)) {
             dry_iters = 0;
-            const bool want = !have && !exhausted;
-            const uint64_t got = wave_hand_out(want, ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
+            bool want = !have && (!exhausted || sharing);
             bool fresh = false; uint64_t qo = 0;
+            if (sharing) {                                          // tasks first: they are the large pieces
+                const uint64_t wm = __ballot(want);
+                unsigned long long th = 0; uint32_t take = 0;
+                if (lane == 0) {
+                    for (;;) {
+                        const unsigned long long h = __atomic_load_n(&ctr->tq_head, __ATOMIC_RELAXED);
+                        unsigned long long t = __atomic_load_n(&ctr->tq_tail, __ATOMIC_RELAXED);
+                        if (t > tq.cap) t = tq.cap;
+                        if (t <= h) break;
+                        const unsigned long long k = t - h < (unsigned long long)__popcll(wm) ? t - h : (unsigned long long)__popcll(wm);
+                        if (atomicCAS(&ctr->tq_head, h, h + k) == h) { th = h; take = (uint32_t)k; break; }
+                    }
+                }
+                take = __builtin_amdgcn_readfirstlane(take);
+                th = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(th >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)th);
+                const uint32_t myrank = (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+                if (want && myrank < take) {
+                    const Task* tk = tq.tasks + th + myrank;
+                    uint64_t qs_ = __atomic_load_n(&tk->q_si, __ATOMIC_ACQUIRE);
+                    while (!(qs_ >> 56)) { __builtin_amdgcn_s_sleep(2); qs_ = __atomic_load_n(&tk->q_si, __ATOMIC_ACQUIRE); }   // (reserved by its exporter, not yet written)
+                    q = qs_ & 0xffffffffffffull; si = (uint32_t)(qs_ >> 48) & 0xffu;
+                    cur = Cur{tk->lb, tk->lbRev, tk->len};
+                    const uint32_t jer = tk->jer;
+                    j = jer & 0xffffu; e = (jer >> 16) & 0xffu; resume = jer >> 24;
+                    pkey = tk->key;
+                    qo = qoff[q]; qs = qbuf + qo; fresh = true;
+                    have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
+                    tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; mark = nodes; nodes0 = nodes;
+                    want = false;
+                }
+                want = want && !exhausted;
+            }
+            const uint64_t got = wave_hand_out(want, ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
             if (want) {
                 if (got >= nq) exhausted = true;
-                else { q = qmap ? (uint64_t)qmap[got] : got; qo = qoff[q]; qs = qbuf + qo; fresh = true; }
+                else {
+                    q = qmap ? (uint64_t)qmap[got] : got; qo = qoff[q]; qs = qbuf + qo; fresh = true;
+                    have = true; is_task = false; si = 0; need_start = true; quota = max_hits; seq = 0; query_over = false; nodes0 = nodes; mark = nodes;
+                }
             }
-            qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
-            if (fresh) { have = true; si = 0; need_start = true; quota = max_hits; seq = 0; query_over = false; nodes0 = nodes; }
+            if (__ballot(fresh)) qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
         }
         {
             const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(have);
             if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
-            if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
+            if (!busy) {
+                if (__ballot(!exhausted) != 0ull) continue;         // fresh reads are left: the next refill fetches them
+                if (!sharing) break;
+                // no lane of the wave has work and no fresh read is left: wait for tasks of the waves that are still busy, leave when none is
+                int cmd = 0;                                        // 0 wait, 1 tasks are waiting, 2 leave
+                if (lane == 0) {
+                    if (wave_busy) atomicAdd((unsigned long long*)&ctr->busy_waves, ~0ull);
+                    unsigned long long t = __atomic_load_n(&ctr->tq_tail, __ATOMIC_RELAXED);
+                    if (t > tq.cap) t = tq.cap;
+                    if (t > __atomic_load_n(&ctr->tq_head, __ATOMIC_RELAXED)) { atomicAdd((unsigned long long*)&ctr->busy_waves, 1ull); cmd = 1; }
+                    else if (__atomic_load_n(&ctr->busy_waves, __ATOMIC_RELAXED) <= 0) cmd = 2;
+                }
+                cmd = __builtin_amdgcn_readfirstlane(cmd);
+                wave_busy = cmd == 1;
+                if (cmd == 2) break;
+                if (cmd == 0) __builtin_amdgcn_s_sleep(32);
+                dry_iters = refill_wait + 1u;                       // try to take tasks at once
+                continue;
+            }
         }
         if (!have) continue;
         {
@@ -1402,7 +1486,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
             if (need_start) {                                       // search_impl (SearchNg26.h:385-390) -> run(): :62-79
                 need_start = false;
                 tab = s_steps + si * stride;
-                cur = Cur{0, 0, n}; e = 0; j = 0; sp = 0; resume = kNoResume; in_tail = false;
+                cur = Cur{0, 0, n}; e = 0; j = 0; sp = 0; sbase = 0; resume = kNoResume; in_tail = false;
+                pkey = (uint64_t)si << 48;
                 if (fa.lut && ((fa.lut_ok >> si) & 1u) && n > 1) {  // the exact first part starts from the prefix table
                     uint32_t code = 0, mul = 1; bool valid = true;
                     for (uint32_t t = 0; t < fa.lutL; ++t) {
@@ -1497,12 +1582,13 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         uint64_t o = (uint64_t)sp * stk.nlanes + gid;
                         stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
                         stk.p1[o] = (uint64_t)cur.len | ((uint64_t)(j & 0xffffu) << 32) | ((uint64_t)(e & 0xffu) << 48) | ((uint64_t)(subs.first() & 0xffu) << 56);
-                        ++sp; tbytes += 16u; ++tacc;
+                        stk.p2[o] = pkey;
+                        ++sp; tbytes += 24u; ++tacc;
                     }
                     resume = kNoResume;
                     if (take_match || take_sub) {
                         cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
-                        if (take_sub) e += 1;
+                        if (take_sub) { pkey = key_with(pkey, e, m, j, take); e += 1; }
                         in_tail = !lastp && (in_tail || (take_match && !xOK));
                         ++j;
                     } else back = true;
@@ -1511,8 +1597,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     // direction — 16 from a walk entry, or up to three from the LF / LF^2 / LF^3 values — is described by the steps at which the
                     // row's symbols differ from the query's (mm, bit 2k = step k), its stretch word (windows) and the row it leads to, and then
                     // walked run by run by ONE piece of code for both kinds.
-                    bool walked = false, have = false, del_after = false;
-                    uint32_t n = 0, mm = 0, sword = 0;
+                    bool walked = false, stretch = false, del_after = false;
+                    uint32_t n = 0, mm = 0, sword = 0, sym3 = 0;   // sym3: the symbols of a <= 3-step stretch, 8 bits each (a 16-step stretch keeps them in we.y)
                     idx_t target = 0;
                     if (use_wj && we.x != 0xffffffffu) {
                         walked = true;
@@ -1521,7 +1607,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         const uint32_t sw = s_stretch[si * stride + j];
                         if (qvalid && ((sw >> 22) & 1u)) {
                             const uint32_t diff = qc ^ we.y;
-                            have = true; n = 16u; mm = (diff | (diff >> 1)) & 0x55555555u; sword = sw; target = we.x;
+                            stretch = true; n = 16u; mm = (diff | (diff >> 1)) & 0x55555555u; sword = sw; target = we.x;
                         } else {                                     // an odd query symbol or two part ends inside: step by step
                             bool dead = false;
                             for (uint32_t kk = 0; kk < 16u && !dead; ++kk) {
@@ -1536,7 +1622,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                                 const bool is_match = b == c && mOK;
                                 nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
                                 if (b == c) { if (!mOK) dead = true; }
-                                else if (sOK) e += 1;
+                                else if (sOK) { pkey = key_with(pkey, e, m, j + kk, b); e += 1; }
                                 else dead = true;
                                 if (!dead) in_tail = !lastp && (in_tail || (is_match && !xOK));
                             }
@@ -1562,10 +1648,10 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                                     const uint32_t bsym = symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, tk);
                                     const uint32_t c = qstage_get(qst, qs, (kk == 0 ? ent : tab[j + kk]) & 0xffffu);
                                     if (bsym < 1u) { nn = kk; del_after = true; }
-                                    else { if (bsym != c) mm |= 1u << (2u * kk); target = tk; }
+                                    else { if (bsym != c) mm |= 1u << (2u * kk); target = tk; sym3 |= bsym << (8u * kk); }
                                 }
                             }
-                            have = true; n = nn; sword = sw3;
+                            stretch = true; n = nn; sword = sw3;
                         } else {
                             idx_t tk = t0, last = t0;
                             uint32_t k = 0;
@@ -1586,7 +1672,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                                     nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
                                     if (b < 1) dead = true;                 // :295-297: a delimiter row ends the walk
                                     else if (b == c) { if (!mOK) dead = true; }
-                                    else if (sOK) e += 1;
+                                    else if (sOK) { pkey = key_with(pkey, e, m, j + kk, b); e += 1; }
                                     else dead = true;
                                     if (!dead) { in_tail = !lastp && (in_tail || (is_match && !xOK)); last = tk; ++k; }
                                 }
@@ -1595,8 +1681,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                             else { if (right) cur.lbRev = last; else cur.lb = last; j += k; }   // one row: the other side's prefix count is 0
                         }
                     }
-                    if (have) {
-                        // Steps up to the part end inside the stretch (offset tb; n: none) have the window [.., hi1], later ones [.., hi2]; the lower
+                    if (stretch) {
+                        // Steps up to the part end inside the stretch (offset tb; n: none) stretch the window [.., hi1], later ones [.., hi2]; the lower
                         // bound lo binds at step tb only.  Extensions are counted as the reference performs them: one per step, one more where an
                         // exact tail starts (a match with no error left and not in a tail yet, :310-314), and the step at which a branch ends is
                         // its last.  A wave spends as many rounds here as its lane with the most differing symbols, not n.
@@ -1626,8 +1712,11 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                             if (!dead && p < n) {                                                // the differing step: a substitution or the end
                                 nodes += 1u;
                                 const uint32_t maxp = p <= tb ? hi1 : hi2, minp = p == tb ? lo : 0u;
-                                if (minp <= e + 1u && e + 1u <= maxp) { e += 1u; in_tail = p != tb && in_tail; }
-                                else dead = true;
+                                if (minp <= e + 1u && e + 1u <= maxp) {
+                                    const uint32_t bs = n == 16u ? ((we.y >> (2u * p)) & 3u) + 1u : (sym3 >> (8u * p)) & 255u;
+                                    pkey = key_with(pkey, e, m, j + p, bs);
+                                    e += 1u; in_tail = p != tb && in_tail;
+                                } else dead = true;
                             }
                             x = p + 1u;
                         }
@@ -1643,27 +1732,49 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
                         quota -= r.len;
                         if (dev_flags & 1) ++count_only;
-                        else { wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq); tbytes += 40u; ++tacc; }
+                        else {
+                            if (use_key) wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e | ((uint32_t)(pkey >> 32) << 8), (uint32_t)pkey);
+                            else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq);
+                            tbytes += 40u; ++tacc;
+                        }
                         ++seq;
                         if (quota == 0) { search_over = true; query_over = true; }   // delegate returned true: no further searches (:372-383)
                     }
                     back = !search_over;
                 }
                 if (back) {
-                    if (sp == 0) search_over = true;
+                    if (sp == sbase) search_over = true;
                     else {
                         --sp;
                         uint64_t o = (uint64_t)sp * stk.nlanes + gid;
                         uint64_t w0 = stk.p0[o], w1 = stk.p1[o];
-                        tbytes += 16u; ++tacc;
+                        pkey = stk.p2[o];
+                        tbytes += 24u; ++tacc;
                         cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32); cur.len = (idx_t)w1;
                         j = (uint32_t)(w1 >> 32) & 0xffffu; e = (uint32_t)(w1 >> 48) & 0xffu; resume = (uint32_t)(w1 >> 56) & 0xffu;
                         in_tail = false;
                     }
                 }
+                if (sharing && !search_over && sp > sbase && nodes - mark >= tq.export_nodes) {
+                    // this read is a large one: hand the bottom frame — the untried siblings of the shallowest branching node — to whoever is idle
+                    mark = nodes;
+                    const unsigned long long slot = atomicAdd(&ctr->tq_tail, 1ull);
+                    if (slot < tq.cap) {
+                        const uint64_t o = (uint64_t)sbase * stk.nlanes + gid;
+                        const uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o];
+                        Task* tk = tq.tasks + slot;
+                        tk->lb = (uint32_t)w0; tk->lbRev = (uint32_t)(w0 >> 32); tk->len = (uint32_t)w1;
+                        tk->jer = (uint32_t)(w1 >> 32);             // j | e << 16 | next sibling << 24, as the frame holds them
+                        tk->key = w2;
+                        __atomic_store_n(&tk->q_si, (q & 0xffffffffffffull) | ((uint64_t)si << 48) | (1ull << 56), __ATOMIC_RELEASE);
+                        ++sbase;
+                        tbytes += 56u; tacc += 2u;
+                    }
+                }
                 if (search_over) {                                  // the next search of the scheme, or the lane is out of work
                     ++si;
-                    if (si == S || query_over) {
+                    if (is_task) { have = false; is_task = false; }  // a task is one subtree of one search: its owner goes on with the other searches
+                    else if (si == S || query_over) {
                         have = false;
                         if ((dev_flags & 129) == 129) reinterpret_cast<uint64_t*>(out)[q] = nodes - nodes0;   // dev: nodes per query instead of records (count-only mode)
                     } else need_start = true;
@@ -2170,6 +2281,11 @@ __global__ __launch_bounds__(256) void k_len_pairs(const uint64_t* __restrict__ 
     if (q < nq) { len[q] = (uint32_t)(qoff[q + 1] - qoff[q]); idx[q] = (uint32_t)q; }
 }
 
+// counters of one launch of the work-sharing kernel: reads are handed out from 0, the task queue is empty, every wave of the grid counts as busy
+__global__ void k_init_sharing(Counters* c, long long waves) {
+    c->next = 0; c->tq_head = 0; c->tq_tail = 0; c->busy_waves = waves;
+}
+
 constexpr size_t kFrameCache = (size_t)2 << 30;
 struct DfsWorkspace {
     uint64_t* planes = nullptr; Counters* ctr = nullptr; StackView view{};
@@ -2212,6 +2328,7 @@ struct DfsWorkspace {
 namespace api {
 #include "fmgpu_api_decl.h"
 int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
+int fmgpu_hits_pack24(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
 int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream);
 
 static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
@@ -2518,6 +2635,24 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         for (const Bucket& b : buckets) { (void)hipMemcpyAsync(d_steps + at, b.tab.data(), b.tab.size() * 4, hipMemcpyHostToDevice, stream); at += b.tab.size(); }
     }
 #endif
+#if !FMGPU_WIDE
+    // path keys order the hits of a read whoever finds them (<= 2 substitutions fit the key); with them and no limit on the hits per read the
+    // lanes share the work of large reads through the task queue
+    const int use_key = fast && !edit && max_u <= 2 && sd.S <= 16 ? 1 : 0;
+    TaskQueue tq{nullptr, 0, kExportNodes};
+    if (use_key && max_hits == ~0ull && !(sd.dev_flags & (1 << 24))) {
+        CallScratch* sc = nullptr;
+        if ((rc = call_scratch(&sc))) { if (d_qmap) (void)hipFree(d_qmap); if (d_steps) (void)hipFree(d_steps); return rc; }
+        const size_t need = (size_t)kTaskCap * sizeof(Task);
+        if (sc->tasks_bytes < need) {
+            if (sc->tasks) { (void)hipFree(sc->tasks); sc->tasks = nullptr; sc->tasks_bytes = 0; }
+            if (hipMalloc(&sc->tasks, need) == hipSuccess) sc->tasks_bytes = need; else (void)hipGetLastError();      // (no room: the search runs without sharing)
+        }
+        if (sc->tasks) { tq.tasks = (Task*)sc->tasks; tq.cap = kTaskCap; }
+        const uint32_t lg = ((uint32_t)sd.dev_flags >> 25) & 31u;     // dev knob: log2 of the export threshold
+        if (lg) tq.export_nodes = 1u << lg;
+    }
+#endif
     timer.start();
 #if !FMGPU_WIDE
     if (fast) {
@@ -2532,8 +2667,9 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             fa.lut = b.lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = b.lut_ok;
             for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
             const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (size_t)kWaveHitWords * 4;
-            FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));   // the fast kernel hands out 64-query rounds from 0
             const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ws.grid, (b.count + 255) / 256)));
+            k_init_sharing<<<1, 1, 0, stream>>>(ws.ctr, (long long)g.x * 4);
+            if (tq.tasks) FM_HIP(hipMemsetAsync(tq.tasks, 0, (size_t)tq.cap * sizeof(Task), stream));
             const uint32_t* qm = d_qmap ? d_qmap + b.first : nullptr;
             if (edit) {
                 if (x->bwt.sigma == 5)
@@ -2544,10 +2680,10 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                                                                               b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
             } else if (x->bwt.sigma == 5)
                 k_scheme_fast<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                    b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
+                                                                    b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, tq, use_key);
             else
                 k_scheme_fast<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
+                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, tq, use_key);
         }
     } else
 #endif
@@ -2825,19 +2961,33 @@ int fmgpu_index_accelerate_locate(fmgpu_index_t h, int32_t enable) {
 
 #if !FMGPU_WIDE   // (fmgpu_hit holds 64-bit fields: the record helpers are width-independent and live in the 32-bit-row build)
 // ---- hit records in the reference's callback order -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hit_keys(const fmgpu_hit* __restrict__ h, uint64_t count, uint64_t* __restrict__ key_q, uint32_t* __restrict__ key_s,
+// order key of a record inside its read: fmgpu_hit::seq, extended by the upper 24 bits of fmgpu_hit::errors (the path key of k_scheme_fast;
+// zero for the kernels that number their reports themselves)
+__global__ __launch_bounds__(256) void k_hit_keys(const fmgpu_hit* __restrict__ h, uint64_t count, uint64_t* __restrict__ key_q, uint64_t* __restrict__ key_s,
                                                   uint32_t* __restrict__ idx) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < count) { key_q[t] = h[t].qidx; key_s[t] = h[t].seq; idx[t] = (uint32_t)t; }
+    if (t < count) { key_q[t] = h[t].qidx; key_s[t] = ((uint64_t)(h[t].errors >> 8) << 32) | h[t].seq; idx[t] = (uint32_t)t; }
 }
 __global__ __launch_bounds__(256) void k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ perm, uint64_t count, uint64_t* __restrict__ dst) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < count) dst[t] = src[perm[t]];
 }
-__global__ __launch_bounds__(256) void k_gather_hits(const fmgpu_hit* __restrict__ src, const uint32_t* __restrict__ perm, uint64_t count, fmgpu_hit* __restrict__ dst) {
+// records in their final order; first[t] = t where a new read starts, else 0 (for the running maximum that finds every record's read start)
+__global__ __launch_bounds__(256) void k_gather_hits(const fmgpu_hit* __restrict__ src, const uint32_t* __restrict__ perm, const uint64_t* __restrict__ sorted_q,
+                                                     uint64_t count, fmgpu_hit* __restrict__ dst, uint32_t* __restrict__ first) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < count) dst[t] = src[perm[t]];
+    if (t >= count) return;
+    dst[t] = src[perm[t]];
+    first[t] = (t > 0 && sorted_q[t] != sorted_q[t - 1]) ? (uint32_t)t : 0u;
 }
+// seq = position of the record within its read (the dense callback index), errors = the error count alone
+__global__ __launch_bounds__(256) void k_renumber_hits(fmgpu_hit* __restrict__ h, const uint32_t* __restrict__ start, uint64_t count) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    h[t].seq = (uint32_t)t - start[t];
+    h[t].errors &= 0xffu;
+}
+struct MaxU32 { __host__ __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
 
 // 16-byte transport form of a hit: word 0 = qidx:32 | lb:32, word 1 = len:32 | errors:8 | seq:24; a record that does not fit raises *bad
 __global__ __launch_bounds__(256) void k_hits_pack16(const fmgpu_hit* __restrict__ h, uint64_t count, ulonglong2* __restrict__ out, unsigned int* __restrict__ bad) {
@@ -2848,66 +2998,80 @@ __global__ __launch_bounds__(256) void k_hits_pack16(const fmgpu_hit* __restrict
     out[t] = make_ulonglong2((r.qidx & 0xffffffffull) | (r.lb << 32),
                              (r.len & 0xffffffffull) | ((uint64_t)(r.errors & 0xffu) << 32) | ((uint64_t)(r.seq & 0xffffffu) << 40));
 }
+// 24-byte transport form: word 0 = qidx:32 | lb:32, word 1 = len:32 | errors:32 (with the upper key bits), word 2 = lb_rev:32 | seq:32 — everything
+// of a record whose rows and read number are below 2^32, order key included
+__global__ __launch_bounds__(256) void k_hits_pack24(const fmgpu_hit* __restrict__ h, uint64_t count, uint64_t* __restrict__ out, unsigned int* __restrict__ bad) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const fmgpu_hit r = h[t];
+    if ((r.qidx | r.lb | r.len | r.lb_rev) >> 32) atomicOr(bad, 1u);
+    out[3 * t] = (r.qidx & 0xffffffffull) | (r.lb << 32);
+    out[3 * t + 1] = (r.len & 0xffffffffull) | ((uint64_t)r.errors << 32);
+    out[3 * t + 2] = (r.lb_rev & 0xffffffffull) | ((uint64_t)r.seq << 32);
+}
 
-int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream_) {
+static int hits_pack(const fmgpu_hit* hits, uint64_t count, uint64_t* out, int words, void* stream_) {
     if (count == 0) return 0;
     if (!hits || !out) return fail(FMGPU_ERR_INVALID, "hits / out is null");
     hipStream_t stream = (hipStream_t)stream_;
     Staged sh, so;
     int rc = sh.in(hits, count * sizeof(fmgpu_hit), stream); if (rc) return rc;
-    if ((rc = so.out(out, count * 16, stream))) return rc;
+    if ((rc = so.out(out, count * 8 * (size_t)words, stream))) return rc;
     CallScratch* sc = nullptr;
     if ((rc = call_scratch(&sc))) return rc;
     unsigned int* bad = reinterpret_cast<unsigned int*>(sc->len2);      // (a word of the thread's scratch; the read-back below orders this call's use of it)
     FM_HIP(hipMemsetAsync(bad, 0, 4, stream));
     FM_GRID(grid, count);
-    k_hits_pack16<<<grid, dim3(256), 0, stream>>>((const fmgpu_hit*)sh.dev, count, (ulonglong2*)so.dev, bad);
-    FM_LAUNCHED("k_hits_pack16");
+    if (words == 2) k_hits_pack16<<<grid, dim3(256), 0, stream>>>((const fmgpu_hit*)sh.dev, count, (ulonglong2*)so.dev, bad);
+    else k_hits_pack24<<<grid, dim3(256), 0, stream>>>((const fmgpu_hit*)sh.dev, count, (uint64_t*)so.dev, bad);
+    FM_LAUNCHED("k_hits_pack");
     unsigned int* hbad = reinterpret_cast<unsigned int*>(sc->pinned);
     FM_HIP(hipMemcpyAsync(hbad, bad, 4, hipMemcpyDeviceToHost, stream));
     FM_HIP(hipStreamSynchronize(stream));
-    if (*hbad) return fail(FMGPU_ERR_UNSUPPORTED, "a hit record does not fit the 16-byte transport form (qidx, lb, len < 2^32, errors < 256, seq < 2^24)");
+    if (*hbad) return fail(FMGPU_ERR_UNSUPPORTED, words == 2 ? "a hit record does not fit the 16-byte transport form (qidx, lb, len < 2^32, errors < 256, seq < 2^24: records in callback order, fmgpu_hits_sort)"
+                                                             : "a hit record does not fit the 24-byte transport form (qidx, lb, lb_rev, len < 2^32)");
     return so.finish();
 }
+int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream) { return hits_pack(hits, count, out, 2, stream); }
+int fmgpu_hits_pack24(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream) { return hits_pack(hits, count, out, 3, stream); }
 
 int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream_) {
-    if (count <= 1) return 0;
+    if (count == 0) return 0;
     if (!hits) return fail(FMGPU_ERR_INVALID, "hits is null");
     if (count >= 0x7fffffffull) return fail(FMGPU_ERR_UNSUPPORTED, "more than 2^31 - 1 records");
     hipStream_t stream = (hipStream_t)stream_;
     Staged sh;
     int rc = sh.out(hits, count * sizeof(fmgpu_hit), stream); if (rc) return rc;            // in and out: host records are copied in first
     if (sh.writeback) FM_HIP(hipMemcpyAsync(sh.dev, hits, count * sizeof(fmgpu_hit), hipMemcpyHostToDevice, stream));
-    // stable LSD order: by seq first, then by qidx
-    uint64_t *kq = nullptr, *kq2 = nullptr; uint32_t *ks = nullptr, *ks2 = nullptr, *ix = nullptr, *ix2 = nullptr; fmgpu_hit* tmp_h = nullptr; void* tmp = nullptr;
-    auto drop = [&] { for (void* p : {(void*)kq, (void*)kq2, (void*)ks, (void*)ks2, (void*)ix, (void*)ix2, (void*)tmp_h, tmp}) if (p) (void)hipFree(p); };
-    hipError_t e = hipMalloc((void**)&kq, count * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&kq2, count * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&ks, count * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&ks2, count * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&ix, count * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&ix2, count * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&tmp_h, count * sizeof(fmgpu_hit));
-    size_t b1 = 0, b2 = 0;
-    if (e == hipSuccess) {
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b1, ks, ks2, ix, ix2, (int)count, 0, 32, stream);
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b2, kq, kq2, ix2, ix, (int)count, 0, 64, stream);
-        e = hipMalloc(&tmp, std::max(b1, b2));
-    }
-    if (e != hipSuccess) { drop(); return hip_fail(e, "hipMalloc(hit sort)"); }
-    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    // stable LSD order: by the order key first, then by qidx; then the keys are replaced by the dense callback index
+    DBuf kq, kq2, ks, ks2, ix, ix2, tmp_h, first, tmp;
+    if ((rc = kq.alloc(count * 8)) || (rc = kq2.alloc(count * 8)) || (rc = ks.alloc(count * 8)) || (rc = ks2.alloc(count * 8)) || (rc = ix.alloc(count * 4)) ||
+        (rc = ix2.alloc(count * 4)) || (rc = tmp_h.alloc(count * sizeof(fmgpu_hit))) || (rc = first.alloc(count * 4))) return rc;
+    size_t b1 = 0, b2 = 0, b3 = 0;
+    FM_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, ks.as<uint64_t>(), ks2.as<uint64_t>(), ix.as<uint32_t>(), ix2.as<uint32_t>(), (int)count, 0, 56, stream));
+    FM_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b2, kq.as<uint64_t>(), kq2.as<uint64_t>(), ix2.as<uint32_t>(), ix.as<uint32_t>(), (int)count, 0, 64, stream));
+    FM_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, b3, first.as<uint32_t>(), first.as<uint32_t>(), MaxU32{}, (int)count, stream));
+    const size_t tb0 = std::max(b1, std::max(b2, b3));
+    if ((rc = tmp.alloc(tb0))) return rc;
+    FM_GRID(grid, count);
+    const dim3 block(256);
     const fmgpu_hit* dh = (const fmgpu_hit*)sh.dev;
-    k_hit_keys<<<grid, block, 0, stream>>>(dh, count, kq, ks, ix);
-    size_t tb = std::max(b1, b2);
-    e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, ks, ks2, ix, ix2, (int)count, 0, 32, stream);          // ix2: order by seq
-    k_gather_u64<<<grid, block, 0, stream>>>(kq, ix2, count, kq2);                                         // qidx in that order
-    tb = std::max(b1, b2);
-    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, kq2, kq, ix2, ix, (int)count, 0, 64, stream);   // stable by qidx: ix = final order
-    k_gather_hits<<<grid, block, 0, stream>>>(dh, ix, count, tmp_h);
-    if (e == hipSuccess) e = hipMemcpyAsync(sh.dev, tmp_h, count * sizeof(fmgpu_hit), hipMemcpyDeviceToDevice, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    drop();
-    if (e != hipSuccess) return hip_fail(e, "hit sort");
+    k_hit_keys<<<grid, block, 0, stream>>>(dh, count, kq.as<uint64_t>(), ks.as<uint64_t>(), ix.as<uint32_t>());
+    FM_LAUNCHED("k_hit_keys");
+    size_t tb = tb0;
+    FM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, ks.as<uint64_t>(), ks2.as<uint64_t>(), ix.as<uint32_t>(), ix2.as<uint32_t>(), (int)count, 0, 56, stream));   // ix2: order by key
+    k_gather_u64<<<grid, block, 0, stream>>>(kq.as<uint64_t>(), ix2.as<uint32_t>(), count, kq2.as<uint64_t>());                                                       // qidx in that order
+    FM_LAUNCHED("k_gather_u64");
+    tb = tb0;
+    FM_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, kq2.as<uint64_t>(), kq.as<uint64_t>(), ix2.as<uint32_t>(), ix.as<uint32_t>(), (int)count, 0, 64, stream));   // stable by qidx: ix = final order
+    k_gather_hits<<<grid, block, 0, stream>>>(dh, ix.as<uint32_t>(), kq.as<uint64_t>(), count, tmp_h.as<fmgpu_hit>(), first.as<uint32_t>());
+    FM_LAUNCHED("k_gather_hits");
+    tb = tb0;
+    FM_HIP(hipcub::DeviceScan::InclusiveScan(tmp.p, tb, first.as<uint32_t>(), first.as<uint32_t>(), MaxU32{}, (int)count, stream));
+    k_renumber_hits<<<grid, block, 0, stream>>>(tmp_h.as<fmgpu_hit>(), first.as<uint32_t>(), count);
+    FM_LAUNCHED("k_renumber_hits");
+    FM_HIP(hipMemcpyAsync(sh.dev, tmp_h.p, count * sizeof(fmgpu_hit), hipMemcpyDeviceToDevice, stream));
+    FM_HIP(hipStreamSynchronize(stream));
     return sh.finish();
 }
 

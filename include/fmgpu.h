@@ -112,8 +112,10 @@ typedef struct fmgpu_index_desc {
 
 typedef struct fmgpu_index* fmgpu_index_t;
 
-/* one reported cursor: search/SearchNg26.h:398-403 delegate(qidx, cursor, errors); `seq` = position
- * of this report within its query in the reference's callback order */
+/* one reported cursor: search/SearchNg26.h:398-403 delegate(qidx, cursor, errors).  Order: the search kernels emit records in no particular
+ * order; inside a read, ascending (errors >> 8, seq) is the reference's callback order — `seq` is either the position of the report within its
+ * read, or (table-driven k-mismatch kernel, which lets idle lanes take over subtrees of a large read) the low 32 bits of a path key whose
+ * upper bits sit in errors[8..31].  fmgpu_hits_sort orders the records and leaves seq = the dense callback position, errors = the error count. */
 typedef struct fmgpu_hit {
     uint64_t qidx, lb, lb_rev, len;
     uint32_t errors, seq;
@@ -258,9 +260,14 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count,
  * synchronises `stream`). */
 int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
 
+/* the 24-byte transport form, for records as the search kernels emit them (not yet in callback order): out[3k] = qidx:32 | lb:32,
+ * out[3k+1] = len:32 | errors:32, out[3k+2] = lb_rev:32 | seq:32 — the whole record, order key included, for rows and read numbers below 2^32
+ * (FMGPU_ERR_UNSUPPORTED otherwise; the call synchronises `stream`). */
+int fmgpu_hits_pack24(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
+
 /* Puts `count` hit records (host or device memory) into the reference's callback order — ascending qidx, inside a query the order the
- * delegate is called in (search/SearchNg26.h:385-390; fmgpu_hit::seq) — with a stable device radix sort.  The search kernels emit records
- * in no particular order. */
+ * delegate is called in (search/SearchNg26.h:385-390) — with a stable device radix sort on (qidx, errors >> 8, seq), and normalises them:
+ * seq = position of the record within its query, errors = the error count (upper bits cleared). */
 int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream);
 
 /* GPU index construction from sequences — replaces FMIndex(Sequences, samplingRate, threads) (fmindex/FMIndex.h:58-104) and

@@ -641,6 +641,48 @@ def test_hit_records_pack16():
     assert np.array_equal(do.to_array(np.uint64, 2 * n).reshape(n, 2), want)
 
 
+def test_hit_records_pack24_and_range_checks():
+    """fmgpu_hits_pack24 carries the whole record of a 32-bit-row index, order key included; both transport forms refuse what does not fit"""
+    rng = np.random.default_rng(4)
+    n = 3000
+    hits = np.zeros(n, dtype=fm.HIT_DTYPE)
+    for f in ("qidx", "lb", "lb_rev", "len", "errors", "seq"):
+        hits[f] = rng.integers(0, 2**32, size=n)
+    out = np.zeros((n, 3), dtype=np.uint64)
+    capi.check(capi.lib().fmgpu_hits_pack24(capi.ptr(hits), n, capi.ptr(out), None))
+    assert np.array_equal(out[:, 0], hits["qidx"] | (hits["lb"] << np.uint64(32)))
+    assert np.array_equal(out[:, 1], hits["len"] | (hits["errors"].astype(np.uint64) << np.uint64(32)))
+    assert np.array_equal(out[:, 2], hits["lb_rev"] | (hits["seq"].astype(np.uint64) << np.uint64(32)))
+    bad = hits[:10].copy(); bad["lb"][3] = 2**32
+    assert capi.lib().fmgpu_hits_pack24(capi.ptr(bad), 10, capi.ptr(out), None) == capi.FMGPU_ERR_UNSUPPORTED
+    for field, value in (("errors", 256), ("seq", 2**24), ("qidx", 2**32), ("len", 2**33)):
+        ok = np.zeros(4, dtype=fm.HIT_DTYPE)
+        assert capi.lib().fmgpu_hits_pack16(capi.ptr(ok), 4, capi.ptr(out), None) == 0
+        ok[field][2] = value
+        assert capi.lib().fmgpu_hits_pack16(capi.ptr(ok), 4, capi.ptr(out), None) == capi.FMGPU_ERR_UNSUPPORTED, field
+
+
+def test_hits_sort_orders_by_path_key_and_normalises():
+    """fmgpu_hits_sort: ascending qidx, inside a read ascending (errors >> 8, seq); afterwards seq is the position inside the read and errors the
+    error count alone — whatever mixture of dense indices and path keys came in"""
+    rng = np.random.default_rng(9)
+    n = 20000
+    hits = np.zeros(n, dtype=fm.HIT_DTYPE)
+    hits["qidx"] = rng.integers(0, 300, size=n)
+    key = rng.permutation(n).astype(np.uint64) * np.uint64(2**40 // n)           # distinct 56-bit keys
+    hits["seq"] = (key & np.uint64(0xffffffff)).astype(np.uint32)
+    e = rng.integers(0, 3, size=n).astype(np.uint32)
+    hits["errors"] = e | ((key >> np.uint64(32)).astype(np.uint32) << np.uint32(8))
+    hits["lb"] = np.arange(n)
+    order = np.lexsort((key, hits["qidx"]))
+    got = hits.copy()
+    capi.check(capi.lib().fmgpu_hits_sort(capi.ptr(got), n, None))
+    assert np.array_equal(got["lb"], hits["lb"][order]) and np.array_equal(got["errors"], e[order])
+    starts = np.r_[0, np.nonzero(np.diff(got["qidx"].astype(np.int64)))[0] + 1]
+    want_seq = np.arange(n) - np.repeat(starts, np.diff(np.r_[starts, n]))
+    assert np.array_equal(got["seq"], want_seq.astype(np.uint32))
+
+
 # ------------------------------------------------------------------------------------------------ concurrency (SURVEY 8b: threads, streams)
 def test_concurrent_host_threads_on_one_handle():
     """the reference is re-entrant on a const index; so is the C-ABI: four host threads run exact, k-mismatch, edit-distance, search_ng21
