@@ -70,7 +70,7 @@ bool want_wide(uint64_t n) {
 // tables) leaves nothing half-initialised behind, and the next call simply tries again.  Keyed by device: a host thread that alternates
 // between handles on two devices re-uses both sets.  FMGPU_FAIL_SCRATCH=k (test knob) fails the k-th allocation of the next creation.
 void CallScratch::drop() {
-    for (void* p : {(void*)ctr, (void*)sink, (void*)len2, frames, dfs_ctr, tasks}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)ctr, (void*)sink, (void*)len2, frames, dfs_ctr}) if (p) (void)hipFree(p);
     if (pinned) (void)hipHostFree(pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
@@ -103,7 +103,7 @@ int call_scratch(CallScratch** out) {
     if ((rc = guard(hipMalloc((void**)&sc.sink, ctr_bytes), "hipMalloc(call scratch: sink)"))) return rc;
     if ((rc = guard(hipMalloc((void**)&sc.len2, (2 * 1024 + 1) * 8), "hipMalloc(call scratch: length reduction)"))) return rc;
     if ((rc = guard(hipHostMalloc((void**)&sc.pinned, (2 * 1024 + 1) * 8, hipHostMallocDefault), "hipHostMalloc(call scratch)"))) return rc;
-    if ((rc = guard(hipMalloc(&sc.dfs_ctr, 64), "hipMalloc(call scratch: DFS counters)"))) return rc;
+    if ((rc = guard(hipMalloc(&sc.dfs_ctr, 256), "hipMalloc(call scratch: DFS counters)"))) return rc;
     if ((rc = guard(hipEventCreate(&sc.ev_a), "hipEventCreate"))) return rc;
     if ((rc = guard(hipEventCreate(&sc.ev_b), "hipEventCreate"))) return rc;
     *out = &(set.by_dev[dev] = sc);

@@ -182,24 +182,17 @@ struct SchemeDev {             // flattened [search][part]; values fit a byte (e
     int dev_flags;                   // dev knobs: 1 = count hits per lane only (no records)
 };
 
-struct Counters { unsigned long long hits, nodes, next, table_bytes, table_accesses, tq_head, tq_tail; long long busy_waves; };
+struct Counters { unsigned long long hits, nodes, next, table_bytes, table_accesses; };
 
-// ---- work sharing between the lanes of k_scheme_fast ---------------------------------------------------------------------------------
+// ---- work sharing between the lanes of a wave in k_scheme_fast -------------------------------------------------------------------------
 // The work of a k-mismatch search is heavy-tailed on a repeat-rich text: the median read visits ~200 nodes, a read from a satellite array
 // half a million (measured on the genome-like text: 0.02 % of the reads hold 13 % of all nodes), and a depth-first walk of one read by one
-// lane takes as long as its node count.  A lane that has spent kExportNodes nodes on its current read therefore hands the BOTTOM frame of its
-// stack — the untried siblings of its shallowest branching node, i.e. the largest piece of work it still owns — to a global task queue; any
-// lane that runs out of work takes tasks before it takes fresh reads.  A task is a self-contained resumed frame (read, search, cursor, step,
-// errors, next sibling, path key).  This needs an order of the hit records that does not depend on who found them: the path key below.
-struct Task {
-    uint64_t q_si;                 // read number (bits 0..47) | search (48..55) | valid (56..63), written last
-    uint32_t lb, lbRev, len;
-    uint32_t jer;                  // step j (bits 0..15) | errors e (16..23) | next sibling (24..31)
-    uint64_t key;
-};
-struct TaskQueue { Task* tasks; uint32_t cap; uint32_t export_nodes; };
-constexpr uint32_t kTaskCap = 1u << 21;
-constexpr uint32_t kExportNodes = 1024;
+// lane takes as long as its node count.  A lane that has spent kShareNodes nodes on its current read therefore offers the BOTTOM frame of its
+// stack — the untried siblings of its shallowest branching node, the largest piece of work it still owns — to the lanes of its wave that
+// are out of work: the frame travels by lane shuffles, the staged read by an LDS column copy, no atomic and no global traffic beyond the
+// three frame words.  (A device-wide task queue was tried first: one queue head for thousands of waiting waves serialised the hand-over at
+// ~1.3 us per task — 2 M tasks, 8 s — and was dropped.)  This needs an order of the hit records that does not depend on who found them:
+constexpr uint32_t kShareNodes = 16;
 
 // Path key: the callback order of the reference is the depth-first order in which every node tries its match child first and its substitution
 // children in ascending symbol order (SearchNg26.h:171-218).  For hits of one read that is the lexicographic order of
@@ -1365,7 +1358,7 @@ template <int SIGMA, int MAXSIG>
 __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
-                                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, TaskQueue tq, int use_key) {
+                                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, int sharing, int use_key) {
     // One flat loop per lane over (query, search, node) with every slow path wave-synchronous.  A wave pays for every slow path any of its 64
     // lanes takes, so nothing with a dependent memory round trip is lane-private: queries are fetched and staged TOGETHER — as soon as
     // kRefillLanes lanes of the wave are out of work (one atomicAdd per refill, query words issued back to back) — and hits are kept in LDS
@@ -1395,9 +1388,9 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     const uint32_t refill_wait = ((uint32_t)dev_flags >> 16) & 255u ? ((uint32_t)dev_flags >> 16) & 255u : kRefillWait;
     uint32_t dry_iters = 0;                                         // iterations since a lane of the wave ran out of work (wave-uniform)
     uint32_t nh = 0, count_only = 0, nodes0 = 0;
-    const bool sharing = tq.tasks != nullptr;                       // work sharing through the task queue (unlimited hits, path keys)
-    bool wave_busy = true, is_task = false;
-    uint32_t sbase = 0, mark = 0;                                   // frames below sbase were handed out; nodes at the lane's last export
+    bool is_task = false;                                           // the lane works on a subtree it took over from another lane
+    uint32_t sbase = 0, mark = 0;                                   // frames below sbase were handed out; nodes at the lane's last hand-out
+    const uint32_t share_nodes = ((uint32_t)dev_flags >> 25) & 31u ? 1u << (((uint32_t)dev_flags >> 25) & 31u) : kShareNodes;   // (dev knob: bits 25..29)
     uint64_t pkey = 0;                                              // path key of the node the lane stands on
     bool have = false, exhausted = n == 0, need_start = false, query_over = false;
     uint64_t q = 0, quota = 0;
@@ -1409,44 +1402,44 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     bool in_tail = false;
     for (;;) {
         // ---- wave-synchronous part: every lane passes here in every iteration
-        const uint64_t needm = __ballot(!have && (!exhausted || sharing)), busym = __ballot(have);
+        if (sharing) {
+            const uint64_t idlem = __ballot(!have), offerm = __ballot(have && sp > sbase && nodes - mark >= share_nodes);
+            if (idlem && offerm) {
+                // the i-th idle lane takes the bottom frame of the i-th offering lane
+                const uint64_t below = (1ull << lane) - 1ull;
+                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
+                const bool give = have && sp > sbase && nodes - mark >= share_nodes && (uint32_t)__popcll(offerm & below) < pairs;
+                const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
+                uint64_t w0 = 0, w1 = 0, w2 = 0;
+                if (give) {
+                    const uint64_t o = (uint64_t)sbase * stk.nlanes + gid;
+                    w0 = stk.p0[o]; w1 = stk.p1[o]; w2 = stk.p2[o];
+                    ++sbase; mark = nodes; tbytes += 24u; ++tacc;
+                }
+                uint64_t om = offerm;                               // the lane of my partner: the (rank + 1)-th offering lane
+                for (uint32_t k = take ? (uint32_t)__popcll(idlem & below) : 0u; k > 0; --k) om &= om - 1ull;
+                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const uint64_t tw0 = __shfl(w0, vl, 64), tw1 = __shfl(w1, vl, 64), tw2 = __shfl(w2, vl, 64), tq_ = __shfl(q, vl, 64);
+                const uint64_t tqs = __shfl((uint64_t)qs, vl, 64);
+                const uint32_t tsi = __shfl(si, vl, 64);
+                if (take) {
+                    q = tq_; si = tsi; qs = reinterpret_cast<const uint8_t*>(tqs);
+                    cur.lb = (idx_t)tw0; cur.lbRev = (idx_t)(tw0 >> 32); cur.len = (idx_t)tw1;
+                    j = (uint32_t)(tw1 >> 32) & 0xffffu; e = (uint32_t)(tw1 >> 48) & 0xffu; resume = (uint32_t)(tw1 >> 56) & 0xffu;
+                    pkey = tw2;
+                    const uint32_t vt = (threadIdx.x & ~63u) | (uint32_t)vl;
+                    for (uint32_t w = 0; w < qwords; ++w) s_dyn[w * 256u + threadIdx.x] = s_dyn[w * 256u + vt];     // the partner's staged read
+                    have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
+                    tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; mark = nodes; nodes0 = nodes;
+                }
+            }
+        }
+        const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
         dry_iters = needm ? dry_iters + 1u : 0u;
         if (needm && ((uint32_t)__popcll(needm) >= refill_at || dry_iters > refill_wait || !busym)) {
             dry_iters = 0;
-            bool want = !have && (!exhausted || sharing);
+            const bool want = !have && !exhausted;
             bool fresh = false; uint64_t qo = 0;
-            if (sharing) {                                          // tasks first: they are the large pieces
-                const uint64_t wm = __ballot(want);
-                unsigned long long th = 0; uint32_t take = 0;
-                if (lane == 0) {
-                    for (;;) {
-                        const unsigned long long h = __atomic_load_n(&ctr->tq_head, __ATOMIC_RELAXED);
-                        unsigned long long t = __atomic_load_n(&ctr->tq_tail, __ATOMIC_RELAXED);
-                        if (t > tq.cap) t = tq.cap;
-                        if (t <= h) break;
-                        const unsigned long long k = t - h < (unsigned long long)__popcll(wm) ? t - h : (unsigned long long)__popcll(wm);
-                        if (atomicCAS(&ctr->tq_head, h, h + k) == h) { th = h; take = (uint32_t)k; break; }
-                    }
-                }
-                take = __builtin_amdgcn_readfirstlane(take);
-                th = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(th >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)th);
-                const uint32_t myrank = (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
-                if (want && myrank < take) {
-                    const Task* tk = tq.tasks + th + myrank;
-                    uint64_t qs_ = __atomic_load_n(&tk->q_si, __ATOMIC_ACQUIRE);
-                    while (!(qs_ >> 56)) { __builtin_amdgcn_s_sleep(2); qs_ = __atomic_load_n(&tk->q_si, __ATOMIC_ACQUIRE); }   // (reserved by its exporter, not yet written)
-                    q = qs_ & 0xffffffffffffull; si = (uint32_t)(qs_ >> 48) & 0xffu;
-                    cur = Cur{tk->lb, tk->lbRev, tk->len};
-                    const uint32_t jer = tk->jer;
-                    j = jer & 0xffffu; e = (jer >> 16) & 0xffu; resume = jer >> 24;
-                    pkey = tk->key;
-                    qo = qoff[q]; qs = qbuf + qo; fresh = true;
-                    have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
-                    tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; mark = nodes; nodes0 = nodes;
-                    want = false;
-                }
-                want = want && !exhausted;
-            }
             const uint64_t got = wave_hand_out(want, ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
             if (want) {
                 if (got >= nq) exhausted = true;
@@ -1455,30 +1448,12 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     have = true; is_task = false; si = 0; need_start = true; quota = max_hits; seq = 0; query_over = false; nodes0 = nodes; mark = nodes;
                 }
             }
-            if (__ballot(fresh)) qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
+            qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
         }
         {
             const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(have);
             if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
-            if (!busy) {
-                if (__ballot(!exhausted) != 0ull) continue;         // fresh reads are left: the next refill fetches them
-                if (!sharing) break;
-                // no lane of the wave has work and no fresh read is left: wait for tasks of the waves that are still busy, leave when none is
-                int cmd = 0;                                        // 0 wait, 1 tasks are waiting, 2 leave
-                if (lane == 0) {
-                    if (wave_busy) atomicAdd((unsigned long long*)&ctr->busy_waves, ~0ull);
-                    unsigned long long t = __atomic_load_n(&ctr->tq_tail, __ATOMIC_RELAXED);
-                    if (t > tq.cap) t = tq.cap;
-                    if (t > __atomic_load_n(&ctr->tq_head, __ATOMIC_RELAXED)) { atomicAdd((unsigned long long*)&ctr->busy_waves, 1ull); cmd = 1; }
-                    else if (__atomic_load_n(&ctr->busy_waves, __ATOMIC_RELAXED) <= 0) cmd = 2;
-                }
-                cmd = __builtin_amdgcn_readfirstlane(cmd);
-                wave_busy = cmd == 1;
-                if (cmd == 2) break;
-                if (cmd == 0) __builtin_amdgcn_s_sleep(32);
-                dry_iters = refill_wait + 1u;                       // try to take tasks at once
-                continue;
-            }
+            if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
         }
         if (!have) continue;
         {
@@ -1753,22 +1728,6 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32); cur.len = (idx_t)w1;
                         j = (uint32_t)(w1 >> 32) & 0xffffu; e = (uint32_t)(w1 >> 48) & 0xffu; resume = (uint32_t)(w1 >> 56) & 0xffu;
                         in_tail = false;
-                    }
-                }
-                if (sharing && !search_over && sp > sbase && nodes - mark >= tq.export_nodes) {
-                    // this read is a large one: hand the bottom frame — the untried siblings of the shallowest branching node — to whoever is idle
-                    mark = nodes;
-                    const unsigned long long slot = atomicAdd(&ctr->tq_tail, 1ull);
-                    if (slot < tq.cap) {
-                        const uint64_t o = (uint64_t)sbase * stk.nlanes + gid;
-                        const uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o];
-                        Task* tk = tq.tasks + slot;
-                        tk->lb = (uint32_t)w0; tk->lbRev = (uint32_t)(w0 >> 32); tk->len = (uint32_t)w1;
-                        tk->jer = (uint32_t)(w1 >> 32);             // j | e << 16 | next sibling << 24, as the frame holds them
-                        tk->key = w2;
-                        __atomic_store_n(&tk->q_si, (q & 0xffffffffffffull) | ((uint64_t)si << 48) | (1ull << 56), __ATOMIC_RELEASE);
-                        ++sbase;
-                        tbytes += 56u; tacc += 2u;
                     }
                 }
                 if (search_over) {                                  // the next search of the scheme, or the lane is out of work
@@ -2281,11 +2240,6 @@ __global__ __launch_bounds__(256) void k_len_pairs(const uint64_t* __restrict__ 
     if (q < nq) { len[q] = (uint32_t)(qoff[q + 1] - qoff[q]); idx[q] = (uint32_t)q; }
 }
 
-// counters of one launch of the work-sharing kernel: reads are handed out from 0, the task queue is empty, every wave of the grid counts as busy
-__global__ void k_init_sharing(Counters* c, long long waves) {
-    c->next = 0; c->tq_head = 0; c->tq_tail = 0; c->busy_waves = waves;
-}
-
 constexpr size_t kFrameCache = (size_t)2 << 30;
 struct DfsWorkspace {
     uint64_t* planes = nullptr; Counters* ctr = nullptr; StackView view{};
@@ -2637,21 +2591,9 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
 #endif
 #if !FMGPU_WIDE
     // path keys order the hits of a read whoever finds them (<= 2 substitutions fit the key); with them and no limit on the hits per read the
-    // lanes share the work of large reads through the task queue
+    // lanes of a wave share the work of large reads
     const int use_key = fast && !edit && max_u <= 2 && sd.S <= 16 ? 1 : 0;
-    TaskQueue tq{nullptr, 0, kExportNodes};
-    if (use_key && max_hits == ~0ull && !(sd.dev_flags & (1 << 24))) {
-        CallScratch* sc = nullptr;
-        if ((rc = call_scratch(&sc))) { if (d_qmap) (void)hipFree(d_qmap); if (d_steps) (void)hipFree(d_steps); return rc; }
-        const size_t need = (size_t)kTaskCap * sizeof(Task);
-        if (sc->tasks_bytes < need) {
-            if (sc->tasks) { (void)hipFree(sc->tasks); sc->tasks = nullptr; sc->tasks_bytes = 0; }
-            if (hipMalloc(&sc->tasks, need) == hipSuccess) sc->tasks_bytes = need; else (void)hipGetLastError();      // (no room: the search runs without sharing)
-        }
-        if (sc->tasks) { tq.tasks = (Task*)sc->tasks; tq.cap = kTaskCap; }
-        const uint32_t lg = ((uint32_t)sd.dev_flags >> 25) & 31u;     // dev knob: log2 of the export threshold
-        if (lg) tq.export_nodes = 1u << lg;
-    }
+    const int sharing = use_key && max_hits == ~0ull && !(sd.dev_flags & (1 << 24)) ? 1 : 0;
 #endif
     timer.start();
 #if !FMGPU_WIDE
@@ -2668,8 +2610,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
             const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (size_t)kWaveHitWords * 4;
             const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ws.grid, (b.count + 255) / 256)));
-            k_init_sharing<<<1, 1, 0, stream>>>(ws.ctr, (long long)g.x * 4);
-            if (tq.tasks) FM_HIP(hipMemsetAsync(tq.tasks, 0, (size_t)tq.cap * sizeof(Task), stream));
+            FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));   // reads are handed out from 0
             const uint32_t* qm = d_qmap ? d_qmap + b.first : nullptr;
             if (edit) {
                 if (x->bwt.sigma == 5)
@@ -2680,10 +2621,10 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                                                                               b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
             } else if (x->bwt.sigma == 5)
                 k_scheme_fast<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                    b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, tq, use_key);
+                                                                    b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
             else
                 k_scheme_fast<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, tq, use_key);
+                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
         }
     } else
 #endif
