@@ -192,7 +192,7 @@ struct Counters { unsigned long long hits, nodes, next, table_bytes, table_acces
 // are out of work: the frame travels by lane shuffles, the staged read by an LDS column copy, no atomic and no global traffic beyond the
 // three frame words.  (A device-wide task queue was tried first: one queue head for thousands of waiting waves serialised the hand-over at
 // ~1.3 us per task — 2 M tasks, 8 s — and was dropped.)  This needs an order of the hit records that does not depend on who found them:
-constexpr uint32_t kShareNodes = 16;
+constexpr uint32_t kShareNodes = 2;
 
 // Path key: the callback order of the reference is the depth-first order in which every node tries its match child first and its substitution
 // children in ascending symbol order (SearchNg26.h:171-218).  For hits of one read that is the lexicographic order of
