@@ -1443,3 +1443,93 @@ def test_rows_beyond_2_32():
     for c in range(5):
         want = np.array([ox.bwt_string().rank(int(i), c) for i in idx], dtype=np.uint64)
         assert np.array_equal(gx.rank(idx, c), want)
+
+
+def test_full_size_protein_wavelet_equals_the_cpu_walk():
+    """BASELINE.json configs[4] at full index size (2e9 residues, sigma = 28, FMIndex<28, Wavelet>): the oracle's Wavelet is built from the GPU-built
+    BWT and the (lb, len) of 100 k reads x 40 aa — every tenth with one substitution — are compared, on the multi-ary tree itself and on its
+    block-table expansion with the exact-search tables; located origins too."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    nseq, slen, sigma, L, nq = 4_000_000, 500, 28, 40, 100_000
+    n = nseq * slen
+    g = torch.Generator(device=dev); g.manual_seed(42)
+    text = torch.empty(n, dtype=torch.uint8, device=dev)
+    for lo in range(0, n, 1 << 28):
+        hi = min(n, lo + (1 << 28))
+        text[lo:hi] = torch.randint(1, sigma, (hi - lo,), generator=g, device=dev, dtype=torch.uint8)
+    seq_id = torch.randint(0, nseq, (nq,), generator=g, device=dev, dtype=torch.int64)
+    off = torch.randint(0, slen - L + 1, (nq,), generator=g, device=dev, dtype=torch.int64)
+    reads = text[(seq_id * slen + off)[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
+    mut = torch.arange(0, nq, 10, device=dev)
+    reads[mut, 7] = reads[mut, 7] % (sigma - 1) + 1
+    seq_off = torch.arange(nseq + 1, device=dev, dtype=torch.int64) * slen
+    gx = fm.FMIndex.from_sequences((_V(text), _V(seq_off)), sigma, "WAVELET", 16, keep_host=True)
+    del text
+    torch.cuda.empty_cache()
+    ox = _oracle_from_built(gx, False, sigma=sigma, layout="WAVELET")
+    hq, ho = reads.reshape(-1).cpu().numpy(), np.arange(nq + 1, dtype=np.uint64) * L
+    olb, oln = ox.search_exact(hq, ho, nthreads=len(os.sched_getaffinity(0)))
+    lb, ln, st = fm.search_no_errors.search(gx, (hq, ho), want_stats=True)
+    assert np.array_equal(lb, olb) and np.array_equal(ln, oln) and st.table_accesses > 0
+    assert int((ln > 0).sum()) >= nq - len(mut)
+    hit = np.nonzero(ln == 1)[0][:20000]
+    sq, pos, steps = gx.locate(lb[hit])
+    assert np.array_equal(sq, seq_id.cpu().numpy()[hit].astype(np.uint64)) and np.array_equal(pos + steps, off.cpu().numpy()[hit].astype(np.uint64))
+    gx.accelerate(1, lut_len=6, walk=2)
+    lb2, ln2 = fm.search_no_errors.search(gx, (hq, ho))
+    assert np.array_equal(lb2, olb) and np.array_equal(ln2, oln)
+
+
+def test_failed_table_requests_leave_the_handle_as_it_was():
+    """a table that cannot be built is refused with an error code — FMGPU_ERR_UNSUPPORTED for more than 2^32 entries, FMGPU_ERR_NOMEM / _HIP for an
+    allocation that does not fit — and neither device_bytes nor the results change (tables are built into local buffers and installed after success)"""
+    text = make_text(50_000, 5, seed=2)
+    ox = fo.OraIndex.build("IB16", 5, [text], 16, True)
+    gx = gpu_index(ox)
+    qbuf, qoff = fm.flatten(sample_reads(text, 500, 30, seed=1, mutate=1))
+    want = fm.search_no_errors.search(gx, (qbuf, qoff))
+    before = gx.device_bytes
+    for call in (lambda: gx.accelerate_search(17, 0), lambda: gx.accelerate(3, lut_len=17), lambda: gx.accelerate(9)):
+        with pytest.raises(fm.FmgpuError) as ei:
+            call()
+        assert ei.value.code in (capi.FMGPU_ERR_UNSUPPORTED, capi.FMGPU_ERR_INVALID)
+    gx.accelerate_search(0, 0); gx.accelerate(1)
+    dbytes = C.c_uint64()
+    capi.check(capi.lib().fmgpu_index_info(gx._h, None, None, None, None, C.byref(dbytes)))
+    assert dbytes.value == before
+    got = fm.search_no_errors.search(gx, (qbuf, qoff))
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_call_scratch_allocation_failure_is_an_error_not_a_fault():
+    """FMGPU_FAIL_SCRATCH=k fails the k-th allocation of the per-thread call scratch: the call returns an error code, nothing half-initialised
+    stays behind, and the next call (on a fresh host thread, whose scratch is created anew) works"""
+    import threading
+    text = make_text(20_000, 5, seed=5)
+    ox = fo.OraIndex.build("IB16", 5, [text], 16, False)
+    gx = gpu_index(ox)
+    qbuf, qoff = fm.flatten(sample_reads(text, 200, 25, seed=2))
+    want = ox.search_exact(qbuf, qoff)
+    out = {}
+
+    def worker(tag, env):
+        if env:
+            os.environ["FMGPU_FAIL_SCRATCH"] = env
+        try:
+            capi.check(capi.lib().fmgpu_set_device(0))
+            try:
+                out[tag] = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)[:2]
+            except fm.FmgpuError as ex:
+                out[tag] = ex
+                out[tag + "_retry"] = None
+                os.environ.pop("FMGPU_FAIL_SCRATCH", None)
+                out[tag + "_retry"] = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)[:2]    # same thread: the scratch is built now
+        finally:
+            os.environ.pop("FMGPU_FAIL_SCRATCH", None)
+    for k in ("1", "4", "6"):
+        t = threading.Thread(target=worker, args=("fail" + k, k)); t.start(); t.join()
+        assert isinstance(out["fail" + k], fm.FmgpuError) and out["fail" + k].code in (capi.FMGPU_ERR_NOMEM, capi.FMGPU_ERR_HIP)
+        r = out["fail" + k + "_retry"]
+        assert r is not None and np.array_equal(r[0], want[0]) and np.array_equal(r[1], want[1])
+
