@@ -45,6 +45,7 @@ BLOCK_BYTES_IB16_S5 = 56       # sizeof(InterleavedBitvector16<5>::Block), SURVE
 BYTES_PER_STEP_DNA = 2 * BLOCK_BYTES_IB16_S5          # both interval ends
 BYTES_PER_STEP_WAVELET28 = 2 * 5 * 17                 # 2 ends x 5 levels x (8 + 1 + 8) B
 PROTEIN_SEQS, PROTEIN_SEQ_LEN = 4_000_000, 500        # UniRef50 stand-in (the release itself is not available offline): 2.0e9 residues
+PROTEIN_SEQS_WIDE = 9_000_000                         # ... and 4.5e9 residues: more than 2^32 rows, the 64-bit-row build of the kernels (UniRef50 itself is ~1e10)
 
 
 def parse():
@@ -60,6 +61,7 @@ def parse():
     ap.add_argument("--prefix-len", type=int, default=16, help="k2 tables: symbols of the prefix table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-protein", action="store_true")
+    ap.add_argument("--no-protein-wide", action="store_true", help="skip the 4.5e9-residue protein record (64-bit rows)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto, ~15 s of CPU work)")
     ap.add_argument("--single-rank-collectives", action="store_true", help="rehearsal only: run the N > 1 code path (process group, asynchronous gather, barrier) with one rank")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -129,7 +131,9 @@ def main():
     for name in texts:
         records += run_dna_text(c, name, primary=(name == texts[0]))
     if not c.multi and not args.no_protein and args.scale == 1.0 and (not c.only or any(o.startswith("protein") for o in c.only)):
-        records += run_protein(c)
+        records += run_protein(c, PROTEIN_SEQS, "protein")
+        if not args.no_protein_wide:
+            records += run_protein(c, PROTEIN_SEQS_WIDE, "protein_wide")
     if rank != 0:
         if c.multi:
             c.dist.destroy_process_group()
@@ -555,14 +559,13 @@ def _scheme_struct(capi, scheme):
 
 
 # ---------------------------------------------------------------------------------------------------------------- protein, configs[4]
-def run_protein(c):
+def run_protein(c, nseq, tag):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
-    ids = ["protein/exact/wavelet", "protein/exact/tables"]
+    ids = [tag + "/exact/wavelet"] + ([tag + "/exact/tables"] if tag == "protein" else [])     # the tables exist for 32-bit rows only
     if c.only and not any(i in c.only for i in ids):
         return []
     sigma, L, nq = 28, 40, args.nq
-    nseq = PROTEIN_SEQS
     total = nseq * PROTEIN_SEQ_LEN
     g = torch.Generator(device=c.dev)
     g.manual_seed(42)
@@ -572,6 +575,7 @@ def run_protein(c):
         text[lo:hi] = torch.randint(1, sigma, (hi - lo,), generator=g, device=c.dev, dtype=torch.uint8)
     seq_off = torch.arange(nseq + 1, device=c.dev, dtype=torch.int64) * PROTEIN_SEQ_LEN
     qbuf, qoff = sample_reads(c, text, None, L, nq, 1000, "exact", sigma=sigma, inside=(nseq, PROTEIN_SEQ_LEN))
+    torch.cuda.synchronize()
     os.environ["FMGPU_LF_TABLE"] = "0"
     t0 = time.time()
     index = fm.FMIndex.from_sequences((_Dev(text), _Dev(seq_off)), sigma, "WAVELET", 16, keep_host=False)
@@ -593,8 +597,8 @@ def run_protein(c):
         r = {"id": rid, "metric": "queries/sec (sigma=28 protein index, 10M x 40aa, exact, Wavelet)", "value": qps, "unit": "queries/s", "n_gpus": 1, "steps": args.steps,
              "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
              "config": {"workload": "protein_exact", "text": {"text": "uniform residues in {1..27}", "symbols": total, "sequences": nseq}, "sigma": sigma, "layout": "Wavelet",
-                        "index": "FMIndex", "index_kind": kind, "queries_per_gpu": nq, "read_len": L, "index_device_bytes": index.device_bytes, "index_build_s": round(b_s, 2),
-                        "tables": tables},
+                        "index": "FMIndex", "index_kind": kind, "row_bits": index.row_bits, "queries_per_gpu": nq, "read_len": L, "index_device_bytes": index.device_bytes,
+                        "index_build_s": round(b_s, 2), "tables": tables},
              "gres_per_s": qps * L / 1e9, "hits": int((out_t[nq:] > 0).sum().item())}
         if kind == "wavelet":
             r["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_WAVELET28, k_ms, kernel, "LF steps")
@@ -611,7 +615,7 @@ def run_protein(c):
     if wanted(c, ids[0]):
         elapsed, log = timed(c, step)
         out.append(rec_of(ids[0], "wavelet", "k_exact_m", elapsed, log, build_s, None))
-    if wanted(c, ids[1]):
+    if len(ids) > 1 and wanted(c, ids[1]):
         t0 = time.time()
         index.accelerate(1, lut_len=6, walk=2)
         b2 = build_s + time.time() - t0

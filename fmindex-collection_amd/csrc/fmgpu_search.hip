@@ -1348,11 +1348,12 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
     add_counters(steps_total, steps, tbytes, tacc);
 }
 
-// when a wave fetches and stages new queries (a wave-synchronous phase of ~15 loads and LDS stores per lane, paid by all 64 lanes): as soon as
-// kRefillLanes lanes are out of work, or kRefillWait iterations after the first one ran dry — on a uniform text the lanes of a wave finish within
-// a few iterations of each other and one refill serves them all (measured, 10 M reads with tables: refill at 4 / 8 / 16 / 32 / 63 idle lanes =
-// 26 / 17 / 10.7 / 7.7 / 6.4 ms); next to a heavy read the others are re-filled after a bounded wait
-constexpr uint32_t kRefillLanes = 48, kRefillWait = 32;
+// when a wave fetches and stages new queries (a wave-synchronous phase of ~15 loads and LDS stores per lane, paid by all 64 lanes): when the
+// iterations its idle lanes have lost add up to kRefillWaste lane-iterations — about what the refill itself costs the wave.  On a uniform text
+// with tables the lanes of a wave finish within a few iterations of each other and one refill serves them all (measured, 10 M reads: refill at
+// 4 / 8 / 16 / 32 / 63 idle lanes = 26 / 17 / 10.7 / 7.7 / 6.4 ms); on the plain index a read takes ten times as many iterations and waiting for
+// 48 idle lanes cost 25 % (77 vs 61 ms at 16); next to a heavy read the others are re-filled after a bounded loss either way
+constexpr uint32_t kRefillWaste = 256;
 
 template <int SIGMA, int MAXSIG>
 __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
@@ -1384,9 +1385,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     const uint32_t sigma = fw.sigma(), R = sigma - 1;
     uint32_t nodes = 0;
     uint64_t tbytes = 0; uint32_t tacc = 0;                         // table bytes consumed / table accesses issued (fmgpu_stats)
-    const uint32_t refill_at = ((uint32_t)dev_flags >> 8) & 63u ? ((uint32_t)dev_flags >> 8) & 63u : kRefillLanes;   // (dev knobs: bits 8..13, 16..23)
-    const uint32_t refill_wait = ((uint32_t)dev_flags >> 16) & 255u ? ((uint32_t)dev_flags >> 16) & 255u : kRefillWait;
-    uint32_t dry_iters = 0;                                         // iterations since a lane of the wave ran out of work (wave-uniform)
+    const uint32_t refill_waste = ((uint32_t)dev_flags >> 8) & 0xffffu ? (((uint32_t)dev_flags >> 8) & 0xffffu) : kRefillWaste;   // (dev knob: bits 8..23)
+    uint32_t waste = 0;                                             // lane-iterations the wave's idle lanes have lost since its last refill (wave-uniform)
     uint32_t nh = 0, count_only = 0, nodes0 = 0;
     bool is_task = false;                                           // the lane works on a subtree it took over from another lane
     uint32_t sbase = 0, mark = 0;                                   // frames below sbase were handed out; nodes at the lane's last hand-out
@@ -1435,9 +1435,9 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
             }
         }
         const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
-        dry_iters = needm ? dry_iters + 1u : 0u;
-        if (needm && ((uint32_t)__popcll(needm) >= refill_at || dry_iters > refill_wait || !busym)) {
-            dry_iters = 0;
+        waste += (uint32_t)__popcll(needm);
+        if (needm && (waste >= refill_waste || !busym)) {
+            waste = 0;
             const bool want = !have && !exhausted;
             bool fresh = false; uint64_t qo = 0;
             const uint64_t got = wave_hand_out(want, ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
