@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--lut-len", type=int, default=15, help="exact tables: symbols of the interval table")
     ap.add_argument("--prefix-len", type=int, default=16, help="k2 tables: symbols of the prefix table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-edit", action="store_true", help="also measure k = 2 EDIT distance (search_ng26<Edit = true>, the reference's default) on 2 M of the 101-bp reads, with the tables")
     ap.add_argument("--no-protein", action="store_true")
     ap.add_argument("--no-protein-wide", action="store_true", help="skip the 4.5e9-residue protein record (64-bit rows)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto, ~15 s of CPU work)")
@@ -459,8 +460,9 @@ def run_dna_text(c, name, primary):
         stats = capi.Stats()
         sc = _scheme_struct(capi, scheme)
 
-        def k2_run(w, L, n_, index_kind, build_s):
-            rid = "%s/%s/%s" % (name, w, index_kind)
+        def k2_run(w, L, n_, index_kind, build_s, edit=False):
+            rid = "%s/%s%s/%s" % (name, w, "_edit" if edit else "", index_kind)
+            sc[0].edit = 1 if edit else 0
             if not wanted(c, rid) or (c.multi and index_kind == "plain"):
                 return None
             qb, qo = reads[w]
@@ -501,9 +503,9 @@ def run_dna_text(c, name, primary):
             elapsed, log = timed(c, step, xch.drain if xch else None)
             k_ms = mean([x["kernel_ms"] for x in log]); units = mean([x["units"] for x in log]); nh = mean([x["hits"] for x in log])
             qps = c.world * n_ * args.steps / elapsed
-            kernel = "k_scheme_fast"
+            kernel = "k_scheme_fast_edit" if edit else "k_scheme_fast"
             part = [L // 4 + (1 if p < L % 4 else 0) for p in range(4)]
-            rec = {"id": rid, "metric": "queries/sec (GRCh38-sized index, %s x %dbp, k=2 Hamming, h2(4,0,2))" % ("10M" if w == "k2" else ("%.1fM per GPU" % (n_ / 1e6)), L),
+            rec = {"id": rid, "metric": "queries/sec (GRCh38-sized index, %s x %dbp, k=2 %s, h2(4,0,2))" % ("10M" if w == "k2" and not edit else ("%.1fM per GPU" % (n_ / 1e6)), L, "edit distance" if edit else "Hamming"),
                    "value": qps, "unit": "queries/s", "n_gpus": c.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                    "higher_is_better": True, "scaling": "strong" if (c.multi and w == "k2_151") else "weak", "vs_baseline": None, "dtype": "u64",
                    "data": "synthetic" if name != "fasta" else "real",
@@ -512,7 +514,7 @@ def run_dna_text(c, name, primary):
                               "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2),
                               "tables": None if index_kind == "plain" else {"lf": True, "prefix_symbols": args.prefix_len, "walk": "LF,LF^2,LF^3 + LF^16"}},
                    "gbp_per_s": qps * L / 1e9, "hits": int(nh)}
-            if index_kind == "plain":
+            if index_kind == "plain" or edit:                  # (the edit-distance kernels do not count their loads: SURVEY 8d's node accounting)
                 rec["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_DNA, k_ms, kernel, "visited nodes (cursor extensions)")
             else:
                 st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
@@ -521,7 +523,7 @@ def run_dna_text(c, name, primary):
                 rec["exchange"] = {"collective": xch.mode, "bytes_per_rank_and_step": int(xch.last[0].numel()), "verified_on_rank0": xch.verify(),
                                    "record": "24 B per hit (qidx:32 | lb:32, len:32 | errors + order key:32, lb_rev:32 | order key:32)"}
             attach_traffic(c, rec)
-            if keep and w == "k2" and index_kind == "tables":
+            if keep and w == "k2" and index_kind == "tables" and not edit:
                 rec["cpu_baseline"] = cpu_baseline(c, index, True, qb, qo, n_, L, scheme, None, None, (hits_bufs[0], state["cnt"]))
             return rec
 
@@ -529,6 +531,11 @@ def run_dna_text(c, name, primary):
             out.append(k2_run(w, L, n_, "plain", build_plain))
         t0 = time.time()
         index.accelerate_lf(True)
+        if args.prefix_len >= 16:                              # the 16-symbol prefix table is 69 GB: keep room for the walk tables (99 GB) and this run's hit buffers
+            free_b, _ = torch.cuda.mem_get_info()
+            if free_b < (69 + 99 + 24) * (1 << 30):
+                print("bench.py: %.0f GB of HBM free: using a 15-symbol prefix table" % (free_b / 2**30), file=sys.stderr, flush=True)
+                args.prefix_len = 15
         try:
             index.accelerate_search(args.prefix_len, 3)
         except fm.FmgpuError as ex:                            # (the 16-symbol table is 69 GB: should the card be short of memory, one symbol less)
@@ -540,6 +547,11 @@ def run_dna_text(c, name, primary):
         build_tab = build_plain + time.time() - t0
         for (w, L, n_) in k2_legs:
             out.append(k2_run(w, L, n_, "tables", build_tab))
+        if args.with_edit and not c.multi and any(w == "k2" for w, _, _ in k2_legs):
+            qb, qo = reads["k2"]
+            n_e = min(2_000_000, nq)
+            reads["k2"] = (qb[: n_e * 101], qo[: n_e + 1])
+            out.append(k2_run("k2", 101, n_e, "tables", build_tab, edit=True))
         index.close()
         del index, reads
     del text

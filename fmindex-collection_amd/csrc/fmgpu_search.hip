@@ -199,6 +199,10 @@ constexpr uint32_t kShareNodes = 2;
 //   (search, [m - step of the 1st substitution, its symbol], [m - step of the 2nd substitution, its symbol])   with "no substitution" = 0:
 // a later first substitution is met earlier on the way back up.  24 bits per substitution; the key travels in fmgpu_hit::seq (low 32 bits) and
 // the upper 24 bits of fmgpu_hit::errors until fmgpu_hits_sort orders the records by (qidx, key) and turns it into the dense callback index.
+// the key of an ancestor that had made `e` substitutions: the fields of the later ones cleared (so frames need not carry keys)
+__device__ __forceinline__ uint64_t key_prefix(uint64_t key, uint32_t e) {
+    return e == 0u ? key & (0xffull << 48) : (e == 1u ? key & ~0xffffffull : key);
+}
 __device__ __forceinline__ uint64_t key_with(uint64_t key, uint32_t e_before, uint32_t m, uint32_t step, uint32_t symb) {
     if (e_before >= 2u) return key;
     return key | ((uint64_t)(((m - step) << 8) | symb) << (24u * (1u - e_before)));
@@ -1349,11 +1353,11 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
 }
 
 // when a wave fetches and stages new queries (a wave-synchronous phase of ~15 loads and LDS stores per lane, paid by all 64 lanes): when the
-// iterations its idle lanes have lost add up to kRefillWaste lane-iterations — about what the refill itself costs the wave.  On a uniform text
-// with tables the lanes of a wave finish within a few iterations of each other and one refill serves them all (measured, 10 M reads: refill at
-// 4 / 8 / 16 / 32 / 63 idle lanes = 26 / 17 / 10.7 / 7.7 / 6.4 ms); on the plain index a read takes ten times as many iterations and waiting for
-// 48 idle lanes cost 25 % (77 vs 61 ms at 16); next to a heavy read the others are re-filled after a bounded loss either way
-constexpr uint32_t kRefillWaste = 256;
+// iterations its idle lanes have lost add up to kRefillWaste lane-iterations.  A refill costs the working lanes more than it looks: measured on
+// 10 M reads, waste threshold 256 / 512 / 2048 / 4096 lane-iterations = uniform text with tables 8.1 / 6.65 / 6.64 / 6.64 ms, uniform plain index
+// 77 / 71 / 61.6 / 64.6 ms, genome text with tables 134 / 131 / 129 / 129 ms — on a uniform text the lanes of a wave finish within a few
+// iterations of each other and one refill serves them all; next to a heavy read the idle lanes are first served by its shared frames
+constexpr uint32_t kRefillWaste = 2048;
 
 template <int SIGMA, int MAXSIG>
 __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
@@ -1413,8 +1417,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 uint64_t w0 = 0, w1 = 0, w2 = 0;
                 if (give) {
                     const uint64_t o = (uint64_t)sbase * stk.nlanes + gid;
-                    w0 = stk.p0[o]; w1 = stk.p1[o]; w2 = stk.p2[o];
-                    ++sbase; mark = nodes; tbytes += 24u; ++tacc;
+                    w0 = stk.p0[o]; w1 = stk.p1[o]; w2 = key_prefix(pkey, (uint32_t)(w1 >> 48) & 0xffu);
+                    ++sbase; mark = nodes; tbytes += 16u; ++tacc;
                 }
                 uint64_t om = offerm;                               // the lane of my partner: the (rank + 1)-th offering lane
                 for (uint32_t k = take ? (uint32_t)__popcll(idlem & below) : 0u; k > 0; --k) om &= om - 1ull;
@@ -1557,8 +1561,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         uint64_t o = (uint64_t)sp * stk.nlanes + gid;
                         stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
                         stk.p1[o] = (uint64_t)cur.len | ((uint64_t)(j & 0xffffu) << 32) | ((uint64_t)(e & 0xffu) << 48) | ((uint64_t)(subs.first() & 0xffu) << 56);
-                        stk.p2[o] = pkey;
-                        ++sp; tbytes += 24u; ++tacc;
+                        ++sp; tbytes += 16u; ++tacc;
                     }
                     resume = kNoResume;
                     if (take_match || take_sub) {
@@ -1723,10 +1726,10 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         --sp;
                         uint64_t o = (uint64_t)sp * stk.nlanes + gid;
                         uint64_t w0 = stk.p0[o], w1 = stk.p1[o];
-                        pkey = stk.p2[o];
-                        tbytes += 24u; ++tacc;
+                        tbytes += 16u; ++tacc;
                         cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32); cur.len = (idx_t)w1;
                         j = (uint32_t)(w1 >> 32) & 0xffffu; e = (uint32_t)(w1 >> 48) & 0xffu; resume = (uint32_t)(w1 >> 56) & 0xffu;
+                        pkey = key_prefix(pkey, e);
                         in_tail = false;
                     }
                 }
