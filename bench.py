@@ -112,6 +112,8 @@ def main():
     if c.multi:
         import torch.distributed as dist
         c.dist = dist
+        if args.single_rank_collectives and "RANK" not in os.environ:      # rehearsal without a launcher: a group of one rank
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29555"))
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=c.dev)
         else:
