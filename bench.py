@@ -347,7 +347,7 @@ def run_dna_text(c, name, primary):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
     legs = ["exact", "k2", "k2_151"]
-    ids = ["%s/%s/%s" % (name, w, i) for w in legs for i in ("plain", "tables")]
+    ids = ["%s/%s/%s" % (name, w, i) for w in legs for i in ("plain", "tables")] + ["%s/k2_edit/tables" % name]
     if c.only and not any(i in c.only for i in ids):
         return []
     text, seq_off, lengths, tinfo = make_text(c, name)
@@ -445,7 +445,8 @@ def run_dna_text(c, name, primary):
     # ------------------------------------------------------------------ k = 2 Hamming, configs[2] (101 bp) and configs[3] (151 bp)
     scheme = fm.search_scheme.h2(4, 0, 2)
     k2_legs = [("k2", 101, nq if not c.multi else 0), ("k2_151", 151, (args.total_k2_reads // c.world) if c.multi else min(12_500_000, max(1, int(12_500_000 * min(1.0, nq / 10_000_000)))))]
-    k2_legs = [(w, L, n_) for (w, L, n_) in k2_legs if n_ > 0 and any(wanted(c, "%s/%s/%s" % (name, w, i)) for i in ("plain", "tables"))]
+    k2_legs = [(w, L, n_) for (w, L, n_) in k2_legs if n_ > 0 and (any(wanted(c, "%s/%s/%s" % (name, w, i)) for i in ("plain", "tables"))
+                                                                    or (w == "k2" and args.with_edit and not c.multi and wanted(c, "%s/k2_edit/tables" % name)))]
     if k2_legs:
         os.environ["FMGPU_LF_TABLE"] = "0"
         t0 = time.time()

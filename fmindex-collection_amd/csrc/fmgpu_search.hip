@@ -1754,15 +1754,39 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
 }
 
 // ---- search_ng26 Edit = true, table-driven ------------------------------------------------------------------------------------------
-// k_scheme_edit's node logic in k_scheme_fast's frame: rounds of 64 equal-length queries per wave, the searches of the scheme started by all
-// lanes together (so the wide first steps of a search coincide and the per-lane slow paths — query fetch, search set-up — are wave-wide
-// phases), the scheme expanded into the per-step table (a step = one query symbol consumed: deletions stay on their step), hits kept in LDS
-// and written out by the wave.  In the flat kernel a wave executes the union of what its 64 lanes are doing; measured lane utilisation ~11 %.
+// k_scheme_edit's node logic in k_scheme_fast's frame: equal-length queries, the scheme expanded into the per-step table (a step = one query
+// symbol consumed: deletions stay on their step), ONE flat loop per lane over (query, search, node) with the slow paths wave-synchronous
+// (queries fetched and staged together, hits kept in LDS and written out by the wave), and the lanes of a wave sharing the work of large reads.
+// Round 1 ran rounds of 64 reads per wave with the searches in step: on a repeat-rich text nearly every round holds a read that visits
+// 10^5 nodes while the median read visits a few hundred, and the other 63 lanes waited for it (measured: 2 M x 101 bp, k = 2:
+// 1178 ms on the genome-like text against 41 ms on the uniform one).
+//
+// Edit path key.  The callback order of the reference is the depth-first order of SearchNg26.h:143-365: a node with several rows tries its
+// match child first, then for every symbol s its deletion and its substitution child (2s-1, 2s), the insertion child last (:171-218); a
+// node with one row tries the insertion FIRST, then the match or substitution child, then the deletion (:286-362).  For two hits of one
+// read and search that is the lexicographic order of their paths written as one letter per tree depth — match, or the error edge taken —
+// with the alphabet  { insertion at a one-row node } < match < { the other error edges in child order }.  Only the <= 3 error edges of a
+// path are kept, 16 bits each: an edge that precedes the match child as (0, depth, 0) — the smaller depth diverges first and wins —, "no
+// further error" as 0x4000, an edge that follows the match child as (2, 255 - depth, child index): a deeper one is met earlier on the way
+// back up.  depth = query symbols consumed + deletions made.  Layout: search:4 | 3 x 16 bits; it travels like the Hamming key (the low
+// 32 bits in fmgpu_hit::seq, the rest in the upper 24 bits of fmgpu_hit::errors) until fmgpu_hits_sort turns it into the callback index.
+constexpr uint64_t kEditKeyNone = 0x400040004000ull;
+__device__ __forceinline__ uint64_t ekey_prefix(uint64_t key, uint32_t e) {   // the key of an ancestor that had made e errors
+    const uint64_t keep = e == 0u ? 0ull : (e == 1u ? 0xffff00000000ull : (e == 2u ? 0xffffffff0000ull : 0xffffffffffffull));
+    return (key & (0xfull << 48)) | (key & keep) | (kEditKeyNone & ~keep);
+}
+__device__ __forceinline__ uint64_t ekey_with(uint64_t key, uint32_t e_before, bool before_match, uint32_t depth, uint32_t code) {
+    if (e_before >= 3u) return key;
+    const uint32_t sh = 32u - 16u * e_before;
+    const uint64_t comp = before_match ? (uint64_t)((depth << 6) | code) : (uint64_t)(0x8000u | ((255u - depth) << 6) | code);
+    return (key & ~(0xffffull << sh)) | (comp << sh);
+}
+
 template <int SIGMA, int MAXSIG>
 __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
-                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap) {
+                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, int sharing, int use_key) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
@@ -1776,190 +1800,284 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     const uint32_t sigma = fw.sigma(), R = sigma - 1;
     const uint32_t INS = 2u * sigma - 1u;
     uint4* const frames = reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u));   // this lane's frames, 32 bytes each
-    uint32_t nodes = 0, nh = 0;
+    uint32_t nodes = 0, nh = 0, count_only = 0;
+    const uint32_t refill_waste = ((uint32_t)dev_flags >> 8) & 0xffffu ? (((uint32_t)dev_flags >> 8) & 0xffffu) : kRefillWaste;   // (dev knob: bits 8..23)
+    const uint32_t share_nodes = ((uint32_t)dev_flags >> 25) & 31u ? 1u << (((uint32_t)dev_flags >> 25) & 31u) : kShareNodes;   // (dev knob: bits 25..29)
+    uint32_t waste = 0;                                             // lane-iterations lost by idle lanes since the wave's last refill (wave-uniform)
+    bool is_task = false;                                           // the lane works on a subtree it took over from another lane
+    uint32_t sbase = 0, mark = 0;                                   // frames below sbase were handed out; nodes at the lane's last hand-out
+    uint64_t pkey = 0;                                              // path key of the node the lane stands on
+    bool have = false, exhausted = n == 0, need_start = false, query_over = false;
+    uint64_t q = 0, quota = 0;
+    const uint8_t* qs = qbuf;
+    const uint32_t* tab = s_steps;
+    uint32_t seq = 0, si = 0;
+    Cur cur{0, 0, 0};
+    uint32_t e = 0, j = 0, sp = 0, resume = kNoResume, side = 0, info = 0, ndel = 0;
+    bool in_tail = false, lf_known = false;
+    idx_t lf_val = 0, cached_lf = 0, cached_lf2 = 0xffffffffu;
+    uint32_t report_slot = kNoResume;
     for (;;) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->next, 64ull);
-        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
-        if (base >= nq) break;
-        const bool present = base + lane < nq;
-        const uint64_t q = present ? (qmap ? (uint64_t)qmap[base + lane] : base + lane) : 0;
-        const uint64_t qo = present ? qoff[q] : 0;
-        const uint8_t* qs = qbuf + qo;
-        qstage_load_sync(qst, qbuf, qo, m, sigma, present, m);
-
-        uint64_t quota = max_hits; uint32_t seq = 0;
-        bool query_over = !(present && n != 0);
-        for (uint32_t si = 0; si < S; ++si) {                       // search_impl (SearchNg26.h:385-390), all lanes in step
-            const uint32_t* tab = s_steps + si * stride;
-            bool done = query_over;
-            Cur cur{0, 0, n};                                       // run(): :62-79
-            uint32_t e = 0, j = 0, sp = 0, resume = kNoResume, side = 0, info = 0;
-            bool in_tail = false, lf_known = false;
-            idx_t lf_val = 0, cached_lf = 0, cached_lf2 = 0xffffffffu;
-            uint32_t report_slot = kNoResume;
+        // ---- wave-synchronous part: every lane passes here in every iteration
+        if (sharing) {
+            // (a frame whose running child still owes it the row's LF^2 — report_slot — stays with its owner for that one iteration)
+            const bool offer = have && sp > sbase && nodes - mark >= share_nodes && report_slot != sbase;
+            const uint64_t idlem = __ballot(!have), offerm = __ballot(offer);
+            if (idlem && offerm) {
+                // the i-th idle lane takes the bottom frame of the i-th offering lane
+                const uint64_t below = (1ull << lane) - 1ull;
+                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
+                const bool give = offer && (uint32_t)__popcll(offerm & below) < pairs;
+                const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
+                uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0;
+                uint64_t gk = 0;
+                if (give) {
+                    g0 = frames[2u * sbase]; g1 = frames[2u * sbase + 1u];
+                    gk = ekey_prefix(pkey, (g0.w >> 16) & 0xffu);
+                    ++sbase; mark = nodes;
+                }
+                uint64_t om = offerm;                               // the lane of my partner: the (rank + 1)-th offering lane
+                for (uint32_t k = take ? (uint32_t)__popcll(idlem & below) : 0u; k > 0; --k) om &= om - 1ull;
+                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                uint4 t0, t1;
+                t0.x = __shfl(g0.x, vl, 64); t0.y = __shfl(g0.y, vl, 64); t0.z = __shfl(g0.z, vl, 64); t0.w = __shfl(g0.w, vl, 64);
+                t1.x = __shfl(g1.x, vl, 64); t1.y = __shfl(g1.y, vl, 64); t1.z = __shfl(g1.z, vl, 64); t1.w = __shfl(g1.w, vl, 64);
+                const uint64_t tk = __shfl(gk, vl, 64), tq_ = __shfl(q, vl, 64), tqs = __shfl((uint64_t)qs, vl, 64);
+                const uint32_t tsi = __shfl(si, vl, 64);
+                if (take) {
+                    q = tq_; si = tsi; qs = reinterpret_cast<const uint8_t*>(tqs);
+                    const bool one_row = (t0.w >> 24) & 1u;
+                    cur.lb = t0.x; cur.lbRev = t0.y; cur.len = one_row ? 1u : t0.z; cached_lf2 = one_row ? t0.z : 0xffffffffu;
+                    j = t0.w & 0xffffu; e = (t0.w >> 16) & 0xffu; info = (t0.w >> 25) & 15u;
+                    resume = t1.x; side = t1.y; cached_lf = t1.z; ndel = t1.w;
+                    pkey = tk;
+                    const uint32_t vt = (threadIdx.x & ~63u) | (uint32_t)vl;
+                    for (uint32_t w = 0; w < qwords; ++w) s_dyn[w * 256u + threadIdx.x] = s_dyn[w * 256u + vt];     // the partner's staged read
+                    have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
+                    tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; lf_known = false; report_slot = kNoResume; mark = nodes;
+                }
+            }
+        }
+        const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
+        waste += (uint32_t)__popcll(needm);
+        if (needm && (waste >= refill_waste || !busym)) {
+            waste = 0;
+            const bool want = !have && !exhausted;
+            bool fresh = false; uint64_t qo = 0;
+            const uint64_t got = wave_hand_out(want, ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
+            if (want) {
+                if (got >= nq) exhausted = true;
+                else {
+                    q = qmap ? (uint64_t)qmap[got] : got; qo = qoff[q]; qs = qbuf + qo; fresh = true;
+                    have = true; is_task = false; si = 0; need_start = true; quota = max_hits; seq = 0; query_over = false; mark = nodes;
+                }
+            }
+            qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
+        }
+        {
+            const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(have);
+            if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
+            if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
+        }
+        if (!have) continue;
+        bool lut_start = false; uint32_t lut_code = 0;
+        if (need_start) {                                           // search_impl (SearchNg26.h:385-390) -> run(): :62-79
+            need_start = false;
+            tab = s_steps + si * stride;
+            cur = Cur{0, 0, n}; e = 0; j = 0; sp = 0; sbase = 0; resume = kNoResume; side = 0; info = 0; ndel = 0;
+            in_tail = false; lf_known = false; cached_lf = 0; cached_lf2 = 0xffffffffu; report_slot = kNoResume;
+            pkey = ((uint64_t)si << 48) | kEditKeyNone;
             if (fa.lut && ((fa.lut_ok >> si) & 1u) && n > 1) {      // the always-exact first part starts from the prefix table
-                uint32_t code = 0, mul = 1; bool valid = !done;
+                uint32_t code = 0, mul = 1; bool valid = true;
                 for (uint32_t t = 0; t < fa.lutL; ++t) {
                     uint32_t c = qstage_get(qst, qs, tab[t] & 0xffffu);
                     valid = valid && c >= 1 && c < sigma;
                     code += (c - 1) * mul; mul *= R;
                 }
-                if (valid) {
-                    const uint4 en = fa.lut[code];
-                    cur = Cur{en.x, en.y, en.z};
-                    nodes += en.w;
-                    j = fa.lutL; in_tail = true;
-                    const uint32_t lastc = qstage_get(qst, qs, tab[fa.lutL - 1u] & 0xffffu);
-                    side = (lastc << 8) | (lastc << 24);
-                    if (en.z == 0) done = true;
-                }
-            }
-            for (;;) {
-                // wave-synchronous: write the buffered hits out when some lane's buffer is full
-                const uint64_t busy = __ballot(!done);
-                if (__ballot(nh == kWaveHitBuf) != 0ull || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
-                if (!busy) break;
-                if (done) continue;
-                const uint32_t ent = tab[j];
-                const bool right = (ent >> 16) & 1u;
-                const uint32_t minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
-                const bool lastp = (ent >> 17) & 1u;
-                const uint32_t c = qstage_get(qst, qs, ent & 0xffffu);
-                const bool multi = cur.len > 1, resuming = resume != kNoResume;
-                const idx_t a = right ? cur.lbRev : cur.lb;
-                const uint32_t d = right ? 1u : 0u;
-                const uint32_t T = (info >> (2u * d)) & 3u;
-                const uint32_t lastR = (side >> (8u * d)) & 255u, lastQ = (side >> (16u + 8u * d)) & 255u;
-                const bool Deletion = T != 1u && T != 2u, Insertion = T != 1u && T != 3u;                      // :146-147
-                const bool mOK = minE <= e && e <= maxE && (T != 2u || c != lastQ) && (T != 3u || c != lastR);    // :160-163
-                const bool iOK = minE <= e + 1 && e + 1 <= maxE;
-                const bool xOK = e + 1 <= maxE;
-                // ---- memory phase
-                idx_t lfa[MAXSIG], lfb[MAXSIG];
-                SymSet<MAXSIG> alive;
-                idx_t lf1 = cached_lf;
-                if (multi) {
-                    const OccA<SIGMA>& occ = right ? rv : fw;
-                    occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
-                    alive = alive_set<MAXSIG>(lfa, lfb, sigma);
-                } else {
-                    if (!resuming) {
-                        lf1 = lf_known ? lf_val : (right ? fa.lf_rv : fa.lf_fw)[a];
-                        if (report_slot != kNoResume) reinterpret_cast<uint32_t*>(frames + 2u * report_slot)[2] = lf1;
-                    }
-                    alive.clear(); alive.insert(symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, lf1));
-                }
-                lf_known = false; report_slot = kNoResume;
-                const bool c_alive = alive.test(c);
-                // ---- child selection (numbering as in k_scheme_edit)
-                const uint32_t start = resuming ? resume : 0u;
-                uint32_t kind = 4u, take = c, nxt = kNoResume;
-                bool start_tail = false;
-                if (in_tail) { if (c_alive) kind = 0u; }
-                else if (multi) {
-                    if (!xOK) { if (!resuming && mOK && c_alive) { kind = 0u; start_tail = true; } }
-                    else {
-                        SymSet<MAXSIG> dels = alive; dels.remove(0); if (!Deletion) dels.clear();
-                        SymSet<MAXSIG> subs = alive; subs.remove(0); subs.remove(c); if (!iOK) subs.clear();
-                        const bool insOK = Insertion && iOK;
-                        auto child_from = [&](uint32_t s0) -> uint32_t {
-                            if (s0 == 0u && mOK && c_alive) return 0u;
-                            SymSet<MAXSIG> dd = dels, ss = subs;
-                            dd.clear_below(s0 <= 1u ? 1u : (s0 + 2u) >> 1);
-                            ss.clear_below(s0 <= 2u ? 1u : (s0 + 1u) >> 1);
-                            uint32_t best = kNoResume;
-                            if (dd.any()) best = 2u * dd.first() - 1u;
-                            if (ss.any()) { uint32_t v = 2u * ss.first(); if (v < best) best = v; }
-                            if (best == kNoResume && insOK && s0 <= INS) best = INS;
-                            return best;
-                        };
-                        const uint32_t idx = child_from(start);
-                        if (idx != kNoResume) {
-                            if (idx == 0u) kind = 0u;
-                            else if (idx == INS) kind = 3u;
-                            else { kind = (idx & 1u) ? 2u : 1u; take = (idx + 1u) >> 1; }
-                            if (idx != INS) nxt = child_from(idx + 1u);
-                        }
-                    }
-                } else {
-                    const uint32_t b = alive.first();
-                    const bool valid = b >= 1u;
-                    const bool same = valid && b == c;
-                    const bool en0 = Insertion && iOK;
-                    const bool en1 = same ? mOK : (valid && xOK && iOK);
-                    const bool en2 = Deletion && valid && xOK;
-                    uint32_t idx = kNoResume;
-                    if (start <= 0u && en0) idx = 0u; else if (start <= 1u && en1) idx = 1u; else if (start <= 2u && en2) idx = 2u;
-                    if (idx == 0u) { kind = 3u; nxt = en1 ? 1u : (en2 ? 2u : kNoResume); }
-                    else if (idx == 1u) {
-                        take = b;
-                        if (same) { kind = 0u; start_tail = !xOK; nxt = (en2 && xOK) ? 2u : kNoResume; }
-                        else { kind = 1u; nxt = en2 ? 2u : kNoResume; }
-                    } else if (idx == 2u) { kind = 2u; take = b; }
-                }
-                nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + (start_tail ? 1u : 0u))));
-                if (kind != 4u && nxt != kNoResume) {               // keep the parent: its remaining children start at nxt
-                    uint4* f = frames + 2u * sp;
-                    f[0] = make_uint4(cur.lb, cur.lbRev, multi ? cur.len : 0xffffffffu, (j & 0xffffu) | ((e & 0xffu) << 16) | ((multi ? 0u : 1u) << 24) | (info << 25));
-                    f[1] = make_uint4(nxt, side, lf1, 0u);
-                    if (!multi && nxt == 2u && (kind == 0u || kind == 1u)) report_slot = sp;
-                    ++sp;
-                }
-                resume = kNoResume;
-                bool back = kind == 4u;
-                if (kind != 4u) {
-                    if (kind != 3u) {
-                        if (multi) cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
-                        else {
-                            cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
-                            if (kind == 2u && resuming && cached_lf2 != 0xffffffffu) { lf_known = true; lf_val = cached_lf2; }
-                        }
-                    } else if (!multi) { lf_known = true; lf_val = lf1; }
-                    if (kind != 0u) e += 1;
-                    const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
-                    if (kind == 0u) { side = (side & rmask & qmask) | (c << (8u * d)) | (c << (16u + 8u * d)); info = info & imask; }
-                    else if (kind == 1u) { side = (side & rmask & qmask) | (take << (8u * d)) | (c << (16u + 8u * d)); info = (info & imask) | (1u << (2u * d)); }
-                    else if (kind == 2u) { side = (side & rmask) | (take << (8u * d)); info = (info & imask) | (3u << (2u * d)); }
-                    else { side = (side & qmask) | (c << (16u + 8u * d)); info = (info & imask) | (2u << (2u * d)); }
-                    if (kind != 2u) {                               // one query symbol consumed: the next step of the table
-                        in_tail = !lastp && (in_tail || start_tail);
-                        ++j;
-                        if (j < m && (((tab[j] >> 16) & 1u) != (right ? 1u : 0u))) { lf_known = false; report_slot = kNoResume; }   // the other index from here on
-                    }
-                }
-                bool search_over = false;
-                if (!back && j == m) {                              // search_next at part == P (:101-108)
-                    const uint32_t fin = tab[m];
-                    const uint32_t li = info & 3u, ri = (info >> 2) & 3u;
-                    if ((li == 0u || li == 2u) && (ri == 0u || ri == 2u) && ((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x3fu)) {
-                        Cur r = cur;
-                        if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
-                        quota -= r.len;
-                        if (dev_flags & 1) ++seq; else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
-                        if (quota == 0) { search_over = true; query_over = true; }
-                    }
-                    back = !search_over;
-                }
-                if (back) {
-                    if (sp == 0) search_over = true;
-                    else {
-                        --sp;
-                        const uint4* f = frames + 2u * sp;
-                        const uint4 a0 = f[0], a1 = f[1];
-                        const bool one_row = (a0.w >> 24) & 1u;
-                        cur.lb = a0.x; cur.lbRev = a0.y; cur.len = one_row ? 1u : a0.z; cached_lf2 = one_row ? a0.z : 0xffffffffu;
-                        j = a0.w & 0xffffu; e = (a0.w >> 16) & 0xffu; info = (a0.w >> 25) & 15u;
-                        resume = a1.x; side = a1.y; cached_lf = a1.z;
-                        in_tail = false; lf_known = false; report_slot = kNoResume;
-                    }
-                }
-                if (search_over) done = true;
+                lut_start = valid; lut_code = code;
             }
         }
+        const uint32_t ent = tab[j];
+        const bool right = (ent >> 16) & 1u;
+        const uint32_t minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
+        const bool lastp = (ent >> 17) & 1u;
+        const uint32_t c = qstage_get(qst, qs, ent & 0xffffu);
+        const bool multi = !lut_start && cur.len > 1, resuming = resume != kNoResume;
+        const idx_t a = right ? cur.lbRev : cur.lb;
+        const uint32_t d = right ? 1u : 0u;
+        const uint32_t T = (info >> (2u * d)) & 3u;
+        const uint32_t lastR = (side >> (8u * d)) & 255u, lastQ = (side >> (16u + 8u * d)) & 255u;
+        const bool Deletion = T != 1u && T != 2u, Insertion = T != 1u && T != 3u;                      // :146-147
+        const bool mOK = minE <= e && e <= maxE && (T != 2u || c != lastQ) && (T != 3u || c != lastR);    // :160-163
+        const bool iOK = minE <= e + 1 && e + 1 <= maxE;
+        const bool xOK = e + 1 <= maxE;
+        // ---- memory phase: ONE 16-byte load per lane, whatever kind of node it stands on (the prefix table entry of a search start, the first
+        // quarter of a multi-row node's block, a one-row node's LF entry — dword-aligned, the tables carry 16 bytes of slack), and the rest
+        // of the two blocks right behind it: an iteration costs the wave one round trip, not one per kind of node.  A one-row node that is
+        // resumed, or that an insertion or a cached deletion led to, knows its LF value and loads nothing (about half of the iterations)
+        constexpr bool kSplit = SIGMA > 0 && SIGMA <= 5;
+        const uint8_t* blk = (right ? rv : fw).v.blk;
+        const uint8_t* p0 = lut_start ? reinterpret_cast<const uint8_t*>(fa.lut + lut_code)
+                          : (multi && kSplit) ? blk + (size_t)(a >> 6) * 64u
+                          : reinterpret_cast<const uint8_t*>((right ? fa.lf_rv : fa.lf_fw) + a);
+        uint4 r0 = make_uint4(0, 0, 0, 0);
+        if (lut_start || multi || (!resuming && !lf_known)) r0 = *reinterpret_cast<const uint4*>(p0);
+        bool back = false, search_over = false;
+        if (lut_start) {
+            cur = Cur{r0.x, r0.y, r0.z};
+            nodes += r0.w;
+            j = fa.lutL; in_tail = true;
+            const uint32_t lastc = qstage_get(qst, qs, tab[fa.lutL - 1u] & 0xffffu);
+            side = (lastc << 8) | (lastc << 24);
+            if (r0.z == 0) search_over = true;
+        } else {
+            idx_t lfa[MAXSIG], lfb[MAXSIG];
+            SymSet<MAXSIG> alive;
+            idx_t lf1 = cached_lf;
+            if (multi) {
+                const OccA<SIGMA>& occ = right ? rv : fw;
+                if constexpr (kSplit) {
+                    const uint4* pa = reinterpret_cast<const uint4*>(p0);
+                    const uint4* pb = reinterpret_cast<const uint4*>(blk + (size_t)((a + cur.len) >> 6) * 64u);
+                    const uint4 r1 = pa[1], r2 = pa[2], r3 = pa[3], s0 = pb[0], s1 = pb[1], s2 = pb[2], s3 = pb[3];
+                    const uint32_t da[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+                    const uint32_t db[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+                    occ.all2_of(da, db, a, a + cur.len, lfa, lfb);
+                } else occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
+                alive = alive_set<MAXSIG>(lfa, lfb, sigma);
+            } else {
+                if (!resuming) {
+                    lf1 = lf_known ? lf_val : (idx_t)r0.x;
+                    if (report_slot != kNoResume) reinterpret_cast<uint32_t*>(frames + 2u * report_slot)[2] = lf1;
+                }
+                alive.clear(); alive.insert(symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, lf1));
+            }
+            lf_known = false; report_slot = kNoResume;
+            const bool c_alive = alive.test(c);
+            // ---- child selection (numbering as in k_scheme_edit)
+            const uint32_t start = resuming ? resume : 0u;
+            uint32_t kind = 4u, take = c, nxt = kNoResume, code = 0;   // code: the child's index among the error children of its node (path key)
+            bool start_tail = false;
+            if (in_tail) { if (c_alive) kind = 0u; }
+            else if (multi) {
+                if (!xOK) { if (!resuming && mOK && c_alive) { kind = 0u; start_tail = true; } }
+                else {
+                    SymSet<MAXSIG> dels = alive; dels.remove(0); if (!Deletion) dels.clear();
+                    SymSet<MAXSIG> subs = alive; subs.remove(0); subs.remove(c); if (!iOK) subs.clear();
+                    const bool insOK = Insertion && iOK;
+                    auto child_from = [&](uint32_t s0) -> uint32_t {
+                        if (s0 == 0u && mOK && c_alive) return 0u;
+                        SymSet<MAXSIG> dd = dels, ss = subs;
+                        dd.clear_below(s0 <= 1u ? 1u : (s0 + 2u) >> 1);
+                        ss.clear_below(s0 <= 2u ? 1u : (s0 + 1u) >> 1);
+                        uint32_t best = kNoResume;
+                        if (dd.any()) best = 2u * dd.first() - 1u;
+                        if (ss.any()) { uint32_t v = 2u * ss.first(); if (v < best) best = v; }
+                        if (best == kNoResume && insOK && s0 <= INS) best = INS;
+                        return best;
+                    };
+                    const uint32_t idx = child_from(start);
+                    if (idx != kNoResume) {
+                        if (idx == 0u) kind = 0u;
+                        else if (idx == INS) kind = 3u;
+                        else { kind = (idx & 1u) ? 2u : 1u; take = (idx + 1u) >> 1; }
+                        if (idx != INS) nxt = child_from(idx + 1u);
+                        code = idx;
+                    }
+                }
+            } else {
+                const uint32_t b = alive.first();
+                const bool valid = b >= 1u;
+                const bool same = valid && b == c;
+                const bool en0 = Insertion && iOK;
+                const bool en1 = same ? mOK : (valid && xOK && iOK);
+                const bool en2 = Deletion && valid && xOK;
+                uint32_t idx = kNoResume;
+                if (start <= 0u && en0) idx = 0u; else if (start <= 1u && en1) idx = 1u; else if (start <= 2u && en2) idx = 2u;
+                if (idx == 0u) { kind = 3u; nxt = en1 ? 1u : (en2 ? 2u : kNoResume); }
+                else if (idx == 1u) {
+                    take = b;
+                    if (same) { kind = 0u; start_tail = !xOK; nxt = (en2 && xOK) ? 2u : kNoResume; }
+                    else { kind = 1u; nxt = en2 ? 2u : kNoResume; }
+                } else if (idx == 2u) { kind = 2u; take = b; }
+                code = idx == kNoResume ? 0u : idx;
+            }
+            nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + (start_tail ? 1u : 0u))));
+            if (kind != 4u && nxt != kNoResume) {                   // keep the parent: its remaining children start at nxt
+                uint4* f = frames + 2u * sp;
+                f[0] = make_uint4(cur.lb, cur.lbRev, multi ? cur.len : 0xffffffffu, (j & 0xffffu) | ((e & 0xffu) << 16) | ((multi ? 0u : 1u) << 24) | (info << 25));
+                f[1] = make_uint4(nxt, side, lf1, ndel);
+                if (!multi && nxt == 2u && (kind == 0u || kind == 1u)) report_slot = sp;
+                ++sp;
+            }
+            resume = kNoResume;
+            back = kind == 4u;
+            if (kind != 4u) {
+                if (kind != 3u) {
+                    if (multi) cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
+                    else {
+                        cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
+                        if (kind == 2u && resuming && cached_lf2 != 0xffffffffu) { lf_known = true; lf_val = cached_lf2; }
+                    }
+                } else if (!multi) { lf_known = true; lf_val = lf1; }
+                if (kind != 0u) {                                   // an error edge: one more component of the path key
+                    if (use_key) pkey = ekey_with(pkey, e, !multi && kind == 3u, j + ndel, code);
+                    e += 1;
+                    if (kind == 2u) ++ndel;
+                }
+                const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
+                if (kind == 0u) { side = (side & rmask & qmask) | (c << (8u * d)) | (c << (16u + 8u * d)); info = info & imask; }
+                else if (kind == 1u) { side = (side & rmask & qmask) | (take << (8u * d)) | (c << (16u + 8u * d)); info = (info & imask) | (1u << (2u * d)); }
+                else if (kind == 2u) { side = (side & rmask) | (take << (8u * d)); info = (info & imask) | (3u << (2u * d)); }
+                else { side = (side & qmask) | (c << (16u + 8u * d)); info = (info & imask) | (2u << (2u * d)); }
+                if (kind != 2u) {                                   // one query symbol consumed: the next step of the table
+                    in_tail = !lastp && (in_tail || start_tail);
+                    ++j;
+                    if (j < m && (((tab[j] >> 16) & 1u) != (right ? 1u : 0u))) { lf_known = false; report_slot = kNoResume; }   // the other index from here on
+                }
+            }
+            if (!back && j == m) {                                  // search_next at part == P (:101-108)
+                const uint32_t fin = tab[m];
+                const uint32_t li = info & 3u, ri = (info >> 2) & 3u;
+                if ((li == 0u || li == 2u) && (ri == 0u || ri == 2u) && ((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x3fu)) {
+                    Cur r = cur;
+                    if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
+                    quota -= r.len;
+                    if (dev_flags & 1) ++count_only;
+                    else if (use_key) wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e | ((uint32_t)(pkey >> 32) << 8), (uint32_t)pkey);
+                    else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq);
+                    ++seq;
+                    if (quota == 0) { search_over = true; query_over = true; }
+                }
+                back = !search_over;
+            }
+            if (back) {
+                if (sp == sbase) search_over = true;
+                else {
+                    --sp;
+                    const uint4* f = frames + 2u * sp;
+                    const uint4 a0 = f[0], a1 = f[1];
+                    const bool one_row = (a0.w >> 24) & 1u;
+                    cur.lb = a0.x; cur.lbRev = a0.y; cur.len = one_row ? 1u : a0.z; cached_lf2 = one_row ? a0.z : 0xffffffffu;
+                    j = a0.w & 0xffffu; e = (a0.w >> 16) & 0xffu; info = (a0.w >> 25) & 15u;
+                    resume = a1.x; side = a1.y; cached_lf = a1.z; ndel = a1.w;
+                    pkey = ekey_prefix(pkey, e);
+                    in_tail = false; lf_known = false; report_slot = kNoResume;
+                }
+            }
+        }
+        if (search_over) {                                          // the next search of the scheme, or the lane is out of work
+            ++si;
+            if (is_task) { have = false; is_task = false; }          // a task is one subtree of one search: its owner goes on with the other searches
+            else if (si == S || query_over) have = false;
+            else need_start = true;
+        }
     }
-    uint32_t tot = wave_sum(nodes);
-    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
+    const uint32_t tot = wave_sum(nodes), co = wave_sum(count_only);
+    if ((threadIdx.x & 63u) == 0 && (tot || co)) {
+        atomicAdd(&ctr->nodes, (unsigned long long)tot);
+        if (co) atomicAdd(&ctr->hits, (unsigned long long)co);
+    }
 }
 
 #endif  // !FMGPU_WIDE
@@ -2595,7 +2713,8 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
 #if !FMGPU_WIDE
     // path keys order the hits of a read whoever finds them (<= 2 substitutions fit the key); with them and no limit on the hits per read the
     // lanes of a wave share the work of large reads
-    const int use_key = fast && !edit && max_u <= 2 && sd.S <= 16 ? 1 : 0;
+    // (edit distance: <= 3 error edges of 16 bits each, the tree depth — query length + deletions — in 8 bits, the child index in 6)
+    const int use_key = !fast || sd.S > 16 ? 0 : (!edit ? (max_u <= 2 ? 1 : 0) : (max_u <= 3 && maxlen + max_u <= 250 && x->bwt.sigma <= 32 ? 1 : 0));
     const int sharing = use_key && max_hits == ~0ull && !(sd.dev_flags & (1 << 24)) ? 1 : 0;
 #endif
     timer.start();
@@ -2618,10 +2737,10 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             if (edit) {
                 if (x->bwt.sigma == 5)
                     k_scheme_fast_edit<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
+                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
                 else
                     k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                              b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm);
+                                                                              b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
             } else if (x->bwt.sigma == 5)
                 k_scheme_fast<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);

@@ -606,6 +606,46 @@ def test_edit_distance_equal_length_fast_path(k, length, sigma):
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)[0])
 
 
+def test_edit_distance_on_a_repeat_structured_text():
+    """k = 2 edit distance on 4 Mbp of the genome-like text (repeat families, satellites, single-symbol runs): reads out of repeats visit 10^4 - 10^6
+    nodes where the median read visits hundreds, so the lanes of a wave hand subtrees to each other all the time (k_scheme_fast_edit) and the
+    callback order has to come out of the path keys: records, order and extension counts equal the CPU walk; with work sharing switched off too"""
+    torch = pytest.importorskip("torch")
+    from fmindex_collection_amd import datasets
+    lengths = [2_500_000, 1_500_000]
+    text, stats = datasets.genome_like_text(lengths, seed=11, device=torch.device("cuda", 0))
+    host = text.cpu().numpy()
+    seqs = np.split(host, np.cumsum(lengths)[:-1])
+    ox = fo.OraIndex.build("IB16", 5, seqs, 16, True)
+    gx = gpu_index(ox)
+    gx.accelerate_search(8, 1)
+    rng = np.random.default_rng(12)
+    L, queries = 50, []
+    for i in range(6000):
+        sq = seqs[i & 1]
+        p = int(rng.integers(0, len(sq) - L - 4)); q = list(sq[p: p + L + 3])
+        for _ in range(int(rng.integers(0, 3))):
+            op = int(rng.integers(0, 3)); jj = int(rng.integers(0, len(q)))
+            if op == 0: q[jj] = int(rng.integers(1, 5))
+            elif op == 1: q.insert(jj, int(rng.integers(1, 5)))
+            else: del q[jj]
+        queries.append(np.array(q[:L], dtype=np.uint8))
+    qbuf, qoff = fm.flatten(queries)
+    sch = fm.search_scheme.h2(4, 0, 2)
+    ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 24)
+    per_read = np.bincount(ohits["qidx"].astype(np.int64), minlength=len(queries))
+    assert per_read.max() > 50 * max(1, int(np.median(per_read)))           # the heavy tail this test is about
+    hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 24)
+    assert same_hits(hits, ohits) and st.lf_steps == nodes
+    os.environ["FMGPU_DEV_FLAGS"] = str(1 << 24)               # no work sharing: the callback index is counted, not derived from keys
+    try:
+        hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 24)
+    finally:
+        del os.environ["FMGPU_DEV_FLAGS"]
+    assert same_hits(hits2, ohits) and st2.lf_steps == nodes
+    assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=3, edit=True), ox.search_ng26(qbuf, qoff, sch, max_hits=3, edit=True)[0])
+
+
 @pytest.mark.parametrize("layout,sigma,tables", [("IB16", 5, False), ("IB16", 5, True), ("WAVELET", 28, False), ("EPR16", 5, False), ("IB16", 256, False)])
 def test_packed_exact_intervals(layout, sigma, tables):
     """fmgpu_search_exact_packed: one word lb << 32 | len per query, equal to the two-array form on every kernel variant"""
