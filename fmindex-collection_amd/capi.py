@@ -101,6 +101,32 @@ EXPORTS = [
 _lib = None
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same sonames as /opt/rocm's).  A process that loads
+    libfmgpu.so first binds the system runtime, and a later `import torch` brings the bundled copy in beside it: two HIP runtimes in one
+    process, and the second one to initialise does not find the GPU (hipErrorNoDevice).  Tensors and streams are shared with torch, so the
+    runtime has to be ONE: if torch is installed but not imported yet, its copies are loaded first and libfmgpu.so binds to them by soname
+    (exactly what happens when torch is imported first).  FMGPU_SYSTEM_HIP=1 leaves the loader alone."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("FMGPU_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -108,6 +134,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing — build it with __graft_entry__.build() "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.fmgpu_last_error.restype = C.c_char_p
     L.fmgpu_device_count.argtypes = [C.POINTER(C.c_int)]

@@ -698,7 +698,33 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
     }
 }
 
-#if !FMGPU_WIDE   // ======== 32-bit rows only: edit distance, search_ng21 and every table-driven kernel (frames, tables and transport words hold 32-bit rows)
+// ---- edit-distance frames (k_scheme_edit, k_ng21): four row-sized fields and four 32-bit words, the frames of a lane consecutive in memory — a DFS
+// pushes and pops them in order, so four (32-bit rows: 32 bytes each; 64-bit rows: 48) share a line or two, where interleaving them by lane
+// would touch one line per frame (the lanes of a wave sit at different depths)
+constexpr uint32_t kEditFrameQuads = kWide ? 3u : 2u;
+constexpr int kEditFramePlanes = kWide ? 6 : 4;                  // (in 8-byte planes of the DFS workspace)
+__device__ __forceinline__ uint4* edit_frame(const StackView& stk, uint64_t gid, uint32_t slot) {
+    return reinterpret_cast<uint4*>(stk.p0) + (size_t)kEditFrameQuads * (gid * ((uint64_t)stk.depth + 1u) + slot);
+}
+__device__ __forceinline__ void edit_frame_put(uint4* f, idx_t r0, idx_t r1, idx_t r2, idx_t r3, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    if constexpr (kWide) {
+        f[0] = make_uint4((uint32_t)r0, (uint32_t)((uint64_t)r0 >> 32), (uint32_t)r1, (uint32_t)((uint64_t)r1 >> 32));
+        f[1] = make_uint4((uint32_t)r2, (uint32_t)((uint64_t)r2 >> 32), (uint32_t)r3, (uint32_t)((uint64_t)r3 >> 32));
+        f[2] = make_uint4(a, b, c, d);
+    } else { f[0] = make_uint4((uint32_t)r0, (uint32_t)r1, (uint32_t)r2, a); f[1] = make_uint4(b, c, d, (uint32_t)r3); }
+}
+__device__ __forceinline__ void edit_frame_get(const uint4* f, idx_t& r0, idx_t& r1, idx_t& r2, idx_t& r3, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    if constexpr (kWide) {
+        const uint4 x = f[0], y = f[1], z = f[2];
+        r0 = (idx_t)((uint64_t)x.x | ((uint64_t)x.y << 32)); r1 = (idx_t)((uint64_t)x.z | ((uint64_t)x.w << 32));
+        r2 = (idx_t)((uint64_t)y.x | ((uint64_t)y.y << 32)); r3 = (idx_t)((uint64_t)y.z | ((uint64_t)y.w << 32));
+        a = z.x; b = z.y; c = z.z; d = z.w;
+    } else { const uint4 x = f[0], y = f[1]; r0 = x.x; r1 = x.y; r2 = x.z; a = x.w; b = y.x; c = y.y; d = y.z; r3 = y.w; }
+}
+__device__ __forceinline__ void edit_frame_set_r2(uint4* f, idx_t v) {     // the third row field alone
+    if constexpr (kWide) reinterpret_cast<uint64_t*>(f)[2] = (uint64_t)v; else reinterpret_cast<uint32_t*>(f)[2] = (uint32_t)v;
+}
+
 // ---- search_ng26, Edit = true (SearchNg26.h:143-224, :251-365 with insertions and deletions) ------------------------------------
 // Same flat (query, search, node) loop and frame stack as k_scheme; a node's children are numbered in the reference's call order
 //   several rows:  0 match | 2i-1 deletion of index symbol i | 2i substitution by i  (i = 1 .. sigma-1) | 2*sigma-1 insertion
@@ -738,7 +764,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
     uint32_t e = 0, part = 0, qL = 0, qR = 0, pev = 0, tail = 0, sp = 0, resume = kNoResume;
     uint32_t side = 0;                      // lastRank[left] | lastRank[right] << 8 | lastQRank[left] << 16 | lastQRank[right] << 24
     uint32_t info = 0;                      // LInfo | RInfo << 2
-    idx_t cached_lf = 0, cached_lf2 = 0xffffffffu;   // a resumed one-row frame: LF of its row, LF of that row (if a child reported it)
+    idx_t cached_lf = 0, cached_lf2 = kNoRow;        // a resumed one-row frame: LF of its row, LF of that row (if a child reported it)
     bool lf_known = false; idx_t lf_val = 0;         // LF of the NEXT node's row is already known (same row after an insertion, or reported)
     uint32_t report_slot = kNoResume;                // frame whose deletion child will stand on this node's row: tell it this node's LF
     bool right = true;
@@ -806,8 +832,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
         if (via_lf) {
             if (resume == kNoResume) {
                 lf1 = lf_known ? lf_val : (right ? lfv.rv : lfv.fw)[a];
-                if (report_slot != kNoResume)                       // (the waiting deletion child of the parent starts from this same row)
-                    reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + report_slot))[2] = lf1;
+                if (report_slot != kNoResume) edit_frame_set_r2(edit_frame(stk, gid, report_slot), lf1);   // (the waiting deletion child of the parent starts from this same row)
             }
         } else occ.template all2<MAXSIG>(a, a + cur.len, lfa, lfb);
         lf_known = false; report_slot = kNoResume;
@@ -873,14 +898,10 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
         }
         nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + ((start_tail) ? 1u : 0u))));
         if (kind != 4u && nxt != kNoResume) {                       // keep the parent: its remaining children start at nxt
-            // one 32-byte record per frame; a lane's frames are consecutive in memory: a DFS pushes and pops them in order, so four share a
-            // 128-byte line (lanes of a wave sit at different depths — interleaving them by lane would touch one line per frame)
-            uint4* f = reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
             const uint64_t w2 = (uint64_t)(nxt | (info << 16) | ((via_lf ? 1u : 0u) << 20)) | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
                                 ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
-            // one-row frames (len = 1): the third word holds LF(LF(row)) once the first child on that row has loaded it
-            f[0] = make_uint4(cur.lb, cur.lbRev, via_lf ? 0xffffffffu : cur.len, (pev & 0xffffu) | ((qR & 0xffffu) << 16));
-            f[1] = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), side, lf1);
+            // one-row frames (len = 1): the third row field holds LF(LF(row)) once the first child on that row has loaded it
+            edit_frame_put(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, via_lf ? kNoRow : cur.len, lf1, (pev & 0xffffu) | ((qR & 0xffffu) << 16), (uint32_t)w2, (uint32_t)(w2 >> 32), side);
             if (via_lf && nxt == 2u && (kind == 0u || kind == 1u)) report_slot = sp;
             ++sp;
         }
@@ -890,7 +911,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             if (kind != 3u) {
                 if (via_lf) {
                     cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
-                    if (kind == 2u && resuming && cached_lf2 != 0xffffffffu) { lf_known = true; lf_val = cached_lf2; }   // reported by the first child on that row
+                    if (kind == 2u && resuming && cached_lf2 != kNoRow) { lf_known = true; lf_val = cached_lf2; }   // reported by the first child on that row
                 } else cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
             } else if (via_lf) { lf_known = true; lf_val = lf1; }    // insertion: the next node stands on the same row
             if (kind != 0u) e += 1;
@@ -936,17 +957,16 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
         if (back) {
             if (sp == 0) { need_search = true; continue; }
             --sp;
-            const uint4* f = reinterpret_cast<const uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
-            const uint4 a0 = f[0], a1 = f[1];
-            const uint64_t w2 = (uint64_t)a1.x | ((uint64_t)a1.y << 32);
+            idx_t f_len = 0; uint32_t fa_ = 0, fb_ = 0, fc_ = 0;
+            edit_frame_get(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, f_len, cached_lf, fa_, fb_, fc_, side);
+            const uint64_t w2 = (uint64_t)fb_ | ((uint64_t)fc_ << 32);
             const bool one_row = ((uint32_t)w2 >> 20) & 1u;
-            cur.lb = a0.x; cur.lbRev = a0.y; cur.len = one_row ? 1u : a0.z; cached_lf2 = one_row ? a0.z : 0xffffffffu;
-            pev = a0.w & 0xffffu; qR = a0.w >> 16;
+            cur.len = one_row ? (idx_t)1 : f_len; cached_lf2 = one_row ? f_len : kNoRow;
+            pev = fa_ & 0xffffu; qR = fa_ >> 16;
             resume = (uint32_t)w2 & 0xffffu; info = ((uint32_t)w2 >> 16) & 15u; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
             lf_known = false; report_slot = kNoResume;
             right = (w2 >> 47) & 1u;
             qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
-            side = a1.z; cached_lf = a1.w;
             tail = 0;
         }
     }
@@ -1085,9 +1105,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
             }
         }
         if (kind != 4u && nxt != kNoResume) {                       // keep the parent: its remaining children start at nxt
-            uint4* f = reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
-            f[0] = make_uint4(cur.lb, cur.lbRev, cur.len, k);
-            f[1] = make_uint4(nxt, e | (info << 8) | (lastRank << 16), lf1, 0u);
+            edit_frame_put(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, cur.len, lf1, k, nxt, e | (info << 8) | (lastRank << 16), 0u);
             ++sp;
         }
         resume = kNoResume;
@@ -1120,16 +1138,16 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
         if (back) {
             if (sp == 0) { need_search = true; continue; }
             --sp;
-            const uint4* f = reinterpret_cast<const uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u) + sp);
-            const uint4 a0 = f[0], a1 = f[1];
-            cur = Cur{a0.x, a0.y, a0.z}; k = a0.w;
-            resume = a1.x; e = a1.y & 255u; info = (a1.y >> 8) & 15u; lastRank = (a1.y >> 16) & 255u; cached_lf = a1.z;
+            uint32_t fc_ = 0, fd_ = 0;
+            edit_frame_get(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, cur.len, cached_lf, k, resume, fc_, fd_);
+            e = fc_ & 255u; info = (fc_ >> 8) & 15u; lastRank = (fc_ >> 16) & 255u;
         }
     }
     uint32_t tot = wave_sum(nodes);
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
 }
 
+#if !FMGPU_WIDE   // ======== 32-bit rows only: every table-driven kernel (tables, their frames and transport words hold 32-bit rows)
 // ---- search_ng26 Hamming, fast path ------------------------------------------------------------------------------
 // For a batch of equal-length queries on a Format-A BiFMIndex the host expands the scheme once into a per-step table
 // (query position, direction, error window [minE, maxE] of the step, "last character of its part"; SearchNg26.h:160-168:
@@ -2551,7 +2569,6 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         if (max_hits == 0 || scheme->n_searches == 0) return 0;                       // SearchNg26.h:408-409
         sd.S = scheme->n_searches; sd.P = scheme->n_parts; sd.uniform = scheme->partition ? 0 : 1;
         edit = scheme->edit != 0;
-        if (kWide && edit) return fail(FMGPU_ERR_UNSUPPORTED, "edit-distance search is not available for indices of 2^32 rows or more (64-bit-row build)");
         { const char* e = getenv("FMGPU_DEV_FLAGS"); sd.dev_flags = e ? atoi(e) : 0; }
         for (int s = 0; s < sd.S; ++s) {
             uint32_t seen = 0;
@@ -2602,9 +2619,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         auto occ_of = [&](auto kernel) { int nb = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, occ_lds) == hipSuccess && nb > 0) bpc = nb; else (void)hipGetLastError(); };
         dispatch_occ(x->bwt, [&](auto occ, auto ms) {
             using O = decltype(occ);
-#if !FMGPU_WIDE
             if (scheme_mode && edit) occ_of(k_scheme_edit<O, decltype(ms)::value>); else
-#endif
             if (scheme_mode) occ_of(k_scheme<O, decltype(ms)::value>); else occ_of(k_backtracking<O, decltype(ms)::value>);
             return 0;
         });
@@ -2698,7 +2713,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
 #endif  // !FMGPU_WIDE
     { const char* ev = getenv("FMGPU_DEV_BPC"); if (ev && atoi(ev) > 0) bpc = atoi(ev); }   // dev knob: resident blocks per CU the grid is sized for
     // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
-    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? 4 : 3))) { if (d_qmap) (void)hipFree(d_qmap); return rc; }
+    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3))) { if (d_qmap) (void)hipFree(d_qmap); return rc; }
     const dim3 grid(ws.grid);
 #if !FMGPU_WIDE
     size_t steps_words = 0;
@@ -2761,14 +2776,12 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             else if constexpr (std::is_same_v<O, OccM>) r = O{rv.vm};
             else r = O{rv.vr};
             (void)hipMemsetAsync(&ws.ctr->next, 0, 8, stream);         // queries are handed out from 0, one reservation per wave
-#if !FMGPU_WIDE
             if (edit) {
                 k_scheme_edit<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
                                                                                   max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, maxlen,
                                                                                   (sd.dev_flags & 4) ? nullptr : x->lut, x->lut_len);
                 return 0;
             }
-#endif
             k_scheme<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
                                                                          max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv);
             return 0;
@@ -2820,10 +2833,6 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
                       uint64_t max_hits_per_query, fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, void* stream_) {
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
-#if FMGPU_WIDE
-    (void)qbuf; (void)qoff; (void)nq; (void)scheme; (void)max_hits_per_query; (void)out; (void)capacity; (void)out_count; (void)stats; (void)stream_;
-    return fail(FMGPU_ERR_UNSUPPORTED, "search_ng21 (edit distance) is not available for indices of 2^32 rows or more (64-bit-row build)");
-#else
     if (int drc = on_handle_device(x)) return drc;
     hipStream_t stream = (hipStream_t)stream_;
     if (stats) *stats = fmgpu_stats{0, 0, 0.f};
@@ -2890,7 +2899,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
         std::lock_guard<std::mutex> g(occ_mu); occ_cache[occ_key] = bpc;
     }
     DfsWorkspace ws;
-    if ((rc = ws.init((uint32_t)M + max_u + 2, nq, bpc, stream, 4))) return rc;       // deletions lengthen the path beyond the query by at most the largest upper bound
+    if ((rc = ws.init((uint32_t)M + max_u + 2, nq, bpc, stream, kEditFramePlanes))) return rc;       // deletions lengthen the path beyond the query by at most the largest upper bound
     uint32_t* d_tab = nullptr;
     FM_HIP(hipMalloc((void**)&d_tab, tab.size() * 4));
     hipError_t le = hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, stream);
@@ -2924,7 +2933,6 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     }
     if (sout.writeback) sout.bytes = hc.hits * sizeof(fmgpu_hit);
     return sout.finish();
-#endif
 }
 
 int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps,

@@ -22,8 +22,9 @@
  *     row indices, interval bounds and counts are uint64_t like the reference's size_t.
  *   - row width: an index of fewer than 2^32 - 64 rows is held in 32-bit device tables and may use every optional accelerator table below;
  *     a larger one (up to 2^40 rows; the reference switches to a 64-bit suffix array at 2^31 rows, utils.h:243-247) is held in 64-bit-row
- *     tables: construction, exact search, search_ng26<Hamming>, search_backtracking, locate, cursor steps and String_c queries work on it,
- *     the accelerator tables, edit distance and the one-word transport forms return FMGPU_ERR_UNSUPPORTED (fmgpu_index_row_bits tells which).
+ *     tables: construction, exact search, search_ng26 (Hamming and edit distance), search_ng21, search_backtracking, locate, cursor steps
+ *     and String_c queries work on it; the accelerator tables (and with them the table-driven kernels) and the one-word transport forms
+ *     return FMGPU_ERR_UNSUPPORTED (fmgpu_index_row_bits tells which).
  */
 #ifndef FMGPU_H
 #define FMGPU_H

@@ -99,9 +99,6 @@ def test_wide_k_mismatch_and_backtracking(layout, sigma, k, lf):
     bh = fm.search_backtracking.search(gx, few, k)
     obh = ox.search_backtracking(few[0], few[1], k)[0]
     assert same_hits(bh, obh)
-    with pytest.raises(fm.FmgpuError) as ei:
-        fm.search_ng26.search(gx, few, sch, edit=True)
-    assert ei.value.code == capi.FMGPU_ERR_UNSUPPORTED
     # cursor steps
     lb0, rev0, len0 = hits["lb"][:50], hits["lb_rev"][:50], hits["len"][:50]
     for right in (False, True):
@@ -110,6 +107,50 @@ def test_wide_k_mismatch_and_backtracking(layout, sigma, k, lf):
             cur = fo.Cursor(int(lb0[i]), int(rev0[i]), int(len0[i]))
             exp = ox.extend_right_all(cur) if right else ox.extend_left_all(cur)
             assert [tuple(map(int, t)) for t in zip(olb[i], orev[i], olen[i])] == [(c.lb, c.lb_rev, c.len) for c in exp]
+
+
+@pytest.mark.parametrize("layout,sigma,k", [("IB16", 5, 1), ("IB16", 5, 2), ("EPRV2_16", 5, 2), ("WAVELET", 28, 1), ("IB16", 256, 1), ("IB16", 5, 3)])
+@pytest.mark.parametrize("lf", [True, False])
+def test_wide_edit_distance_and_ng21(layout, sigma, k, lf):
+    """search_ng26<Edit = true> and search_ng21 on 64-bit rows (48-byte frames): records, callback order and extension counts of the CPU walk,
+    search_n clipping, ragged batches"""
+    rng = np.random.default_rng(500 + sigma + k)
+    hi = min(sigma, 8)
+    base = rng.integers(1, hi, size=1500, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[300:800]]), rng.integers(1, hi, size=400, dtype=np.uint8)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 4, True)
+    gx = wide_index(ox)
+    if not lf:
+        gx.accelerate_lf(False)
+    length, queries = 26, []
+    for i in range(300 if k < 3 else 80):
+        p = int(rng.integers(0, len(seqs[0]) - length - 4)); q = list(seqs[0][p: p + length + 3])
+        for _ in range(int(rng.integers(0, k + 2))):
+            op = int(rng.integers(0, 3)); jj = int(rng.integers(0, len(q)))
+            if op == 0: q[jj] = int(rng.integers(1, hi))
+            elif op == 1: q.insert(jj, int(rng.integers(1, hi)))
+            else: del q[jj]
+        queries.append(np.array(q[:length], dtype=np.uint8))
+    qbuf, qoff = fm.flatten(queries)
+    total = 0
+    for sch in (fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k)):
+        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 21)
+        ohits, _, nodes = ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes, (layout, k, lf)
+        ex = fm.search_scheme.expand(sch, length)
+        hits, st = fm.search_ng21.search(gx, (qbuf, qoff), ex, want_stats=True, capacity=1 << 21)
+        ohits, _, nodes = ox.search_ng21(qbuf, qoff, ex, cap=1 << 21)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes, (layout, k, lf)
+        total += len(ohits)
+    assert total > 0
+    sch = fm.search_scheme.h2(k + 2, 0, k)
+    for n in (1, 3):
+        assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=n, edit=True), ox.search_ng26(qbuf, qoff, sch, max_hits=n, edit=True)[0])
+        ex = fm.search_scheme.expand(sch, length)
+        assert same_hits(fm.search_ng21.search_n(gx, (qbuf, qoff), ex, n), ox.search_ng21(qbuf, qoff, ex, max_hits=n)[0])
+    ragged = mutated_queries(seqs, 200, 12, 40, k, seed=23, sigma=sigma)
+    rb, ro = fm.flatten(ragged)
+    assert same_hits(fm.search_ng26.search(gx, (rb, ro), sch, edit=True, capacity=1 << 21), ox.search_ng26(rb, ro, sch, edit=True, cap=1 << 21)[0])
 
 
 @pytest.mark.parametrize("bidir", [False, True])

@@ -131,3 +131,35 @@ def test_shard_ranges_cover_the_batch():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+_RUNTIME_PROBE = """
+import sys
+sys.path.insert(0, %r)
+from fmindex_collection_amd import capi
+capi.lib()
+import torch
+libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))
+print('HIPLIBS', len(libs))
+if %d:
+    import ctypes as C
+    p = C.c_void_p()
+    assert capi.lib().fmgpu_malloc(C.byref(p), 1 << 20) == 0
+    assert float(torch.ones(8, device='cuda').sum()) == 8.0
+    print('GPU ok')
+"""
+
+
+def test_one_hip_runtime_when_the_library_is_loaded_before_torch():
+    """the torch wheel bundles its own libamdhip64.so; loading libfmgpu.so first used to leave two HIP runtimes in the process (and the second one
+    to initialise finds no GPU): capi.lib() binds to torch's copy when torch is installed"""
+    pytest.importorskip("torch")
+    r = subprocess.run([sys.executable, "-c", _RUNTIME_PROBE % (ROOT, 0)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HIPLIBS 1" in r.stdout, r.stdout + r.stderr[-800:]
+
+
+@pytest.mark.gpu
+def test_library_first_then_torch_on_the_gpu():
+    pytest.importorskip("torch")
+    r = subprocess.run([sys.executable, "-c", _RUNTIME_PROBE % (ROOT, 1)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "HIPLIBS 1" in r.stdout and "GPU ok" in r.stdout, r.stdout + r.stderr[-800:]
