@@ -1405,6 +1405,11 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sigma = fw.sigma(), R = sigma - 1;
+    // 16-byte frames, lane-interleaved: frame d of lane g at [d * nlanes + g] — one store, one load (two 8-byte planes: genome text, plain index 196 -> 183 ms).
+    // (Tried and dropped: the substitution children of a node waiting on the stack as nodes of their own, so that nobody re-reads the node's blocks
+    // for the next sibling — the same number of frames, but deriving and storing up to three children in the node's iteration costs every lane of
+    // the wave their instructions: genome text, plain index 183 -> 227 ms, with tables 130 -> 141 ms.)
+    ulonglong2* const frames = reinterpret_cast<ulonglong2*>(stk.p0);
     uint32_t nodes = 0;
     uint64_t tbytes = 0; uint32_t tacc = 0;                         // table bytes consumed / table accesses issued (fmgpu_stats)
     const uint32_t refill_waste = ((uint32_t)dev_flags >> 8) & 0xffffu ? (((uint32_t)dev_flags >> 8) & 0xffffu) : kRefillWaste;   // (dev knob: bits 8..23)
@@ -1434,8 +1439,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
                 uint64_t w0 = 0, w1 = 0, w2 = 0;
                 if (give) {
-                    const uint64_t o = (uint64_t)sbase * stk.nlanes + gid;
-                    w0 = stk.p0[o]; w1 = stk.p1[o]; w2 = key_prefix(pkey, (uint32_t)(w1 >> 48) & 0xffu);
+                    const ulonglong2 fr = frames[(uint64_t)sbase * stk.nlanes + gid];
+                    w0 = fr.x; w1 = fr.y; w2 = key_prefix(pkey, (uint32_t)(w1 >> 48) & 0xffu);
                     ++sbase; mark = nodes; tbytes += 16u; ++tacc;
                 }
                 uint64_t om = offerm;                               // the lane of my partner: the (rank + 1)-th offering lane
@@ -1576,9 +1581,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     if (take_sub) { take = subs.first(); subs.remove(take); }
                     nodes += (!resuming && (in_tail || xOK || mOK)) ? 1u : 0u;   // node accounting as the reference works (see k_scheme)
                     if ((take_match || take_sub) && subs.any()) {  // (re-)push the parent: remaining siblings start at subs.first()
-                        uint64_t o = (uint64_t)sp * stk.nlanes + gid;
-                        stk.p0[o] = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
-                        stk.p1[o] = (uint64_t)cur.len | ((uint64_t)(j & 0xffffu) << 32) | ((uint64_t)(e & 0xffu) << 48) | ((uint64_t)(subs.first() & 0xffu) << 56);
+                        frames[(uint64_t)sp * stk.nlanes + gid] = make_ulonglong2((uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32),
+                            (uint64_t)cur.len | ((uint64_t)(j & 0xffffu) << 32) | ((uint64_t)(e & 0xffu) << 48) | ((uint64_t)(subs.first() & 0xffu) << 56));
                         ++sp; tbytes += 16u; ++tacc;
                     }
                     resume = kNoResume;
@@ -1742,8 +1746,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     if (sp == sbase) search_over = true;
                     else {
                         --sp;
-                        uint64_t o = (uint64_t)sp * stk.nlanes + gid;
-                        uint64_t w0 = stk.p0[o], w1 = stk.p1[o];
+                        const ulonglong2 fr = frames[(uint64_t)sp * stk.nlanes + gid];
+                        const uint64_t w0 = fr.x, w1 = fr.y;
                         tbytes += 16u; ++tacc;
                         cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32); cur.len = (idx_t)w1;
                         j = (uint32_t)(w1 >> 32) & 0xffffu; e = (uint32_t)(w1 >> 48) & 0xffu; resume = (uint32_t)(w1 >> 56) & 0xffu;
