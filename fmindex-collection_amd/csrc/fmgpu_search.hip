@@ -1534,6 +1534,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 else { tbytes += lut_start ? 16u : from_block ? 64u : use_wj ? 8u : w3 ? 12u : 4u; ++tacc; }
                 const uint2 we = make_uint2(r0.x, r0.y);
                 idx_t t0 = r0.x, t1 = r0.y, t2 = r0.z;
+                uint32_t row_sym = 0;                               // plain index: the symbol of a one-row node's row, read off its block
                 if constexpr (kSplit) {
                     if (from_block) {
                         const uint4* pa = reinterpret_cast<const uint4*>(p0);
@@ -1544,7 +1545,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
 #pragma unroll
                         for (uint32_t cc = 0; cc < (uint32_t)SIGMA; ++cc) {
                             const uint64_t bits = (uint64_t)da[3 * cc + 1] | ((uint64_t)da[3 * cc + 2] << 32);
-                            if ((bits >> bit) & 1ull) t0 = da[3 * cc] + popc64(bits & lowmask(bit));
+                            if ((bits >> bit) & 1ull) { t0 = da[3 * cc] + popc64(bits & lowmask(bit)); row_sym = cc; }
                         }
                     }
                 }
@@ -1600,7 +1601,26 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     bool walked = false, stretch = false, del_after = false;
                     uint32_t n = 0, mm = 0, sword = 0, sym3 = 0;   // sym3: the symbols of a <= 3-step stretch, 8 bits each (a 16-step stretch keeps them in we.y)
                     idx_t target = 0;
-                    if (use_wj && we.x != 0xffffffffu) {
+                    if (from_block) {
+                        // plain index: ONE step from the row's own block — none of the stretch machinery below (a wave pays for the instructions
+                        // of every path one of its lanes takes; with no tables no lane takes them)
+                        walked = true;
+                        const uint32_t minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
+                        const bool lastp = (ent >> 17) & 1u;
+                        const uint32_t c = qstage_get(qst, qs, ent & 0xffffu);
+                        const bool mOK = minE <= e && e <= maxE;
+                        const bool sOK = minE <= e + 1 && e + 1 <= maxE;
+                        const bool xOK = e + 1 <= maxE;
+                        const bool is_match = row_sym >= 1u && row_sym == c && mOK;
+                        nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
+                        bool dead = false;
+                        if (row_sym < 1u) dead = true;              // :295-297: a delimiter row ends the walk
+                        else if (row_sym == c) { if (!mOK) dead = true; }
+                        else if (sOK) { pkey = key_with(pkey, e, m, j, row_sym); e += 1; }
+                        else dead = true;
+                        if (dead) back = true;
+                        else { in_tail = !lastp && (in_tail || (is_match && !xOK)); if (right) cur.lbRev = t0; else cur.lb = t0; ++j; }
+                    } else if (use_wj && we.x != 0xffffffffu) {
                         walked = true;
                         bool qvalid = false;
                         const uint32_t qc = query_code16(qst, ent & 0xffffu, right, qvalid);
