@@ -1377,7 +1377,16 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
 // iterations of each other and one refill serves them all; next to a heavy read the idle lanes are first served by its shared frames
 constexpr uint32_t kRefillWaste = 2048;
 
-template <int SIGMA, int MAXSIG>
+// PLAIN: the index holds no tables (no LF, walk or prefix table: the ~6 GB configuration) — every node reads blocks and the table paths are
+// compiled out (fewer scalar registers spilled; genome text 168 -> 164 ms).
+// What was measured on this kernel and did NOT pay (10 M x 101 bp, k = 2, genome-like text, plain index; 91 % of the lanes of a wave are busy
+// in an iteration, an iteration takes ~8.6 us, VALU busy 41 %, scratch-free at 96 VGPRs = 5 waves per SIMD, which the LDS allows too):
+//   * the substitution children of a node waiting on the stack as nodes of their own (no node is read twice): 183 -> 227 ms;
+//   * asking for a waiting frame at the end of an iteration and taking it at the end of the next (the L2 round trip under the next block loads
+//     instead of behind them): 164 -> 222 ms — four more live registers spill to scratch inside the loop;
+//   * 6 / 7 / 8 waves per SIMD by launch bounds: 32 / 48 / 86 VGPRs spilled.
+// The loop is bound by instruction issue and register pressure together with the random-line rate, not by lane utilisation.
+template <int SIGMA, int MAXSIG, bool PLAIN>
 __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
@@ -1490,7 +1499,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 tab = s_steps + si * stride;
                 cur = Cur{0, 0, n}; e = 0; j = 0; sp = 0; sbase = 0; resume = kNoResume; in_tail = false;
                 pkey = (uint64_t)si << 48;
-                if (fa.lut && ((fa.lut_ok >> si) & 1u) && n > 1) {  // the exact first part starts from the prefix table
+                if (!PLAIN && fa.lut && ((fa.lut_ok >> si) & 1u) && n > 1) {  // the exact first part starts from the prefix table
                     uint32_t code = 0, mul = 1; bool valid = true;
                     for (uint32_t t = 0; t < fa.lutL; ++t) {
                         uint32_t c = qstage_get(qst, qs, tab[t] & 0xffffu);
@@ -1511,12 +1520,12 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 // (ONE unconditional 16-byte load per lane — the first quarter of a multi-row lane's block, or a one-row lane's walk / LF^1..3 /
                 // LF entry, all dword-aligned, the tables carry 16 bytes of slack — and the rest of the two blocks right behind it)
                 constexpr bool kSplit = SIGMA > 0 && SIGMA <= 5;
-                const uint2* wj = right ? fa.wj_rv : fa.wj_fw;
-                const idx_t* w3 = right ? fa.w3_rv : fa.w3_fw;
-                const bool use_wj = !lut_start && !multi && wj && ((ent >> 29) & 1u);
+                const uint2* wj = PLAIN ? nullptr : (right ? fa.wj_rv : fa.wj_fw);
+                const idx_t* w3 = PLAIN ? nullptr : (right ? fa.w3_rv : fa.w3_fw);
+                const bool use_wj = !PLAIN && !lut_start && !multi && wj && ((ent >> 29) & 1u);
                 const uint8_t* blk = (right ? rv : fw).v.blk;
                 // the plain index (no LF tables: the ~6 GB configuration): a one-row node reads its 64-byte block and takes the row's symbol and LF from it
-                const bool from_block = kSplit && !lut_start && !multi && fa.lf_fw == nullptr;
+                const bool from_block = PLAIN ? !multi : (kSplit && !lut_start && !multi && fa.lf_fw == nullptr);
                 const uint8_t* p0 = lut_start ? reinterpret_cast<const uint8_t*>(fa.lut + lut_code)
                                   : ((multi && kSplit) || from_block) ? blk + (size_t)(a >> 6) * 64u
                                   : use_wj ? reinterpret_cast<const uint8_t*>(wj + a)
@@ -2780,11 +2789,14 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                 else
                     k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                               b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
-            } else if (x->bwt.sigma == 5)
-                k_scheme_fast<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+            } else if (x->bwt.sigma == 5 && !have_lf)
+                k_scheme_fast<5, 5, true><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                          b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
+            else if (x->bwt.sigma == 5)
+                k_scheme_fast<5, 5, false><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
             else
-                k_scheme_fast<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                k_scheme_fast<0, 32, false><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                      b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
         }
     } else
