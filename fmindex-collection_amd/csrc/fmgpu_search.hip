@@ -1377,6 +1377,13 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
 // iterations of each other and one refill serves them all; next to a heavy read the idle lanes are first served by its shared frames
 constexpr uint32_t kRefillWaste = 2048;
 
+// a counter that costs nothing where it is not wanted
+template <class T, bool ON> struct Tally {
+    T v = 0;
+    __device__ __forceinline__ void operator+=(T x) { if (ON) v += x; }
+    __device__ __forceinline__ void operator++() { if (ON) ++v; }
+};
+
 // PLAIN: the index holds no tables (no LF, walk or prefix table: the ~6 GB configuration) — every node reads blocks and the table paths are
 // compiled out (fewer scalar registers spilled; genome text 168 -> 164 ms).
 // What was measured on this kernel and did NOT pay (10 M x 101 bp, k = 2, genome-like text, plain index; 91 % of the lanes of a wave are busy
@@ -1420,7 +1427,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     // the wave their instructions: genome text, plain index 183 -> 227 ms, with tables 130 -> 141 ms.)
     ulonglong2* const frames = reinterpret_cast<ulonglong2*>(stk.p0);
     uint32_t nodes = 0;
-    uint64_t tbytes = 0; uint32_t tacc = 0;                         // table bytes consumed / table accesses issued (fmgpu_stats)
+    Tally<uint64_t, !PLAIN> tbytes; Tally<uint32_t, !PLAIN> tacc;   // table bytes consumed / table accesses issued (fmgpu_stats; the plain index is priced per node)
     const uint32_t refill_waste = ((uint32_t)dev_flags >> 8) & 0xffffu ? (((uint32_t)dev_flags >> 8) & 0xffffu) : kRefillWaste;   // (dev knob: bits 8..23)
     uint32_t waste = 0;                                             // lane-iterations the wave's idle lanes have lost since its last refill (wave-uniform)
     uint32_t nh = 0, count_only = 0, nodes0 = 0;
@@ -1796,7 +1803,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
         }
     }
     uint32_t tot = wave_sum(nodes);
-    const unsigned long long tb = wave_sum64(tbytes); const uint32_t ta = wave_sum(tacc), co = wave_sum(count_only);
+    const unsigned long long tb = wave_sum64(tbytes.v); const uint32_t ta = wave_sum(tacc.v), co = wave_sum(count_only);
     if ((threadIdx.x & 63u) == 0 && (tot || co)) {
         atomicAdd(&ctr->nodes, (unsigned long long)tot);
         atomicAdd(&ctr->table_bytes, tb); atomicAdd(&ctr->table_accesses, (unsigned long long)ta);
