@@ -180,6 +180,7 @@ struct SchemeDev {             // flattened [search][part]; values fit a byte (e
     uint32_t psum;                   // sum of partition[] (queries of another length are skipped)
     int uniform;
     int dev_flags;                   // dev knobs: 1 = count hits per lane only (no records)
+    int use_key, sharing;            // k_scheme: hit records carry path keys / idle lanes take subtrees from the busy lanes of their wave
 };
 
 struct Counters { unsigned long long hits, nodes, next, table_bytes, table_accesses; };
@@ -505,7 +506,8 @@ __global__ __launch_bounds__(256) void k_exact_m(ViewM v, const uint8_t* __restr
 
 // ---- search_ng26 Hamming --------------------------------------------------------------------------------------
 template <class Occ, int MAXSIG>
-__global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
+// (5 resident blocks — 4 with 64-bit rows — is what the LDS of a 101-symbol batch allows anyway; 6 spilled 45 registers once the sharing state came in)
+__global__ __launch_bounds__(256, MAXSIG <= 5 ? (kWide ? 4 : 5) : 1) void k_scheme(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
                                                 const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                 fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv) {
     extern __shared__ uint32_t s_query[];
@@ -546,8 +548,75 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
         return sch.uniform ? pbase + (p < prem ? 1u : 0u) : s_part[p];
     };
     bool need_search = true;
+    // work sharing at the end of the batch (see k_scheme_fast): once the queries are handed out, a lane that is out of work takes the bottom
+    // frame of a busy lane of its wave; the hits of a read are ordered by path keys then (Hamming: <= 2 substitutions)
+    bool is_task = false;
+    uint32_t sbase = 0, mark = 0;
+    uint64_t pkey = 0;
+    auto frame_words = [&](uint64_t& w0, uint64_t& w1, uint64_t& w2, uint32_t nxt) {      // the node the lane stands on as a frame; nxt = its next child
+        if constexpr (kWide) {                                     // rows of up to 40 bits: one cursor field per word
+            w0 = (uint64_t)cur.lb | ((uint64_t)(pev & 0xffffu) << 40) | ((uint64_t)(e & 0xffu) << 56);
+            w1 = (uint64_t)cur.lbRev | ((uint64_t)(qR & 0xffffu) << 40) | ((uint64_t)(nxt & 0xffu) << 56);
+            w2 = (uint64_t)cur.len | ((uint64_t)((qL + 1u) & 0xffffu) << 40) | ((uint64_t)(part & 0x7fu) << 56) | ((uint64_t)(right ? 1u : 0u) << 63);
+        } else {
+            w0 = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
+            w1 = (uint64_t)cur.len | ((uint64_t)(pev & 0xffffu) << 32) | ((uint64_t)(qR & 0xffffu) << 48);
+            w2 = (uint64_t)nxt | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
+                 ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
+        }
+    };
+    auto frame_take = [&](uint64_t w0, uint64_t w1, uint64_t w2) {  // stand on a frame's node again
+        if constexpr (kWide) {
+            const uint64_t m40 = (1ull << 40) - 1ull;
+            cur.lb = (idx_t)(w0 & m40); pev = (uint32_t)(w0 >> 40) & 0xffffu; e = (uint32_t)(w0 >> 56) & 0xffu;
+            cur.lbRev = (idx_t)(w1 & m40); qR = (uint32_t)(w1 >> 40) & 0xffffu; resume = (uint32_t)(w1 >> 56) & 0xffu;
+            cur.len = (idx_t)(w2 & m40); qL = ((uint32_t)(w2 >> 40) & 0xffffu) - 1u; part = (uint32_t)(w2 >> 56) & 0x7fu; right = (w2 >> 63) & 1u;
+        } else {
+            cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32);
+            cur.len = (idx_t)w1; pev = (uint32_t)(w1 >> 32) & 0xffffu; qR = (uint32_t)(w1 >> 48) & 0xffffu;
+            resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
+            right = (w2 >> 47) & 1u;
+            qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
+        }
+        tail = 0;
+    };
     for (;;) {
         // ---- wave-synchronous part: all 64 lanes pass here in every iteration
+        if (sch.sharing) {
+            if (is_task && need_search) { is_task = false; idle = true; }      // a task is one subtree of one search
+            const bool offer = !idle && !need_search && sp > sbase && nodes - mark >= kShareNodes;
+            const uint64_t idlem = __ballot(idle), offerm = __ballot(offer);
+            if (idlem && offerm) {
+                const uint64_t below = (1ull << lane) - 1ull;
+                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
+                const bool give = offer && (uint32_t)__popcll(offerm & below) < pairs;
+                const bool take = idle && (uint32_t)__popcll(idlem & below) < pairs;
+                uint64_t w0 = 0, w1 = 0, w2 = 0, wk = 0;
+                if (give) {
+                    const uint64_t o = (uint64_t)sbase * stk.nlanes + gid;
+                    w0 = stk.p0[o]; w1 = stk.p1[o]; w2 = stk.p2[o];
+                    wk = key_prefix(pkey, kWide ? ((uint32_t)(w0 >> 56) & 0xffu) : ((uint32_t)(w2 >> 32) & 0xffu));
+                    ++sbase; mark = nodes; tbytes += 24u; ++tacc;
+                }
+                uint64_t om = offerm;                               // my partner: the (rank + 1)-th offering lane
+                for (uint32_t t = take ? (uint32_t)__popcll(idlem & below) : 0u; t > 0; --t) om &= om - 1ull;
+                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const uint64_t t0 = __shfl(w0, vl, 64), t1 = __shfl(w1, vl, 64), t2 = __shfl(w2, vl, 64), tk = __shfl(wk, vl, 64);
+                const uint64_t tq = __shfl(q, vl, 64), tqs = __shfl((uint64_t)qs, vl, 64);
+                const uint32_t tsi = __shfl(si, vl, 64), tm = __shfl(m, vl, 64);
+                if (take) {
+                    q = tq; qs = reinterpret_cast<const uint8_t*>(tqs); si = tsi; m = tm;
+                    pbase = m / P; prem = m - pbase * P;
+                    pi = s_pi + si * kMaxParts; L = s_l + si * kMaxParts; U = s_u + si * kMaxParts;
+                    frame_take(t0, t1, t2);
+                    pkey = tk;
+                    const uint32_t vt = (threadIdx.x & ~63u) | (uint32_t)vl;
+                    for (uint32_t w = 0; w < qwords; ++w) s_query[w * 256u + threadIdx.x] = s_query[w * 256u + vt];      // the partner's staged query
+                    idle = false; is_task = true; need_search = false; have_query = true; fresh = false;
+                    quota = max_hits; seq = 0; sp = 0; sbase = 0; mark = nodes;
+                }
+            }
+        }
         const bool want_q = !idle && need_search && !(have_query && si + 1 < S && quota != 0);   // search_impl / search_n_impl, SearchNg26.h:369-391, :407-423
         const uint64_t got = wave_hand_out(want_q, ctr, lane);
         if (want_q) {
@@ -577,6 +646,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
             // run(): SearchNg26.h:62-79
             cur = Cur{0, 0, n};
             e = 0; part = 0; qL = 0; qR = 0; tail = 0; sp = 0; resume = kNoResume;
+            sbase = 0; mark = nodes; pkey = (uint64_t)si << 48;
             for (uint32_t i = 0; i < pi[0]; ++i) { uint32_t pl = part_len(i); qL += pl; qR += pl; }
             qL -= 1;                                               // may wrap; not read until it is valid again
             pev = part_len(pi[0]);
@@ -630,16 +700,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
         nodes += in_tail ? 1u : multi ? ((!resuming && (xOK || mOK)) ? 1u : 0u) : (1u + ((take_match && !xOK) ? 1u : 0u));
         if (ok && multi && !in_tail && subs.any()) {               // (re-)push the parent: its remaining siblings start at subs.first()
             uint64_t w0, w1, w2;
-            if constexpr (kWide) {                                 // rows of up to 40 bits: one cursor field per word
-                w0 = (uint64_t)cur.lb | ((uint64_t)(pev & 0xffffu) << 40) | ((uint64_t)(e & 0xffu) << 56);
-                w1 = (uint64_t)cur.lbRev | ((uint64_t)(qR & 0xffffu) << 40) | ((uint64_t)(subs.first() & 0xffu) << 56);
-                w2 = (uint64_t)cur.len | ((uint64_t)((qL + 1u) & 0xffffu) << 40) | ((uint64_t)(part & 0x7fu) << 56) | ((uint64_t)(right ? 1u : 0u) << 63);
-            } else {
-                w0 = (uint64_t)cur.lb | ((uint64_t)cur.lbRev << 32);
-                w1 = (uint64_t)cur.len | ((uint64_t)(pev & 0xffffu) << 32) | ((uint64_t)(qR & 0xffffu) << 48);
-                w2 = (uint64_t)subs.first() | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
-                     ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
-            }
+            frame_words(w0, w1, w2, subs.first());
             uint64_t o = (uint64_t)sp * stk.nlanes + gid;
             stk.p0[o] = w0; stk.p1[o] = w1; stk.p2[o] = w2;
             ++sp; tbytes += 24u; ++tacc;
@@ -649,7 +710,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
         if (ok) {
             if (via_lf) cur = right ? Cur{cur.lb, lf1, 1} : Cur{lf1, cur.lbRev, 1};
             else cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
-            if (take_sub) e += 1;
+            if (take_sub) { if (sch.use_key) pkey = key_with(pkey, e, m, qR - qL - 1u, take); e += 1; }   // (qR - qL - 1 = symbols consumed so far = the step)
             if (right) ++qR; else --qL;                            // one query symbol consumed (search_next_pos :122-124 / tail)
             if (in_tail) { to_next = --tail == 0; if (to_next) { ++part; pev = part != P ? part_len(pi[part]) : 0; } }
             else if (start_tail) { tail = pev - 1; to_next = tail == 0; if (to_next) { ++part; pev = part != P ? part_len(pi[part]) : 0; } }
@@ -661,7 +722,9 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
                     Cur r = cur;
                     if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
                     quota -= r.len;
-                    if (sch.dev_flags & 1) ++seq; else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
+                    if (sch.dev_flags & 1) ++seq;
+                    else if (sch.use_key) { wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e | ((uint32_t)(pkey >> 32) << 8), (uint32_t)pkey); ++seq; }
+                    else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
                     if (quota == 0) { need_search = true; continue; }     // delegate returned true: skip the remaining searches
                 }
                 back = true;
@@ -670,24 +733,13 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 6 : 1) void k_scheme(Occ fw, Occ
             }
         }
         if (back) {
-            if (sp == 0) { need_search = true; continue; }
+            if (sp == sbase) { need_search = true; continue; }
             --sp;
             uint64_t o = (uint64_t)sp * stk.nlanes + gid;
             uint64_t w0 = stk.p0[o], w1 = stk.p1[o], w2 = stk.p2[o];
             tbytes += 24u; ++tacc;
-            if constexpr (kWide) {
-                const uint64_t m40 = (1ull << 40) - 1ull;
-                cur.lb = (idx_t)(w0 & m40); pev = (uint32_t)(w0 >> 40) & 0xffffu; e = (uint32_t)(w0 >> 56) & 0xffu;
-                cur.lbRev = (idx_t)(w1 & m40); qR = (uint32_t)(w1 >> 40) & 0xffffu; resume = (uint32_t)(w1 >> 56) & 0xffu;
-                cur.len = (idx_t)(w2 & m40); qL = ((uint32_t)(w2 >> 40) & 0xffffu) - 1u; part = (uint32_t)(w2 >> 56) & 0x7fu; right = (w2 >> 63) & 1u;
-            } else {
-                cur.lb = (idx_t)w0; cur.lbRev = (idx_t)(w0 >> 32);
-                cur.len = (idx_t)w1; pev = (uint32_t)(w1 >> 32) & 0xffffu; qR = (uint32_t)(w1 >> 48) & 0xffffu;
-                resume = (uint32_t)w2; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
-                right = (w2 >> 47) & 1u;
-                qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
-            }
-            tail = 0;
+            frame_take(w0, w1, w2);
+            pkey = key_prefix(pkey, e);
         }
     }
     uint32_t tot = wave_sum(nodes);
@@ -2610,6 +2662,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         sd.S = scheme->n_searches; sd.P = scheme->n_parts; sd.uniform = scheme->partition ? 0 : 1;
         edit = scheme->edit != 0;
         { const char* e = getenv("FMGPU_DEV_FLAGS"); sd.dev_flags = e ? atoi(e) : 0; }
+        sd.use_key = 0; sd.sharing = 0;                              // set below for the general Hamming kernel
         for (int s = 0; s < sd.S; ++s) {
             uint32_t seen = 0;
             for (int p = 0; p < sd.P; ++p) {
@@ -2809,6 +2862,10 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     } else
 #endif
     if (scheme_mode) {
+        // the general Hamming kernel: path keys order the hits of a read (<= 2 substitutions), and with them and no limit on the hits per read the
+        // lanes that run out of queries at the end of the batch take subtrees from the busy lanes of their wave
+        sd.use_key = !edit && max_u <= 2 && sd.S <= 16 ? 1 : 0;
+        sd.sharing = sd.use_key && max_hits == ~0ull && !(sd.dev_flags & (1 << 24)) ? 1 : 0;
         const DevString& rv = x->rev;
         LfView lfv{nullptr, nullptr, nullptr};
         if (x->bwt.lf_table && rv.lf_table && !(sd.dev_flags & 16)) lfv = LfView{x->bwt.lf_table, rv.lf_table, x->dC};
