@@ -347,7 +347,7 @@ def run_dna_text(c, name, primary):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
     legs = ["exact", "k2", "k2_151"]
-    ids = ["%s/%s/%s" % (name, w, i) for w in legs for i in ("plain", "tables")] + ["%s/k2_edit/tables" % name]
+    ids = ["%s/%s/%s" % (name, w, i) for w in legs + ["locate"] for i in ("plain", "tables")] + ["%s/k2_edit/tables" % name]
     if c.only and not any(i in c.only for i in ids):
         return []
     text, seq_off, lengths, tinfo = make_text(c, name)
@@ -358,7 +358,7 @@ def run_dna_text(c, name, primary):
     base_cfg = {"text": tinfo, "sigma": 5, "layout": "InterleavedBitvector16", "scale": args.scale}
 
     # ------------------------------------------------------------------ exact search, configs[1]
-    if any(wanted(c, "%s/exact/%s" % (name, i)) for i in ("plain", "tables")):
+    if any(wanted(c, "%s/%s/%s" % (name, w_, i)) for w_ in ("exact", "locate") for i in ("plain", "tables")):
         L = 101
         qbuf, qoff = sample_reads(c, text, lengths, L, nq, 1000 + c.rank, "exact")
         torch.cuda.synchronize()
@@ -409,7 +409,46 @@ def run_dna_text(c, name, primary):
             attach_traffic(c, rec)
             return rec
 
+        def locate_run(rid, index_kind, build_s):
+            """locate (LocateLinear / FMIndex::locate, fmindex/FMIndex.h:113-124) of the row every hit interval starts at: part of the path
+            (north_star: ... -> SA interval -> locate).  SURVEY 8d: per LF step one block (symbol + rank) and one presence-bit probe."""
+            lb, ln = outs[0][:nq], outs[0][nq:]
+            sel = ln > 0
+            rows = lb[sel].contiguous()
+            nr = int(rows.numel())
+            if nr == 0:
+                return None
+            res = [torch.empty(nr, dtype=torch.int64, device=c.dev) for _ in range(3)]
+            lstats = capi.Stats()
+
+            def lstep(log):
+                capi.check(capi.lib().fmgpu_locate(index._h, C.c_void_p(rows.data_ptr()), nr, C.c_void_p(res[0].data_ptr()), C.c_void_p(res[1].data_ptr()),
+                                                   C.c_void_p(res[2].data_ptr()), C.byref(lstats), None))
+                log.append({"kernel_ms": lstats.kernel_ms, "units": lstats.lf_steps})
+            elapsed, log = timed(c, lstep)
+            k_ms = mean([x["kernel_ms"] for x in log]); units = mean([x["units"] for x in log])
+            # size-independent check: every located position holds the read that found it (text[seq_off[seq] + pos + steps ...] == read)
+            pick = torch.arange(0, nr, max(1, nr // 200_000), device=c.dev)
+            tpos = seq_off[res[0][pick]] + res[1][pick] + res[2][pick]
+            ridx = torch.nonzero(sel).view(-1)[pick]
+            ar = torch.arange(L, device=c.dev)
+            same = bool((text[tpos[:, None] + ar[None, :]] == qbuf[(ridx * L)[:, None] + ar[None, :]]).all().item())
+            pps = nr * args.steps / elapsed
+            rec = {"id": rid, "metric": "located positions/sec (first row of every exact hit, 10M x 101bp reads, sampled suffix array rate 16)", "value": pps, "unit": "positions/s",
+                   "n_gpus": c.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": "u64", "data": "synthetic" if name != "fasta" else "real",
+                   "config": {"workload": "grch38_locate", **base_cfg, "index": "FMIndex", "index_kind": index_kind, "rows_per_gpu": nr, "sampling_rate": 16,
+                              "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
+                   "lf_steps_per_row": units / nr, "located_positions_hold_their_reads": same}
+            if index_kind == "plain":
+                rec["roofline"] = roofline_sec8d(units + nr, BLOCK_BYTES_IB16_S5 + 64, k_ms, "k_locate", "locate steps (LF steps + the final probe; one block + one presence-bit line each)")
+            else:
+                rec["roofline"] = roofline_loaded({"table_bytes": 12.0 * nr, "table_accesses": float(nr)}, nr * 32, k_ms, "k_locate_tab", units, "LF steps of locate")
+            return rec
+
         plain_ms = None
+        if wanted(c, name + "/locate/plain") and not c.multi and not wanted(c, name + "/exact/plain"):
+            step([])                                              # the rows come from the exact search
         if wanted(c, name + "/exact/plain") and not c.multi:
             elapsed, log = timed(c, step)
             r = finish(name + "/exact/plain", "plain", "k_exact_a", elapsed, log, build_plain, {"tables": None})
@@ -424,7 +463,9 @@ def run_dna_text(c, name, primary):
                                               "what": "query symbols consumed until the SA interval holds <= 1 row (fmgpu_search_exact_depth), over the same reads"}
                 del depth, d
             out.append(r)
-        if wanted(c, name + "/exact/tables"):
+        if wanted(c, name + "/locate/plain") and not c.multi:
+            out.append(locate_run(name + "/locate/plain", "plain", build_plain))
+        if wanted(c, name + "/exact/tables") or wanted(c, name + "/locate/tables"):
             t0 = time.time()
             os.environ.pop("FMGPU_LF_TABLE", None)
             index.accelerate(3, lut_len=args.lut_len, walk=2)
@@ -436,7 +477,12 @@ def run_dna_text(c, name, primary):
                 r["roofline"]["speedup_over_plain_index_kernel"] = plain_ms / r["roofline"]["kernel_ms"]
             if want_cpu:
                 r["cpu_baseline"] = cpu_baseline(c, index, False, qbuf, qoff, nq, L, None, outs[0][:nq], outs[0][nq:], None)
-            out.append(r)
+            if wanted(c, name + "/exact/tables"):
+                out.append(r)
+            if wanted(c, name + "/locate/tables") and not c.multi:
+                t0 = time.time()
+                index.accelerate_locate()
+                out.append(locate_run(name + "/locate/tables", "tables", build_tab + time.time() - t0))
         os.environ.pop("FMGPU_LF_TABLE", None)
         index.close()
         del index, qbuf, qoff, outs, packed
