@@ -165,6 +165,39 @@ def test_exact_search_with_kstep_accelerator(layout, sigma, kstep):
     assert np.array_equal(lb2, lb) and np.array_equal(ln2, ln)
 
 
+@pytest.mark.parametrize("sigma,walk", [(5, 2), (5, True), (4, 2), (6, True)])
+def test_exact_search_interval_walks_in_repeats_and_runs(sigma, walk):
+    """reads that never reach one row — inside exact and slightly diverged repeat copies, tandem arrays and runs of one symbol — take the walk tables
+    for their whole interval (k_exact_kstep: both end rows carry the query's symbols); cursors and step counts equal the CPU walk, also where an
+    end row leaves the interval in the middle of a stretch, at delimiters and at the text ends"""
+    rng = np.random.default_rng(40 + sigma)
+    unit = rng.integers(1, sigma, size=400, dtype=np.uint8)
+    copies = []
+    for k in range(7):
+        cp = unit.copy()
+        for _ in range(k):                                      # copy k differs from the consensus in k places
+            cp[int(rng.integers(0, cp.size))] = rng.integers(1, sigma)
+        copies.append(cp); copies.append(rng.integers(1, sigma, size=int(rng.integers(5, 60)), dtype=np.uint8))
+    tandem = np.tile(rng.integers(1, sigma, size=7, dtype=np.uint8), 90)
+    seqs = [np.concatenate(copies), np.concatenate([np.full(700, 1, dtype=np.uint8), tandem, unit[:250]]), np.full(130, 2, dtype=np.uint8)]
+    ox = fo.OraIndex.build("IB16", sigma, seqs, 8, False)
+    gx = gpu_index(ox)
+    queries = []
+    for i in range(1500):
+        sq = seqs[i % 3]; m = int(rng.integers(20, 121)); m = min(m, len(sq)); p = int(rng.integers(0, len(sq) - m + 1)); q = sq[p: p + m].copy()
+        if i % 5 == 0:
+            q[int(rng.integers(0, m))] = rng.integers(1, sigma)
+        queries.append(q)
+    queries += [np.full(101, 1, dtype=np.uint8), np.full(131, 2, dtype=np.uint8), np.tile(tandem[:7], 15)[:101]]
+    qbuf, qoff = fm.flatten(queries)
+    olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
+    assert (oln > 1).sum() > 500                              # most of these reads end on several rows
+    for kstep, lut_len in ((3, 4), (2, 0), (1, 3)):
+        gx.accelerate(kstep, lut_len=lut_len, walk=walk)
+        lb, ln, st = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+        assert np.array_equal(lb, olb) and np.array_equal(ln, oln) and st.lf_steps == int(ost.sum()), (kstep, lut_len, walk)
+
+
 @pytest.mark.parametrize("layout,sigma", [("IB16", 256), ("IB16", 21), ("EPRV5", 6), ("FBV_512_64K", 255)])
 def test_exact_search_tables_other_alphabets(layout, sigma):
     """interval table and walk table with symbols wider than 2 bits (walk length 32 / bit_width(sigma-2): 4 symbols at sigma = 256)"""
