@@ -166,10 +166,10 @@ def test_exact_search_with_kstep_accelerator(layout, sigma, kstep):
 
 
 @pytest.mark.parametrize("sigma,walk", [(5, 2), (5, True), (4, 2), (6, True)])
-def test_exact_search_interval_walks_in_repeats_and_runs(sigma, walk):
-    """reads that never reach one row — inside exact and slightly diverged repeat copies, tandem arrays and runs of one symbol — take the walk tables
-    for their whole interval (k_exact_kstep: both end rows carry the query's symbols); cursors and step counts equal the CPU walk, also where an
-    end row leaves the interval in the middle of a stretch, at delimiters and at the text ends"""
+def test_exact_search_in_repeats_and_runs(sigma, walk):
+    """reads that never reach one row — inside exact and slightly diverged repeat copies, tandem arrays and runs of one symbol — through every table
+    combination of the exact search: cursors and step counts equal the CPU walk, also where the interval shrinks in the middle of a table
+    stretch, at delimiters and at the text ends"""
     rng = np.random.default_rng(40 + sigma)
     unit = rng.integers(1, sigma, size=400, dtype=np.uint8)
     copies = []
