@@ -750,6 +750,19 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? (kWide ? 4 : 5) : 1) void k_sche
     }
 }
 
+// ---- edit path keys (described at k_scheme_fast_edit) ----
+constexpr uint64_t kEditKeyNone = 0x400040004000ull;
+__device__ __forceinline__ uint64_t ekey_prefix(uint64_t key, uint32_t e) {   // the key of an ancestor that had made e errors
+    const uint64_t keep = e == 0u ? 0ull : (e == 1u ? 0xffff00000000ull : (e == 2u ? 0xffffffff0000ull : 0xffffffffffffull));
+    return (key & (0xfull << 48)) | (key & keep) | (kEditKeyNone & ~keep);
+}
+__device__ __forceinline__ uint64_t ekey_with(uint64_t key, uint32_t e_before, bool before_match, uint32_t depth, uint32_t code) {
+    if (e_before >= 3u) return key;
+    const uint32_t sh = 32u - 16u * e_before;
+    const uint64_t comp = before_match ? (uint64_t)((depth << 6) | code) : (uint64_t)(0x8000u | ((255u - depth) << 6) | code);
+    return (key & ~(0xffffull << sh)) | (comp << sh);
+}
+
 // ---- edit-distance frames (k_scheme_edit, k_ng21): four row-sized fields and four 32-bit words, the frames of a lane consecutive in memory — a DFS
 // pushes and pops them in order, so four (32-bit rows: 32 bytes each; 64-bit rows: 48) share a line or two, where interleaving them by lane
 // would touch one line per frame (the lanes of a wave sit at different depths)
@@ -823,8 +836,60 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
     const uint8_t *pi = s_pi, *L = s_l, *U = s_u;
     auto part_len = [&](uint32_t p) -> uint32_t { return sch.uniform ? pbase + (p < prem ? 1u : 0u) : s_part[p]; };
     bool need_search = true;
+    // path keys and work sharing at the end of the batch, as in k_scheme (keys: see k_scheme_fast_edit; ndel = deletions on the path, for the tree depth)
+    bool is_task = false;
+    uint32_t sbase = 0, mark = 0, ndel = 0;
+    uint64_t pkey = 0;
+    auto frame_take = [&](idx_t f_lb, idx_t f_rev, idx_t f_len, idx_t f_lf, uint32_t fa_, uint32_t fb_, uint32_t fc_, uint32_t f_side) {
+        const uint64_t w2 = (uint64_t)fb_ | ((uint64_t)fc_ << 32);
+        const bool one_row = ((uint32_t)w2 >> 20) & 1u;
+        cur.lb = f_lb; cur.lbRev = f_rev; cur.len = one_row ? (idx_t)1 : f_len; cached_lf2 = one_row ? f_len : kNoRow; cached_lf = f_lf; side = f_side;
+        pev = fa_ & 0xffffu; qR = fa_ >> 16;
+        resume = (uint32_t)w2 & 0xffffu; info = ((uint32_t)w2 >> 16) & 15u; ndel = ((uint32_t)w2 >> 21) & 0xffu;
+        e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
+        lf_known = false; report_slot = kNoResume;
+        right = (w2 >> 47) & 1u;
+        qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
+        tail = 0;
+    };
     for (;;) {
         // ---- wave-synchronous part: all 64 lanes pass here in every iteration (a lane without work idles until the wave is done)
+        if (sch.sharing) {
+            if (is_task && need_search) { is_task = false; idle = true; }      // a task is one subtree of one search
+            // (a frame whose running child still owes it the row's LF^2 — report_slot — stays with its owner for that one iteration)
+            const bool offer = !idle && !need_search && sp > sbase && nodes - mark >= kShareNodes && report_slot != sbase;
+            const uint64_t idlem = __ballot(idle), offerm = __ballot(offer);
+            if (idlem && offerm) {
+                const uint64_t below = (1ull << lane) - 1ull;
+                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
+                const bool give = offer && (uint32_t)__popcll(offerm & below) < pairs;
+                const bool take = idle && (uint32_t)__popcll(idlem & below) < pairs;
+                idx_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; uint32_t ga = 0, gb = 0, gc = 0, gd = 0; uint64_t gk = 0;
+                if (give) {
+                    edit_frame_get(edit_frame(stk, gid, sbase), g0, g1, g2, g3, ga, gb, gc, gd);
+                    gk = ekey_prefix(pkey, gc & 0xffu);             // (e sits in the low byte of the frame's third word)
+                    ++sbase; mark = nodes;
+                }
+                uint64_t om = offerm;                               // my partner: the (rank + 1)-th offering lane
+                for (uint32_t t = take ? (uint32_t)__popcll(idlem & below) : 0u; t > 0; --t) om &= om - 1ull;
+                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const uint64_t t0 = __shfl((uint64_t)g0, vl, 64), t1 = __shfl((uint64_t)g1, vl, 64), t2 = __shfl((uint64_t)g2, vl, 64), t3 = __shfl((uint64_t)g3, vl, 64);
+                const uint32_t ta = __shfl(ga, vl, 64), tb = __shfl(gb, vl, 64), tc = __shfl(gc, vl, 64), td = __shfl(gd, vl, 64);
+                const uint64_t tk = __shfl(gk, vl, 64), tq = __shfl(q, vl, 64), tqs = __shfl((uint64_t)qs, vl, 64);
+                const uint32_t tsi = __shfl(si, vl, 64), tm = __shfl(m, vl, 64);
+                if (take) {
+                    q = tq; qs = reinterpret_cast<const uint8_t*>(tqs); si = tsi; m = tm;
+                    pbase = m / P; prem = m - pbase * P;
+                    pi = s_pi + si * kMaxParts; L = s_l + si * kMaxParts; U = s_u + si * kMaxParts;
+                    frame_take((idx_t)t0, (idx_t)t1, (idx_t)t2, (idx_t)t3, ta, tb, tc, td);
+                    pkey = tk;
+                    const uint32_t vt = (threadIdx.x & ~63u) | (uint32_t)vl;
+                    for (uint32_t w = 0; w < qwords; ++w) s_query[w * 256u + threadIdx.x] = s_query[w * 256u + vt];      // the partner's staged query
+                    idle = false; is_task = true; need_search = false; have_query = true; fresh = false;
+                    quota = max_hits; seq = 0; sp = 0; sbase = 0; mark = nodes;
+                }
+            }
+        }
         const bool want_q = !idle && need_search && !(have_query && si + 1 < S && quota != 0);   // search_impl / search_n_impl, :369-391, :407-423
         const uint64_t got = wave_hand_out(want_q, ctr, lane);
         if (want_q) {
@@ -853,6 +918,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             pi = s_pi + si * kMaxParts; L = s_l + si * kMaxParts; U = s_u + si * kMaxParts;
             cur = Cur{0, 0, n};                                    // run(): :62-79
             e = 0; part = 0; qL = 0; qR = 0; tail = 0; sp = 0; resume = kNoResume; side = 0; info = 0;
+            sbase = 0; mark = nodes; ndel = 0; pkey = ((uint64_t)si << 48) | kEditKeyNone;
             for (uint32_t i = 0; i < pi[0]; ++i) { uint32_t pl = part_len(i); qL += pl; qR += pl; }
             qL -= 1;
             pev = part_len(pi[0]);
@@ -904,7 +970,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
         const bool xOK = e + 1 <= Up;
         const uint32_t start = resuming ? resume : 0u;
         // kind: 0 match, 1 substitution, 2 deletion, 3 insertion, 4 nothing left; `take` = index symbol of the child; `nxt` = number of the following child
-        uint32_t kind = 4u, take = c, nxt = kNoResume;
+        uint32_t kind = 4u, take = c, nxt = kNoResume, code = 0;   // code: the child's index among the error children of its node (path key)
         bool start_tail = false;
         if (in_tail) { if (c_alive) kind = 0u; }
         else if (multi) {
@@ -930,6 +996,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
                     else if (idx == INS) kind = 3u;
                     else { kind = (idx & 1u) ? 2u : 1u; take = (idx + 1u) >> 1; }
                     if (idx != INS) nxt = child_from(idx + 1u);
+                    code = idx;
                 }
             }
         } else {
@@ -947,10 +1014,11 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
                 if (same) { kind = 0u; start_tail = !xOK; nxt = (en2 && xOK) ? 2u : kNoResume; }   // :310-314: the exact tail's result is returned as is
                 else { kind = 1u; nxt = en2 ? 2u : kNoResume; }
             } else if (idx == 2u) { kind = 2u; take = b; }
+            code = idx == kNoResume ? 0u : idx;
         }
         nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + ((start_tail) ? 1u : 0u))));
         if (kind != 4u && nxt != kNoResume) {                       // keep the parent: its remaining children start at nxt
-            const uint64_t w2 = (uint64_t)(nxt | (info << 16) | ((via_lf ? 1u : 0u) << 20)) | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
+            const uint64_t w2 = (uint64_t)(nxt | (info << 16) | ((via_lf ? 1u : 0u) << 20) | ((ndel & 0xffu) << 21)) | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
                                 ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
             // one-row frames (len = 1): the third row field holds LF(LF(row)) once the first child on that row has loaded it
             edit_frame_put(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, via_lf ? kNoRow : cur.len, lf1, (pev & 0xffffu) | ((qR & 0xffffu) << 16), (uint32_t)w2, (uint32_t)(w2 >> 32), side);
@@ -966,7 +1034,11 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
                     if (kind == 2u && resuming && cached_lf2 != kNoRow) { lf_known = true; lf_val = cached_lf2; }   // reported by the first child on that row
                 } else cur = kid_of<MAXSIG>(lfa, lfb, cur, take, right, sigma);
             } else if (via_lf) { lf_known = true; lf_val = lf1; }    // insertion: the next node stands on the same row
-            if (kind != 0u) e += 1;
+            if (kind != 0u) {                                       // an error edge: one more component of the path key (depth = symbols consumed + deletions)
+                if (sch.use_key) pkey = ekey_with(pkey, e, !multi && kind == 3u, (qR - qL - 1u) + ndel, code);
+                e += 1;
+                if (kind == 2u) ++ndel;
+            }
             const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
             if (kind == 0u) {                                       // in the exact tail the values written last survive (:236-237)
                 side = (side & rmask & qmask) | (c << (8u * d)) | (c << (16u + 8u * d));
@@ -996,6 +1068,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
                     if ((uint64_t)r.len > quota) r.len = (idx_t)quota;
                     quota -= r.len;
                     if (sch.dev_flags & 1) ++seq;
+                    else if (sch.use_key) { wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e | ((uint32_t)(pkey >> 32) << 8), (uint32_t)pkey); ++seq; }
                     else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
                     if (quota == 0) { need_search = true; continue; }
                 }
@@ -1007,19 +1080,12 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             }
         }
         if (back) {
-            if (sp == 0) { need_search = true; continue; }
+            if (sp == sbase) { need_search = true; continue; }
             --sp;
-            idx_t f_len = 0; uint32_t fa_ = 0, fb_ = 0, fc_ = 0;
-            edit_frame_get(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, f_len, cached_lf, fa_, fb_, fc_, side);
-            const uint64_t w2 = (uint64_t)fb_ | ((uint64_t)fc_ << 32);
-            const bool one_row = ((uint32_t)w2 >> 20) & 1u;
-            cur.len = one_row ? (idx_t)1 : f_len; cached_lf2 = one_row ? f_len : kNoRow;
-            pev = fa_ & 0xffffu; qR = fa_ >> 16;
-            resume = (uint32_t)w2 & 0xffffu; info = ((uint32_t)w2 >> 16) & 15u; e = (uint32_t)(w2 >> 32) & 0xffu; part = (uint32_t)(w2 >> 40) & 0x7fu;
-            lf_known = false; report_slot = kNoResume;
-            right = (w2 >> 47) & 1u;
-            qL = ((uint32_t)(w2 >> 48) & 0xffffu) - 1u;
-            tail = 0;
+            idx_t f0 = 0, f1 = 0, f2 = 0, f3 = 0; uint32_t fa_ = 0, fb_ = 0, fc_ = 0, fd_ = 0;
+            edit_frame_get(edit_frame(stk, gid, sp), f0, f1, f2, f3, fa_, fb_, fc_, fd_);
+            frame_take(f0, f1, f2, f3, fa_, fb_, fc_, fd_);
+            pkey = ekey_prefix(pkey, e);
         }
     }
     uint32_t tot = wave_sum(nodes);
@@ -1880,18 +1946,6 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
 // further error" as 0x4000, an edge that follows the match child as (2, 255 - depth, child index): a deeper one is met earlier on the way
 // back up.  depth = query symbols consumed + deletions made.  Layout: search:4 | 3 x 16 bits; it travels like the Hamming key (the low
 // 32 bits in fmgpu_hit::seq, the rest in the upper 24 bits of fmgpu_hit::errors) until fmgpu_hits_sort turns it into the callback index.
-constexpr uint64_t kEditKeyNone = 0x400040004000ull;
-__device__ __forceinline__ uint64_t ekey_prefix(uint64_t key, uint32_t e) {   // the key of an ancestor that had made e errors
-    const uint64_t keep = e == 0u ? 0ull : (e == 1u ? 0xffff00000000ull : (e == 2u ? 0xffffffff0000ull : 0xffffffffffffull));
-    return (key & (0xfull << 48)) | (key & keep) | (kEditKeyNone & ~keep);
-}
-__device__ __forceinline__ uint64_t ekey_with(uint64_t key, uint32_t e_before, bool before_match, uint32_t depth, uint32_t code) {
-    if (e_before >= 3u) return key;
-    const uint32_t sh = 32u - 16u * e_before;
-    const uint64_t comp = before_match ? (uint64_t)((depth << 6) | code) : (uint64_t)(0x8000u | ((255u - depth) << 6) | code);
-    return (key & ~(0xffffull << sh)) | (comp << sh);
-}
-
 template <int SIGMA, int MAXSIG>
 __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
@@ -2862,9 +2916,9 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     } else
 #endif
     if (scheme_mode) {
-        // the general Hamming kernel: path keys order the hits of a read (<= 2 substitutions), and with them and no limit on the hits per read the
+        // the general kernels: path keys order the hits of a read (Hamming: <= 2 substitutions; edit distance: <= 3 errors), and with them and no limit on the hits per read the
         // lanes that run out of queries at the end of the batch take subtrees from the busy lanes of their wave
-        sd.use_key = !edit && max_u <= 2 && sd.S <= 16 ? 1 : 0;
+        sd.use_key = sd.S > 16 ? 0 : (!edit ? (max_u <= 2 ? 1 : 0) : (max_u <= 3 && maxlen + max_u <= 250 && x->bwt.sigma <= 32 ? 1 : 0));
         sd.sharing = sd.use_key && max_hits == ~0ull && !(sd.dev_flags & (1 << 24)) ? 1 : 0;
         const DevString& rv = x->rev;
         LfView lfv{nullptr, nullptr, nullptr};
