@@ -1103,7 +1103,7 @@ template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ rv, const uint32_t* __restrict__ tab, uint32_t S, uint32_t M,
                                                      const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                      fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib,
-                                                     LfView lfv, uint32_t tab_lds, const uint4* __restrict__ lut, uint32_t lutL) {
+                                                     LfView lfv, uint32_t tab_lds, const uint4* __restrict__ lut, uint32_t lutL, int use_key, int sharing) {
     extern __shared__ uint32_t s_query[];
     const QStage qst{s_query, qwords, qnib};
     __shared__ uint32_t s_hb[kWaveHitWords];
@@ -1128,7 +1128,46 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
     Cur cur{0, 0, 0};
     uint32_t e = 0, k = 0, sp = 0, resume = kNoResume, lastRank = 0, info = 0;     // info: LInfo | RInfo << 2 (0 M, 1 S, 2 I, 3 D)
     idx_t cached_lf = 0;                                            // a resumed one-row frame brings the LF value of its row along
+    // path keys and work sharing at the end of the batch, as in k_scheme_edit.  Every error child of a search_ng21 node follows its match child
+    // (2i - 1 deletion, 2i substitution, insertion last), so every component of the key is (2, 255 - depth, child index)
+    bool is_task = false;
+    uint32_t sbase = 0, mark = 0, ndel = 0;
+    uint64_t pkey = 0;
     for (;;) {
+        if (sharing) {
+            if (is_task && need_search) { is_task = false; idle = true; }
+            const bool offer = !idle && !need_search && sp > sbase && nodes - mark >= kShareNodes;
+            const uint64_t idlem = __ballot(idle), offerm = __ballot(offer);
+            if (idlem && offerm) {
+                const uint64_t below = (1ull << lane) - 1ull;
+                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
+                const bool give = offer && (uint32_t)__popcll(offerm & below) < pairs;
+                const bool take = idle && (uint32_t)__popcll(idlem & below) < pairs;
+                idx_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; uint32_t ga = 0, gb = 0, gc = 0, gd = 0; uint64_t gk = 0;
+                if (give) {
+                    edit_frame_get(edit_frame(stk, gid, sbase), g0, g1, g2, g3, ga, gb, gc, gd);
+                    gk = ekey_prefix(pkey, gc & 255u);
+                    ++sbase; mark = nodes;
+                }
+                uint64_t om = offerm;
+                for (uint32_t t = take ? (uint32_t)__popcll(idlem & below) : 0u; t > 0; --t) om &= om - 1ull;
+                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const uint64_t t0 = __shfl((uint64_t)g0, vl, 64), t1 = __shfl((uint64_t)g1, vl, 64), t2 = __shfl((uint64_t)g2, vl, 64), t3 = __shfl((uint64_t)g3, vl, 64);
+                const uint32_t ta = __shfl(ga, vl, 64), tb = __shfl(gb, vl, 64), tc = __shfl(gc, vl, 64), td = __shfl(gd, vl, 64);
+                const uint64_t tk = __shfl(gk, vl, 64), tq = __shfl(q, vl, 64), tqs = __shfl((uint64_t)qs, vl, 64);
+                const uint32_t tsi = __shfl(si, vl, 64);
+                if (take) {
+                    q = tq; qs = reinterpret_cast<const uint8_t*>(tqs); si = tsi; T = tab + (size_t)si * M;
+                    cur = Cur{(idx_t)t0, (idx_t)t1, (idx_t)t2}; cached_lf = (idx_t)t3; k = ta; resume = tb;
+                    e = tc & 255u; info = (tc >> 8) & 15u; lastRank = (tc >> 16) & 255u; ndel = td;
+                    pkey = tk;
+                    const uint32_t vt = (threadIdx.x & ~63u) | (uint32_t)vl;
+                    for (uint32_t w = 0; w < qwords; ++w) s_query[w * 256u + threadIdx.x] = s_query[w * 256u + vt];
+                    idle = false; is_task = true; need_search = false; have_query = true; fresh = false;
+                    quota = max_hits; seq = 0; sp = 0; sbase = 0; mark = nodes;
+                }
+            }
+        }
         const bool want_q = !idle && need_search && !(have_query && si + 1 < S && quota != 0);   // search_reordered, :168-181: the next search unless the delegate said stop
         const uint64_t got = wave_hand_out(want_q, ctr, lane);
         if (want_q) {
@@ -1152,6 +1191,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
             T = tab + (size_t)si * M;
             cur = Cur{0, 0, n};                                    // run(): :43-48
             e = 0; k = 0; sp = 0; resume = kNoResume; lastRank = 0; info = 0;
+            sbase = 0; mark = nodes; ndel = 0; pkey = ((uint64_t)si << 48) | kEditKeyNone;
             need_search = false;
             if (lut && (T[0] >> 31)) {                              // the first lutL steps are exact, rightwards and adjacent: start from the prefix table
                 const uint32_t p0 = T[0] & 0xffffu;
@@ -1181,7 +1221,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
         bool mOK = Lk <= e && e <= Uk && (TI != 3u || c != lastRank);                                        // :105-107
         if (mOK && TI == 2u) mOK = c != qstage_get(qst, qs, T[k - 1u] & 0xffffu);                           // (TI = I only after a step)
         const bool xOK = Lk <= e + 1u && e + 1u <= Uk;                                                      // :108
-        uint32_t kind = 4u, take = c, nxt = kNoResume;          // kind: 0 match, 1 substitution, 2 deletion, 3 insertion, 4 nothing left
+        uint32_t kind = 4u, take = c, nxt = kNoResume, code = 0; // kind: 0 match, 1 substitution, 2 deletion, 3 insertion, 4 nothing left; code: the child's number
         idx_t lfa[MAXSIG], lfb[MAXSIG];
         const bool via_lf = lfv.fw != nullptr && cur.len == 1;      // one row: its only child comes from the LF table (one 4-byte load)
         idx_t lf1 = cached_lf;
@@ -1219,11 +1259,12 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
                     else if (idx == INS) kind = 3u;
                     else { kind = (idx & 1u) ? 2u : 1u; take = (idx + 1u) >> 1; }
                     if (idx != INS) nxt = child_from(idx + 1u);
+                    code = idx;
                 }
             }
         }
         if (kind != 4u && nxt != kNoResume) {                       // keep the parent: its remaining children start at nxt
-            edit_frame_put(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, cur.len, lf1, k, nxt, e | (info << 8) | (lastRank << 16), 0u);
+            edit_frame_put(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, cur.len, lf1, k, nxt, e | (info << 8) | (lastRank << 16), ndel);
             ++sp;
         }
         resume = kNoResume;
@@ -1236,7 +1277,9 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
             const uint32_t imask = ~(3u << (2u * d));
             if (kind == 0u) { info = info & imask; lastRank = c; }
             else {
+                if (use_key) pkey = ekey_with(pkey, e, false, k + ndel, code);
                 e += 1u;
+                if (kind == 2u) ++ndel;
                 info = (info & imask) | ((kind == 1u ? 1u : (kind == 2u ? 3u : 2u)) << (2u * d));
                 if (kind != 3u) lastRank = take;
             }
@@ -1247,18 +1290,20 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
                     Cur r = cur;
                     if ((uint64_t)r.len > quota) r.len = (idx_t)quota;       // search_n, :229-235
                     quota -= r.len;
-                    wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
+                    if (use_key) { wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e | ((uint32_t)(pkey >> 32) << 8), (uint32_t)pkey); ++seq; }
+                    else wave_keep_hit(s_hb, nh, out, cap, ctr, q, r, e, seq++);
                     if (quota == 0) { need_search = true; continue; }
                 }
                 back = true;
             }
         }
         if (back) {
-            if (sp == 0) { need_search = true; continue; }
+            if (sp == sbase) { need_search = true; continue; }
             --sp;
-            uint32_t fc_ = 0, fd_ = 0;
-            edit_frame_get(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, cur.len, cached_lf, k, resume, fc_, fd_);
+            uint32_t fc_ = 0;
+            edit_frame_get(edit_frame(stk, gid, sp), cur.lb, cur.lbRev, cur.len, cached_lf, k, resume, fc_, ndel);
             e = fc_ & 255u; info = (fc_ >> 8) & 15u; lastRank = (fc_ >> 16) & 255u;
+            pkey = ekey_prefix(pkey, e);
         }
     }
     uint32_t tot = wave_sum(nodes);
@@ -3052,6 +3097,11 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
         });
         std::lock_guard<std::mutex> g(occ_mu); occ_cache[occ_key] = bpc;
     }
+    // path keys (<= 3 errors, depth and child index within their bit fields) order the hits of a read; with them and no limit on the hits per read the
+    // lanes that find the query queue empty take subtrees from the busy lanes of their wave
+    const char* dfl = getenv("FMGPU_DEV_FLAGS");
+    const int use_key = S <= 16 && max_u <= 3 && M + max_u <= 250 && x->bwt.sigma <= 32 ? 1 : 0;
+    const int sharing = use_key && max_hits_per_query == ~0ull && !(dfl && (atoi(dfl) & (1 << 24))) ? 1 : 0;
     DfsWorkspace ws;
     if ((rc = ws.init((uint32_t)M + max_u + 2, nq, bpc, stream, kEditFramePlanes))) return rc;       // deletions lengthen the path beyond the query by at most the largest upper bound
     uint32_t* d_tab = nullptr;
@@ -3068,7 +3118,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
         else if constexpr (std::is_same_v<O, OccM>) r = O{rv.vm};
         else r = O{rv.vr};
         k_ng21<O, decltype(ms)::value><<<dim3(ws.grid), dim3(256), lds_bytes, stream>>>(occ, r, d_tab, S, (uint32_t)M, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                                   nq, n, max_hits_per_query, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, tab_lds, x->lut, x->lut_len);
+                                                                                   nq, n, max_hits_per_query, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, tab_lds, x->lut, x->lut_len, use_key, sharing);
         return 0;
     });
     timer.stop();

@@ -677,6 +677,20 @@ def test_edit_distance_on_a_repeat_structured_text():
         del os.environ["FMGPU_DEV_FLAGS"]
     assert same_hits(hits2, ohits) and st2.lf_steps == nodes
     assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=3, edit=True), ox.search_ng26(qbuf, qoff, sch, max_hits=3, edit=True)[0])
+    # the general kernels (ragged batches, other layouts, 64-bit rows) share work at the end of the batch, with the same keys; search_ng21 too
+    hh, _, hnodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 24)
+    os.environ["FMGPU_DEV_FLAGS"] = "2"
+    try:
+        hits3, st3 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 24)
+        hits4, st4 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
+    finally:
+        del os.environ["FMGPU_DEV_FLAGS"]
+    assert same_hits(hits3, ohits) and st3.lf_steps == nodes
+    assert same_hits(hits4, hh) and st4.lf_steps == hnodes
+    ex = fm.search_scheme.expand(sch, L)
+    h21, st21 = fm.search_ng21.search(gx, (qbuf, qoff), ex, want_stats=True, capacity=1 << 24)
+    o21, _, n21 = ox.search_ng21(qbuf, qoff, ex, cap=1 << 24)
+    assert same_hits(h21, o21) and st21.lf_steps == n21
 
 
 @pytest.mark.parametrize("layout,sigma,tables", [("IB16", 5, False), ("IB16", 5, True), ("WAVELET", 28, False), ("EPR16", 5, False), ("IB16", 256, False)])
