@@ -115,8 +115,9 @@ typedef struct fmgpu_index* fmgpu_index_t;
 
 /* one reported cursor: search/SearchNg26.h:398-403 delegate(qidx, cursor, errors).  Order: the search kernels emit records in no particular
  * order; inside a read, ascending (errors >> 8, seq) is the reference's callback order — `seq` is either the position of the report within its
- * read, or (table-driven k-mismatch kernel, which lets idle lanes take over subtrees of a large read) the low 32 bits of a path key whose
- * upper bits sit in errors[8..31].  fmgpu_hits_sort orders the records and leaves seq = the dense callback position, errors = the error count. */
+ * read, or (search_ng26 with <= 2 substitutions / <= 3 edit errors and search_ng21, where idle lanes take over subtrees of a large read) the
+ * low 32 bits of a path key whose upper bits sit in errors[8..31].  fmgpu_hits_sort orders the records and leaves seq = the dense callback
+ * position, errors = the error count; a caller that reads raw records takes the error count from errors & 0xff. */
 typedef struct fmgpu_hit {
     uint64_t qidx, lb, lb_rev, len;
     uint32_t errors, seq;
@@ -231,7 +232,7 @@ int fmgpu_cursor_extend(fmgpu_index_t h, int32_t direction, uint64_t count, cons
 
 /* search_ng26::search<Edit=false>(index, queries, scheme, partition, delegate, n) (search/SearchNg26.h:426-433);
  * BiFMIndex only.  max_hits_per_query = n (UINT64_MAX = unlimited).  Records are appended in no particular order across
- * queries; (qidx, seq) restores the reference's callback order.  *out_count = records produced (also when > capacity). */
+ * queries; fmgpu_hits_sort restores the reference's callback order (see fmgpu_hit).  *out_count = records produced (also when > capacity). */
 int fmgpu_search_scheme(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                         const fmgpu_scheme* scheme, uint64_t max_hits_per_query,
                         fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, void* stream);
