@@ -580,6 +580,11 @@ def run_dna_text(c, name, primary):
             out.append(k2_run(w, L, n_, "plain", build_plain))
         t0 = time.time()
         index.accelerate_lf(True)
+        if c.multi and args.prefix_len >= 16 and max(n_ for _, _, n_ in k2_legs) > 12_500_000:
+            # fewer than 8 ranks: a rank's share of the 100 M reads grows (2 ranks: 50 M reads, ~2 x 10^8 hit records in double-buffered raw, packed and
+            # gathered form: ~50 GB beside 232 GB of index and reads) — the 15-symbol prefix table (17 GB instead of 69) keeps it well inside 288 GB
+            print("bench.py: %d reads per rank: using a 15-symbol prefix table" % max(n_ for _, _, n_ in k2_legs), file=sys.stderr, flush=True)
+            args.prefix_len = 15
         if args.prefix_len >= 16:                              # the 16-symbol prefix table is 69 GB: keep room for the walk tables (99 GB) and this run's hit buffers
             free_b, _ = torch.cuda.mem_get_info()
             if free_b < (69 + 99 + 24) * (1 << 30):
