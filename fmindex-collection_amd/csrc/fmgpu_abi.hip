@@ -70,7 +70,7 @@ bool want_wide(uint64_t n) {
 // tables) leaves nothing half-initialised behind, and the next call simply tries again.  Keyed by device: a host thread that alternates
 // between handles on two devices re-uses both sets.  FMGPU_FAIL_SCRATCH=k (test knob) fails the k-th allocation of the next creation.
 void CallScratch::drop() {
-    for (void* p : {(void*)ctr, (void*)sink, (void*)len2, frames, dfs_ctr}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)ctr, (void*)sink, (void*)len2, frames, dfs_ctr, order}) if (p) (void)hipFree(p);
     if (pinned) (void)hipHostFree(pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
@@ -78,7 +78,7 @@ void CallScratch::drop() {
 }
 struct ScratchSet {
     std::map<int, CallScratch> by_dev;
-    ~ScratchSet() { for (auto& kv : by_dev) if (kv.second.frames) (void)hipFree(kv.second.frames); }   // a host thread that ends returns its frame stacks
+    ~ScratchSet() { for (auto& kv : by_dev) for (void* p : {kv.second.frames, kv.second.order}) if (p) (void)hipFree(p); }   // a host thread that ends returns its large buffers
 };
 int call_scratch(CallScratch** out) {
     static thread_local ScratchSet set;

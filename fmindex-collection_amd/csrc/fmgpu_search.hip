@@ -2565,6 +2565,55 @@ static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, uin
 }
 
 // (length, query number) pairs for the length buckets of a ragged batch
+// Heavy reads first.  The reads of a batch are handed out in order, and the few that sit in high-copy repeats visit 10^3 times the nodes of the median
+// read: those that start last keep a handful of waves busy long after the others have drained (measured on the genome-like text: 90 % of the
+// waves are done at 89 ms of 105).  The prefix table tells which reads these are before the search starts — the interval of the first 16
+// symbols of the first search IS the copy number — so the batch is handed out with them in front (a stable partition of the read numbers).
+struct LutPositions { uint32_t pos[16]; };
+__global__ __launch_bounds__(256) void k_heavy_flags(const uint4* __restrict__ lut, uint32_t lutL, uint32_t R, LutPositions lp, const uint8_t* __restrict__ qbuf,
+                                                     const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t sigma, uint32_t threshold, uint8_t* __restrict__ flags,
+                                                     uint32_t* __restrict__ count) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool heavy = false;
+    if (q < nq) {
+        const uint8_t* s = qbuf + qoff[q];
+        uint32_t code = 0, mul = 1; bool valid = true;
+        for (uint32_t t = 0; t < lutL; ++t) {
+            const uint32_t c = s[lp.pos[t]];
+            valid = valid && c >= 1 && c < sigma;
+            code += (c - 1) * mul; mul *= R;
+        }
+        heavy = valid && lut[code].z > threshold;
+        flags[q] = heavy ? 1 : 0;
+    }
+    const uint64_t m = __ballot(heavy);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
+}
+// the same question without tables: the interval of the read's last 16 symbols by backward search on the blocks (16 of the ~500 nodes a read visits)
+template <int SIGMA>
+__global__ __launch_bounds__(256) void k_heavy_flags_plain(OccA<SIGMA> occ, idx_t n, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t m,
+                                                           uint32_t threshold, uint8_t* __restrict__ flags, uint32_t* __restrict__ count) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool heavy = false;
+    if (q < nq) {
+        const uint8_t* s = qbuf + qoff[q];
+        idx_t lb = 0, len = n;
+        const uint32_t sigma = occ.sigma();
+        for (uint32_t t = 0; t < 16u && len != 0; ++t) {
+            const uint32_t c = s[m - 1u - t];
+            if (c < 1 || c >= sigma) { len = 0; break; }
+            idx_t ra, rb;
+            occ.lf2(lb, lb + len, c, ra, rb);
+            lb = ra; len = rb - ra;
+        }
+        heavy = len > threshold;
+        flags[q] = heavy ? 1 : 0;
+    }
+    const uint64_t mk = __ballot(heavy);
+    if ((threadIdx.x & 63u) == 0 && mk) atomicAdd(count, (uint32_t)__popcll(mk));
+}
+constexpr uint32_t kHeavyInterval = 8;                            // rows of the 16-symbol interval above which a read counts as one of a high-copy repeat
+
 __global__ __launch_bounds__(256) void k_len_pairs(const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t* __restrict__ len, uint32_t* __restrict__ idx) {
     uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q < nq) { len[q] = (uint32_t)(qoff[q + 1] - qoff[q]); idx[q] = (uint32_t)q; }
@@ -2827,6 +2876,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     const idx_t n = (idx_t)x->bwt.n;
     const dim3 block(256);
     uint32_t* d_qmap = nullptr;
+    bool qmap_owned = true;                                        // (the heavy-first order lives in the thread's call scratch)
     uint32_t* d_steps = nullptr;
     bool fast = false;
 #if !FMGPU_WIDE
@@ -2844,6 +2894,46 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         Bucket b{maxlen, 0, nq, {}, 0};
         fast = build_step_table(sd, maxlen, lutL, use_wj ? 16u : 0u, b.tab, b.lut_ok);
         if (fast) buckets.push_back(std::move(b));
+        const char* hf = getenv("FMGPU_HEAVY_FIRST");
+        const bool by_lut = x->lut && lutL >= 8 && lutL <= 16 && (buckets[0].lut_ok & 1u);
+        const bool by_blocks = !have_lf && x->bwt.sigma == 5 && maxlen >= 16;     // (the plain-index instantiation)
+        if (fast && (by_lut || by_blocks) && nq >= (1u << 16) && nq < 0x7fffffffull && !(hf && atoi(hf) == 0)) {
+            // hand the reads of high-copy repeats out first (k_heavy_flags).  A sample of the batch decides whether it is worth a pass over all of it
+            // (a text without repeats: nothing to reorder, and the pass would cost 5 % of a 7 ms batch); the buffers live in the thread's call scratch
+            LutPositions lp{};
+            if (by_lut) for (uint32_t t = 0; t < lutL; ++t) lp.pos[t] = buckets[0].tab[t] & 0xffffu;
+            CallScratch* sc = nullptr;
+            if ((rc = call_scratch(&sc))) return rc;
+            size_t tb = 0;
+            (void)hipcub::DevicePartition::Flagged(nullptr, tb, hipcub::CountingInputIterator<uint32_t>(0u), (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)nq, stream);
+            const size_t off_flags = (nq * 4 + 255) / 256 * 256, off_cnt = off_flags + (nq + 255) / 256 * 256, off_tmp = off_cnt + 256;
+            const size_t need = off_tmp + std::max<size_t>(tb, 16);
+            if (sc->order_bytes < need) {
+                if (sc->order) { (void)hipFree(sc->order); sc->order = nullptr; sc->order_bytes = 0; }
+                FM_HIP(hipMalloc(&sc->order, need));
+                sc->order_bytes = need;
+            }
+            uint8_t* base = (uint8_t*)sc->order;
+            uint32_t* order = (uint32_t*)base; uint8_t* flags = base + off_flags; uint32_t* cnt = (uint32_t*)(base + off_cnt);
+            auto flag_pass = [&](uint64_t count_reads) {
+                const dim3 g((unsigned)((count_reads + 255) / 256));
+                if (by_lut) k_heavy_flags<<<g, 256, 0, stream>>>(x->lut, lutL, (uint32_t)x->bwt.sigma - 1u, lp, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads,
+                                                                 (uint32_t)x->bwt.sigma, kHeavyInterval, flags, cnt);
+                else k_heavy_flags_plain<5><<<g, 256, 0, stream>>>(OccA<5>{x->bwt.va}, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads, maxlen, kHeavyInterval, flags, cnt);
+            };
+            const uint64_t ns = std::min<uint64_t>(nq, 1u << 16);
+            FM_HIP(hipMemsetAsync(cnt, 0, 8, stream));
+            flag_pass(ns);
+            FM_LAUNCHED("k_heavy_flags");
+            uint32_t heavy = 0;
+            FM_HIP(hipMemcpyAsync(&heavy, cnt, 4, hipMemcpyDeviceToHost, stream));
+            FM_HIP(hipStreamSynchronize(stream));
+            if ((uint64_t)heavy * 2000u >= ns) {                    // >= 0.05 % of the sample
+                if (nq > ns) { flag_pass(nq); FM_LAUNCHED("k_heavy_flags"); }
+                FM_HIP(hipcub::DevicePartition::Flagged(base + off_tmp, tb, hipcub::CountingInputIterator<uint32_t>(0u), flags, order, cnt + 1, (int)nq, stream));
+                d_qmap = order; qmap_owned = false;
+            }
+        }
     } else if (fast_ok && nq >= (1u << 16) && nq < 0x7fffffffull && !(sd.dev_flags & 64)) {
         uint32_t *klen = nullptr, *kidx = nullptr, *slen = nullptr, *runs = nullptr;
         void* tmp = nullptr; size_t tmp_bytes = 0, tmp2 = 0;
@@ -2859,7 +2949,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp2, slen, runs, runs + max_runs, runs + 2 * max_runs, (int)nq, stream);
             he = hipMalloc(&tmp, std::max(tmp_bytes, tmp2));
         }
-        if (he != hipSuccess) { drop(); if (d_qmap) (void)hipFree(d_qmap); return hip_fail(he, "hipMalloc(length buckets)"); }
+        if (he != hipSuccess) { drop(); if (d_qmap && qmap_owned) (void)hipFree(d_qmap); return hip_fail(he, "hipMalloc(length buckets)"); }
         k_len_pairs<<<dim3((unsigned)((nq + 255) / 256)), 256, 0, stream>>>((const uint64_t*)soff.dev, nq, klen, kidx);
         size_t tb = std::max(tmp_bytes, tmp2);
         he = hipcub::DeviceRadixSort::SortPairs(tmp, tb, klen, slen, kidx, d_qmap, (int)nq, 0, 16, stream);
@@ -2905,14 +2995,14 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
 #endif  // !FMGPU_WIDE
     { const char* ev = getenv("FMGPU_DEV_BPC"); if (ev && atoi(ev) > 0) bpc = atoi(ev); }   // dev knob: resident blocks per CU the grid is sized for
     // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
-    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3))) { if (d_qmap) (void)hipFree(d_qmap); return rc; }
+    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3))) { if (d_qmap && qmap_owned) (void)hipFree(d_qmap); return rc; }
     const dim3 grid(ws.grid);
 #if !FMGPU_WIDE
     size_t steps_words = 0;
     if (fast) {
         for (const Bucket& b : buckets) steps_words += b.tab.size();
         hipError_t he = hipMalloc((void**)&d_steps, std::max<size_t>(steps_words, 1) * 4);
-        if (he != hipSuccess) { if (d_qmap) (void)hipFree(d_qmap); return hip_fail(he, "hipMalloc(step tables)"); }
+        if (he != hipSuccess) { if (d_qmap && qmap_owned) (void)hipFree(d_qmap); return hip_fail(he, "hipMalloc(step tables)"); }
         size_t at = 0;
         for (const Bucket& b : buckets) { (void)hipMemcpyAsync(d_steps + at, b.tab.data(), b.tab.size() * 4, hipMemcpyHostToDevice, stream); at += b.tab.size(); }
     }
@@ -2999,7 +3089,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (le == hipSuccess) le = hipMemcpyAsync(&hc, ws.ctr, sizeof hc, hipMemcpyDeviceToHost, stream);
     if (le == hipSuccess) le = hipStreamSynchronize(stream);
     if (d_steps) (void)hipFree(d_steps);
-    if (d_qmap) (void)hipFree(d_qmap);
+    if (d_qmap && qmap_owned) (void)hipFree(d_qmap);
     if (le != hipSuccess) return hip_fail(le, "search kernel");
     *out_count = hc.hits;
     if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); stats->table_bytes = hc.table_bytes; stats->table_accesses = hc.table_accesses; }
