@@ -1455,6 +1455,19 @@ def test_full_size_k2_records_equal_the_cpu_walk():
         check("general kernel")
     finally:
         del os.environ["FMGPU_DEV_FLAGS"]
+    # edit distance at full size (20 k reads, single-threaded CPU walk): the table-driven kernel with its path keys, work sharing and the
+    # heavy-reads-first hand-out order (the batch is below its 64 k threshold: FMGPU_DEV_FLAGS keeps the order on for a repeated batch)
+    hq, ho = batches[101]
+    eq, eo = hq[: 20_000 * 101], ho[: 20_001]
+    oe, _, enodes = ox.search_ng26(eq, eo, sch, edit=True, cap=1 << 22)
+    ehits, est = fm.search_ng26.search(gx, (eq, eo), sch, want_stats=True, edit=True, capacity=1 << 22)
+    assert est.lf_steps == enodes and same_hits(ehits, oe)
+    rep = 4                                                    # 80 k reads: the sampled, reordered hand-out
+    rq = np.tile(eq, rep); ro = (np.arange(20_000 * rep + 1, dtype=np.uint64) * 101)
+    rhits, rst = fm.search_ng26.search(gx, (rq, ro), sch, want_stats=True, edit=True, capacity=1 << 24)
+    assert rst.lf_steps == rep * enodes and len(rhits) == rep * len(oe)
+    first = rhits[rhits["qidx"] < 20_000]
+    assert same_hits(first, oe)
 
 
 def test_gpu_builder_on_a_repeat_structured_text():
