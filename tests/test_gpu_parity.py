@@ -391,6 +391,50 @@ def test_scheme_search_equal_length_fast_path(k, length):
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, fm.search_scheme.h2(k + 2, 0, k))[0])
 
 
+@pytest.mark.parametrize("mix", ["all_heavy", "none_heavy", "some_heavy"])
+def test_heavy_reads_first_hand_out_order(mix):
+    """batches of 2^16 reads and more are handed out with the reads of high-copy repeats in front (k_heavy_flags / k_heavy_flags_plain, decided on a
+    sample): records, order and node counts are those of the CPU walk whatever the mix — with the prefix table, on the plain index, with the
+    order switched off, for Hamming and edit distance"""
+    rng = np.random.default_rng(5)
+    unit = rng.integers(1, 5, size=300, dtype=np.uint8)
+    rep = np.concatenate([np.concatenate([unit, rng.integers(1, 5, size=7, dtype=np.uint8)]) for _ in range(12)])      # 12 copies: intervals of 12 rows
+    uniq = rng.integers(1, 5, size=30000, dtype=np.uint8)
+    seqs = [rep, uniq]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 8, True)
+    L, nq = 40, 70_000
+    src = {"all_heavy": [0], "none_heavy": [1], "some_heavy": [1] * 19 + [0]}[mix]
+    reads = np.empty((nq, L), dtype=np.uint8)
+    for i in range(nq):
+        sq = seqs[src[i % len(src)]]
+        p = int(rng.integers(0, len(sq) - L))
+        reads[i] = sq[p: p + L]
+    flip = rng.integers(0, nq, size=nq // 3)
+    reads[flip, rng.integers(0, L, size=flip.size)] = rng.integers(1, 5, size=flip.size)
+    qbuf, qoff = reads.reshape(-1), np.arange(nq + 1, dtype=np.uint64) * L
+    sch = fm.search_scheme.h2(3, 0, 1)
+    want, _, wnodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 23)
+    os.environ["FMGPU_LF_TABLE"] = "0"
+    try:
+        gx = gpu_index(ox)                                    # plain index: the sample and the flags come from 16 LF steps on the blocks
+    finally:
+        del os.environ["FMGPU_LF_TABLE"]
+    hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 23)
+    assert same_hits(hits, want) and st.lf_steps == wnodes
+    gx.accelerate_lf(True); gx.accelerate_search(8, 1)        # ... from the 8-symbol prefix table
+    hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 23)
+    assert same_hits(hits, want) and st.lf_steps == wnodes
+    ewant, _, enodes = ox.search_ng26(qbuf[: 66_000 * L], qoff[: 66_001], sch, edit=True, cap=1 << 23)
+    ehits, est = fm.search_ng26.search(gx, (qbuf[: 66_000 * L], qoff[: 66_001]), sch, want_stats=True, edit=True, capacity=1 << 23)
+    assert same_hits(ehits, ewant) and est.lf_steps == enodes
+    os.environ["FMGPU_HEAVY_FIRST"] = "0"
+    try:
+        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 23)
+    finally:
+        del os.environ["FMGPU_HEAVY_FIRST"]
+    assert same_hits(hits, want) and st.lf_steps == wnodes
+
+
 def test_scheme_search_ragged_batch_in_length_buckets():
     """a large ragged batch is sorted by length on the device and runs the table-driven kernel once per length: same records, order and
     node count as the CPU walk and as the general kernel; queries shorter than the number of parts are skipped in both"""
