@@ -2993,6 +2993,11 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         }
     }
 #endif  // !FMGPU_WIDE
+#if !FMGPU_WIDE
+    // the plain-index instantiation runs best with 4 resident blocks per CU (measured on the genome-like text, 10 M x 101 bp: 2 / 3 / 4 / 5 blocks =
+    // 197 / 159 / 150 / 159 ms): a fifth block adds issue contention and cache pressure, not throughput
+    if (fast && !edit && !have_lf) bpc = std::min(bpc, 4);
+#endif
     { const char* ev = getenv("FMGPU_DEV_BPC"); if (ev && atoi(ev) > 0) bpc = atoi(ev); }   // dev knob: resident blocks per CU the grid is sized for
     // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
     if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3))) { if (d_qmap && qmap_owned) (void)hipFree(d_qmap); return rc; }
