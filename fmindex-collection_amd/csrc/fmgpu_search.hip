@@ -2666,6 +2666,8 @@ int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream);
 
 static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                         uint64_t* out_lb, uint64_t* out_len, bool packed, fmgpu_stats* stats, void* stream_) {
+    size_t dev_extra_lds = 0;                                      // dev knob: unused dynamic LDS per block, to limit the resident blocks per CU
+    { const char* ev = getenv("FMGPU_DEV_EXACT_LDS"); if (ev) dev_extra_lds = (size_t)atoi(ev); }
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
     if (int drc = on_handle_device(x)) return drc;
@@ -2707,7 +2709,7 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         const DevString& bs = x->bwt;
         ExactAccel ac{bs.kblk, bs.kstep, bs.kcodes, bs.slut, bs.slut_len, bs.walkj, bs.walk_J, bs.walk_bits, bs.walk2j};
         rc = dispatch_occ(bs, [&](auto occ, auto) {
-            k_exact_kstep<decltype(occ)><<<grid, block, (size_t)kq_words * 1024, stream>>>(occ, ac, (uint32_t)bs.sigma - 1,
+            k_exact_kstep<decltype(occ)><<<grid, block, (size_t)kq_words * 1024 + dev_extra_lds, stream>>>(occ, ac, (uint32_t)bs.sigma - 1,
                                                                     (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev,
                                                                     (uint64_t*)slen.dev, dsteps, kq_words, kq_nib, kq_max);
             return 0;
@@ -2716,8 +2718,11 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
 #endif
     if (x->bwt.search_family() == FAM_A) {
         auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
-        if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, 0, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
-        else k_exact_a<0><<<grid, block, 0, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
+        // k_exact_a runs best with 5 resident blocks per CU, not the 8 its 28 registers allow (measured on the 3.09 Gbp index, 10 M x 101 bp: 8 / 6 / 5 / 4 / 3
+        // blocks = 19.53 / 19.23 / 18.92 / 19.10 / 18.95 ms — more waves only queue up at the memory system): 28 KB of unused dynamic LDS set the residency
+        const size_t lds_a = getenv("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)28 * 1024;
+        if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
+        else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
     } else if (x->bwt.search_family() == FAM_WAVELET) {
         uint32_t mx = shape_max, mn = 0;
         if (!have_shape && (rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) return rc;
@@ -2728,14 +2733,14 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
         const size_t lds = (size_t)qw * 1024;
         switch (vm.bitct) {                                      // the digits of digits_of() as template arguments
-        case 1: k_exact_m<1, 0, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 2: k_exact_m<2, 0, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 3: k_exact_m<3, 0, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 4: k_exact_m<2, 2, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 5: k_exact_m<3, 2, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 6: k_exact_m<3, 3, 0><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 7: k_exact_m<3, 2, 2><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        default: k_exact_m<3, 3, 2><<<grid, block, lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 1: k_exact_m<1, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 2: k_exact_m<2, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 3: k_exact_m<3, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 4: k_exact_m<2, 2, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 5: k_exact_m<3, 2, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 6: k_exact_m<3, 3, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 7: k_exact_m<3, 2, 2><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        default: k_exact_m<3, 3, 2><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
         }
     } else {
         rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
