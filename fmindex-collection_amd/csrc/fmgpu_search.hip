@@ -3241,6 +3241,10 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
 
 int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps,
                  fmgpu_stats* stats, void* stream_) {
+    // k_locate runs best with 4 resident blocks per CU (9 M rows of the 3.09 Gbp index: 8 / 5 / 4 / 3 blocks = 4.73 / 4.20 / 3.99 / 4.03 ms — its lanes
+    // leave after 0 .. 15 LF steps and more waves only queue up at the memory system): 36 KB of unused dynamic LDS set the residency
+    size_t locate_lds = (size_t)36 * 1024;
+    { const char* ev = getenv("FMGPU_DEV_LOCATE_LDS"); if (ev) locate_lds = (size_t)atoi(ev); }
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
     if (int drc = on_handle_device(x)) return drc;
@@ -3268,7 +3272,7 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
     else
 #endif
     rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
-        k_locate<decltype(occ)><<<grid, block, 0, stream>>>(occ, x->bwt.lf_table, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev,
+        k_locate<decltype(occ)><<<grid, block, locate_lds, stream>>>(occ, x->bwt.lf_table, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev,
                                                            (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
         return 0;
     });
