@@ -509,7 +509,8 @@ template <class Occ, int MAXSIG>
 // (5 resident blocks — 4 with 64-bit rows — is what the LDS of a 101-symbol batch allows anyway; 6 spilled 45 registers once the sharing state came in)
 __global__ __launch_bounds__(256, MAXSIG <= 5 ? (kWide ? 4 : 5) : 1) void k_scheme(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
                                                 const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
-                                                fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv) {
+                                                fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv,
+                                                const uint32_t* __restrict__ order) {   // order (or null): the batch is handed out in this order (heavy reads first)
     extern __shared__ uint32_t s_query[];
     const QStage qst{s_query, qwords, qnib};
     __shared__ uint8_t s_pi[kMaxSearches * kMaxParts], s_l[kMaxSearches * kMaxParts], s_u[kMaxSearches * kMaxParts];
@@ -624,6 +625,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? (kWide ? 4 : 5) : 1) void k_sche
             have_query = false;
             if (q >= nq) idle = true;
             else {
+                if (order) q = order[q];
                 const uint64_t qo = qoff[q];
                 m = (uint32_t)(qoff[q + 1] - qo);
                 qs = qbuf + qo;
@@ -801,7 +803,8 @@ constexpr int kEditWaves = 4;         // waves per SIMD the register allocation 
 template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_edit(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
                                                      const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
-                                                     fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv, uint32_t maxm, const uint4* __restrict__ lut, uint32_t lutL) {
+                                                     fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib, LfView lfv, uint32_t maxm, const uint4* __restrict__ lut, uint32_t lutL,
+                                                     const uint32_t* __restrict__ order) {
     extern __shared__ uint32_t s_query[];
     const QStage qst{s_query, qwords, qnib};
     __shared__ uint8_t s_pi[kMaxSearches * kMaxParts], s_l[kMaxSearches * kMaxParts], s_u[kMaxSearches * kMaxParts];
@@ -897,6 +900,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             have_query = false;
             if (q >= nq) idle = true;
             else {
+                if (order) q = order[q];
                 const uint64_t qo = qoff[q];
                 m = (uint32_t)(qoff[q + 1] - qo);
                 qs = qbuf + qo;
@@ -2590,17 +2594,19 @@ __global__ __launch_bounds__(256) void k_heavy_flags(const uint4* __restrict__ l
     if ((threadIdx.x & 63u) == 0 && m) atomicAdd(count, (uint32_t)__popcll(m));
 }
 // the same question without tables: the interval of the read's last 16 symbols by backward search on the blocks (16 of the ~500 nodes a read visits)
-template <int SIGMA>
-__global__ __launch_bounds__(256) void k_heavy_flags_plain(OccA<SIGMA> occ, idx_t n, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t m,
-                                                           uint32_t threshold, uint8_t* __restrict__ flags, uint32_t* __restrict__ count) {
+template <class Occ>
+__global__ __launch_bounds__(256) void k_heavy_flags_plain(Occ occ, idx_t n, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t m,
+                                                           uint32_t threshold, uint8_t* __restrict__ flags, uint32_t* __restrict__ count) {   // m = 0: every read has its own length
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool heavy = false;
     if (q < nq) {
-        const uint8_t* s = qbuf + qoff[q];
-        idx_t lb = 0, len = n;
+        const uint64_t o = qoff[q];
+        const uint32_t len_q = m ? m : (uint32_t)(qoff[q + 1] - o);
+        const uint8_t* s = qbuf + o;
+        idx_t lb = 0, len = len_q >= 16u ? n : (idx_t)0;
         const uint32_t sigma = occ.sigma();
         for (uint32_t t = 0; t < 16u && len != 0; ++t) {
-            const uint32_t c = s[m - 1u - t];
+            const uint32_t c = s[len_q - 1u - t];
             if (c < 1 || c >= sigma) { len = 0; break; }
             idx_t ra, rb;
             occ.lf2(lb, lb + len, c, ra, rb);
@@ -2657,6 +2663,39 @@ struct DfsWorkspace {
     }
     ~DfsWorkspace() { if (planes && own_planes) (void)hipFree(planes); }
 };
+
+// the hand-out order of a batch with the reads of high-copy repeats in front (see k_heavy_flags): flag_pass(count, flags, counter) launches the
+// flag kernel over the first `count` reads.  A 64 k sample decides whether the pass over the whole batch is worth it; *out_order stays null if not.
+// The buffers live in the calling thread's scratch (the order is valid until the thread's next search call).
+template <class FlagPass>
+static int heavy_first_order(uint64_t nq, hipStream_t stream, FlagPass&& flag_pass, uint32_t** out_order) {
+    *out_order = nullptr;
+    CallScratch* sc = nullptr;
+    int rc = call_scratch(&sc); if (rc) return rc;
+    size_t tb = 0;
+    (void)hipcub::DevicePartition::Flagged(nullptr, tb, hipcub::CountingInputIterator<uint32_t>(0u), (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)nq, stream);
+    const size_t off_flags = (nq * 4 + 255) / 256 * 256, off_cnt = off_flags + (nq + 255) / 256 * 256, off_tmp = off_cnt + 256;
+    const size_t need = off_tmp + std::max<size_t>(tb, 16);
+    if (sc->order_bytes < need) {
+        if (sc->order) { (void)hipFree(sc->order); sc->order = nullptr; sc->order_bytes = 0; }
+        FM_HIP(hipMalloc(&sc->order, need));
+        sc->order_bytes = need;
+    }
+    uint8_t* base = (uint8_t*)sc->order;
+    uint32_t* order = (uint32_t*)base; uint8_t* flags = base + off_flags; uint32_t* cnt = (uint32_t*)(base + off_cnt);
+    const uint64_t ns = std::min<uint64_t>(nq, 1u << 16);
+    FM_HIP(hipMemsetAsync(cnt, 0, 8, stream));
+    flag_pass(ns, flags, cnt);
+    FM_LAUNCHED("k_heavy_flags");
+    uint32_t heavy = 0;
+    FM_HIP(hipMemcpyAsync(&heavy, cnt, 4, hipMemcpyDeviceToHost, stream));
+    FM_HIP(hipStreamSynchronize(stream));
+    if ((uint64_t)heavy * 2000u < ns) return 0;                     // < 0.05 % of the sample: nothing worth moving
+    if (nq > ns) { flag_pass(nq, flags, cnt); FM_LAUNCHED("k_heavy_flags"); }
+    FM_HIP(hipcub::DevicePartition::Flagged(base + off_tmp, tb, hipcub::CountingInputIterator<uint32_t>(0u), flags, order, cnt + 1, (int)nq, stream));
+    *out_order = order;
+    return 0;
+}
 
 namespace api {
 #include "fmgpu_api_decl.h"
@@ -2903,41 +2942,18 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         const bool by_lut = x->lut && lutL >= 8 && lutL <= 16 && (buckets[0].lut_ok & 1u);
         const bool by_blocks = !have_lf && x->bwt.sigma == 5 && maxlen >= 16;     // (the plain-index instantiation)
         if (fast && (by_lut || by_blocks) && nq >= (1u << 16) && nq < 0x7fffffffull && !(hf && atoi(hf) == 0)) {
-            // hand the reads of high-copy repeats out first (k_heavy_flags).  A sample of the batch decides whether it is worth a pass over all of it
-            // (a text without repeats: nothing to reorder, and the pass would cost 5 % of a 7 ms batch); the buffers live in the thread's call scratch
+            // hand the reads of high-copy repeats out first (k_heavy_flags; decided on a sample of the batch — a text without repeats has nothing to
+            // reorder, and the pass would cost 5 % of a 7 ms batch)
             LutPositions lp{};
             if (by_lut) for (uint32_t t = 0; t < lutL; ++t) lp.pos[t] = buckets[0].tab[t] & 0xffffu;
-            CallScratch* sc = nullptr;
-            if ((rc = call_scratch(&sc))) return rc;
-            size_t tb = 0;
-            (void)hipcub::DevicePartition::Flagged(nullptr, tb, hipcub::CountingInputIterator<uint32_t>(0u), (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)nq, stream);
-            const size_t off_flags = (nq * 4 + 255) / 256 * 256, off_cnt = off_flags + (nq + 255) / 256 * 256, off_tmp = off_cnt + 256;
-            const size_t need = off_tmp + std::max<size_t>(tb, 16);
-            if (sc->order_bytes < need) {
-                if (sc->order) { (void)hipFree(sc->order); sc->order = nullptr; sc->order_bytes = 0; }
-                FM_HIP(hipMalloc(&sc->order, need));
-                sc->order_bytes = need;
-            }
-            uint8_t* base = (uint8_t*)sc->order;
-            uint32_t* order = (uint32_t*)base; uint8_t* flags = base + off_flags; uint32_t* cnt = (uint32_t*)(base + off_cnt);
-            auto flag_pass = [&](uint64_t count_reads) {
-                const dim3 g((unsigned)((count_reads + 255) / 256));
-                if (by_lut) k_heavy_flags<<<g, 256, 0, stream>>>(x->lut, lutL, (uint32_t)x->bwt.sigma - 1u, lp, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads,
-                                                                 (uint32_t)x->bwt.sigma, kHeavyInterval, flags, cnt);
-                else k_heavy_flags_plain<5><<<g, 256, 0, stream>>>(OccA<5>{x->bwt.va}, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads, maxlen, kHeavyInterval, flags, cnt);
-            };
-            const uint64_t ns = std::min<uint64_t>(nq, 1u << 16);
-            FM_HIP(hipMemsetAsync(cnt, 0, 8, stream));
-            flag_pass(ns);
-            FM_LAUNCHED("k_heavy_flags");
-            uint32_t heavy = 0;
-            FM_HIP(hipMemcpyAsync(&heavy, cnt, 4, hipMemcpyDeviceToHost, stream));
-            FM_HIP(hipStreamSynchronize(stream));
-            if ((uint64_t)heavy * 2000u >= ns) {                    // >= 0.05 % of the sample
-                if (nq > ns) { flag_pass(nq); FM_LAUNCHED("k_heavy_flags"); }
-                FM_HIP(hipcub::DevicePartition::Flagged(base + off_tmp, tb, hipcub::CountingInputIterator<uint32_t>(0u), flags, order, cnt + 1, (int)nq, stream));
-                d_qmap = order; qmap_owned = false;
-            }
+            uint32_t* order = nullptr;
+            if ((rc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
+                    const dim3 g((unsigned)((count_reads + 255) / 256));
+                    if (by_lut) k_heavy_flags<<<g, 256, 0, stream>>>(x->lut, lutL, (uint32_t)x->bwt.sigma - 1u, lp, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads,
+                                                                     (uint32_t)x->bwt.sigma, kHeavyInterval, flags, cnt);
+                    else k_heavy_flags_plain<OccA<5>><<<g, 256, 0, stream>>>(OccA<5>{x->bwt.va}, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads, maxlen, kHeavyInterval, flags, cnt);
+                }, &order))) return rc;
+            if (order) { d_qmap = order; qmap_owned = false; }
         }
     } else if (fast_ok && nq >= (1u << 16) && nq < 0x7fffffffull && !(sd.dev_flags & 64)) {
         uint32_t *klen = nullptr, *kidx = nullptr, *slen = nullptr, *runs = nullptr;
@@ -3065,6 +3081,22 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         // lanes that run out of queries at the end of the batch take subtrees from the busy lanes of their wave
         sd.use_key = sd.S > 16 ? 0 : (!edit ? (max_u <= 2 ? 1 : 0) : (max_u <= 3 && maxlen + max_u <= 250 && x->bwt.sigma <= 32 ? 1 : 0));
         sd.sharing = sd.use_key && max_hits == ~0ull && !(sd.dev_flags & (1 << 24)) ? 1 : 0;
+        // ... and the reads of high-copy repeats are handed out first here too (16 LF steps per read on whatever layout the index has)
+        uint32_t* gen_order = nullptr;
+        {
+            const char* hf = getenv("FMGPU_HEAVY_FIRST");
+            if (nq >= (1u << 16) && nq < 0x7fffffffull && minlen >= 1 && !(hf && atoi(hf) == 0)) {
+                int orc = 0;
+                rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
+                    orc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
+                        k_heavy_flags_plain<decltype(occ)><<<dim3((unsigned)((count_reads + 255) / 256)), 256, 0, stream>>>(occ, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                                                                         count_reads, 0u, kHeavyInterval, flags, cnt);
+                    }, &gen_order);
+                    return 0;
+                });
+                if (rc || orc) return rc ? rc : orc;
+            }
+        }
         const DevString& rv = x->rev;
         LfView lfv{nullptr, nullptr, nullptr};
         if (x->bwt.lf_table && rv.lf_table && !(sd.dev_flags & 16)) lfv = LfView{x->bwt.lf_table, rv.lf_table, x->dC};
@@ -3078,11 +3110,11 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             if (edit) {
                 k_scheme_edit<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
                                                                                   max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, maxlen,
-                                                                                  (sd.dev_flags & 4) ? nullptr : x->lut, x->lut_len);
+                                                                                  (sd.dev_flags & 4) ? nullptr : x->lut, x->lut_len, gen_order);
                 return 0;
             }
             k_scheme<O, decltype(ms)::value><<<grid, block, lds_bytes, stream>>>(occ, r, sd, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
-                                                                         max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv);
+                                                                         max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, gen_order);
             return 0;
         });
     } else {

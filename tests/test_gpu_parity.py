@@ -433,6 +433,27 @@ def test_heavy_reads_first_hand_out_order(mix):
     finally:
         del os.environ["FMGPU_HEAVY_FIRST"]
     assert same_hits(hits, want) and st.lf_steps == wnodes
+    os.environ["FMGPU_DEV_FLAGS"] = "2"                       # the general kernels order their hand-out too (16 LF steps per read on any layout)
+    try:
+        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 23)
+        ehits, est = fm.search_ng26.search(gx, (qbuf[: 66_000 * L], qoff[: 66_001]), sch, want_stats=True, edit=True, capacity=1 << 23)
+    finally:
+        del os.environ["FMGPU_DEV_FLAGS"]
+    assert same_hits(hits, want) and st.lf_steps == wnodes
+    assert same_hits(ehits, ewant) and est.lf_steps == enodes
+    if mix == "some_heavy":                                   # ragged lengths, 64-bit rows
+        rl = rng.integers(14, L + 1, size=nq)
+        rq = np.concatenate([reads[i, : rl[i]] for i in range(nq)])
+        ro = np.concatenate([[0], np.cumsum(rl)]).astype(np.uint64)
+        rwant, _, rnodes = ox.search_ng26(rq, ro, sch, cap=1 << 23)
+        os.environ["FMGPU_FORCE_WIDE"] = "1"
+        try:
+            wx = gpu_index(ox)
+        finally:
+            del os.environ["FMGPU_FORCE_WIDE"]
+        assert wx.row_bits == 64
+        rhits, rst = fm.search_ng26.search(wx, (rq, ro), sch, want_stats=True, capacity=1 << 23)
+        assert same_hits(rhits, rwant) and rst.lf_steps == rnodes
 
 
 def test_scheme_search_ragged_batch_in_length_buckets():
