@@ -1107,7 +1107,8 @@ template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ rv, const uint32_t* __restrict__ tab, uint32_t S, uint32_t M,
                                                      const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                      fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk, uint32_t qwords, uint32_t qnib,
-                                                     LfView lfv, uint32_t tab_lds, const uint4* __restrict__ lut, uint32_t lutL, int use_key, int sharing) {
+                                                     LfView lfv, uint32_t tab_lds, const uint4* __restrict__ lut, uint32_t lutL, int use_key, int sharing,
+                                                     const uint32_t* __restrict__ order) {
     extern __shared__ uint32_t s_query[];
     const QStage qst{s_query, qwords, qnib};
     __shared__ uint32_t s_hb[kWaveHitWords];
@@ -1179,6 +1180,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
             have_query = false;
             if (q >= nq) idle = true;
             else {
+                if (order) q = order[q];
                 const uint64_t qo = qoff[q];
                 qs = qbuf + qo;
                 if ((uint32_t)(qoff[q + 1] - qo) >= M && n != 0) { have_query = true; fresh = true; }   // (a shorter query is read out of bounds by the reference)
@@ -3242,6 +3244,18 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     EventTimer timer(stream, stats != nullptr);
     const idx_t n = (idx_t)x->bwt.n;
     timer.start();
+    uint32_t* order = nullptr;                                     // heavy reads first, as in search_ng26
+    if (le == hipSuccess && nq >= (1u << 16) && nq < 0x7fffffffull && !(getenv("FMGPU_HEAVY_FIRST") && atoi(getenv("FMGPU_HEAVY_FIRST")) == 0)) {
+        int orc = 0;
+        rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
+            orc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
+                k_heavy_flags_plain<decltype(occ)><<<dim3((unsigned)((count_reads + 255) / 256)), 256, 0, stream>>>(occ, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                                                                 count_reads, 0u, kHeavyInterval, flags, cnt);
+            }, &order);
+            return 0;
+        });
+        if (rc || orc) { (void)hipFree(d_tab); return rc ? rc : orc; }
+    }
     if (le == hipSuccess) rc = dispatch_occ(x->bwt, [&](auto occ, auto ms) {
         using O = decltype(occ);
         const DevString& rv = x->rev;
@@ -3250,7 +3264,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
         else if constexpr (std::is_same_v<O, OccM>) r = O{rv.vm};
         else r = O{rv.vr};
         k_ng21<O, decltype(ms)::value><<<dim3(ws.grid), dim3(256), lds_bytes, stream>>>(occ, r, d_tab, S, (uint32_t)M, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                                   nq, n, max_hits_per_query, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, tab_lds, x->lut, x->lut_len, use_key, sharing);
+                                                                                   nq, n, max_hits_per_query, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, lfv, tab_lds, x->lut, x->lut_len, use_key, sharing, order);
         return 0;
     });
     timer.stop();

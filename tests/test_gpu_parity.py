@@ -441,6 +441,10 @@ def test_heavy_reads_first_hand_out_order(mix):
         del os.environ["FMGPU_DEV_FLAGS"]
     assert same_hits(hits, want) and st.lf_steps == wnodes
     assert same_hits(ehits, ewant) and est.lf_steps == enodes
+    ex = fm.search_scheme.expand(sch, L)                     # search_ng21 too
+    h21, st21 = fm.search_ng21.search(gx, (qbuf[: 66_000 * L], qoff[: 66_001]), ex, want_stats=True, capacity=1 << 23)
+    o21, _, n21 = ox.search_ng21(qbuf[: 66_000 * L], qoff[: 66_001], ex, cap=1 << 23)
+    assert same_hits(h21, o21) and st21.lf_steps == n21
     if mix == "some_heavy":                                   # ragged lengths, 64-bit rows
         rl = rng.integers(14, L + 1, size=nq)
         rq = np.concatenate([reads[i, : rl[i]] for i in range(nq)])
