@@ -2620,7 +2620,10 @@ __global__ __launch_bounds__(256) void k_heavy_flags_plain(Occ occ, idx_t n, con
     const uint64_t mk = __ballot(heavy);
     if ((threadIdx.x & 63u) == 0 && mk) atomicAdd(count, (uint32_t)__popcll(mk));
 }
-constexpr uint32_t kHeavyInterval = 8;                            // rows of the 16-symbol interval above which a read counts as one of a high-copy repeat
+// rows of the 16-symbol interval above which a read counts as one of a high-copy repeat (genome-like text, plain index / with tables:
+// > 2 rows 157.8 / 115.7 ms, > 8: 155.8 / 111.5, > 64: 151.3 / 111.1, > 1000: 157.1 / 114.6)
+constexpr uint32_t kHeavyInterval = 64;
+static uint32_t heavy_rows() { const char* e = getenv("FMGPU_DEV_HEAVY_ROWS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : kHeavyInterval; }   // (dev knob)
 
 __global__ __launch_bounds__(256) void k_len_pairs(const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t* __restrict__ len, uint32_t* __restrict__ idx) {
     uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2952,8 +2955,8 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             if ((rc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
                     const dim3 g((unsigned)((count_reads + 255) / 256));
                     if (by_lut) k_heavy_flags<<<g, 256, 0, stream>>>(x->lut, lutL, (uint32_t)x->bwt.sigma - 1u, lp, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads,
-                                                                     (uint32_t)x->bwt.sigma, kHeavyInterval, flags, cnt);
-                    else k_heavy_flags_plain<OccA<5>><<<g, 256, 0, stream>>>(OccA<5>{x->bwt.va}, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads, maxlen, kHeavyInterval, flags, cnt);
+                                                                     (uint32_t)x->bwt.sigma, heavy_rows(), flags, cnt);
+                    else k_heavy_flags_plain<OccA<5>><<<g, 256, 0, stream>>>(OccA<5>{x->bwt.va}, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads, maxlen, heavy_rows(), flags, cnt);
                 }, &order))) return rc;
             if (order) { d_qmap = order; qmap_owned = false; }
         }
@@ -3092,7 +3095,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                 rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
                     orc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
                         k_heavy_flags_plain<decltype(occ)><<<dim3((unsigned)((count_reads + 255) / 256)), 256, 0, stream>>>(occ, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                                                                         count_reads, 0u, kHeavyInterval, flags, cnt);
+                                                                                                                         count_reads, 0u, heavy_rows(), flags, cnt);
                     }, &gen_order);
                     return 0;
                 });
@@ -3250,7 +3253,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
         rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
             orc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
                 k_heavy_flags_plain<decltype(occ)><<<dim3((unsigned)((count_reads + 255) / 256)), 256, 0, stream>>>(occ, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                                                                 count_reads, 0u, kHeavyInterval, flags, cnt);
+                                                                                                                 count_reads, 0u, heavy_rows(), flags, cnt);
             }, &order);
             return 0;
         });

@@ -398,7 +398,7 @@ def test_heavy_reads_first_hand_out_order(mix):
     order switched off, for Hamming and edit distance"""
     rng = np.random.default_rng(5)
     unit = rng.integers(1, 5, size=300, dtype=np.uint8)
-    rep = np.concatenate([np.concatenate([unit, rng.integers(1, 5, size=7, dtype=np.uint8)]) for _ in range(12)])      # 12 copies: intervals of 12 rows
+    rep = np.concatenate([np.concatenate([unit, rng.integers(1, 5, size=7, dtype=np.uint8)]) for _ in range(80)])      # 80 copies: intervals of 80 rows (> the 64 that count as heavy)
     uniq = rng.integers(1, 5, size=30000, dtype=np.uint8)
     seqs = [rep, uniq]
     ox = fo.OraIndex.build("IB16", 5, seqs, 8, True)
