@@ -83,7 +83,7 @@ class ExpandedScheme(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("lf_steps", C.c_uint64), ("hits", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32),
+    _fields_ = [("lf_steps", C.c_uint64), ("hits", C.c_uint64), ("kernel_ms", C.c_float), ("prepass_ms", C.c_float),
                 ("table_bytes", C.c_uint64), ("table_accesses", C.c_uint64)]
 
 

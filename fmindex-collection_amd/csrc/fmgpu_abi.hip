@@ -78,7 +78,7 @@ void CallScratch::drop() {
 }
 struct ScratchSet {
     std::map<int, CallScratch> by_dev;
-    ~ScratchSet() { for (auto& kv : by_dev) for (void* p : {kv.second.frames, kv.second.order}) if (p) (void)hipFree(p); }   // a host thread that ends returns its large buffers
+    ~ScratchSet() { for (auto& kv : by_dev) kv.second.drop(); }   // a host thread that ends returns everything it held (errors of a runtime that is already shutting down are ignored)
 };
 int call_scratch(CallScratch** out) {
     static thread_local ScratchSet set;

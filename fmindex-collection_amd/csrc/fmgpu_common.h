@@ -92,6 +92,28 @@ inline int grid_of(uint64_t threads, dim3* out, uint64_t cap_blocks = 0) {
 }
 #define FM_GRID(var, threads)       dim3 var; do { int rc_ = ::fmgpu::grid_of((threads), &var); if (rc_) return rc_; } while (0)
 
+// Environment switches.  The shipped library honours FMGPU_HEAVY_FIRST, FMGPU_LF_TABLE, FMGPU_FORCE_WIDE and FMGPU_FAIL_SCRATCH (test knobs) and the
+// kernel-SELECTION bits of FMGPU_DEV_FLAGS (which of several result-identical kernels / tables serves a call: the parity tests run every
+// kernel through them).  Everything else — count-only runs, per-read node dumps, tuning fields, residency overrides (FMGPU_DEV_*) — exists in
+// builds made with -DFMGPU_DEV only (make DEV=1; tools/k2_*_probe.py): a stray environment variable cannot make the shipped library drop records
+// or write outside a caller's buffer.
+constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 24);   // general kernel | no prefix table | no LF^1..3 | no LF table in the general kernels | no walk table | no length buckets | no work sharing
+inline const char* dev_env(const char* name) {
+#ifdef FMGPU_DEV
+    return getenv(name);
+#else
+    (void)name; return nullptr;
+#endif
+}
+inline int dev_flags_env() {
+    const char* e = getenv("FMGPU_DEV_FLAGS");
+    int f = e ? atoi(e) : 0;
+#ifndef FMGPU_DEV
+    f &= kSelectFlags;
+#endif
+    return f;
+}
+
 struct DBuf {    // RAII device allocation
     void* p = nullptr; size_t bytes = 0;
     int alloc(size_t b) {

@@ -16,6 +16,7 @@
 #include "fmgpu_common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -1599,7 +1600,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     Tally<uint64_t, !PLAIN> tbytes; Tally<uint32_t, !PLAIN> tacc;   // table bytes consumed / table accesses issued (fmgpu_stats; the plain index is priced per node)
     const uint32_t refill_waste = ((uint32_t)dev_flags >> 8) & 0xffffu ? (((uint32_t)dev_flags >> 8) & 0xffffu) : kRefillWaste;   // (dev knob: bits 8..23)
     uint32_t waste = 0;                                             // lane-iterations the wave's idle lanes have lost since its last refill (wave-uniform)
-    uint32_t nh = 0, count_only = 0, nodes0 = 0;
+    uint32_t nh = 0, count_only = 0; [[maybe_unused]] uint32_t nodes0 = 0;
     bool is_task = false;                                           // the lane works on a subtree it took over from another lane
     uint32_t sbase = 0, mark = 0;                                   // frames below sbase were handed out; nodes at the lane's last hand-out
     const uint32_t share_nodes = ((uint32_t)dev_flags >> 25) & 31u ? 1u << (((uint32_t)dev_flags >> 25) & 31u) : kShareNodes;   // (dev knob: bits 25..29)
@@ -1965,7 +1966,9 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     if (is_task) { have = false; is_task = false; }  // a task is one subtree of one search: its owner goes on with the other searches
                     else if (si == S || query_over) {
                         have = false;
-                        if ((dev_flags & 129) == 129) reinterpret_cast<uint64_t*>(out)[q] = nodes - nodes0;   // dev: nodes per query instead of records (count-only mode)
+#ifdef FMGPU_DEV
+                        if ((dev_flags & 129) == 129 && (q + 1) * 8 <= cap * sizeof(fmgpu_hit)) reinterpret_cast<uint64_t*>(out)[q] = nodes - nodes0;   // dev build: nodes per query instead of records (count-only mode)
+#endif
                     } else need_start = true;
                 }
             }
@@ -2623,7 +2626,7 @@ __global__ __launch_bounds__(256) void k_heavy_flags_plain(Occ occ, idx_t n, con
 // rows of the 16-symbol interval above which a read counts as one of a high-copy repeat (genome-like text, plain index / with tables:
 // > 2 rows 157.8 / 115.7 ms, > 8: 155.8 / 111.5, > 64: 151.3 / 111.1, > 1000: 157.1 / 114.6)
 constexpr uint32_t kHeavyInterval = 64;
-static uint32_t heavy_rows() { const char* e = getenv("FMGPU_DEV_HEAVY_ROWS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : kHeavyInterval; }   // (dev knob)
+static uint32_t heavy_rows() { const char* e = dev_env("FMGPU_DEV_HEAVY_ROWS"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : kHeavyInterval; }   // (dev knob)
 
 __global__ __launch_bounds__(256) void k_len_pairs(const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t* __restrict__ len, uint32_t* __restrict__ idx) {
     uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2711,11 +2714,11 @@ int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream);
 static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
                         uint64_t* out_lb, uint64_t* out_len, bool packed, fmgpu_stats* stats, void* stream_) {
     size_t dev_extra_lds = 0;                                      // dev knob: unused dynamic LDS per block, to limit the resident blocks per CU
-    { const char* ev = getenv("FMGPU_DEV_EXACT_LDS"); if (ev) dev_extra_lds = (size_t)atoi(ev); }
+    { const char* ev = dev_env("FMGPU_DEV_EXACT_LDS"); if (ev) dev_extra_lds = (size_t)atoi(ev); }
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
     if (int drc = on_handle_device(x)) return drc;
-    if (stats) *stats = fmgpu_stats{0, 0, 0.f};
+    if (stats) *stats = fmgpu_stats{};
     if (nq == 0) return 0;
     if (!qbuf || !qoff || !out_lb || (!out_len && !packed)) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out_lb / out_len is null");
     if (kWide && packed) return fail(FMGPU_ERR_UNSUPPORTED, "the one-word interval form (lb << 32 | len) needs rows below 2^32; use fmgpu_search_exact");
@@ -2764,7 +2767,7 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
         // k_exact_a runs best with 5 resident blocks per CU, not the 8 its 28 registers allow (measured on the 3.09 Gbp index, 10 M x 101 bp: 8 / 6 / 5 / 4 / 3
         // blocks = 19.53 / 19.23 / 18.92 / 19.10 / 18.95 ms — more waves only queue up at the memory system): 28 KB of unused dynamic LDS set the residency
-        const size_t lds_a = getenv("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)28 * 1024;
+        const size_t lds_a = dev_env("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)28 * 1024;
         if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
     } else if (x->bwt.search_family() == FAM_WAVELET) {
@@ -2843,7 +2846,7 @@ int fmgpu_search_exact_depth(fmgpu_index_t h, const uint8_t* qbuf, const uint64_
 
 static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme,
                    uint64_t max_hits, uint32_t K, fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, hipStream_t stream) {
-    if (stats) *stats = fmgpu_stats{0, 0, 0.f};
+    if (stats) *stats = fmgpu_stats{};
     if (out_count) *out_count = 0;
     if (nq == 0) return 0;
     if (!qbuf || !qoff || (!out && capacity) || !out_count) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out / out_count is null");
@@ -2858,7 +2861,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         if (max_hits == 0 || scheme->n_searches == 0) return 0;                       // SearchNg26.h:408-409
         sd.S = scheme->n_searches; sd.P = scheme->n_parts; sd.uniform = scheme->partition ? 0 : 1;
         edit = scheme->edit != 0;
-        { const char* e = getenv("FMGPU_DEV_FLAGS"); sd.dev_flags = e ? atoi(e) : 0; }
+        sd.dev_flags = dev_flags_env();
         sd.use_key = 0; sd.sharing = 0;                              // set below for the general Hamming kernel
         for (int s = 0; s < sd.S; ++s) {
             uint32_t seen = 0;
@@ -2924,10 +2927,11 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     EventTimer timer(stream, stats != nullptr);
     const idx_t n = (idx_t)x->bwt.n;
     const dim3 block(256);
-    uint32_t* d_qmap = nullptr;
-    bool qmap_owned = true;                                        // (the heavy-first order lives in the thread's call scratch)
+    uint32_t* d_qmap = nullptr;                                    // hand-out order: the thread's call scratch (heavy reads first) or qmap_buf (length buckets)
+    DBuf qmap_buf, steps_buf;                                      // released on every return path
     uint32_t* d_steps = nullptr;
     bool fast = false;
+    float prepass_ms = 0.f;                                        // the hand-out order pass (flag kernel, sample read-back, partition): reported beside kernel_ms, never inside it
 #if !FMGPU_WIDE
     // fast path: equal-length batch on a Format-A BiFMIndex — with LF tables, or (Hamming, sigma <= 5) on the blocks alone
     // 16-symbol walk: 2-bit symbols, queries staged in LDS as nibbles
@@ -2944,7 +2948,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         fast = build_step_table(sd, maxlen, lutL, use_wj ? 16u : 0u, b.tab, b.lut_ok);
         if (fast) buckets.push_back(std::move(b));
         const char* hf = getenv("FMGPU_HEAVY_FIRST");
-        const bool by_lut = x->lut && lutL >= 8 && lutL <= 16 && (buckets[0].lut_ok & 1u);
+        const bool by_lut = fast && x->lut && lutL >= 8 && lutL <= 16 && (buckets[0].lut_ok & 1u);     // (no step table — m < P, a scheme too large for it: the general kernel below)
         const bool by_blocks = !have_lf && x->bwt.sigma == 5 && maxlen >= 16;     // (the plain-index instantiation)
         if (fast && (by_lut || by_blocks) && nq >= (1u << 16) && nq < 0x7fffffffull && !(hf && atoi(hf) == 0)) {
             // hand the reads of high-copy repeats out first (k_heavy_flags; decided on a sample of the batch — a text without repeats has nothing to
@@ -2952,13 +2956,14 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             LutPositions lp{};
             if (by_lut) for (uint32_t t = 0; t < lutL; ++t) lp.pos[t] = buckets[0].tab[t] & 0xffffu;
             uint32_t* order = nullptr;
+            const auto pre_t0 = std::chrono::steady_clock::now();
             if ((rc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
                     const dim3 g((unsigned)((count_reads + 255) / 256));
                     if (by_lut) k_heavy_flags<<<g, 256, 0, stream>>>(x->lut, lutL, (uint32_t)x->bwt.sigma - 1u, lp, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads,
                                                                      (uint32_t)x->bwt.sigma, heavy_rows(), flags, cnt);
                     else k_heavy_flags_plain<OccA<5>><<<g, 256, 0, stream>>>(OccA<5>{x->bwt.va}, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, count_reads, maxlen, heavy_rows(), flags, cnt);
                 }, &order))) return rc;
-            if (order) { d_qmap = order; qmap_owned = false; }
+            if (order) { d_qmap = order; prepass_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - pre_t0).count(); }
         }
     } else if (fast_ok && nq >= (1u << 16) && nq < 0x7fffffffull && !(sd.dev_flags & 64)) {
         uint32_t *klen = nullptr, *kidx = nullptr, *slen = nullptr, *runs = nullptr;
@@ -2968,14 +2973,14 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         hipError_t he = hipMalloc((void**)&klen, nq * 4);
         if (he == hipSuccess) he = hipMalloc((void**)&kidx, nq * 4);
         if (he == hipSuccess) he = hipMalloc((void**)&slen, nq * 4);
-        if (he == hipSuccess) he = hipMalloc((void**)&d_qmap, nq * 4);
+        if (he == hipSuccess) { if (qmap_buf.alloc(nq * 4) == 0) d_qmap = qmap_buf.as<uint32_t>(); else he = hipErrorOutOfMemory; }
         if (he == hipSuccess) he = hipMalloc((void**)&runs, ((size_t)max_runs * 2 + 1) * 4);
         if (he == hipSuccess) {
             (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, klen, slen, kidx, d_qmap, (int)nq, 0, 16, stream);
             (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp2, slen, runs, runs + max_runs, runs + 2 * max_runs, (int)nq, stream);
             he = hipMalloc(&tmp, std::max(tmp_bytes, tmp2));
         }
-        if (he != hipSuccess) { drop(); if (d_qmap && qmap_owned) (void)hipFree(d_qmap); return hip_fail(he, "hipMalloc(length buckets)"); }
+        if (he != hipSuccess) { drop(); return hip_fail(he, "hipMalloc(length buckets)"); }
         k_len_pairs<<<dim3((unsigned)((nq + 255) / 256)), 256, 0, stream>>>((const uint64_t*)soff.dev, nq, klen, kidx);
         size_t tb = std::max(tmp_bytes, tmp2);
         he = hipcub::DeviceRadixSort::SortPairs(tmp, tb, klen, slen, kidx, d_qmap, (int)nq, 0, 16, stream);
@@ -2985,7 +2990,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         if (he == hipSuccess) he = hipMemcpyAsync(hruns.data(), runs, hruns.size() * 4, hipMemcpyDeviceToHost, stream);
         if (he == hipSuccess) he = hipStreamSynchronize(stream);
         drop();
-        if (he != hipSuccess) { (void)hipFree(d_qmap); return hip_fail(he, "length buckets"); }
+        if (he != hipSuccess) return hip_fail(he, "length buckets");
         const uint32_t nruns = hruns[(size_t)max_runs * 2];
         fast = nruns > 0 && nq / nruns >= 4096;                    // buckets of a few thousand queries at least (a launch and a step table each)
         uint64_t first = 0;
@@ -2999,7 +3004,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             }
             first += cnt;
         }
-        if (!fast) { buckets.clear(); (void)hipFree(d_qmap); d_qmap = nullptr; }
+        if (!fast) { buckets.clear(); qmap_buf.release(); d_qmap = nullptr; }
     }
     // the workspace is sized for the kernel that will run: the table-driven edit-distance kernel keeps 5 blocks per CU resident where the
     // general one (launch bounds for 4) keeps 4 — a grid of 4 leaves a fifth of its wave slots empty (84.5 -> 77.3 ms per 4 M reads)
@@ -3024,18 +3029,18 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     // 197 / 159 / 150 / 159 ms): a fifth block adds issue contention and cache pressure, not throughput
     if (fast && !edit && !have_lf) bpc = std::min(bpc, 4);
 #endif
-    { const char* ev = getenv("FMGPU_DEV_BPC"); if (ev && atoi(ev) > 0) bpc = atoi(ev); }   // dev knob: resident blocks per CU the grid is sized for
+    { const char* ev = dev_env("FMGPU_DEV_BPC"); if (ev && atoi(ev) > 0) bpc = atoi(ev); }   // dev knob: resident blocks per CU the grid is sized for
     // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
-    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3))) { if (d_qmap && qmap_owned) (void)hipFree(d_qmap); return rc; }
+    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3))) return rc;
     const dim3 grid(ws.grid);
 #if !FMGPU_WIDE
     size_t steps_words = 0;
     if (fast) {
         for (const Bucket& b : buckets) steps_words += b.tab.size();
-        hipError_t he = hipMalloc((void**)&d_steps, std::max<size_t>(steps_words, 1) * 4);
-        if (he != hipSuccess) { if (d_qmap && qmap_owned) (void)hipFree(d_qmap); return hip_fail(he, "hipMalloc(step tables)"); }
+        if ((rc = steps_buf.alloc(std::max<size_t>(steps_words, 1) * 4))) return rc;
+        d_steps = steps_buf.as<uint32_t>();
         size_t at = 0;
-        for (const Bucket& b : buckets) { (void)hipMemcpyAsync(d_steps + at, b.tab.data(), b.tab.size() * 4, hipMemcpyHostToDevice, stream); at += b.tab.size(); }
+        for (const Bucket& b : buckets) { FM_HIP(hipMemcpyAsync(d_steps + at, b.tab.data(), b.tab.size() * 4, hipMemcpyHostToDevice, stream)); at += b.tab.size(); }
     }
 #endif
 #if !FMGPU_WIDE
@@ -3092,6 +3097,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             const char* hf = getenv("FMGPU_HEAVY_FIRST");
             if (nq >= (1u << 16) && nq < 0x7fffffffull && minlen >= 1 && !(hf && atoi(hf) == 0)) {
                 int orc = 0;
+                const auto pre_t0 = std::chrono::steady_clock::now();
                 rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
                     orc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
                         k_heavy_flags_plain<decltype(occ)><<<dim3((unsigned)((count_reads + 255) / 256)), 256, 0, stream>>>(occ, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
@@ -3100,6 +3106,8 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                     return 0;
                 });
                 if (rc || orc) return rc ? rc : orc;
+                if (gen_order) prepass_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - pre_t0).count();
+                timer.start();                                      // kernel_ms = the search kernel alone, as in the table-driven path
             }
         }
         const DevString& rv = x->rev;
@@ -3135,11 +3143,9 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     Counters hc{};
     if (le == hipSuccess) le = hipMemcpyAsync(&hc, ws.ctr, sizeof hc, hipMemcpyDeviceToHost, stream);
     if (le == hipSuccess) le = hipStreamSynchronize(stream);
-    if (d_steps) (void)hipFree(d_steps);
-    if (d_qmap && qmap_owned) (void)hipFree(d_qmap);
     if (le != hipSuccess) return hip_fail(le, "search kernel");
     *out_count = hc.hits;
-    if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); stats->table_bytes = hc.table_bytes; stats->table_accesses = hc.table_accesses; }
+    if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); stats->prepass_ms = prepass_ms; stats->table_bytes = hc.table_bytes; stats->table_accesses = hc.table_accesses; }
     if (hc.hits > capacity) {
         if (sout.writeback) { sout.bytes = capacity * sizeof(fmgpu_hit); (void)sout.finish(); }
         return fail(FMGPU_ERR_CAPACITY, "result buffer holds " + std::to_string(capacity) + " records, " + std::to_string(hc.hits) + " produced");
@@ -3171,7 +3177,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
     if (int drc = on_handle_device(x)) return drc;
     hipStream_t stream = (hipStream_t)stream_;
-    if (stats) *stats = fmgpu_stats{0, 0, 0.f};
+    if (stats) *stats = fmgpu_stats{};
     if (out_count) *out_count = 0;
     if (!x->bidirectional) return fail(FMGPU_ERR_INVALID, "search_ng21 needs a BiFMIndex (bwt_rev)");
     if (!scheme) return fail(FMGPU_ERR_INVALID, "scheme is null");
@@ -3236,17 +3242,17 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     }
     // path keys (<= 3 errors, depth and child index within their bit fields) order the hits of a read; with them and no limit on the hits per read the
     // lanes that find the query queue empty take subtrees from the busy lanes of their wave
-    const char* dfl = getenv("FMGPU_DEV_FLAGS");
     const int use_key = S <= 16 && max_u <= 3 && M + max_u <= 250 && x->bwt.sigma <= 32 ? 1 : 0;
-    const int sharing = use_key && max_hits_per_query == ~0ull && !(dfl && (atoi(dfl) & (1 << 24))) ? 1 : 0;
+    const int sharing = use_key && max_hits_per_query == ~0ull && !(dev_flags_env() & (1 << 24)) ? 1 : 0;
     DfsWorkspace ws;
     if ((rc = ws.init((uint32_t)M + max_u + 2, nq, bpc, stream, kEditFramePlanes))) return rc;       // deletions lengthen the path beyond the query by at most the largest upper bound
-    uint32_t* d_tab = nullptr;
-    FM_HIP(hipMalloc((void**)&d_tab, tab.size() * 4));
+    DBuf tab_buf;
+    if ((rc = tab_buf.alloc(tab.size() * 4))) return rc;
+    uint32_t* d_tab = tab_buf.as<uint32_t>();
     hipError_t le = hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, stream);
     EventTimer timer(stream, stats != nullptr);
     const idx_t n = (idx_t)x->bwt.n;
-    timer.start();
+    const auto pre_t0 = std::chrono::steady_clock::now();
     uint32_t* order = nullptr;                                     // heavy reads first, as in search_ng26
     if (le == hipSuccess && nq >= (1u << 16) && nq < 0x7fffffffull && !(getenv("FMGPU_HEAVY_FIRST") && atoi(getenv("FMGPU_HEAVY_FIRST")) == 0)) {
         int orc = 0;
@@ -3257,8 +3263,10 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
             }, &order);
             return 0;
         });
-        if (rc || orc) { (void)hipFree(d_tab); return rc ? rc : orc; }
+        if (rc || orc) return rc ? rc : orc;
     }
+    const float prepass_ms = order ? std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - pre_t0).count() : 0.f;
+    timer.start();                                                  // kernel_ms = the search kernel alone, in every path (the hand-out order is prepass_ms)
     if (le == hipSuccess) rc = dispatch_occ(x->bwt, [&](auto occ, auto ms) {
         using O = decltype(occ);
         const DevString& rv = x->rev;
@@ -3275,11 +3283,10 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     Counters hc{};
     if (le == hipSuccess) le = hipMemcpyAsync(&hc, ws.ctr, sizeof hc, hipMemcpyDeviceToHost, stream);
     if (le == hipSuccess) le = hipStreamSynchronize(stream);
-    (void)hipFree(d_tab);
     if (le != hipSuccess) return hip_fail(le, "search_ng21 kernel");
     if (rc) return rc;
     *out_count = hc.hits;
-    if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); }
+    if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); stats->prepass_ms = prepass_ms; }
     if (hc.hits > capacity) {
         if (sout.writeback) { sout.bytes = capacity * sizeof(fmgpu_hit); (void)sout.finish(); }
         return fail(FMGPU_ERR_CAPACITY, "result buffer holds " + std::to_string(capacity) + " records, " + std::to_string(hc.hits) + " produced");
@@ -3293,12 +3300,12 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
     // k_locate runs best with 4 resident blocks per CU (9 M rows of the 3.09 Gbp index: 8 / 5 / 4 / 3 blocks = 4.73 / 4.20 / 3.99 / 4.03 ms — its lanes
     // leave after 0 .. 15 LF steps and more waves only queue up at the memory system): 36 KB of unused dynamic LDS set the residency
     size_t locate_lds = (size_t)36 * 1024;
-    { const char* ev = getenv("FMGPU_DEV_LOCATE_LDS"); if (ev) locate_lds = (size_t)atoi(ev); }
+    { const char* ev = dev_env("FMGPU_DEV_LOCATE_LDS"); if (ev) locate_lds = (size_t)atoi(ev); }
     Index* x = reinterpret_cast<Index*>(h);
     if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
     if (int drc = on_handle_device(x)) return drc;
     if (!x->has_sa) return fail(FMGPU_ERR_INVALID, "index was created without an annotated (sampled suffix) array");
-    if (stats) *stats = fmgpu_stats{0, 0, 0.f};
+    if (stats) *stats = fmgpu_stats{};
     if (count == 0) return 0;
     if (!rows || !out_seq || !out_pos || !out_steps) return fail(FMGPU_ERR_INVALID, "rows / outputs is null");
     hipStream_t stream = (hipStream_t)stream_;

@@ -143,8 +143,10 @@ typedef struct fmgpu_expanded_scheme {
 typedef struct fmgpu_stats {
     uint64_t lf_steps;       /* exact search: executed extensions;  k-mismatch: visited nodes (cursor extensions) */
     uint64_t hits;           /* records produced */
-    float    kernel_ms;      /* duration of the dominant kernel, measured with hipEvents on `stream` (0 if not requested) */
-    uint32_t reserved;
+    float    kernel_ms;      /* duration of the dominant kernel alone, measured with hipEvents on `stream` (0 if not requested) */
+    float    prepass_ms;     /* k-mismatch searches: host-measured duration of the pass that orders the batch's hand-out (reads of high-copy repeats first: a flag
+                                kernel, a sample read-back, a partition) when it ran, else 0 — part of a call's wall time, never of kernel_ms (same size and
+                                offset as the `reserved` word of ABI 4) */
     /* what the dominant kernel actually asked of the memory system on the index tables, counted by the kernel itself (0 for kernels that do
      * not count): table_bytes = sum over issued table loads of the entry bytes consumed (a 12-byte block entry, an 8-byte walk entry, a
      * 64-byte block of an extend-all, a 16-byte frame ...), table_accesses = number of such accesses that can each touch a different

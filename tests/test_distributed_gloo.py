@@ -68,12 +68,18 @@ def test_bench_two_ranks_on_one_gpu():
                         "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.02",
                         "--nq", "200000", "--total-k2-reads", "100000", "--lut-len", "10", "--prefix-len", "11", "--dist-backend", "gloo", "--all-ranks-device0"], capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, r.stdout[-500:] + r.stderr[-1500:]
+    assert r.returncode == 0 and len(lines) == 1 and r.stdout.rstrip().endswith(lines[0]), r.stdout[-500:] + r.stderr[-1500:]
+    assert len(lines[0]) < 4000                                   # the driver keeps 8 KB of stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and "cpu_baseline" not in out
     assert out["config"]["workload"] == "grch38_exact" and out["config"]["queries_per_gpu"] == 200000
+    assert out["config"]["index_kind"] == "plain" and out["roofline"]["kernel"] == "k_exact_a"      # the headline: the plain index, at every N
     assert out["exchange"]["verified_on_rank0"] is True and out["exchange"]["bytes_per_rank_and_step"] > 0   # rank 0 received what both ranks sent
+    assert out["exchange"]["world_size_seen"] == 2
     assert 0 < out["roofline"]["frac"] <= 1.0
     sec = out["secondary"]                                       # configs[3]: k = 2, 151 bp, the batch sharded over the ranks (strong scaling)
-    assert sec["scaling"] == "strong" and sec["config"]["read_len"] == 151 and sec["config"]["queries_per_gpu"] == 50000 and sec["config"]["partition"] == [38, 38, 38, 37]
-    assert sec["exchange"]["verified_on_rank0"] is True and sec["value"] > 0
+    assert sec["scaling"] == "strong" and sec["value"] > 0 and sec["exchange"]["verified_on_rank0"] is True and sec["exchange"]["world_size_seen"] == 2
+    full = json.load(open(os.path.join(root, out["records_file"])))   # every full record, written beside bench.py
+    rec = next(x for x in full["records"] if x["id"] == sec["record"])
+    assert rec["config"]["read_len"] == 151 and rec["config"]["queries_per_gpu"] == 50000 and rec["config"]["partition"] == [38, 38, 38, 37]
+    assert rec["config"]["index_kind"] == "plain"

@@ -460,6 +460,32 @@ def test_heavy_reads_first_hand_out_order(mix):
         assert same_hits(rhits, rwant) and rst.lf_steps == rnodes
 
 
+def test_equal_length_batch_without_a_step_table():
+    """an equal-length batch of 2^16 reads whose scheme has NO per-step table — reads shorter than the scheme has parts (skipped, expand.h:325-327), and
+    reads so long that the three tables would not fit the LDS (3 searches x 911 steps) — on an index WITH an 8-symbol prefix table: the host must not
+    look at a bucket that was never made (it did, round 2) and the general kernel serves the batch"""
+    rng = np.random.default_rng(17)
+    text = rng.integers(1, 5, size=40_000, dtype=np.uint8)
+    ox = fo.OraIndex.build("IB16", 5, [text], 8, True)
+    gx = gpu_index(ox)
+    gx.accelerate_lf(True); gx.accelerate_search(8, 1)
+    sch = fm.search_scheme.h2(4, 0, 2)                            # 3 searches, 4 parts
+    nq = 1 << 16
+    short = rng.integers(1, 5, size=(nq, 3), dtype=np.uint8)      # m = 3 < P = 4
+    qbuf, qoff = short.reshape(-1), np.arange(nq + 1, dtype=np.uint64) * 3
+    hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True)
+    assert len(hits) == 0 and len(ox.search_ng26(qbuf, qoff, sch)[0]) == 0
+    L = 912                                                       # 3 x 913 > 2730 words
+    starts = rng.integers(0, len(text) - L, size=nq)
+    reads = text[starts[:, None] + np.arange(L)[None, :]].copy()
+    flip = rng.integers(0, nq, size=nq // 2)
+    reads[flip, rng.integers(0, L, size=flip.size)] = rng.integers(1, 5, size=flip.size)
+    qbuf, qoff = reads.reshape(-1), np.arange(nq + 1, dtype=np.uint64) * L
+    want, _, wnodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 22)
+    hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 22)
+    assert same_hits(hits, want) and st.lf_steps == wnodes
+
+
 def test_scheme_search_ragged_batch_in_length_buckets():
     """a large ragged batch is sorted by length on the device and runs the table-driven kernel once per length: same records, order and
     node count as the CPU walk and as the general kernel; queries shorter than the number of parts are skipped in both"""

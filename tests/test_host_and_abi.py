@@ -163,3 +163,41 @@ def test_library_first_then_torch_on_the_gpu():
     pytest.importorskip("torch")
     r = subprocess.run([sys.executable, "-c", _RUNTIME_PROBE % (ROOT, 1)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "HIPLIBS 1" in r.stdout and "GPU ok" in r.stdout, r.stdout + r.stderr[-800:]
+
+
+def test_bench_line_is_compact():
+    """the driver keeps 8 KB of stdout: bench.py's last line (headline + roofline + cpu_baseline + a summary of every record) must stay well below
+    that however many records a run holds; the full records go to a file"""
+    sys.path.insert(0, ROOT)
+    import bench
+    long_text = {"text": "genome", "generator": "x" * 300, "symbols": 3088286401, "sequences": 25, "repeat_fraction": 0.45}
+    def rec(rid, kernel, frac):
+        return {"id": rid, "metric": "queries/sec (GRCh38-sized index, 10M x 101bp, exact)", "value": 5.3e8, "unit": "queries/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+                "ms_per_step": 18.912345678, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": "grch38_exact", "text": long_text, "sigma": 5, "layout": "InterleavedBitvector16", "index": "FMIndex", "index_kind": rid.split("/")[-1],
+                           "queries_per_gpu": 10_000_000, "read_len": 101, "index_device_bytes": 4_200_000_000, "tables": {"a": "y" * 200}},
+                "gbp_per_s": 53.5, "hits": 9_000_000,
+                "roofline": {"bound": "hbm", "achieved": 5600.123456, "peak": 8000.0, "unit": "GB/s", "frac": frac, "traffic": 1.349e11, "kernel": kernel, "kernel_ms": 18.9,
+                             "units_per_launch": 961847926.0, "bytes_per_unit": 112, "accounting": "z" * 400, "traffic_source": "w" * 300},
+                "exchange": {"collective": "gather", "bytes_per_rank_and_step": 80_000_000, "verified_on_rank0": True, "world_size_seen": 8, "record": "r" * 200}}
+    ids = ["%s/%s/%s" % (t_, w, k) for t_ in ("genome", "uniform") for w in ("exact", "locate", "k2", "k2_151", "k2_edit") for k in ("plain", "tables")]
+    ids += ["protein/exact/wavelet", "protein/exact/tables", "protein_wide/exact/wavelet", "protein_wide/exact/tables"]
+    records = [rec(i, "k_scheme_fast_edit", 0.4712345) for i in ids]
+    head = next(r for r in records if r["id"] == "genome/exact/plain")
+    head["cpu_baseline"] = {"value": 2.6e5, "unit": "queries/s", "cores": 16, "kind": "port", "sample_reads": 3_104_452, "seconds": 11.9, "sample": "s" * 400,
+                            "single_thread": {"value": 1.3e5, "unit": "queries/s", "sample": "t" * 100}, "parallel_efficiency": 0.98, "gpu_results_match_on_sample": True,
+                            "compared": "c" * 100}
+    next(r for r in records if r["id"] == "genome/k2/plain")["cpu_baseline"] = dict(head["cpu_baseline"])
+    for multi in (False, True):
+        line = bench.compact_line(records, multi, "bench_records.json")
+        assert len(line) < bench.MAX_LINE <= 4000 and "\n" not in line
+        d = json.loads(line)
+        assert d["config"]["record"] == "genome/exact/plain" and d["config"]["index_kind"] == "plain"       # the headline is the plain index
+        assert d["roofline"]["frac"] == pytest.approx(0.4712, rel=1e-3) and d["roofline"]["bytes_per_unit"] == 112 and d["roofline"]["kernel_ms"] == 18.9
+        assert d["cpu_baseline"]["cores"] == 16 and d["cpu_baseline"]["gpu_results_match_on_sample"] is True
+        assert set(d["summary"]) == set(ids) and d["with_tables"]["record"] == "genome/exact/tables"
+        assert ("secondary" in d) == multi
+    # a run with absurdly many records still prints a parseable headline (the optional parts go first)
+    many = records + [rec("x%d/exact/plain" % i, "k", 0.1) for i in range(400)]
+    line = bench.compact_line(many, False, "bench_records.json")
+    assert len(line) < bench.MAX_LINE and json.loads(line)["roofline"]["kernel"] == "k_scheme_fast_edit"
