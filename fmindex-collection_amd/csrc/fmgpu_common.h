@@ -97,7 +97,7 @@ inline int grid_of(uint64_t threads, dim3* out, uint64_t cap_blocks = 0) {
 // kernel through them).  Everything else — count-only runs, per-read node dumps, tuning fields, residency overrides (FMGPU_DEV_*) — exists in
 // builds made with -DFMGPU_DEV only (make DEV=1; tools/k2_*_probe.py): a stray environment variable cannot make the shipped library drop records
 // or write outside a caller's buffer.
-constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 24);   // general kernel | no prefix table | no LF^1..3 | no LF table in the general kernels | no walk table | no length buckets | no work sharing
+constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 24) | (1 << 30);   // general kernel | no prefix table | no LF^1..3 | no LF table in the general kernels | no walk table | no length buckets | no work sharing | k_scheme_fast<PLAIN> instead of k_scheme_lean
 inline const char* dev_env(const char* name) {
 #ifdef FMGPU_DEV
     return getenv(name);

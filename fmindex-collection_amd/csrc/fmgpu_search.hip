@@ -1662,6 +1662,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                 }
             }
             qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
+            __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0) in this rare path: or the compiler, unsure whether a staging load is still pending, waits for vmcnt(0) in every iteration
         }
         {
             const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(have);
@@ -1718,6 +1719,11 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                     tbytes += same ? 64u : 128u; tacc += same ? 1u : 2u;
                 } else if (multi) { tbytes += 24u * sigma; tacc += 2u; }
                 else { tbytes += lut_start ? 16u : from_block ? 64u : use_wj ? 8u : w3 ? 12u : 4u; ++tacc; }
+                // r0 is first READ here, behind the loads of the rest of the blocks: without this the compiler copies two of its words out of the way right
+                // after the load — behind a vmcnt(0), i.e. a multi-row node paid two dependent round trips per iteration (rocprofv3 / ISA, round 3)
+                uint4 r0v = r0;
+                asm volatile("" : "+v"(r0v.x), "+v"(r0v.y), "+v"(r0v.z), "+v"(r0v.w));
+#define r0 r0v
                 const uint2 we = make_uint2(r0.x, r0.y);
                 idx_t t0 = r0.x, t1 = r0.y, t2 = r0.z;
                 uint32_t row_sym = 0;                               // plain index: the symbol of a one-row node's row, read off its block
@@ -1931,6 +1937,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         else if (n) { if (right) cur.lbRev = target; else cur.lb = target; j += n; }
                     }
                 }
+#undef r0
                 if (!lut_start && !back && j == m) {                // search_next at part == P (:101-108)
                     const uint32_t fin = tab[m];
                     if (((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x3fu)) {
@@ -2091,6 +2098,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 }
             }
             qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
+            __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0) in this rare path: or the compiler, unsure whether a staging load is still pending, waits for vmcnt(0) in every iteration
         }
         {
             const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(have);
@@ -2296,6 +2304,303 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
         atomicAdd(&ctr->nodes, (unsigned long long)tot);
         if (co) atomicAdd(&ctr->hits, (unsigned long long)co);
     }
+}
+
+// ---- search_ng26 Hamming on the PLAIN index (sigma = 5, no table of any kind): the lean kernel -----------------------------------------
+// k_scheme_fast<5, 5, PLAIN> carries the frame of the table-driven kernel; on the plain index it ran at 0.47 of the HBM roofline,
+// bound by latency at 5 waves per SIMD: per iteration a wave paid (a) the pop of a frame from its stack in HBM and then, dependent on it, (b) the
+// block loads of the popped node, (c) one returning atomicAdd on ONE device-wide word per ~6 hit records (8.8 M of them per 10 M reads — the word
+// saturates near 88 M/s).  This kernel does the same walk (search/SearchNg26.h:143-365, Edit = false) with
+//   * the top frame of a lane's stack cached in LDS: a pop is served from there, and the frame below is requested at once by an LDS-DMA load
+//     (global_load_lds: no register holds it, nothing waits for it) a whole iteration before it can be needed — the stack never sits on the
+//     dependent chain (pushes still write through, so the frames in HBM are complete);
+//   * hit records appended to a ring per WAVE in LDS (slot by LDS atomic) and written out with one reservation per >= kRingFlush records;
+//   * reads staged with 2 bits per symbol (a read with a byte outside 1..4 is read from global memory instead), 12 instead of 16 dwords per
+//     block end (the entry of the delimiter is derived: a query that holds a 0 takes a slow path), no table paths, no quota:
+//   72 registers and 21 KB of LDS per block at 101 bp = 7 resident blocks per CU.
+// Path keys, sharing of the bottom frame between the lanes of a wave, heavy reads first: as in k_scheme_fast.
+constexpr uint32_t kRingCap = 96;        // hit records a wave keeps in LDS ...
+constexpr uint32_t kRingFlush = 32;      // ... written out as soon as there are this many: 64 more (one per lane and iteration) always fit
+constexpr uint32_t kRingWords = 6;       // qidx, lb, lbRev, len, errors | key high, key low
+constexpr uint32_t kLeanNoResume = 7u;
+constexpr int kLeanWaves = 6;            // resident blocks per CU the kernel is built for
+
+struct LeanArgs {
+    const uint8_t* fw; const uint8_t* rv;    // Format A blocks of bwt / bwtRev (64 bytes per 64 rows)
+    const uint32_t* steps;                   // [S][m + 1]: pos:16 | right:1 | lastOfPart:1 | minE:5 | maxE:6 (build_step_table)
+    uint32_t S, m;
+};
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+struct __attribute__((packed, aligned(4))) Quad4 { uint32_t x, y, z, w; };   // 16 bytes at dword alignment (the entries of symbols 1..4 start 12 bytes into a block)
+
+// eight query bytes in 1..4 -> 16 bits (2 per symbol, symbol - 1); ok = false if a byte is outside 1..4
+__device__ __forceinline__ uint32_t pack2_8(uint64_t x, bool& ok) {
+    const uint64_t k1 = 0x0101010101010101ull;
+    const uint64_t v = x - k1;                                    // (a zero byte borrows: caught below)
+    if ((((x - k1) & ~x & (0x80ull * k1)) != 0ull) || ((v & (0xfcull * k1)) != 0ull)) ok = false;
+    uint64_t t = v & (0x03ull * k1);
+    t = (t | (t >> 6)) & 0x000f000f000f000full;
+    t = (t | (t >> 12)) & 0x000000ff000000ffull;
+    t = (t | (t >> 24)) & 0xffffull;
+    return (uint32_t)t;
+}
+// wave-synchronous staging of one equal-length read per lane, 16 symbols per LDS word; returns false for a read that holds a byte outside 1..4
+__device__ __forceinline__ bool stage2_sync(uint32_t* lds, const uint8_t* __restrict__ qbuf, uint64_t off, uint32_t m, bool active) {
+    const uint8_t* p = qbuf + off;
+    const uint32_t mis = (uint32_t)((uint64_t)p & 7ull);
+    const uint64_t* base = reinterpret_cast<const uint64_t*>(p - mis);      // (pointer arithmetic, not integer: the loads stay global_load, not flat_load)
+    const uint32_t nw = active ? ((mis + m + 7u) >> 3) : 0u;
+    bool ok = true;
+    uint64_t carry = 0;
+    uint32_t half = 0;
+    for (uint32_t k0 = 0; k0 <= ((m + 14u) >> 3); k0 += 8) {
+        uint64_t r[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) r[k] = (k0 + k < nw) ? base[k0 + k] : 0ull;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t widx = k0 + k;
+            if (widx == 0) { carry = r[k]; continue; }
+            uint64_t x = mis ? ((carry >> (8u * mis)) | (r[k] << (64u - 8u * mis))) : carry;
+            carry = r[k];
+            const uint32_t g = widx - 1u, p0 = g * 8u;             // group g = query positions 8g .. 8g + 7
+            if (active && p0 < m) {
+                const uint32_t nv = m - p0;                        // bytes of the group that belong to the read
+                if (nv < 8u) x = (x & ((1ull << (8u * nv)) - 1ull)) | (0x0101010101010101ull << (8u * nv));
+                const uint32_t code = pack2_8(x, ok);
+                if (g & 1u) lds[(g >> 1) * 256u + threadIdx.x] = half | (code << 16);
+                else { half = code; if (nv <= 8u) lds[(g >> 1) * 256u + threadIdx.x] = half; }     // (the read's last group)
+            }
+        }
+    }
+    return ok;
+}
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ void ring_flush(lds_u32* s_cnt_w, const uint32_t* ring, uint32_t lane, fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr) {   // all lanes call
+    const uint32_t total = __hip_atomic_load(s_cnt_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&ctr->hits, (unsigned long long)total);
+    base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0, 64) << 32) | __shfl((uint32_t)base, 0, 64);
+    for (uint32_t k = lane; k < total; k += 64u) {
+        const unsigned long long at = base + k;
+        if (at < cap) {
+            fmgpu_hit rec;
+            rec.qidx = ring[k]; rec.lb = ring[kRingCap + k]; rec.lb_rev = ring[2u * kRingCap + k]; rec.len = ring[3u * kRingCap + k];
+            rec.errors = ring[4u * kRingCap + k]; rec.seq = ring[5u * kRingCap + k];
+            out[at] = rec;
+        }
+    }
+    if (lane == 0) __hip_atomic_store(s_cnt_w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
+template <int WAVES>      // waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
+__global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t n,
+                                                             fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, ulonglong2* __restrict__ frames, uint64_t nlanes,
+                                                             uint32_t qwords, const uint32_t* __restrict__ qmap) {
+    extern __shared__ uint32_t s_dyn[];                             // [qwords][256] staged reads | [256] top frames (16 B) | [S][m + 1] steps | [4] ring fill | 4 x [kRingWords][kRingCap] rings
+    const uint32_t S = la.S, m = la.m, stride = la.m + 1;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    lds_u32x4* const s_tos = (lds_u32x4*)(s_dyn + (size_t)qwords * 256u);
+    lds_u32x4* const tos_slot = s_tos + tid;                        // the frame at depth sp - 1 of this lane (valid while sp > sbase)
+    uint32_t* const s_steps = s_dyn + (size_t)qwords * 256u + 1024u;
+    lds_u32* const s_cnt_w = (lds_u32*)(s_steps + S * stride + wave);
+    uint32_t* const ring = s_steps + S * stride + 4u + wave * (kRingWords * kRingCap);
+    for (uint32_t i = tid; i < S * stride; i += 256u) s_steps[i] = la.steps[i];
+    if (tid < 4u) s_steps[S * stride + tid] = 0u;
+    __syncthreads();
+
+    const uint32_t gid = blockIdx.x * 256u + tid;                   // frame d of this lane at frames[d * nlanes + gid]
+    uint32_t nodes = 0, mark = 0, waste = 0;
+    bool have = false, exhausted = n == 0, need_start = false, is_task = false, odd = false, in_tail = false;
+    uint32_t q = 0, si = 0, e = 0, j = 0, sp = 0, sbase = 0, resume = kLeanNoResume;
+    uint32_t lb = 0, lbRev = 0, len = 0;
+    uint64_t pkey = 0;
+    // Order of the top-frame slot's accesses.  The slot is refilled by an LDS-DMA load issued at the END of an iteration (after a pop); every other
+    // access of the slot in the node phase (push, pop) comes after the lane has consumed its block loads of that iteration, which were issued after the
+    // DMA: vector-memory operations of a wave complete in order, so the DMA has landed.  The one access outside the node phase (handing the only
+    // frame to an idle lane) waits for vmcnt(0) itself.
+    for (;;) {
+        // ---- wave-synchronous part
+        {
+            const bool can_give = have && sp > sbase && nodes - mark >= kShareNodes;
+            const uint64_t idlem = __ballot(!have), offerm = __ballot(can_give);
+            if (idlem && offerm) {                                  // the i-th idle lane takes the bottom frame of the i-th offering lane
+                const uint64_t below = (1ull << lane) - 1ull;
+                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
+                const bool give = can_give && (uint32_t)__popcll(offerm & below) < pairs;
+                const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
+                uint64_t w0 = 0, w1 = 0, w2 = 0;
+                if (give) {
+                    if (sp - sbase > 1u) { const ulonglong2 f = frames[(uint64_t)sbase * nlanes + gid]; w0 = f.x; w1 = f.y; }
+                    else {                                          // a stack of one frame: the cached one
+                        __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0): a refill of the slot may still be in flight
+                        asm volatile("" ::: "memory");
+                        const u32x4 t = *tos_slot;
+                        w0 = (uint64_t)t.x | ((uint64_t)t.y << 32); w1 = (uint64_t)t.z | ((uint64_t)t.w << 32);
+                    }
+                    w2 = key_prefix(pkey, (uint32_t)(w1 >> 48) & 0xffu);
+                    ++sbase; mark = nodes;
+                }
+                uint64_t om = offerm;
+                for (uint32_t k = take ? (uint32_t)__popcll(idlem & below) : 0u; k > 0; --k) om &= om - 1ull;
+                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const uint64_t tw0 = __shfl(w0, vl, 64), tw1 = __shfl(w1, vl, 64), tw2 = __shfl(w2, vl, 64);
+                const uint32_t tq = __shfl(q, vl, 64), tsi = __shfl(si, vl, 64), todd = __shfl((uint32_t)odd, vl, 64);
+                if (take) {
+                    q = tq; si = tsi; odd = todd != 0u;
+                    lb = (uint32_t)tw0; lbRev = (uint32_t)(tw0 >> 32); len = (uint32_t)tw1;
+                    j = (uint32_t)(tw1 >> 32) & 0xffffu; e = (uint32_t)(tw1 >> 48) & 0xffu; resume = (uint32_t)(tw1 >> 56) & 0xffu;
+                    pkey = tw2;
+                    const uint32_t vt = (tid & ~63u) | (uint32_t)vl;
+                    for (uint32_t w = 0; w < qwords; ++w) s_dyn[w * 256u + tid] = s_dyn[w * 256u + vt];     // the partner's staged read
+                    have = true; is_task = true; need_start = false; sp = 0; sbase = 0; in_tail = false; mark = nodes;
+                }
+            }
+        }
+        {
+            const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
+            waste += (uint32_t)__popcll(needm);
+            if (needm && (waste >= kRefillWaste || !busym)) {
+                waste = 0;
+                const bool want = !have && !exhausted;
+                bool fresh = false; uint64_t qo = 0;
+                const uint64_t got = wave_hand_out(want, ctr, lane);
+                if (want) {
+                    if (got >= nq) exhausted = true;
+                    else { q = qmap ? qmap[got] : (uint32_t)got; qo = qoff[q]; fresh = true; have = true; is_task = false; si = 0; need_start = true; mark = nodes; }
+                }
+                const bool ok = stage2_sync(s_dyn, qbuf, qo, m, fresh);
+                if (fresh) odd = !ok;
+                __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0) here, in the rare path: or the compiler, unsure whether a staging load is still pending on some path,
+                                                                    // waits for vmcnt(0) in EVERY iteration before it overwrites one of their registers — ahead of the block loads
+            }
+        }
+        {
+            const uint32_t filled = __hip_atomic_load(s_cnt_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const uint64_t busy = __ballot(have);
+            if (filled >= kRingFlush || (!busy && filled)) ring_flush(s_cnt_w, ring, lane, out, cap, ctr);
+            if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
+        }
+        if (!have) continue;
+        // ---- one node per lane
+        if (need_start) {                                           // search_impl (SearchNg26.h:385-390) -> run(): :62-79
+            need_start = false;
+            lb = 0; lbRev = 0; len = n; e = 0; j = 0; sp = 0; sbase = 0; resume = kLeanNoResume; in_tail = false;
+            pkey = (uint64_t)si << 48;
+        }
+        const uint32_t ent = s_steps[si * stride + j];
+        const bool right = (ent >> 16) & 1u, multi = len > 1u;
+        const uint32_t a = right ? lbRev : lb, b = a + len;
+        const uint8_t* blk = right ? la.rv : la.fw;
+        // memory phase: the entries of symbols 1..4 of the block(s) — 48 bytes, 12 into the block — of both interval ends (one end for a one-row node)
+        const Quad4* pa = reinterpret_cast<const Quad4*>(blk + (size_t)(a >> 6) * 64u + 12u);
+        const Quad4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
+        Quad4 b0, b1, b2;                                           // (only a multi-row node reads them: no default, or the compiler waits for A before it asks for B)
+        if (multi) { const Quad4* pb = reinterpret_cast<const Quad4*>(blk + (size_t)(b >> 6) * 64u + 12u); b0 = pb[0]; b1 = pb[1]; b2 = pb[2]; }
+        const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
+        const bool lastp = (ent >> 17) & 1u;
+        uint32_t c;
+        if (odd) { const uint32_t v = qbuf[qoff[q] + pos]; c = v < 5u ? v : 255u; }      // a read with bytes outside 1..4: from global memory (rare)
+        else c = ((s_dyn[(pos >> 4) * 256u + tid] >> ((pos & 15u) * 2u)) & 3u) + 1u;
+        // LF of symbols 1..4 at a (and b): cnt + popcount(bits below the row)
+        const uint32_t abit = a & 63u, bbit = b & 63u;
+        const uint32_t ma_lo = abit >= 32u ? 0xffffffffu : (1u << abit) - 1u, ma_hi = abit >= 32u ? (1u << (abit - 32u)) - 1u : 0u;
+        const uint32_t mb_lo = bbit >= 32u ? 0xffffffffu : (1u << bbit) - 1u, mb_hi = bbit >= 32u ? (1u << (bbit - 32u)) - 1u : 0u;
+        const uint32_t la1 = a0.x + __popc(a0.y & ma_lo) + __popc(a0.z & ma_hi), la2 = a0.w + __popc(a1.x & ma_lo) + __popc(a1.y & ma_hi);
+        const uint32_t la3 = a1.z + __popc(a1.w & ma_lo) + __popc(a2.x & ma_hi), la4 = a2.y + __popc(a2.z & ma_lo) + __popc(a2.w & ma_hi);
+        bool back = false, search_over = false;
+        const bool mOK = minE <= e && e <= maxE, sOK = minE <= e + 1u && e + 1u <= maxE, xOK = e + 1u <= maxE;
+        if (multi) {
+            // ---- extend-all node (search_next_dir, :143-224) or exact-tail step over several rows
+            const uint32_t d1 = b0.x + __popc(b0.y & mb_lo) + __popc(b0.z & mb_hi) - la1, d2 = b0.w + __popc(b1.x & mb_lo) + __popc(b1.y & mb_hi) - la2;
+            const uint32_t d3 = b1.z + __popc(b1.w & mb_lo) + __popc(b2.x & mb_hi) - la3, d4 = b2.y + __popc(b2.z & mb_lo) + __popc(b2.w & mb_hi) - la4;
+            const uint32_t d0 = len - (d1 + d2 + d3 + d4);          // rows of the interval that hold the delimiter
+            const uint32_t alive = (d0 ? 1u : 0u) | (d1 ? 2u : 0u) | (d2 ? 4u : 0u) | (d3 ? 8u : 0u) | (d4 ? 16u : 0u);
+            const bool resuming = resume != kLeanNoResume;
+            uint32_t subs = alive & ~1u & ~(c < 5u ? 1u << c : 0u);  // substitution children: FirstSymb = 1 (fmindex/BiFMIndex.h:26), != query symbol
+            if (!sOK) subs = 0u;
+            if (resuming) subs &= ~((1u << resume) - 1u);
+            const bool take_match = !resuming && mOK && c < 5u && ((alive >> c) & 1u);     // match child first (:171-181)
+            const bool take_sub = !take_match && subs != 0u;
+            uint32_t take = c;
+            if (take_sub) { take = (uint32_t)__ffs((int)subs) - 1u; subs &= subs - 1u; }
+            nodes += (!resuming && (in_tail || xOK || mOK)) ? 1u : 0u;
+            if ((take_match || take_sub) && subs) {                 // (re-)push the parent: its remaining siblings start at the lowest of subs
+                const u32x4 f = {lb, lbRev, len, (j & 0xffffu) | ((e & 0xffu) << 16) | (((uint32_t)__ffs((int)subs) - 1u) << 24)};
+                uint32_t g = gid; asm volatile("" : "+v"(g));     // (kept out of loop-invariant hoisting: the 64-bit address of the lane's frame column would hold two registers through the loop)
+                *reinterpret_cast<u32x4*>(frames + ((uint64_t)sp * nlanes + g)) = f;     // write-through: the stack in HBM is always complete
+                *tos_slot = f; ++sp;
+            }
+            resume = kLeanNoResume;
+            if (take_match || take_sub) {
+                uint32_t kla = la1, kd = d1, pre = d0;
+                if (take == 2u) { kla = la2; kd = d2; pre = d0 + d1; }
+                else if (take == 3u) { kla = la3; kd = d3; pre = d0 + d1 + d2; }
+                else if (take == 4u) { kla = la4; kd = d4; pre = d0 + d1 + d2 + d3; }
+                else if (take == 0u) {                              // a delimiter in the QUERY matched against delimiter rows: the entry of symbol 0
+                    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(blk + (size_t)(a >> 6) * 64u);
+                    kla = p0[0] + __popc(p0[1] & ma_lo) + __popc(p0[2] & ma_hi); kd = d0; pre = 0u;
+                }
+                len = kd;
+                if (right) { lbRev = kla; lb += pre; } else { lb = kla; lbRev += pre; }     // fmindex/BiFMIndexCursor.h:58-82
+                if (take_sub) { pkey = key_with(pkey, e, m, j, take); e += 1u; }
+                in_tail = !lastp && (in_tail || (take_match && !xOK));
+                ++j;
+            } else back = true;
+        } else {
+            // ---- single row (search_next_dir_single, :251-365): the only child is the BWT symbol of the row, read off its block
+            const uint32_t bt_lo = abit >= 32u ? 0u : 1u << abit, bt_hi = abit >= 32u ? 1u << (abit - 32u) : 0u;
+            uint32_t row_sym = 0u, t0 = 0u;
+            if ((a0.y & bt_lo) | (a0.z & bt_hi)) { row_sym = 1u; t0 = la1; }
+            if ((a1.x & bt_lo) | (a1.y & bt_hi)) { row_sym = 2u; t0 = la2; }
+            if ((a1.w & bt_lo) | (a2.x & bt_hi)) { row_sym = 3u; t0 = la3; }
+            if ((a2.z & bt_lo) | (a2.w & bt_hi)) { row_sym = 4u; t0 = la4; }
+            const bool is_match = row_sym >= 1u && row_sym == c && mOK;
+            nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
+            bool dead = false;
+            if (row_sym < 1u) dead = true;                          // :295-297: a delimiter row ends the walk
+            else if (row_sym == c) { if (!mOK) dead = true; }
+            else if (sOK) { pkey = key_with(pkey, e, m, j, row_sym); e += 1u; }
+            else dead = true;
+            if (dead) back = true;
+            else { in_tail = !lastp && (in_tail || (is_match && !xOK)); if (right) lbRev = t0; else lb = t0; ++j; }
+        }
+        if (!back && j == m) {                                      // search_next at part == P (:101-108)
+            const uint32_t fin = s_steps[si * stride + m];
+            if (((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x3fu)) {
+                const uint32_t slot = __hip_atomic_fetch_add(s_cnt_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // < kRingCap: the wave flushes at kRingFlush and appends one record per lane and iteration at most
+                ring[slot] = q; ring[kRingCap + slot] = lb; ring[2u * kRingCap + slot] = lbRev; ring[3u * kRingCap + slot] = len;
+                ring[4u * kRingCap + slot] = e | ((uint32_t)(pkey >> 32) << 8); ring[5u * kRingCap + slot] = (uint32_t)pkey;
+            }
+            back = true;
+        }
+        if (back) {
+            if (sp == sbase) search_over = true;
+            else {
+                --sp;
+                asm volatile("" ::: "memory");                      // (the slot is read here, not ahead of the branch)
+                const u32x4 t = *tos_slot;                          // the cached top frame ...
+                lb = t.x; lbRev = t.y; len = t.z;
+                j = t.w & 0xffffu; e = (t.w >> 16) & 0xffu; resume = t.w >> 24;
+                pkey = key_prefix(pkey, e);
+                in_tail = false;
+                uint32_t g = gid; asm volatile("" : "+v"(g));
+                if (sp > sbase)                                     // ... and the one below it, requested an iteration before it can be needed, straight into the slot
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(frames + ((uint64_t)(sp - 1u) * nlanes + g)),
+                                                     (__attribute__((address_space(3))) void*)(s_tos + wave * 64u), 16, 0, 0);
+            }
+        }
+        if (search_over) {                                          // the next search of the scheme, or the lane is out of work
+            ++si;
+            if (is_task) { have = false; is_task = false; }         // a task is one subtree of one search: its owner goes on with the other searches
+            else if (si == S) have = false;
+            else need_start = true;
+        }
+    }
+    const uint32_t tot = wave_sum(nodes);
+    if (lane == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
 }
 
 #endif  // !FMGPU_WIDE
@@ -3025,9 +3330,36 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     }
 #endif  // !FMGPU_WIDE
 #if !FMGPU_WIDE
-    // the plain-index instantiation runs best with 4 resident blocks per CU (measured on the genome-like text, 10 M x 101 bp: 2 / 3 / 4 / 5 blocks =
+    // path keys order the hits of a read whoever finds them (<= 2 substitutions fit the key); with them and no limit on the hits per read the
+    // lanes of a wave share the work of large reads
+    // (edit distance: <= 3 error edges of 16 bits each, the tree depth — query length + deletions — in 8 bits, the child index in 6)
+    const int use_key = !fast || sd.S > 16 ? 0 : (!edit ? (max_u <= 2 ? 1 : 0) : (max_u <= 3 && maxlen + max_u <= 250 && x->bwt.sigma <= 32 ? 1 : 0));
+    const int sharing = use_key && max_hits == ~0ull && !(sd.dev_flags & (1 << 24)) ? 1 : 0;
+    // the plain index (sigma = 5, no table) with path keys and unlimited hits per read: the lean kernel (k_scheme_lean); bit 30 of FMGPU_DEV_FLAGS keeps
+    // k_scheme_fast<PLAIN> (the parity tests run both)
+    const bool lean = fast && !edit && !have_lf && x->bwt.sigma == 5 && sharing && nq <= 0xffffffffull && n >= 2 && !(sd.dev_flags & (1 << 30));
+    const uint32_t lean_qwords = (maxlen + 15) / 16;
+    size_t lean_lds = 0;
+    if (lean) {
+        size_t max_tab = 0;
+        for (const Bucket& b : buckets) max_tab = std::max(max_tab, b.tab.size() / 3);
+        lean_lds = (size_t)lean_qwords * 1024 + 4096 + max_tab * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;
+        const auto key = std::make_tuple(-2, x->bwt.sigma, 4, lean_lds);
+        bool known = false;
+        { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(key); if (it != occ_cache.end()) { bpc = it->second; known = true; } }
+        if (!known) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scheme_lean<kLeanWaves>, 256, lean_lds) == hipSuccess && nb > 0) bpc = nb; else { (void)hipGetLastError(); bpc = 4; }
+            std::lock_guard<std::mutex> g(occ_mu); occ_cache[key] = bpc;
+        }
+        // measured on the genome-like text, 10 M x 101 bp (kernel ms): 7 / 6 / 5 / 4 resident blocks per CU = 141 / 126 / 120 / 118 (151 bp: 212 / 211 / 210 / 204) — the
+        // loop is bound by instruction issue (rocprofv3: ~550 wave instructions per iteration, the waves of a SIMD active 100 % of its time at 4 per SIMD;
+        // at 7 they spend 48 % of their cycles waiting to issue), so more resident waves only add contention
+        bpc = std::min(bpc, 4);
+    }
+    // k_scheme_fast<PLAIN> runs best with 4 resident blocks per CU (measured on the genome-like text, 10 M x 101 bp: 2 / 3 / 4 / 5 blocks =
     // 197 / 159 / 150 / 159 ms): a fifth block adds issue contention and cache pressure, not throughput
-    if (fast && !edit && !have_lf) bpc = std::min(bpc, 4);
+    else if (fast && !edit && !have_lf) bpc = std::min(bpc, 4);
 #endif
     { const char* ev = dev_env("FMGPU_DEV_BPC"); if (ev && atoi(ev) > 0) bpc = atoi(ev); }   // dev knob: resident blocks per CU the grid is sized for
     // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
@@ -3042,13 +3374,6 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         size_t at = 0;
         for (const Bucket& b : buckets) { FM_HIP(hipMemcpyAsync(d_steps + at, b.tab.data(), b.tab.size() * 4, hipMemcpyHostToDevice, stream)); at += b.tab.size(); }
     }
-#endif
-#if !FMGPU_WIDE
-    // path keys order the hits of a read whoever finds them (<= 2 substitutions fit the key); with them and no limit on the hits per read the
-    // lanes of a wave share the work of large reads
-    // (edit distance: <= 3 error edges of 16 bits each, the tree depth — query length + deletions — in 8 bits, the child index in 6)
-    const int use_key = !fast || sd.S > 16 ? 0 : (!edit ? (max_u <= 2 ? 1 : 0) : (max_u <= 3 && maxlen + max_u <= 250 && x->bwt.sigma <= 32 ? 1 : 0));
-    const int sharing = use_key && max_hits == ~0ull && !(sd.dev_flags & (1 << 24)) ? 1 : 0;
 #endif
     timer.start();
 #if !FMGPU_WIDE
@@ -3074,6 +3399,11 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                 else
                     k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                               b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
+            } else if (lean) {
+                LeanArgs la{x->bwt.va.blk, x->rev.va.blk, fa.steps, (uint32_t)sd.S, b.m};
+                const size_t lds_lean = (size_t)lean_qwords * 1024 + 4096 + (b.tab.size() / 3) * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;
+                k_scheme_lean<kLeanWaves><<<g, block, lds_lean, stream>>>(la, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (uint32_t)n, (fmgpu_hit*)sout.dev, capacity,
+                                                                         ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes, lean_qwords, qm);
             } else if (x->bwt.sigma == 5 && !have_lf)
                 k_scheme_fast<5, 5, true><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                           b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);

@@ -460,6 +460,64 @@ def test_heavy_reads_first_hand_out_order(mix):
         assert same_hits(rhits, rwant) and rst.lf_steps == rnodes
 
 
+@pytest.mark.parametrize("k,length", [(1, 20), (2, 31), (2, 101), (2, 151), (2, 255), (3, 64), (0, 40)])
+def test_lean_kernel_on_the_plain_index(k, length):
+    """equal-length batches on a BiFMIndex<5> WITHOUT any table take k_scheme_lean (top frame of the stack cached in LDS and refilled by LDS-DMA, hit ring
+    per wave, 2-bit staged reads): records in callback order and node counts equal the CPU walk and k_scheme_fast<PLAIN> (FMGPU_DEV_FLAGS bit 30) —
+    on a repeat-rich text (deep stacks, thousands of hits per read: ring flushes, work sharing), with reads that hold delimiters and bytes outside
+    the alphabet (read from global memory), and with more hits than the caller's buffer holds"""
+    seqs = repeat_text(70 + k, n=9000) + [np.tile(np.array([1, 1, 1, 2], dtype=np.uint8), 300), np.full(700, 3, dtype=np.uint8)]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
+    os.environ["FMGPU_LF_TABLE"] = "0"
+    try:
+        gx = gpu_index(ox)
+    finally:
+        del os.environ["FMGPU_LF_TABLE"]
+    queries = mutated_queries([q for q in seqs if len(q) > length], 3000, length, length + 1, k + 1, seed=21 + k)
+    rng = np.random.default_rng(k)
+    for i in range(0, len(queries), 97):                      # delimiters inside reads, at the ends and inside: the lane reads such a read from global memory
+        queries[i][int(rng.integers(0, length))] = 0
+    queries[5][0] = 0; queries[6][length - 1] = 0
+    assert len({len(q) for q in queries}) == 1
+    qbuf, qoff = fm.flatten(queries)
+    schemes = [fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k)] if k else [fm.search_scheme.backtracking(1, 0, 0)]
+    for sch in schemes:
+        ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 24)
+        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes, (k, length)
+        os.environ["FMGPU_DEV_FLAGS"] = str(1 << 30)               # k_scheme_fast<PLAIN>
+        try:
+            hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
+        finally:
+            del os.environ["FMGPU_DEV_FLAGS"]
+        assert same_hits(hits2, ohits) and st2.lf_steps == nodes
+        if len(ohits) > 10:                                       # a buffer that is too small: FMGPU_ERR_CAPACITY with the exact count (the wrapper then asks again with that capacity)
+            assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, capacity=len(ohits) // 2), ohits)
+    # bytes outside the alphabet are outside the reference's domain (it indexes an array of sigma cursors with them); the kernels treat them as "matches nothing":
+    # the three Hamming kernels agree on it
+    odd = [q.copy() for q in queries[:600]]
+    for i, q in enumerate(odd):
+        q[int(rng.integers(0, length))] = [5, 9, 255, 15][i % 4]
+    qb2, qo2 = fm.flatten(odd)
+    got = []
+    for flags in (None, 1 << 30, 2):
+        if flags is not None:
+            os.environ["FMGPU_DEV_FLAGS"] = str(flags)
+        try:
+            got.append(fm.search_ng26.search(gx, (qb2, qo2), schemes[0], want_stats=True, capacity=1 << 22))
+        finally:
+            os.environ.pop("FMGPU_DEV_FLAGS", None)
+    assert same_hits(got[0][0], got[1][0]) and same_hits(got[0][0], got[2][0]) and got[0][1].lf_steps == got[1][1].lf_steps == got[2][1].lf_steps
+    # the poly-A / satellite reads alone: 64 lanes of a wave all deep in one repeat
+    sat = [seqs[3][i: i + length] for i in range(0, 400)] + [seqs[4][:length]] * 200
+    if all(len(q) == length for q in sat):
+        qbuf, qoff = fm.flatten(sat)
+        sch = schemes[0]
+        ohits, _, nodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 25)
+        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 25)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes
+
+
 def test_equal_length_batch_without_a_step_table():
     """an equal-length batch of 2^16 reads whose scheme has NO per-step table — reads shorter than the scheme has parts (skipped, expand.h:325-327), and
     reads so long that the three tables would not fit the LDS (3 searches x 911 steps) — on an index WITH an 8-symbol prefix table: the host must not
