@@ -347,7 +347,7 @@ static int make_format_a(const uint8_t* bwt, uint64_t n, uint32_t sigma, const i
     FM_HIP(hipStreamSynchronize(stream));
     s.blk_bytes = blk.bytes; s.blk = blk.take();
     s.sup_bytes = kWide ? sup.bytes : 0; s.sup = sup.take();
-    s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC, (const uint64_t*)s.sup};
+    s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC, (const uint64_t*)s.sup, 0u, 0};
     return 0;
 }
 
@@ -674,6 +674,7 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
     }
     x->device_bytes += x->bwt.blk_bytes + x->bwt.aux_bytes + x->bwt.sup_bytes + x->rev.blk_bytes + x->rev.aux_bytes + x->rev.sup_bytes +
                        (x->bwt.lf_table ? n * sizeof(idx_t) : 0) + (x->rev.lf_table ? n * sizeof(idx_t) : 0);
+    if ((rc = fuse_presence_bits(x.get(), stream))) return bail(rc);
     *out = reinterpret_cast<fmgpu_index_t>(x.release());
     if (built_out) *built_out = reinterpret_cast<fmgpu_built_t>(built.release());
     return 0;

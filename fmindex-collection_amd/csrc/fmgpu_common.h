@@ -17,6 +17,11 @@
 //     LF(i, c) = cnt + popc(bits & lowmask(i & 63)),  rank(i, c) = LF(i, c) - C[c].
 //     Wide rows: cnt is relative to the block's super-block (2^30 rows); super[(i >> 30) * sigma + c] (u64, a few hundred bytes, cache
 //     resident) holds the rest:  LF(i, c) = super + cnt + popc(...).
+//     Fused presence bits (sigma <= 5, the bwt of an index with a sampled suffix array): the 8 bytes of entry 0's bitmap hold the SparseArray's
+//     presence bits of the block's 64 rows instead (ViewA::fused) — locate reads "is this row sampled", the row's symbol and its LF from ONE
+//     line per step.  The delimiter's own LF is not lost: the ranks of all symbols at i add up to i, so
+//         LF(i, 0) = i + (C[1] + ... + C[sigma-1]) - (LF(i, 1) + ... + LF(i, sigma-1))      (ViewA::ksum holds the sum of C)
+//     and a row holds the delimiter iff no other symbol's bit is set.  Every reader of Format A goes through OccA, which applies this.
 //     The reference stores u16 counts relative to a 65 536-row super-block plus a u64 super-block table
 //     (string/InterleavedBitvector.h:13-60) and shifts rows by one bit (row p <-> bit (p+1)&63 of block
 //     (p+1)>>6); both are normalised away at upload, results are identical.
@@ -199,6 +204,8 @@ struct ViewA {            // Format A
     uint32_t sigma;
     const idx_t* C;       // sigma+1 entries (device)
     const uint64_t* super;// wide rows only: [row >> 30][sigma]
+    uint32_t fused;       // 1: entry 0's bitmap holds the sampled suffix array's presence bits (see above)
+    idx_t ksum;           // C[1] + ... + C[sigma-1] (mod 2^width), for LF(i, 0) of a fused table
 };
 
 struct ViewR {            // Format R (EPR / EPRV2 reference layout)
@@ -282,13 +289,22 @@ struct OccA {
     static constexpr int kMaxSigma = SIGMA > 0 ? SIGMA : 256;
     __device__ __forceinline__ uint32_t sigma() const { return SIGMA > 0 ? (uint32_t)SIGMA : v.sigma; }
 
+    // LF(i, 0) of a fused table: i + sum C - sum over the other symbols (each one entry of the same block)
+    __device__ __forceinline__ idx_t lf0_fused(idx_t i) const {
+        idx_t r = i + v.ksum;
+        const uint32_t s = sigma();
+        for (uint32_t c = 1; c < s; ++c) { EntryA e = load_entry_a(v, i, c); r -= e.cnt + popc64(e.bits & lowmask((uint32_t)i & 63u)); }
+        return r;
+    }
     __device__ __forceinline__ void lf2(idx_t a, idx_t b, uint32_t c, idx_t& ra, idx_t& rb) const {
+        if (v.fused && c == 0) { ra = lf0_fused(a); rb = lf0_fused(b); return; }
         EntryA ea = load_entry_a(v, a, c);
         EntryA eb = load_entry_a(v, b, c);
         ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
         rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
     }
     __device__ __forceinline__ idx_t lf(idx_t i, uint32_t c) const {
+        if (v.fused && c == 0) return lf0_fused(i);
         EntryA e = load_entry_a(v, i, c);
         return e.cnt + popc64(e.bits & lowmask((uint32_t)i & 63u));
     }
@@ -301,6 +317,10 @@ struct OccA {
     __device__ __forceinline__ uint32_t symbol(idx_t i) const {
         const uint32_t s = sigma();
         uint32_t bit = (uint32_t)i & 63u;
+        if (v.fused) {                                           // the delimiter row is the one no other symbol claims
+            for (uint32_t c = 1; c < s; ++c) { EntryA e = load_entry_a(v, i, c); if ((e.bits >> bit) & 1ull) return c; }
+            return 0;
+        }
         for (uint32_t c = 0; c + 1 < s; ++c) {
             EntryA e = load_entry_a(v, i, c);
             if ((e.bits >> bit) & 1ull) return c;
@@ -311,6 +331,14 @@ struct OccA {
     __device__ __forceinline__ idx_t lf_symbol(idx_t i, uint32_t& symb) const {
         const uint32_t s = sigma();
         uint32_t bit = (uint32_t)i & 63u;
+        if (v.fused) {
+            for (uint32_t c = 1; c < s; ++c) {
+                EntryA e = load_entry_a(v, i, c);
+                if ((e.bits >> bit) & 1ull) { symb = c; return e.cnt + popc64(e.bits & lowmask(bit)); }
+            }
+            symb = 0;
+            return lf0_fused(i);
+        }
         uint32_t c = 0;
         EntryA e = load_entry_a(v, i, 0);
         while (c + 1 < s && !((e.bits >> bit) & 1ull)) { ++c; e = load_entry_a(v, i, c); }
@@ -338,6 +366,12 @@ struct OccA {
                 lfa[c] += v.super[(size_t)(a >> kSuperShift) * S + c];
                 lfb[c] += v.super[(size_t)(b >> kSuperShift) * S + c];
             }
+        }
+        if (v.fused) {                                           // entry 0's bitmap holds presence bits: the delimiter's LF from the other symbols'
+            idx_t ra = a + v.ksum, rb = b + v.ksum;
+#pragma unroll
+            for (uint32_t c = 1; c < S; ++c) { ra -= lfa[c]; rb -= lfb[c]; }
+            lfa[0] = ra; lfb[0] = rb;
         }
     }
     template <int MS>
@@ -368,6 +402,11 @@ struct OccA {
                 lfa[c] = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
                 lfb[c] = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
             }
+        }
+        if (v.fused) {                                           // (fused tables have sigma <= 5: this path only for a runtime-sigma instantiation)
+            idx_t ra = a + v.ksum, rb = b + v.ksum;
+            for (uint32_t c = 1; c < s; ++c) { ra -= lfa[c]; rb -= lfb[c]; }
+            lfa[0] = ra; lfb[0] = rb;
         }
     }
 };
@@ -623,6 +662,8 @@ int on_handle_device(const Index* x);
 
 // fills s.lf_table from the device string (all layouts); defined in fmgpu_index.hip
 int build_lf_table(DevString& s, hipStream_t stream);
+// moves the sampled suffix array's presence bits into the bwt's Format A blocks (sigma <= 5; see "Fused presence bits"); defined in fmgpu_index.hip
+int fuse_presence_bits(Index* x, hipStream_t stream);
 void free_string(DevString& s);
 
 struct Index {

@@ -113,7 +113,34 @@ static int alloc_format_a(DevString& s, uint64_t n, uint32_t sigma, const idx_t*
     s.blk_bytes = blk.bytes; s.blk = blk.take();
     s.sup_bytes = kWide ? sup.bytes : 0; s.sup = sup.take();
     s.family = FAM_A;
-    s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC, (const uint64_t*)s.sup};
+    s.va = ViewA{(const uint8_t*)s.blk, bstride, sigma, dC, (const uint64_t*)s.sup, 0u, 0};
+    return 0;
+}
+
+// ---- fused presence bits (fmgpu_common.h): word B of the SparseArray's presence bitvector (bitvector/Bitvector2L.h:30-33, bit r of word B = row 64 B + r)
+// replaces the bitmap of entry 0 in block B of the bwt's Format A table
+__global__ __launch_bounds__(256) void k_fuse_presence(uint8_t* __restrict__ blk, ViewSA sa, uint64_t nblocks) {
+    const uint64_t B = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (B >= nblocks) return;
+    const uint64_t w = sa.bits[B];
+    uint32_t* o = reinterpret_cast<uint32_t*>(blk + B * 64u);
+    o[1] = (uint32_t)w; o[2] = (uint32_t)(w >> 32);
+    // 32-bit rows: the block's 4 spare bytes hold the number of sampled rows before it (bitvector/Bitvector2L.h:123-142 evaluated at the block's first
+    // row), so that the rank of a sampled row — the index of its SparseArray value — comes from the line that said it is sampled
+    if constexpr (!kWide) o[15] = (uint32_t)sa_rank(sa, (idx_t)(B * 64u));
+}
+int fuse_presence_bits(Index* x, hipStream_t stream) {
+    DevString& s = x->bwt;
+    const char* off = getenv("FMGPU_FUSED_LOCATE");
+    if (!x->has_sa || s.family != FAM_A || s.shadow || s.va.bstride != 64u || s.sigma < 2 || s.va.fused || (off && atoi(off) == 0)) return 0;
+    const uint64_t nblocks = s.n / 64 + 1;
+    FM_GRID(grid, nblocks);
+    k_fuse_presence<<<grid, dim3(256), 0, stream>>>((uint8_t*)s.blk, x->vsa, nblocks);
+    FM_LAUNCHED("k_fuse_presence");
+    FM_HIP(hipStreamSynchronize(stream));
+    idx_t ksum = 0;
+    for (int c = 1; c < s.sigma; ++c) ksum += (idx_t)x->hC[c];
+    s.va.fused = 1u; s.va.ksum = ksum;
     return 0;
 }
 
@@ -705,6 +732,7 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
                         (const uint64_t*)x->sa_f0, (const uint64_t*)x->sa_f1,
                         sa->field[0].bits, sa->field[1].bits, sa->field[0].common_divisor, sa->field[1].common_divisor};
         x->has_sa = true;
+        rc = fuse_presence_bits(x.get(), nullptr); if (rc) return bail(rc);
     }
     *out = reinterpret_cast<fmgpu_index_t>(x.release());
     return 0;

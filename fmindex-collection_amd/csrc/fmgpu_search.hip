@@ -155,12 +155,16 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
                 ++steps;
                 if (c >= sigma) { lb = 0; len = 0; break; }
                 const idx_t a = lb, b = lb + len;
-                EntryA ea = load_entry_a(occ.v, a, c);
-                EntryA eb = ea;
-                ++acc;
-                if ((a >> 6) != (b >> 6)) { eb = load_entry_a(occ.v, b, c); ++acc; }
-                idx_t ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
-                idx_t rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
+                idx_t ra, rb;
+                if (c == 0 && occ.v.fused) { occ.lf2(a, b, 0, ra, rb); acc += 2; }      // a delimiter in the query on a table whose entry 0 carries presence bits (rare)
+                else {
+                    EntryA ea = load_entry_a(occ.v, a, c);
+                    EntryA eb = ea;
+                    ++acc;
+                    if ((a >> 6) != (b >> 6)) { eb = load_entry_a(occ.v, b, c); ++acc; }
+                    ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
+                    rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
+                }
                 lb = ra; len = rb - ra;
                 if (len == 0) break;
             }
@@ -1735,7 +1739,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
                         const uint32_t bit = a & 63u;
                         t0 = 0;
 #pragma unroll
-                        for (uint32_t cc = 0; cc < (uint32_t)SIGMA; ++cc) {
+                        for (uint32_t cc = 1; cc < (uint32_t)SIGMA; ++cc) {      // (a delimiter row — no symbol >= 1 claims it — ends the walk; entry 0 may hold presence bits)
                             const uint64_t bits = (uint64_t)da[3 * cc + 1] | ((uint64_t)da[3 * cc + 2] << 32);
                             if ((bits >> bit) & 1ull) { t0 = da[3 * cc] + popc64(bits & lowmask(bit)); row_sym = cc; }
                         }
@@ -2329,6 +2333,7 @@ struct LeanArgs {
     const uint8_t* fw; const uint8_t* rv;    // Format A blocks of bwt / bwtRev (64 bytes per 64 rows)
     const uint32_t* steps;                   // [S][m + 1]: pos:16 | right:1 | lastOfPart:1 | minE:5 | maxE:6 (build_step_table)
     uint32_t S, m;
+    uint32_t ksum;                           // C[1] + ... + C[4] mod 2^32: LF(i, 0) = i + ksum - sum of the other symbols' LF (the kernel never reads entry 0)
 };
 typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 struct __attribute__((packed, aligned(4))) Quad4 { uint32_t x, y, z, w; };   // 16 bytes at dword alignment (the entries of symbols 1..4 start 12 bytes into a block)
@@ -2539,10 +2544,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 if (take == 2u) { kla = la2; kd = d2; pre = d0 + d1; }
                 else if (take == 3u) { kla = la3; kd = d3; pre = d0 + d1 + d2; }
                 else if (take == 4u) { kla = la4; kd = d4; pre = d0 + d1 + d2 + d3; }
-                else if (take == 0u) {                              // a delimiter in the QUERY matched against delimiter rows: the entry of symbol 0
-                    const uint32_t* p0 = reinterpret_cast<const uint32_t*>(blk + (size_t)(a >> 6) * 64u);
-                    kla = p0[0] + __popc(p0[1] & ma_lo) + __popc(p0[2] & ma_hi); kd = d0; pre = 0u;
-                }
+                else if (take == 0u) { kla = a + la.ksum - (la1 + la2 + la3 + la4); kd = d0; pre = 0u; }   // a delimiter in the QUERY matched against delimiter rows: the ranks of all symbols at a add up to a
                 len = kd;
                 if (right) { lbRev = kla; lb += pre; } else { lb = kla; lbRev += pre; }     // fmindex/BiFMIndexCursor.h:58-82
                 if (take_sub) { pkey = key_with(pkey, e, m, j, take); e += 1u; }
@@ -2709,6 +2711,61 @@ __global__ __launch_bounds__(256) void k_locate_tab(const uint32_t* __restrict__
 
 #endif
 constexpr uint32_t kLocateStepCap = 1u << 24;   // a valid index reaches a sampled row long before; bounds a corrupt one
+
+// FMIndex::locate on a Format A table with fused presence bits (sigma <= 5; fmgpu_common.h): ONE 64-byte block per step answers "is this row
+// sampled", "which symbol precedes it" and "where does that lead" (fmindex/FMIndex.h:113-124 with suffixarray/SparseArray.h:63-70's presence test
+// read from the block); the Bitvector2L rank and the two DenseVector reads happen once, at the sampled row.
+template <int SIGMA>
+__global__ __launch_bounds__(256) void k_locate_fused(OccA<SIGMA> occ, ViewSA sa, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
+                                                      uint64_t* __restrict__ out_seq, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_steps,
+                                                      unsigned long long* __restrict__ steps_total) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t steps = 0;
+    if (t < count) {
+        uint64_t r64 = rows[t];
+        uint64_t seq = ~0ull, pos = ~0ull, st = ~0ull;
+        if (r64 < n) {
+            idx_t row = (idx_t)r64;
+            bool found = false;
+            uint64_t k = 0;
+            const uint32_t s = occ.sigma();
+            while (steps < kLocateStepCap) {
+                const uint4* p = reinterpret_cast<const uint4*>(occ.v.blk + (size_t)(row >> 6) * 64u);
+                const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];             // the whole block: one line
+                const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                const uint32_t bit = (uint32_t)row & 63u;
+                const uint64_t present = (uint64_t)d[1] | ((uint64_t)d[2] << 32);
+                if ((present >> bit) & 1ull) {
+                    found = true;
+                    if constexpr (!kWide) k = (uint64_t)d[15] + popc64(present & lowmask(bit));      // sampled rows before this one: the block's own count + its presence bits
+                    break;
+                }
+                idx_t next = row + occ.v.ksum;                                   // the delimiter's LF unless a symbol >= 1 claims the row
+                bool claimed = false;
+#pragma unroll
+                for (uint32_t c = 1; c < (uint32_t)(SIGMA > 0 ? SIGMA : 5); ++c) {
+                    if (c < s) {
+                        const uint64_t bits = (uint64_t)d[3 * c + 1] | ((uint64_t)d[3 * c + 2] << 32);
+                        idx_t lfc = d[3 * c] + popc64(bits & lowmask(bit));
+                        if constexpr (kWide) lfc += occ.v.super[(size_t)(row >> kSuperShift) * s + c];
+                        if ((bits >> bit) & 1ull) { claimed = true; next = lfc; }
+                        else if (!claimed) next -= lfc;
+                    }
+                }
+                row = next;
+                ++steps;
+            }
+            if (found) {
+                if constexpr (kWide) k = sa_rank(sa, row);
+                seq = dense_access(sa.f0, sa.bits0, sa.div0, k);
+                pos = dense_access(sa.f1, sa.bits1, sa.div1, k);
+                st = steps;
+            }
+        }
+        out_seq[t] = seq; out_pos[t] = pos; out_steps[t] = st;
+    }
+    add_counters(steps_total, steps, 0u, 0u);
+}
 
 template <class Occ>
 __global__ __launch_bounds__(256) void k_locate(Occ occ, const idx_t* __restrict__ lf_table, ViewSA sa, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
@@ -3400,7 +3457,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                     k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                               b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
             } else if (lean) {
-                LeanArgs la{x->bwt.va.blk, x->rev.va.blk, fa.steps, (uint32_t)sd.S, b.m};
+                LeanArgs la{x->bwt.va.blk, x->rev.va.blk, fa.steps, (uint32_t)sd.S, b.m, (uint32_t)(x->hC[1] + x->hC[2] + x->hC[3] + x->hC[4])};
                 const size_t lds_lean = (size_t)lean_qwords * 1024 + 4096 + (b.tab.size() / 3) * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;
                 k_scheme_lean<kLeanWaves><<<g, block, lds_lean, stream>>>(la, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (uint32_t)n, (fmgpu_hit*)sout.dev, capacity,
                                                                          ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes, lean_qwords, qm);
@@ -3657,6 +3714,10 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
         k_locate_tab<<<grid, block, 0, stream>>>(x->loc_tab, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
     else
 #endif
+    if (x->bwt.va.fused && !x->bwt.shadow && x->bwt.family == FAM_A) {      // one line per step: presence bit, symbol and LF from the row's block (also ahead of the explicit LF table: that is two lines per step)
+        if (x->bwt.sigma == 5) k_locate_fused<5><<<grid, block, locate_lds, stream>>>(OccA<5>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
+        else k_locate_fused<0><<<grid, block, locate_lds, stream>>>(OccA<0>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
+    } else
     rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
         k_locate<decltype(occ)><<<grid, block, locate_lds, stream>>>(occ, x->bwt.lf_table, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev,
                                                            (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);

@@ -1297,6 +1297,25 @@ def test_locate_random(layout, rate):
     # out-of-range rows are flagged, not walked
     seq, pos, steps = gx.locate(np.array([ox.n, ox.n + 5], dtype=np.uint64))
     assert np.all(steps == np.uint64(2**64 - 1))
+    # an index with a sampled suffix array keeps the presence bits in entry 0 of its sigma <= 5 blocks (one line per locate step): every String_c answer,
+    # the delimiter's included, is unchanged, and so are searches whose queries hold delimiters
+    ork, opr = ox.bwt_string().rank_table()
+    idx = np.repeat(np.arange(ox.n + 1, dtype=np.uint64), 5)
+    sym = np.tile(np.arange(5, dtype=np.uint8), ox.n + 1)
+    assert np.array_equal(gx.rank(idx, sym).reshape(ox.n + 1, 5), ork) and np.array_equal(gx.prefix_rank(idx, sym).reshape(ox.n + 1, 5), opr)
+    bw = ox.bwt_string()
+    assert np.array_equal(gx.symbol(rows), np.array([bw.symbol(int(r)) for r in rows], dtype=np.uint64))
+    queries = [[0], [1, 0], [0, 2], [2, 0, 1], [0, 0], list(seqs[0][-3:]) + [0], [0] + list(seqs[1][:4])] + [list(q) for q in mutated_queries(seqs, 50, 2, 30, 0, seed=rate)]
+    qbuf, qoff = fm.flatten(queries)
+    lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
+    olb, oln = ox.search_exact(qbuf, qoff)
+    assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
+    os.environ["FMGPU_FUSED_LOCATE"] = "0"                    # the same index without the fusion: the two-line locate
+    try:
+        gx0 = gpu_index(ox)
+    finally:
+        del os.environ["FMGPU_FUSED_LOCATE"]
+    assert all(np.array_equal(a, b) for a, b in zip(gx0.locate(rows), gx.locate(rows)))
 
 
 # ------------------------------------------------------------------------------------------------ GPU index construction
