@@ -9,6 +9,7 @@ search_backtracking.search (search/Backtracking.h), search_ng26.search (search/S
 There is no CPU fallback anywhere in this package: without libfmgpu.so and a GPU every compute call raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -156,6 +157,23 @@ class FMIndex:
                                                 1 if bidirectional else 0, 1 if keep_host else 0, C.byref(h),
                                                 C.byref(b) if keep_host else None))
         return cls(h, built=b if keep_host else None)
+
+    # -------------------------------------------------------------- index file (replaces saveIndex / loadIndex, fmindex/diskStorage.h:12-27)
+    def save(self, path, tables=True):
+        """write the index to this library's own flat file (header + every device array with a checksum); tables=True keeps the optional tables the
+        handle holds right now.  Not the reference's cereal format (include/fmgpu.h)"""
+        capi.check(capi.lib().fmgpu_index_save(self._h, os.fsencode(path), 1 if tables else 0))
+        return self
+
+    @classmethod
+    def load(cls, path):
+        """an index written by save(); FMIndex.load returns a BiFMIndex object for a bidirectional file (and vice versa): the file says what it holds"""
+        h = C.c_void_p()
+        capi.check(capi.lib().fmgpu_index_load(os.fsencode(path), C.byref(h)))
+        x = FMIndex(h)
+        if x.bidirectional:
+            x.__class__ = BiFMIndex
+        return x
 
     def built_array(self, part, dtype=np.uint8):
         """host copy of a construction by-product (keep_host=True): 0 = BWT bytes, 1 = BWT of the reversed text, 2 = C"""

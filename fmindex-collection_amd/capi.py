@@ -96,6 +96,7 @@ EXPORTS = [
     "fmgpu_build_index", "fmgpu_built_free", "fmgpu_built_get", "fmgpu_index_accelerate", "fmgpu_index_accelerate_search",
     "fmgpu_index_accelerate_exact", "fmgpu_index_accelerate_locate", "fmgpu_hits_sort", "fmgpu_hits_pack16",
     "fmgpu_index_row_bits", "fmgpu_index_accelerate_lf", "fmgpu_search_exact_depth", "fmgpu_cursor_extend", "fmgpu_hits_pack24",
+    "fmgpu_index_save", "fmgpu_index_load",
 ]
 
 _lib = None
@@ -173,6 +174,8 @@ def lib():
     L.fmgpu_index_accelerate_lf.argtypes = [C.c_void_p, C.c_int32]
     L.fmgpu_search_exact_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.fmgpu_cursor_extend.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fmgpu_index_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    L.fmgpu_index_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     L.fmgpu_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
     L.fmgpu_free.argtypes = [C.c_void_p]
     L.fmgpu_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]

@@ -3,6 +3,8 @@
 // handle is routed to the 32-bit-row build (namespace fmgpu32) or the 64-bit-row build (fmgpu64) of the kernels by IndexHeader::wide.
 #include "fmgpu_common.h"
 
+#include <cstdio>
+
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -181,6 +183,25 @@ int fmgpu_built_get(fmgpu_built_t b_, int32_t part, const void** ptr, uint64_t* 
     return 0;
 }
 
+int fmgpu_index_save(fmgpu_index_t h, const char* path, int32_t include_tables) { ROUTE(h, fmgpu_index_save(h, path, include_tables)); }
+int fmgpu_index_load(const char* path, fmgpu_index_t* out) {
+    if (!path || !out) return fail(FMGPU_ERR_INVALID, "path / out is null");
+    *out = nullptr;
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(FMGPU_ERR_INVALID, std::string("index file: cannot open ") + path);
+    struct { char magic[8]; uint32_t version, abi, wide, endian_probe; uint64_t meta_bytes, meta_sum, reserved[3]; } fh;
+    static_assert(sizeof fh == 64, "file header is 64 bytes");
+    int rc = 0;
+    if (fread(&fh, 1, sizeof fh, f) != sizeof fh) rc = fail(FMGPU_ERR_INVALID, "index file: truncated (header)");
+    else if (std::memcmp(fh.magic, "FMGPUIDX", 8) != 0) rc = fail(FMGPU_ERR_INVALID, "index file: not an index file of this library (the reference's cereal files are not read: see INTEGRATION.md)");
+    else if (fh.endian_probe != 0x01020304u) rc = fail(FMGPU_ERR_UNSUPPORTED, "index file: written on a machine of the other byte order");
+    else if (fh.version != 1) rc = fail(FMGPU_ERR_UNSUPPORTED, "index file: format version " + std::to_string(fh.version) + " (this library reads version 1)");
+    else if (fh.abi != FMGPU_ABI_VERSION) rc = fail(FMGPU_ERR_UNSUPPORTED, "index file: written by ABI version " + std::to_string(fh.abi) + " of the library, this is " + std::to_string(FMGPU_ABI_VERSION) + " (the device formats may differ: rebuild the index)");
+    else if (fh.wide > 1) rc = fail(FMGPU_ERR_INVALID, "index file: bad row width");
+    else rc = fh.wide ? fmgpu64::api::index_load(f, &fh, out) : fmgpu32::api::index_load(f, &fh, out);
+    fclose(f);
+    return rc;
+}
 int fmgpu_index_destroy(fmgpu_index_t h) { if (!h) return 0; ROUTE(h, fmgpu_index_destroy(h)); }
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes) {
     ROUTE(h, fmgpu_index_info(h, n, sigma, layout, bidirectional, device_bytes));

@@ -505,7 +505,7 @@ int build_format_a_shadow(DevString& s, const idx_t* dC, hipStream_t stream) {
     FM_LAUNCHED("k_symbols");
     DevString t;
     if ((rc = make_format_a(sym.as<uint8_t>(), s.n, (uint32_t)s.sigma, dC, t, s.layout, stream))) return rc;
-    s.shadow = t.blk; s.shadow_bytes = t.blk_bytes + t.sup_bytes; s.shadow_sup = t.sup; s.va = t.va;
+    s.shadow = t.blk; s.shadow_bytes = t.blk_bytes + t.sup_bytes; s.shadow_sup = t.sup; s.shadow_sup_bytes = t.sup_bytes; s.va = t.va;
     return 0;
 }
 
@@ -636,6 +636,7 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
         x->vsa = ViewSA{(const uint64_t*)x->sa_l0, (const uint16_t*)x->sa_l1, (const uint64_t*)x->sa_bits, (const uint64_t*)x->sa_f0, (const uint64_t*)x->sa_f1, w0, w1, div0, div1};
         x->has_sa = true;
         x->device_bytes += nwords * 8 + nl0 * 8 + nl1 * 2 + (f0words + f1words + 2) * 8;
+        x->sa_bytes[0] = nl0 * 8; x->sa_bytes[1] = nl1 * 2; x->sa_bytes[2] = nwords * 8; x->sa_bytes[3] = (f0words + 1) * 8; x->sa_bytes[4] = (f1words + 1) * 8;
         if (built) {
             auto grab = [&](int part, const void* dev, size_t bytes) -> int {
                 built->part[part].resize(bytes);

@@ -44,6 +44,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -646,8 +647,8 @@ struct DevString {
     uint32_t* walk2j = nullptr;
     // Format A shadow of a Format R / M string (fmgpu_index_accelerate, kstep >= 1): the searches then read `va` (one line per
     // LF step instead of one per level); fmgpu_string_query keeps answering from the native format.
-    void* shadow = nullptr; size_t shadow_bytes = 0;
-    void* shadow_sup = nullptr;
+    void* shadow = nullptr; size_t shadow_bytes = 0;   // (shadow_bytes = blocks + super table)
+    void* shadow_sup = nullptr; size_t shadow_sup_bytes = 0;
     int search_family() const { return shadow ? (int)FAM_A : family; }
 };
 
@@ -674,6 +675,7 @@ struct Index {
     uint64_t hC[258] = {0};
     // sampled SA
     void *sa_l0 = nullptr, *sa_l1 = nullptr, *sa_bits = nullptr, *sa_f0 = nullptr, *sa_f1 = nullptr;
+    size_t sa_bytes[5] = {0, 0, 0, 0, 0};          // allocation sizes of l0, l1, bits, f0, f1 (the index file stores them as they are)
     ViewSA vsa{};
     // fmgpu_index_accelerate_locate: the (seqId, pos, steps) answer of every row, 3 x u32 per row (or null)
     uint32_t* loc_tab = nullptr;

@@ -728,6 +728,8 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
             x->device_bytes += bytes;
         }
         x->device_bytes += sa->n_l0 * 8 + sa->n_l1 * 2 + sa->n_bit_words * 8;
+        x->sa_bytes[0] = sa->n_l0 * 8; x->sa_bytes[1] = sa->n_l1 * 2; x->sa_bytes[2] = sa->n_bit_words * 8;
+        x->sa_bytes[3] = (sa->field[0].n_words + 1) * 8; x->sa_bytes[4] = (sa->field[1].n_words + 1) * 8;
         x->vsa = ViewSA{(const uint64_t*)x->sa_l0, (const uint16_t*)x->sa_l1, (const uint64_t*)x->sa_bits,
                         (const uint64_t*)x->sa_f0, (const uint64_t*)x->sa_f1,
                         sa->field[0].bits, sa->field[1].bits, sa->field[0].common_divisor, sa->field[1].common_divisor};

@@ -79,6 +79,7 @@ template <size_t TSigma, template <size_t> class String, bool Bidirectional>
 struct GpuIndexBase {
     static constexpr size_t Sigma = TSigma;
     static constexpr size_t FirstSymb = 1;
+    static constexpr bool IsBidirectional = Bidirectional;
     using LEntry = std::tuple<uint32_t, uint32_t, size_t>;   // (seqId, pos, steps): decltype(tuple_cat(ADEntry{}, tuple<size_t>{}))
 
     fmgpu_index_t handle{};
@@ -130,6 +131,23 @@ template <size_t TSigma, template <size_t> class String = string::FlattenedBitve
 struct BiFMIndex : GpuIndexBase<TSigma, String, true> {
     using GpuIndexBase<TSigma, String, true>::GpuIndexBase;
 };
+
+// saveIndex / loadIndex (fmindex/diskStorage.h:12-27) on this library's own index file (include/fmgpu.h: fmgpu_index_save / fmgpu_index_load — a
+// flat file of the device arrays, NOT the reference's cereal archive).  withTables: also the optional tables the handle holds right now.
+template <typename Index>
+void saveIndex(Index const& index, std::string const& fileName, bool withTables = true) {
+    detail::check(fmgpu_index_save(index.handle, fileName.c_str(), withTables ? 1 : 0));
+}
+template <typename Index>
+auto loadIndex(std::string const& fileName) -> Index {
+    Index index{};
+    detail::check(fmgpu_index_load(fileName.c_str(), &index.handle));
+    int32_t sigma{}, bidir{};
+    detail::check(fmgpu_index_info(index.handle, &index.n, &sigma, nullptr, &bidir, nullptr));
+    if (static_cast<size_t>(sigma) != Index::Sigma || (bidir != 0) != Index::IsBidirectional)
+        throw std::runtime_error("loadIndex: " + fileName + " holds an index of Sigma " + std::to_string(sigma) + (bidir ? " (BiFMIndex)" : " (FMIndex)"));
+    return index;
+}
 
 // ------------------------------------------------------------------------------------------------ cursors
 struct IntIterator {   // utils.h:656-669

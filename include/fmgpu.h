@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FMGPU_ABI_VERSION 4
+#define FMGPU_ABI_VERSION 5
 
 typedef enum fmgpu_status {
     FMGPU_OK = 0,
@@ -167,6 +167,15 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out);
 int fmgpu_index_destroy(fmgpu_index_t h);
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes);
 int fmgpu_index_row_bits(fmgpu_index_t h, int32_t* bits);   /* 32 or 64: the width of the device tables this index is held in */
+
+/* The library's own index file — replaces saveIndex / loadIndex (fmindex/diskStorage.h:12-27) for a handle of this library: a header, a description of
+ * the handle and every device array as it sits in HBM, each with a checksum; include_tables != 0 also stores whatever optional tables the handle
+ * holds at that moment (LF, k-step, interval, walk, prefix, locate tables, Format A expansion), so that a process start costs one read and one copy per
+ * array instead of a suffix sort and the table construction.  fmgpu_index_load creates the handle on the calling thread's current device; a file
+ * that is truncated, damaged (checksums), of another format / ABI version or byte order is refused with an error code and nothing is created.
+ * NOT the reference's cereal format: its byte layout for the mmser members cannot be pinned without a reference-written file. */
+int fmgpu_index_save(fmgpu_index_t h, const char* path, int32_t include_tables);
+int fmgpu_index_load(const char* path, fmgpu_index_t* out);
 
 /* The explicit LF mapping (one word per row and direction: LF(row) = C[s] + rank(row, s) of the row's own symbol s): one-load one-row
  * search nodes and locate steps, and what the walk tables are built from.  Built at creation unless FMGPU_LF_TABLE=0 is set in the

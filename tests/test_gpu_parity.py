@@ -1471,6 +1471,68 @@ def test_locate_answer_table(layout, sigma, rate):
     assert gx.device_bytes == before and all(np.array_equal(a, b) for a, b in zip(gx.locate(rows), want))
 
 
+@pytest.mark.parametrize("layout,sigma,bidir", [("IB16", 5, True), ("IB16", 5, False), ("WAVELET", 28, False), ("EPRV2_16", 5, True), ("EPR16", 6, False), ("IB16", 28, True)])
+def test_index_file_round_trip(layout, sigma, bidir, tmp_path):
+    """fmgpu_index_save -> fmgpu_index_load (the library's own flat file): the loaded handle answers exact search, k-mismatch search, locate and String_c
+    queries bit for bit like the one that was saved — plain, and with every optional table in the file; a damaged, truncated or foreign file is an
+    error code and no handle"""
+    seqs = repeat_text(5 + sigma, n=4000) if sigma == 5 else [make_text(3000, sigma, seed=sigma), make_text(500, sigma, seed=sigma + 1)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 8, bidir)
+    gx = gpu_index(ox)
+    queries = mutated_queries(seqs, 400, 8, 60, 1, seed=3, sigma=sigma)
+    qbuf, qoff = fm.flatten(queries)
+    rows = np.arange(0, ox.n, 3, dtype=np.uint64)
+    sch = fm.search_scheme.h2(3, 0, 1)
+
+    def answers(x):
+        out = [fm.search_no_errors.search(x, (qbuf, qoff)), x.locate(rows), (x.rank(rows, 1), x.prefix_rank(rows, sigma - 1), x.symbol(rows[:-1]))]
+        if bidir:
+            h = fm.search_ng26.search(x, (qbuf, qoff), sch)
+            out.append(tuple(h[k] for k in HIT_KEYS))
+        return out
+
+    def same(a, b):
+        return all(all(np.array_equal(u, v) for u, v in zip(p, q)) for p, q in zip(a, b))
+
+    want = answers(gx)
+    f1 = str(tmp_path / "plain.fmgpu")
+    gx.save(f1, tables=False)
+    lx = fm.FMIndex.load(f1)
+    assert type(lx) is (fm.BiFMIndex if bidir else fm.FMIndex) and (lx.n, lx.Sigma, lx.row_bits) == (gx.n, gx.Sigma, gx.row_bits)
+    assert same(answers(lx), want)
+    # with tables: whatever the handle holds when it is saved
+    gx.accelerate(2 if sigma <= 6 else 1, lut_len=3, walk=2)
+    if bidir:
+        gx.accelerate_search(4, 3)
+    gx.accelerate_locate()
+    f2 = str(tmp_path / "tables.fmgpu")
+    gx.save(f2, tables=True)
+    assert os.path.getsize(f2) > os.path.getsize(f1)
+    tx = fm.FMIndex.load(f2)
+    assert abs(tx.device_bytes - gx.device_bytes) < 4096 and same(answers(tx), want) and same(answers(gx), want)      # (the file also counts the tables' slack bytes)
+    tx.save(str(tmp_path / "again.fmgpu"), tables=True)           # a loaded handle saves to the same bytes
+    assert open(str(tmp_path / "again.fmgpu"), "rb").read() == open(f2, "rb").read()
+    # damage: one flipped payload byte (checksum), a cut file (trailer / short read), a foreign header
+    blob = bytearray(open(f1, "rb").read())
+    for name, data in (("flip", bytes(blob[:len(blob) // 2]) + bytes([blob[len(blob) // 2] ^ 0x40]) + bytes(blob[len(blob) // 2 + 1:])),
+                       ("cut", bytes(blob[:len(blob) - 24])), ("cut_more", bytes(blob[:len(blob) // 3])), ("foreign", b"CEREAL\0\0" + bytes(blob[8:]))):
+        bad = str(tmp_path / (name + ".fmgpu"))
+        open(bad, "wb").write(data)
+        with pytest.raises(fm.FmgpuError) as e:
+            fm.FMIndex.load(bad)
+        assert e.value.code == capi.FMGPU_ERR_INVALID, name
+    if layout == "IB16" and sigma == 5 and bidir:                 # 64-bit rows: its own file, refused by nothing but read by the wide build
+        os.environ["FMGPU_FORCE_WIDE"] = "1"
+        try:
+            wx = gpu_index(ox)
+        finally:
+            del os.environ["FMGPU_FORCE_WIDE"]
+        f3 = str(tmp_path / "wide.fmgpu")
+        wx.save(f3)
+        lw = fm.FMIndex.load(f3)
+        assert lw.row_bits == 64 and same(answers(lw), want)
+
+
 def test_index_create_argument_checks():
     text = make_text(500, 5, 3)
     ox = fo.OraIndex.build("IB16", 5, [text], 4, True)

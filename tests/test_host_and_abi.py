@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.fmgpu_abi_version() == 4
+    assert L.fmgpu_abi_version() == 5
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -51,6 +51,27 @@ def test_no_gpu_means_loud_failure_not_fallback():
     h = C.c_void_p()
     assert capi.lib().fmgpu_index_create(C.byref(d), C.byref(h)) == capi.FMGPU_ERR_NO_DEVICE
     assert b"no CPU fallback" in capi.lib().fmgpu_last_error()
+
+
+def test_index_file_errors_without_a_gpu(tmp_path):
+    """fmgpu_index_load refuses what is not an index file of this library before it touches a device: missing file, foreign bytes (e.g. a cereal archive
+    of the reference), a truncated header, another format version, another ABI version, the other byte order"""
+    L = capi.lib()
+    h = C.c_void_p()
+    assert L.fmgpu_index_load(None, C.byref(h)) == capi.FMGPU_ERR_INVALID
+    assert L.fmgpu_index_load(os.fsencode(tmp_path / "missing.idx"), C.byref(h)) == capi.FMGPU_ERR_INVALID and b"cannot open" in L.fmgpu_last_error()
+    assert L.fmgpu_index_save(None, b"/tmp/x", 1) == capi.FMGPU_ERR_INVALID
+    import struct
+    def header(magic=b"FMGPUIDX", version=1, abi=5, wide=0, probe=0x01020304):
+        return magic + struct.pack("<IIIIQQQQQ", version, abi, wide, probe, 0, 0, 0, 0, 0)
+    cases = [(b"\x01\x00\x00\x00cereal-like bytes" * 8, capi.FMGPU_ERR_INVALID, b"not an index file"), (header()[:40], capi.FMGPU_ERR_INVALID, b"truncated"),
+             (header(version=2), capi.FMGPU_ERR_UNSUPPORTED, b"format version"), (header(abi=4), capi.FMGPU_ERR_UNSUPPORTED, b"ABI version"),
+             (header(probe=0x04030201), capi.FMGPU_ERR_UNSUPPORTED, b"byte order"), (header(wide=7), capi.FMGPU_ERR_INVALID, b"row width")]
+    for k, (blob, code, msg) in enumerate(cases):
+        f = tmp_path / ("bad%d.idx" % k)
+        f.write_bytes(blob)
+        assert L.fmgpu_index_load(os.fsencode(f), C.byref(h)) == code and msg in L.fmgpu_last_error(), (k, L.fmgpu_last_error())
+        assert not h.value
 
 
 def test_argument_errors():
