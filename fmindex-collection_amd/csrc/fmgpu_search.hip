@@ -138,6 +138,8 @@ struct QueryReader {
 };
 
 template <int SIGMA>
+__device__ __noinline__ void lf0_pair(const OccA<SIGMA>& occ, idx_t a, idx_t b, idx_t& ra, idx_t& rb) { ra = occ.lf0_fused(a); rb = occ.lf0_fused(b); }
+template <int SIGMA>
 __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                  unsigned long long* __restrict__ steps_total) {
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
                 if (c >= sigma) { lb = 0; len = 0; break; }
                 const idx_t a = lb, b = lb + len;
                 idx_t ra, rb;
-                if (c == 0 && occ.v.fused) { occ.lf2(a, b, 0, ra, rb); acc += 2; }      // a delimiter in the query on a table whose entry 0 carries presence bits (rare)
+                if (c == 0 && occ.v.fused) { lf0_pair(occ, a, b, ra, rb); acc += 2; }   // a delimiter in the query on a table whose entry 0 carries presence bits (rare; out of line)
                 else {
                     EntryA ea = load_entry_a(occ.v, a, c);
                     EntryA eb = ea;
@@ -455,7 +457,7 @@ __device__ __forceinline__ uint64_t match_m(const uint64_t (&pl)[3], uint32_t va
 }
 // one level of the descent for both interval ends
 template <int D, int SHIFT, int FIRST>
-__device__ __forceinline__ void level_m(const ViewM& v, const uint64_t* s_off, uint32_t c, idx_t& a, idx_t& b, uint32_t& bytes, uint32_t& acc) {
+__device__ __forceinline__ void level_m(const ViewM& v, const uint64_t* s_off, const uint32_t* nsup, const uint64_t* sup, uint32_t c, idx_t& a, idx_t& b, uint32_t& bytes, uint32_t& acc) {
     constexpr uint32_t stride = D == 3 ? 64u : (D == 2 ? 32u : 16u);
     const uint32_t val = (c >> SHIFT) & ((1u << D) - 1u), node = (uint32_t)FIRST + (c >> (SHIFT + D));
     const uint8_t* nb = v.data + s_off[node];
@@ -466,23 +468,34 @@ __device__ __forceinline__ void level_m(const ViewM& v, const uint64_t* s_off, u
     else { cb = ca; pb[0] = pa[0]; pb[1] = pa[1]; pb[2] = pa[2]; }
     idx_t xa = ca + popc64(match_m<D>(pa, val) & lowmask((uint32_t)a & 63u));
     idx_t xb = cb + popc64(match_m<D>(pb, val) & lowmask((uint32_t)b & 63u));
-    if constexpr (kWide) {
-        const size_t row = v.node_super[node];
-        xa += (idx_t)v.super[(row + (size_t)(a >> kSuperShift)) * 8u + val];
-        xb += (idx_t)v.super[(row + (size_t)(b >> kSuperShift)) * 8u + val];
+    if constexpr (kWide) {                                          // counts are relative to super-blocks of 2^30 positions: the rest from the super table (LDS when it is small)
+        const size_t row = nsup[node];
+        xa += (idx_t)sup[(row + (size_t)(a >> kSuperShift)) * 8u + val];
+        xb += (idx_t)sup[(row + (size_t)(b >> kSuperShift)) * 8u + val];
     }
     a = xa; b = xb;
 }
 template <int D0, int D1, int D2>
 __global__ __launch_bounds__(256) void k_exact_m(ViewM v, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
                                                  uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len, unsigned long long* __restrict__ steps_total,
-                                                 uint32_t qwords) {
+                                                 uint32_t qwords, uint32_t super_rows) {
     extern __shared__ uint32_t s_query[];
     __shared__ uint64_t s_off[kMaxNodesM];
     __shared__ idx_t s_C[257];
+    // 64-bit rows: the super table (a few rows of 8 counts per node: 13 rows for 4.5 x 10^9 residues) and the nodes' first rows staged in LDS — from global
+    // memory they were two more dependent loads per level and interval end on the chain of every LF step (protein_wide 0.41-0.46 of the roofline vs 0.56 with 32-bit rows)
+    constexpr uint32_t kSuperLds = kWide ? 96u : 1u;
+    __shared__ uint64_t s_sup[kSuperLds * 8u];
+    __shared__ uint32_t s_nsup[kWide ? kMaxNodesM : 1];
     const uint32_t sigma = v.sigma;
     for (uint32_t i = threadIdx.x; i < v.nnodes; i += blockDim.x) s_off[i] = v.node_off[i];
     for (uint32_t i = threadIdx.x; i <= sigma; i += blockDim.x) s_C[i] = v.C[i];
+    const uint64_t* sup = nullptr; const uint32_t* nsup = nullptr;
+    if constexpr (kWide) {
+        for (uint32_t i = threadIdx.x; i < v.nnodes; i += blockDim.x) s_nsup[i] = v.node_super[i];
+        nsup = s_nsup; sup = v.super;
+        if (super_rows <= kSuperLds) { for (uint32_t i = threadIdx.x; i < super_rows * 8u; i += blockDim.x) s_sup[i] = v.super[i]; sup = s_sup; }
+    }
     __syncthreads();
     constexpr int BITCT = D0 + D1 + D2;
     const QStage qst{s_query, qwords, 0u};
@@ -498,9 +511,9 @@ __global__ __launch_bounds__(256) void k_exact_m(ViewM v, const uint8_t* __restr
             uint32_t c = qstage_get(qst, qs, i);
             ++steps;
             if (c >= sigma) { a = b = 0; break; }
-            level_m<D0, BITCT - D0, 0>(v, s_off, c, a, b, bytes, acc);
-            if constexpr (D1 > 0) level_m<D1, BITCT - D0 - D1, 1>(v, s_off, c, a, b, bytes, acc);
-            if constexpr (D2 > 0) level_m<D2, 0, 1 + (1 << D0)>(v, s_off, c, a, b, bytes, acc);
+            level_m<D0, BITCT - D0, 0>(v, s_off, nsup, sup, c, a, b, bytes, acc);
+            if constexpr (D1 > 0) level_m<D1, BITCT - D0 - D1, 1>(v, s_off, nsup, sup, c, a, b, bytes, acc);
+            if constexpr (D2 > 0) level_m<D2, 0, 1 + (1 << D0)>(v, s_off, nsup, sup, c, a, b, bytes, acc);
             a += s_C[c]; b += s_C[c];
             if (a == b) break;
         }
@@ -3139,17 +3152,18 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         if ((size_t)qw * 1024 > 48 * 1024) qw = 0;
         timer.start();
         const ViewM& vm = x->bwt.vm;
+        const uint32_t m_super_rows = kWide && x->bwt.sup_bytes ? (uint32_t)std::min<uint64_t>(0xffffffffu, (x->bwt.sup_bytes - ((uint64_t)vm.nnodes * 4 + 63) / 64 * 64) / 64) : 0u;
         auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
         const size_t lds = (size_t)qw * 1024;
         switch (vm.bitct) {                                      // the digits of digits_of() as template arguments
-        case 1: k_exact_m<1, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 2: k_exact_m<2, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 3: k_exact_m<3, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 4: k_exact_m<2, 2, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 5: k_exact_m<3, 2, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 6: k_exact_m<3, 3, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        case 7: k_exact_m<3, 2, 2><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
-        default: k_exact_m<3, 3, 2><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw); break;
+        case 1: k_exact_m<1, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
+        case 2: k_exact_m<2, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
+        case 3: k_exact_m<3, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
+        case 4: k_exact_m<2, 2, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
+        case 5: k_exact_m<3, 2, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
+        case 6: k_exact_m<3, 3, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
+        case 7: k_exact_m<3, 2, 2><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
+        default: k_exact_m<3, 3, 2><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
         }
     } else {
         rc = dispatch_occ(x->bwt, [&](auto occ, auto) {

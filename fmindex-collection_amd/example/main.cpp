@@ -189,10 +189,119 @@ struct StopWatch {
     }
 };
 
+// ---- one run of the harness ---------------------------------------------------------------------------------------------------------
+// What the reference's main loop does for one (algorithm, k) pair, in this order: search (every reported cursor is a Hit), locate every row of
+// every cursor (one batched device call here; the rows and their order are those of the per-cursor LocateLinear loops), count, print the
+// statistics line, write the optional output file.
+constexpr size_t Sigma = 5;                                      // $ A C G T (src/example/utils.h:81-85)
+using Index = fmc::BiFMIndex<Sigma, fmc::string::InterleavedBitvector16>;
+enum class Algorithm { ng21, ng26, noerror };
+
+Algorithm algorithmByName(std::string const& name) {
+    if (name == "ng21") return Algorithm::ng21;
+    if (name == "ng26") return Algorithm::ng26;
+    if (name == "noerror") return Algorithm::noerror;
+    throw std::runtime_error("algorithm \"" + name + "\" is not part of this build (available: ng21, ng26, noerror)");
+}
+
+Index openIndex(Options const& config) {
+    std::printf("start loading %s ...", "str");                  // (the one String of the example: InterleavedBitvector16)
+    std::fflush(stdout);
+    auto reference = readFasta(config.referenceFasta, Sigma, config.unknownToA);
+    if (reference.empty()) throw std::runtime_error("no sequences in --index " + config.referenceFasta);
+    Index index{reference, /*samplingRate*/ 16, /*threads*/ 1};   // built on the GPU at every start (seconds for a human genome)
+    std::printf("done\n");
+    return index;
+}
+
+struct Hit { size_t read; uint64_t firstRow, rows; size_t errors; };
+struct Placement {
+    size_t read, sequence, position, errors;
+    bool operator<(Placement const& o) const { return std::tie(read, sequence, position, errors) < std::tie(o.read, o.sequence, o.position, o.errors); }
+    bool operator==(Placement const& o) const { return std::tie(read, sequence, position, errors) == std::tie(o.read, o.sequence, o.position, o.errors); }
+};
+
+struct Run {
+    Options const& config;
+    Index index;
+
+    std::vector<Hit> search(Algorithm kind, size_t k, std::vector<std::vector<uint8_t>> const& reads) const {
+        std::vector<Hit> hits;
+        auto collect = [&](size_t read, auto const& cursor, size_t errors) { hits.push_back({read, cursor.lb, cursor.len, errors}); };
+        size_t const perRead = config.hitsPerRead == 0 ? std::numeric_limits<size_t>::max() : config.hitsPerRead;
+        auto schemesUpTo = [&](auto&& make) {                      // best-hit modes try 0, 1, .. k errors in turn
+            using T = decltype(make(size_t{}));
+            std::vector<T> list;
+            for (size_t j = 0; j <= k; ++j) list.push_back(make(j));
+            return list;
+        };
+        switch (kind) {
+        case Algorithm::noerror:
+            fmc::search_no_errors::search(index, reads, [&](size_t read, auto const& cursor) { collect(read, cursor, 0); });
+            break;
+        case Algorithm::ng26: {
+            if (config.hitMode == HitMode::all) fmc::search_ng26::search<true>(index, reads, schemeByName(config.schemeName, 0, k), {}, collect, perRead);
+            else fmc::search_ng26::search_best<true>(index, reads, schemesUpTo([&](size_t j) {
+                     return std::tuple<fmc::search_scheme::Scheme, std::vector<size_t>>{schemeByName(config.schemeName, j, j), {}}; }), collect, perRead);
+            break;
+        }
+        case Algorithm::ng21: {
+            size_t const len = reads[0].size();
+            if (config.hitMode == HitMode::all) {
+                auto const expanded = fmc::search_scheme::expand(schemeByName(config.schemeName, 0, k), len);
+                if (config.hitsPerRead == 0) fmc::search_ng21::search(index, reads, expanded, collect);
+                else fmc::search_ng21::search_n(index, reads, expanded, config.hitsPerRead, collect);
+            } else {
+                auto const ladder = schemesUpTo([&](size_t j) { return fmc::search_scheme::expand(schemeByName(config.schemeName, j, j), len); });
+                if (config.hitsPerRead == 0) fmc::search_ng21::search_best(index, reads, ladder, collect);
+                else fmc::search_ng21::search_best_n(index, reads, ladder, config.hitsPerRead, collect);
+            }
+            break;
+        }
+        }
+        return hits;
+    }
+
+    std::vector<Placement> locate(std::vector<Hit> const& hits) const {
+        std::vector<uint64_t> rows;
+        for (auto const& h : hits) for (uint64_t r = 0; r < h.rows; ++r) rows.push_back(h.firstRow + r);
+        auto const where = index.locate(rows);
+        std::vector<Placement> placed;
+        placed.reserve(rows.size());
+        size_t at = 0;
+        for (auto const& h : hits)
+            for (uint64_t r = 0; r < h.rows; ++r, ++at) {
+                auto const& [sequence, sampled, walked] = where[at];
+                placed.push_back({h.read, sequence, sampled + walked, h.errors});
+            }
+        return placed;
+    }
+
+    void oneErrorBudget(Algorithm kind, size_t k, std::vector<std::vector<uint8_t>> const& reads) const {
+        StopWatch clock;
+        auto const hits = search(kind, k, reads);
+        double const tSearch = clock.reset();
+        auto const placed = locate(hits);
+        double const tLocate = clock.reset();
+
+        auto distinct = placed;
+        std::sort(distinct.begin(), distinct.end());
+        distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+        std::unordered_set<size_t> readsWithHits;                  // a read and its reverse complement (second half of the batch) count once
+        for (auto const& h : hits) readsWithHits.insert(h.read > reads.size() / 2 ? h.read - reads.size() / 2 : h.read);
+        std::printf("%-15s %3zu: %10.3gs (%10.3gs+%10.3gs) %10.3gq/s - results: %10zu/%10zu/%10zu/%10zu - mem: %13zu\n", "str", k, tSearch + tLocate, tSearch, tLocate,
+                    reads.size() / (tSearch + tLocate), placed.size(), placed.size(), distinct.size(), readsWithHits.size(), size_t{0});
+        if (config.outputFile.empty()) return;
+        auto* out = std::fopen(config.outputFile.c_str(), "w");
+        if (!out) throw std::runtime_error("cannot write " + config.outputFile);
+        for (auto const& p : placed) std::fprintf(out, "%zu %zu %zu\n", p.read, p.sequence, p.position);
+        std::fclose(out);
+    }
+};
+
 }  // namespace
 
 int main(int argc, char const* const* argv) try {
-    constexpr size_t Sigma = 5;
     auto config = parseCommandLine(argc, argv);
     if (config.wantHelp) {
         std::printf("Usage:\n"
@@ -215,104 +324,21 @@ int main(int argc, char const* const* argv) try {
         return 0;
     }
     if (config.schemeDyn) throw std::runtime_error("the _dyn generators (expandByWNC) are not part of this build");
-    auto const forward = readFasta(config.readsFasta, Sigma, config.unknownToA);
-    auto const queries = config.withReverseComplement ? withReverseComplements(forward) : forward;
-    if (!queries.empty()) {
-        std::printf("loaded %zu queries (incl reverse complements)\n", queries.size());
+    auto reads = readFasta(config.readsFasta, Sigma, config.unknownToA);
+    if (config.withReverseComplement) reads = withReverseComplements(reads);
+    if (!reads.empty()) {
+        std::printf("loaded %zu queries (incl reverse complements)\n", reads.size());
         std::printf("%-15s: %10s  (%10s +%10s ) %10s    - results: %10s/%10s/%10s/%10s - mem: %13s\n", "name", "time_search + time_locate", "time_search",
                     "time_locate", "(time_search+time_locate)/queries.size()", "resultCt", "results.size()", "uniqueResults.size()", "readIds.size()", "memory");
     }
-
-    std::string name = "str";                                     // visitAllStrings: the one String of the example, InterleavedBitvector16 (utils.h:262-265)
-    std::printf("start loading %s ...", name.c_str());
-    std::fflush(stdout);
-    size_t samplingRate = 16;
-    using Index = fmc::BiFMIndex<Sigma, fmc::string::InterleavedBitvector16>;
-    auto index = [&]() {                                          // loadDenseIndex, utils.h:150-259 (always the build branch)
-        auto ref = readFasta(config.referenceFasta, Sigma, config.unknownToA);
-        if (ref.empty()) throw std::runtime_error("no sequences in --index " + config.referenceFasta);
-        return Index{ref, samplingRate, 1};
-    }();
-    std::printf("done\n");
-
+    Run run{config, openIndex(config)};
+    if (config.readLimit != 0 && reads.size() > config.readLimit) reads.resize(config.readLimit);
+    if (config.trimTo != 0) for (auto& r : reads) if (r.size() > config.trimTo) r.resize(config.trimTo);
     for (auto const& algorithm : config.algorithms) {
         std::printf("using algorithm %s\n", algorithm.c_str());
-        if (algorithm != "ng21" && algorithm != "ng26" && algorithm != "noerror")
-            throw std::runtime_error("algorithm \"" + algorithm + "\" is not part of this build (available: ng21, ng26, noerror)");
-        auto mut_queries = queries;
-        if (config.readLimit != 0) mut_queries.resize(std::min(mut_queries.size(), config.readLimit));
-        if (config.trimTo != 0) for (auto& q : mut_queries) q.resize(std::min(config.trimTo, q.size()));
-        if (mut_queries.empty()) continue;
-
-        for (size_t k{config.firstK}; k <= config.lastK; k = k + config.stepK) {
-            auto len = mut_queries[0].size();
-            auto oss = schemeByName(config.schemeName, 0, k);
-            auto search_scheme = fmc::search_scheme::expand(oss, len);
-            auto search_schemes = std::vector<fmc::search_scheme::Scheme>{};
-            for (size_t j{0}; j <= k; ++j) search_schemes.emplace_back(fmc::search_scheme::expand(schemeByName(config.schemeName, j, j), len));
-
-            size_t resultCt{};
-            StopWatch sw;
-            auto results = std::vector<std::tuple<size_t, size_t, size_t, size_t>>{};
-            auto resultCursors = std::vector<std::tuple<size_t, fmc::BiFMIndexCursor<Index>, size_t>>{};
-            auto res_cb = [&](size_t queryId, auto cursor, size_t errors) { resultCursors.emplace_back(queryId, cursor, errors); };
-
-            if (algorithm == "ng21") {                            // main.cpp:176-185
-                if (config.hitMode == HitMode::all) {
-                    if (config.hitsPerRead == 0) fmc::search_ng21::search(index, mut_queries, search_scheme, res_cb);
-                    else fmc::search_ng21::search_n(index, mut_queries, search_scheme, config.hitsPerRead, res_cb);
-                } else {
-                    if (config.hitsPerRead == 0) fmc::search_ng21::search_best(index, mut_queries, search_schemes, res_cb);
-                    else fmc::search_ng21::search_best_n(index, mut_queries, search_schemes, config.hitsPerRead, res_cb);
-                }
-            } else if (algorithm == "ng26") {
-                auto n = config.hitsPerRead == 0 ? std::numeric_limits<size_t>::max() : config.hitsPerRead;
-                if (config.hitMode == HitMode::all) fmc::search_ng26::search<true>(index, mut_queries, oss, {}, res_cb, n);
-                else {
-                    auto list = std::vector<std::tuple<fmc::search_scheme::Scheme, std::vector<size_t>>>{};
-                    for (size_t j{0}; j <= k; ++j) list.emplace_back(schemeByName(config.schemeName, j, j), std::vector<size_t>{});
-                    fmc::search_ng26::search_best<true>(index, mut_queries, list, res_cb, n);
-                }
-            } else {                                              // noerror, main.cpp:213-215
-                fmc::search_no_errors::search(index, mut_queries, [&](size_t queryId, auto cursor) { res_cb(queryId, cursor, 0); });
-            }
-            auto time_search = sw.reset();
-
-            {   // main.cpp:236-243: LocateLinear over every cursor, here as one batched locate of all their rows
-                std::vector<uint64_t> rows;
-                for (auto const& [queryId, cursor, e] : resultCursors) {
-                    for (size_t r = 0; r < cursor.len; ++r) rows.push_back(cursor.lb + r);
-                    resultCt += cursor.len;
-                }
-                auto located = index.locate(rows);
-                results.reserve(rows.size());
-                size_t at = 0;
-                for (auto const& [queryId, cursor, e] : resultCursors)
-                    for (size_t r = 0; r < cursor.len; ++r, ++at) {
-                        auto [seqId, pos, offset] = located[at];
-                        results.emplace_back(queryId, seqId, pos + offset, e);
-                    }
-            }
-            auto time_locate = sw.reset();
-
-            auto uniqueResults = results;
-            std::sort(uniqueResults.begin(), uniqueResults.end());
-            uniqueResults.erase(std::unique(uniqueResults.begin(), uniqueResults.end()), uniqueResults.end());
-            std::unordered_set<size_t> readIds;
-            for (auto const& [queryId, cursor, e] : resultCursors) {   // main.cpp:251-258
-                if (queryId > mut_queries.size() / 2) readIds.insert(queryId - mut_queries.size() / 2);
-                else readIds.insert(queryId);
-            }
-            std::printf("%-15s %3zu: %10.3gs (%10.3gs+%10.3gs) %10.3gq/s - results: %10zu/%10zu/%10zu/%10zu - mem: %13zu\n", name.c_str(), k,
-                        time_search + time_locate, time_search, time_locate, mut_queries.size() / (time_search + time_locate), resultCt, results.size(),
-                        uniqueResults.size(), readIds.size(), size_t{0});
-            if (!config.outputFile.empty()) {
-                auto ofs = std::fopen(config.outputFile.c_str(), "w");
-                if (!ofs) throw std::runtime_error("cannot write " + config.outputFile);
-                for (auto const& [queryId, seqId, pos, e] : results) std::fprintf(ofs, "%zu %zu %zu\n", queryId, seqId, pos);
-                std::fclose(ofs);
-            }
-        }
+        auto const kind = algorithmByName(algorithm);
+        if (reads.empty()) continue;
+        for (size_t k = config.firstK; k <= config.lastK; k += config.stepK) run.oneErrorBudget(kind, k, reads);
     }
     return 0;
 } catch (std::exception const& e) {

@@ -1648,9 +1648,10 @@ def test_full_size_k2_records_equal_the_cpu_walk():
     n = int(text.numel())
     seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64))])).to(dev)
     g = torch.Generator(device=dev); g.manual_seed(11)
-    batches = {}
+    batches, origins = {}, {}
     for L, nq in ((101, 100_000), (151, 100_000)):
         starts = torch.randint(0, n - L, (nq,), generator=g, device=dev, dtype=torch.int64)
+        origins[L] = starts.cpu().numpy()
         reads = text[starts[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
         rows = torch.arange(nq, device=dev)
         for k in range(2):                                     # 0 / 1 / 2 substitutions
@@ -1679,6 +1680,26 @@ def test_full_size_k2_records_equal_the_cpu_walk():
             assert st.lf_steps == onodes, (tag, L, st.lf_steps, onodes)
             assert same_hits(hits, oh), (tag, L)
     check("plain index")
+    # An anchor that does not pass through the GPU-built BWT the oracle was fed: every read was cut from the TEXT at a known offset with <= 2
+    # substitutions, so that offset must be among the located positions of its e <= 2 hits (reads that straddle two sequences, and the few
+    # reads of high-copy repeats whose hits cover more than 4096 rows, are left out)
+    seq_off_h = seq_off.cpu().numpy()
+    for L, (hq, ho) in batches.items():
+        nq_a = 3000
+        hits = fm.search_ng26.search(gx, (hq[: nq_a * L], ho[: nq_a + 1]), sch)
+        org = origins[L][:nq_a]
+        inside = seq_off_h[np.searchsorted(seq_off_h, org, side="right")] >= org + L        # the read lies within one sequence
+        per_read = np.bincount(hits["qidx"].astype(np.int64), weights=hits["len"].astype(np.float64), minlength=nq_a)
+        use = inside & (per_read <= 4096)
+        hsel = hits[use[hits["qidx"].astype(np.int64)]]
+        owner = np.repeat(hsel["qidx"].astype(np.int64), hsel["len"].astype(np.int64))
+        first = np.repeat(hsel["lb"].astype(np.int64), hsel["len"].astype(np.int64))
+        within = np.arange(owner.size) - np.repeat(np.cumsum(hsel["len"].astype(np.int64)) - hsel["len"].astype(np.int64), hsel["len"].astype(np.int64))
+        seq, pos, steps = gx.locate((first + within).astype(np.uint64))
+        tpos = seq_off_h[seq.astype(np.int64)] + pos.astype(np.int64) + steps.astype(np.int64)
+        found = np.zeros(nq_a, dtype=bool)
+        np.logical_or.at(found, owner, tpos == org[owner])
+        assert use.sum() > nq_a * 0.9 and bool(found[use].all()), (L, int(use.sum()), int((~found[use]).sum()))
     gx.accelerate_lf(True)
     check("LF tables")
     for accel in ((11, 1), (0, 2), (16, 3)):
