@@ -2336,11 +2336,12 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
 //     block end (the entry of the delimiter is derived: a query that holds a 0 takes a slow path), no table paths, no quota:
 //   72 registers and 21 KB of LDS per block at 101 bp = 7 resident blocks per CU.
 // Path keys, sharing of the bottom frame between the lanes of a wave, heavy reads first: as in k_scheme_fast.
-constexpr uint32_t kRingCap = 96;        // hit records a wave keeps in LDS ...
-constexpr uint32_t kRingFlush = 32;      // ... written out as soon as there are this many: 64 more (one per lane and iteration) always fit
+constexpr uint32_t kRingCap = 160;       // hit records a wave keeps in LDS ...
+constexpr uint32_t kRingFlush = 32;      // ... written out as soon as there are this many: 128 more always fit; a pass (kLeanSteps node steps) that reports more sends the excess out one by one
 constexpr uint32_t kRingWords = 6;       // qidx, lb, lbRev, len, errors | key high, key low
 constexpr uint32_t kLeanNoResume = 7u;
 constexpr int kLeanWaves = 6;            // resident blocks per CU the kernel is built for
+constexpr int kLeanSteps = 4;            // node steps per pass through the wave-synchronous part (genome text, kernel ms at 101 / 151 bp: 1 step 119 / 213, 2: 114 / 195, 4: 112 / 183)
 
 struct LeanArgs {
     const uint8_t* fw; const uint8_t* rv;    // Format A blocks of bwt / bwtRev (64 bytes per 64 rows)
@@ -2396,7 +2397,7 @@ __device__ __forceinline__ bool stage2_sync(uint32_t* lds, const uint8_t* __rest
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ void ring_flush(lds_u32* s_cnt_w, const uint32_t* ring, uint32_t lane, fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr) {   // all lanes call
-    const uint32_t total = __hip_atomic_load(s_cnt_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const uint32_t total = min(__hip_atomic_load(s_cnt_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT), kRingCap);      // (appends beyond the ring went out one by one)
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(&ctr->hits, (unsigned long long)total);
     base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0, 64) << 32) | __shfl((uint32_t)base, 0, 64);
@@ -2412,10 +2413,12 @@ __device__ __forceinline__ void ring_flush(lds_u32* s_cnt_w, const uint32_t* rin
     if (lane == 0) __hip_atomic_store(s_cnt_w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-template <int WAVES>      // waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
+// NSTEP: nodes a lane visits per pass through the wave-synchronous part (work sharing, refill, ring flush: ~150 of the ~550 wave instructions of an
+// iteration — the loop is bound by instruction issue): a lane that runs out of work inside the inner loop waits for the next pass
+template <int WAVES, int NSTEP>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
 __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t n,
                                                              fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, ulonglong2* __restrict__ frames, uint64_t nlanes,
-                                                             uint32_t qwords, const uint32_t* __restrict__ qmap) {
+                                                             uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste) {
     extern __shared__ uint32_t s_dyn[];                             // [qwords][256] staged reads | [256] top frames (16 B) | [S][m + 1] steps | [4] ring fill | 4 x [kRingWords][kRingCap] rings
     const uint32_t S = la.S, m = la.m, stride = la.m + 1;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -2434,7 +2437,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     bool have = false, exhausted = n == 0, need_start = false, is_task = false, odd = false, in_tail = false;
     uint32_t q = 0, si = 0, e = 0, j = 0, sp = 0, sbase = 0, resume = kLeanNoResume;
     uint32_t lb = 0, lbRev = 0, len = 0;
-    uint64_t pkey = 0;
+    uint32_t k1 = 0, k2 = 0;                                        // path key fields of the 1st / 2nd substitution on the lane's path: (m - step) << 8 | symbol, 0 = none (key_with / key_prefix)
     // Order of the top-frame slot's accesses.  The slot is refilled by an LDS-DMA load issued at the END of an iteration (after a pop); every other
     // access of the slot in the node phase (push, pop) comes after the lane has consumed its block loads of that iteration, which were issued after the
     // DMA: vector-memory operations of a wave complete in order, so the DMA has landed.  The one access outside the node phase (handing the only
@@ -2458,7 +2461,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                         const u32x4 t = *tos_slot;
                         w0 = (uint64_t)t.x | ((uint64_t)t.y << 32); w1 = (uint64_t)t.z | ((uint64_t)t.w << 32);
                     }
-                    w2 = key_prefix(pkey, (uint32_t)(w1 >> 48) & 0xffu);
+                    { const uint32_t fe = (uint32_t)(w1 >> 48) & 0xffu; w2 = ((uint64_t)(fe >= 1u ? k1 : 0u) << 32) | (fe >= 2u ? k2 : 0u); }      // the key of the frame's node: the fields of later substitutions cleared
                     ++sbase; mark = nodes;
                 }
                 uint64_t om = offerm;
@@ -2470,7 +2473,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                     q = tq; si = tsi; odd = todd != 0u;
                     lb = (uint32_t)tw0; lbRev = (uint32_t)(tw0 >> 32); len = (uint32_t)tw1;
                     j = (uint32_t)(tw1 >> 32) & 0xffffu; e = (uint32_t)(tw1 >> 48) & 0xffu; resume = (uint32_t)(tw1 >> 56) & 0xffu;
-                    pkey = tw2;
+                    k1 = (uint32_t)(tw2 >> 32); k2 = (uint32_t)tw2;
                     const uint32_t vt = (tid & ~63u) | (uint32_t)vl;
                     for (uint32_t w = 0; w < qwords; ++w) s_dyn[w * 256u + tid] = s_dyn[w * 256u + vt];     // the partner's staged read
                     have = true; is_task = true; need_start = false; sp = 0; sbase = 0; in_tail = false; mark = nodes;
@@ -2480,7 +2483,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         {
             const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
             waste += (uint32_t)__popcll(needm);
-            if (needm && (waste >= kRefillWaste || !busym)) {
+            if (needm && (waste >= refill_waste || !busym)) {
                 waste = 0;
                 const bool want = !have && !exhausted;
                 bool fresh = false; uint64_t qo = 0;
@@ -2501,12 +2504,14 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             if (filled >= kRingFlush || (!busy && filled)) ring_flush(s_cnt_w, ring, lane, out, cap, ctr);
             if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
         }
+#pragma unroll 1
+        for (int step = 0; step < NSTEP; ++step) {
         if (!have) continue;
         // ---- one node per lane
         if (need_start) {                                           // search_impl (SearchNg26.h:385-390) -> run(): :62-79
             need_start = false;
             lb = 0; lbRev = 0; len = n; e = 0; j = 0; sp = 0; sbase = 0; resume = kLeanNoResume; in_tail = false;
-            pkey = (uint64_t)si << 48;
+            k1 = 0; k2 = 0;
         }
         const uint32_t ent = s_steps[si * stride + j];
         const bool right = (ent >> 16) & 1u, multi = len > 1u;
@@ -2535,7 +2540,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             const uint32_t d1 = b0.x + __popc(b0.y & mb_lo) + __popc(b0.z & mb_hi) - la1, d2 = b0.w + __popc(b1.x & mb_lo) + __popc(b1.y & mb_hi) - la2;
             const uint32_t d3 = b1.z + __popc(b1.w & mb_lo) + __popc(b2.x & mb_hi) - la3, d4 = b2.y + __popc(b2.z & mb_lo) + __popc(b2.w & mb_hi) - la4;
             const uint32_t d0 = len - (d1 + d2 + d3 + d4);          // rows of the interval that hold the delimiter
-            const uint32_t alive = (d0 ? 1u : 0u) | (d1 ? 2u : 0u) | (d2 ? 4u : 0u) | (d3 ? 8u : 0u) | (d4 ? 16u : 0u);
+            const uint32_t alive = min(d0, 1u) | (min(d1, 1u) << 1) | (min(d2, 1u) << 2) | (min(d3, 1u) << 3) | (min(d4, 1u) << 4);
             const bool resuming = resume != kLeanNoResume;
             uint32_t subs = alive & ~1u & ~(c < 5u ? 1u << c : 0u);  // substitution children: FirstSymb = 1 (fmindex/BiFMIndex.h:26), != query symbol
             if (!sOK) subs = 0u;
@@ -2560,7 +2565,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 else if (take == 0u) { kla = a + la.ksum - (la1 + la2 + la3 + la4); kd = d0; pre = 0u; }   // a delimiter in the QUERY matched against delimiter rows: the ranks of all symbols at a add up to a
                 len = kd;
                 if (right) { lbRev = kla; lb += pre; } else { lb = kla; lbRev += pre; }     // fmindex/BiFMIndexCursor.h:58-82
-                if (take_sub) { pkey = key_with(pkey, e, m, j, take); e += 1u; }
+                if (take_sub) { const uint32_t kf = ((m - j) << 8) | take; if (e == 0u) k1 = kf; else if (e == 1u) k2 = kf; e += 1u; }
                 in_tail = !lastp && (in_tail || (take_match && !xOK));
                 ++j;
             } else back = true;
@@ -2577,7 +2582,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             bool dead = false;
             if (row_sym < 1u) dead = true;                          // :295-297: a delimiter row ends the walk
             else if (row_sym == c) { if (!mOK) dead = true; }
-            else if (sOK) { pkey = key_with(pkey, e, m, j, row_sym); e += 1u; }
+            else if (sOK) { const uint32_t kf = ((m - j) << 8) | row_sym; if (e == 0u) k1 = kf; else if (e == 1u) k2 = kf; e += 1u; }
             else dead = true;
             if (dead) back = true;
             else { in_tail = !lastp && (in_tail || (is_match && !xOK)); if (right) lbRev = t0; else lb = t0; ++j; }
@@ -2585,9 +2590,12 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         if (!back && j == m) {                                      // search_next at part == P (:101-108)
             const uint32_t fin = s_steps[si * stride + m];
             if (((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x3fu)) {
-                const uint32_t slot = __hip_atomic_fetch_add(s_cnt_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // < kRingCap: the wave flushes at kRingFlush and appends one record per lane and iteration at most
-                ring[slot] = q; ring[kRingCap + slot] = lb; ring[2u * kRingCap + slot] = lbRev; ring[3u * kRingCap + slot] = len;
-                ring[4u * kRingCap + slot] = e | ((uint32_t)(pkey >> 32) << 8); ring[5u * kRingCap + slot] = (uint32_t)pkey;
+                const uint32_t slot = __hip_atomic_fetch_add(s_cnt_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const uint32_t kw = e | ((si << 16 | k1 >> 8) << 8), ks = (k1 << 24) | k2;    // path key = si:8 | k1:24 | k2:24 (key_with): errors word carries its upper 24 bits, seq the lower 32
+                if (slot < kRingCap) {                              // the wave flushes at kRingFlush and appends at most 64 NSTEP records per pass: room unless NSTEP > 2
+                    ring[slot] = q; ring[kRingCap + slot] = lb; ring[2u * kRingCap + slot] = lbRev; ring[3u * kRingCap + slot] = len;
+                    ring[4u * kRingCap + slot] = kw; ring[5u * kRingCap + slot] = ks;
+                } else emit_hit(out, cap, ctr, q, Cur{lb, lbRev, len}, kw, ks);
             }
             back = true;
         }
@@ -2599,7 +2607,8 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 const u32x4 t = *tos_slot;                          // the cached top frame ...
                 lb = t.x; lbRev = t.y; len = t.z;
                 j = t.w & 0xffffu; e = (t.w >> 16) & 0xffu; resume = t.w >> 24;
-                pkey = key_prefix(pkey, e);
+                if (e == 0u) k1 = 0u;                                // the key of the popped node: the fields of later substitutions cleared
+                if (e <= 1u) k2 = 0u;
                 in_tail = false;
                 uint32_t g = gid; asm volatile("" : "+v"(g));
                 if (sp > sbase)                                     // ... and the one below it, requested an iteration before it can be needed, straight into the slot
@@ -2613,6 +2622,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             else if (si == S) have = false;
             else need_start = true;
         }
+        }   // NSTEP
     }
     const uint32_t tot = wave_sum(nodes);
     if (lane == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
@@ -3420,13 +3430,14 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(key); if (it != occ_cache.end()) { bpc = it->second; known = true; } }
         if (!known) {
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scheme_lean<kLeanWaves>, 256, lean_lds) == hipSuccess && nb > 0) bpc = nb; else { (void)hipGetLastError(); bpc = 4; }
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scheme_lean<kLeanWaves, kLeanSteps>, 256, lean_lds) == hipSuccess && nb > 0) bpc = nb; else { (void)hipGetLastError(); bpc = 4; }
             std::lock_guard<std::mutex> g(occ_mu); occ_cache[key] = bpc;
         }
-        // measured on the genome-like text, 10 M x 101 bp (kernel ms): 7 / 6 / 5 / 4 resident blocks per CU = 141 / 126 / 120 / 118 (151 bp: 212 / 211 / 210 / 204) — the
-        // loop is bound by instruction issue (rocprofv3: ~550 wave instructions per iteration, the waves of a SIMD active 100 % of its time at 4 per SIMD;
-        // at 7 they spend 48 % of their cycles waiting to issue), so more resident waves only add contention
-        bpc = std::min(bpc, 4);
+        // measured on the genome-like text, 10 M x 101 bp (kernel ms): 7 / 6 / 5 / 4 resident blocks per CU = 141 / 126 / 120 / 118 (151 bp: 212 / 211 / 210 / 204); with
+        // 4 node steps per pass 4 / 3 / 2 blocks = 111 / 106-108 / 134 (151 bp: 189 / 180-182 / 221) — the loop is bound by instruction issue (rocprofv3: ~550
+        // wave instructions per iteration, the waves of a SIMD active 100 % of its time at 4 per SIMD; at 7 they spend 48 % of their cycles waiting to
+        // issue), so resident waves beyond the 3-4 that keep the issue port busy only add contention
+        bpc = std::min(bpc, 3);
     }
     // k_scheme_fast<PLAIN> runs best with 4 resident blocks per CU (measured on the genome-like text, 10 M x 101 bp: 2 / 3 / 4 / 5 blocks =
     // 197 / 159 / 150 / 159 ms): a fifth block adds issue contention and cache pressure, not throughput
@@ -3473,8 +3484,15 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             } else if (lean) {
                 LeanArgs la{x->bwt.va.blk, x->rev.va.blk, fa.steps, (uint32_t)sd.S, b.m, (uint32_t)(x->hC[1] + x->hC[2] + x->hC[3] + x->hC[4])};
                 const size_t lds_lean = (size_t)lean_qwords * 1024 + 4096 + (b.tab.size() / 3) * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;
-                k_scheme_lean<kLeanWaves><<<g, block, lds_lean, stream>>>(la, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (uint32_t)n, (fmgpu_hit*)sout.dev, capacity,
-                                                                         ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes, lean_qwords, qm);
+                uint32_t waste = kRefillWaste; int steps = kLeanSteps;
+                if (const char* ev = dev_env("FMGPU_DEV_LEAN_WASTE")) waste = (uint32_t)std::max(1, atoi(ev));
+                if (const char* ev = dev_env("FMGPU_DEV_LEAN_STEPS")) steps = atoi(ev);
+                auto launch = [&](auto kern) { kern<<<g, block, lds_lean, stream>>>(la, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (uint32_t)n, (fmgpu_hit*)sout.dev, capacity,
+                                                                                 ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes, lean_qwords, qm, waste); };
+#ifdef FMGPU_DEV
+                if (steps == 1) launch(k_scheme_lean<kLeanWaves, 1>); else if (steps == 2) launch(k_scheme_lean<kLeanWaves, 2>); else if (steps == 8) launch(k_scheme_lean<kLeanWaves, 8>); else
+#endif
+                launch(k_scheme_lean<kLeanWaves, kLeanSteps>);
             } else if (x->bwt.sigma == 5 && !have_lf)
                 k_scheme_fast<5, 5, true><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                           b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
