@@ -2323,6 +2323,8 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     }
 }
 
+#endif  // !FMGPU_WIDE (the table-driven kernels)
+
 // ---- search_ng26 Hamming on the PLAIN index (sigma = 5, no table of any kind): the lean kernel -----------------------------------------
 // k_scheme_fast<5, 5, PLAIN> carries the frame of the table-driven kernel; on the plain index it ran at 0.47 of the HBM roofline,
 // bound by latency at 5 waves per SIMD: per iteration a wave paid (a) the pop of a frame from its stack in HBM and then, dependent on it, (b) the
@@ -2334,21 +2336,48 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
 //   * hit records appended to a ring per WAVE in LDS (slot by LDS atomic) and written out with one reservation per >= kRingFlush records;
 //   * reads staged with 2 bits per symbol (a read with a byte outside 1..4 is read from global memory instead), 12 instead of 16 dwords per
 //     block end (the entry of the delimiter is derived: a query that holds a 0 takes a slow path), no table paths, no quota:
-//   72 registers and 21 KB of LDS per block at 101 bp = 7 resident blocks per CU.
+//   ~76 registers and 27 KB of LDS per block at 101 bp.
 // Path keys, sharing of the bottom frame between the lanes of a wave, heavy reads first: as in k_scheme_fast.
+// Both row widths.  With 64-bit rows (n < 2^38, reads of <= 255 symbols) a 16-byte frame holds lb:38 | lbRev:38 | len:38 | step:8 | errors:3 | next sibling:3,
+// the counts of a block are relative to its super-block of 2^30 rows (the super table, a few hundred bytes, is staged in LDS), a hit record takes 7 words.
 constexpr uint32_t kRingCap = 160;       // hit records a wave keeps in LDS ...
 constexpr uint32_t kRingFlush = 32;      // ... written out as soon as there are this many: 128 more always fit; a pass (kLeanSteps node steps) that reports more sends the excess out one by one
-constexpr uint32_t kRingWords = 6;       // qidx, lb, lbRev, len, errors | key high, key low
+constexpr uint32_t kRingWords = kWide ? 7u : 6u;   // qidx, lb, lbRev, len, errors | key high, key low (, the rows' bits 32..39)
+constexpr uint32_t kLeanRefillWaste = 2048;        // (kRefillWaste of k_scheme_fast)
+constexpr uint32_t kLeanSuperRows = kWide ? 64u : 1u;   // super-block rows per direction staged in LDS (64 x 2^30 rows: more than HBM holds)
 constexpr uint32_t kLeanNoResume = 7u;
-constexpr int kLeanWaves = 6;            // resident blocks per CU the kernel is built for
+constexpr int kLeanWaves = kWide ? 4 : 6;   // resident blocks per CU the register allocation allows (the grid asks for 3; 64-bit rows need ~100 registers)
 constexpr int kLeanSteps = 4;            // node steps per pass through the wave-synchronous part (genome text, kernel ms at 101 / 151 bp: 1 step 119 / 213, 2: 114 / 195, 4: 112 / 183)
 
 struct LeanArgs {
     const uint8_t* fw; const uint8_t* rv;    // Format A blocks of bwt / bwtRev (64 bytes per 64 rows)
     const uint32_t* steps;                   // [S][m + 1]: pos:16 | right:1 | lastOfPart:1 | minE:5 | maxE:6 (build_step_table)
     uint32_t S, m;
-    uint32_t ksum;                           // C[1] + ... + C[4] mod 2^32: LF(i, 0) = i + ksum - sum of the other symbols' LF (the kernel never reads entry 0)
+    idx_t ksum;                              // C[1] + ... + C[4] mod 2^width: LF(i, 0) = i + ksum - sum of the other symbols' LF (the kernel never reads entry 0)
+    const uint64_t* sup_fw; const uint64_t* sup_rv;   // 64-bit rows: [row >> 30][5] counts at the start of each super-block
+    uint32_t super_rows;
 };
+// a frame as two 64-bit words (what travels between lanes when a subtree is handed over) <-> its fields
+__device__ __forceinline__ void lean_pack(idx_t lb, idx_t lbRev, idx_t len, uint32_t j, uint32_t e, uint32_t next, uint64_t& w0, uint64_t& w1) {
+    if constexpr (kWide) {
+        w0 = (uint64_t)lb | ((uint64_t)lbRev << 38);
+        w1 = ((uint64_t)lbRev >> 26) | ((uint64_t)len << 12) | ((uint64_t)(j & 0xffu) << 50) | ((uint64_t)(e & 7u) << 58) | ((uint64_t)(next & 7u) << 61);
+    } else {
+        w0 = (uint64_t)lb | ((uint64_t)lbRev << 32);
+        w1 = (uint64_t)len | ((uint64_t)(j & 0xffffu) << 32) | ((uint64_t)(e & 0xffu) << 48) | ((uint64_t)(next & 0xffu) << 56);
+    }
+}
+__device__ __forceinline__ void lean_unpack(uint64_t w0, uint64_t w1, idx_t& lb, idx_t& lbRev, idx_t& len, uint32_t& j, uint32_t& e, uint32_t& next) {
+    if constexpr (kWide) {
+        const uint64_t m38 = (1ull << 38) - 1ull;
+        lb = (idx_t)(w0 & m38); lbRev = (idx_t)(((w0 >> 38) | (w1 << 26)) & m38); len = (idx_t)((w1 >> 12) & m38);
+        j = (uint32_t)(w1 >> 50) & 0xffu; e = (uint32_t)(w1 >> 58) & 7u; next = (uint32_t)(w1 >> 61) & 7u;
+    } else {
+        lb = (idx_t)w0; lbRev = (idx_t)(w0 >> 32); len = (idx_t)w1;
+        j = (uint32_t)(w1 >> 32) & 0xffffu; e = (uint32_t)(w1 >> 48) & 0xffu; next = (uint32_t)(w1 >> 56) & 0xffu;
+    }
+}
+__device__ __forceinline__ uint32_t lean_frame_errors(uint64_t w1) { return kWide ? (uint32_t)(w1 >> 58) & 7u : (uint32_t)(w1 >> 48) & 0xffu; }
 typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 struct __attribute__((packed, aligned(4))) Quad4 { uint32_t x, y, z, w; };   // 16 bytes at dword alignment (the entries of symbols 1..4 start 12 bytes into a block)
 
@@ -2407,6 +2436,7 @@ __device__ __forceinline__ void ring_flush(lds_u32* s_cnt_w, const uint32_t* rin
             fmgpu_hit rec;
             rec.qidx = ring[k]; rec.lb = ring[kRingCap + k]; rec.lb_rev = ring[2u * kRingCap + k]; rec.len = ring[3u * kRingCap + k];
             rec.errors = ring[4u * kRingCap + k]; rec.seq = ring[5u * kRingCap + k];
+            if constexpr (kWide) { const uint64_t hi = ring[6u * kRingCap + k]; rec.lb |= (hi & 0xffull) << 32; rec.lb_rev |= ((hi >> 8) & 0xffull) << 32; rec.len |= ((hi >> 16) & 0xffull) << 32; }
             out[at] = rec;
         }
     }
@@ -2416,10 +2446,11 @@ __device__ __forceinline__ void ring_flush(lds_u32* s_cnt_w, const uint32_t* rin
 // NSTEP: nodes a lane visits per pass through the wave-synchronous part (work sharing, refill, ring flush: ~150 of the ~550 wave instructions of an
 // iteration — the loop is bound by instruction issue): a lane that runs out of work inside the inner loop waits for the next pass
 template <int WAVES, int NSTEP>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
-__global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, uint32_t n,
+__global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
                                                              fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, ulonglong2* __restrict__ frames, uint64_t nlanes,
                                                              uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste) {
     extern __shared__ uint32_t s_dyn[];                             // [qwords][256] staged reads | [256] top frames (16 B) | [S][m + 1] steps | [4] ring fill | 4 x [kRingWords][kRingCap] rings
+    __shared__ uint64_t s_sup[2u * kLeanSuperRows * 5u];            // 64-bit rows: the super tables of bwt and bwtRev
     const uint32_t S = la.S, m = la.m, stride = la.m + 1;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
@@ -2430,13 +2461,23 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     uint32_t* const ring = s_steps + S * stride + 4u + wave * (kRingWords * kRingCap);
     for (uint32_t i = tid; i < S * stride; i += 256u) s_steps[i] = la.steps[i];
     if (tid < 4u) s_steps[S * stride + tid] = 0u;
+    const uint64_t* sup_fw = la.sup_fw; const uint64_t* sup_rv = la.sup_rv;
+    if constexpr (kWide) {
+        if (la.super_rows <= kLeanSuperRows) {
+            for (uint32_t i = tid; i < la.super_rows * 5u; i += 256u) { s_sup[i] = la.sup_fw[i]; s_sup[kLeanSuperRows * 5u + i] = la.sup_rv[i]; }
+            sup_fw = s_sup; sup_rv = s_sup + kLeanSuperRows * 5u;
+        }
+    }
     __syncthreads();
 
     const uint32_t gid = blockIdx.x * 256u + tid;                   // frame d of this lane at frames[d * nlanes + gid]
     uint32_t nodes = 0, mark = 0, waste = 0;
+#ifdef FMGPU_DEV
+    uint32_t dev_multi = 0, dev_iter = 0, dev_busy = 0;             // dev build: lane-iterations on multi-row nodes / wave iterations / busy lane-iterations (reported through table_accesses, table_bytes)
+#endif
     bool have = false, exhausted = n == 0, need_start = false, is_task = false, odd = false, in_tail = false;
     uint32_t q = 0, si = 0, e = 0, j = 0, sp = 0, sbase = 0, resume = kLeanNoResume;
-    uint32_t lb = 0, lbRev = 0, len = 0;
+    idx_t lb = 0, lbRev = 0, len = 0;
     uint32_t k1 = 0, k2 = 0;                                        // path key fields of the 1st / 2nd substitution on the lane's path: (m - step) << 8 | symbol, 0 = none (key_with / key_prefix)
     // Order of the top-frame slot's accesses.  The slot is refilled by an LDS-DMA load issued at the END of an iteration (after a pop); every other
     // access of the slot in the node phase (push, pop) comes after the lane has consumed its block loads of that iteration, which were issued after the
@@ -2461,7 +2502,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                         const u32x4 t = *tos_slot;
                         w0 = (uint64_t)t.x | ((uint64_t)t.y << 32); w1 = (uint64_t)t.z | ((uint64_t)t.w << 32);
                     }
-                    { const uint32_t fe = (uint32_t)(w1 >> 48) & 0xffu; w2 = ((uint64_t)(fe >= 1u ? k1 : 0u) << 32) | (fe >= 2u ? k2 : 0u); }      // the key of the frame's node: the fields of later substitutions cleared
+                    { const uint32_t fe = lean_frame_errors(w1); w2 = ((uint64_t)(fe >= 1u ? k1 : 0u) << 32) | (fe >= 2u ? k2 : 0u); }      // the key of the frame's node: the fields of later substitutions cleared
                     ++sbase; mark = nodes;
                 }
                 uint64_t om = offerm;
@@ -2471,8 +2512,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 const uint32_t tq = __shfl(q, vl, 64), tsi = __shfl(si, vl, 64), todd = __shfl((uint32_t)odd, vl, 64);
                 if (take) {
                     q = tq; si = tsi; odd = todd != 0u;
-                    lb = (uint32_t)tw0; lbRev = (uint32_t)(tw0 >> 32); len = (uint32_t)tw1;
-                    j = (uint32_t)(tw1 >> 32) & 0xffffu; e = (uint32_t)(tw1 >> 48) & 0xffu; resume = (uint32_t)(tw1 >> 56) & 0xffu;
+                    lean_unpack(tw0, tw1, lb, lbRev, len, j, e, resume);
                     k1 = (uint32_t)(tw2 >> 32); k2 = (uint32_t)tw2;
                     const uint32_t vt = (tid & ~63u) | (uint32_t)vl;
                     for (uint32_t w = 0; w < qwords; ++w) s_dyn[w * 256u + tid] = s_dyn[w * 256u + vt];     // the partner's staged read
@@ -2515,7 +2555,10 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         }
         const uint32_t ent = s_steps[si * stride + j];
         const bool right = (ent >> 16) & 1u, multi = len > 1u;
-        const uint32_t a = right ? lbRev : lb, b = a + len;
+#ifdef FMGPU_DEV
+        dev_multi += multi ? 1u : 0u; ++dev_busy; if (lane == (uint32_t)__ffsll((unsigned long long)__ballot(true)) - 1u) ++dev_iter;
+#endif
+        const idx_t a = right ? lbRev : lb, b = a + len;
         const uint8_t* blk = right ? la.rv : la.fw;
         // memory phase: the entries of symbols 1..4 of the block(s) — 48 bytes, 12 into the block — of both interval ends (one end for a one-row node)
         const Quad4* pa = reinterpret_cast<const Quad4*>(blk + (size_t)(a >> 6) * 64u + 12u);
@@ -2528,19 +2571,28 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         if (odd) { const uint32_t v = qbuf[qoff[q] + pos]; c = v < 5u ? v : 255u; }      // a read with bytes outside 1..4: from global memory (rare)
         else c = ((s_dyn[(pos >> 4) * 256u + tid] >> ((pos & 15u) * 2u)) & 3u) + 1u;
         // LF of symbols 1..4 at a (and b): cnt + popcount(bits below the row)
-        const uint32_t abit = a & 63u, bbit = b & 63u;
+        const uint32_t abit = (uint32_t)a & 63u, bbit = (uint32_t)b & 63u;
         const uint32_t ma_lo = abit >= 32u ? 0xffffffffu : (1u << abit) - 1u, ma_hi = abit >= 32u ? (1u << (abit - 32u)) - 1u : 0u;
         const uint32_t mb_lo = bbit >= 32u ? 0xffffffffu : (1u << bbit) - 1u, mb_hi = bbit >= 32u ? (1u << (bbit - 32u)) - 1u : 0u;
-        const uint32_t la1 = a0.x + __popc(a0.y & ma_lo) + __popc(a0.z & ma_hi), la2 = a0.w + __popc(a1.x & ma_lo) + __popc(a1.y & ma_hi);
-        const uint32_t la3 = a1.z + __popc(a1.w & ma_lo) + __popc(a2.x & ma_hi), la4 = a2.y + __popc(a2.z & ma_lo) + __popc(a2.w & ma_hi);
+        idx_t la1 = a0.x + __popc(a0.y & ma_lo) + __popc(a0.z & ma_hi), la2 = a0.w + __popc(a1.x & ma_lo) + __popc(a1.y & ma_hi);
+        idx_t la3 = a1.z + __popc(a1.w & ma_lo) + __popc(a2.x & ma_hi), la4 = a2.y + __popc(a2.z & ma_lo) + __popc(a2.w & ma_hi);
+        if constexpr (kWide) {                                      // block counts are relative to the super-block: the rest from the super table
+            const uint64_t* sp_ = (right ? sup_rv : sup_fw) + (size_t)(a >> kSuperShift) * 5u;
+            la1 += sp_[1]; la2 += sp_[2]; la3 += sp_[3]; la4 += sp_[4];
+        }
         bool back = false, search_over = false;
         const bool mOK = minE <= e && e <= maxE, sOK = minE <= e + 1u && e + 1u <= maxE, xOK = e + 1u <= maxE;
         if (multi) {
             // ---- extend-all node (search_next_dir, :143-224) or exact-tail step over several rows
-            const uint32_t d1 = b0.x + __popc(b0.y & mb_lo) + __popc(b0.z & mb_hi) - la1, d2 = b0.w + __popc(b1.x & mb_lo) + __popc(b1.y & mb_hi) - la2;
-            const uint32_t d3 = b1.z + __popc(b1.w & mb_lo) + __popc(b2.x & mb_hi) - la3, d4 = b2.y + __popc(b2.z & mb_lo) + __popc(b2.w & mb_hi) - la4;
-            const uint32_t d0 = len - (d1 + d2 + d3 + d4);          // rows of the interval that hold the delimiter
-            const uint32_t alive = min(d0, 1u) | (min(d1, 1u) << 1) | (min(d2, 1u) << 2) | (min(d3, 1u) << 3) | (min(d4, 1u) << 4);
+            idx_t lb1 = b0.x + __popc(b0.y & mb_lo) + __popc(b0.z & mb_hi), lb2 = b0.w + __popc(b1.x & mb_lo) + __popc(b1.y & mb_hi);
+            idx_t lb3 = b1.z + __popc(b1.w & mb_lo) + __popc(b2.x & mb_hi), lb4 = b2.y + __popc(b2.z & mb_lo) + __popc(b2.w & mb_hi);
+            if constexpr (kWide) {
+                const uint64_t* sp_ = (right ? sup_rv : sup_fw) + (size_t)(b >> kSuperShift) * 5u;
+                lb1 += sp_[1]; lb2 += sp_[2]; lb3 += sp_[3]; lb4 += sp_[4];
+            }
+            const idx_t d1 = lb1 - la1, d2 = lb2 - la2, d3 = lb3 - la3, d4 = lb4 - la4;
+            const idx_t d0 = len - (d1 + d2 + d3 + d4);             // rows of the interval that hold the delimiter
+            const uint32_t alive = (uint32_t)min(d0, (idx_t)1) | ((uint32_t)min(d1, (idx_t)1) << 1) | ((uint32_t)min(d2, (idx_t)1) << 2) | ((uint32_t)min(d3, (idx_t)1) << 3) | ((uint32_t)min(d4, (idx_t)1) << 4);
             const bool resuming = resume != kLeanNoResume;
             uint32_t subs = alive & ~1u & ~(c < 5u ? 1u << c : 0u);  // substitution children: FirstSymb = 1 (fmindex/BiFMIndex.h:26), != query symbol
             if (!sOK) subs = 0u;
@@ -2551,14 +2603,16 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             if (take_sub) { take = (uint32_t)__ffs((int)subs) - 1u; subs &= subs - 1u; }
             nodes += (!resuming && (in_tail || xOK || mOK)) ? 1u : 0u;
             if ((take_match || take_sub) && subs) {                 // (re-)push the parent: its remaining siblings start at the lowest of subs
-                const u32x4 f = {lb, lbRev, len, (j & 0xffffu) | ((e & 0xffu) << 16) | (((uint32_t)__ffs((int)subs) - 1u) << 24)};
+                uint64_t fw0, fw1;
+                lean_pack(lb, lbRev, len, j, e, (uint32_t)__ffs((int)subs) - 1u, fw0, fw1);
+                const u32x4 f = {(uint32_t)fw0, (uint32_t)(fw0 >> 32), (uint32_t)fw1, (uint32_t)(fw1 >> 32)};
                 uint32_t g = gid; asm volatile("" : "+v"(g));     // (kept out of loop-invariant hoisting: the 64-bit address of the lane's frame column would hold two registers through the loop)
                 *reinterpret_cast<u32x4*>(frames + ((uint64_t)sp * nlanes + g)) = f;     // write-through: the stack in HBM is always complete
                 *tos_slot = f; ++sp;
             }
             resume = kLeanNoResume;
             if (take_match || take_sub) {
-                uint32_t kla = la1, kd = d1, pre = d0;
+                idx_t kla = la1, kd = d1, pre = d0;
                 if (take == 2u) { kla = la2; kd = d2; pre = d0 + d1; }
                 else if (take == 3u) { kla = la3; kd = d3; pre = d0 + d1 + d2; }
                 else if (take == 4u) { kla = la4; kd = d4; pre = d0 + d1 + d2 + d3; }
@@ -2572,7 +2626,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         } else {
             // ---- single row (search_next_dir_single, :251-365): the only child is the BWT symbol of the row, read off its block
             const uint32_t bt_lo = abit >= 32u ? 0u : 1u << abit, bt_hi = abit >= 32u ? 1u << (abit - 32u) : 0u;
-            uint32_t row_sym = 0u, t0 = 0u;
+            uint32_t row_sym = 0u; idx_t t0 = 0;
             if ((a0.y & bt_lo) | (a0.z & bt_hi)) { row_sym = 1u; t0 = la1; }
             if ((a1.x & bt_lo) | (a1.y & bt_hi)) { row_sym = 2u; t0 = la2; }
             if ((a1.w & bt_lo) | (a2.x & bt_hi)) { row_sym = 3u; t0 = la3; }
@@ -2593,8 +2647,9 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 const uint32_t slot = __hip_atomic_fetch_add(s_cnt_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 const uint32_t kw = e | ((si << 16 | k1 >> 8) << 8), ks = (k1 << 24) | k2;    // path key = si:8 | k1:24 | k2:24 (key_with): errors word carries its upper 24 bits, seq the lower 32
                 if (slot < kRingCap) {                              // the wave flushes at kRingFlush and appends at most 64 NSTEP records per pass: room unless NSTEP > 2
-                    ring[slot] = q; ring[kRingCap + slot] = lb; ring[2u * kRingCap + slot] = lbRev; ring[3u * kRingCap + slot] = len;
+                    ring[slot] = q; ring[kRingCap + slot] = (uint32_t)lb; ring[2u * kRingCap + slot] = (uint32_t)lbRev; ring[3u * kRingCap + slot] = (uint32_t)len;
                     ring[4u * kRingCap + slot] = kw; ring[5u * kRingCap + slot] = ks;
+                    if constexpr (kWide) ring[6u * kRingCap + slot] = (uint32_t)((uint64_t)lb >> 32) | ((uint32_t)((uint64_t)lbRev >> 32) << 8) | ((uint32_t)((uint64_t)len >> 32) << 16);
                 } else emit_hit(out, cap, ctr, q, Cur{lb, lbRev, len}, kw, ks);
             }
             back = true;
@@ -2605,8 +2660,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 --sp;
                 asm volatile("" ::: "memory");                      // (the slot is read here, not ahead of the branch)
                 const u32x4 t = *tos_slot;                          // the cached top frame ...
-                lb = t.x; lbRev = t.y; len = t.z;
-                j = t.w & 0xffffu; e = (t.w >> 16) & 0xffu; resume = t.w >> 24;
+                lean_unpack((uint64_t)t.x | ((uint64_t)t.y << 32), (uint64_t)t.z | ((uint64_t)t.w << 32), lb, lbRev, len, j, e, resume);
                 if (e == 0u) k1 = 0u;                                // the key of the popped node: the fields of later substitutions cleared
                 if (e <= 1u) k2 = 0u;
                 in_tail = false;
@@ -2626,9 +2680,12 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     }
     const uint32_t tot = wave_sum(nodes);
     if (lane == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
+#ifdef FMGPU_DEV
+    { const uint32_t a1 = wave_sum(dev_multi), a2 = wave_sum(dev_iter), a3 = wave_sum(dev_busy);
+      if (lane == 0) { atomicAdd(&ctr->table_accesses, (unsigned long long)a1 | ((unsigned long long)a2 << 40)); atomicAdd(&ctr->table_bytes, (unsigned long long)a3); } }
+#endif
 }
 
-#endif  // !FMGPU_WIDE
 
 // ---- search_backtracking ----------------------------------------------------------------------------------------
 template <class Occ, int MAXSIG>
@@ -3230,6 +3287,26 @@ int fmgpu_search_exact_depth(fmgpu_index_t h, const uint8_t* qbuf, const uint64_
     return sout.finish();
 }
 
+static size_t lean_lds_bytes(uint32_t m, size_t step_words) {
+    return (size_t)((m + 15) / 16) * 1024 + 4096 + step_words * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;
+}
+static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uint32_t m, size_t step_words, dim3 g, const uint8_t* dq, const uint64_t* doff, uint64_t count,
+                        fmgpu_hit* dout, uint64_t capacity, const DfsWorkspace& ws, const uint32_t* qm, hipStream_t stream) {
+    const idx_t n = (idx_t)x->bwt.n;
+    LeanArgs la{x->bwt.va.blk, x->rev.va.blk, d_steps, S, m, (idx_t)(x->hC[1] + x->hC[2] + x->hC[3] + x->hC[4]), x->bwt.va.super, x->rev.va.super,
+                kWide ? (uint32_t)((x->bwt.n >> kSuperShift) + 1) : 0u};
+    const size_t lds = lean_lds_bytes(m, step_words);
+    uint32_t waste = kLeanRefillWaste; [[maybe_unused]] int steps = kLeanSteps;
+    if (const char* ev = dev_env("FMGPU_DEV_LEAN_WASTE")) waste = (uint32_t)std::max(1, atoi(ev));
+    if (const char* ev = dev_env("FMGPU_DEV_LEAN_STEPS")) steps = atoi(ev);
+    auto launch = [&](auto kern) { kern<<<g, dim3(256), lds, stream>>>(la, dq, doff, count, n, dout, capacity, ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes,
+                                                                    (m + 15) / 16, qm, waste); };
+#ifdef FMGPU_DEV
+    if (steps == 1) launch(k_scheme_lean<kLeanWaves, 1>); else if (steps == 2) launch(k_scheme_lean<kLeanWaves, 2>); else if (steps == 8) launch(k_scheme_lean<kLeanWaves, 8>); else
+#endif
+    launch(k_scheme_lean<kLeanWaves, kLeanSteps>);
+}
+
 static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme,
                    uint64_t max_hits, uint32_t K, fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, hipStream_t stream) {
     if (stats) *stats = fmgpu_stats{};
@@ -3318,6 +3395,31 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     uint32_t* d_steps = nullptr;
     bool fast = false;
     float prepass_ms = 0.f;                                        // the hand-out order pass (flag kernel, sample read-back, partition): reported beside kernel_ms, never inside it
+#if FMGPU_WIDE
+    // 64-bit rows hold no tables; an equal-length Hamming batch on the plain sigma = 5 blocks still takes k_scheme_lean (16-byte frames of 38-bit rows, reads of
+    // <= 255 symbols, path keys, unlimited hits per read) — a genome with its reverse complement (6.2 G rows) is not confined to the general kernel
+    std::vector<uint32_t> wide_tab;
+    bool lean_wide = false;
+    if (scheme_mode && !edit && x->bwt.family == FAM_A && !x->bwt.shadow && x->bwt.sigma == 5 && x->bwt.va.bstride == 64u && minlen == maxlen && maxlen <= 255 && max_hits == ~0ull &&
+        sd.S <= 16 && max_u <= 2 && nq <= 0xffffffffull && n >= 2 && n < ((idx_t)1 << 38) && !(sd.dev_flags & (2 | (1 << 24) | (1 << 30)))) {
+        uint32_t lut_ok = 0;
+        lean_wide = build_step_table(sd, maxlen, 0, 0, wide_tab, lut_ok);
+        if (lean_wide) {
+            wide_tab.resize(wide_tab.size() / 3);                  // (the stretch words serve the walk tables)
+            const char* hf = getenv("FMGPU_HEAVY_FIRST");
+            if (maxlen >= 16 && nq >= (1u << 16) && nq < 0x7fffffffull && !(hf && atoi(hf) == 0)) {
+                uint32_t* order = nullptr;
+                const auto pre_t0 = std::chrono::steady_clock::now();
+                if ((rc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
+                        k_heavy_flags_plain<OccA<5>><<<dim3((unsigned)((count_reads + 255) / 256)), 256, 0, stream>>>(OccA<5>{x->bwt.va}, n, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                                                                   count_reads, maxlen, heavy_rows(), flags, cnt);
+                    }, &order))) return rc;
+                if (order) { d_qmap = order; prepass_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - pre_t0).count(); }
+            }
+            bpc = 3;
+        }
+    }
+#endif
 #if !FMGPU_WIDE
     // fast path: equal-length batch on a Format-A BiFMIndex — with LF tables, or (Hamming, sigma <= 5) on the blocks alone
     // 16-symbol walk: 2-bit symbols, queries staged in LDS as nibbles
@@ -3424,7 +3526,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (lean) {
         size_t max_tab = 0;
         for (const Bucket& b : buckets) max_tab = std::max(max_tab, b.tab.size() / 3);
-        lean_lds = (size_t)lean_qwords * 1024 + 4096 + max_tab * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;
+        lean_lds = lean_lds_bytes(maxlen, max_tab);
         const auto key = std::make_tuple(-2, x->bwt.sigma, 4, lean_lds);
         bool known = false;
         { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(key); if (it != occ_cache.end()) { bpc = it->second; known = true; } }
@@ -3457,7 +3559,20 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         for (const Bucket& b : buckets) { FM_HIP(hipMemcpyAsync(d_steps + at, b.tab.data(), b.tab.size() * 4, hipMemcpyHostToDevice, stream)); at += b.tab.size(); }
     }
 #endif
+#if FMGPU_WIDE
+    if (lean_wide) {
+        if ((rc = steps_buf.alloc(wide_tab.size() * 4))) return rc;
+        d_steps = steps_buf.as<uint32_t>();
+        FM_HIP(hipMemcpyAsync(d_steps, wide_tab.data(), wide_tab.size() * 4, hipMemcpyHostToDevice, stream));
+    }
+#endif
     timer.start();
+#if FMGPU_WIDE
+    if (lean_wide) {
+        FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));
+        launch_lean(x, d_steps, (uint32_t)sd.S, maxlen, wide_tab.size(), grid, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, (fmgpu_hit*)sout.dev, capacity, ws, d_qmap, stream);
+    } else
+#endif
 #if !FMGPU_WIDE
     if (fast) {
         size_t at = 0;
@@ -3482,17 +3597,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                     k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                               b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
             } else if (lean) {
-                LeanArgs la{x->bwt.va.blk, x->rev.va.blk, fa.steps, (uint32_t)sd.S, b.m, (uint32_t)(x->hC[1] + x->hC[2] + x->hC[3] + x->hC[4])};
-                const size_t lds_lean = (size_t)lean_qwords * 1024 + 4096 + (b.tab.size() / 3) * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;
-                uint32_t waste = kRefillWaste; int steps = kLeanSteps;
-                if (const char* ev = dev_env("FMGPU_DEV_LEAN_WASTE")) waste = (uint32_t)std::max(1, atoi(ev));
-                if (const char* ev = dev_env("FMGPU_DEV_LEAN_STEPS")) steps = atoi(ev);
-                auto launch = [&](auto kern) { kern<<<g, block, lds_lean, stream>>>(la, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (uint32_t)n, (fmgpu_hit*)sout.dev, capacity,
-                                                                                 ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes, lean_qwords, qm, waste); };
-#ifdef FMGPU_DEV
-                if (steps == 1) launch(k_scheme_lean<kLeanWaves, 1>); else if (steps == 2) launch(k_scheme_lean<kLeanWaves, 2>); else if (steps == 8) launch(k_scheme_lean<kLeanWaves, 8>); else
-#endif
-                launch(k_scheme_lean<kLeanWaves, kLeanSteps>);
+                launch_lean(x, fa.steps, (uint32_t)sd.S, b.m, b.tab.size() / 3, g, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (fmgpu_hit*)sout.dev, capacity, ws, qm, stream);
             } else if (x->bwt.sigma == 5 && !have_lf)
                 k_scheme_fast<5, 5, true><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                           b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);

@@ -109,6 +109,31 @@ def test_wide_k_mismatch_and_backtracking(layout, sigma, k, lf):
             assert [tuple(map(int, t)) for t in zip(olb[i], orev[i], olen[i])] == [(c.lb, c.lb_rev, c.len) for c in exp]
 
 
+@pytest.mark.parametrize("k,length", [(1, 20), (2, 31), (2, 101), (2, 151), (2, 255), (0, 40)])
+def test_wide_lean_kernel(k, length):
+    """equal-length Hamming batches on a 64-bit-row BiFMIndex<5> take k_scheme_lean too (16-byte frames of 38-bit rows, super-block counts from LDS, 7-word
+    hit records): records in callback order and node counts equal the CPU walk and the general kernel, delimiters in the reads included"""
+    seqs = repeat_text(90 + k, n=9000) + [np.tile(np.array([1, 1, 1, 2], dtype=np.uint8), 300), np.full(700, 3, dtype=np.uint8)]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
+    gx = wide_index(ox)
+    queries = mutated_queries([q for q in seqs if len(q) > length], 2500, length, length + 1, k + 1, seed=31 + k)
+    rng = np.random.default_rng(k)
+    for i in range(0, len(queries), 89):
+        queries[i][int(rng.integers(0, length))] = 0
+    qbuf, qoff = fm.flatten(queries)
+    schemes = [fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k)] if k else [fm.search_scheme.backtracking(1, 0, 0)]
+    for sch in schemes:
+        ohits, _, nodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 24)
+        hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
+        assert same_hits(hits, ohits) and st.lf_steps == nodes, (k, length)
+        os.environ["FMGPU_DEV_FLAGS"] = "2"                        # the general kernel
+        try:
+            hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
+        finally:
+            del os.environ["FMGPU_DEV_FLAGS"]
+        assert same_hits(hits2, ohits) and st2.lf_steps == nodes
+
+
 @pytest.mark.parametrize("layout,sigma,k", [("IB16", 5, 1), ("IB16", 5, 2), ("EPRV2_16", 5, 2), ("WAVELET", 28, 1), ("IB16", 256, 1), ("IB16", 5, 3)])
 @pytest.mark.parametrize("lf", [True, False])
 def test_wide_edit_distance_and_ng21(layout, sigma, k, lf):
