@@ -710,7 +710,7 @@ def _scheme_struct(capi, scheme):
 def run_protein(c, nseq, tag):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
-    ids = [tag + "/exact/wavelet"] + ([tag + "/exact/tables"] if tag == "protein" else [])     # the tables exist for 32-bit rows only
+    ids = [tag + "/exact/wavelet", tag + "/exact/tables"]
     if c.only and not any(i in c.only for i in ids):
         return []
     sigma, L, nq = 28, 40, args.nq
@@ -765,10 +765,11 @@ def run_protein(c, nseq, tag):
         out.append(rec_of(ids[0], "wavelet", "k_exact_m", elapsed, log, build_s, None))
     if len(ids) > 1 and wanted(c, ids[1]):
         t0 = time.time()
-        index.accelerate(1, lut_len=6, walk=2)
+        wide = index.row_bits == 64                            # 64-bit rows: 16-byte entries — the 6-symbol walk alone (72 GB at 4.5e9 rows), no 12-symbol one
+        index.accelerate(1, lut_len=6, walk=1 if wide else 2)
         b2 = build_s + time.time() - t0
         elapsed, log = timed(c, step)
-        out.append(rec_of(ids[1], "tables", "k_exact_kstep", elapsed, log, b2, {"block_table_expansion": True, "suffix_interval_symbols": 6, "walk_symbols_per_load": 12}))
+        out.append(rec_of(ids[1], "tables", "k_exact_kstep", elapsed, log, b2, {"block_table_expansion": True, "suffix_interval_symbols": 6, "walk_symbols_per_load": 6 if wide else 12}))
     index.close()
     torch.cuda.empty_cache()
     return out

@@ -193,6 +193,10 @@ using idx_t = uint64_t;
 using idx_t = uint32_t;
 #endif
 constexpr bool kWide = FMGPU_WIDE != 0;
+// entries of the exact-search tables (fmgpu_index_accelerate_exact).  32-bit rows: interval {lb, len} 8 bytes, walk {LF^J row, code} 8 bytes,
+// double walk {LF^2J row, code, code} 12 bytes.  64-bit rows: 16 bytes each — {lb, len} as two u64; {row lo, row hi, code, 0}; {row lo, row hi, code, code};
+// a walk that meets a delimiter has row = all ones.
+constexpr size_t kSlutEntryBytes = kWide ? 16 : 8, kWalkEntryBytes = kWide ? 16 : 8, kWalk2EntryBytes = kWide ? 16 : 12;
 constexpr uint32_t kSuperShift = 30;          // wide rows: counts are kept relative to super-blocks of 2^30 rows / node positions
 constexpr idx_t kNoRow = ~(idx_t)0;
 

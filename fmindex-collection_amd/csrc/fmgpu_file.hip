@@ -111,9 +111,9 @@ static void describe_string(const DevString& s, bool tables, SavedString& o, con
         put(SEC_LF, s.lf_table, n * sizeof(idx_t) + 16);
         put(SEC_KBLK, s.kblk, s.kblk_bytes);
         put(SEC_WALK3, s.walk3, n * 12 + 16);
-        put(SEC_SLUT, s.slut, s.slut_entries * 8);
-        put(SEC_WALKJ, s.walkj, n * 8 + 16);
-        put(SEC_WALK2J, s.walk2j, n * 12 + 16);
+        put(SEC_SLUT, s.slut, s.slut_entries * kSlutEntryBytes);
+        put(SEC_WALKJ, s.walkj, n * kWalkEntryBytes + 16);
+        put(SEC_WALK2J, s.walk2j, n * kWalk2EntryBytes + 16);
         put(SEC_SHADOW, s.shadow, s.shadow_bytes - s.shadow_sup_bytes);
         put(SEC_SHADOW_SUP, s.shadow_sup, s.shadow_sup_bytes);
         o.kstep = s.kblk ? s.kstep : 0; o.kcodes = s.kblk ? s.kcodes : 0;

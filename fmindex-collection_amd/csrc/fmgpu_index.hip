@@ -430,6 +430,69 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
     return make_format_m(sym.as<uint8_t>(), d.n, sigma, dC, s, d.layout, nullptr);
 }
 
+constexpr uint64_t kTableGridCap = 1u << 22;      // blocks of the grid-stride table builders
+
+// ------------------------------------------------------------------ exact-search tables, both row widths (entry shapes: fmgpu_common.h)
+// suffix table: the interval of the L symbols c_0 (consumed first = the query's last symbol), c_1, ...
+template <class Occ>
+__global__ __launch_bounds__(256) void k_suffix_lut(Occ occ, uint64_t entries, uint32_t L, uint32_t R, idx_t n, void* __restrict__ lut) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < entries; w += (uint64_t)gridDim.x * blockDim.x) {   // (2^32 entries: more than one launch's threads)
+        idx_t lb = 0, len = n;
+        uint64_t rest = w;
+        for (uint32_t t = 0; t < L && len != 0; ++t) {
+            uint32_t c = (uint32_t)(rest % R) + 1; rest /= R;
+            idx_t ra, rb;
+            occ.lf2(lb, lb + len, c, ra, rb);
+            lb = ra; len = rb - ra;
+        }
+        if constexpr (kWide) reinterpret_cast<ulonglong2*>(lut)[w] = make_ulonglong2(lb, len);
+        else reinterpret_cast<uint2*>(lut)[w] = make_uint2(lb, len);
+    }
+}
+// J LF steps from every row, remembering the symbols met
+__global__ __launch_bounds__(256) void k_walkj(const idx_t* __restrict__ lf, const idx_t* __restrict__ C, uint32_t sigma, uint64_t n, uint32_t J, uint32_t bits,
+                                               void* __restrict__ out) {
+    __shared__ idx_t sC[257];
+    for (uint32_t i = threadIdx.x; i <= sigma; i += blockDim.x) sC[i] = C[i];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        idx_t r = (idx_t)i;
+        uint32_t code = 0; bool ok = true;
+        for (uint32_t t = 0; t < J; ++t) {
+            idx_t nr = lf[r];
+            uint32_t lo = 0, hi = sigma;                   // symbol of the step: C[s] <= LF < C[s+1]
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sC[mid] <= nr) lo = mid; else hi = mid; }
+            if (lo == 0) { ok = false; break; }
+            code |= (lo - 1u) << (bits * t);
+            r = nr;
+        }
+        if constexpr (kWide) reinterpret_cast<uint4*>(out)[i] = ok ? make_uint4((uint32_t)r, (uint32_t)((uint64_t)r >> 32), code, 0u) : make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+        else reinterpret_cast<uint2*>(out)[i] = ok ? make_uint2((uint32_t)r, code) : make_uint2(0xffffffffu, 0u);
+    }
+}
+// 2J steps = two J-step entries chained
+__global__ __launch_bounds__(256) void k_walk2j(const void* __restrict__ wj_, uint64_t n, void* __restrict__ out_) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if constexpr (kWide) {
+            const uint4* wj = reinterpret_cast<const uint4*>(wj_);
+            const uint4 a = wj[i];
+            uint4 r = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+            if (!(a.x == 0xffffffffu && a.y == 0xffffffffu)) {
+                const uint4 b = wj[(uint64_t)a.x | ((uint64_t)a.y << 32)];
+                if (!(b.x == 0xffffffffu && b.y == 0xffffffffu)) r = make_uint4(b.x, b.y, a.z, b.z);
+            }
+            reinterpret_cast<uint4*>(out_)[i] = r;
+        } else {
+            const uint2* wj = reinterpret_cast<const uint2*>(wj_);
+            uint32_t* out = reinterpret_cast<uint32_t*>(out_);
+            const uint2 a = wj[i];
+            uint32_t r = 0xffffffffu, c0 = 0, c1 = 0;
+            if (a.x != 0xffffffffu) { const uint2 b = wj[a.x]; if (b.x != 0xffffffffu) { r = b.x; c0 = a.y; c1 = b.y; } }
+            out[3 * i] = r; out[3 * i + 1] = c0; out[3 * i + 2] = c1;
+        }
+    }
+}
+
 #if !FMGPU_WIDE
 // ------------------------------------------------------------------ multi-symbol-step table
 // context code of row j: walk K LF steps from j collecting the BWT symbols s_1 (immediately before the suffix), s_2, ...;
@@ -495,50 +558,6 @@ __global__ __launch_bounds__(256) void k_walk3(const idx_t* __restrict__ lf, uin
         out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
     }
 }
-// suffix table for exact search: the interval of the L symbols c_0 (consumed first = the query's last symbol), c_1, ...
-template <class Occ>
-__global__ __launch_bounds__(256) void k_suffix_lut(Occ occ, uint64_t entries, uint32_t L, uint32_t R, idx_t n, uint2* __restrict__ lut) {
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < entries; w += (uint64_t)gridDim.x * blockDim.x) {   // (2^32 entries: more than one launch's threads)
-        idx_t lb = 0, len = n;
-        uint64_t rest = w;
-        for (uint32_t t = 0; t < L && len != 0; ++t) {
-            uint32_t c = (uint32_t)(rest % R) + 1; rest /= R;
-            idx_t ra, rb;
-            occ.lf2(lb, lb + len, c, ra, rb);
-            lb = ra; len = rb - ra;
-        }
-        lut[w] = make_uint2(lb, len);
-    }
-}
-// J LF steps from every row, remembering the symbols met
-__global__ __launch_bounds__(256) void k_walkj(const idx_t* __restrict__ lf, const idx_t* __restrict__ C, uint32_t sigma, uint64_t n, uint32_t J, uint32_t bits,
-                                               uint2* __restrict__ out) {
-    __shared__ idx_t sC[257];
-    for (uint32_t i = threadIdx.x; i <= sigma; i += blockDim.x) sC[i] = C[i];
-    __syncthreads();
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        idx_t r = (idx_t)i;
-        uint32_t code = 0; bool ok = true;
-        for (uint32_t t = 0; t < J; ++t) {
-            idx_t nr = lf[r];
-            uint32_t lo = 0, hi = sigma;                   // symbol of the step: C[s] <= LF < C[s+1]
-            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sC[mid] <= nr) lo = mid; else hi = mid; }
-            if (lo == 0) { ok = false; break; }
-            code |= (lo - 1u) << (bits * t);
-            r = nr;
-        }
-        out[i] = ok ? make_uint2(r, code) : make_uint2(0xffffffffu, 0u);
-    }
-}
-// 2J steps = two J-step entries chained
-__global__ __launch_bounds__(256) void k_walk2j(const uint2* __restrict__ wj, uint64_t n, uint32_t* __restrict__ out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint2 a = wj[i];
-        uint32_t r = 0xffffffffu, c0 = 0, c1 = 0;
-        if (a.x != 0xffffffffu) { const uint2 b = wj[a.x]; if (b.x != 0xffffffffu) { r = b.x; c0 = a.y; c1 = b.y; } }
-        out[3 * i] = r; out[3 * i + 1] = c0; out[3 * i + 2] = c1;
-    }
-}
 // bidirectional interval of every string w of L symbols in [1, sigma): extendRight symbol by symbol (fmindex/BiFMIndexCursor.h:121-128)
 template <class Occ>
 __global__ __launch_bounds__(256) void k_prefix_lut(Occ rv, uint64_t entries, uint32_t L, uint32_t R, idx_t n, uint4* __restrict__ lut) {
@@ -562,7 +581,6 @@ __global__ __launch_bounds__(256) void k_prefix_lut(Occ rv, uint64_t entries, ui
     }
 }
 
-constexpr uint64_t kTableGridCap = 1u << 22;      // blocks of the grid-stride table builders
 
 // the table is built into local allocations and installed in the handle only after every launch and the final synchronisation have succeeded
 template <class Occ>
@@ -778,11 +796,6 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
     }
     return no_wide("the multi-symbol-step table");
 }
-int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk) {
-    if (lut_len < 0 || lut_len > 32) return fail(FMGPU_ERR_INVALID, "lut_len must be in [0, 32]");
-    if (kstep > 1 || lut_len > 0 || walk) return no_wide("the exact-search tables");
-    return api::fmgpu_index_accelerate(h, kstep);
-}
 int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t walk) {
     if (!h) return fail(FMGPU_ERR_INVALID, "index handle is null");
     if (prefix_len < 0 || prefix_len > 32) return fail(FMGPU_ERR_INVALID, "prefix_len must be in [0, 32]");
@@ -813,64 +826,6 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
     rc = dispatch_occ(s, [&](auto occ, auto) { return accelerate_with(s, occ, (uint32_t)kstep); });
     if (rc == 0) x->device_bytes += s.kblk_bytes;
     return rc;
-}
-
-int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk) {
-    Index* x = reinterpret_cast<Index*>(h);
-    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
-    if (int drc = on_handle_device(x)) return drc;
-    if (lut_len < 0 || lut_len > 32) return fail(FMGPU_ERR_INVALID, "lut_len must be in [0, 32]");
-    int rc = api::fmgpu_index_accelerate(h, kstep);
-    if (rc) return rc;
-    DevString& s = x->bwt;
-    const uint64_t n = s.n;
-    if (s.slut) { (void)hipFree(s.slut); x->device_bytes -= s.slut_entries * 8; s.slut = nullptr; s.slut_len = 0; s.slut_entries = 0; }
-    if (s.walk2j) { (void)hipFree(s.walk2j); x->device_bytes -= n * 12; s.walk2j = nullptr; }
-    if (s.walkj && !walk) { (void)hipFree(s.walkj); x->device_bytes -= n * 8; s.walkj = nullptr; s.walk_J = 0; }
-    if (n == 0) return 0;
-    const uint32_t sigma = (uint32_t)s.sigma, R = sigma - 1;
-    if (lut_len > 0) {
-        uint64_t entries = 1;
-        for (int t = 0; t < lut_len; ++t) { entries *= R; if (entries > (1ull << 32)) return fail(FMGPU_ERR_UNSUPPORTED, "suffix table would exceed 2^32 entries"); }
-        DBuf lut;
-        if ((rc = lut.alloc(entries * 8))) return rc;
-        dim3 grid;
-        if ((rc = grid_of(entries, &grid, kTableGridCap))) return rc;
-        rc = dispatch_occ(s, [&](auto occ, auto) {
-            k_suffix_lut<decltype(occ)><<<grid, dim3(256)>>>(occ, entries, (uint32_t)lut_len, R, (idx_t)n, lut.as<uint2>());
-            return 0;
-        });
-        FM_LAUNCHED("k_suffix_lut");
-        FM_HIP(hipDeviceSynchronize());
-        s.slut = (uint2*)lut.take(); s.slut_len = (uint32_t)lut_len; s.slut_entries = entries;
-        x->device_bytes += entries * 8;
-    }
-    if (walk) {
-        if (!s.lf_table) { if ((rc = build_lf_table(s, nullptr))) return rc; x->device_bytes += n * sizeof(idx_t); }
-        uint32_t bits = 1; while ((1u << bits) < R) ++bits;               // symbols 1 .. sigma-1 stored as 0 .. sigma-2
-        const uint32_t J = 32u / bits;
-        dim3 grid;
-        if ((rc = grid_of(n, &grid, kTableGridCap))) return rc;
-        if (!s.walkj) {
-            DBuf wj;
-            if ((rc = wj.alloc(n * 8 + 16))) return rc;
-            k_walkj<<<grid, 256>>>(s.lf_table, x->dC, sigma, n, J, bits, wj.as<uint2>());
-            FM_LAUNCHED("k_walkj");
-            FM_HIP(hipDeviceSynchronize());
-            s.walkj = (uint2*)wj.take(); s.walk_J = J; s.walk_bits = bits;
-            x->device_bytes += n * 8;
-        }
-        if (walk >= 2) {
-            DBuf w2;
-            if ((rc = w2.alloc(n * 12 + 16))) return rc;
-            k_walk2j<<<grid, 256>>>(s.walkj, n, w2.as<uint32_t>());
-            FM_LAUNCHED("k_walk2j");
-            FM_HIP(hipDeviceSynchronize());
-            s.walk2j = (uint32_t*)w2.take();
-            x->device_bytes += n * 12;
-        }
-    }
-    return 0;
 }
 
 int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t walk) {
@@ -905,7 +860,7 @@ int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t w
             if ((walk & 2) && !s->walkj) {                          // (the forward one may exist already: fmgpu_index_accelerate_exact)
                 DBuf wj;
                 if ((rc = wj.alloc(n * 8 + 16))) return rc;
-                k_walkj<<<grid, 256>>>(s->lf_table, x->dC, sigma, n, 32u / bits, bits, wj.as<uint2>());
+                k_walkj<<<grid, 256>>>(s->lf_table, x->dC, sigma, n, 32u / bits, bits, wj.p);
                 FM_LAUNCHED("k_walkj");
                 FM_HIP(hipDeviceSynchronize());
                 s->walkj = (uint2*)wj.take(); s->walk_J = 32u / bits; s->walk_bits = bits;
@@ -933,6 +888,66 @@ int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t w
     return 0;
 }
 #endif  // FMGPU_WIDE
+
+// the interval and walk tables of the exact search, both row widths (entry shapes: fmgpu_common.h)
+int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
+    if (int drc = on_handle_device(x)) return drc;
+    if (lut_len < 0 || lut_len > 32) return fail(FMGPU_ERR_INVALID, "lut_len must be in [0, 32]");
+    int rc = api::fmgpu_index_accelerate(h, kstep);    // (64-bit rows: kstep <= 1 — the Format A expansion; the multi-symbol-step table holds 32-bit counts)
+    if (rc) return rc;
+    DevString& s = x->bwt;
+    const uint64_t n = s.n;
+    if (s.slut) { (void)hipFree(s.slut); x->device_bytes -= s.slut_entries * kSlutEntryBytes; s.slut = nullptr; s.slut_len = 0; s.slut_entries = 0; }
+    if (s.walk2j) { (void)hipFree(s.walk2j); x->device_bytes -= n * kWalk2EntryBytes; s.walk2j = nullptr; }
+    if (s.walkj && !walk) { (void)hipFree(s.walkj); x->device_bytes -= n * kWalkEntryBytes; s.walkj = nullptr; s.walk_J = 0; }
+    if (n == 0) return 0;
+    const uint32_t sigma = (uint32_t)s.sigma, R = sigma - 1;
+    if (lut_len > 0) {
+        uint64_t entries = 1;
+        for (int t = 0; t < lut_len; ++t) { entries *= R; if (entries > (1ull << 32)) return fail(FMGPU_ERR_UNSUPPORTED, "suffix table would exceed 2^32 entries"); }
+        DBuf lut;
+        if ((rc = lut.alloc(entries * kSlutEntryBytes))) return rc;
+        dim3 grid;
+        if ((rc = grid_of(entries, &grid, kTableGridCap))) return rc;
+        rc = dispatch_occ(s, [&](auto occ, auto) {
+            k_suffix_lut<decltype(occ)><<<grid, dim3(256)>>>(occ, entries, (uint32_t)lut_len, R, (idx_t)n, lut.p);
+            return 0;
+        });
+        FM_LAUNCHED("k_suffix_lut");
+        FM_HIP(hipDeviceSynchronize());
+        s.slut = (uint2*)lut.take(); s.slut_len = (uint32_t)lut_len; s.slut_entries = entries;
+        x->device_bytes += entries * kSlutEntryBytes;
+    }
+    if (walk) {
+        if (!s.lf_table) { if ((rc = build_lf_table(s, nullptr))) return rc; x->device_bytes += n * sizeof(idx_t); }
+        uint32_t bits = 1; while ((1u << bits) < R) ++bits;               // symbols 1 .. sigma-1 stored as 0 .. sigma-2
+        const uint32_t J = 32u / bits;
+        dim3 grid;
+        if ((rc = grid_of(n, &grid, kTableGridCap))) return rc;
+        if (!s.walkj) {
+            DBuf wj;
+            if ((rc = wj.alloc(n * kWalkEntryBytes + 16))) return rc;
+            k_walkj<<<grid, 256>>>(s.lf_table, x->dC, sigma, n, J, bits, wj.p);
+            FM_LAUNCHED("k_walkj");
+            FM_HIP(hipDeviceSynchronize());
+            s.walkj = (uint2*)wj.take(); s.walk_J = J; s.walk_bits = bits;
+            x->device_bytes += n * kWalkEntryBytes;
+        }
+        if (walk >= 2) {
+            DBuf w2;
+            if ((rc = w2.alloc(n * kWalk2EntryBytes + 16))) return rc;
+            k_walk2j<<<grid, 256>>>(s.walkj, n, w2.p);
+            FM_LAUNCHED("k_walk2j");
+            FM_HIP(hipDeviceSynchronize());
+            s.walk2j = (uint32_t*)w2.take();
+            x->device_bytes += n * kWalk2EntryBytes;
+        }
+    }
+    return 0;
+}
+
 
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes) {
     Index* x = reinterpret_cast<Index*>(h);

@@ -1334,7 +1334,6 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
 }
 
-#if !FMGPU_WIDE   // ======== 32-bit rows only: every table-driven kernel (tables, their frames and transport words hold 32-bit rows)
 // ---- search_ng26 Hamming, fast path ------------------------------------------------------------------------------
 // For a batch of equal-length queries on a Format-A BiFMIndex the host expands the scheme once into a per-step table
 // (query position, direction, error window [minE, maxE] of the step, "last character of its part"; SearchNg26.h:160-168:
@@ -1425,11 +1424,11 @@ __device__ __forceinline__ uint32_t query_code16(const QStage& qst, uint32_t pos
     return qc;
 }
 
-struct ExactAccel {
-    const uint8_t* kblk; uint32_t K, ncodes;        // k-symbol-step table (or null)
-    const uint2* slut; uint32_t lutL;               // interval of the query's last lutL symbols (or null)
-    const uint2* walk; uint32_t J, wbits;           // per row LF^J + the J symbols met (or null)
-    const uint32_t* walk2;                          // per row LF^(2J) + the 2J symbols met as two codes (or null)
+struct ExactAccel {                                 // (entry shapes by row width: fmgpu_common.h)
+    const uint8_t* kblk; uint32_t K, ncodes;        // k-symbol-step table (or null; 32-bit rows only)
+    const void* slut; uint32_t lutL;                // interval of the query's last lutL symbols (or null)
+    const void* walk; uint32_t J, wbits;            // per row LF^J + the J symbols met (or null)
+    const void* walk2;                              // per row LF^(2J) + the 2J symbols met as two codes (or null)
 };
 
 template <class Occ>
@@ -1469,7 +1468,13 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
                 if (ac.lutL < 16u) code &= (1u << (2u * ac.lutL)) - 1u;
                 if (!v) code = code_of(0, ac.lutL, 0, v);       // (an odd symbol among the 16: decide on the lutL symbols alone)
             } else code = code_of(0, ac.lutL, 0, v);
-            if (v) { const uint2 en = ac.slut[code]; tbytes += 8u; ++tacc; if (en.y != 0) { lb = en.x; len = en.y; done = ac.lutL; steps = ac.lutL; } }
+            if (v) {
+                idx_t elb, elen;
+                if constexpr (kWide) { const ulonglong2 en = reinterpret_cast<const ulonglong2*>(ac.slut)[code]; elb = (idx_t)en.x; elen = (idx_t)en.y; }
+                else { const uint2 en = reinterpret_cast<const uint2*>(ac.slut)[code]; elb = en.x; elen = en.y; }
+                tbytes += (uint32_t)kSlutEntryBytes; ++tacc;
+                if (elen != 0) { lb = elb; len = elen; done = ac.lutL; steps = ac.lutL; }
+            }
         }
         // main phase: one table load per iteration.  One row left: J (or 2J) symbols per load from the walk tables; otherwise K symbols from the
         // context table.  A step that would empty the interval (or meets an odd symbol) ends the phase WITHOUT touching the cursor:
@@ -1496,12 +1501,12 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
                 q0 = nib16 ? query_code16(qst, m - 1u - done, false, v0) : code_of(done, ac.J, ac.wbits, v0);
                 q1 = nib16 ? query_code16(qst, m - 17u - done, false, v1) : code_of(done + ac.J, ac.J, ac.wbits, v1);
                 if (!(v0 && v1)) break;
-                kind = 1; p0 = reinterpret_cast<const uint8_t*>(ac.walk2 + 3u * (size_t)lb);
+                kind = 1; p0 = reinterpret_cast<const uint8_t*>(ac.walk2) + (size_t)lb * kWalk2EntryBytes;
             } else if (ac.walk && len == 1 && m - done >= ac.J) {
                 bool v = false;
                 q0 = nib16 ? query_code16(qst, m - 1u - done, false, v) : code_of(done, ac.J, ac.wbits, v);
                 if (!v) break;
-                kind = 2; p0 = reinterpret_cast<const uint8_t*>(ac.walk + lb);
+                kind = 2; p0 = reinterpret_cast<const uint8_t*>(ac.walk) + (size_t)lb * kWalkEntryBytes;
             } else if (ac.kblk) {
                 bool valid = false;
                 const uint32_t code = code_of(done, K, 0, valid);
@@ -1520,20 +1525,24 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
             }
             const uint4 r0 = *reinterpret_cast<const uint4*>(p0);
             uint4 r1 = r0;
-            tbytes += kind == 2u ? 8u : 12u; ++tacc;
+            tbytes += kind == 2u ? (uint32_t)kWalkEntryBytes : (kind == 1u ? (uint32_t)kWalk2EntryBytes : 12u); ++tacc;
+            // the entry's fields by row width: the row reached (all ones: a delimiter on the way) and the code(s) of the symbols met
+            const bool w_none = kWide ? (r0.x == 0xffffffffu && r0.y == 0xffffffffu) : r0.x == 0xffffffffu;
+            const idx_t w_row = kWide ? (idx_t)((uint64_t)r0.x | ((uint64_t)r0.y << 32)) : (idx_t)r0.x;
+            const uint32_t w_c0 = kWide ? r0.z : r0.y, w_c1 = kWide ? r0.w : r0.z;
             if (kind == 3u && (a >> 6) != (b >> 6)) { r1 = *reinterpret_cast<const uint4*>(p0 + ((size_t)(b >> 6) - (size_t)(a >> 6)) * ((size_t)ncodes * 16u)); tbytes += 12u; ++tacc; }
             if (kind == 1u) {
-                if (r0.x == 0xffffffffu) break;
-                if (r0.y != q0 || r0.z != q1) {                  // symbols matching before the first differing one
-                    const uint32_t same = r0.y != q0 ? ((uint32_t)__ffs((int)(r0.y ^ q0)) - 1u) / ac.wbits : ac.J + ((uint32_t)__ffs((int)(r0.z ^ q1)) - 1u) / ac.wbits;
+                if (w_none) break;
+                if (w_c0 != q0 || w_c1 != q1) {                  // symbols matching before the first differing one
+                    const uint32_t same = w_c0 != q0 ? ((uint32_t)__ffs((int)(w_c0 ^ q0)) - 1u) / ac.wbits : ac.J + ((uint32_t)__ffs((int)(w_c1 ^ q1)) - 1u) / ac.wbits;
                     walks = false; limit = done + same;
                     continue;
                 }
-                lb = r0.x; done += 2u * ac.J; steps += 2u * ac.J;
+                lb = w_row; done += 2u * ac.J; steps += 2u * ac.J;
             } else if (kind == 2u) {
-                if (r0.x == 0xffffffffu) break;
-                if (r0.y != q0) { walks = false; limit = done + ((uint32_t)__ffs((int)(r0.y ^ q0)) - 1u) / ac.wbits; continue; }
-                lb = r0.x; done += ac.J; steps += ac.J;
+                if (w_none) break;
+                if (w_c0 != q0) { walks = false; limit = done + ((uint32_t)__ffs((int)(w_c0 ^ q0)) - 1u) / ac.wbits; continue; }
+                lb = w_row; done += ac.J; steps += ac.J;
             } else {
                 const idx_t ra = r0.x + popc64(((uint64_t)r0.y | ((uint64_t)r0.z << 32)) & lowmask(a & 63u));
                 const idx_t rb = r1.x + popc64(((uint64_t)r1.y | ((uint64_t)r1.z << 32)) & lowmask(b & 63u));
@@ -1557,6 +1566,7 @@ __global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uin
     add_counters(steps_total, steps, tbytes, tacc);
 }
 
+#if !FMGPU_WIDE   // ======== 32-bit rows only: the table-driven k-mismatch kernels (LF / walk / prefix tables, their frames and transport words hold 32-bit rows)
 // when a wave fetches and stages new queries (a wave-synchronous phase of ~15 loads and LDS stores per lane, paid by all 64 lanes): when the
 // iterations its idle lanes have lost add up to kRefillWaste lane-iterations.  A refill costs the working lanes more than it looks: measured on
 // 10 M reads, waste threshold 256 / 512 / 2048 / 4096 lane-iterations = uniform text with tables 8.1 / 6.65 / 6.64 / 6.64 ms, uniform plain index
@@ -3183,7 +3193,6 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
     const dim3 block(256);
     const idx_t n = (idx_t)x->bwt.n;
     timer.start();
-#if !FMGPU_WIDE
     uint32_t kq_words = 0, kq_max = 0, kq_nib = x->bwt.sigma <= 15 ? 1u : 0u;
     const bool accel = x->bwt.kblk || x->bwt.slut || x->bwt.walkj;
     if (accel) {                                                 // LDS staging needs the longest query of the batch
@@ -3204,7 +3213,6 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
             return 0;
         });
     } else
-#endif
     if (x->bwt.search_family() == FAM_A) {
         auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
         // k_exact_a runs best with 5 resident blocks per CU, not the 8 its 28 registers allow (measured on the 3.09 Gbp index, 10 M x 101 bp: 8 / 6 / 5 / 4 / 3

@@ -22,9 +22,10 @@
  *     row indices, interval bounds and counts are uint64_t like the reference's size_t.
  *   - row width: an index of fewer than 2^32 - 64 rows is held in 32-bit device tables and may use every optional accelerator table below;
  *     a larger one (up to 2^40 rows; the reference switches to a 64-bit suffix array at 2^31 rows, utils.h:243-247) is held in 64-bit-row
- *     tables: construction, exact search, search_ng26 (Hamming and edit distance), search_ng21, search_backtracking, locate, cursor steps
- *     and String_c queries work on it; the accelerator tables (and with them the table-driven kernels) and the one-word transport forms
- *     return FMGPU_ERR_UNSUPPORTED (fmgpu_index_row_bits tells which).
+ *     tables: construction, exact search (with the interval and walk tables of fmgpu_index_accelerate_exact, 16-byte entries), search_ng26
+ *     (Hamming and edit distance; equal-length Hamming batches on the lean kernel like 32-bit rows), search_ng21, search_backtracking, locate,
+ *     cursor steps, String_c queries and the index file work on it; the multi-symbol-step table, the k-mismatch tables (LF^1..3, walk, prefix),
+ *     the locate answer table and the one-word transport forms return FMGPU_ERR_UNSUPPORTED (fmgpu_index_row_bits tells which).
  */
 #ifndef FMGPU_H
 #define FMGPU_H
@@ -198,7 +199,8 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep);   /* (all fmgpu_inde
  *                starts from the entry of its last lut_len symbols instead of lut_len wide-interval steps;
  *   walk != 0:   per row LF^J and the J symbols met on the way, J = 32 / bit_width(sigma-2) (DNA: 16 symbols, protein: 6; 8 bytes per row):
  *                once the interval is one row, J query symbols are checked and consumed with one load;
- *   walk >= 2:   additionally LF^(2J) and the 2J symbols (12 bytes per row): 32 bp / 12 aa per load while that many symbols remain. */
+ *   walk >= 2:   additionally LF^(2J) and the 2J symbols (12 bytes per row): 32 bp / 12 aa per load while that many symbols remain.
+ * 64-bit-row indices: kstep <= 1 (the multi-symbol-step table holds 32-bit counts), every entry of the interval and walk tables is 16 bytes. */
 int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk);
 
 /* Optional accelerators for fmgpu_search_scheme on a BiFMIndex (results unchanged):

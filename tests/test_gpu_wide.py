@@ -70,15 +70,25 @@ def test_wide_exact_search_and_locate(layout, sigma):
     for k in range(0, rows.size, 7):
         assert (seq[k], pos[k], steps[k]) == ox.locate(int(rows[k]))
     # what only the 32-bit-row build offers says so instead of misbehaving
-    for call in (lambda: gx.accelerate(3), lambda: gx.accelerate(1, lut_len=4), lambda: gx.accelerate_locate(),
-                 lambda: fm.search_no_errors.search_packed(gx, (qbuf, qoff))):
+    for call in (lambda: gx.accelerate(3), lambda: gx.accelerate_locate(), lambda: fm.search_no_errors.search_packed(gx, (qbuf, qoff))):
         with pytest.raises(fm.FmgpuError) as ei:
             call()
         assert ei.value.code == capi.FMGPU_ERR_UNSUPPORTED
-    if layout not in ("IB16", "IBP16", "IB16A", "FBV_512_64K", "EPRV5"):       # Format A expansion of the other layouts works in both builds
-        gx.accelerate(1)
-        lb2, ln2 = fm.search_no_errors.search(gx, (qbuf, qoff))
-        assert np.array_equal(lb2, olb) and np.array_equal(ln2, oln)
+    # the exact-search tables of 64-bit rows (16-byte entries): interval table, LF^J walk, LF^2J walk — on the native layout or its Format A expansion;
+    # cursor and executed steps are those of the CPU walk whatever the tables
+    osteps = ox.search_exact(qbuf, qoff, want_steps=True)[2]
+    long_reads = sample_reads(text, 1500, 70 if sigma <= 6 else 40, seed=19, mutate=1, sigma=sigma)
+    lq, lo_ = fm.flatten(long_reads)
+    llb, lln, lsteps = ox.search_exact(lq, lo_, want_steps=True)
+    for kstep, lut_len, walk in ((1, 4, 0), (1, 0, 1), (1, 3, 2), (0, 2, 1)):
+        if sigma > 32 and lut_len > 2:
+            lut_len = 2
+        gx.accelerate(kstep, lut_len=lut_len, walk=walk)
+        lb2, ln2, st2 = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+        assert np.array_equal(lb2, olb) and np.array_equal(ln2, oln) and st2.lf_steps == int(osteps.sum()), (kstep, lut_len, walk)
+        lb3, ln3, st3 = fm.search_no_errors.search(gx, (lq, lo_), want_stats=True)
+        assert np.array_equal(lb3, llb) and np.array_equal(ln3, lln) and st3.lf_steps == int(lsteps.sum()), (kstep, lut_len, walk)
+    gx.accelerate(0)
 
 
 @pytest.mark.parametrize("layout,sigma,k", [("IB16", 5, 1), ("IB16", 5, 2), ("EPRV2_16", 5, 2), ("WAVELET", 28, 1), ("IB16", 256, 1), ("IB8", 6, 2)])
