@@ -328,11 +328,16 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
 // ---- wave-level reservations for the DFS kernels ----------------------------------------------------------------------------------
 // One atomicAdd per hit (or per query handed out) queues millions of atomics behind each other on one address: ~9 ns each, more than the
 // searches themselves.  Instead every lane of a wave passes a synchronous section in each loop iteration (a lane without work idles until
-// the whole wave is done): queries are handed out with one reservation for all lanes that want one, hits are kept in LDS
-// (kWaveHitBuf per lane) and written out by the whole wave with one reservation as soon as some lane's buffer is full.
-constexpr uint32_t kWaveHitBuf = 2;
+// the whole wave is done): queries are handed out with one reservation for all lanes that want one, and hit records go to a ring per WAVE in
+// LDS — the slot from an LDS atomic on the ring's fill count — that the whole wave writes out with ONE reservation once it holds kWaveRingFlush
+// records.  (Round 2 kept two slots per LANE and flushed when one lane's were full: a lane in a repeat fills its two while the other 63 are
+// empty — one reservation per ~6 records, 8.8 M returning atomics on one word per 10 M reads, near the ~88 M/s a single word sustains.)
+constexpr uint32_t kWaveHitBuf = 2;                               // (sizes the LDS area: 2 x 64 record slots per wave)
 constexpr uint32_t kHitWords = kWide ? 10u : 7u;                  // [qidx lo, qidx hi, lb, lbRev, len, e, seq (, high words of lb, lbRev, len)]
-constexpr uint32_t kWaveHitWords = kWaveHitBuf * kHitWords * 256u;   // [slot][word][thread]
+constexpr uint32_t kWaveHitWords = kWaveHitBuf * kHitWords * 256u;   // per block: 4 waves x [word][128 slots]; slot 0 of word 0 is the ring's fill count
+constexpr uint32_t kWaveRingSlots = kWaveHitBuf * 64u - 1u;       // 127 records per wave
+constexpr uint32_t kWaveRingFlush = 64u;                          // written out once this many are waiting: 63 more fit (one per lane and iteration), a surplus goes out one by one
+typedef __attribute__((address_space(3))) uint32_t lds_word;
 
 __device__ __forceinline__ uint64_t wave_hand_out(bool want, Counters* ctr, uint32_t lane) {     // all lanes call; valid for lanes with `want`
     const uint64_t wm = __ballot(want);
@@ -343,30 +348,44 @@ __device__ __forceinline__ uint64_t wave_hand_out(bool want, Counters* ctr, uint
     base = ((unsigned long long)__shfl((uint32_t)(base >> 32), leader, 64) << 32) | __shfl((uint32_t)base, leader, 64);
     return base + (uint64_t)__popcll(wm & ((1ull << lane) - 1ull));
 }
-__device__ __forceinline__ void wave_keep_hit(uint32_t* s_hb, uint32_t& nh, fmgpu_hit* out, uint64_t cap, Counters* ctr, uint64_t q, Cur r, uint32_t e, uint32_t seq) {
-    if (nh < kWaveHitBuf) {
-        uint32_t* h = s_hb + (size_t)nh * kHitWords * 256u + threadIdx.x;
-        h[0] = (uint32_t)q; h[256] = (uint32_t)(q >> 32); h[512] = (uint32_t)r.lb; h[768] = (uint32_t)r.lbRev; h[1024] = (uint32_t)r.len; h[1280] = e; h[1536] = seq;
-        if constexpr (kWide) { h[1792] = (uint32_t)((uint64_t)r.lb >> 32); h[2048] = (uint32_t)((uint64_t)r.lbRev >> 32); h[2304] = (uint32_t)((uint64_t)r.len >> 32); }
-        ++nh;
-    } else emit_hit(out, cap, ctr, q, r, e, seq);                  // (cannot happen while the wave flushes whenever a buffer is full)
+__device__ __forceinline__ uint32_t* wave_ring(uint32_t* s_hb) { return s_hb + (threadIdx.x >> 6) * (kWaveHitBuf * kHitWords * 64u); }
+__device__ __forceinline__ void wave_ring_init(uint32_t* s_hb) {  // every wave, before its first record (LDS operations of one wave execute in order)
+    if ((threadIdx.x & 63u) == 0) __hip_atomic_store((lds_word*)wave_ring(s_hb), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
-__device__ __forceinline__ void wave_flush_hits(const uint32_t* s_hb, uint32_t& nh, uint32_t lane, fmgpu_hit* out, uint64_t cap, Counters* ctr) {   // all lanes call
-    const uint32_t before = wave_excl_scan(nh, lane);
-    const uint32_t total = __shfl(before + nh, 63, 64);
-    unsigned long long slot = 0;
-    if (lane == 0 && total) slot = atomicAdd(&ctr->hits, (unsigned long long)total);
-    slot = ((unsigned long long)__shfl((uint32_t)(slot >> 32), 0, 64) << 32) | __shfl((uint32_t)slot, 0, 64);
-    for (uint32_t k = 0; k < nh; ++k) {
-        const uint32_t* h = s_hb + (size_t)k * kHitWords * 256u + threadIdx.x;
-        const unsigned long long at = slot + before + k;
-        if (at < cap) {
-            fmgpu_hit rec;
-            rec.qidx = (uint64_t)h[0] | ((uint64_t)h[256] << 32); rec.lb = h[512]; rec.lb_rev = h[768]; rec.len = h[1024];
-            if constexpr (kWide) { rec.lb |= (uint64_t)h[1792] << 32; rec.lb_rev |= (uint64_t)h[2048] << 32; rec.len |= (uint64_t)h[2304] << 32; }
-            rec.errors = h[1280]; rec.seq = h[1536];
-            out[at] = rec;
+__device__ __forceinline__ uint32_t wave_ring_fill(uint32_t* s_hb) {   // wave-uniform
+    return __hip_atomic_load((lds_word*)wave_ring(s_hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void wave_keep_hit(uint32_t* s_hb, uint32_t& nh, fmgpu_hit* out, uint64_t cap, Counters* ctr, uint64_t q, Cur r, uint32_t e, uint32_t seq) {
+    uint32_t* ring = wave_ring(s_hb);
+    const uint32_t slot = 1u + __hip_atomic_fetch_add((lds_word*)ring, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    constexpr uint32_t W = kWaveHitBuf * 64u;                      // slots per word plane
+    if (slot <= kWaveRingSlots) {
+        uint32_t* h = ring + slot;
+        h[0] = (uint32_t)q; h[W] = (uint32_t)(q >> 32); h[2 * W] = (uint32_t)r.lb; h[3 * W] = (uint32_t)r.lbRev; h[4 * W] = (uint32_t)r.len; h[5 * W] = e; h[6 * W] = seq;
+        if constexpr (kWide) { h[7 * W] = (uint32_t)((uint64_t)r.lb >> 32); h[8 * W] = (uint32_t)((uint64_t)r.lbRev >> 32); h[9 * W] = (uint32_t)((uint64_t)r.len >> 32); }
+    } else emit_hit(out, cap, ctr, q, r, e, seq);                  // the ring is full (more than 63 records since the wave last looked): this one goes out alone
+    (void)nh;
+}
+__device__ __forceinline__ void wave_flush_hits(uint32_t* s_hb, uint32_t& nh, uint32_t lane, fmgpu_hit* out, uint64_t cap, Counters* ctr) {   // all lanes call
+    uint32_t* ring = wave_ring(s_hb);
+    const uint32_t total = min(wave_ring_fill(s_hb), kWaveRingSlots);
+    constexpr uint32_t W = kWaveHitBuf * 64u;
+    if (total) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->hits, (unsigned long long)total);
+        base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0, 64) << 32) | __shfl((uint32_t)base, 0, 64);
+        for (uint32_t k = 1u + lane; k <= total; k += 64u) {
+            const uint32_t* h = ring + k;
+            const unsigned long long at = base + (k - 1u);
+            if (at < cap) {
+                fmgpu_hit rec;
+                rec.qidx = (uint64_t)h[0] | ((uint64_t)h[W] << 32); rec.lb = h[2 * W]; rec.lb_rev = h[3 * W]; rec.len = h[4 * W];
+                if constexpr (kWide) { rec.lb |= (uint64_t)h[7 * W] << 32; rec.lb_rev |= (uint64_t)h[8 * W] << 32; rec.len |= (uint64_t)h[9 * W] << 32; }
+                rec.errors = h[5 * W]; rec.seq = h[6 * W];
+                out[at] = rec;
+            }
         }
+        if (lane == 0) __hip_atomic_store((lds_word*)ring, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
     nh = 0;
 }
@@ -554,6 +573,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? (kWide ? 4 : 5) : 1) void k_sche
     const uint32_t lane = threadIdx.x & 63u;
     __shared__ uint32_t s_hb[kWaveHitWords];
     uint32_t nh = 0;
+    wave_ring_init(s_hb);
     uint64_t q = 0;
     uint32_t si = 0;                        // current search
     bool idle = false, have_query = false, fresh = false;
@@ -651,7 +671,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? (kWide ? 4 : 5) : 1) void k_sche
                 if (m >= P && m <= stk.depth && (sch.uniform || m == sch.psum) && n != 0) { have_query = true; fresh = true; }
             }
         }
-        const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(!idle);
+        const bool full = wave_ring_fill(s_hb) >= kWaveRingFlush; const uint64_t busy = __ballot(!idle);
         if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
         if (!busy) break;
         if (idle) continue;
@@ -841,6 +861,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
     const uint32_t lane = threadIdx.x & 63u;
     __shared__ uint32_t s_hb[kWaveHitWords];
     uint32_t nh = 0;
+    wave_ring_init(s_hb);
     uint64_t q = 0;
     uint32_t si = 0;
     bool idle = false, have_query = false, fresh = false;
@@ -926,7 +947,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
                 if (m >= P && m <= maxm && (sch.uniform || m == sch.psum) && n != 0) { have_query = true; fresh = true; }
             }
         }
-        const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(!idle);
+        const bool full = wave_ring_fill(s_hb) >= kWaveRingFlush; const uint64_t busy = __ballot(!idle);
         if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
         if (!busy) break;
         if (idle) continue;
@@ -1130,6 +1151,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
     extern __shared__ uint32_t s_query[];
     const QStage qst{s_query, qwords, qnib};
     __shared__ uint32_t s_hb[kWaveHitWords];
+    wave_ring_init(s_hb);
     __shared__ idx_t s_C[257];
     if (lfv.fw) for (uint32_t i = threadIdx.x; i <= fw.sigma(); i += blockDim.x) s_C[i] = lfv.C[i];
     if (tab_lds) {                                                  // the step table sits behind the staged queries
@@ -1204,7 +1226,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
                 if ((uint32_t)(qoff[q + 1] - qo) >= M && n != 0) { have_query = true; fresh = true; }   // (a shorter query is read out of bounds by the reference)
             }
         }
-        const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(!idle);
+        const bool full = wave_ring_fill(s_hb) >= kWaveRingFlush; const uint64_t busy = __ballot(!idle);
         if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
         if (!busy) break;
         if (idle) continue;
@@ -1610,7 +1632,8 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
     const uint32_t* s_stretch = s_steps + S * stride;               // stretch words of the run16 steps
     const uint32_t* s_stretch3 = s_steps + 2u * S * stride;         // ... and of the <= 3 steps of a `run`
-    uint32_t* s_hb = s_steps + 3u * S * stride;                     // kWaveHitWords: the wave's hit buffers (wave_keep_hit / wave_flush_hits)
+    uint32_t* s_hb = s_steps + 3u * S * stride;                     // kWaveHitWords: the waves' hit rings (wave_keep_hit / wave_flush_hits)
+    wave_ring_init(s_hb);
     const QStage qst{s_dyn, qwords, qnib};
     for (uint32_t i = threadIdx.x; i < 3u * S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
     __syncthreads();
@@ -1692,7 +1715,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
             __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0) in this rare path: or the compiler, unsure whether a staging load is still pending, waits for vmcnt(0) in every iteration
         }
         {
-            const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(have);
+            const bool full = wave_ring_fill(s_hb) >= kWaveRingFlush; const uint64_t busy = __ballot(have);
             if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
             if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
         }
@@ -2043,6 +2066,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
     uint32_t* s_hb = s_steps + 2u * S * stride;                     // kWaveHitWords
+    wave_ring_init(s_hb);
     const QStage qst{s_dyn, qwords, qnib};
     for (uint32_t i = threadIdx.x; i < 2u * S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
     __syncthreads();
@@ -2128,7 +2152,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
             __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0) in this rare path: or the compiler, unsure whether a staging load is still pending, waits for vmcnt(0) in every iteration
         }
         {
-            const uint64_t full = __ballot(nh == kWaveHitBuf), busy = __ballot(have);
+            const bool full = wave_ring_fill(s_hb) >= kWaveRingFlush; const uint64_t busy = __ballot(have);
             if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
             if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
         }
