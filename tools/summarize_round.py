@@ -25,6 +25,10 @@ try:
     res["bench_line"] = json.loads(open(d + "/bench_line.json").read())
 except Exception:
     pass
+try:                                                             # the full records of the trace pass (bench.py writes them beside its compact line)
+    res["bench_records"] = [{k: r[k] for k in ("id", "value", "unit", "ms_per_step", "roofline", "hits") if k in r} for r in json.load(open(d + "/bench_records_trace.json"))["records"]]
+except Exception:
+    pass
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("hbm_traffic_bytes_per_launch",) if k in res}))
 print([ (k["name"][:60], k["avg_ms"]) for k in res["kernel_stats"][:4]])
