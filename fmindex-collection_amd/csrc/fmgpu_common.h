@@ -26,6 +26,13 @@
 //     (string/InterleavedBitvector.h:13-60) and shifts rows by one bit (row p <-> bit (p+1)&63 of block
 //     (p+1)>>6); both are normalised away at upload, results are identical.
 //
+//  Format D  ("dense DNA": sigma = 5 strings of a BiFMIndex with 32-bit rows, beside Format A — what the k-mismatch kernel on the plain index reads):
+//     one block of 32 bytes per 64 rows:  u32 occ[4] = C[c] + #{ j < 64B : s[j] == c } for c = 1..4;  u64 p0, p1 = bit r: bit 0 / bit 1 of (s[64B + r] - 1).
+//     The depth-first kernels are bound by the number of vector-memory instructions a node costs (16 bytes per lane and instruction at most; one more
+//     access per interval end, same line: 107 -> 140 ms): two per end here, three from Format A.  A delimiter row is written as code 0 and would count as an
+//     'A'; the few rows that hold one (one per sequence) are listed — `dense_ex`, ascending — and blocks that may hold one are marked in a 2048-bit filter
+//     (block number mod 2048): a marked block takes a slow path that consults the list.  Built when the string has at most 256 delimiters.
+//
 //  Format R  (reference layout as is — InterleavedEPR*, InterleavedEPRV2*): blocks + superBlocks copied verbatim.
 //
 //  Format W  (the reference's binary wavelet tree, one 64-byte line per 384 node bits; built from Wavelet::bitvector[*] at upload and only
@@ -103,7 +110,7 @@ inline int grid_of(uint64_t threads, dim3* out, uint64_t cap_blocks = 0) {
 // kernel through them).  Everything else — count-only runs, per-read node dumps, tuning fields, residency overrides (FMGPU_DEV_*) — exists in
 // builds made with -DFMGPU_DEV only (make DEV=1; tools/k2_*_probe.py): a stray environment variable cannot make the shipped library drop records
 // or write outside a caller's buffer.
-constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 24) | (1 << 30);   // general kernel | no prefix table | no LF^1..3 | no LF table in the general kernels | no walk table | no length buckets | no work sharing | k_scheme_fast<PLAIN> instead of k_scheme_lean
+constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 24) | (1 << 29) | (1 << 30);   // general kernel | no prefix table | no LF^1..3 | no LF table in the general kernels | no walk table | no length buckets | no work sharing | k_scheme_lean on Format A although Format D exists | k_scheme_fast<PLAIN> instead of k_scheme_lean
 inline const char* dev_env(const char* name) {
 #ifdef FMGPU_DEV
     return getenv(name);
@@ -651,6 +658,8 @@ struct DevString {
     uint32_t* walk2j = nullptr;
     // Format A shadow of a Format R / M string (fmgpu_index_accelerate, kstep >= 1): the searches then read `va` (one line per
     // LF step instead of one per level); fmgpu_string_query keeps answering from the native format.
+    // Format D (see the head of this file): dense DNA blocks + the ascending list of the rows that hold a delimiter (u32, `dense_nex` of them)
+    void* dense = nullptr; size_t dense_bytes = 0; uint32_t* dense_ex = nullptr; uint32_t dense_nex = 0;
     void* shadow = nullptr; size_t shadow_bytes = 0;   // (shadow_bytes = blocks + super table)
     void* shadow_sup = nullptr; size_t shadow_sup_bytes = 0;
     int search_family() const { return shadow ? (int)FAM_A : family; }
@@ -667,6 +676,8 @@ int on_handle_device(const Index* x);
 
 // fills s.lf_table from the device string (all layouts); defined in fmgpu_index.hip
 int build_lf_table(DevString& s, hipStream_t stream);
+// builds Format D beside a sigma = 5 Format A string (no-op where it does not apply); defined in fmgpu_index.hip
+int build_dense_dna(DevString& s, hipStream_t stream);
 // moves the sampled suffix array's presence bits into the bwt's Format A blocks (sigma <= 5; see "Fused presence bits"); defined in fmgpu_index.hip
 int fuse_presence_bits(Index* x, hipStream_t stream);
 void free_string(DevString& s);

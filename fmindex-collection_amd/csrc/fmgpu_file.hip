@@ -277,6 +277,12 @@ int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
             s.vm.super = (kWide && s.sup) ? reinterpret_cast<const uint64_t*>((const uint8_t*)s.sup + o.vm_super_off) : nullptr;
         }
     }
+    // Format D is derived data (a few ms): rebuilt rather than stored
+    if (x->bidirectional) {
+        for (DevString* t : {&x->bwt, &x->rev}) if ((rc = build_dense_dna(*t, nullptr))) return bail(rc);
+        if (x->bwt.dense && !x->rev.dense) { (void)hipFree(x->bwt.dense); (void)hipFree(x->bwt.dense_ex); x->bwt.dense = nullptr; x->bwt.dense_ex = nullptr; x->bwt.dense_bytes = 0; x->bwt.dense_nex = 0; }
+        x->device_bytes += x->bwt.dense_bytes + x->rev.dense_bytes;
+    }
     FM_HIP(hipDeviceSynchronize());
     *out = reinterpret_cast<fmgpu_index_t>(x.release());
     return 0;

@@ -144,6 +144,51 @@ int fuse_presence_bits(Index* x, hipStream_t stream) {
     return 0;
 }
 
+// ---- Format D (fmgpu_common.h): from the Format A blocks of a sigma = 5 string.  One thread per block; a delimiter row (no symbol >= 1 claims it) is appended to the list
+constexpr uint32_t kDenseMaxDelims = 256;
+__global__ __launch_bounds__(256) void k_dense_dna(const uint8_t* __restrict__ blk, uint64_t nblocks, uint64_t n, uint4* __restrict__ out, uint32_t* __restrict__ ex, uint32_t* __restrict__ nex) {
+    const uint64_t B = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (B >= nblocks) return;
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(blk + B * 64u);
+    uint64_t bits[5];
+    for (int c = 1; c < 5; ++c) bits[c] = (uint64_t)d[3 * c + 1] | ((uint64_t)d[3 * c + 2] << 32);
+    const uint64_t p0 = bits[2] | bits[4], p1 = bits[3] | bits[4];
+    out[2 * B] = make_uint4(d[3], d[6], d[9], d[12]);
+    out[2 * B + 1] = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
+    const uint64_t rows = n - B * 64u < 64u ? n - B * 64u : 64u;
+    uint64_t none = ~(bits[1] | bits[2] | bits[3] | bits[4]);
+    if (rows < 64u) none &= (1ull << rows) - 1ull;
+    while (none) {
+        const uint32_t r = (uint32_t)__ffsll((unsigned long long)none) - 1u;
+        none &= none - 1ull;
+        const uint32_t k = atomicAdd(nex, 1u);
+        if (k < kDenseMaxDelims) ex[k] = (uint32_t)(B * 64u + r);
+    }
+}
+int build_dense_dna(DevString& s, hipStream_t stream) {
+    const char* off = getenv("FMGPU_DENSE_DNA");
+    if (kWide || s.sigma != 5 || s.family != FAM_A || s.shadow || s.va.bstride != 64u || s.n < 2 || s.dense || (off && atoi(off) == 0)) return 0;
+    // (reads the entries of symbols 1..4 only: entry 0's bitmap may already hold the presence bits)
+    const uint64_t nblocks = s.n / 64 + 1;
+    DBuf out, ex, cnt; int rc;
+    if ((rc = out.alloc(nblocks * 32 + 64)) || (rc = ex.alloc(kDenseMaxDelims * 4)) || (rc = cnt.alloc(8))) return rc;
+    FM_HIP(hipMemsetAsync(cnt.p, 0, 8, stream));
+    FM_HIP(hipMemsetAsync(ex.p, 0xff, kDenseMaxDelims * 4, stream));
+    FM_GRID(grid, nblocks);
+    k_dense_dna<<<grid, dim3(256), 0, stream>>>((const uint8_t*)s.blk, nblocks, s.n, out.as<uint4>(), ex.as<uint32_t>(), cnt.as<uint32_t>());
+    FM_LAUNCHED("k_dense_dna");
+    uint32_t nex = 0;
+    FM_HIP(hipMemcpyAsync(&nex, cnt.p, 4, hipMemcpyDeviceToHost, stream));
+    FM_HIP(hipStreamSynchronize(stream));
+    if (nex > kDenseMaxDelims) return 0;                         // many sequences: the k-mismatch kernel reads Format A
+    std::vector<uint32_t> rows(nex);
+    if (nex) FM_HIP(hipMemcpy(rows.data(), ex.p, nex * 4, hipMemcpyDeviceToHost));
+    std::sort(rows.begin(), rows.end());
+    if (nex) FM_HIP(hipMemcpy(ex.p, rows.data(), nex * 4, hipMemcpyHostToDevice));
+    s.dense_bytes = out.bytes; s.dense = out.take(); s.dense_ex = (uint32_t*)ex.take(); s.dense_nex = nex;
+    return 0;
+}
+
 // EPRV3 / EPRV4 / EPRV5 / InterleavedEPRV7 -> Format A.  thread = (block B, symbol c): the symbol-match mask of the bit planes
 // (EPRV3.h:55-68) becomes the entry's bitmap (position p <-> bit p & 63, as in Format A), the counters of every level that
 // cover row 64B (EPRV3.h:205-213, EPRV4.h:128-142, EPRV5.h:126-139, InterleavedEPRV7.h:190-199) are summed into cnt.
@@ -290,7 +335,7 @@ int on_handle_device(const Index* x) {
 }
 
 void free_string(DevString& s) {
-    for (void* p : {s.blk, s.aux, s.sup, (void*)s.lf_table, (void*)s.kblk, (void*)s.walk3, s.shadow, s.shadow_sup, (void*)s.slut, (void*)s.walkj, (void*)s.walk2j})
+    for (void* p : {s.blk, s.aux, s.sup, (void*)s.lf_table, (void*)s.kblk, (void*)s.walk3, s.shadow, s.shadow_sup, (void*)s.slut, (void*)s.walkj, (void*)s.walk2j, s.dense, (void*)s.dense_ex})
         if (p) (void)hipFree(p);
     s = DevString{};
 }
@@ -716,11 +761,13 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
     if (rc) return bail(rc);
     rc = create_string(desc->bwt, x->dC, x->bwt); if (rc) return bail(rc);
     if (desc->bwt_rev) { rc = create_string(*desc->bwt_rev, x->dC, x->rev); if (rc) return bail(rc); x->bidirectional = true; }
+    if (x->bidirectional) for (DevString* t : {&x->bwt, &x->rev}) { rc = build_dense_dna(*t, nullptr); if (rc) return bail(rc); }
+    if (x->bwt.dense && !x->rev.dense) { (void)hipFree(x->bwt.dense); (void)hipFree(x->bwt.dense_ex); x->bwt.dense = nullptr; x->bwt.dense_ex = nullptr; x->bwt.dense_bytes = 0; x->bwt.dense_nex = 0; }
     if (lf_table_wanted()) {
         rc = build_lf_table(x->bwt, nullptr); if (rc) return bail(rc);
         if (x->bidirectional) { rc = build_lf_table(x->rev, nullptr); if (rc) return bail(rc); }
     }
-    x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->bwt.sup_bytes + x->rev.blk_bytes + x->rev.aux_bytes + x->rev.sup_bytes +
+    x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->bwt.sup_bytes + x->rev.blk_bytes + x->rev.aux_bytes + x->rev.sup_bytes + x->bwt.dense_bytes + x->rev.dense_bytes +
                       (x->bwt.lf_table ? x->bwt.n * sizeof(idx_t) : 0) + (x->rev.lf_table ? x->rev.n * sizeof(idx_t) : 0);
     if (const fmgpu_sparse_array_desc* sa = desc->annotated_array) {
         if (sa->n != desc->bwt.n) return bail(fail(FMGPU_ERR_INVALID, "annotated_array.n != bwt.n"));

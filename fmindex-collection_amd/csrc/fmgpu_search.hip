@@ -2380,7 +2380,7 @@ constexpr uint32_t kRingWords = kWide ? 7u : 6u;   // qidx, lb, lbRev, len, erro
 constexpr uint32_t kLeanRefillWaste = 2048;        // (kRefillWaste of k_scheme_fast)
 constexpr uint32_t kLeanSuperRows = kWide ? 64u : 1u;   // super-block rows per direction staged in LDS (64 x 2^30 rows: more than HBM holds)
 constexpr uint32_t kLeanNoResume = 7u;
-constexpr int kLeanWaves = kWide ? 4 : 6;   // resident blocks per CU the register allocation allows (the grid asks for 3; 64-bit rows need ~100 registers)
+constexpr int kLeanWaves = 4;            // resident blocks per CU the register allocation allows (the grid asks for 3: the loop is bound by the L1 access rate, not by latency)
 constexpr int kLeanSteps = 4;            // node steps per pass through the wave-synchronous part (genome text, kernel ms at 101 / 151 bp: 1 step 119 / 213, 2: 114 / 195, 4: 112 / 183)
 
 struct LeanArgs {
@@ -2390,6 +2390,8 @@ struct LeanArgs {
     idx_t ksum;                              // C[1] + ... + C[4] mod 2^width: LF(i, 0) = i + ksum - sum of the other symbols' LF (the kernel never reads entry 0)
     const uint64_t* sup_fw; const uint64_t* sup_rv;   // 64-bit rows: [row >> 30][5] counts at the start of each super-block
     uint32_t super_rows;
+    const uint4* dfw; const uint4* drv;               // Format D blocks (DENSE instantiation), two uint4 per 64 rows
+    const uint32_t* ex_fw; const uint32_t* ex_rv; uint32_t nex_fw, nex_rv;   // ... and their delimiter rows, ascending
 };
 // a frame as two 64-bit words (what travels between lanes when a subtree is handed over) <-> its fields
 __device__ __forceinline__ void lean_pack(idx_t lb, idx_t lbRev, idx_t len, uint32_t j, uint32_t e, uint32_t next, uint64_t& w0, uint64_t& w1) {
@@ -2479,12 +2481,17 @@ __device__ __forceinline__ void ring_flush(lds_u32* s_cnt_w, const uint32_t* rin
 
 // NSTEP: nodes a lane visits per pass through the wave-synchronous part (work sharing, refill, ring flush: ~150 of the ~550 wave instructions of an
 // iteration — the loop is bound by instruction issue): a lane that runs out of work inside the inner loop waits for the next pass
-template <int WAVES, int NSTEP>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
+// DENSE: the blocks are Format D (fmgpu_common.h; 32 bytes per 64 rows: two vector-memory instructions per interval end instead of three — the loop is bound
+// by their number); the delimiter rows, written as 'A' there, are corrected from a list behind a filter, both staged in LDS.
+constexpr uint32_t kDenseFilterBits = 32768;      // block number mod this: 25 delimiter rows mark 0.08 % of the blocks, ~7 % of the iterations of a wave meet one
+template <int WAVES, int NSTEP, bool DENSE>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
 __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
                                                              fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, ulonglong2* __restrict__ frames, uint64_t nlanes,
                                                              uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste) {
     extern __shared__ uint32_t s_dyn[];                             // [qwords][256] staged reads | [256] top frames (16 B) | [S][m + 1] steps | [4] ring fill | 4 x [kRingWords][kRingCap] rings
     __shared__ uint64_t s_sup[2u * kLeanSuperRows * 5u];            // 64-bit rows: the super tables of bwt and bwtRev
+    __shared__ uint32_t s_filt[DENSE ? 2u * kDenseFilterBits / 32u : 1u];   // Format D: which blocks (mod kDenseFilterBits) may hold a delimiter row, per direction
+    __shared__ uint32_t s_ex[DENSE ? 2u * 256u : 1u];               // ... and the rows themselves, ascending
     const uint32_t S = la.S, m = la.m, stride = la.m + 1;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
@@ -2495,6 +2502,15 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     uint32_t* const ring = s_steps + S * stride + 4u + wave * (kRingWords * kRingCap);
     for (uint32_t i = tid; i < S * stride; i += 256u) s_steps[i] = la.steps[i];
     if (tid < 4u) s_steps[S * stride + tid] = 0u;
+    if constexpr (DENSE) {
+        for (uint32_t i = tid; i < 2u * kDenseFilterBits / 32u; i += 256u) s_filt[i] = 0u;
+        for (uint32_t i = tid; i < 512u; i += 256u) s_ex[i] = i < 256u ? (i < la.nex_fw ? la.ex_fw[i] : 0xffffffffu) : (i - 256u < la.nex_rv ? la.ex_rv[i - 256u] : 0xffffffffu);
+        __syncthreads();
+        for (uint32_t i = tid; i < 512u; i += 256u) {
+            const uint32_t r = s_ex[i];
+            if (r != 0xffffffffu) { const uint32_t bk = (r >> 6) & (kDenseFilterBits - 1u); atomicOr(&s_filt[(i >> 8) * (kDenseFilterBits / 32u) + (bk >> 5)], 1u << (bk & 31u)); }
+        }
+    }
     const uint64_t* sup_fw = la.sup_fw; const uint64_t* sup_rv = la.sup_rv;
     if constexpr (kWide) {
         if (la.super_rows <= kLeanSuperRows) {
@@ -2593,12 +2609,17 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         dev_multi += multi ? 1u : 0u; ++dev_busy; if (lane == (uint32_t)__ffsll((unsigned long long)__ballot(true)) - 1u) ++dev_iter;
 #endif
         const idx_t a = right ? lbRev : lb, b = a + len;
-        const uint8_t* blk = right ? la.rv : la.fw;
-        // memory phase: the entries of symbols 1..4 of the block(s) — 48 bytes, 12 into the block — of both interval ends (one end for a one-row node)
-        const Quad4* pa = reinterpret_cast<const Quad4*>(blk + (size_t)(a >> 6) * 64u + 12u);
-        const Quad4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
-        Quad4 b0, b1, b2;                                           // (only a multi-row node reads them: no default, or the compiler waits for A before it asks for B)
-        if (multi) { const Quad4* pb = reinterpret_cast<const Quad4*>(blk + (size_t)(b >> 6) * 64u + 12u); b0 = pb[0]; b1 = pb[1]; b2 = pb[2]; }
+        const uint8_t* blk = right ? (DENSE ? reinterpret_cast<const uint8_t*>(la.drv) : la.rv) : (DENSE ? reinterpret_cast<const uint8_t*>(la.dfw) : la.fw);
+        // memory phase: the entries of symbols 1..4 of the block(s) of both interval ends (one end for a one-row node) — Format A: 48 bytes, 12 into the 64-byte
+        // block; Format D: the whole 32-byte block
+        constexpr uint32_t kBlk = DENSE ? 32u : 64u, kOff = DENSE ? 0u : 12u;
+        const Quad4* pa = reinterpret_cast<const Quad4*>(blk + (size_t)(a >> 6) * kBlk + kOff);
+        const Quad4 a0 = pa[0], a1 = pa[1];
+        Quad4 a2, b0, b1, b2;                                       // (only a multi-row node reads b: no default, or the compiler waits for A before it asks for B)
+        if constexpr (!DENSE) a2 = pa[2];
+        // the second end's block only when it is another one (the ends of a short interval share their block)
+        const bool far = multi && (a >> 6) != (b >> 6);
+        if (far) { const Quad4* pb = reinterpret_cast<const Quad4*>(blk + (size_t)(b >> 6) * kBlk + kOff); b0 = pb[0]; b1 = pb[1]; if constexpr (!DENSE) b2 = pb[2]; }
         const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
         const bool lastp = (ent >> 17) & 1u;
         uint32_t c;
@@ -2608,8 +2629,30 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         const uint32_t abit = (uint32_t)a & 63u, bbit = (uint32_t)b & 63u;
         const uint32_t ma_lo = abit >= 32u ? 0xffffffffu : (1u << abit) - 1u, ma_hi = abit >= 32u ? (1u << (abit - 32u)) - 1u : 0u;
         const uint32_t mb_lo = bbit >= 32u ? 0xffffffffu : (1u << bbit) - 1u, mb_hi = bbit >= 32u ? (1u << (bbit - 32u)) - 1u : 0u;
-        idx_t la1 = a0.x + __popc(a0.y & ma_lo) + __popc(a0.z & ma_hi), la2 = a0.w + __popc(a1.x & ma_lo) + __popc(a1.y & ma_hi);
-        idx_t la3 = a1.z + __popc(a1.w & ma_lo) + __popc(a2.x & ma_hi), la4 = a2.y + __popc(a2.z & ma_lo) + __popc(a2.w & ma_hi);
+        idx_t la1, la2, la3, la4;
+        // Format D: delimiter rows before position i of its block (they sit in the planes as code 0 and were counted as symbol 1); `at` = whether row i itself is one
+        [[maybe_unused]] auto delims_before = [&](idx_t i, bool& at) -> uint32_t {
+            const uint32_t bk = ((uint32_t)i >> 6) & (kDenseFilterBits - 1u), dir = right ? 1u : 0u;
+            at = false;
+            if (!((s_filt[dir * (kDenseFilterBits / 32u) + (bk >> 5)] >> (bk & 31u)) & 1u)) return 0u;
+            const uint32_t* ex = s_ex + dir * 256u;
+            const uint32_t first = (uint32_t)i & ~63u;
+            uint32_t cnt = 0;
+            for (uint32_t t = 0; t < 256u && ex[t] <= (uint32_t)i; ++t) { if (ex[t] >= first && ex[t] < (uint32_t)i) ++cnt; if (ex[t] == (uint32_t)i) at = true; }
+            return cnt;
+        };
+        bool a_is_delim = false;
+        if constexpr (DENSE) {
+            // a0 = occ[1..4], a1 = {p0 lo, p0 hi, p1 lo, p1 hi}: symbol c matches where the two planes spell c - 1
+            const uint32_t n0l = ~a1.x, n0h = ~a1.y, n1l = ~a1.z, n1h = ~a1.w;
+            la1 = a0.x + __popc(n0l & n1l & ma_lo) + __popc(n0h & n1h & ma_hi) - delims_before(a, a_is_delim);
+            la2 = a0.y + __popc(a1.x & n1l & ma_lo) + __popc(a1.y & n1h & ma_hi);
+            la3 = a0.z + __popc(n0l & a1.z & ma_lo) + __popc(n0h & a1.w & ma_hi);
+            la4 = a0.w + __popc(a1.x & a1.z & ma_lo) + __popc(a1.y & a1.w & ma_hi);
+        } else {
+            la1 = a0.x + __popc(a0.y & ma_lo) + __popc(a0.z & ma_hi); la2 = a0.w + __popc(a1.x & ma_lo) + __popc(a1.y & ma_hi);
+            la3 = a1.z + __popc(a1.w & ma_lo) + __popc(a2.x & ma_hi); la4 = a2.y + __popc(a2.z & ma_lo) + __popc(a2.w & ma_hi);
+        }
         if constexpr (kWide) {                                      // block counts are relative to the super-block: the rest from the super table
             const uint64_t* sp_ = (right ? sup_rv : sup_fw) + (size_t)(a >> kSuperShift) * 5u;
             la1 += sp_[1]; la2 += sp_[2]; la3 += sp_[3]; la4 += sp_[4];
@@ -2618,8 +2661,19 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         const bool mOK = minE <= e && e <= maxE, sOK = minE <= e + 1u && e + 1u <= maxE, xOK = e + 1u <= maxE;
         if (multi) {
             // ---- extend-all node (search_next_dir, :143-224) or exact-tail step over several rows
-            idx_t lb1 = b0.x + __popc(b0.y & mb_lo) + __popc(b0.z & mb_hi), lb2 = b0.w + __popc(b1.x & mb_lo) + __popc(b1.y & mb_hi);
-            idx_t lb3 = b1.z + __popc(b1.w & mb_lo) + __popc(b2.x & mb_hi), lb4 = b2.y + __popc(b2.z & mb_lo) + __popc(b2.w & mb_hi);
+            if (!far) { b0 = a0; b1 = a1; if constexpr (!DENSE) b2 = a2; }   // (after the loads have been waited for: selects, no copy ahead of the second end's loads)
+            idx_t lb1, lb2, lb3, lb4;
+            if constexpr (DENSE) {
+                const uint32_t n0l = ~b1.x, n0h = ~b1.y, n1l = ~b1.z, n1h = ~b1.w;
+                bool unused_at;
+                lb1 = b0.x + __popc(n0l & n1l & mb_lo) + __popc(n0h & n1h & mb_hi) - delims_before(b, unused_at);
+                lb2 = b0.y + __popc(b1.x & n1l & mb_lo) + __popc(b1.y & n1h & mb_hi);
+                lb3 = b0.z + __popc(n0l & b1.z & mb_lo) + __popc(n0h & b1.w & mb_hi);
+                lb4 = b0.w + __popc(b1.x & b1.z & mb_lo) + __popc(b1.y & b1.w & mb_hi);
+            } else {
+                lb1 = b0.x + __popc(b0.y & mb_lo) + __popc(b0.z & mb_hi); lb2 = b0.w + __popc(b1.x & mb_lo) + __popc(b1.y & mb_hi);
+                lb3 = b1.z + __popc(b1.w & mb_lo) + __popc(b2.x & mb_hi); lb4 = b2.y + __popc(b2.z & mb_lo) + __popc(b2.w & mb_hi);
+            }
             if constexpr (kWide) {
                 const uint64_t* sp_ = (right ? sup_rv : sup_fw) + (size_t)(b >> kSuperShift) * 5u;
                 lb1 += sp_[1]; lb2 += sp_[2]; lb3 += sp_[3]; lb4 += sp_[4];
@@ -2661,10 +2715,16 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             // ---- single row (search_next_dir_single, :251-365): the only child is the BWT symbol of the row, read off its block
             const uint32_t bt_lo = abit >= 32u ? 0u : 1u << abit, bt_hi = abit >= 32u ? 1u << (abit - 32u) : 0u;
             uint32_t row_sym = 0u; idx_t t0 = 0;
-            if ((a0.y & bt_lo) | (a0.z & bt_hi)) { row_sym = 1u; t0 = la1; }
-            if ((a1.x & bt_lo) | (a1.y & bt_hi)) { row_sym = 2u; t0 = la2; }
-            if ((a1.w & bt_lo) | (a2.x & bt_hi)) { row_sym = 3u; t0 = la3; }
-            if ((a2.z & bt_lo) | (a2.w & bt_hi)) { row_sym = 4u; t0 = la4; }
+            if constexpr (DENSE) {                                  // the row's symbol from the two planes; a delimiter row (listed) ends the walk
+                const uint32_t code = (((a1.x & bt_lo) | (a1.y & bt_hi)) ? 1u : 0u) | (((a1.z & bt_lo) | (a1.w & bt_hi)) ? 2u : 0u);
+                row_sym = a_is_delim ? 0u : code + 1u;
+                t0 = code == 0u ? la1 : (code == 1u ? la2 : (code == 2u ? la3 : la4));
+            } else {
+                if ((a0.y & bt_lo) | (a0.z & bt_hi)) { row_sym = 1u; t0 = la1; }
+                if ((a1.x & bt_lo) | (a1.y & bt_hi)) { row_sym = 2u; t0 = la2; }
+                if ((a1.w & bt_lo) | (a2.x & bt_hi)) { row_sym = 3u; t0 = la3; }
+                if ((a2.z & bt_lo) | (a2.w & bt_hi)) { row_sym = 4u; t0 = la4; }
+            }
             const bool is_match = row_sym >= 1u && row_sym == c && mOK;
             nodes += 1u + ((!in_tail && is_match && !xOK) ? 1u : 0u);
             bool dead = false;
@@ -3325,8 +3385,10 @@ static size_t lean_lds_bytes(uint32_t m, size_t step_words) {
 static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uint32_t m, size_t step_words, dim3 g, const uint8_t* dq, const uint64_t* doff, uint64_t count,
                         fmgpu_hit* dout, uint64_t capacity, const DfsWorkspace& ws, const uint32_t* qm, hipStream_t stream) {
     const idx_t n = (idx_t)x->bwt.n;
+    const bool dense = x->bwt.dense && x->rev.dense && !(dev_flags_env() & (1 << 29));      // (bit 29 of FMGPU_DEV_FLAGS: read Format A although Format D exists)
     LeanArgs la{x->bwt.va.blk, x->rev.va.blk, d_steps, S, m, (idx_t)(x->hC[1] + x->hC[2] + x->hC[3] + x->hC[4]), x->bwt.va.super, x->rev.va.super,
-                kWide ? (uint32_t)((x->bwt.n >> kSuperShift) + 1) : 0u};
+                kWide ? (uint32_t)((x->bwt.n >> kSuperShift) + 1) : 0u,
+                (const uint4*)x->bwt.dense, (const uint4*)x->rev.dense, x->bwt.dense_ex, x->rev.dense_ex, x->bwt.dense_nex, x->rev.dense_nex};
     const size_t lds = lean_lds_bytes(m, step_words);
     uint32_t waste = kLeanRefillWaste; [[maybe_unused]] int steps = kLeanSteps;
     if (const char* ev = dev_env("FMGPU_DEV_LEAN_WASTE")) waste = (uint32_t)std::max(1, atoi(ev));
@@ -3334,9 +3396,10 @@ static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uin
     auto launch = [&](auto kern) { kern<<<g, dim3(256), lds, stream>>>(la, dq, doff, count, n, dout, capacity, ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes,
                                                                     (m + 15) / 16, qm, waste); };
 #ifdef FMGPU_DEV
-    if (steps == 1) launch(k_scheme_lean<kLeanWaves, 1>); else if (steps == 2) launch(k_scheme_lean<kLeanWaves, 2>); else if (steps == 8) launch(k_scheme_lean<kLeanWaves, 8>); else
+    if (steps == 1) launch(k_scheme_lean<kLeanWaves, 1, false>); else if (steps == 2) launch(k_scheme_lean<kLeanWaves, 2, false>); else if (steps == 8) launch(k_scheme_lean<kLeanWaves, 8, false>); else
 #endif
-    launch(k_scheme_lean<kLeanWaves, kLeanSteps>);
+    if constexpr (!kWide) { if (dense) { launch(k_scheme_lean<kLeanWaves, kLeanSteps, true>); return; } }
+    launch(k_scheme_lean<kLeanWaves, kLeanSteps, false>);
 }
 
 static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme,
@@ -3564,7 +3627,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(key); if (it != occ_cache.end()) { bpc = it->second; known = true; } }
         if (!known) {
             int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scheme_lean<kLeanWaves, kLeanSteps>, 256, lean_lds) == hipSuccess && nb > 0) bpc = nb; else { (void)hipGetLastError(); bpc = 4; }
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_scheme_lean<kLeanWaves, kLeanSteps, false>, 256, lean_lds) == hipSuccess && nb > 0) bpc = nb; else { (void)hipGetLastError(); bpc = 4; }
             std::lock_guard<std::mutex> g(occ_mu); occ_cache[key] = bpc;
         }
         // measured on the genome-like text, 10 M x 101 bp (kernel ms): 7 / 6 / 5 / 4 resident blocks per CU = 141 / 126 / 120 / 118 (151 bp: 212 / 211 / 210 / 204); with

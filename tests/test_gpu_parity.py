@@ -485,12 +485,13 @@ def test_lean_kernel_on_the_plain_index(k, length):
         ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 24)
         hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
         assert same_hits(hits, ohits) and st.lf_steps == nodes, (k, length)
-        os.environ["FMGPU_DEV_FLAGS"] = str(1 << 30)               # k_scheme_fast<PLAIN>
-        try:
-            hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
-        finally:
-            del os.environ["FMGPU_DEV_FLAGS"]
-        assert same_hits(hits2, ohits) and st2.lf_steps == nodes
+        for flags in (1 << 30, 1 << 29):                           # k_scheme_fast<PLAIN>; k_scheme_lean on the Format A blocks (the default reads the dense Format D)
+            os.environ["FMGPU_DEV_FLAGS"] = str(flags)
+            try:
+                hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
+            finally:
+                del os.environ["FMGPU_DEV_FLAGS"]
+            assert same_hits(hits2, ohits) and st2.lf_steps == nodes, flags
         if len(ohits) > 10:                                       # a buffer that is too small: FMGPU_ERR_CAPACITY with the exact count (the wrapper then asks again with that capacity)
             assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, capacity=len(ohits) // 2), ohits)
     # bytes outside the alphabet are outside the reference's domain (it indexes an array of sigma cursors with them); the kernels treat them as "matches nothing":
