@@ -2378,6 +2378,7 @@ constexpr uint32_t kRingCap = 160;       // hit records a wave keeps in LDS ...
 constexpr uint32_t kRingFlush = 32;      // ... written out as soon as there are this many: 128 more always fit; a pass (kLeanSteps node steps) that reports more sends the excess out one by one
 constexpr uint32_t kRingWords = kWide ? 7u : 6u;   // qidx, lb, lbRev, len, errors | key high, key low (, the rows' bits 32..39)
 constexpr uint32_t kLeanRefillWaste = 2048;        // (kRefillWaste of k_scheme_fast)
+constexpr uint32_t kLeanShareHeavy = 64;           // nodes a lane spends on a read before it offers subtrees of it
 constexpr uint32_t kLeanSuperRows = kWide ? 64u : 1u;   // super-block rows per direction staged in LDS (64 x 2^30 rows: more than HBM holds)
 constexpr uint32_t kLeanNoResume = 7u;
 constexpr int kLeanWaves = 4;            // resident blocks per CU the register allocation allows (the grid asks for 3: the loop is bound by the L1 access rate, not by latency)
@@ -2487,7 +2488,7 @@ constexpr uint32_t kDenseFilterBits = 32768;      // block number mod this: 25 d
 template <int WAVES, int NSTEP, bool DENSE>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
 __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
                                                              fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, ulonglong2* __restrict__ frames, uint64_t nlanes,
-                                                             uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste) {
+                                                             uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste, uint32_t share_heavy) {
     extern __shared__ uint32_t s_dyn[];                             // [qwords][256] staged reads | [256] top frames (16 B) | [S][m + 1] steps | [4] ring fill | 4 x [kRingWords][kRingCap] rings
     __shared__ uint64_t s_sup[2u * kLeanSuperRows * 5u];            // 64-bit rows: the super tables of bwt and bwtRev
     __shared__ uint32_t s_filt[DENSE ? 2u * kDenseFilterBits / 32u : 1u];   // Format D: which blocks (mod kDenseFilterBits) may hold a delimiter row, per direction
@@ -2497,7 +2498,9 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
     lds_u32x4* const s_tos = (lds_u32x4*)(s_dyn + (size_t)qwords * 256u);
     lds_u32x4* const tos_slot = s_tos + tid;                        // the frame at depth sp - 1 of this lane (valid while sp > sbase)
-    uint32_t* const s_steps = s_dyn + (size_t)qwords * 256u + 1024u;
+    lds_u32x4* const s_bos = s_tos + 256;
+    lds_u32x4* const bos_slot = s_bos + tid;                        // the frame at depth sbase (the next one a lane hands over), valid while sp > sbase
+    uint32_t* const s_steps = s_dyn + (size_t)qwords * 256u + 2048u;
     lds_u32* const s_cnt_w = (lds_u32*)(s_steps + S * stride + wave);
     uint32_t* const ring = s_steps + S * stride + 4u + wave * (kRingWords * kRingCap);
     for (uint32_t i = tid; i < S * stride; i += 256u) s_steps[i] = la.steps[i];
@@ -2521,7 +2524,13 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     __syncthreads();
 
     const uint32_t gid = blockIdx.x * 256u + tid;                   // frame d of this lane at frames[d * nlanes + gid]
-    uint32_t nodes = 0, mark = 0, waste = 0;
+    uint32_t nodes = 0, mark = 0, waste = 0, nodes0 = 0;            // nodes0: the lane's count when it took its current read (or subtree)
+#ifdef FMGPU_DEV_STAMPS
+    unsigned long long st_top = 0, st_share = 0, st_refill = 0, st_sync = 0, st_issue = 0, st_wait = 0, st_node = 0, st_tail = 0, st_t = __builtin_amdgcn_s_memtime(), st_steps = 0;
+#define STAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(acc) do { } while (0)
+#endif
 #ifdef FMGPU_DEV
     uint32_t dev_multi = 0, dev_iter = 0, dev_busy = 0;             // dev build: lane-iterations on multi-row nodes / wave iterations / busy lane-iterations (reported through table_accesses, table_bytes)
 #endif
@@ -2535,8 +2544,11 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     // frame to an idle lane) waits for vmcnt(0) itself.
     for (;;) {
         // ---- wave-synchronous part
+        STAMP(st_top);
         {
-            const bool can_give = have && sp > sbase && nodes - mark >= kShareNodes;
+            // a lane offers the bottom frame of its stack once its read has proven heavy (share_heavy nodes; the median read visits a few hundred, a read in a
+            // satellite 10^5): with an offer from every read after 2 nodes (round 2) the hand-over ran in nearly every pass and cost a quarter of the kernel's cycles
+            const bool can_give = have && sp > sbase && nodes - mark >= kShareNodes && nodes - nodes0 >= share_heavy;
             const uint64_t idlem = __ballot(!have), offerm = __ballot(can_give);
             if (idlem && offerm) {                                  // the i-th idle lane takes the bottom frame of the i-th offering lane
                 const uint64_t below = (1ull << lane) - 1ull;
@@ -2545,15 +2557,18 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
                 uint64_t w0 = 0, w1 = 0, w2 = 0;
                 if (give) {
-                    if (sp - sbase > 1u) { const ulonglong2 f = frames[(uint64_t)sbase * nlanes + gid]; w0 = f.x; w1 = f.y; }
-                    else {                                          // a stack of one frame: the cached one
-                        __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0): a refill of the slot may still be in flight
-                        asm volatile("" ::: "memory");
-                        const u32x4 t = *tos_slot;
+                    {                                               // the bottom frame from its LDS slot (written by the push onto an empty stack, or refilled below: an
+                        asm volatile("" ::: "memory");              // LDS-DMA issued a whole pass ago — the node steps in between consumed block loads issued after it)
+                        const u32x4 t = *bos_slot;
                         w0 = (uint64_t)t.x | ((uint64_t)t.y << 32); w1 = (uint64_t)t.z | ((uint64_t)t.w << 32);
                     }
                     { const uint32_t fe = lean_frame_errors(w1); w2 = ((uint64_t)(fe >= 1u ? k1 : 0u) << 32) | (fe >= 2u ? k2 : 0u); }      // the key of the frame's node: the fields of later substitutions cleared
                     ++sbase; mark = nodes;
+                    if (sp > sbase) {                               // the new bottom frame, straight into the slot (nothing waits for it)
+                        uint32_t g = gid; asm volatile("" : "+v"(g));
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(frames + ((uint64_t)sbase * nlanes + g)),
+                                                         (__attribute__((address_space(3))) void*)(s_bos + wave * 64u), 16, 0, 0);
+                    }
                 }
                 uint64_t om = offerm;
                 for (uint32_t k = take ? (uint32_t)__popcll(idlem & below) : 0u; k > 0; --k) om &= om - 1ull;
@@ -2566,10 +2581,11 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                     k1 = (uint32_t)(tw2 >> 32); k2 = (uint32_t)tw2;
                     const uint32_t vt = (tid & ~63u) | (uint32_t)vl;
                     for (uint32_t w = 0; w < qwords; ++w) s_dyn[w * 256u + tid] = s_dyn[w * 256u + vt];     // the partner's staged read
-                    have = true; is_task = true; need_start = false; sp = 0; sbase = 0; in_tail = false; mark = nodes;
+                    have = true; is_task = true; need_start = false; sp = 0; sbase = 0; in_tail = false; mark = nodes; nodes0 = nodes;
                 }
             }
         }
+        STAMP(st_share);
         {
             const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
             waste += (uint32_t)__popcll(needm);
@@ -2580,7 +2596,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 const uint64_t got = wave_hand_out(want, ctr, lane);
                 if (want) {
                     if (got >= nq) exhausted = true;
-                    else { q = qmap ? qmap[got] : (uint32_t)got; qo = qoff[q]; fresh = true; have = true; is_task = false; si = 0; need_start = true; mark = nodes; }
+                    else { q = qmap ? qmap[got] : (uint32_t)got; qo = qoff[q]; fresh = true; have = true; is_task = false; si = 0; need_start = true; mark = nodes; nodes0 = nodes; }
                 }
                 const bool ok = stage2_sync(s_dyn, qbuf, qo, m, fresh);
                 if (fresh) odd = !ok;
@@ -2588,15 +2604,20 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                                                                     // waits for vmcnt(0) in EVERY iteration before it overwrites one of their registers — ahead of the block loads
             }
         }
+        STAMP(st_refill);
         {
             const uint32_t filled = __hip_atomic_load(s_cnt_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             const uint64_t busy = __ballot(have);
             if (filled >= kRingFlush || (!busy && filled)) ring_flush(s_cnt_w, ring, lane, out, cap, ctr);
             if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
         }
+        STAMP(st_sync);
 #pragma unroll 1
         for (int step = 0; step < NSTEP; ++step) {
         if (!have) continue;
+#ifdef FMGPU_DEV_STAMPS
+        ++st_steps;
+#endif
         // ---- one node per lane
         if (need_start) {                                           // search_impl (SearchNg26.h:385-390) -> run(): :62-79
             need_start = false;
@@ -2620,6 +2641,10 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         // the second end's block only when it is another one (the ends of a short interval share their block)
         const bool far = multi && (a >> 6) != (b >> 6);
         if (far) { const Quad4* pb = reinterpret_cast<const Quad4*>(blk + (size_t)(b >> 6) * kBlk + kOff); b0 = pb[0]; b1 = pb[1]; if constexpr (!DENSE) b2 = pb[2]; }
+        STAMP(st_issue);
+#ifdef FMGPU_DEV_STAMPS
+        __builtin_amdgcn_s_waitcnt(0x0f70); STAMP(st_wait);
+#endif
         const uint32_t pos = ent & 0xffffu, minE = (ent >> 18) & 0x1fu, maxE = (ent >> 23) & 0x3fu;
         const bool lastp = (ent >> 17) & 1u;
         uint32_t c;
@@ -2696,7 +2721,9 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 const u32x4 f = {(uint32_t)fw0, (uint32_t)(fw0 >> 32), (uint32_t)fw1, (uint32_t)(fw1 >> 32)};
                 uint32_t g = gid; asm volatile("" : "+v"(g));     // (kept out of loop-invariant hoisting: the 64-bit address of the lane's frame column would hold two registers through the loop)
                 *reinterpret_cast<u32x4*>(frames + ((uint64_t)sp * nlanes + g)) = f;     // write-through: the stack in HBM is always complete
-                *tos_slot = f; ++sp;
+                *tos_slot = f;
+                if (sp == sbase) *bos_slot = f;                     // the first frame of the stack is also its bottom
+                ++sp;
             }
             resume = kLeanNoResume;
             if (take_match || take_sub) {
@@ -2735,6 +2762,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             if (dead) back = true;
             else { in_tail = !lastp && (in_tail || (is_match && !xOK)); if (right) lbRev = t0; else lb = t0; ++j; }
         }
+        STAMP(st_node);
         if (!back && j == m) {                                      // search_next at part == P (:101-108)
             const uint32_t fin = s_steps[si * stride + m];
             if (((fin >> 18) & 0x1fu) <= e && e <= ((fin >> 23) & 0x3fu)) {
@@ -2770,10 +2798,17 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             else if (si == S) have = false;
             else need_start = true;
         }
+        STAMP(st_tail);
         }   // NSTEP
     }
     const uint32_t tot = wave_sum(nodes);
     if (lane == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
+#ifdef FMGPU_DEV_STAMPS
+    if (lane == 0) {                                                // (wave-uniform sums, cycles of s_memtime; a debug area behind the counters)
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(ctr) + 8;
+        atomicAdd(dbg + 0, st_sync); atomicAdd(dbg + 1, st_issue); atomicAdd(dbg + 2, st_wait); atomicAdd(dbg + 3, st_node); atomicAdd(dbg + 4, st_tail); atomicAdd(dbg + 5, st_steps); atomicAdd(dbg + 6, 1ull); atomicAdd(dbg + 7, st_share); atomicAdd(dbg + 8, st_refill); atomicAdd(dbg + 9, st_top);
+    }
+#endif
 #ifdef FMGPU_DEV
     { const uint32_t a1 = wave_sum(dev_multi), a2 = wave_sum(dev_iter), a3 = wave_sum(dev_busy);
       if (lane == 0) { atomicAdd(&ctr->table_accesses, (unsigned long long)a1 | ((unsigned long long)a2 << 40)); atomicAdd(&ctr->table_bytes, (unsigned long long)a3); } }
@@ -3202,7 +3237,7 @@ struct DfsWorkspace {
         }
         view.p0 = planes; view.p1 = planes + words; view.p2 = planes + 2 * words; view.p3 = nplanes > 3 ? planes + 3 * words : nullptr;
         ctr = (Counters*)sc->dfs_ctr;
-        FM_HIP(hipMemsetAsync(ctr, 0, sizeof(Counters), stream));            // next: the query hand-out counter of the scheme kernels
+        FM_HIP(hipMemsetAsync(ctr, 0, 256, stream));                         // next: the query hand-out counter of the scheme kernels (+ a debug area)
         return 0;
     }
     ~DfsWorkspace() { if (planes && own_planes) (void)hipFree(planes); }
@@ -3380,7 +3415,7 @@ int fmgpu_search_exact_depth(fmgpu_index_t h, const uint8_t* qbuf, const uint64_
 }
 
 static size_t lean_lds_bytes(uint32_t m, size_t step_words) {
-    return (size_t)((m + 15) / 16) * 1024 + 4096 + step_words * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;
+    return (size_t)((m + 15) / 16) * 1024 + 8192 + step_words * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;      // staged reads | top and bottom frame slots | steps | ring fill | rings
 }
 static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uint32_t m, size_t step_words, dim3 g, const uint8_t* dq, const uint64_t* doff, uint64_t count,
                         fmgpu_hit* dout, uint64_t capacity, const DfsWorkspace& ws, const uint32_t* qm, hipStream_t stream) {
@@ -3390,11 +3425,12 @@ static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uin
                 kWide ? (uint32_t)((x->bwt.n >> kSuperShift) + 1) : 0u,
                 (const uint4*)x->bwt.dense, (const uint4*)x->rev.dense, x->bwt.dense_ex, x->rev.dense_ex, x->bwt.dense_nex, x->rev.dense_nex};
     const size_t lds = lean_lds_bytes(m, step_words);
-    uint32_t waste = kLeanRefillWaste; [[maybe_unused]] int steps = kLeanSteps;
+    uint32_t waste = kLeanRefillWaste, heavy = kLeanShareHeavy; [[maybe_unused]] int steps = kLeanSteps;
     if (const char* ev = dev_env("FMGPU_DEV_LEAN_WASTE")) waste = (uint32_t)std::max(1, atoi(ev));
+    if (const char* ev = dev_env("FMGPU_DEV_LEAN_HEAVY")) heavy = (uint32_t)std::max(0, atoi(ev));
     if (const char* ev = dev_env("FMGPU_DEV_LEAN_STEPS")) steps = atoi(ev);
     auto launch = [&](auto kern) { kern<<<g, dim3(256), lds, stream>>>(la, dq, doff, count, n, dout, capacity, ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes,
-                                                                    (m + 15) / 16, qm, waste); };
+                                                                    (m + 15) / 16, qm, waste, heavy); };
 #ifdef FMGPU_DEV
     if (steps == 1) launch(k_scheme_lean<kLeanWaves, 1, false>); else if (steps == 2) launch(k_scheme_lean<kLeanWaves, 2, false>); else if (steps == 8) launch(k_scheme_lean<kLeanWaves, 8, false>); else
 #endif
@@ -3763,6 +3799,11 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (le == hipSuccess) le = hipMemcpyAsync(&hc, ws.ctr, sizeof hc, hipMemcpyDeviceToHost, stream);
     if (le == hipSuccess) le = hipStreamSynchronize(stream);
     if (le != hipSuccess) return hip_fail(le, "search kernel");
+#ifdef FMGPU_DEV_STAMPS
+    { unsigned long long dbg[12]; (void)hipMemcpy(dbg, reinterpret_cast<unsigned long long*>(ws.ctr) + 8, sizeof dbg, hipMemcpyDeviceToHost);
+      if (dbg[6]) fprintf(stderr, "stamps: waves %llu, wave node-steps %llu; cycles per node-step: top %.0f share %.0f refill %.0f flush+rest %.0f issue %.0f wait %.0f node %.0f tail %.0f\n", dbg[6], dbg[5],
+                          (double)dbg[9] / dbg[5], (double)dbg[7] / dbg[5], (double)dbg[8] / dbg[5], (double)dbg[0] / dbg[5], (double)dbg[1] / dbg[5], (double)dbg[2] / dbg[5], (double)dbg[3] / dbg[5], (double)dbg[4] / dbg[5]); }
+#endif
     *out_count = hc.hits;
     if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); stats->prepass_ms = prepass_ms; stats->table_bytes = hc.table_bytes; stats->table_accesses = hc.table_accesses; }
     if (hc.hits > capacity) {
