@@ -201,6 +201,9 @@ struct Counters { unsigned long long hits, nodes, next, table_bytes, table_acces
 // three frame words.  (A device-wide task queue was tried first: one queue head for thousands of waiting waves serialised the hand-over at
 // ~1.3 us per task — 2 M tasks, 8 s — and was dropped.)  This needs an order of the hit records that does not depend on who found them:
 constexpr uint32_t kShareNodes = 2;
+// ... and only from a read that has proven heavy: with offers from every read the hand-over ran in nearly every iteration of a wave (some lane is always
+// out of work) and cost more than it returned (uniform text, plain index: 56.8 -> 39.8 ms once reads of fewer than 64 nodes stopped offering)
+[[maybe_unused]] constexpr uint32_t kShareHeavy = 64;
 
 // Path key: the callback order of the reference is the depth-first order in which every node tries its match child first and its substitution
 // children in ascending symbol order (SearchNg26.h:171-218).  For hits of one read that is the lexicographic order of
@@ -1654,6 +1657,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     bool is_task = false;                                           // the lane works on a subtree it took over from another lane
     uint32_t sbase = 0, mark = 0;                                   // frames below sbase were handed out; nodes at the lane's last hand-out
     const uint32_t share_nodes = ((uint32_t)dev_flags >> 25) & 31u ? 1u << (((uint32_t)dev_flags >> 25) & 31u) : kShareNodes;   // (dev knob: bits 25..29)
+    const uint32_t share_heavy = (dev_flags & 129) == 128 ? 0u : kShareHeavy;   // (dev knob: bit 7 alone = every read may offer)
     uint64_t pkey = 0;                                              // path key of the node the lane stands on
     bool have = false, exhausted = n == 0, need_start = false, query_over = false;
     uint64_t q = 0, quota = 0;
@@ -1666,12 +1670,12 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
     for (;;) {
         // ---- wave-synchronous part: every lane passes here in every iteration
         if (sharing) {
-            const uint64_t idlem = __ballot(!have), offerm = __ballot(have && sp > sbase && nodes - mark >= share_nodes);
+            const uint64_t idlem = __ballot(!have), offerm = __ballot(have && sp > sbase && nodes - mark >= share_nodes && nodes - nodes0 >= share_heavy);
             if (idlem && offerm) {
                 // the i-th idle lane takes the bottom frame of the i-th offering lane
                 const uint64_t below = (1ull << lane) - 1ull;
                 const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
-                const bool give = have && sp > sbase && nodes - mark >= share_nodes && (uint32_t)__popcll(offerm & below) < pairs;
+                const bool give = have && sp > sbase && nodes - mark >= share_nodes && nodes - nodes0 >= share_heavy && (uint32_t)__popcll(offerm & below) < pairs;
                 const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
                 uint64_t w0 = 0, w1 = 0, w2 = 0;
                 if (give) {
@@ -2079,6 +2083,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     uint32_t nodes = 0, nh = 0, count_only = 0;
     const uint32_t refill_waste = ((uint32_t)dev_flags >> 8) & 0xffffu ? (((uint32_t)dev_flags >> 8) & 0xffffu) : kRefillWaste;   // (dev knob: bits 8..23)
     const uint32_t share_nodes = ((uint32_t)dev_flags >> 25) & 31u ? 1u << (((uint32_t)dev_flags >> 25) & 31u) : kShareNodes;   // (dev knob: bits 25..29)
+    const uint32_t share_heavy = (dev_flags & 129) == 128 ? 0u : kShareHeavy;   // (dev knob: bit 7 alone = every read may offer)
     uint32_t waste = 0;                                             // lane-iterations lost by idle lanes since the wave's last refill (wave-uniform)
     bool is_task = false;                                           // the lane works on a subtree it took over from another lane
     uint32_t sbase = 0, mark = 0;                                   // frames below sbase were handed out; nodes at the lane's last hand-out
@@ -2089,7 +2094,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     const uint32_t* tab = s_steps;
     uint32_t seq = 0, si = 0;
     Cur cur{0, 0, 0};
-    uint32_t e = 0, j = 0, sp = 0, resume = kNoResume, side = 0, info = 0, ndel = 0;
+    uint32_t e = 0, j = 0, sp = 0, resume = kNoResume, side = 0, info = 0, ndel = 0, nodes0 = 0;
     bool in_tail = false, lf_known = false;
     idx_t lf_val = 0, cached_lf = 0, cached_lf2 = 0xffffffffu;
     uint32_t report_slot = kNoResume;
@@ -2097,7 +2102,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
         // ---- wave-synchronous part: every lane passes here in every iteration
         if (sharing) {
             // (a frame whose running child still owes it the row's LF^2 — report_slot — stays with its owner for that one iteration)
-            const bool offer = have && sp > sbase && nodes - mark >= share_nodes && report_slot != sbase;
+            const bool offer = have && sp > sbase && nodes - mark >= share_nodes && nodes - nodes0 >= share_heavy && report_slot != sbase;
             const uint64_t idlem = __ballot(!have), offerm = __ballot(offer);
             if (idlem && offerm) {
                 // the i-th idle lane takes the bottom frame of the i-th offering lane
@@ -2130,7 +2135,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                     const uint32_t vt = (threadIdx.x & ~63u) | (uint32_t)vl;
                     for (uint32_t w = 0; w < qwords; ++w) s_dyn[w * 256u + threadIdx.x] = s_dyn[w * 256u + vt];     // the partner's staged read
                     have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
-                    tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; lf_known = false; report_slot = kNoResume; mark = nodes;
+                    tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; lf_known = false; report_slot = kNoResume; mark = nodes; nodes0 = nodes;
                 }
             }
         }
@@ -2145,7 +2150,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 if (got >= nq) exhausted = true;
                 else {
                     q = qmap ? (uint64_t)qmap[got] : got; qo = qoff[q]; qs = qbuf + qo; fresh = true;
-                    have = true; is_task = false; si = 0; need_start = true; quota = max_hits; seq = 0; query_over = false; mark = nodes;
+                    have = true; is_task = false; si = 0; need_start = true; quota = max_hits; seq = 0; query_over = false; mark = nodes; nodes0 = nodes;
                 }
             }
             qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
