@@ -33,6 +33,15 @@
 //     'A'; the few rows that hold one (one per sequence) are listed — `dense_ex`, ascending — and blocks that may hold one are marked in a 2048-bit filter
 //     (block number mod 2048): a marked block takes a slow path that consults the list.  Built when the string has at most 256 delimiters.
 //
+//  Format P  ("pairs": the bwt of a sigma = 5 index with 32-bit rows, beside Format A — what exact search reads, two symbols per step):
+//     one line of 128 bytes per 128 rows:  u32 cnt[16] = (first row of the interval of "xy") + #{ j < 128L : the pair of row j is (x, y) }, index
+//     (x-1)*4 + (y-1);  then for rows 0..63 and for rows 64..127 four u64 planes = bit k of the pair code of each row.  The pair of row j is
+//     (s[LF(j)], s[j]) — the two symbols in front of suffix j — so with lb' = cnt[xy] + (rows of the pair before lb) a search prepends "xy" in ONE
+//     step:  LF_x(LF_y(i)) = C[x] + rank_x(C[y]) + #{ j < i : pair(j) = (x, y) }  (LF keeps the order of the rows of one symbol).  An exact search
+//     is bound by the random 128-byte line fills it causes (tools/membench.hip: 52-55 G lines/s whatever is read of a line), one per step and
+//     interval end; this format halves the lines of a query.  Rows whose pair holds a delimiter (two per sequence) carry code 0, are left out of
+//     the counts and are listed (`pairs_ex`, ascending) behind a filter on the line number; built when there are at most 512 of them.
+//
 //  Format R  (reference layout as is — InterleavedEPR*, InterleavedEPRV2*): blocks + superBlocks copied verbatim.
 //
 //  Format W  (the reference's binary wavelet tree, one 64-byte line per 384 node bits; built from Wavelet::bitvector[*] at upload and only
@@ -110,7 +119,8 @@ inline int grid_of(uint64_t threads, dim3* out, uint64_t cap_blocks = 0) {
 // kernel through them).  Everything else — count-only runs, per-read node dumps, tuning fields, residency overrides (FMGPU_DEV_*) — exists in
 // builds made with -DFMGPU_DEV only (make DEV=1; tools/k2_*_probe.py): a stray environment variable cannot make the shipped library drop records
 // or write outside a caller's buffer.
-constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 24) | (1 << 29) | (1 << 30);   // general kernel | no prefix table | no LF^1..3 | no LF table in the general kernels | no walk table | no length buckets | no work sharing | k_scheme_lean on Format A although Format D exists | k_scheme_fast<PLAIN> instead of k_scheme_lean
+constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 22) | (1 << 24) | (1 << 29) | (1 << 30);   // (bit 22: exact search in one-symbol steps although Format P exists)
+//   // general kernel | no prefix table | no LF^1..3 | no LF table in the general kernels | no walk table | no length buckets | no work sharing | k_scheme_lean on Format A although Format D exists | k_scheme_fast<PLAIN> instead of k_scheme_lean
 inline const char* dev_env(const char* name) {
 #ifdef FMGPU_DEV
     return getenv(name);
@@ -660,6 +670,8 @@ struct DevString {
     // LF step instead of one per level); fmgpu_string_query keeps answering from the native format.
     // Format D (see the head of this file): dense DNA blocks + the ascending list of the rows that hold a delimiter (u32, `dense_nex` of them)
     void* dense = nullptr; size_t dense_bytes = 0; uint32_t* dense_ex = nullptr; uint32_t dense_nex = 0;
+    // Format P (see the head of this file): pair lines of the bwt + the ascending list of the rows left out of them (u32, `pairs_nex` of them)
+    uint8_t* pairs = nullptr; size_t pairs_bytes = 0; uint32_t* pairs_ex = nullptr; uint32_t pairs_nex = 0;
     void* shadow = nullptr; size_t shadow_bytes = 0;   // (shadow_bytes = blocks + super table)
     void* shadow_sup = nullptr; size_t shadow_sup_bytes = 0;
     int search_family() const { return shadow ? (int)FAM_A : family; }
@@ -680,6 +692,8 @@ int build_lf_table(DevString& s, hipStream_t stream);
 int build_dense_dna(DevString& s, hipStream_t stream);
 // moves the sampled suffix array's presence bits into the bwt's Format A blocks (sigma <= 5; see "Fused presence bits"); defined in fmgpu_index.hip
 int fuse_presence_bits(Index* x, hipStream_t stream);
+// builds Format P beside the bwt of a sigma = 5 index with 32-bit rows (no-op where it does not apply; adds its bytes to device_bytes); defined in fmgpu_index.hip
+int build_pair_table(Index* x, hipStream_t stream);
 void free_string(DevString& s);
 
 struct Index {

@@ -189,6 +189,96 @@ int build_dense_dna(DevString& s, hipStream_t stream) {
     return 0;
 }
 
+// ---- Format P (fmgpu_common.h): the occurrence table of the two-symbol-step BWT of a sigma = 5 string, from its Format A blocks.
+// Row i's pair is (x, y) = (s[LF(i)], s[i]): prepending "xy" to the suffixes of an interval is one rank of the pair.  A row whose pair holds a delimiter
+// is written as code 0, left out of the counts and listed.
+constexpr uint32_t kPairMaxRows = 512;              // listed rows (two per sequence): more than these and the table is not built
+__global__ __launch_bounds__(256) void k_pair_codes(OccA<5> occ, uint64_t n, uint8_t* __restrict__ lines, uint32_t* __restrict__ part, uint64_t nlines,
+                                                    uint32_t* __restrict__ ex, uint32_t* __restrict__ nex) {
+    __shared__ uint32_t s_cnt[4][16];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    uint32_t code = 0; bool listed = false;
+    if (i < n) {
+        const uint32_t y = occ.symbol((idx_t)i);
+        if (y == 0) listed = true;
+        else {
+            const uint32_t x = occ.symbol(occ.lf((idx_t)i, y));
+            if (x == 0) listed = true; else code = (x - 1u) * 4u + (y - 1u);
+        }
+    }
+    const bool counted = i < n && !listed;
+    uint64_t plane[4];
+    for (int k = 0; k < 4; ++k) plane[k] = __ballot(counted && ((code >> k) & 1u));
+    const uint64_t valid = __ballot(counted);
+    uint64_t lm = __ballot(listed);
+    if (lane == 0) while (lm) {
+        const uint32_t r = (uint32_t)__ffsll((unsigned long long)lm) - 1u; lm &= lm - 1ull;
+        const uint32_t k = atomicAdd(nex, 1u);
+        if (k < kPairMaxRows) ex[k] = (uint32_t)((uint64_t)blockIdx.x * 256u + wave * 64u + r);
+    }
+    const uint64_t L = (uint64_t)blockIdx.x * 2u + (wave >> 1);         // this wave's 128-row line
+    if (lane < 4 && L < nlines) reinterpret_cast<uint64_t*>(lines + L * 128u + 64u + (wave & 1u) * 32u)[lane] = plane[lane];
+    if (lane < 16) {
+        uint64_t mm = valid;
+        for (int k = 0; k < 4; ++k) mm &= ((lane >> k) & 1u) ? plane[k] : ~plane[k];
+        s_cnt[wave][lane] = (uint32_t)__popcll((unsigned long long)mm);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const uint32_t b = threadIdx.x >> 4, pc = threadIdx.x & 15u;
+        const uint64_t L2 = (uint64_t)blockIdx.x * 2u + b;
+        if (L2 < nlines) part[(size_t)pc * nlines + L2] = s_cnt[2 * b][pc] + s_cnt[2 * b + 1][pc];
+    }
+}
+// counts of line L = where the interval of the pair starts + the pair's occurrences before the line (part: scanned per pair)
+__global__ __launch_bounds__(256) void k_pair_counts(OccA<5> occ, const uint32_t* __restrict__ part, uint64_t nlines, uint8_t* __restrict__ lines) {
+    __shared__ uint32_t s_c2[16];
+    if (threadIdx.x < 16) {                                             // "xy" from the whole table: y first, then x
+        const uint32_t x = threadIdx.x >> 2, y = threadIdx.x & 3u;
+        s_c2[threadIdx.x] = (uint32_t)occ.lf(occ.lf(0, y + 1u), x + 1u);
+    }
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t L = t >> 4; const uint32_t pc = (uint32_t)t & 15u;
+    if (L < nlines) reinterpret_cast<uint32_t*>(lines + L * 128u)[pc] = s_c2[pc] + part[(size_t)pc * nlines + L];
+}
+int build_pair_table(Index* x, hipStream_t stream) {
+    DevString& s = x->bwt;
+    const char* off = getenv("FMGPU_PAIRS");
+    if (kWide || s.sigma != 5 || s.family != FAM_A || s.shadow || s.va.bstride != 64u || s.n < 2 || s.pairs || (off && atoi(off) == 0)) return 0;
+    const uint64_t nlines = s.n / 128 + 1;
+    DBuf out, part, ex, cnt, tmp; int rc;
+    if ((rc = out.alloc(nlines * 128)) || (rc = part.alloc(nlines * 16 * 4)) || (rc = ex.alloc(kPairMaxRows * 4)) || (rc = cnt.alloc(8))) return rc;
+    FM_HIP(hipMemsetAsync(cnt.p, 0, 8, stream));
+    FM_HIP(hipMemsetAsync(ex.p, 0xff, kPairMaxRows * 4, stream));
+    FM_GRID(grid, nlines * 128);
+    k_pair_codes<<<grid, dim3(256), 0, stream>>>(OccA<5>{s.va}, s.n, out.as<uint8_t>(), part.as<uint32_t>(), nlines, ex.as<uint32_t>(), cnt.as<uint32_t>());
+    FM_LAUNCHED("k_pair_codes");
+    uint32_t nex = 0;
+    FM_HIP(hipMemcpyAsync(&nex, cnt.p, 4, hipMemcpyDeviceToHost, stream));
+    FM_HIP(hipStreamSynchronize(stream));
+    if (nex > kPairMaxRows) return 0;                             // many sequences: exact search keeps its one-symbol steps
+    size_t tb = 0;
+    FM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, part.as<uint32_t>(), part.as<uint32_t>(), (size_t)nlines));
+    if ((rc = tmp.alloc(tb))) return rc;
+    for (uint32_t pc = 0; pc < 16; ++pc) {
+        uint32_t* p = part.as<uint32_t>() + (size_t)pc * nlines; size_t b2 = tb;
+        FM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, b2, p, p, (size_t)nlines, stream));
+    }
+    FM_GRID(grid2, nlines * 16);
+    k_pair_counts<<<grid2, dim3(256), 0, stream>>>(OccA<5>{s.va}, part.as<uint32_t>(), nlines, out.as<uint8_t>());
+    FM_LAUNCHED("k_pair_counts");
+    std::vector<uint32_t> rows(nex);
+    if (nex) FM_HIP(hipMemcpyAsync(rows.data(), ex.p, nex * 4, hipMemcpyDeviceToHost, stream));
+    FM_HIP(hipStreamSynchronize(stream));
+    std::sort(rows.begin(), rows.end());
+    if (nex) FM_HIP(hipMemcpy(ex.p, rows.data(), nex * 4, hipMemcpyHostToDevice));
+    s.pairs_bytes = out.bytes; s.pairs = (uint8_t*)out.take(); s.pairs_ex = (uint32_t*)ex.take(); s.pairs_nex = nex;
+    x->device_bytes += s.pairs_bytes;
+    return 0;
+}
+
 // EPRV3 / EPRV4 / EPRV5 / InterleavedEPRV7 -> Format A.  thread = (block B, symbol c): the symbol-match mask of the bit planes
 // (EPRV3.h:55-68) becomes the entry's bitmap (position p <-> bit p & 63, as in Format A), the counters of every level that
 // cover row 64B (EPRV3.h:205-213, EPRV4.h:128-142, EPRV5.h:126-139, InterleavedEPRV7.h:190-199) are summed into cnt.
@@ -335,7 +425,7 @@ int on_handle_device(const Index* x) {
 }
 
 void free_string(DevString& s) {
-    for (void* p : {s.blk, s.aux, s.sup, (void*)s.lf_table, (void*)s.kblk, (void*)s.walk3, s.shadow, s.shadow_sup, (void*)s.slut, (void*)s.walkj, (void*)s.walk2j, s.dense, (void*)s.dense_ex})
+    for (void* p : {s.blk, s.aux, s.sup, (void*)s.lf_table, (void*)s.kblk, (void*)s.walk3, s.shadow, s.shadow_sup, (void*)s.slut, (void*)s.walkj, (void*)s.walk2j, s.dense, (void*)s.dense_ex, (void*)s.pairs, (void*)s.pairs_ex})
         if (p) (void)hipFree(p);
     s = DevString{};
 }
@@ -769,6 +859,7 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
     }
     x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->bwt.sup_bytes + x->rev.blk_bytes + x->rev.aux_bytes + x->rev.sup_bytes + x->bwt.dense_bytes + x->rev.dense_bytes +
                       (x->bwt.lf_table ? x->bwt.n * sizeof(idx_t) : 0) + (x->rev.lf_table ? x->rev.n * sizeof(idx_t) : 0);
+    rc = build_pair_table(x.get(), nullptr); if (rc) return bail(rc);
     if (const fmgpu_sparse_array_desc* sa = desc->annotated_array) {
         if (sa->n != desc->bwt.n) return bail(fail(FMGPU_ERR_INVALID, "annotated_array.n != bwt.n"));
         if (sa->n_l0 < sa->n / 65536 + 1 || sa->n_l1 < sa->n / 512 + 1 || sa->n_bit_words < (sa->n / 512 + 1) * 8)

@@ -176,6 +176,111 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
     add_counters(steps_total, steps, 12u * acc, acc);
 }
 
+// ---- exact search in two-symbol steps on Format P (fmgpu_common.h): one 128-byte line per interval end and PAIR of symbols.  An exact search is bound
+// by the random line fills it causes (tools/membench.hip: 52-55 G dependent lines/s, whatever is read of a line), so halving the lines of a read halves
+// its time.  A pair whose interval comes out empty is taken again in one-symbol steps (Format A), which yields the row and the step count a
+// one-symbol search ends with; so is a pair that holds a delimiter or a byte outside the alphabet, and the last symbol of a read of odd length.
+constexpr uint32_t kPairFilterBits = 32768;
+constexpr uint32_t kExactPairLds = 0;               // unused dynamic LDS that would limit k_exact_p's residency: none (resident blocks per CU 8 / 7 / 6 / 5 / 4: see DESIGN)
+struct PairLine { uint32_t cnt; uint4 w[4]; };       // the pair's count + rows 0..63: planes 0,1 | 2,3; rows 64..127: planes 0,1 | 2,3
+__device__ __forceinline__ PairLine load_pair_line(const uint8_t* __restrict__ pairs, uint32_t i, uint32_t pc) {
+    const uint8_t* L = pairs + (size_t)(i >> 7) * 128u;
+    PairLine r;
+    r.cnt = reinterpret_cast<const uint32_t*>(L)[pc];
+    const uint4* P = reinterpret_cast<const uint4*>(L + 64);
+    r.w[0] = P[0]; r.w[1] = P[1]; r.w[2] = P[2]; r.w[3] = P[3];
+    return r;
+}
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+// rows of the pair before row i (inv[k] = ~0 where the pair code has bit k clear)
+__device__ __forceinline__ uint32_t pair_rows_before(const PairLine& l, uint32_t i, const uint64_t* inv) {
+    const uint32_t off = i & 127u;
+    const uint64_t m0 = off >= 64u ? ~0ull : lowmask(off), m1 = off > 64u ? lowmask(off - 64u) : 0ull;
+    const uint64_t h0 = (u64_of(l.w[0].x, l.w[0].y) ^ inv[0]) & (u64_of(l.w[0].z, l.w[0].w) ^ inv[1]) & (u64_of(l.w[1].x, l.w[1].y) ^ inv[2]) & (u64_of(l.w[1].z, l.w[1].w) ^ inv[3]);
+    const uint64_t h1 = (u64_of(l.w[2].x, l.w[2].y) ^ inv[0]) & (u64_of(l.w[2].z, l.w[2].w) ^ inv[1]) & (u64_of(l.w[3].x, l.w[3].y) ^ inv[2]) & (u64_of(l.w[3].z, l.w[3].w) ^ inv[3]);
+    return popc64(h0 & m0) + popc64(h1 & m1);
+}
+__global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __restrict__ pairs, const uint32_t* __restrict__ ex, uint32_t nex,
+                                                 const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
+                                                 uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
+                                                 unsigned long long* __restrict__ steps_total) {
+    __shared__ uint32_t s_filt[kPairFilterBits / 32u];
+    __shared__ uint32_t s_ex[512];
+    for (uint32_t t = threadIdx.x; t < kPairFilterBits / 32u; t += 256u) s_filt[t] = 0u;
+    for (uint32_t t = threadIdx.x; t < 512u; t += 256u) s_ex[t] = t < nex ? ex[t] : 0xffffffffu;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < 512u; t += 256u) {
+        const uint32_t r = s_ex[t];
+        if (r != 0xffffffffu) { const uint32_t bk = (r >> 7) & (kPairFilterBits - 1u); atomicOr(&s_filt[bk >> 5], 1u << (bk & 31u)); }
+    }
+    __syncthreads();
+    // listed rows in [first row of i's line, i): they sit in the planes as code 0 and are in no count
+    auto listed_before = [&](uint32_t i) -> uint32_t {
+        const uint32_t bk = (i >> 7) & (kPairFilterBits - 1u);
+        if (!((s_filt[bk >> 5] >> (bk & 31u)) & 1u)) return 0u;
+        const uint32_t first = i & ~127u;
+        uint32_t c = 0;
+        for (uint32_t t = 0; t < 512u && s_ex[t] < i; ++t) if (s_ex[t] >= first) ++c;
+        return c;
+    };
+    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t steps = 0, acc = 0, acc2 = 0;
+    if (q < nq) {
+        uint64_t o = qoff[q];
+        uint32_t m = (uint32_t)(qoff[q + 1] - o);
+        idx_t lb = 0, len = n;
+        if (m) {
+            QueryReader qr; qr.init(qbuf, o, m);
+            // one symbol, as k_exact_a does it; false once the search is over
+            auto single = [&](uint32_t c) -> bool {
+                ++steps;
+                if (c >= 5u) { lb = 0; len = 0; return false; }
+                const idx_t a = lb, b = lb + len;
+                idx_t ra, rb;
+                if (c == 0 && occ.v.fused) { lf0_pair(occ, a, b, ra, rb); acc += 2; }
+                else {
+                    EntryA ea = load_entry_a(occ.v, a, c);
+                    EntryA eb = ea;
+                    ++acc;
+                    if ((a >> 6) != (b >> 6)) { eb = load_entry_a(occ.v, b, c); ++acc; }
+                    ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
+                    rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
+                }
+                lb = ra; len = rb - ra;
+                return len != 0;
+            };
+            uint32_t i = 0;
+            bool over = false;
+            while (i + 2u <= m) {
+                const uint32_t y = qr.next(), x = qr.next();
+                i += 2u;
+                bool stepped = false;
+                if (y - 1u < 4u && x - 1u < 4u) {
+                    const uint32_t pc = (x - 1u) * 4u + (y - 1u);
+                    const uint32_t a = (uint32_t)lb, b = (uint32_t)(lb + len);
+                    const bool far = (a >> 7) != (b >> 7);
+                    // (both ends' lines in flight together where they are two — one step in seven: taking them one after the other, which fits 8 instead of
+                    //  5 waves per SIMD, cost 10.8 -> 13.1 ms)
+                    const PairLine la = load_pair_line(pairs, a, pc);
+                    PairLine lbl;
+                    if (far) lbl = load_pair_line(pairs, b, pc);
+                    acc2 += far ? 2u : 1u;
+                    uint64_t inv[4];
+                    for (int k = 0; k < 4; ++k) inv[k] = ((pc >> k) & 1u) ? 0ull : ~0ull;
+                    uint32_t ra = la.cnt + pair_rows_before(la, a, inv);
+                    uint32_t rb = far ? lbl.cnt + pair_rows_before(lbl, b, inv) : la.cnt + pair_rows_before(la, b, inv);
+                    if (pc == 0u) { ra -= listed_before(a); rb -= listed_before(b); }
+                    if (rb > ra) { lb = ra; len = rb - ra; steps += 2u; stepped = true; }
+                }
+                if (!stepped && !(single(y) && single(x))) { over = true; break; }
+            }
+            if (!over && i < m) single(qr.next());
+        }
+        store_interval(out_lb, out_len, q, lb, len);
+    }
+    add_counters(steps_total, steps, 12u * acc + 68u * acc2, acc + acc2);
+}
+
 // ------------------------------------------------------------------ DFS machinery
 constexpr int kMaxParts = 16;
 constexpr int kMaxSearches = 16;
@@ -3342,6 +3447,13 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         // k_exact_a runs best with 5 resident blocks per CU, not the 8 its 28 registers allow (measured on the 3.09 Gbp index, 10 M x 101 bp: 8 / 6 / 5 / 4 / 3
         // blocks = 19.53 / 19.23 / 18.92 / 19.10 / 18.95 ms — more waves only queue up at the memory system): 28 KB of unused dynamic LDS set the residency
         const size_t lds_a = dev_env("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)28 * 1024;
+        if constexpr (!kWide) {
+            if (x->bwt.sigma == 5 && x->bwt.pairs && !(dev_flags_env() & (1 << 22))) {
+                const size_t lds_p = dev_env("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)kExactPairLds;
+                k_exact_p<<<grid, block, lds_p, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, qb, qo, nq, n, ol, on, dsteps);
+            } else if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
+            else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
+        } else
         if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
     } else if (x->bwt.search_family() == FAM_WAVELET) {

@@ -101,6 +101,54 @@ def test_exact_search_all_layouts(layout):
     assert st.lf_steps == int(ost.sum())
 
 
+@pytest.mark.parametrize("shape", ["repeats", "many_sequences", "poly_a", "too_many_sequences", "tiny"])
+def test_exact_search_in_pair_steps(shape, monkeypatch):
+    """Format P / k_exact_p (two symbols per step on a sigma = 5 index): intervals, rows of misses and step counts equal the one-symbol search's
+    (the oracle's: SearchNoErrors.h:12-26) — reads of odd and even length, misses found in the first and in the second symbol of a pair, delimiters
+    and bytes outside the alphabet inside reads, 'AA'-rich texts (listed rows sit in the planes as the pair 'AA')."""
+    rng = np.random.default_rng(77)
+    if shape == "repeats":
+        seqs = repeat_text(5, n=6000)
+    elif shape == "many_sequences":
+        seqs = [rng.integers(1, 5, size=int(rng.integers(1, 90)), dtype=np.uint8) for _ in range(250)]
+    elif shape == "poly_a":
+        seqs = [np.where(rng.random(int(rng.integers(2, 700))) < 0.85, 1, rng.integers(1, 5, size=1)[0]).astype(np.uint8) for _ in range(60)]
+    elif shape == "too_many_sequences":
+        seqs = [rng.integers(1, 5, size=int(rng.integers(1, 30)), dtype=np.uint8) for _ in range(300)]
+    else:
+        seqs = [np.array([1], dtype=np.uint8), np.array([2, 1], dtype=np.uint8)]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 4, False)
+    gx = gpu_index(ox)
+    monkeypatch.setenv("FMGPU_PAIRS", "0")
+    gx_single = gpu_index(ox)
+    monkeypatch.delenv("FMGPU_PAIRS")
+    has_table = gx.device_bytes > gx_single.device_bytes
+    assert has_table == (shape != "too_many_sequences")
+    long_enough = [q for q in seqs if len(q) > 2]
+    queries = mutated_queries(long_enough, 1500, 1, 140, 2, seed=6) if long_enough else []
+    queries += [[], [1], [1, 1], [1, 1, 1], [4, 4, 4, 4], [0], [1, 0], [0, 1], [1, 0, 1, 1], [2, 1, 0],
+                [1] * 64, [1] * 65, [1] * 129, [2, 1], [1, 2]]
+    for s_ in seqs[:40]:                                     # whole sequences, their ends and what follows a delimiter
+        queries += [s_, s_[-3:], s_[:3], np.concatenate([s_[-2:], [0]]), np.concatenate([[0], s_[:2]])]
+    qbuf, qoff = fm.flatten(queries)
+    olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
+    for flags in ("0", str(1 << 22)):
+        monkeypatch.setenv("FMGPU_DEV_FLAGS", flags)
+        for g in (gx, gx_single):
+            lb, ln, st = fm.search_no_errors.search(g, (qbuf, qoff), want_stats=True)
+            assert np.array_equal(ln, oln) and np.array_equal(lb, olb), (shape, flags)
+            assert st.lf_steps == int(ost.sum())
+    monkeypatch.delenv("FMGPU_DEV_FLAGS")
+    # the packed form (one word per read) goes through the same kernel
+    packed = fm.search_no_errors.search_packed(gx, (qbuf, qoff))
+    assert np.array_equal(packed, (olb << np.uint64(32)) | oln)
+    # bytes outside the alphabet (undefined in the reference, an empty interval here): both kernels end at the same step
+    odd = fm.flatten([[1, 2, 9, 1], [9, 1], [1, 9], [7], [1, 1, 9], [9, 1, 1], [1, 1, 1, 9, 1, 1]])
+    a = fm.search_no_errors.search(gx, odd, want_stats=True)
+    b = fm.search_no_errors.search(gx_single, odd, want_stats=True)
+    assert not a[1].any() and np.array_equal(a[0], b[0]) and a[2].lf_steps == b[2].lf_steps
+
+
 def test_exact_search_edge_cases():
     text = make_text(5000, 5, seed=9)
     ox = fo.OraIndex.build("IB16", 5, [text], 16, False)
