@@ -681,6 +681,7 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
                        (x->bwt.lf_table ? n * sizeof(idx_t) : 0) + (x->rev.lf_table ? n * sizeof(idx_t) : 0);
     if ((rc = fuse_presence_bits(x.get(), stream))) return bail(rc);
     if ((rc = build_pair_table(x.get(), stream))) return bail(rc);
+    if ((rc = build_flat_table(x.get(), stream))) return bail(rc);
     *out = reinterpret_cast<fmgpu_index_t>(x.release());
     if (built_out) *built_out = reinterpret_cast<fmgpu_built_t>(built.release());
     return 0;

@@ -42,6 +42,13 @@
 //     interval end; this format halves the lines of a query.  Rows whose pair holds a delimiter (two per sequence) carry code 0, are left out of
 //     the counts and are listed (`pairs_ex`, ascending) behind a filter on the line number; built when there are at most 512 of them.
 //
+//  Format S  ("symbol planes": the bwt of a Wavelet index with 6 <= sigma <= 29, beside Format M — what exact search reads there, one line per LF step and end):
+//     one line of 128 bytes per 64 rows:  u64 plane[5] = bit k of each row's symbol;  then sigma 3-byte numbers = the rows before the line that hold
+//     symbol c, counted from the start of the line's super-block of 2^24 rows (read with one unaligned dword load);  flat_super[sb][c] = C[c] + the rows holding c before
+//     super-block sb (sigma * 3 + 40 <= 128 bytes: sigma <= 29).  LF(i, c) = flat_super[i >> 24][c] + count24[c] + popcount(rows of the line below i
+//     whose five plane bits spell c).  The multi-ary wavelet tree takes two lines per step and end for sigma = 28 (two levels); the super table (13 KB at
+//     2 x 10^9 rows) stays in L2.  2 bytes per row.
+//
 //  Format R  (reference layout as is — InterleavedEPR*, InterleavedEPRV2*): blocks + superBlocks copied verbatim.
 //
 //  Format W  (the reference's binary wavelet tree, one 64-byte line per 384 node bits; built from Wavelet::bitvector[*] at upload and only
@@ -119,7 +126,7 @@ inline int grid_of(uint64_t threads, dim3* out, uint64_t cap_blocks = 0) {
 // kernel through them).  Everything else — count-only runs, per-read node dumps, tuning fields, residency overrides (FMGPU_DEV_*) — exists in
 // builds made with -DFMGPU_DEV only (make DEV=1; tools/k2_*_probe.py): a stray environment variable cannot make the shipped library drop records
 // or write outside a caller's buffer.
-constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 22) | (1 << 24) | (1 << 29) | (1 << 30);   // (bit 22: exact search in one-symbol steps although Format P exists)
+constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 21) | (1 << 22) | (1 << 24) | (1 << 29) | (1 << 30);   // (bit 22: exact search in one-symbol steps although Format P exists; bit 21: exact search on the wavelet levels although Format S exists)
 //   // general kernel | no prefix table | no LF^1..3 | no LF table in the general kernels | no walk table | no length buckets | no work sharing | k_scheme_lean on Format A although Format D exists | k_scheme_fast<PLAIN> instead of k_scheme_lean
 inline const char* dev_env(const char* name) {
 #ifdef FMGPU_DEV
@@ -672,6 +679,8 @@ struct DevString {
     void* dense = nullptr; size_t dense_bytes = 0; uint32_t* dense_ex = nullptr; uint32_t dense_nex = 0;
     // Format P (see the head of this file): pair lines of the bwt + the ascending list of the rows left out of them (u32, `pairs_nex` of them)
     uint8_t* pairs = nullptr; size_t pairs_bytes = 0; uint32_t* pairs_ex = nullptr; uint32_t pairs_nex = 0;
+    // Format S (see the head of this file): one line per 64 rows of a Wavelet bwt with 6 <= sigma <= 29 + the counts at the start of every 2^24 rows ([flat_nsb][sigma], C folded in)
+    uint8_t* flat = nullptr; size_t flat_bytes = 0; idx_t* flat_super = nullptr; uint32_t flat_nsb = 0;
     void* shadow = nullptr; size_t shadow_bytes = 0;   // (shadow_bytes = blocks + super table)
     void* shadow_sup = nullptr; size_t shadow_sup_bytes = 0;
     int search_family() const { return shadow ? (int)FAM_A : family; }
@@ -694,6 +703,8 @@ int build_dense_dna(DevString& s, hipStream_t stream);
 int fuse_presence_bits(Index* x, hipStream_t stream);
 // builds Format P beside the bwt of a sigma = 5 index with 32-bit rows (no-op where it does not apply; adds its bytes to device_bytes); defined in fmgpu_index.hip
 int build_pair_table(Index* x, hipStream_t stream);
+// builds Format S beside the Wavelet bwt of an index with 6 <= sigma <= 29 (no-op where it does not apply; adds its bytes to device_bytes); defined in fmgpu_index.hip
+int build_flat_table(Index* x, hipStream_t stream);
 void free_string(DevString& s);
 
 struct Index {

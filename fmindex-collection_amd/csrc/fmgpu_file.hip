@@ -283,7 +283,8 @@ int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
         if (x->bwt.dense && !x->rev.dense) { (void)hipFree(x->bwt.dense); (void)hipFree(x->bwt.dense_ex); x->bwt.dense = nullptr; x->bwt.dense_ex = nullptr; x->bwt.dense_bytes = 0; x->bwt.dense_nex = 0; }
         x->device_bytes += x->bwt.dense_bytes + x->rev.dense_bytes;
     }
-    if ((rc = build_pair_table(x.get(), nullptr))) return bail(rc);       // ... and so is Format P
+    if ((rc = build_pair_table(x.get(), nullptr))) return bail(rc);       // ... and so are Formats P and S
+    if ((rc = build_flat_table(x.get(), nullptr))) return bail(rc);
     FM_HIP(hipDeviceSynchronize());
     *out = reinterpret_cast<fmgpu_index_t>(x.release());
     return 0;

@@ -197,38 +197,41 @@ __global__ __launch_bounds__(256) void k_pair_codes(OccA<5> occ, uint64_t n, uin
                                                     uint32_t* __restrict__ ex, uint32_t* __restrict__ nex) {
     __shared__ uint32_t s_cnt[4][16];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    uint32_t code = 0; bool listed = false;
-    if (i < n) {
-        const uint32_t y = occ.symbol((idx_t)i);
-        if (y == 0) listed = true;
-        else {
-            const uint32_t x = occ.symbol(occ.lf((idx_t)i, y));
-            if (x == 0) listed = true; else code = (x - 1u) * 4u + (y - 1u);
+    for (uint64_t chunk = blockIdx.x; chunk * 2u < nlines; chunk += gridDim.x) {     // 256 rows = two lines per pass (a grid-stride loop: the thread count of a launch stays below 2^32)
+        const uint64_t i = chunk * 256u + threadIdx.x;
+        uint32_t code = 0; bool listed = false;
+        if (i < n) {
+            const uint32_t y = occ.symbol((idx_t)i);
+            if (y == 0) listed = true;
+            else {
+                const uint32_t x = occ.symbol(occ.lf((idx_t)i, y));
+                if (x == 0) listed = true; else code = (x - 1u) * 4u + (y - 1u);
+            }
         }
-    }
-    const bool counted = i < n && !listed;
-    uint64_t plane[4];
-    for (int k = 0; k < 4; ++k) plane[k] = __ballot(counted && ((code >> k) & 1u));
-    const uint64_t valid = __ballot(counted);
-    uint64_t lm = __ballot(listed);
-    if (lane == 0) while (lm) {
-        const uint32_t r = (uint32_t)__ffsll((unsigned long long)lm) - 1u; lm &= lm - 1ull;
-        const uint32_t k = atomicAdd(nex, 1u);
-        if (k < kPairMaxRows) ex[k] = (uint32_t)((uint64_t)blockIdx.x * 256u + wave * 64u + r);
-    }
-    const uint64_t L = (uint64_t)blockIdx.x * 2u + (wave >> 1);         // this wave's 128-row line
-    if (lane < 4 && L < nlines) reinterpret_cast<uint64_t*>(lines + L * 128u + 64u + (wave & 1u) * 32u)[lane] = plane[lane];
-    if (lane < 16) {
-        uint64_t mm = valid;
-        for (int k = 0; k < 4; ++k) mm &= ((lane >> k) & 1u) ? plane[k] : ~plane[k];
-        s_cnt[wave][lane] = (uint32_t)__popcll((unsigned long long)mm);
-    }
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        const uint32_t b = threadIdx.x >> 4, pc = threadIdx.x & 15u;
-        const uint64_t L2 = (uint64_t)blockIdx.x * 2u + b;
-        if (L2 < nlines) part[(size_t)pc * nlines + L2] = s_cnt[2 * b][pc] + s_cnt[2 * b + 1][pc];
+        const bool counted = i < n && !listed;
+        uint64_t plane[4];
+        for (int k = 0; k < 4; ++k) plane[k] = __ballot(counted && ((code >> k) & 1u));
+        const uint64_t valid = __ballot(counted);
+        uint64_t lm = __ballot(listed);
+        if (lane == 0) while (lm) {
+            const uint32_t r = (uint32_t)__ffsll((unsigned long long)lm) - 1u; lm &= lm - 1ull;
+            const uint32_t k = atomicAdd(nex, 1u);
+            if (k < kPairMaxRows) ex[k] = (uint32_t)(chunk * 256u + wave * 64u + r);
+        }
+        const uint64_t L = chunk * 2u + (wave >> 1);                // this wave's 128-row line
+        if (lane < 4 && L < nlines) reinterpret_cast<uint64_t*>(lines + L * 128u + 64u + (wave & 1u) * 32u)[lane] = plane[lane];
+        if (lane < 16) {
+            uint64_t mm = valid;
+            for (int k = 0; k < 4; ++k) mm &= ((lane >> k) & 1u) ? plane[k] : ~plane[k];
+            s_cnt[wave][lane] = (uint32_t)__popcll((unsigned long long)mm);
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const uint32_t b = threadIdx.x >> 4, pc = threadIdx.x & 15u;
+            const uint64_t L2 = chunk * 2u + b;
+            if (L2 < nlines) part[(size_t)pc * nlines + L2] = s_cnt[2 * b][pc] + s_cnt[2 * b + 1][pc];
+        }
+        __syncthreads();
     }
 }
 // counts of line L = where the interval of the pair starts + the pair's occurrences before the line (part: scanned per pair)
@@ -252,7 +255,7 @@ int build_pair_table(Index* x, hipStream_t stream) {
     if ((rc = out.alloc(nlines * 128)) || (rc = part.alloc(nlines * 16 * 4)) || (rc = ex.alloc(kPairMaxRows * 4)) || (rc = cnt.alloc(8))) return rc;
     FM_HIP(hipMemsetAsync(cnt.p, 0, 8, stream));
     FM_HIP(hipMemsetAsync(ex.p, 0xff, kPairMaxRows * 4, stream));
-    FM_GRID(grid, nlines * 128);
+    dim3 grid; if ((rc = grid_of(nlines * 128, &grid, 1u << 22))) return rc;
     k_pair_codes<<<grid, dim3(256), 0, stream>>>(OccA<5>{s.va}, s.n, out.as<uint8_t>(), part.as<uint32_t>(), nlines, ex.as<uint32_t>(), cnt.as<uint32_t>());
     FM_LAUNCHED("k_pair_codes");
     uint32_t nex = 0;
@@ -276,6 +279,76 @@ int build_pair_table(Index* x, hipStream_t stream) {
     if (nex) FM_HIP(hipMemcpy(ex.p, rows.data(), nex * 4, hipMemcpyHostToDevice));
     s.pairs_bytes = out.bytes; s.pairs = (uint8_t*)out.take(); s.pairs_ex = (uint32_t*)ex.take(); s.pairs_nex = nex;
     x->device_bytes += s.pairs_bytes;
+    return 0;
+}
+
+// ---- Format S (fmgpu_common.h): a flat one-line-per-64-rows occurrence table from the symbols of a Wavelet string.
+constexpr uint32_t kFlatSuperShift = 24;            // rows per super-block: the counts inside a line are 24 bits wide
+__global__ __launch_bounds__(256) void k_flat_planes(OccM occ, uint64_t n, uint32_t sigma, uint8_t* __restrict__ lines, uint8_t* __restrict__ cnt8, uint64_t nlines) {
+    const uint32_t lane = threadIdx.x & 63u;
+    // (a grid-stride loop: a launch of more than 2^32 threads is not a thing HIP does)
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; (i >> 6) < nlines; i += (uint64_t)gridDim.x * 256u) {
+        const uint64_t L = i >> 6;
+        const bool in = i < n;
+        const uint32_t sym = in ? occ.symbol((idx_t)i) : 0u;
+        uint64_t plane[5];
+        for (int k = 0; k < 5; ++k) plane[k] = __ballot(in && ((sym >> k) & 1u));
+        const uint64_t valid = __ballot(in);
+        if (lane < 5) reinterpret_cast<uint64_t*>(lines + L * 128u)[lane] = plane[lane];
+        if (lane < sigma) {
+            uint64_t mm = valid;
+            for (int k = 0; k < 5; ++k) mm &= ((lane >> k) & 1u) ? plane[k] : ~plane[k];
+            cnt8[(size_t)lane * nlines + L] = (uint8_t)__popcll((unsigned long long)mm);
+        }
+    }
+}
+// workgroup (sb, c): the running count of symbol c through the lines of super-block sb, written into the lines; the super-block's total
+__global__ __launch_bounds__(256) void k_flat_counts(const uint8_t* __restrict__ cnt8, uint64_t nlines, uint32_t sigma, uint8_t* __restrict__ lines, uint32_t* __restrict__ totals) {
+    typedef hipcub::BlockScan<uint32_t, 256> Scan;
+    __shared__ typename Scan::TempStorage tmp;
+    const uint32_t sb = blockIdx.x, c = blockIdx.y;
+    const uint64_t first = (uint64_t)sb << (kFlatSuperShift - 6), last = min(nlines, first + (1ull << (kFlatSuperShift - 6)));
+    uint32_t run = 0;
+    for (uint64_t base = first; base < last; base += 256u) {
+        const uint64_t L = base + threadIdx.x;
+        const uint32_t v = L < last ? cnt8[(size_t)c * nlines + L] : 0u;
+        uint32_t before, sum;
+        Scan(tmp).ExclusiveSum(v, before, sum);
+        __syncthreads();
+        if (L < last) {
+            const uint32_t t = run + before;
+            uint8_t* ln = lines + L * 128u;
+            ln[40u + 3u * c] = (uint8_t)t; ln[41u + 3u * c] = (uint8_t)(t >> 8); ln[42u + 3u * c] = (uint8_t)(t >> 16);
+        }
+        run += sum;
+    }
+    if (threadIdx.x == 0) totals[(size_t)sb * sigma + c] = run;
+}
+__global__ void k_flat_super(const idx_t* __restrict__ C, const uint32_t* __restrict__ totals, uint32_t nsb, uint32_t sigma, idx_t* __restrict__ super) {
+    const uint32_t c = threadIdx.x;
+    if (c >= sigma) return;
+    idx_t run = C[c];
+    for (uint32_t sb = 0; sb < nsb; ++sb) { super[(size_t)sb * sigma + c] = run; run += (idx_t)totals[(size_t)sb * sigma + c]; }
+}
+int build_flat_table(Index* x, hipStream_t stream) {
+    DevString& s = x->bwt;
+    const char* off = getenv("FMGPU_FLAT");
+    if (s.family != FAM_WAVELET || s.sigma < 6 || s.sigma > 29 || s.n < 2 || s.flat || (off && atoi(off) == 0)) return 0;
+    const uint64_t nlines = s.n / 64 + 1;
+    const uint32_t nsb = (uint32_t)(s.n >> kFlatSuperShift) + 1u, sigma = (uint32_t)s.sigma;
+    DBuf out, cnt8, totals, super; int rc;
+    if ((rc = out.alloc(nlines * 128)) || (rc = cnt8.alloc(nlines * sigma)) || (rc = totals.alloc((size_t)nsb * sigma * 4)) || (rc = super.alloc((size_t)nsb * sigma * sizeof(idx_t)))) return rc;
+    FM_HIP(hipMemsetAsync(out.p, 0, out.bytes, stream));
+    dim3 grid; if ((rc = grid_of(nlines * 64, &grid, 1u << 22))) return rc;
+    k_flat_planes<<<grid, dim3(256), 0, stream>>>(OccM{s.vm}, s.n, sigma, out.as<uint8_t>(), cnt8.as<uint8_t>(), nlines);
+    FM_LAUNCHED("k_flat_planes");
+    k_flat_counts<<<dim3(nsb, sigma), dim3(256), 0, stream>>>(cnt8.as<uint8_t>(), nlines, sigma, out.as<uint8_t>(), totals.as<uint32_t>());
+    FM_LAUNCHED("k_flat_counts");
+    k_flat_super<<<1, 32, 0, stream>>>(x->dC, totals.as<uint32_t>(), nsb, sigma, super.as<idx_t>());
+    FM_LAUNCHED("k_flat_super");
+    FM_HIP(hipStreamSynchronize(stream));
+    s.flat_bytes = out.bytes + super.bytes; s.flat = (uint8_t*)out.take(); s.flat_super = (idx_t*)super.take(); s.flat_nsb = nsb;
+    x->device_bytes += s.flat_bytes;
     return 0;
 }
 
@@ -425,7 +498,7 @@ int on_handle_device(const Index* x) {
 }
 
 void free_string(DevString& s) {
-    for (void* p : {s.blk, s.aux, s.sup, (void*)s.lf_table, (void*)s.kblk, (void*)s.walk3, s.shadow, s.shadow_sup, (void*)s.slut, (void*)s.walkj, (void*)s.walk2j, s.dense, (void*)s.dense_ex, (void*)s.pairs, (void*)s.pairs_ex})
+    for (void* p : {s.blk, s.aux, s.sup, (void*)s.lf_table, (void*)s.kblk, (void*)s.walk3, s.shadow, s.shadow_sup, (void*)s.slut, (void*)s.walkj, (void*)s.walk2j, s.dense, (void*)s.dense_ex, (void*)s.pairs, (void*)s.pairs_ex, (void*)s.flat, (void*)s.flat_super})
         if (p) (void)hipFree(p);
     s = DevString{};
 }
@@ -860,6 +933,7 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
     x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->bwt.sup_bytes + x->rev.blk_bytes + x->rev.aux_bytes + x->rev.sup_bytes + x->bwt.dense_bytes + x->rev.dense_bytes +
                       (x->bwt.lf_table ? x->bwt.n * sizeof(idx_t) : 0) + (x->rev.lf_table ? x->rev.n * sizeof(idx_t) : 0);
     rc = build_pair_table(x.get(), nullptr); if (rc) return bail(rc);
+    rc = build_flat_table(x.get(), nullptr); if (rc) return bail(rc);
     if (const fmgpu_sparse_array_desc* sa = desc->annotated_array) {
         if (sa->n != desc->bwt.n) return bail(fail(FMGPU_ERR_INVALID, "annotated_array.n != bwt.n"));
         if (sa->n_l0 < sa->n / 65536 + 1 || sa->n_l1 < sa->n / 512 + 1 || sa->n_bit_words < (sa->n / 512 + 1) * 8)

@@ -281,6 +281,111 @@ __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __r
     add_counters(steps_total, steps, 12u * acc + 68u * acc2, acc + acc2);
 }
 
+// ---- exact search on Format S (fmgpu_common.h): ONE 128-byte line per LF step and interval end where the multi-ary wavelet tree of sigma = 28 takes two —
+// the five symbol planes of the line's 64 rows, the symbol's 24-bit count before the line and the super-block's count (a small table, LDS or L2).
+// The lines are fetched by the lanes of an OCTET together: a lane that reads 44 bytes of its own random line with four load instructions pays four address
+// translations and four passes through the texture path per line, and that — not the line fills — bounds the kernel (tools/membench.hip modes 8 / 9 / 4:
+// 33 / 47 / 44 G lines/s on a 3.1 GB table, 24 / 22 / 25 on a 4.2 GB one, where one load per line keeps 51).  Here instruction k of a round has the eight lanes of
+// every octet load the eight 16-byte pieces of the line of the octet's lane k — one coalesced 128-byte request and one translation per line — straight into
+// LDS (LDS-DMA: piece j of lane 8o + k's line lands at region k, offset 128 o + 16 j), from where the owner reads its planes and count.  The loop is
+// wave-uniform (reads that are over ride along with a dummy line); waves do not synchronise with each other.
+constexpr uint32_t kFlatRegion = 1024u + 16u;        // bytes per region (64 pieces + padding that spreads the owners' reads over the LDS banks)
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+typedef uint32_t __attribute__((ext_vector_type(4))) flat_u32x4;
+__device__ __forceinline__ void flat_round(const uint8_t* __restrict__ flat, uint32_t line, uint32_t lane, lds_word* wave_lds) {
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t l = __shfl(line, (int)((lane & ~7u) | k), 64);
+        const uint8_t* g = flat + (size_t)l * 128u + (lane & 7u) * 16u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(wave_lds + k * (kFlatRegion / 4u)), 16, 0, 0);
+    }
+}
+// rows before row i that hold symbol c in the owner's line (now in LDS) + the line's count of c
+__device__ __forceinline__ uint32_t flat_rank_lds(const lds_word* own, uint32_t i, uint32_t c) {
+    const flat_u32x4 p01 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own);
+    const flat_u32x4 p23 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 4);
+    const uint32_t p4l = own[8], p4h = own[9];
+    const lds_word* g = own + 10u + 3u * (c >> 2);
+    const uint32_t d0 = g[0], d1 = g[1], d2 = g[2], k = c & 3u;
+    const uint32_t cnt = k == 0u ? (d0 & 0xffffffu) : (k == 1u ? ((d0 >> 24) | ((d1 & 0xffffu) << 8)) : (k == 2u ? ((d1 >> 16) | ((d2 & 0xffu) << 16)) : (d2 >> 8)));
+    const uint32_t i0 = (c & 1u) ? 0u : ~0u, i1 = (c & 2u) ? 0u : ~0u, i2 = (c & 4u) ? 0u : ~0u, i3 = (c & 8u) ? 0u : ~0u, i4 = (c & 16u) ? 0u : ~0u;
+    const uint32_t off = i & 63u;
+    const uint32_t mlo = off >= 32u ? ~0u : (1u << off) - 1u, mhi = off > 32u ? (1u << (off - 32u)) - 1u : 0u;
+    const uint32_t lo = (p01.x ^ i0) & (p01.z ^ i1) & (p23.x ^ i2) & (p23.z ^ i3) & (p4l ^ i4);
+    const uint32_t hi = (p01.y ^ i0) & (p01.w ^ i1) & (p23.y ^ i2) & (p23.w ^ i3) & (p4h ^ i4);
+    return cnt + __popc(lo & mlo) + __popc(hi & mhi);
+}
+__global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ flat, const idx_t* __restrict__ super, uint32_t sigma,
+                                                 const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
+                                                 uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
+                                                 unsigned long long* __restrict__ steps_total, uint32_t super_lds) {
+    extern __shared__ uint32_t s_flat[];                            // 4 waves x 8 regions | the super table, when it is small (super_lds entries)
+    idx_t* const s_super = reinterpret_cast<idx_t*>(s_flat + 4u * 8u * (kFlatRegion / 4u));
+    for (uint32_t t = threadIdx.x; t < super_lds; t += 256u) s_super[t] = super[t];
+    __syncthreads();
+    const idx_t* sup = super_lds ? s_super : super;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    lds_word* const wave_lds = (lds_word*)(s_flat + wave * 8u * (kFlatRegion / 4u));
+    const lds_word* const own = wave_lds + (lane & 7u) * (kFlatRegion / 4u) + (lane >> 3) * 32u;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t steps = 0, acc = 0, m = 0;
+    idx_t lb = 0, len = n;
+    QueryReader qr;
+    if (q < nq) {
+        const uint64_t o = qoff[q];
+        m = (uint32_t)(qoff[q + 1] - o);
+        if (m) qr.init(qbuf, o, m);
+    }
+    bool alive = m != 0;
+    uint32_t mmax = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, (uint32_t)__shfl_xor(mmax, off, 64));
+    for (uint32_t i = 0; i < mmax; ++i) {
+        if (i >= m) alive = false;                                  // (a shorter read of the wave is done)
+        if (!__ballot(alive)) break;
+        uint32_t c = 0;
+        if (alive) {
+            c = qr.next();
+            ++steps;
+            if (c >= sigma) { lb = 0; len = 0; alive = false; }
+        }
+        const idx_t a = lb, b = lb + len;
+        const uint32_t la = alive ? (uint32_t)(a >> 6) : 0u, lbn = alive ? (uint32_t)(b >> 6) : 0u;
+        const bool far = alive && la != lbn;
+        flat_round(flat, la, lane, wave_lds);
+        idx_t sa = 0, sb = 0;
+        if (alive) {
+            sa = sup[(size_t)(a >> 24) * sigma + c];
+            sb = sa;
+            if ((a >> 24) != (b >> 24)) sb = sup[(size_t)(b >> 24) * sigma + c];
+            acc += far ? 2u : 1u;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): the round's pieces are in LDS
+        asm volatile("" ::: "memory");
+        idx_t ra = 0, rb = 0;
+        if (alive) {
+            ra = sa + flat_rank_lds(own, (uint32_t)a, c);
+            if (!far) rb = sb + flat_rank_lds(own, (uint32_t)b, c);
+        }
+        if (__ballot(far)) {                                        // the other end's lines, where they are other lines (the first log_sigma(n) steps of a read)
+            __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): every lane has read what it needs of the first round
+            asm volatile("" ::: "memory");
+            flat_round(flat, far ? lbn : 0u, lane, wave_lds);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            asm volatile("" ::: "memory");
+            if (far) rb = sb + flat_rank_lds(own, (uint32_t)b, c);
+        }
+        if (alive) {
+            lb = ra; len = rb - ra;
+            if (len == 0) alive = false;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                         // the next round overwrites the regions
+        asm volatile("" ::: "memory");
+    }
+    if (q < nq) store_interval(out_lb, out_len, q, lb, len);
+    add_counters(steps_total, steps, 44u * acc, acc);
+}
+
 // ------------------------------------------------------------------ DFS machinery
 constexpr int kMaxParts = 16;
 constexpr int kMaxSearches = 16;
@@ -3456,6 +3561,11 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         } else
         if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
+    } else if (x->bwt.search_family() == FAM_WAVELET && x->bwt.flat && !(dev_flags_env() & (1 << 21))) {
+        const size_t super_bytes = (size_t)x->bwt.flat_nsb * x->bwt.sigma * sizeof(idx_t);
+        const uint32_t super_lds = super_bytes <= 16 * 1024 ? x->bwt.flat_nsb * (uint32_t)x->bwt.sigma : 0u;      // (2 x 10^9 rows, sigma = 28: 13 KB)
+        k_exact_s<<<grid, block, 4 * 8 * kFlatRegion + (super_lds ? super_bytes : 0) + dev_extra_lds, stream>>>(x->bwt.flat, x->bwt.flat_super, (uint32_t)x->bwt.sigma, (const uint8_t*)sbuf.dev,
+                                                           (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps, super_lds);
     } else if (x->bwt.search_family() == FAM_WAVELET) {
         uint32_t mx = shape_max, mn = 0;
         if (!have_shape && (rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) return rc;

@@ -149,6 +149,39 @@ def test_exact_search_in_pair_steps(shape, monkeypatch):
     assert not a[1].any() and np.array_equal(a[0], b[0]) and a[2].lf_steps == b[2].lf_steps
 
 
+@pytest.mark.parametrize("sigma", [6, 21, 28, 29, 30])
+@pytest.mark.parametrize("built_on_gpu", [False, True])
+def test_exact_search_on_symbol_planes(sigma, built_on_gpu, monkeypatch):
+    """Format S / k_exact_s (one line per LF step and end beside a Wavelet bwt, 6 <= sigma <= 29): intervals, miss rows and step counts equal the
+    search on the wavelet levels (k_exact_m) and the oracle's; sigma = 30 has no room for its counts in a line and keeps the tree."""
+    rng = np.random.default_rng(sigma)
+    base = rng.integers(1, sigma, size=5000, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[700:1900]]), rng.integers(1, min(sigma, 4), size=900, dtype=np.uint8), rng.integers(1, sigma, size=64, dtype=np.uint8),
+            np.full(200, sigma - 1, dtype=np.uint8), np.array([1], dtype=np.uint8)]
+    ox = fo.OraIndex.build("WAVELET", sigma, seqs, 8, False)
+    make = (lambda: fm.FMIndex.from_sequences(seqs, sigma, "WAVELET", 8)) if built_on_gpu else (lambda: gpu_index(ox))
+    gx = make()
+    monkeypatch.setenv("FMGPU_FLAT", "0")
+    gx_tree = make()
+    monkeypatch.delenv("FMGPU_FLAT")
+    assert (gx.device_bytes > gx_tree.device_bytes) == (sigma <= 29)
+    queries = mutated_queries([q for q in seqs if len(q) > 2], 1500, 1, 90, 1, seed=3, sigma=sigma)
+    queries += [[], [1], [sigma - 1], [0], [1, 0], [0, 1], [sigma - 1] * 64, [sigma - 1] * 201, seqs[2], seqs[2][1:], np.concatenate([seqs[2][-5:], [0]])]
+    qbuf, qoff = fm.flatten(queries)
+    olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
+    for flags in ("0", str(1 << 21)):
+        monkeypatch.setenv("FMGPU_DEV_FLAGS", flags)
+        for g in (gx, gx_tree):
+            lb, ln, st = fm.search_no_errors.search(g, (qbuf, qoff), want_stats=True)
+            assert np.array_equal(ln, oln) and np.array_equal(lb, olb), (sigma, flags)
+            assert st.lf_steps == int(ost.sum())
+    monkeypatch.delenv("FMGPU_DEV_FLAGS")
+    odd = fm.flatten([[1, 2, sigma, 1], [sigma + 3, 1], [1, 255]])       # bytes outside the alphabet: an empty interval, at the same step in both kernels
+    a = fm.search_no_errors.search(gx, odd, want_stats=True)
+    b = fm.search_no_errors.search(gx_tree, odd, want_stats=True)
+    assert not a[1].any() and np.array_equal(a[0], b[0]) and a[2].lf_steps == b[2].lf_steps
+
+
 def test_exact_search_edge_cases():
     text = make_text(5000, 5, seed=9)
     ox = fo.OraIndex.build("IB16", 5, [text], 16, False)

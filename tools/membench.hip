@@ -17,6 +17,8 @@ __device__ __forceinline__ uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51a
 // MODE 5: one 8-B read per step
 // MODE 6: 64-B line as 4 x dwordx4, but 4 adjacent lanes share a line (quad-cooperative)
 // MODE 7: a random 32-B sector per step as 2 x dwordx4 (Format D: 64 rows in 32 bytes)
+// MODE 8: a random 128-B line per step as dwordx4 @0, dwordx4 @16, dwordx2 @32, dwordx3 @40 + 12 k (Format S)
+// MODE 9: a random 128-B line per step as dword @4 k, 4 x dwordx4 @64 (Format P)
 template <int MODE, int CHAINS>
 __global__ __launch_bounds__(256) void gather(const uint8_t* __restrict__ buf, uint64_t nlines, int steps, uint64_t* __restrict__ out) {
     uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -31,6 +33,9 @@ __global__ __launch_bounds__(256) void gather(const uint8_t* __restrict__ buf, u
             uint64_t v = (uint64_t)p[0] + p[1] + p[2];
             if (MODE == 4) { const uint4* b4 = reinterpret_cast<const uint4*>(buf + line * 64); v = 0; for (int k = 0; k < 4; ++k) { uint4 t = b4[k]; v += (uint64_t)t.x + t.y + t.z + t.w; } }
             if (MODE == 7) { const uint4* b4 = reinterpret_cast<const uint4*>(buf + (st[c] % (nlines * 2)) * 32); uint4 t = b4[0], u = b4[1]; v = (uint64_t)t.x + t.y + t.z + t.w + u.x + u.y + u.z + u.w; }
+            if (MODE == 8) { const uint8_t* L = buf + (st[c] % (nlines / 2)) * 128; uint4 t = *reinterpret_cast<const uint4*>(L), u = *reinterpret_cast<const uint4*>(L + 16); uint2 w = *reinterpret_cast<const uint2*>(L + 32);
+                             const uint32_t* g = reinterpret_cast<const uint32_t*>(L + 40 + 12 * ((st[c] >> 58) % 7)); v = (uint64_t)t.x + t.y + t.z + t.w + u.x + u.y + u.z + u.w + w.x + w.y + g[0] + g[1] + g[2]; }
+            if (MODE == 9) { const uint8_t* L = buf + (st[c] % (nlines / 2)) * 128; v = reinterpret_cast<const uint32_t*>(L)[(st[c] >> 58) & 15]; const uint4* b4 = reinterpret_cast<const uint4*>(L + 64); for (int k = 0; k < 4; ++k) { uint4 t = b4[k]; v += (uint64_t)t.x + t.y + t.z + t.w; } }
             if (MODE == 5) { v = *reinterpret_cast<const uint64_t*>(buf + line * 64 + ((st[c] >> 60) & 7) * 8); }
             if (MODE == 6) {   // lanes 4j..4j+3 fetch the four 16-B pieces of the lines of lanes 4j..4j+3 in turn
                 v = 0;
@@ -76,7 +81,7 @@ int main(int argc, char** argv) {
     bool quick = argc > 2;
     for (int blocks : {2048}) {
         run<0, 1>(buf, nlines, steps, out, blocks);
-        if (quick) { run<7, 1>(buf, nlines, steps, out, blocks); continue; }
+        if (quick) { run<7, 1>(buf, nlines, steps, out, blocks); run<8, 1>(buf, nlines, steps, out, blocks); run<9, 1>(buf, nlines, steps, out, blocks); run<4, 1>(buf, nlines, steps, out, blocks); continue; }
         run<1, 1>(buf, nlines, steps, out, blocks);
         run<2, 1>(buf, nlines, steps, out, blocks);
         run<3, 2>(buf, nlines, steps, out, blocks);
