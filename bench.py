@@ -22,8 +22,9 @@ At N = 1 the default run measures, one after the other in this process, for each
                       (table bytes it counted + query bytes + result bytes) / kernel time / 8 TB/s, and the same at one 128-byte line per access
     k2 / plain        search_ng26<Hamming>, h2(4,0,2), on the two occurrence tables alone (6.2 GB); visited nodes x 112 B
     k2 / tables       the same with LF, prefix and walk tables
-plus configs[3]'s single-GPU share (k = 2, 12.5 M x 151 bp) and configs[4] (protein, sigma = 28, FMIndex<28, Wavelet>, 10 M x 40 aa: the
-multi-ary wavelet tree itself at 170 B per LF step, and its block-table expansion with tables).
+plus configs[3]'s single-GPU share (k = 2, 12.5 M x 151 bp) and configs[4] (protein, sigma = 28, FMIndex<28, Wavelet>, 10 M x 40 aa: `.../exact/wavelet` = k_exact_s
+on the one-line-per-step table the library keeps beside the tree, 88 B per LF step; `.../exact/tree` = k_exact_m on the multi-ary wavelet tree itself at SURVEY 8d's
+170 B per LF step; and its block-table expansion with tables).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the index is replicated (every rank builds the same seeded text), the query batch is
 sharded, the only exchange is the RCCL gather of the results to rank 0 inside the timed region (double-buffered: the gather of step i crosses xGMI
@@ -52,6 +53,7 @@ BLOCK_BYTES_IB16_S5 = 56       # sizeof(InterleavedBitvector16<5>::Block), SURVE
 BYTES_PER_STEP_DNA = 2 * BLOCK_BYTES_IB16_S5          # both interval ends
 BYTES_PER_STEP_PAIRS = 68                             # Format P: 2 ends x (4-byte count + 64 bytes of planes) per two-symbol step = 68 B per symbol
 BYTES_PER_STEP_WAVELET28 = 2 * 5 * 17                 # 2 ends x 5 levels x (8 + 1 + 8) B
+BYTES_PER_STEP_FLAT28 = 2 * 44                        # Format S: 2 ends x (five 8-byte planes + a 3-byte count, 44 B counted) of one line per LF step
 PROTEIN_SEQS, PROTEIN_SEQ_LEN = 4_000_000, 500        # UniRef50 stand-in (the release itself is not available offline): 2.0e9 residues
 PROTEIN_SEQS_WIDE = 9_000_000                         # ... and 4.5e9 residues: more than 2^32 rows, the 64-bit-row build of the kernels (UniRef50 itself is ~1e10)
 
@@ -753,7 +755,7 @@ def _scheme_struct(capi, scheme):
 def run_protein(c, nseq, tag):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
-    ids = [tag + "/exact/wavelet", tag + "/exact/tables"]
+    ids = [tag + "/exact/wavelet", tag + "/exact/tables", tag + "/exact/tree"]
     if c.only and not any(i in c.only for i in ids):
         return []
     sigma, L, nq = 28, 40, args.nq
@@ -792,10 +794,20 @@ def run_protein(c, nseq, tag):
                         "index_build_s": round(b_s, 2), "tables": tables},
              "gres_per_s": qps * L / 1e9, "hits": int((out_t[nq:] > 0).sum().item())}
         if kind == "wavelet":
-            r["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_WAVELET28, k_ms, kernel, "LF steps")
             st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
-            r["roofline"]["loaded"] = {"bytes_per_launch": st["table_bytes"], "accesses_per_launch": st["table_accesses"],
-                                       "what": "bytes / blocks the kernel actually read from the two-level multi-ary tree (counted in the kernel)"}
+            if kernel == "k_exact_s":
+                r["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_FLAT28, k_ms, kernel, "LF steps")
+                r["roofline"]["accounting"] = ("k_exact_s reads Format S beside the tree (one 128-byte line per 64 rows: 5 symbol planes + sigma 24-bit counts): algorithmic bytes in SURVEY 8d's form = "
+                                               "2 interval ends x 44 B read of a line (40 B of planes + the symbol's count) per executed LF step, / kernel time (HIP events on the launch stream).  "
+                                               "SURVEY 8d's own figure, 170 useful bytes per LF step of the reference's binary wavelet tree, is applied to the search on the tree itself: record "
+                                               + tag + "/exact/tree (k_exact_m, same index, same reads, same run)")
+                r["roofline"]["loaded"] = {"bytes_per_launch": st["table_bytes"], "lines_per_launch": st["table_accesses"],
+                                           "line_granular_frac": st["table_accesses"] * 128.0 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "what": "lines the kernel fetched (an interval end whose line is the other end's is one), counted in the kernel; every line priced at its 128 bytes"}
+            else:
+                r["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_WAVELET28, k_ms, kernel, "LF steps")
+                r["roofline"]["loaded"] = {"bytes_per_launch": st["table_bytes"], "accesses_per_launch": st["table_accesses"],
+                                           "what": "bytes / blocks the kernel actually read from the two-level multi-ary tree (counted in the kernel)"}
         else:
             st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
             r["roofline"] = roofline_loaded(st, nq * (L + 8 + 16), k_ms, kernel, units, "LF steps")
@@ -803,9 +815,29 @@ def run_protein(c, nseq, tag):
         return r
 
     out = []
+    flat = os.environ.get("FMGPU_FLAT", "1") != "0" and not (int(os.environ.get("FMGPU_DEV_FLAGS", "0")) & (1 << 21))
+    flat_ms = None
     if wanted(c, ids[0]):
         elapsed, log = timed(c, step)
-        out.append(rec_of(ids[0], "wavelet", "k_exact_m", elapsed, log, build_s, None))
+        out.append(rec_of(ids[0], "wavelet", "k_exact_s" if flat else "k_exact_m", elapsed, log, build_s, None))
+        flat_ms = out[-1]["roofline"]["kernel_ms"]
+    if flat and wanted(c, ids[2]):                                # the same index and reads on the tree itself: SURVEY 8d's accounting as written
+        if not wanted(c, ids[0]):
+            step([]); torch.cuda.synchronize()
+        keep = out_t.clone()
+        os.environ["FMGPU_DEV_FLAGS"] = str(1 << 21)
+        try:
+            elapsed, log = timed(c, step)
+        finally:
+            os.environ.pop("FMGPU_DEV_FLAGS", None)
+        r1 = rec_of(ids[2], "wavelet", "k_exact_m", elapsed, log, build_s, None)
+        r1["equal_to_the_line_kernel"] = bool(torch.equal(keep, out_t))
+        if not r1["equal_to_the_line_kernel"]:
+            raise SystemExit("bench.py: k_exact_m and k_exact_s disagree")
+        if flat_ms:
+            r1["roofline"]["line_kernel_speedup"] = r1["roofline"]["kernel_ms"] / flat_ms
+        out.append(r1)
+        del keep
     if len(ids) > 1 and wanted(c, ids[1]):
         t0 = time.time()
         wide = index.row_bits == 64                            # 64-bit rows: 16-byte entries — the 6-symbol walk alone (72 GB at 4.5e9 rows), no 12-symbol one

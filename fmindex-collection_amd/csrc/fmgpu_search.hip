@@ -180,30 +180,45 @@ __global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t*
 // by the random line fills it causes (tools/membench.hip: 52-55 G dependent lines/s, whatever is read of a line), so halving the lines of a read halves
 // its time.  A pair whose interval comes out empty is taken again in one-symbol steps (Format A), which yields the row and the step count a
 // one-symbol search ends with; so is a pair that holds a delimiter or a byte outside the alphabet, and the last symbol of a read of odd length.
-constexpr uint32_t kPairFilterBits = 32768;
-constexpr uint32_t kExactPairLds = 0;               // unused dynamic LDS that would limit k_exact_p's residency: none (resident blocks per CU 8 / 7 / 6 / 5 / 4: see DESIGN)
-struct PairLine { uint32_t cnt; uint4 w[4]; };       // the pair's count + rows 0..63: planes 0,1 | 2,3; rows 64..127: planes 0,1 | 2,3
-__device__ __forceinline__ PairLine load_pair_line(const uint8_t* __restrict__ pairs, uint32_t i, uint32_t pc) {
-    const uint8_t* L = pairs + (size_t)(i >> 7) * 128u;
-    PairLine r;
-    r.cnt = reinterpret_cast<const uint32_t*>(L)[pc];
-    const uint4* P = reinterpret_cast<const uint4*>(L + 64);
-    r.w[0] = P[0]; r.w[1] = P[1]; r.w[2] = P[2]; r.w[3] = P[3];
-    return r;
+constexpr uint32_t kPairFilterBits = 32768;          // line number mod this: the ~50 listed rows of a genome mark 0.15 % of the lines
+// ---- lines fetched by the eight lanes of an octet together (k_exact_p, k_exact_s).  A lane that reads 44-68 bytes of its own random line with four or five load
+// instructions pays as many address translations and passes through the texture path per line, and that — not the line fills — bounds such a kernel
+// (tools/membench.hip modes 8 / 9 / 4: 33 / 47 / 44 G lines/s on a 3.1 GB table, 24 / 22 / 25 on a 4.2 GB one, where one load per line keeps 51).  Here
+// instruction k of a round has the eight lanes of every octet load the eight 16-byte pieces of the line of the octet's lane k — one coalesced 128-byte
+// request and one translation per line — straight into LDS (LDS-DMA: piece j of lane 8o + k's line lands at region k, offset 128 o + 16 j), from where the
+// owner reads what it needs.  The loops are wave-uniform (reads that are over ride along with a dummy line); waves do not synchronise with each other.
+constexpr uint32_t kCoopRegion = 1024u + 16u;        // bytes per region (64 pieces + padding that spreads the owners' reads over the LDS banks)
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+typedef uint32_t __attribute__((ext_vector_type(4))) flat_u32x4;
+__device__ __forceinline__ void coop_round(const uint8_t* __restrict__ flat, uint32_t line, uint32_t lane, lds_word* wave_lds) {
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t l = __shfl(line, (int)((lane & ~7u) | k), 64);
+        const uint8_t* g = flat + (size_t)l * 128u + (lane & 7u) * 16u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(wave_lds + k * (kCoopRegion / 4u)), 16, 0, 0);
+    }
 }
-__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
-// rows of the pair before row i (inv[k] = ~0 where the pair code has bit k clear)
-__device__ __forceinline__ uint32_t pair_rows_before(const PairLine& l, uint32_t i, const uint64_t* inv) {
+// rows of the pair before row i in the owner's line (now in LDS) + the pair's count
+__device__ __forceinline__ uint32_t pair_rank_lds(const lds_word* own, uint32_t i, uint32_t pc) {
+    const uint32_t cnt = own[pc];
+    const flat_u32x4 w0 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 16), w1 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 20);
+    const flat_u32x4 w2 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 24), w3 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 28);
+    const uint32_t i0 = (pc & 1u) ? 0u : ~0u, i1 = (pc & 2u) ? 0u : ~0u, i2 = (pc & 4u) ? 0u : ~0u, i3 = (pc & 8u) ? 0u : ~0u;
     const uint32_t off = i & 127u;
-    const uint64_t m0 = off >= 64u ? ~0ull : lowmask(off), m1 = off > 64u ? lowmask(off - 64u) : 0ull;
-    const uint64_t h0 = (u64_of(l.w[0].x, l.w[0].y) ^ inv[0]) & (u64_of(l.w[0].z, l.w[0].w) ^ inv[1]) & (u64_of(l.w[1].x, l.w[1].y) ^ inv[2]) & (u64_of(l.w[1].z, l.w[1].w) ^ inv[3]);
-    const uint64_t h1 = (u64_of(l.w[2].x, l.w[2].y) ^ inv[0]) & (u64_of(l.w[2].z, l.w[2].w) ^ inv[1]) & (u64_of(l.w[3].x, l.w[3].y) ^ inv[2]) & (u64_of(l.w[3].z, l.w[3].w) ^ inv[3]);
-    return popc64(h0 & m0) + popc64(h1 & m1);
+    const uint32_t m0 = off >= 32u ? ~0u : (1u << off) - 1u;
+    const uint32_t m1 = off >= 64u ? ~0u : (off > 32u ? (1u << (off - 32u)) - 1u : 0u);
+    const uint32_t m2 = off >= 96u ? ~0u : (off > 64u ? (1u << (off - 64u)) - 1u : 0u);
+    const uint32_t m3 = off > 96u ? (1u << (off - 96u)) - 1u : 0u;
+    // rows 0..63: w0 = planes 0, 1 (lo, hi words each), w1 = planes 2, 3; rows 64..127: w2, w3
+    const uint32_t h0 = (w0.x ^ i0) & (w0.z ^ i1) & (w1.x ^ i2) & (w1.z ^ i3), h1 = (w0.y ^ i0) & (w0.w ^ i1) & (w1.y ^ i2) & (w1.w ^ i3);
+    const uint32_t h2 = (w2.x ^ i0) & (w2.z ^ i1) & (w3.x ^ i2) & (w3.z ^ i3), h3 = (w2.y ^ i0) & (w2.w ^ i1) & (w3.y ^ i2) & (w3.w ^ i3);
+    return cnt + __popc(h0 & m0) + __popc(h1 & m1) + __popc(h2 & m2) + __popc(h3 & m3);
 }
 __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __restrict__ pairs, const uint32_t* __restrict__ ex, uint32_t nex,
                                                  const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                  unsigned long long* __restrict__ steps_total) {
+    extern __shared__ uint32_t s_coop[];                            // 4 waves x 8 regions
     __shared__ uint32_t s_filt[kPairFilterBits / 32u];
     __shared__ uint32_t s_ex[512];
     for (uint32_t t = threadIdx.x; t < kPairFilterBits / 32u; t += 256u) s_filt[t] = 0u;
@@ -223,61 +238,83 @@ __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __r
         for (uint32_t t = 0; t < 512u && s_ex[t] < i; ++t) if (s_ex[t] >= first) ++c;
         return c;
     };
-    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0, acc = 0, acc2 = 0;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    lds_word* const wave_lds = (lds_word*)(s_coop + wave * 8u * (kCoopRegion / 4u));
+    const lds_word* const own = wave_lds + (lane & 7u) * (kCoopRegion / 4u) + (lane >> 3) * 32u;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t steps = 0, acc = 0, acc2 = 0, m = 0;
+    idx_t lb = 0, len = n;
+    QueryReader qr;
     if (q < nq) {
-        uint64_t o = qoff[q];
-        uint32_t m = (uint32_t)(qoff[q + 1] - o);
-        idx_t lb = 0, len = n;
-        if (m) {
-            QueryReader qr; qr.init(qbuf, o, m);
-            // one symbol, as k_exact_a does it; false once the search is over
-            auto single = [&](uint32_t c) -> bool {
-                ++steps;
-                if (c >= 5u) { lb = 0; len = 0; return false; }
-                const idx_t a = lb, b = lb + len;
-                idx_t ra, rb;
-                if (c == 0 && occ.v.fused) { lf0_pair(occ, a, b, ra, rb); acc += 2; }
-                else {
-                    EntryA ea = load_entry_a(occ.v, a, c);
-                    EntryA eb = ea;
-                    ++acc;
-                    if ((a >> 6) != (b >> 6)) { eb = load_entry_a(occ.v, b, c); ++acc; }
-                    ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
-                    rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
-                }
-                lb = ra; len = rb - ra;
-                return len != 0;
-            };
-            uint32_t i = 0;
-            bool over = false;
-            while (i + 2u <= m) {
-                const uint32_t y = qr.next(), x = qr.next();
-                i += 2u;
-                bool stepped = false;
-                if (y - 1u < 4u && x - 1u < 4u) {
-                    const uint32_t pc = (x - 1u) * 4u + (y - 1u);
-                    const uint32_t a = (uint32_t)lb, b = (uint32_t)(lb + len);
-                    const bool far = (a >> 7) != (b >> 7);
-                    // (both ends' lines in flight together where they are two — one step in seven: taking them one after the other, which fits 8 instead of
-                    //  5 waves per SIMD, cost 10.8 -> 13.1 ms)
-                    const PairLine la = load_pair_line(pairs, a, pc);
-                    PairLine lbl;
-                    if (far) lbl = load_pair_line(pairs, b, pc);
-                    acc2 += far ? 2u : 1u;
-                    uint64_t inv[4];
-                    for (int k = 0; k < 4; ++k) inv[k] = ((pc >> k) & 1u) ? 0ull : ~0ull;
-                    uint32_t ra = la.cnt + pair_rows_before(la, a, inv);
-                    uint32_t rb = far ? lbl.cnt + pair_rows_before(lbl, b, inv) : la.cnt + pair_rows_before(la, b, inv);
-                    if (pc == 0u) { ra -= listed_before(a); rb -= listed_before(b); }
-                    if (rb > ra) { lb = ra; len = rb - ra; steps += 2u; stepped = true; }
-                }
-                if (!stepped && !(single(y) && single(x))) { over = true; break; }
-            }
-            if (!over && i < m) single(qr.next());
-        }
-        store_interval(out_lb, out_len, q, lb, len);
+        const uint64_t o = qoff[q];
+        m = (uint32_t)(qoff[q + 1] - o);
+        if (m) qr.init(qbuf, o, m);
     }
+    // one symbol, as k_exact_a does it; false once the search is over
+    auto single = [&](uint32_t c) -> bool {
+        ++steps;
+        if (c >= 5u) { lb = 0; len = 0; return false; }
+        const idx_t a = lb, b = lb + len;
+        idx_t ra, rb;
+        if (c == 0 && occ.v.fused) { lf0_pair(occ, a, b, ra, rb); acc += 2; }
+        else {
+            EntryA ea = load_entry_a(occ.v, a, c);
+            EntryA eb = ea;
+            ++acc;
+            if ((a >> 6) != (b >> 6)) { eb = load_entry_a(occ.v, b, c); ++acc; }
+            ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
+            rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
+        }
+        lb = ra; len = rb - ra;
+        return len != 0;
+    };
+    bool alive = m != 0;
+    uint32_t mmax = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, (uint32_t)__shfl_xor(mmax, off, 64));
+    for (uint32_t i = 0; i < mmax; i += 2u) {                       // every lane of the wave stands at symbol i of its read (or is done)
+        if (i >= m) alive = false;
+        if (!__ballot(alive)) break;
+        const bool two = alive && i + 2u <= m;
+        uint32_t y = 0, x = 0;
+        if (alive) { y = qr.next(); if (two) x = qr.next(); }
+        const bool pairable = two && y - 1u < 4u && x - 1u < 4u;
+        bool stepped = false;
+        if (__ballot(pairable)) {
+            const uint32_t pc = pairable ? (x - 1u) * 4u + (y - 1u) : 0u;
+            const uint32_t a = (uint32_t)lb, b = (uint32_t)(lb + len);
+            const uint32_t la = pairable ? a >> 7 : 0u, lbn = pairable ? b >> 7 : 0u;
+            const bool far = pairable && la != lbn;
+            coop_round(pairs, la, lane, wave_lds);
+            __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0): the round's pieces are in LDS
+            asm volatile("" ::: "memory");
+            uint32_t ra = 0, rb = 0;
+            if (pairable) {
+                acc2 += far ? 2u : 1u;
+                ra = pair_rank_lds(own, a, pc);
+                if (!far) rb = pair_rank_lds(own, b, pc);
+            }
+            if (__ballot(far)) {                                    // the other end's lines, where they are other lines (the first ~14 symbols of a read)
+                __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): every lane has read what it needs of the first round
+                asm volatile("" ::: "memory");
+                coop_round(pairs, far ? lbn : 0u, lane, wave_lds);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                asm volatile("" ::: "memory");
+                if (far) rb = pair_rank_lds(own, b, pc);
+            }
+            if (pairable) {
+                if (pc == 0u) { ra -= listed_before(a); rb -= listed_before(b); }
+                if (rb > ra) { lb = ra; len = rb - ra; steps += 2u; stepped = true; }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                     // the next round overwrites the regions
+            asm volatile("" ::: "memory");
+        }
+        if (alive && !stepped) {                                    // rare: a pair that came out empty or cannot be a pair, the last symbol of an odd read
+            alive = single(y);
+            if (alive && two) alive = single(x);
+        }
+    }
+    if (q < nq) store_interval(out_lb, out_len, q, lb, len);
     add_counters(steps_total, steps, 12u * acc + 68u * acc2, acc + acc2);
 }
 
@@ -289,17 +326,6 @@ __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __r
 // every octet load the eight 16-byte pieces of the line of the octet's lane k — one coalesced 128-byte request and one translation per line — straight into
 // LDS (LDS-DMA: piece j of lane 8o + k's line lands at region k, offset 128 o + 16 j), from where the owner reads its planes and count.  The loop is
 // wave-uniform (reads that are over ride along with a dummy line); waves do not synchronise with each other.
-constexpr uint32_t kFlatRegion = 1024u + 16u;        // bytes per region (64 pieces + padding that spreads the owners' reads over the LDS banks)
-typedef __attribute__((address_space(3))) uint32_t lds_word;
-typedef uint32_t __attribute__((ext_vector_type(4))) flat_u32x4;
-__device__ __forceinline__ void flat_round(const uint8_t* __restrict__ flat, uint32_t line, uint32_t lane, lds_word* wave_lds) {
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; ++k) {
-        const uint32_t l = __shfl(line, (int)((lane & ~7u) | k), 64);
-        const uint8_t* g = flat + (size_t)l * 128u + (lane & 7u) * 16u;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(wave_lds + k * (kFlatRegion / 4u)), 16, 0, 0);
-    }
-}
 // rows before row i that hold symbol c in the owner's line (now in LDS) + the line's count of c
 __device__ __forceinline__ uint32_t flat_rank_lds(const lds_word* own, uint32_t i, uint32_t c) {
     const flat_u32x4 p01 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own);
@@ -320,13 +346,13 @@ __global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ fla
                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                  unsigned long long* __restrict__ steps_total, uint32_t super_lds) {
     extern __shared__ uint32_t s_flat[];                            // 4 waves x 8 regions | the super table, when it is small (super_lds entries)
-    idx_t* const s_super = reinterpret_cast<idx_t*>(s_flat + 4u * 8u * (kFlatRegion / 4u));
+    idx_t* const s_super = reinterpret_cast<idx_t*>(s_flat + 4u * 8u * (kCoopRegion / 4u));
     for (uint32_t t = threadIdx.x; t < super_lds; t += 256u) s_super[t] = super[t];
     __syncthreads();
     const idx_t* sup = super_lds ? s_super : super;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    lds_word* const wave_lds = (lds_word*)(s_flat + wave * 8u * (kFlatRegion / 4u));
-    const lds_word* const own = wave_lds + (lane & 7u) * (kFlatRegion / 4u) + (lane >> 3) * 32u;
+    lds_word* const wave_lds = (lds_word*)(s_flat + wave * 8u * (kCoopRegion / 4u));
+    const lds_word* const own = wave_lds + (lane & 7u) * (kCoopRegion / 4u) + (lane >> 3) * 32u;
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t steps = 0, acc = 0, m = 0;
     idx_t lb = 0, len = n;
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ fla
         const idx_t a = lb, b = lb + len;
         const uint32_t la = alive ? (uint32_t)(a >> 6) : 0u, lbn = alive ? (uint32_t)(b >> 6) : 0u;
         const bool far = alive && la != lbn;
-        flat_round(flat, la, lane, wave_lds);
+        coop_round(flat, la, lane, wave_lds);
         idx_t sa = 0, sb = 0;
         if (alive) {
             sa = sup[(size_t)(a >> 24) * sigma + c];
@@ -370,7 +396,7 @@ __global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ fla
         if (__ballot(far)) {                                        // the other end's lines, where they are other lines (the first log_sigma(n) steps of a read)
             __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): every lane has read what it needs of the first round
             asm volatile("" ::: "memory");
-            flat_round(flat, far ? lbn : 0u, lane, wave_lds);
+            coop_round(flat, far ? lbn : 0u, lane, wave_lds);
             __builtin_amdgcn_s_waitcnt(0x0f70);
             asm volatile("" ::: "memory");
             if (far) rb = sb + flat_rank_lds(own, (uint32_t)b, c);
@@ -3554,8 +3580,7 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         const size_t lds_a = dev_env("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)28 * 1024;
         if constexpr (!kWide) {
             if (x->bwt.sigma == 5 && x->bwt.pairs && !(dev_flags_env() & (1 << 22))) {
-                const size_t lds_p = dev_env("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)kExactPairLds;
-                k_exact_p<<<grid, block, lds_p, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, qb, qo, nq, n, ol, on, dsteps);
+                k_exact_p<<<grid, block, 4 * 8 * kCoopRegion + dev_extra_lds, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, qb, qo, nq, n, ol, on, dsteps);
             } else if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
             else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         } else
@@ -3564,7 +3589,7 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
     } else if (x->bwt.search_family() == FAM_WAVELET && x->bwt.flat && !(dev_flags_env() & (1 << 21))) {
         const size_t super_bytes = (size_t)x->bwt.flat_nsb * x->bwt.sigma * sizeof(idx_t);
         const uint32_t super_lds = super_bytes <= 16 * 1024 ? x->bwt.flat_nsb * (uint32_t)x->bwt.sigma : 0u;      // (2 x 10^9 rows, sigma = 28: 13 KB)
-        k_exact_s<<<grid, block, 4 * 8 * kFlatRegion + (super_lds ? super_bytes : 0) + dev_extra_lds, stream>>>(x->bwt.flat, x->bwt.flat_super, (uint32_t)x->bwt.sigma, (const uint8_t*)sbuf.dev,
+        k_exact_s<<<grid, block, 4 * 8 * kCoopRegion + (super_lds ? super_bytes : 0) + dev_extra_lds, stream>>>(x->bwt.flat, x->bwt.flat_super, (uint32_t)x->bwt.sigma, (const uint8_t*)sbuf.dev,
                                                            (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps, super_lds);
     } else if (x->bwt.search_family() == FAM_WAVELET) {
         uint32_t mx = shape_max, mn = 0;
