@@ -73,7 +73,7 @@ def test_bench_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and "cpu_baseline" not in out
     assert out["config"]["workload"] == "grch38_exact" and out["config"]["queries_per_gpu"] == 200000
-    assert out["config"]["index_kind"] == "plain" and out["roofline"]["kernel"] == "k_exact_a"      # the headline: the plain index, at every N
+    assert out["config"]["index_kind"] == "plain" and out["roofline"]["kernel"] == "k_exact_p"      # the headline: the plain index, at every N
     assert out["exchange"]["verified_on_rank0"] is True and out["exchange"]["bytes_per_rank_and_step"] > 0   # rank 0 received what both ranks sent
     assert out["exchange"]["world_size_seen"] == 2
     assert 0 < out["roofline"]["frac"] <= 1.0
