@@ -545,7 +545,7 @@ def run_dna_text(c, name, primary):
                               "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
                    "lf_steps_per_row": units / nr, "located_positions_hold_their_reads": same}
             if index_kind == "plain":
-                rec["roofline"] = roofline_sec8d(units + nr, BLOCK_BYTES_IB16_S5 + 64, k_ms, "k_locate", "locate steps (LF steps + the final probe; one block + one presence-bit line each)")
+                rec["roofline"] = roofline_sec8d(units + nr, BLOCK_BYTES_IB16_S5 + 64, k_ms, "k_locate_fused" if os.environ.get("FMGPU_FUSED_LOCATE", "1") != "0" else "k_locate", "locate steps (LF steps + the final probe; one block + one presence-bit line each)")
             else:
                 rec["roofline"] = roofline_loaded({"table_bytes": 12.0 * nr, "table_accesses": float(nr)}, nr * 32, k_ms, "k_locate_tab", units, "LF steps of locate")
             return rec
@@ -673,7 +673,8 @@ def run_dna_text(c, name, primary):
             elapsed, log = timed(c, step, xch.drain if xch else None)
             k_ms = mean([x["kernel_ms"] for x in log]); units = mean([x["units"] for x in log]); nh = mean([x["hits"] for x in log])
             qps = c.world * n_ * args.steps / elapsed
-            kernel = "k_scheme_fast_edit" if edit else "k_scheme_fast"
+            lean_off = int(os.environ.get("FMGPU_DEV_FLAGS", "0")) & (1 << 30)
+            kernel = "k_scheme_fast_edit" if edit else ("k_scheme_lean" if index_kind == "plain" and not lean_off else "k_scheme_fast")
             part = [L // 4 + (1 if p < L % 4 else 0) for p in range(4)]
             rec = {"id": rid, "metric": "queries/sec (GRCh38-sized index, %s x %dbp, k=2 %s, h2(4,0,2))" % ("10M" if w == "k2" and not edit else ("%.1fM per GPU" % (n_ / 1e6)), L, "edit distance" if edit else "Hamming"),
                    "value": qps, "unit": "queries/s", "n_gpus": c.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
