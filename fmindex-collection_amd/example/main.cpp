@@ -8,7 +8,7 @@
 //     (a cereal archive, not read or written here); --partialBuildUp, --threads and --ext are accepted and have nothing to switch;
 //   * --algo: `ng21` (all four modes, main.cpp:176-185), `noerror` (:213-215), and `ng26` (search_ng26::search, Edit = true, over the
 //     un-expanded scheme with a uniform partition) are available; the other research variants are not part of this build;
-//   * --gen: backtracking, pigeon, pigeon_opt, h2-k1, h2-k2, h2-k3 (generator/all.h:35-96); `_dyn` (expandByWNC) is not available;
+//   * --gen: backtracking, pigeon, pigeon_opt, h2-k1, h2-k2, h2-k3 (generator/all.h:35-96); `<name>_dyn` stretches the scheme to the read length by expandByWNC (Edit = true, sigma 4, 3e9 rows: main.cpp:116) instead of uniformly;
 //   * locating is one batched call over all rows of all cursors (the rows and their order are the reference's).
 #include "../../include/fmc_gpu.hpp"
 
@@ -225,6 +225,12 @@ struct Run {
     Options const& config;
     Index index;
 
+    // a scheme stretched to the read length: uniformly, or (--gen <name>_dyn) part by part where the weighted node count grows least — with the constants
+    // the reference's example passes (src/example/main.cpp:116, :135: Edit = true, sigma 4, 3e9 rows)
+    fmc::search_scheme::Scheme stretch(fmc::search_scheme::Scheme const& scheme, size_t len) const {
+        return config.schemeDyn ? fmc::search_scheme::expandByWNC<true>(scheme, len, 4, 3'000'000'000) : fmc::search_scheme::expand(scheme, len);
+    }
+
     std::vector<Hit> search(Algorithm kind, size_t k, std::vector<std::vector<uint8_t>> const& reads) const {
         std::vector<Hit> hits;
         auto collect = [&](size_t read, auto const& cursor, size_t errors) { hits.push_back({read, cursor.lb, cursor.len, errors}); };
@@ -248,11 +254,11 @@ struct Run {
         case Algorithm::ng21: {
             size_t const len = reads[0].size();
             if (config.hitMode == HitMode::all) {
-                auto const expanded = fmc::search_scheme::expand(schemeByName(config.schemeName, 0, k), len);
+                auto const expanded = stretch(schemeByName(config.schemeName, 0, k), len);
                 if (config.hitsPerRead == 0) fmc::search_ng21::search(index, reads, expanded, collect);
                 else fmc::search_ng21::search_n(index, reads, expanded, config.hitsPerRead, collect);
             } else {
-                auto const ladder = schemesUpTo([&](size_t j) { return fmc::search_scheme::expand(schemeByName(config.schemeName, j, j), len); });
+                auto const ladder = schemesUpTo([&](size_t j) { return stretch(schemeByName(config.schemeName, j, j), len); });
                 if (config.hitsPerRead == 0) fmc::search_ng21::search_best(index, reads, ladder, collect);
                 else fmc::search_ng21::search_best_n(index, reads, ladder, config.hitsPerRead, collect);
             }
@@ -323,7 +329,6 @@ int main(int argc, char const* const* argv) try {
                     "          --maxhitperquery <int> (some int, 0 = infinite hits)\n");
         return 0;
     }
-    if (config.schemeDyn) throw std::runtime_error("the _dyn generators (expandByWNC) are not part of this build");
     auto reads = readFasta(config.readsFasta, Sigma, config.unknownToA);
     if (config.withReverseComplement) reads = withReverseComplements(reads);
     if (!reads.empty()) {

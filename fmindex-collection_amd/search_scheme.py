@@ -144,12 +144,20 @@ def isValid(scheme):
 
 def expand(scheme, newLen):
     """expand.h:146-165: stretch every search to newLen parts (uniformly), drop searches that become invalid"""
-    pi, l, u = (np.asarray(x, dtype=np.int64) for x in scheme)
-    S, P = pi.shape
+    P = np.asarray(scheme[0]).shape[1]
     counts = [int(c) for c in createUniformPartition(P, newLen)] if newLen >= P else None
     if counts is None:
         base, rest = divmod(newLen, P)
         counts = [base + (1 if i < rest else 0) for i in range(P)]
+    return expandByCounts(scheme, counts)
+
+
+def expandByCounts(scheme, counts):
+    """expand.h:167-189: part p of every search becomes counts[p] parts, searches that become invalid are dropped"""
+    pi, l, u = (np.asarray(x, dtype=np.int64) for x in scheme)
+    S, P = pi.shape
+    counts = [int(c) for c in counts]
+    newLen = sum(counts)
     starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
     rows = []
     for s in range(S):
@@ -237,3 +245,58 @@ def nodeCount(scheme, sigma, edit=False):
             last = cur
         total += float(acc)
     return total
+
+
+def weightedNodeCount(scheme, sigma, N, edit=False):
+    """weightedNodeCount.h:21-69: nodes a search visits when a node of depth n survives with probability min(1, N / sigma^n) — the reference's
+    arithmetic: the weight in double, the sums in long double (80 bits on x86-64, numpy.longdouble)"""
+    pi, l, u = (np.asarray(x, dtype=np.int64) for x in scheme)
+    total = np.longdouble(0)
+    for L, U in zip(l, u):
+        e = int(U.max())
+        last = [np.longdouble(0)] * (e + 1)
+        last[0] = np.longdouble(1)
+        acc = np.longdouble(0)
+        for n in range(1, len(L) + 1):
+            with np.errstate(over="ignore"):
+                f = float(np.float64(N) / np.power(np.float64(sigma), np.float64(n)))      # (std::pow in double: inf for a deep trie, f = 0)
+            if f > 1:
+                f = 1.0
+            cur = [np.longdouble(0)] * (e + 1)
+            for i in range(e + 1):
+                if L[n - 1] <= i <= U[n - 1]:
+                    v = last[i]
+                    if i > 0:
+                        v = v + ((sigma - 1) * last[i - 1] + sigma * last[i - 1] + last[i - 1] if edit else (sigma - 1) * last[i - 1])
+                    v = v * f
+                    cur[i] = v
+                    acc = acc + v
+            last = cur
+        total = total + acc
+    return total
+
+
+def optimizeByWNC(scheme, newLen, sigma, N, edit=False):
+    """expand.h:218-241: grow the parts one position at a time, each time where the weighted node count of the expanded scheme is smallest
+    (the running best is kept in a double, as there)"""
+    P = np.asarray(scheme[0]).shape[1]
+    if np.asarray(scheme[0]).shape[0] == 0:
+        return []
+    counts = [1] * P
+    for _ in range(newLen - P):
+        best, bestPos = float(np.finfo(np.float64).max), 0
+        for j in range(P):
+            counts[j] += 1
+            f = weightedNodeCount(expandByCounts(scheme, counts), sigma, N, edit)
+            counts[j] -= 1
+            if f < np.longdouble(best):
+                best, bestPos = float(f), j
+        counts[bestPos] += 1
+    return counts
+
+
+def expandByWNC(scheme, newLen, sigma, N, edit=False):
+    """expand.h:243-247 — what the example's `--gen <name>_dyn` uses (src/example/main.cpp:116, :135: Edit = true, sigma = 4, N = 3e9)"""
+    if np.asarray(scheme[0]).shape[0] == 0:
+        return scheme
+    return expandByCounts(scheme, optimizeByWNC(scheme, newLen, sigma, N, edit))

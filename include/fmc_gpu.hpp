@@ -16,6 +16,7 @@
 #include "fmgpu.h"
 
 #include <algorithm>
+#include <cmath>
 #include <array>
 #include <cstddef>
 #include <cstdint>
@@ -270,11 +271,13 @@ inline auto createUniformPartition(Scheme const& ss, size_t totalSum) -> std::ve
     return createUniformPartition(ss[0].pi.size(), totalSum);
 }
 
-inline auto expand(Search const& s, size_t newLen) -> std::optional<Search> {   // expand.h:146-155
-    size_t P = s.pi.size();
-    std::vector<size_t> counts(P, newLen / P), starts(P, 0);
-    for (size_t i = 0; i < newLen % P; ++i) counts[i] += 1;
+// part p of the search becomes counts[p] parts (expand.h:167-177)
+inline auto expand(Search const& s, std::vector<size_t> const& counts) -> std::optional<Search> {
+    size_t P = s.pi.size(), newLen = 0;
+    if (counts.size() != P) throw std::invalid_argument("expand: one count per part");
+    std::vector<size_t> starts(P, 0);
     for (size_t i = 1; i < P; ++i) starts[i] = starts[i - 1] + counts[i - 1];
+    for (size_t c : counts) newLen += c;
     Search r;
     for (size_t i = 0; i < P; ++i) {
         bool forward = i == 0 ? (P == 1 || s.pi[1] > s.pi[0]) : s.pi[i] > s.pi[i - 1];
@@ -287,10 +290,74 @@ inline auto expand(Search const& s, size_t newLen) -> std::optional<Search> {   
     if (r.pi.size() != newLen || !isValid(r)) return std::nullopt;
     return r;
 }
+inline auto expand(Search const& s, size_t newLen) -> std::optional<Search> {   // expand.h:146-155: uniformly
+    size_t P = s.pi.size();
+    std::vector<size_t> counts(P, newLen / P);
+    for (size_t i = 0; i < newLen % P; ++i) counts[i] += 1;
+    return expand(s, counts);
+}
 inline auto expand(Scheme const& ss, size_t newLen) -> Scheme {
     Scheme r;
     for (auto const& s : ss) if (auto o = expand(s, newLen)) r.push_back(*o);
     return r;
+}
+inline auto expand(Scheme const& ss, std::vector<size_t> const& counts) -> Scheme {   // expand.h:179-189
+    Scheme r;
+    for (auto const& s : ss) if (auto o = expand(s, counts)) r.push_back(*o);
+    return r;
+}
+// nodes a search visits when a node of depth n survives with probability min(1, N / sigma^n) (weightedNodeCount.h:21-69; the weight in double, the sums in
+// long double as there, so that expandByWNC takes the reference's decisions)
+template <bool Edit>
+inline long double weightedNodeCount(Search const& s, size_t sigma, size_t N) {
+    size_t e = *std::max_element(s.u.begin(), s.u.end());
+    std::vector<long double> last(e + 1, 0), cur(e + 1, 0);
+    last[0] = 1;
+    long double acc = 0;
+    for (size_t n = 1; n <= s.pi.size(); ++n) {
+        double f = static_cast<double>(N) / std::pow(static_cast<double>(sigma), static_cast<double>(n));
+        if (f > 1) f = 1.;
+        for (size_t i = 0; i <= e; ++i) {
+            if (s.l[n - 1] <= i && i <= s.u[n - 1]) {
+                cur[i] = last[i];
+                if (i > 0) cur[i] += Edit ? (sigma - 1) * last[i - 1] + sigma * last[i - 1] + last[i - 1] : (sigma - 1) * last[i - 1];
+                cur[i] *= f;
+                acc += cur[i];
+            } else cur[i] = 0;
+        }
+        std::swap(cur, last);
+    }
+    return acc;
+}
+template <bool Edit>
+inline long double weightedNodeCount(Scheme const& ss, size_t sigma, size_t N) {
+    long double v = 0;
+    for (auto const& s : ss) v = v + weightedNodeCount<Edit>(s, sigma, N);
+    return v;
+}
+// expand.h:218-247: the parts grow one position at a time, each time where the weighted node count of the expanded scheme is smallest
+template <bool Edit = false>
+inline auto optimizeByWNC(Scheme const& ss, size_t newLen, size_t sigma, size_t N) -> std::vector<size_t> {
+    if (ss.empty()) return {};
+    size_t P = ss[0].pi.size();
+    if (newLen < P) throw std::invalid_argument("optimizeByWNC: the new length is shorter than the scheme");
+    std::vector<size_t> counts(P, 1);
+    for (size_t i = 0; i < newLen - P; ++i) {
+        double best = std::numeric_limits<double>::max();      // (a double, like the reference's running best)
+        size_t bestPos = 0;
+        for (size_t j = 0; j < P; ++j) {
+            counts[j] += 1;
+            long double f = weightedNodeCount<Edit>(expand(ss, counts), sigma, N);
+            counts[j] -= 1;
+            if (f < best) { best = static_cast<double>(f); bestPos = j; }
+        }
+        counts[bestPos] += 1;
+    }
+    return counts;
+}
+template <bool Edit = false>
+inline auto expandByWNC(Scheme const& ss, size_t newLen, size_t sigma, size_t N) -> Scheme {
+    return expand(ss, optimizeByWNC<Edit>(ss, newLen, sigma, N));
 }
 inline auto limitToHamming(Scheme ss) -> Scheme {   // expand.h:301-319
     for (auto& s : ss) {

@@ -567,6 +567,10 @@ def ref():
         R.fmref_scheme_node_count_hamming.restype = C.c_double
         R.fmref_scheme_node_count_hamming.argtypes = [C.c_int, C.c_uint64, u64p, u64p, u64p, C.c_uint64]
         R.fmref_uniform_partition.argtypes = [C.c_uint64, C.c_uint64, u64p]
+        if hasattr(R, "fmref_scheme_expand_by_wnc"):
+            R.fmref_scheme_expand_by_wnc.argtypes = [C.c_int, C.c_uint64, u64p, u64p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int] + sig
+            R.fmref_scheme_weighted_node_count.restype = C.c_double
+            R.fmref_scheme_weighted_node_count.argtypes = [C.c_int, C.c_uint64, u64p, u64p, u64p, C.c_uint64, C.c_uint64, C.c_int]
         _ref = R
     return _ref
 
@@ -660,6 +664,16 @@ def ref_scheme_is_complete(scheme, minK, maxK):
 def ref_scheme_node_count_hamming(scheme, sigma):
     pi, l, u = (as_u64(x) for x in scheme)
     return ref().fmref_scheme_node_count_hamming(pi.shape[0], pi.shape[1], _p64(pi), _p64(l), _p64(u), sigma)
+
+
+def ref_scheme_expand_by_wnc(scheme, new_len, sigma, N, edit):
+    pi, l, u = (as_u64(x) for x in scheme)
+    return _ref_scheme(ref().fmref_scheme_expand_by_wnc, pi.shape[0], pi.shape[1], _p64(pi), _p64(l), _p64(u), new_len, sigma, N, 1 if edit else 0, cap=1 << 16)
+
+
+def ref_scheme_weighted_node_count(scheme, sigma, N, edit):
+    pi, l, u = (as_u64(x) for x in scheme)
+    return ref().fmref_scheme_weighted_node_count(pi.shape[0], pi.shape[1], _p64(pi), _p64(l), _p64(u), sigma, N, 1 if edit else 0)
 
 
 def ref_uniform_partition(parts, total):

@@ -29,6 +29,7 @@
 #include <search_scheme/isValid.h>
 #include <search_scheme/isComplete.h>
 #include <search_scheme/nodeCount.h>
+#include <search_scheme/weightedNodeCount.h>
 
 #include <cstdint>
 #include <cstring>
@@ -255,6 +256,16 @@ int fmref_scheme_is_complete(int nsearch, uint64_t parts, uint64_t const* pi, ui
 }
 double fmref_scheme_node_count_hamming(int nsearch, uint64_t parts, uint64_t const* pi, uint64_t const* l, uint64_t const* u, uint64_t sigma) {
     return static_cast<double>(fmc::search_scheme::nodeCount<false>(unflatten(nsearch, parts, pi, l, u), sigma));
+}
+// expandByWNC (expand.h:218-247) as the example calls it (src/example/main.cpp:116, :135): Edit = true for the optimisation
+int fmref_scheme_expand_by_wnc(int nsearch, uint64_t parts_in, uint64_t const* pi_in, uint64_t const* l_in, uint64_t const* u_in, uint64_t newLen, uint64_t sigma, uint64_t N,
+                               int edit, uint64_t* pi, uint64_t* l, uint64_t* u, uint64_t cap, uint64_t* parts) {
+    auto ss = unflatten(nsearch, parts_in, pi_in, l_in, u_in);
+    return flatten(edit ? fmc::search_scheme::expandByWNC<true>(ss, newLen, sigma, N) : fmc::search_scheme::expandByWNC<false>(ss, newLen, sigma, N), pi, l, u, cap, parts);
+}
+double fmref_scheme_weighted_node_count(int nsearch, uint64_t parts, uint64_t const* pi, uint64_t const* l, uint64_t const* u, uint64_t sigma, uint64_t N, int edit) {
+    auto ss = unflatten(nsearch, parts, pi, l, u);
+    return static_cast<double>(edit ? fmc::search_scheme::weightedNodeCount<true>(ss, sigma, N) : fmc::search_scheme::weightedNodeCount<false>(ss, sigma, N));
 }
 void fmref_uniform_partition(uint64_t parts, uint64_t total, uint64_t* out) {
     auto p = fmc::search_scheme::createUniformPartition(parts, total);

@@ -13,8 +13,29 @@ static int failures = 0;
 
 using Results = std::vector<std::tuple<size_t, size_t, size_t>>;
 
-int main() {
+// `test_fmc_gpu wnc`: for every line "gen len edit sigma N" on stdin print expandByWNC's scheme as "searches parts" and the three flattened tables
+// (tests/test_cpp_mirror.py compares them with the real reference's, tests/golden/ref_schemes.json)
+static int wncMode() {
     namespace ss = fmc::search_scheme;
+    char gen[64]; unsigned long long len, sigma, N; int edit;
+    while (std::scanf("%63s %llu %d %llu %llu", gen, &len, &edit, &sigma, &N) == 5) {
+        std::string const g = gen;
+        ss::Scheme s = g == "h2-k1" ? ss::generator::h2(3, 0, 1) : g == "h2-k2" ? ss::generator::h2(4, 0, 2) : g == "h2-k3" ? ss::generator::h2(5, 0, 3)
+                     : g == "pigeon_opt-k2" ? ss::generator::pigeon_opt(0, 2) : g == "pigeon-k1" ? ss::generator::pigeon_trivial(0, 1) : ss::generator::backtracking(1, 0, 2);
+        auto const e = edit ? ss::expandByWNC<true>(s, len, sigma, N) : ss::expandByWNC<false>(s, len, sigma, N);
+        std::printf("%zu %zu\n", e.size(), e.empty() ? size_t{0} : e[0].pi.size());
+        for (int t = 0; t < 3; ++t) {
+            for (auto const& x : e) for (size_t v : (t == 0 ? x.pi : t == 1 ? x.l : x.u)) std::printf("%zu ", v);
+            std::printf("\n");
+        }
+        std::printf("%.17g\n", static_cast<double>(edit ? ss::weightedNodeCount<true>(e, sigma, N) : ss::weightedNodeCount<false>(e, sigma, N)));
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    namespace ss = fmc::search_scheme;
+    if (argc > 1 && std::string(argv[1]) == "wnc") return wncMode();
     {   // search_scheme/expand.cpp
         auto real = ss::expand(ss::Scheme{ss::Search{{0, 1}, {0, 0}, {0, 1}}}, 4);
         CHECK(ss::isValid(real));

@@ -215,6 +215,21 @@ def ref_vectors():
                                       "complete": fo.ref_scheme_is_complete(s, minK, K)})
             s = fo.ref_scheme_backtracking(4, minK, K)
             schemes["backtracking"].append({"N": 4, "minK": minK, "K": K, "pi": s[0].tolist(), "l": s[1].tolist(), "u": s[2].tolist()})
+    # expandByWNC as the example's `--gen <name>_dyn` calls it (src/example/main.cpp:116, :135: Edit = true, sigma = 4, N = 3e9) and with Edit = false
+    schemes["expandByWNC"] = []
+    gens = {"h2-k1": lambda: fo.ref_scheme_h2(3, 0, 1), "h2-k2": lambda: fo.ref_scheme_h2(4, 0, 2), "h2-k3": lambda: fo.ref_scheme_h2(5, 0, 3),
+            "pigeon_opt-k2": lambda: fo.ref_scheme_pigeon_opt(0, 2), "pigeon-k1": lambda: fo.ref_scheme_pigeon_trivial(0, 1), "backtracking-k2": lambda: fo.ref_scheme_backtracking(1, 0, 2)}
+    for gname, make in gens.items():
+        s = make()
+        for L in (s[0].shape[1], 20, 31, 50, 101, 151, 250):
+            for edit, sigma, N in ((True, 4, 3_000_000_000), (False, 4, 3_000_000_000), (True, 27, 2_000_000_000), (True, 4, 1000)):
+                if L < s[0].shape[1]:
+                    continue
+                e = fo.ref_scheme_expand_by_wnc(s, L, sigma, N, edit)
+                schemes["expandByWNC"].append({"gen": gname, "len": L, "edit": edit, "sigma": sigma, "N": N, "searches": int(e[0].shape[0]),
+                                               "crc": zlib.crc32(b"".join(x.tobytes() for x in e)),
+                                               "wnc": fo.ref_scheme_weighted_node_count(e, sigma, N, edit),
+                                               "first_search_pi_runs": [int(c) for c in np.bincount(np.cumsum(np.abs(np.diff(e[0][0].astype(np.int64))) != 1))] if e[0].shape[0] else []})
     for parts, total in ((4, 101), (4, 151), (3, 31), (2, 2), (5, 7), (1, 9)):
         schemes["partition"].append({"parts": parts, "total": total, "out": fo.ref_uniform_partition(parts, total).tolist()})
     return strings, schemes

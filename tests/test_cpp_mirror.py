@@ -1,8 +1,11 @@
 """include/fmc_gpu.hpp: the C++ mirror of the reference's template API compiles against libfmgpu.so (CPU check: scheme tables
 only) and reproduces the reference's search tests on the GPU (tests/cpp/test_fmc_gpu.cpp)."""
+import json
 import os
 import subprocess
+import zlib
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,6 +23,23 @@ def test_cpp_mirror_compiles_and_host_checks_pass():
     _build()
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode in (0, 77), r.stdout + r.stderr      # 77 = no GPU here: only the host-side scheme checks ran (and passed)
+
+
+def test_cpp_expand_by_wnc_equals_the_real_reference():
+    """expand.h:218-247 (what the example's `--gen <name>_dyn` uses): the C++ mirror takes the reference's decisions — every scheme of
+    tests/golden/ref_schemes.json["expandByWNC"] (produced by the real headers) bit for bit, the weighted node count to 1e-12"""
+    _build()
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_schemes.json")))["expandByWNC"]
+    text = "".join("%s %d %d %d %d\n" % (c["gen"], c["len"], 1 if c["edit"] else 0, c["sigma"], c["N"]) for c in cases)
+    r = subprocess.run([EXE, "wnc"], input=text, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    for k, c in enumerate(cases):
+        head, pi, l, u, w = lines[5 * k: 5 * k + 5]
+        searches, parts = (int(x) for x in head.split())
+        arrs = [np.array([int(x) for x in row.split()], dtype=np.uint64).reshape(searches, parts) for row in (pi, l, u)]
+        assert searches == c["searches"] and zlib.crc32(b"".join(a.tobytes() for a in arrs)) == c["crc"], c
+        assert float(w) == pytest.approx(c["wnc"], rel=1e-12)
 
 
 @pytest.mark.gpu

@@ -15,6 +15,7 @@ PKG = os.path.join(ROOT, "fmindex-collection_amd")
 EXE = os.path.join(PKG, "example", "example")
 
 import fmoracle as fo  # noqa: E402
+from fmindex_collection_amd import search_scheme as ss_host  # noqa: E402   (expandByWNC, checked against the real reference in test_host_and_abi.py)
 
 
 def _build():
@@ -70,7 +71,15 @@ def generate(name, min_k, max_k):
             "h2-k2": lambda: fo.scheme_h2(max_k + 2, min_k, max_k), "h2-k3": lambda: fo.scheme_h2(max_k + 3, min_k, max_k)}[name]()
 
 
-def expected_output(ref_fa, query_fa, algo, gen, k, mode="all", maxhits=0, reverse=True, max_queries=0, read_length=0, convert=False):
+def stretch(scheme, m, dyn):
+    """main.cpp:114-123: the scheme at read length — uniformly, or (`<name>_dyn`) by expandByWNC<Edit = true>(oss, len, 4, 3e9)"""
+    if not dyn:
+        return fo.scheme_expand(scheme, m)
+    e = ss_host.expandByWNC(scheme, m, 4, 3_000_000_000, True)
+    return tuple(np.ascontiguousarray(x, dtype=np.uint64) for x in e)
+
+
+def expected_output(ref_fa, query_fa, algo, gen, k, mode="all", maxhits=0, reverse=True, max_queries=0, read_length=0, convert=False, dyn=False):
     ref = load_fasta(ref_fa, False, convert)
     x = fo.OraIndex.build("IB16", 5, [np.array(s, dtype=np.uint8) for s in ref], 16, True)
     queries = load_fasta(query_fa, reverse, convert)
@@ -83,9 +92,9 @@ def expected_output(ref_fa, query_fa, algo, gen, k, mode="all", maxhits=0, rever
     m = len(queries[0])
     if algo == "ng21":
         if mode == "all":
-            hits, _, _ = x.search_ng21(qbuf, qoff, fo.scheme_expand(generate(gen, 0, k), m), max_hits=n)
+            hits, _, _ = x.search_ng21(qbuf, qoff, stretch(generate(gen, 0, k), m, dyn), max_hits=n)
         else:
-            hits, _ = x.search_ng21_best(qbuf, qoff, [fo.scheme_expand(generate(gen, j, j), m) for j in range(k + 1)], max_hits=n)
+            hits, _ = x.search_ng21_best(qbuf, qoff, [stretch(generate(gen, j, j), m, dyn) for j in range(k + 1)], max_hits=n)
     elif algo == "ng26":
         hits, _, _ = x.search_ng26(qbuf, qoff, generate(gen, 0, k), max_hits=n, edit=True)
     else:
@@ -139,6 +148,8 @@ def test_example_output_matches_the_reference_flow(tmp_path):
          dict(algo="ng21", gen="h2-k1", k=1, maxhits=2, reverse=False)),
         (["--algo", "ng21", "--gen", "backtracking", "--min_k", "1", "--max_k", "1", "--mode", "besthits", "--maxhitperquery", "1", "--queries", "50", "--read_length", "24"],
          dict(algo="ng21", gen="backtracking", k=1, mode="besthits", maxhits=1, max_queries=50, read_length=24)),
+        (["--algo", "ng21", "--gen", "h2-k2_dyn", "--min_k", "2", "--max_k", "2"], dict(algo="ng21", gen="h2-k2", k=2, dyn=True)),
+        (["--algo", "ng21", "--gen", "pigeon_opt_dyn", "--min_k", "1", "--max_k", "1", "--mode", "besthits"], dict(algo="ng21", gen="pigeon_opt", k=1, mode="besthits", dyn=True)),
         (["--algo", "noerror", "--min_k", "0", "--max_k", "0"], dict(algo="noerror", gen="h2-k2", k=0)),
         (["--algo", "ng26", "--gen", "h2-k2", "--min_k", "2", "--max_k", "2"], dict(algo="ng26", gen="h2-k2", k=2)),
     ]
@@ -159,7 +170,7 @@ def test_example_output_matches_the_reference_flow(tmp_path):
 @pytest.mark.gpu
 def test_example_fasta_quirks_and_errors(tmp_path):
     """no trailing newline: the reference's reader drops the last base (utils.h:63, :78-80); unknown letters: error unless --convertUnknownChar
-    (-> rank 1, utils.h:91-99); unknown generator / algorithm / _dyn: error"""
+    (-> rank 1, utils.h:91-99); unknown generator / algorithm: error"""
     _build()
     rng = np.random.default_rng(12)
     ref, qry, rp, qp = _fasta(rng, tmp_path)
@@ -179,7 +190,7 @@ def test_example_fasta_quirks_and_errors(tmp_path):
     r = subprocess.run(base + ["--convertUnknownChar"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(out).read().split("\n")[:-1] == expected_output(ref, qry.replace("A", "N", 3), algo="ng21", gen="h2-k2", k=1, convert=True)
-    for extra, msg in ((["--gen", "kianfar"], "unknown search scheme"), (["--gen", "h2-k2_dyn"], "_dyn"), (["--algo", "ng12"], "not part of this build")):
+    for extra, msg in ((["--gen", "kianfar"], "unknown search scheme"), (["--gen", "kianfar_dyn"], "unknown search scheme"), (["--algo", "ng12"], "not part of this build")):
         r = subprocess.run([EXE, "--index", rp, "--query", qp, "--min_k", "1", "--max_k", "1"] + (["--algo", "ng21"] if extra[0] != "--algo" else []) + extra,
                            capture_output=True, text=True)
         assert r.returncode == 1 and msg in r.stderr, (extra, r.stderr)

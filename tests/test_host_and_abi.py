@@ -116,6 +116,19 @@ def test_scheme_generators_match_the_real_reference():
         assert ss.createUniformPartition(g["parts"], g["total"]).tolist() == g["out"]
 
 
+def test_expand_by_wnc_equals_the_real_reference():
+    """expand.h:218-247 + weightedNodeCount.h:21-69 (long double sums, a double running best): the Python mirror reproduces every scheme the real
+    reference's expandByWNC produced (tests/golden/ref_schemes.json), incl. the example's call — Edit = true, sigma 4, N = 3e9"""
+    for g in REFSCH["expandByWNC"]:
+        if g["len"] > 101 and g["gen"] not in ("h2-k2", "pigeon-k1"):
+            continue                                              # (the longest cases of every generator run in the C++ twin of this test)
+        base = {"h2-k1": lambda: ss.h2(3, 0, 1), "h2-k2": lambda: ss.h2(4, 0, 2), "h2-k3": lambda: ss.h2(5, 0, 3), "pigeon_opt-k2": lambda: ss.pigeon_opt(0, 2),
+                "pigeon-k1": lambda: ss.pigeon_trivial(0, 1), "backtracking-k2": lambda: ss.backtracking(1, 0, 2)}[g["gen"]]()
+        e = ss.expandByWNC(base, g["len"], g["sigma"], g["N"], g["edit"])
+        assert e[0].shape[0] == g["searches"] and zlib.crc32(b"".join(np.ascontiguousarray(x, dtype=np.uint64).tobytes() for x in e)) == g["crc"], g
+        assert float(ss.weightedNodeCount(e, g["sigma"], g["N"], g["edit"])) == pytest.approx(g["wnc"], rel=1e-12)
+
+
 def test_scheme_reference_test_cases():
     """search_scheme/expand.cpp:11-60, checkGeneratorsIsComplete.cpp:48-60"""
     for c in REF["expand"]["cases"]:
