@@ -18,7 +18,7 @@ from .capi import FmgpuError, DeviceBuffer, LAYOUTS, UINT64_MAX, HIT_DTYPE
 from . import search_scheme  # noqa: F401
 
 __all__ = ["FMIndex", "BiFMIndex", "search_no_errors", "search_backtracking", "search_ng26", "search_ng21", "search", "search_n", "search_best", "LocateLinear",
-           "search_scheme", "FmgpuError", "DeviceBuffer", "flatten", "device_count"]
+           "search_scheme", "FmgpuError", "DeviceBuffer", "flatten", "device_count", "Replicas"]
 
 
 def device_count():
@@ -390,6 +390,58 @@ class search_ng26:
         hits, st = _run_hits(lambda out, c, cnt, st: capi.lib().fmgpu_search_scheme(
             index._h, capi.ptr(qbuf), capi.ptr(qoff), nq, C.byref(sc), n, capi.ptr(out), c, C.byref(cnt), C.byref(st), None), cap)
         return (hits, st) if want_stats else hits
+
+
+class Replicas:
+    """one index file on several GPUs of this process (fmgpu_replicas_*; SURVEY 8b `fmgpu_set_devices`): a batch is cut into contiguous ranges, one per
+    replica, searched concurrently; results land in host arrays in batch order.  devices=None: every visible device."""
+
+    def __init__(self, handle):
+        self._r = handle
+        n = C.c_int32()
+        capi.check(capi.lib().fmgpu_replicas_info(self._r, C.byref(n), None, 0, None))
+        dev = (C.c_int32 * n.value)()
+        capi.check(capi.lib().fmgpu_replicas_info(self._r, None, dev, n.value, None))
+        self.devices = list(dev)
+
+    @classmethod
+    def load(cls, path, devices=None):
+        h = C.c_void_p()
+        d = (C.c_int32 * len(devices))(*devices) if devices else None
+        capi.check(capi.lib().fmgpu_replicas_load(os.fsencode(path), d, len(devices) if devices else 0, C.byref(h)))
+        return cls(h)
+
+    def search_exact(self, queries, want_stats=False):
+        qbuf, qoff, nq = _queries(queries)
+        lb, ln = np.empty(nq, dtype=np.uint64), np.empty(nq, dtype=np.uint64)
+        st = capi.Stats()
+        capi.check(capi.lib().fmgpu_replicas_search_exact(self._r, capi.ptr(qbuf), capi.ptr(qoff), nq, capi.ptr(lb), capi.ptr(ln), C.byref(st)))
+        return (lb, ln, st) if want_stats else (lb, ln)
+
+    def search_scheme(self, queries, scheme, partition=None, n=UINT64_MAX, capacity=None, want_stats=False, edit=False):
+        qbuf, qoff, nq = _queries(queries)
+        pi, l, u = (_u64(x) for x in scheme)
+        sc = capi.Scheme()
+        sc.n_searches, sc.n_parts = pi.shape
+        sc.pi, sc.l, sc.u = (x.ctypes.data_as(capi.u64p) for x in (pi, l, u))
+        part = _u64(partition) if partition is not None else None
+        sc.partition = part.ctypes.data_as(capi.u64p) if part is not None else None
+        sc.edit = 1 if edit else 0
+        cap = capacity if capacity is not None else max(1024, 4 * nq)
+        hits, st = _run_hits(lambda out, c, cnt, st: capi.lib().fmgpu_replicas_search_scheme(
+            self._r, capi.ptr(qbuf), capi.ptr(qoff), nq, C.byref(sc), n, capi.ptr(out), c, C.byref(cnt), C.byref(st)), cap)
+        return (hits, st) if want_stats else hits
+
+    def close(self):
+        if self._r:
+            capi.check(capi.lib().fmgpu_replicas_destroy(self._r))
+            self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class search_ng21:

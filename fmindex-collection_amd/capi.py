@@ -97,6 +97,7 @@ EXPORTS = [
     "fmgpu_index_accelerate_exact", "fmgpu_index_accelerate_locate", "fmgpu_hits_sort", "fmgpu_hits_pack16",
     "fmgpu_index_row_bits", "fmgpu_index_accelerate_lf", "fmgpu_search_exact_depth", "fmgpu_cursor_extend", "fmgpu_hits_pack24",
     "fmgpu_index_save", "fmgpu_index_load",
+    "fmgpu_replicas_load", "fmgpu_replicas_destroy", "fmgpu_replicas_info", "fmgpu_replicas_search_exact", "fmgpu_replicas_search_scheme",
 ]
 
 _lib = None
@@ -176,6 +177,12 @@ def lib():
     L.fmgpu_cursor_extend.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.fmgpu_index_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.fmgpu_index_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    if hasattr(L, "fmgpu_replicas_load"):
+        L.fmgpu_replicas_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
+        L.fmgpu_replicas_destroy.argtypes = [C.c_void_p]
+        L.fmgpu_replicas_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
+        L.fmgpu_replicas_search_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.fmgpu_replicas_search_scheme.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Scheme), C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats)]
     L.fmgpu_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
     L.fmgpu_free.argtypes = [C.c_void_p]
     L.fmgpu_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]

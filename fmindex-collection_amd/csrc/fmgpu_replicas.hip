@@ -1,0 +1,179 @@
+// fmgpu_replicas.hip — one index replicated on several GPUs of a node, a query batch sharded over them (SURVEY 8b's `fmgpu_set_devices`, 8e): for callers
+// that are ONE process (the C++ mirror, a reference build with the binding of INTEGRATION.md).  The path shards by independent queries and the index is
+// read-only, so there is no exchange between the replicas: every replica searches a contiguous range of the batch on its own device, from its own host
+// thread, and writes its results into its range of the caller's HOST arrays — the "gather" is that write.  (Ranks of a torch.distributed job gather with
+// RCCL instead: bench.py / parallel.py.)  Built on the public entry points only; no kernel lives here.
+#include "fmgpu_common.h"
+
+#include <algorithm>
+#include <thread>
+#include <vector>
+
+namespace fmgpu {
+struct Replicas {
+    std::vector<fmgpu_index_t> index;
+    std::vector<int> device;
+};
+namespace {
+struct DeviceGuard {                       // the calling thread keeps its current device
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+// runs fn(i) for every replica on a thread of its own with the replica's device current; the first error (code + text) is the call's
+template <class F>
+int on_every_replica(const Replicas& r, F&& fn) {
+    const size_t n = r.index.size();
+    std::vector<int> rc(n, 0);
+    std::vector<std::string> msg(n);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < n; ++i)
+        th.emplace_back([&, i] {
+            hipError_t e = hipSetDevice(r.device[i]);
+            if (e != hipSuccess) { rc[i] = hip_fail(e, "hipSetDevice"); msg[i] = last_error_cstr(); return; }
+            rc[i] = fn(i);
+            if (rc[i]) msg[i] = last_error_cstr();
+        });
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < n; ++i) if (rc[i]) return fail(rc[i], "replica " + std::to_string(i) + " (device " + std::to_string(r.device[i]) + "): " + msg[i]);
+    return 0;
+}
+struct Shard { uint64_t first, count; std::vector<uint64_t> qoff; };
+// contiguous ranges of the batch, offsets rebased to each range's first query
+std::vector<Shard> shards_of(const uint64_t* qoff, uint64_t nq, size_t n) {
+    std::vector<Shard> s(n);
+    for (size_t i = 0; i < n; ++i) {
+        s[i].first = nq / n * i + std::min<uint64_t>(i, nq % n);
+        s[i].count = nq / n + (i < nq % n ? 1 : 0);
+        s[i].qoff.resize(s[i].count + 1);
+        for (uint64_t k = 0; k <= s[i].count; ++k) s[i].qoff[k] = qoff[s[i].first + k] - qoff[s[i].first];
+    }
+    return s;
+}
+void add_stats(fmgpu_stats* total, const fmgpu_stats& s) {
+    total->lf_steps += s.lf_steps; total->hits += s.hits; total->table_bytes += s.table_bytes; total->table_accesses += s.table_accesses;
+    total->kernel_ms = std::max(total->kernel_ms, s.kernel_ms); total->prepass_ms = std::max(total->prepass_ms, s.prepass_ms);
+}
+int host_only(const void* p, const char* what) {
+    if (p && is_device_pointer(p)) return fail(FMGPU_ERR_INVALID, std::string(what) + " lives in one device's memory: the replicas take and fill host buffers");
+    return 0;
+}
+}  // namespace
+}  // namespace fmgpu
+
+using namespace fmgpu;
+
+extern "C" {
+
+int fmgpu_replicas_load(const char* path, const int32_t* devices, int32_t ndev, fmgpu_replicas_t* out) {
+    if (!path || !out || (ndev > 0 && !devices)) return fail(FMGPU_ERR_INVALID, "path / devices / out is null");
+    *out = nullptr;
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have == 0) { (void)hipGetLastError(); return fail(FMGPU_ERR_NO_DEVICE, "no HIP device visible — the product path has no CPU fallback"); }
+    auto r = std::unique_ptr<Replicas>(new (std::nothrow) Replicas);
+    if (!r) return fail(FMGPU_ERR_NOMEM, "out of host memory");
+    if (ndev <= 0) for (int d = 0; d < have; ++d) r->device.push_back(d);             // every visible device
+    else for (int32_t i = 0; i < ndev; ++i) {
+        if (devices[i] < 0 || devices[i] >= have) return fail(FMGPU_ERR_INVALID, "device " + std::to_string(devices[i]) + " is not one of the " + std::to_string(have) + " visible devices");
+        r->device.push_back(devices[i]);                                                // (the same device twice is allowed: two replicas share its HBM)
+    }
+    r->index.assign(r->device.size(), nullptr);
+    DeviceGuard keep;
+    const std::string file = path;
+    int rc = on_every_replica(*r, [&](size_t i) { return fmgpu_index_load(file.c_str(), &r->index[i]); });
+    if (rc) {
+        const std::string why = last_error_cstr();
+        for (size_t i = 0; i < r->index.size(); ++i) if (r->index[i]) { (void)hipSetDevice(r->device[i]); (void)fmgpu_index_destroy(r->index[i]); }
+        return fail(rc, why);
+    }
+    *out = reinterpret_cast<fmgpu_replicas_t>(r.release());
+    return 0;
+}
+
+int fmgpu_replicas_destroy(fmgpu_replicas_t rh) {
+    if (!rh) return 0;
+    auto* r = reinterpret_cast<Replicas*>(rh);
+    DeviceGuard keep;
+    int rc = 0;
+    for (size_t i = 0; i < r->index.size(); ++i) {
+        if (hipSetDevice(r->device[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        int e = fmgpu_index_destroy(r->index[i]);
+        if (e && !rc) rc = e;
+    }
+    delete r;
+    return rc;
+}
+
+int fmgpu_replicas_info(fmgpu_replicas_t rh, int32_t* count, int32_t* devices, int32_t capacity, fmgpu_index_t* first) {
+    if (!rh) return fail(FMGPU_ERR_INVALID, "null replica set");
+    auto* r = reinterpret_cast<Replicas*>(rh);
+    if (count) *count = (int32_t)r->index.size();
+    if (devices) for (int32_t i = 0; i < capacity && (size_t)i < r->device.size(); ++i) devices[i] = r->device[i];
+    if (first) *first = r->index[0];
+    return 0;
+}
+
+int fmgpu_replicas_search_exact(fmgpu_replicas_t rh, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats) {
+    if (!rh) return fail(FMGPU_ERR_INVALID, "null replica set");
+    if (nq && (!qoff || !out_lb || !out_len)) return fail(FMGPU_ERR_INVALID, "null buffer");
+    int rc;
+    if ((rc = host_only(qbuf, "qbuf")) || (rc = host_only(qoff, "qoff")) || (rc = host_only(out_lb, "out_lb")) || (rc = host_only(out_len, "out_len"))) return rc;
+    auto* r = reinterpret_cast<Replicas*>(rh);
+    if (stats) *stats = fmgpu_stats{};
+    if (nq == 0) return 0;
+    const auto sh = shards_of(qoff, nq, r->index.size());
+    std::vector<fmgpu_stats> st(sh.size());
+    DeviceGuard keep;
+    rc = on_every_replica(*r, [&](size_t i) {
+        if (sh[i].count == 0) return 0;
+        return fmgpu_search_exact(r->index[i], qbuf + qoff[sh[i].first], sh[i].qoff.data(), sh[i].count, out_lb + sh[i].first, out_len + sh[i].first, stats ? &st[i] : nullptr, nullptr);
+    });
+    if (rc) return rc;
+    if (stats) for (const auto& s : st) add_stats(stats, s);
+    return 0;
+}
+
+int fmgpu_replicas_search_scheme(fmgpu_replicas_t rh, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme, uint64_t max_hits_per_query,
+                                 fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats) {
+    if (!rh) return fail(FMGPU_ERR_INVALID, "null replica set");
+    if (!scheme || !out_count || (nq && !qoff) || (capacity && !out)) return fail(FMGPU_ERR_INVALID, "null buffer");
+    int rc;
+    if ((rc = host_only(qbuf, "qbuf")) || (rc = host_only(qoff, "qoff")) || (rc = host_only(out, "out"))) return rc;
+    auto* r = reinterpret_cast<Replicas*>(rh);
+    if (stats) *stats = fmgpu_stats{};
+    *out_count = 0;
+    if (nq == 0) return 0;
+    const auto sh = shards_of(qoff, nq, r->index.size());
+    std::vector<fmgpu_stats> st(sh.size());
+    std::vector<std::vector<fmgpu_hit>> part(sh.size());
+    std::vector<uint64_t> got(sh.size(), 0);
+    DeviceGuard keep;
+    rc = on_every_replica(*r, [&](size_t i) {
+        if (sh[i].count == 0) return 0;
+        // a replica's records first go to a buffer of its own (its share of the caller's capacity, grown once if the shard holds more: the records of a
+        // batch are not spread evenly — one read of a satellite repeat has thousands)
+        uint64_t cap = std::min<uint64_t>(capacity, capacity / sh.size() + capacity / (4 * sh.size()) + 1024);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            part[i].resize(cap);
+            int e = fmgpu_search_scheme(r->index[i], qbuf + qoff[sh[i].first], sh[i].qoff.data(), sh[i].count, scheme, max_hits_per_query, part[i].data(), cap, &got[i],
+                                        stats ? &st[i] : nullptr, nullptr);
+            if (e != FMGPU_ERR_CAPACITY) return e;
+            if (got[i] > capacity || attempt) return e;            // more than the whole call may return: the caller's to grow
+            cap = got[i];
+        }
+        return 0;
+    });
+    uint64_t total = 0;
+    for (uint64_t g : got) total += g;
+    *out_count = total;                                             // (records produced, also when they do not fit: like fmgpu_search_scheme)
+    if (rc) return rc;
+    if (total > capacity) return fail(FMGPU_ERR_CAPACITY, std::to_string(total) + " hit records, capacity " + std::to_string(capacity));
+    uint64_t at = 0;
+    for (size_t i = 0; i < sh.size(); ++i) {
+        for (uint64_t k = 0; k < got[i]; ++k) { fmgpu_hit h = part[i][k]; h.qidx += sh[i].first; out[at++] = h; }     // query numbers of the whole batch
+        if (stats) add_stats(stats, st[i]);
+    }
+    return 0;
+}
+
+}  // extern "C"

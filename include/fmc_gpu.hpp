@@ -720,4 +720,47 @@ struct Search {
 };
 template <typename I, typename Q, typename D> Search(I const&, Q const&, bool, size_t, std::optional<size_t>, D const&) -> Search<I, Q, D>;
 
+// One index file on several GPUs of this process (include/fmgpu.h: fmgpu_replicas_*): loadReplicas<Index>(file, {0, 1, 2, 3}) loads the file once per listed
+// device (empty list: every visible device); searches cut the batch into contiguous ranges, one per replica, run them concurrently and report in batch order.
+// `front()` is the first replica as an Index (locate and cursor steps go through it with its device current).
+template <typename Index>
+struct Replicas {
+    fmgpu_replicas_t handle{nullptr};
+    Index first{};
+    Replicas() = default;
+    Replicas(Replicas const&) = delete;
+    Replicas& operator=(Replicas const&) = delete;
+    Replicas(Replicas&& o) noexcept : handle{o.handle}, first{std::move(o.first)} { o.handle = nullptr; o.first.handle = nullptr; }
+    ~Replicas() { first.handle = nullptr; if (handle) fmgpu_replicas_destroy(handle); }       // (the first replica's handle is borrowed from the set)
+    auto size() const -> size_t { int32_t n{}; detail::check(fmgpu_replicas_info(handle, &n, nullptr, 0, nullptr)); return static_cast<size_t>(n); }
+    auto front() const -> Index const& { return first; }
+    // search_no_errors::search over the replicas: delegate(qidx, cursor) for every non-empty cursor, in batch order
+    template <typename Queries, typename Delegate>
+    void searchNoErrors(Queries const& queries, Delegate&& delegate) const {
+        std::vector<uint8_t> buf; std::vector<uint64_t> off;
+        detail::flatten(queries, buf, off);
+        size_t nq = off.size() - 1;
+        std::vector<uint64_t> lb(nq), len(nq);
+        detail::check(fmgpu_replicas_search_exact(handle, buf.data(), off.data(), nq, lb.data(), len.data(), nullptr));
+        using cursor_t = select_cursor_t<Index>;
+        for (size_t q = 0; q < nq; ++q) {
+            if (len[q] == 0) continue;
+            cursor_t cur{};
+            cur.index = &first; cur.lb = lb[q]; cur.len = len[q];
+            delegate(q, cur);
+        }
+    }
+};
+template <typename Index>
+auto loadReplicas(std::string const& fileName, std::vector<int32_t> const& devices = {}) -> Replicas<Index> {
+    Replicas<Index> r;
+    detail::check(fmgpu_replicas_load(fileName.c_str(), devices.empty() ? nullptr : devices.data(), static_cast<int32_t>(devices.size()), &r.handle));
+    detail::check(fmgpu_replicas_info(r.handle, nullptr, nullptr, 0, &r.first.handle));
+    int32_t sigma{}, bidir{};
+    detail::check(fmgpu_index_info(r.first.handle, &r.first.n, &sigma, nullptr, &bidir, nullptr));
+    if (static_cast<size_t>(sigma) != Index::Sigma || (bidir != 0) != Index::IsBidirectional)
+        throw std::runtime_error("loadReplicas: " + fileName + " holds an index of Sigma " + std::to_string(sigma) + (bidir ? " (BiFMIndex)" : " (FMIndex)"));
+    return r;
+}
+
 }  // namespace fmc

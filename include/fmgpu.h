@@ -304,6 +304,20 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
 int fmgpu_built_get(fmgpu_built_t b, int32_t part, const void** ptr, uint64_t* bytes);
 int fmgpu_built_free(fmgpu_built_t b);
 
+/* ---- one index on several GPUs of a node, for a caller that is ONE process (SURVEY 8b `fmgpu_set_devices`, 8e): the index file is loaded once per listed
+ * device (ndev <= 0: every visible device; a device may be listed twice), a batch is cut into contiguous ranges of queries, every replica searches its range
+ * on its own device from its own host thread and writes into its range of the caller's HOST arrays (queries are independent and the index is read-only: there
+ * is no exchange between replicas; ranks of a multi-process job gather with RCCL instead — bench.py).  Results equal the single-handle calls' on the same
+ * batch (hit records: the same set, query numbers of the whole batch; fmgpu_hits_sort orders them).  stats: sums, kernel_ms / prepass_ms = the slowest replica's.
+ * All buffers must be host memory (FMGPU_ERR_INVALID otherwise).  fmgpu_replicas_info: count, the device of each replica, the first replica's handle (borrowed). */
+typedef struct fmgpu_replicas* fmgpu_replicas_t;
+int fmgpu_replicas_load(const char* path, const int32_t* devices, int32_t ndev, fmgpu_replicas_t* out);
+int fmgpu_replicas_destroy(fmgpu_replicas_t r);
+int fmgpu_replicas_info(fmgpu_replicas_t r, int32_t* count, int32_t* devices, int32_t capacity, fmgpu_index_t* first);
+int fmgpu_replicas_search_exact(fmgpu_replicas_t r, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats);
+int fmgpu_replicas_search_scheme(fmgpu_replicas_t r, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme, uint64_t max_hits_per_query,
+                                 fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats);
+
 /* device memory helpers for callers that keep queries / results resident in HBM */
 int fmgpu_malloc(void** ptr, uint64_t bytes);
 int fmgpu_free(void* ptr);

@@ -258,6 +258,29 @@ int main(int argc, char** argv) {
         fmc::Search{index, queries, /*editDistance*/ false, size_t{1}, std::optional<size_t>{3}, rep}();
         CHECK(viaStruct.size() == 6);
     }
+    {   // saveIndex / loadIndex (fmindex/diskStorage.h:12-27) and the same file on several replicas of this process (here: one device listed twice)
+        auto text = std::vector<std::vector<uint8_t>>{std::vector<uint8_t>(900)};
+        for (size_t i = 0; i < text[0].size(); ++i) text[0][i] = static_cast<uint8_t>(1 + (i * 2654435761u >> 7) % 4);
+        auto index = fmc::BiFMIndex<5>{text, 4, 1};
+        std::string const file = "/tmp/fmc_gpu_test_index.fmgpu";
+        fmc::saveIndex(index, file);
+        auto again = fmc::loadIndex<fmc::BiFMIndex<5>>(file);
+        auto reads = std::vector<std::vector<uint8_t>>{};
+        for (size_t p = 0; p + 20 <= 900; p += 37) reads.emplace_back(text[0].begin() + p, text[0].begin() + p + 20);
+        reads[3][7] = reads[3][7] % 4 + 1;
+        auto run = [&](auto&& searchFn) { Results r; searchFn([&](size_t qidx, auto cursor) { r.emplace_back(qidx, cursor.lb, cursor.len); }); return r; };
+        auto direct = run([&](auto&& d) { fmc::search_no_errors::search(index, reads, d); });
+        auto loaded = run([&](auto&& d) { fmc::search_no_errors::search(again, reads, d); });
+        auto replicas = fmc::loadReplicas<fmc::BiFMIndex<5>>(file, {0, 0});
+        auto sharded = run([&](auto&& d) { replicas.searchNoErrors(reads, d); });
+        CHECK(!direct.empty() && direct == loaded && direct == sharded && replicas.size() == 2);
+        size_t located = 0;
+        replicas.searchNoErrors(reads, [&](size_t qidx, auto cursor) {
+            for (auto [sid, spos, offset] : fmc::LocateLinear{replicas.front(), cursor}) if (sid == 0 && spos + offset == qidx * 37) ++located;
+        });
+        CHECK(located + 1 >= reads.size());
+        std::remove(file.c_str());
+    }
     std::printf("%s (%d failures)\n", failures ? "FAILED" : "all checks passed", failures);
     return failures ? 1 : 0;
 }

@@ -1615,6 +1615,56 @@ def test_index_file_round_trip(layout, sigma, bidir, tmp_path):
         assert lw.row_bits == 64 and same(answers(lw), want)
 
 
+def test_replicas_shard_a_batch_over_devices(tmp_path):
+    """fmgpu_replicas_* (one process, several devices): an index file loaded once per listed device, the batch cut into contiguous
+    ranges — intervals, step counts and hit records equal the single-handle calls' on the whole batch.  One GPU here: the same device listed
+    twice / three times exercises the sharding, the threads and the re-numbering of the queries (N > 1 devices: the same code, other ids)."""
+    seqs = repeat_text(11, n=5000)
+    ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
+    gx = gpu_index(ox)
+    path = str(tmp_path / "bi.fmgpu")
+    gx.save(path)
+    queries = mutated_queries(seqs, 1001, 20, 90, 2, seed=8)
+    qbuf, qoff = fm.flatten(queries)
+    olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
+    sch = fm.search_scheme.h2(4, 0, 2)
+    want = fm.search_ng26.search(gx, (qbuf, qoff), sch)
+    capi.check(capi.lib().fmgpu_hits_sort(capi.ptr(want), len(want), None))
+    for devices in ([0], [0, 0], [0, 0, 0], None):
+        r = fm.Replicas.load(path, devices)
+        assert r.devices == (devices if devices else list(range(fm.device_count())))
+        lb, ln, st = r.search_exact((qbuf, qoff), want_stats=True)
+        assert np.array_equal(lb, olb) and np.array_equal(ln, oln) and st.lf_steps == int(ost.sum())
+        hits, st = r.search_scheme((qbuf, qoff), sch, want_stats=True)
+        capi.check(capi.lib().fmgpu_hits_sort(capi.ptr(hits), len(hits), None))
+        assert same_hits(hits, want) and st.hits == len(want)
+        small = r.search_scheme((qbuf, qoff), sch, capacity=len(want))          # exactly enough room for the whole call, not for an uneven share: grown inside
+        assert len(small) == len(want)
+        with pytest.raises(fm.FmgpuError):                                        # too small for the call: the caller's to grow (the wrapper's retry is off with n given)
+            capi.check(capi.lib().fmgpu_replicas_search_scheme(r._r, capi.ptr(qbuf), capi.ptr(qoff), len(queries), C.byref(_scheme_struct(sch)), fm.UINT64_MAX,
+                                                              capi.ptr(np.zeros(8, dtype=fm.HIT_DTYPE)), 8, C.byref(C.c_uint64()), None))
+        assert r.search_exact([])[0].size == 0 and len(r.search_scheme([], sch)) == 0
+        two = r.search_exact([queries[0], queries[1]])                            # fewer queries than replicas
+        assert np.array_equal(two[0], olb[:2])
+        dq = fm.DeviceBuffer.from_array(qbuf)
+        with pytest.raises(fm.FmgpuError):                                        # device buffers belong to one device
+            r.search_exact((dq, qoff))
+        r.close()
+    with pytest.raises(fm.FmgpuError):
+        fm.Replicas.load(path, [0, 99])
+    with pytest.raises(fm.FmgpuError):
+        fm.Replicas.load(str(tmp_path / "missing.fmgpu"), [0])
+
+
+def _scheme_struct(scheme):
+    pi, l, u = (np.ascontiguousarray(x, dtype=np.uint64) for x in scheme)
+    sc = capi.Scheme()
+    sc.n_searches, sc.n_parts = pi.shape
+    sc.pi, sc.l, sc.u = (x.ctypes.data_as(capi.u64p) for x in (pi, l, u))
+    sc._keep = (pi, l, u)
+    return sc
+
+
 def test_index_create_argument_checks():
     text = make_text(500, 5, 3)
     ox = fo.OraIndex.build("IB16", 5, [text], 4, True)

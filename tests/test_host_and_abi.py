@@ -72,6 +72,11 @@ def test_index_file_errors_without_a_gpu(tmp_path):
         f.write_bytes(blob)
         assert L.fmgpu_index_load(os.fsencode(f), C.byref(h)) == code and msg in L.fmgpu_last_error(), (k, L.fmgpu_last_error())
         assert not h.value
+    # the replica set (one process, several devices) refuses the same way: null arguments; no device in this container
+    r = C.c_void_p()
+    assert L.fmgpu_replicas_load(None, None, 0, C.byref(r)) == capi.FMGPU_ERR_INVALID
+    assert L.fmgpu_replicas_load(b"/tmp/x.idx", None, 0, C.byref(r)) in (capi.FMGPU_ERR_NO_DEVICE, capi.FMGPU_ERR_INVALID) and not r.value
+    assert L.fmgpu_replicas_search_exact(None, None, None, 0, None, None, None) == capi.FMGPU_ERR_INVALID and L.fmgpu_replicas_destroy(None) == 0
 
 
 def test_argument_errors():
