@@ -3776,7 +3776,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     uint32_t* d_qmap = nullptr;                                    // hand-out order: the thread's call scratch (heavy reads first) or qmap_buf (length buckets)
     DBuf qmap_buf, steps_buf;                                      // released on every return path
     uint32_t* d_steps = nullptr;
-    bool fast = false;
+    [[maybe_unused]] bool fast = false;
     float prepass_ms = 0.f;                                        // the hand-out order pass (flag kernel, sample read-back, partition): reported beside kernel_ms, never inside it
 #if FMGPU_WIDE
     // 64-bit rows hold no tables; an equal-length Hamming batch on the plain sigma = 5 blocks still takes k_scheme_lean (16-byte frames of 38-bit rows, reads of
@@ -3904,7 +3904,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     // the plain index (sigma = 5, no table) with path keys and unlimited hits per read: the lean kernel (k_scheme_lean); bit 30 of FMGPU_DEV_FLAGS keeps
     // k_scheme_fast<PLAIN> (the parity tests run both)
     const bool lean = fast && !edit && !have_lf && x->bwt.sigma == 5 && sharing && nq <= 0xffffffffull && n >= 2 && !(sd.dev_flags & (1 << 30));
-    const uint32_t lean_qwords = (maxlen + 15) / 16;
+    [[maybe_unused]] const uint32_t lean_qwords = (maxlen + 15) / 16;
     size_t lean_lds = 0;
     if (lean) {
         size_t max_tab = 0;
