@@ -432,6 +432,25 @@ class Replicas:
             self._r, capi.ptr(qbuf), capi.ptr(qoff), nq, C.byref(sc), n, capi.ptr(out), c, C.byref(cnt), C.byref(st)), cap)
         return (hits, st) if want_stats else hits
 
+    def search_ng21(self, queries, scheme, n=UINT64_MAX, capacity=None, want_stats=False):
+        """search_ng21::search / search_n over an expanded scheme (pi, l, u arrays [searches][query length])"""
+        qbuf, qoff, nq = _queries(queries)
+        pi, l, u = (_u64(x) for x in scheme)
+        sc = capi.ExpandedScheme()
+        sc.n_searches, sc.length = (pi.shape if pi.ndim == 2 else (0, 0))
+        sc.pi, sc.l, sc.u = (x.ctypes.data_as(capi.u64p) for x in (pi, l, u))
+        cap = capacity if capacity is not None else max(1024, 4 * nq)
+        hits, st = _run_hits(lambda out, c, cnt, st: capi.lib().fmgpu_replicas_search_ng21(
+            self._r, capi.ptr(qbuf), capi.ptr(qoff), nq, C.byref(sc), n, capi.ptr(out), c, C.byref(cnt), C.byref(st)), cap)
+        return (hits, st) if want_stats else hits
+
+    def locate(self, rows):
+        """(seq, pos, steps) of every row (FMIndex::locate), the rows sharded over the replicas"""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = [np.empty(len(rows), dtype=np.uint64) for _ in range(3)]
+        capi.check(capi.lib().fmgpu_replicas_locate(self._r, capi.ptr(rows), len(rows), capi.ptr(out[0]), capi.ptr(out[1]), capi.ptr(out[2]), None))
+        return tuple(out)
+
     def close(self):
         if self._r:
             capi.check(capi.lib().fmgpu_replicas_destroy(self._r))

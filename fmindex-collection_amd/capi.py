@@ -98,6 +98,7 @@ EXPORTS = [
     "fmgpu_index_row_bits", "fmgpu_index_accelerate_lf", "fmgpu_search_exact_depth", "fmgpu_cursor_extend", "fmgpu_hits_pack24",
     "fmgpu_index_save", "fmgpu_index_load",
     "fmgpu_replicas_load", "fmgpu_replicas_destroy", "fmgpu_replicas_info", "fmgpu_replicas_search_exact", "fmgpu_replicas_search_scheme",
+    "fmgpu_replicas_search_ng21", "fmgpu_replicas_locate",
 ]
 
 _lib = None
@@ -183,6 +184,8 @@ def lib():
         L.fmgpu_replicas_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
         L.fmgpu_replicas_search_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.fmgpu_replicas_search_scheme.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Scheme), C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats)]
+        L.fmgpu_replicas_search_ng21.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(ExpandedScheme), C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats)]
+        L.fmgpu_replicas_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.fmgpu_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
     L.fmgpu_free.argtypes = [C.c_void_p]
     L.fmgpu_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]

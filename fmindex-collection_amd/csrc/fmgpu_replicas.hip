@@ -133,13 +133,13 @@ int fmgpu_replicas_search_exact(fmgpu_replicas_t rh, const uint8_t* qbuf, const 
     return 0;
 }
 
-int fmgpu_replicas_search_scheme(fmgpu_replicas_t rh, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme, uint64_t max_hits_per_query,
-                                 fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats) {
-    if (!rh) return fail(FMGPU_ERR_INVALID, "null replica set");
-    if (!scheme || !out_count || (nq && !qoff) || (capacity && !out)) return fail(FMGPU_ERR_INVALID, "null buffer");
-    int rc;
-    if ((rc = host_only(qbuf, "qbuf")) || (rc = host_only(qoff, "qoff")) || (rc = host_only(out, "out"))) return rc;
-    auto* r = reinterpret_cast<Replicas*>(rh);
+}  // extern "C"
+
+namespace fmgpu {
+namespace {
+// a search that produces hit records, sharded: call(i, qbuf, qoff, nq, out, cap, &count, stats) runs it on replica i
+template <class Call>
+int sharded_hits(Replicas* r, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats, Call&& call) {
     if (stats) *stats = fmgpu_stats{};
     *out_count = 0;
     if (nq == 0) return 0;
@@ -148,15 +148,14 @@ int fmgpu_replicas_search_scheme(fmgpu_replicas_t rh, const uint8_t* qbuf, const
     std::vector<std::vector<fmgpu_hit>> part(sh.size());
     std::vector<uint64_t> got(sh.size(), 0);
     DeviceGuard keep;
-    rc = on_every_replica(*r, [&](size_t i) {
+    int rc = on_every_replica(*r, [&](size_t i) {
         if (sh[i].count == 0) return 0;
         // a replica's records first go to a buffer of its own (its share of the caller's capacity, grown once if the shard holds more: the records of a
         // batch are not spread evenly — one read of a satellite repeat has thousands)
         uint64_t cap = std::min<uint64_t>(capacity, capacity / sh.size() + capacity / (4 * sh.size()) + 1024);
         for (int attempt = 0; attempt < 2; ++attempt) {
             part[i].resize(cap);
-            int e = fmgpu_search_scheme(r->index[i], qbuf + qoff[sh[i].first], sh[i].qoff.data(), sh[i].count, scheme, max_hits_per_query, part[i].data(), cap, &got[i],
-                                        stats ? &st[i] : nullptr, nullptr);
+            int e = call(i, qbuf + qoff[sh[i].first], sh[i].qoff.data(), sh[i].count, part[i].data(), cap, &got[i], stats ? &st[i] : nullptr);
             if (e != FMGPU_ERR_CAPACITY) return e;
             if (got[i] > capacity || attempt) return e;            // more than the whole call may return: the caller's to grow
             cap = got[i];
@@ -165,7 +164,7 @@ int fmgpu_replicas_search_scheme(fmgpu_replicas_t rh, const uint8_t* qbuf, const
     });
     uint64_t total = 0;
     for (uint64_t g : got) total += g;
-    *out_count = total;                                             // (records produced, also when they do not fit: like fmgpu_search_scheme)
+    *out_count = total;                                             // (records produced, also when they do not fit: like the single-handle calls)
     if (rc) return rc;
     if (total > capacity) return fail(FMGPU_ERR_CAPACITY, std::to_string(total) + " hit records, capacity " + std::to_string(capacity));
     uint64_t at = 0;
@@ -173,6 +172,56 @@ int fmgpu_replicas_search_scheme(fmgpu_replicas_t rh, const uint8_t* qbuf, const
         for (uint64_t k = 0; k < got[i]; ++k) { fmgpu_hit h = part[i][k]; h.qidx += sh[i].first; out[at++] = h; }     // query numbers of the whole batch
         if (stats) add_stats(stats, st[i]);
     }
+    return 0;
+}
+}  // namespace
+}  // namespace fmgpu
+
+extern "C" {
+
+int fmgpu_replicas_search_scheme(fmgpu_replicas_t rh, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme, uint64_t max_hits_per_query,
+                                 fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats) {
+    if (!rh) return fail(FMGPU_ERR_INVALID, "null replica set");
+    if (!scheme || !out_count || (nq && !qoff) || (capacity && !out)) return fail(FMGPU_ERR_INVALID, "null buffer");
+    int rc;
+    if ((rc = host_only(qbuf, "qbuf")) || (rc = host_only(qoff, "qoff")) || (rc = host_only(out, "out"))) return rc;
+    auto* r = reinterpret_cast<Replicas*>(rh);
+    return sharded_hits(r, qbuf, qoff, nq, out, capacity, out_count, stats, [&](size_t i, const uint8_t* qb, const uint64_t* qo, uint64_t n, fmgpu_hit* o, uint64_t cap, uint64_t* cnt, fmgpu_stats* st) {
+        return fmgpu_search_scheme(r->index[i], qb, qo, n, scheme, max_hits_per_query, o, cap, cnt, st, nullptr);
+    });
+}
+
+int fmgpu_replicas_search_ng21(fmgpu_replicas_t rh, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_expanded_scheme* scheme, uint64_t max_hits_per_query,
+                               fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats) {
+    if (!rh) return fail(FMGPU_ERR_INVALID, "null replica set");
+    if (!scheme || !out_count || (nq && !qoff) || (capacity && !out)) return fail(FMGPU_ERR_INVALID, "null buffer");
+    int rc;
+    if ((rc = host_only(qbuf, "qbuf")) || (rc = host_only(qoff, "qoff")) || (rc = host_only(out, "out"))) return rc;
+    auto* r = reinterpret_cast<Replicas*>(rh);
+    return sharded_hits(r, qbuf, qoff, nq, out, capacity, out_count, stats, [&](size_t i, const uint8_t* qb, const uint64_t* qo, uint64_t n, fmgpu_hit* o, uint64_t cap, uint64_t* cnt, fmgpu_stats* st) {
+        return fmgpu_search_ng21(r->index[i], qb, qo, n, scheme, max_hits_per_query, o, cap, cnt, st, nullptr);
+    });
+}
+
+// FMIndex::locate of `count` rows, sharded like a batch of queries (rows are rows of the index, the same on every replica)
+int fmgpu_replicas_locate(fmgpu_replicas_t rh, const uint64_t* rows, uint64_t count, uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps, fmgpu_stats* stats) {
+    if (!rh) return fail(FMGPU_ERR_INVALID, "null replica set");
+    if (count && (!rows || !out_seq || !out_pos || !out_steps)) return fail(FMGPU_ERR_INVALID, "null buffer");
+    int rc;
+    if ((rc = host_only(rows, "rows")) || (rc = host_only(out_seq, "out_seq")) || (rc = host_only(out_pos, "out_pos")) || (rc = host_only(out_steps, "out_steps"))) return rc;
+    auto* r = reinterpret_cast<Replicas*>(rh);
+    if (stats) *stats = fmgpu_stats{};
+    if (count == 0) return 0;
+    const size_t n = r->index.size();
+    std::vector<fmgpu_stats> st(n);
+    DeviceGuard keep;
+    rc = on_every_replica(*r, [&](size_t i) {
+        const uint64_t first = count / n * i + std::min<uint64_t>(i, count % n), mine = count / n + (i < count % n ? 1 : 0);
+        if (mine == 0) return 0;
+        return fmgpu_locate(r->index[i], rows + first, mine, out_seq + first, out_pos + first, out_steps + first, stats ? &st[i] : nullptr, nullptr);
+    });
+    if (rc) return rc;
+    if (stats) for (const auto& s : st) add_stats(stats, s);
     return 0;
 }
 

@@ -317,6 +317,9 @@ int fmgpu_replicas_info(fmgpu_replicas_t r, int32_t* count, int32_t* devices, in
 int fmgpu_replicas_search_exact(fmgpu_replicas_t r, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats);
 int fmgpu_replicas_search_scheme(fmgpu_replicas_t r, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme, uint64_t max_hits_per_query,
                                  fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats);
+int fmgpu_replicas_search_ng21(fmgpu_replicas_t r, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_expanded_scheme* scheme, uint64_t max_hits_per_query,
+                               fmgpu_hit* out, uint64_t capacity, uint64_t* out_count, fmgpu_stats* stats);
+int fmgpu_replicas_locate(fmgpu_replicas_t r, const uint64_t* rows, uint64_t count, uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps, fmgpu_stats* stats);
 
 /* device memory helpers for callers that keep queries / results resident in HBM */
 int fmgpu_malloc(void** ptr, uint64_t bytes);

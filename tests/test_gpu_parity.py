@@ -1643,7 +1643,19 @@ def test_replicas_shard_a_batch_over_devices(tmp_path):
         with pytest.raises(fm.FmgpuError):                                        # too small for the call: the caller's to grow (the wrapper's retry is off with n given)
             capi.check(capi.lib().fmgpu_replicas_search_scheme(r._r, capi.ptr(qbuf), capi.ptr(qoff), len(queries), C.byref(_scheme_struct(sch)), fm.UINT64_MAX,
                                                               capi.ptr(np.zeros(8, dtype=fm.HIT_DTYPE)), 8, C.byref(C.c_uint64()), None))
-        assert r.search_exact([])[0].size == 0 and len(r.search_scheme([], sch)) == 0
+        eq = [q for q in queries if len(q) >= 40]
+        eq = [q[:40] for q in eq]
+        ex = fm.search_scheme.expand(fm.search_scheme.pigeon_opt(0, 1), 40)
+        w21 = fm.search_ng21.search(gx, eq, ex)
+        h21 = r.search_ng21(eq, ex)
+        for h_ in (w21, h21):
+            capi.check(capi.lib().fmgpu_hits_sort(capi.ptr(h_), len(h_), None))
+        assert same_hits(h21, w21) and len(w21) > 0
+        rows = np.concatenate([want["lb"][:300], olb[oln > 0][:300]]).astype(np.uint64)
+        one = gx.locate(rows)
+        many = r.locate(rows)
+        assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(one, many))
+        assert r.search_exact([])[0].size == 0 and len(r.search_scheme([], sch)) == 0 and r.locate([])[0].size == 0
         two = r.search_exact([queries[0], queries[1]])                            # fewer queries than replicas
         assert np.array_equal(two[0], olb[:2])
         dq = fm.DeviceBuffer.from_array(qbuf)
