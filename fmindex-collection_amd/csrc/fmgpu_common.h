@@ -33,7 +33,7 @@
 //     'A'; the few rows that hold one (one per sequence) are listed — `dense_ex`, ascending — and blocks that may hold one are marked in a 2048-bit filter
 //     (block number mod 2048): a marked block takes a slow path that consults the list.  Built when the string has at most 256 delimiters.
 //
-//  Format P  ("pairs": the bwt of a sigma = 5 index with 32-bit rows, beside Format A — what exact search reads, two symbols per step):
+//  Format P  ("pairs": the bwt of a sigma = 5 index, beside Format A — what exact search reads, two symbols per step):
 //     one line of 128 bytes per 128 rows:  u32 cnt[16] = (first row of the interval of "xy") + #{ j < 128L : the pair of row j is (x, y) }, index
 //     (x-1)*4 + (y-1);  then for rows 0..63 and for rows 64..127 four u64 planes = bit k of the pair code of each row.  The pair of row j is
 //     (s[LF(j)], s[j]) — the two symbols in front of suffix j — so with lb' = cnt[xy] + (rows of the pair before lb) a search prepends "xy" in ONE
@@ -41,6 +41,7 @@
 //     is bound by the random 128-byte line fills it causes (tools/membench.hip: 52-55 G lines/s whatever is read of a line), one per step and
 //     interval end; this format halves the lines of a query.  Rows whose pair holds a delimiter (two per sequence) carry code 0, are left out of
 //     the counts and are listed (`pairs_ex`, ascending) behind a filter on the line number; built when there are at most 512 of them.
+//     64-bit rows (n < 2^38): the line's counts are relative to its super-block of 2^30 rows, `pairs_super[sb][16]` holds the interval start + the count before it.
 //
 //  Format S  ("symbol planes": the bwt of a Wavelet index with 6 <= sigma <= 29, beside Format M — what exact search reads there, one line per LF step and end):
 //     one line of 128 bytes per 64 rows:  u64 plane[5] = bit k of each row's symbol;  then sigma 3-byte numbers = the rows before the line that hold
@@ -678,7 +679,8 @@ struct DevString {
     // Format D (see the head of this file): dense DNA blocks + the ascending list of the rows that hold a delimiter (u32, `dense_nex` of them)
     void* dense = nullptr; size_t dense_bytes = 0; uint32_t* dense_ex = nullptr; uint32_t dense_nex = 0;
     // Format P (see the head of this file): pair lines of the bwt + the ascending list of the rows left out of them (u32, `pairs_nex` of them)
-    uint8_t* pairs = nullptr; size_t pairs_bytes = 0; uint32_t* pairs_ex = nullptr; uint32_t pairs_nex = 0;
+    uint8_t* pairs = nullptr; size_t pairs_bytes = 0; idx_t* pairs_ex = nullptr; uint32_t pairs_nex = 0;
+    idx_t* pairs_super = nullptr; uint32_t pairs_nsb = 0;     // 64-bit rows: the line counts are relative to super-blocks of 2^30 rows, [pairs_nsb][16] holds the rest
     // Format S (see the head of this file): one line per 64 rows of a Wavelet bwt with 6 <= sigma <= 29 + the counts at the start of every 2^24 rows ([flat_nsb][sigma], C folded in)
     uint8_t* flat = nullptr; size_t flat_bytes = 0; idx_t* flat_super = nullptr; uint32_t flat_nsb = 0;
     void* shadow = nullptr; size_t shadow_bytes = 0;   // (shadow_bytes = blocks + super table)

@@ -194,7 +194,7 @@ int build_dense_dna(DevString& s, hipStream_t stream) {
 // is written as code 0, left out of the counts and listed.
 constexpr uint32_t kPairMaxRows = 512;              // listed rows (two per sequence): more than these and the table is not built
 __global__ __launch_bounds__(256) void k_pair_codes(OccA<5> occ, uint64_t n, uint8_t* __restrict__ lines, uint32_t* __restrict__ part, uint64_t nlines,
-                                                    uint32_t* __restrict__ ex, uint32_t* __restrict__ nex) {
+                                                    idx_t* __restrict__ ex, uint32_t* __restrict__ nex) {
     __shared__ uint32_t s_cnt[4][16];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint64_t chunk = blockIdx.x; chunk * 2u < nlines; chunk += gridDim.x) {     // 256 rows = two lines per pass (a grid-stride loop: the thread count of a launch stays below 2^32)
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_pair_codes(OccA<5> occ, uint64_t n, uin
         if (lane == 0) while (lm) {
             const uint32_t r = (uint32_t)__ffsll((unsigned long long)lm) - 1u; lm &= lm - 1ull;
             const uint32_t k = atomicAdd(nex, 1u);
-            if (k < kPairMaxRows) ex[k] = (uint32_t)(chunk * 256u + wave * 64u + r);
+            if (k < kPairMaxRows) ex[k] = (idx_t)(chunk * 256u + wave * 64u + r);
         }
         const uint64_t L = chunk * 2u + (wave >> 1);                // this wave's 128-row line
         if (lane < 4 && L < nlines) reinterpret_cast<uint64_t*>(lines + L * 128u + 64u + (wave & 1u) * 32u)[lane] = plane[lane];
@@ -246,38 +246,73 @@ __global__ __launch_bounds__(256) void k_pair_counts(OccA<5> occ, const uint32_t
     const uint64_t L = t >> 4; const uint32_t pc = (uint32_t)t & 15u;
     if (L < nlines) reinterpret_cast<uint32_t*>(lines + L * 128u)[pc] = s_c2[pc] + part[(size_t)pc * nlines + L];
 }
+// 64-bit rows: workgroup (sb, pc) runs the count of pair pc through the lines of super-block sb (2^30 rows) and writes it into the lines; the super-block's total
+__global__ __launch_bounds__(256) void k_pair_counts_seg(const uint32_t* __restrict__ part, uint64_t nlines, uint8_t* __restrict__ lines, uint64_t* __restrict__ totals) {
+    typedef hipcub::BlockScan<uint32_t, 256> Scan;
+    __shared__ typename Scan::TempStorage tmp;
+    const uint32_t sb = blockIdx.x, pc = blockIdx.y;
+    const uint64_t first = (uint64_t)sb << (kSuperShift - 7), last = min(nlines, first + (1ull << (kSuperShift - 7)));
+    uint32_t run = 0;                                                // < 2^30: fits
+    for (uint64_t base = first; base < last; base += 256u) {
+        const uint64_t L = base + threadIdx.x;
+        const uint32_t v = L < last ? part[(size_t)pc * nlines + L] : 0u;
+        uint32_t before, sum;
+        Scan(tmp).ExclusiveSum(v, before, sum);
+        __syncthreads();
+        if (L < last) reinterpret_cast<uint32_t*>(lines + L * 128u)[pc] = run + before;
+        run += sum;
+    }
+    if (threadIdx.x == 0) totals[(size_t)sb * 16u + pc] = run;
+}
+__global__ void k_pair_super(OccA<5> occ, const uint64_t* __restrict__ totals, uint32_t nsb, idx_t* __restrict__ super) {
+    const uint32_t pc = threadIdx.x;
+    if (pc >= 16u) return;
+    idx_t run = occ.lf(occ.lf(0, (pc & 3u) + 1u), (pc >> 2) + 1u);  // "xy" from the whole table: y first, then x
+    for (uint32_t sb = 0; sb < nsb; ++sb) { super[(size_t)sb * 16u + pc] = run; run += (idx_t)totals[(size_t)sb * 16u + pc]; }
+}
 int build_pair_table(Index* x, hipStream_t stream) {
     DevString& s = x->bwt;
     const char* off = getenv("FMGPU_PAIRS");
-    if (kWide || s.sigma != 5 || s.family != FAM_A || s.shadow || s.va.bstride != 64u || s.n < 2 || s.pairs || (off && atoi(off) == 0)) return 0;
+    if (s.sigma != 5 || s.family != FAM_A || s.shadow || s.va.bstride != 64u || s.n < 2 || s.n >= (1ull << 38) || s.pairs || (off && atoi(off) == 0)) return 0;
     const uint64_t nlines = s.n / 128 + 1;
-    DBuf out, part, ex, cnt, tmp; int rc;
-    if ((rc = out.alloc(nlines * 128)) || (rc = part.alloc(nlines * 16 * 4)) || (rc = ex.alloc(kPairMaxRows * 4)) || (rc = cnt.alloc(8))) return rc;
+    DBuf out, part, ex, cnt, tmp, totals, super; int rc;
+    if ((rc = out.alloc(nlines * 128)) || (rc = part.alloc(nlines * 16 * 4)) || (rc = ex.alloc(kPairMaxRows * sizeof(idx_t))) || (rc = cnt.alloc(8))) return rc;
     FM_HIP(hipMemsetAsync(cnt.p, 0, 8, stream));
-    FM_HIP(hipMemsetAsync(ex.p, 0xff, kPairMaxRows * 4, stream));
+    FM_HIP(hipMemsetAsync(ex.p, 0xff, kPairMaxRows * sizeof(idx_t), stream));
     dim3 grid; if ((rc = grid_of(nlines * 128, &grid, 1u << 22))) return rc;
-    k_pair_codes<<<grid, dim3(256), 0, stream>>>(OccA<5>{s.va}, s.n, out.as<uint8_t>(), part.as<uint32_t>(), nlines, ex.as<uint32_t>(), cnt.as<uint32_t>());
+    k_pair_codes<<<grid, dim3(256), 0, stream>>>(OccA<5>{s.va}, s.n, out.as<uint8_t>(), part.as<uint32_t>(), nlines, ex.as<idx_t>(), cnt.as<uint32_t>());
     FM_LAUNCHED("k_pair_codes");
     uint32_t nex = 0;
     FM_HIP(hipMemcpyAsync(&nex, cnt.p, 4, hipMemcpyDeviceToHost, stream));
     FM_HIP(hipStreamSynchronize(stream));
     if (nex > kPairMaxRows) return 0;                             // many sequences: exact search keeps its one-symbol steps
-    size_t tb = 0;
-    FM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, part.as<uint32_t>(), part.as<uint32_t>(), (size_t)nlines));
-    if ((rc = tmp.alloc(tb))) return rc;
-    for (uint32_t pc = 0; pc < 16; ++pc) {
-        uint32_t* p = part.as<uint32_t>() + (size_t)pc * nlines; size_t b2 = tb;
-        FM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, b2, p, p, (size_t)nlines, stream));
+    uint32_t nsb = 0;
+    if constexpr (kWide) {
+        nsb = (uint32_t)(s.n >> kSuperShift) + 1u;
+        if ((rc = totals.alloc((size_t)nsb * 16 * 8)) || (rc = super.alloc((size_t)nsb * 16 * sizeof(idx_t)))) return rc;
+        k_pair_counts_seg<<<dim3(nsb, 16), dim3(256), 0, stream>>>(part.as<uint32_t>(), nlines, out.as<uint8_t>(), totals.as<uint64_t>());
+        FM_LAUNCHED("k_pair_counts_seg");
+        k_pair_super<<<1, 16, 0, stream>>>(OccA<5>{s.va}, totals.as<uint64_t>(), nsb, super.as<idx_t>());
+        FM_LAUNCHED("k_pair_super");
+    } else {
+        size_t tb = 0;
+        FM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, part.as<uint32_t>(), part.as<uint32_t>(), (size_t)nlines));
+        if ((rc = tmp.alloc(tb))) return rc;
+        for (uint32_t pc = 0; pc < 16; ++pc) {
+            uint32_t* p = part.as<uint32_t>() + (size_t)pc * nlines; size_t b2 = tb;
+            FM_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, b2, p, p, (size_t)nlines, stream));
+        }
+        FM_GRID(grid2, nlines * 16);
+        k_pair_counts<<<grid2, dim3(256), 0, stream>>>(OccA<5>{s.va}, part.as<uint32_t>(), nlines, out.as<uint8_t>());
+        FM_LAUNCHED("k_pair_counts");
     }
-    FM_GRID(grid2, nlines * 16);
-    k_pair_counts<<<grid2, dim3(256), 0, stream>>>(OccA<5>{s.va}, part.as<uint32_t>(), nlines, out.as<uint8_t>());
-    FM_LAUNCHED("k_pair_counts");
-    std::vector<uint32_t> rows(nex);
-    if (nex) FM_HIP(hipMemcpyAsync(rows.data(), ex.p, nex * 4, hipMemcpyDeviceToHost, stream));
+    std::vector<idx_t> rows(nex);
+    if (nex) FM_HIP(hipMemcpyAsync(rows.data(), ex.p, nex * sizeof(idx_t), hipMemcpyDeviceToHost, stream));
     FM_HIP(hipStreamSynchronize(stream));
     std::sort(rows.begin(), rows.end());
-    if (nex) FM_HIP(hipMemcpy(ex.p, rows.data(), nex * 4, hipMemcpyHostToDevice));
-    s.pairs_bytes = out.bytes; s.pairs = (uint8_t*)out.take(); s.pairs_ex = (uint32_t*)ex.take(); s.pairs_nex = nex;
+    if (nex) FM_HIP(hipMemcpy(ex.p, rows.data(), nex * sizeof(idx_t), hipMemcpyHostToDevice));
+    s.pairs_bytes = out.bytes + super.bytes; s.pairs = (uint8_t*)out.take(); s.pairs_ex = (idx_t*)ex.take(); s.pairs_nex = nex;
+    s.pairs_super = kWide ? (idx_t*)super.take() : nullptr; s.pairs_nsb = nsb;
     x->device_bytes += s.pairs_bytes;
     return 0;
 }
@@ -498,7 +533,7 @@ int on_handle_device(const Index* x) {
 }
 
 void free_string(DevString& s) {
-    for (void* p : {s.blk, s.aux, s.sup, (void*)s.lf_table, (void*)s.kblk, (void*)s.walk3, s.shadow, s.shadow_sup, (void*)s.slut, (void*)s.walkj, (void*)s.walk2j, s.dense, (void*)s.dense_ex, (void*)s.pairs, (void*)s.pairs_ex, (void*)s.flat, (void*)s.flat_super})
+    for (void* p : {s.blk, s.aux, s.sup, (void*)s.lf_table, (void*)s.kblk, (void*)s.walk3, s.shadow, s.shadow_sup, (void*)s.slut, (void*)s.walkj, (void*)s.walk2j, s.dense, (void*)s.dense_ex, (void*)s.pairs, (void*)s.pairs_ex, (void*)s.pairs_super, (void*)s.flat, (void*)s.flat_super})
         if (p) (void)hipFree(p);
     s = DevString{};
 }

@@ -214,26 +214,26 @@ __device__ __forceinline__ uint32_t pair_rank_lds(const lds_word* own, uint32_t 
     const uint32_t h2 = (w2.x ^ i0) & (w2.z ^ i1) & (w3.x ^ i2) & (w3.z ^ i3), h3 = (w2.y ^ i0) & (w2.w ^ i1) & (w3.y ^ i2) & (w3.w ^ i3);
     return cnt + __popc(h0 & m0) + __popc(h1 & m1) + __popc(h2 & m2) + __popc(h3 & m3);
 }
-__global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __restrict__ pairs, const uint32_t* __restrict__ ex, uint32_t nex,
+__global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __restrict__ pairs, const idx_t* __restrict__ ex, uint32_t nex, const idx_t* __restrict__ psuper,
                                                  const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                  unsigned long long* __restrict__ steps_total) {
     extern __shared__ uint32_t s_coop[];                            // 4 waves x 8 regions
     __shared__ uint32_t s_filt[kPairFilterBits / 32u];
-    __shared__ uint32_t s_ex[512];
+    __shared__ idx_t s_ex[512];
     for (uint32_t t = threadIdx.x; t < kPairFilterBits / 32u; t += 256u) s_filt[t] = 0u;
-    for (uint32_t t = threadIdx.x; t < 512u; t += 256u) s_ex[t] = t < nex ? ex[t] : 0xffffffffu;
+    for (uint32_t t = threadIdx.x; t < 512u; t += 256u) s_ex[t] = t < nex ? ex[t] : ~(idx_t)0;
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < 512u; t += 256u) {
-        const uint32_t r = s_ex[t];
-        if (r != 0xffffffffu) { const uint32_t bk = (r >> 7) & (kPairFilterBits - 1u); atomicOr(&s_filt[bk >> 5], 1u << (bk & 31u)); }
+        const idx_t r = s_ex[t];
+        if (r != ~(idx_t)0) { const uint32_t bk = (uint32_t)(r >> 7) & (kPairFilterBits - 1u); atomicOr(&s_filt[bk >> 5], 1u << (bk & 31u)); }
     }
     __syncthreads();
     // listed rows in [first row of i's line, i): they sit in the planes as code 0 and are in no count
-    auto listed_before = [&](uint32_t i) -> uint32_t {
-        const uint32_t bk = (i >> 7) & (kPairFilterBits - 1u);
+    auto listed_before = [&](idx_t i) -> uint32_t {
+        const uint32_t bk = (uint32_t)(i >> 7) & (kPairFilterBits - 1u);
         if (!((s_filt[bk >> 5] >> (bk & 31u)) & 1u)) return 0u;
-        const uint32_t first = i & ~127u;
+        const idx_t first = i & ~(idx_t)127;
         uint32_t c = 0;
         for (uint32_t t = 0; t < 512u && s_ex[t] < i; ++t) if (s_ex[t] >= first) ++c;
         return c;
@@ -282,17 +282,17 @@ __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __r
         bool stepped = false;
         if (__ballot(pairable)) {
             const uint32_t pc = pairable ? (x - 1u) * 4u + (y - 1u) : 0u;
-            const uint32_t a = (uint32_t)lb, b = (uint32_t)(lb + len);
-            const uint32_t la = pairable ? a >> 7 : 0u, lbn = pairable ? b >> 7 : 0u;
+            const idx_t a = lb, b = lb + len;
+            const uint32_t la = pairable ? (uint32_t)(a >> 7) : 0u, lbn = pairable ? (uint32_t)(b >> 7) : 0u;      // (n < 2^38: a line number fits 31 bits)
             const bool far = pairable && la != lbn;
             coop_round(pairs, la, lane, wave_lds);
             __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0): the round's pieces are in LDS
             asm volatile("" ::: "memory");
-            uint32_t ra = 0, rb = 0;
+            idx_t ra = 0, rb = 0;
             if (pairable) {
                 acc2 += far ? 2u : 1u;
-                ra = pair_rank_lds(own, a, pc);
-                if (!far) rb = pair_rank_lds(own, b, pc);
+                ra = pair_rank_lds(own, (uint32_t)a, pc);
+                if (!far) rb = pair_rank_lds(own, (uint32_t)b, pc);
             }
             if (__ballot(far)) {                                    // the other end's lines, where they are other lines (the first ~14 symbols of a read)
                 __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): every lane has read what it needs of the first round
@@ -300,9 +300,13 @@ __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __r
                 coop_round(pairs, far ? lbn : 0u, lane, wave_lds);
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 asm volatile("" ::: "memory");
-                if (far) rb = pair_rank_lds(own, b, pc);
+                if (far) rb = pair_rank_lds(own, (uint32_t)b, pc);
             }
             if (pairable) {
+                if constexpr (kWide) {                              // the line's counts are relative to its super-block of 2^30 rows
+                    const idx_t sa = psuper[(size_t)(a >> kSuperShift) * 16u + pc];
+                    ra += sa; rb += (a >> kSuperShift) == (b >> kSuperShift) ? sa : psuper[(size_t)(b >> kSuperShift) * 16u + pc];
+                }
                 if (pc == 0u) { ra -= listed_before(a); rb -= listed_before(b); }
                 if (rb > ra) { lb = ra; len = rb - ra; steps += 2u; stepped = true; }
             }
@@ -3578,13 +3582,9 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         // k_exact_a runs best with 5 resident blocks per CU, not the 8 its 28 registers allow (measured on the 3.09 Gbp index, 10 M x 101 bp: 8 / 6 / 5 / 4 / 3
         // blocks = 19.53 / 19.23 / 18.92 / 19.10 / 18.95 ms — more waves only queue up at the memory system): 28 KB of unused dynamic LDS set the residency
         const size_t lds_a = dev_env("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)28 * 1024;
-        if constexpr (!kWide) {
-            if (x->bwt.sigma == 5 && x->bwt.pairs && !(dev_flags_env() & (1 << 22))) {
-                k_exact_p<<<grid, block, 4 * 8 * kCoopRegion + dev_extra_lds, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, qb, qo, nq, n, ol, on, dsteps);
-            } else if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
-            else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
-        } else
-        if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
+        if (x->bwt.sigma == 5 && x->bwt.pairs && !(dev_flags_env() & (1 << 22)))
+            k_exact_p<<<grid, block, 4 * 8 * kCoopRegion + dev_extra_lds, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, x->bwt.pairs_super, qb, qo, nq, n, ol, on, dsteps);
+        else if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
     } else if (x->bwt.search_family() == FAM_WAVELET && x->bwt.flat && !(dev_flags_env() & (1 << 21))) {
         const size_t super_bytes = (size_t)x->bwt.flat_nsb * x->bwt.sigma * sizeof(idx_t);

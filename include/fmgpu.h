@@ -27,8 +27,8 @@
  *     cursor steps, String_c queries and the index file work on it; the multi-symbol-step table, the k-mismatch tables (LF^1..3, walk, prefix),
  *     the locate answer table and the one-word transport forms return FMGPU_ERR_UNSUPPORTED (fmgpu_index_row_bits tells which).
  *   - derived occurrence tables: beside the layout it is handed, an index keeps what its kernels read fastest, built on the device at creation,
- *     construction and load and counted in device_bytes — sigma = 5, 32-bit rows: a symbol-pair table (1 byte per row; exact search takes two
- *     symbols per step) and, for a BiFMIndex, dense DNA blocks (0.5 byte per row and direction; the equal-length k-mismatch kernel); a Wavelet
+ *     construction and load and counted in device_bytes — sigma = 5: a symbol-pair table (1 byte per row; exact search takes two symbols per
+ *     step; both row widths) and, for a BiFMIndex with 32-bit rows, dense DNA blocks (0.5 byte per row and direction; the equal-length k-mismatch kernel); a Wavelet
  *     bwt with 6 <= sigma <= 29: a symbol-plane table (2 bytes per row; exact search takes one memory line per step and interval end instead of
  *     one per tree level).  Results do not depend on them (FMGPU_PAIRS=0 / FMGPU_DENSE_DNA=0 / FMGPU_FLAT=0 in the environment keep them out).
  */

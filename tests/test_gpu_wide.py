@@ -214,3 +214,34 @@ def test_wide_gpu_builder(layout, sigma, bidir):
     seq, pos, steps = gx.locate(rows)
     for r in range(0, rows.size, 11):
         assert (seq[r], pos[r], steps[r]) == ox.locate(int(r))
+
+
+@pytest.mark.parametrize("shape", ["repeats", "many_sequences", "poly_a"])
+def test_wide_exact_search_in_pair_steps(shape, monkeypatch):
+    """Format P / k_exact_p on 64-bit rows (line counts relative to super-blocks of 2^30 rows + a super table, listed rows as 64-bit numbers):
+    intervals, miss rows and step counts equal the oracle's and the one-symbol kernel's"""
+    rng = np.random.default_rng(78)
+    if shape == "repeats":
+        seqs = repeat_text(6, n=6000)
+    elif shape == "many_sequences":
+        seqs = [rng.integers(1, 5, size=int(rng.integers(1, 90)), dtype=np.uint8) for _ in range(250)]
+    else:
+        seqs = [np.where(rng.random(int(rng.integers(2, 700))) < 0.85, 1, rng.integers(1, 5, size=1)[0]).astype(np.uint8) for _ in range(60)]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 4, False)
+    gx = wide_index(ox)
+    monkeypatch.setenv("FMGPU_PAIRS", "0")
+    gx_single = wide_index(ox)
+    monkeypatch.delenv("FMGPU_PAIRS")
+    assert gx.device_bytes > gx_single.device_bytes
+    queries = mutated_queries([q for q in seqs if len(q) > 2], 1500, 1, 140, 2, seed=6)
+    queries += [[], [1], [1, 1], [1, 1, 1], [4, 4, 4, 4], [0], [1, 0], [0, 1], [1, 0, 1, 1], [2, 1, 0], [1] * 64, [1] * 65, [1] * 129, [2, 1], [1, 2]]
+    for s_ in seqs[:40]:
+        queries += [s_, s_[-3:], s_[:3], np.concatenate([s_[-2:], [0]]), np.concatenate([[0], s_[:2]])]
+    qbuf, qoff = fm.flatten(queries)
+    olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
+    for flags in ("0", str(1 << 22)):
+        monkeypatch.setenv("FMGPU_DEV_FLAGS", flags)
+        for g in (gx, gx_single):
+            lb, ln, st = fm.search_no_errors.search(g, (qbuf, qoff), want_stats=True)
+            assert np.array_equal(ln, oln) and np.array_equal(lb, olb), (shape, flags)
+            assert st.lf_steps == int(ost.sum())
