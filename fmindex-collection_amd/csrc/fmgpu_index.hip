@@ -368,7 +368,7 @@ __global__ void k_flat_super(const idx_t* __restrict__ C, const uint32_t* __rest
 int build_flat_table(Index* x, hipStream_t stream) {
     DevString& s = x->bwt;
     const char* off = getenv("FMGPU_FLAT");
-    if (s.family != FAM_WAVELET || s.sigma < 6 || s.sigma > 29 || s.n < 2 || s.flat || (off && atoi(off) == 0)) return 0;
+    if (s.family != FAM_WAVELET || s.sigma < 6 || s.sigma > 29 || s.n < 2 || s.n >= (1ull << 38) || s.flat || (off && atoi(off) == 0)) return 0;   // (n < 2^38: a line number fits 32 bits in k_exact_s)
     const uint64_t nlines = s.n / 64 + 1;
     const uint32_t nsb = (uint32_t)(s.n >> kFlatSuperShift) + 1u, sigma = (uint32_t)s.sigma;
     DBuf out, cnt8, totals, super; int rc;
