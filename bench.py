@@ -436,7 +436,7 @@ def run_dna_text(c, name, primary):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
     legs = ["exact", "k2", "k2_151"]
-    ids = ["%s/%s/%s" % (name, w, i) for w in legs + ["locate"] for i in ("plain", "tables")] + ["%s/k2_edit/tables" % name, "%s/exact/single" % name]
+    ids = ["%s/%s/%s" % (name, w, i) for w in legs + ["locate"] for i in ("plain", "tables")] + ["%s/k2_edit/tables" % name, "%s/k2_edit/plain" % name, "%s/exact/single" % name]
     if c.only and not any(i in c.only for i in ids):
         return []
     text, seq_off, lengths, tinfo = make_text(c, name)
@@ -616,7 +616,7 @@ def run_dna_text(c, name, primary):
     scheme = fm.search_scheme.h2(4, 0, 2)
     k2_legs = [("k2", 101, nq if not c.multi else 0), ("k2_151", 151, (args.total_k2_reads // c.world) if c.multi else min(12_500_000, max(1, int(12_500_000 * min(1.0, nq / 10_000_000)))))]
     k2_legs = [(w, L, n_) for (w, L, n_) in k2_legs if n_ > 0 and (any(wanted(c, "%s/%s/%s" % (name, w, i)) for i in ("plain", "tables"))
-                                                                    or (w == "k2" and args.with_edit and not c.multi and wanted(c, "%s/k2_edit/tables" % name)))]
+                                                                    or (w == "k2" and args.with_edit and not c.multi and (wanted(c, "%s/k2_edit/tables" % name) or wanted(c, "%s/k2_edit/plain" % name))))]
     if k2_legs:
         os.environ["FMGPU_LF_TABLE"] = "0"
         t0 = time.time()
@@ -702,6 +702,13 @@ def run_dna_text(c, name, primary):
 
         for (w, L, n_) in k2_legs:
             out.append(k2_run(w, L, n_, "plain", build_plain))
+        if args.with_edit and not c.multi and any(w == "k2" for w, _, _ in k2_legs) and wanted(c, "%s/k2_edit/plain" % name):
+            qb, qo = reads["k2"]                                    # edit distance (the reference's default, search_ng26<true>) on the plain index: one-row nodes read their row's block
+            n_e = min(2_000_000, nq)
+            full = reads["k2"]
+            reads["k2"] = (qb[: n_e * 101], qo[: n_e + 1])
+            out.append(k2_run("k2", 101, n_e, "plain", build_plain, edit=True))
+            reads["k2"] = full
         # the optional tables (LF, prefix, walk: 224 GB at this size).  N > 1 runs on the plain ~6 GB index north_star replicates, unless --multi-tables
         want_tab = (not c.multi or args.multi_tables) and (any(wanted(c, "%s/%s/tables" % (name, w)) for w, _, _ in k2_legs) or
                                                             (args.with_edit and not c.multi and wanted(c, "%s/k2_edit/tables" % name)))

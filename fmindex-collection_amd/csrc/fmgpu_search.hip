@@ -2439,11 +2439,16 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
         // resumed, or that an insertion or a cached deletion led to, knows its LF value and loads nothing (about half of the iterations)
         constexpr bool kSplit = SIGMA > 0 && SIGMA <= 5;
         const uint8_t* blk = (right ? rv : fw).v.blk;
+        // (the plain index — no LF table, sigma = 5: a one-row node reads its row's symbol and LF off the row's block, like a multi-row node reads its counts)
+        const bool plain = kSplit && fa.lf_fw == nullptr;
         const uint8_t* p0 = lut_start ? reinterpret_cast<const uint8_t*>(fa.lut + lut_code)
-                          : (multi && kSplit) ? blk + (size_t)(a >> 6) * 64u
+                          : ((multi && kSplit) || plain) ? blk + (size_t)(a >> 6) * 64u
                           : reinterpret_cast<const uint8_t*>((right ? fa.lf_rv : fa.lf_fw) + a);
         uint4 r0 = make_uint4(0, 0, 0, 0);
-        if (lut_start || multi || (!resuming && !lf_known)) r0 = *reinterpret_cast<const uint4*>(p0);
+        const bool row_load = !lut_start && !multi && !resuming && !lf_known;
+        if (lut_start || multi || row_load) r0 = *reinterpret_cast<const uint4*>(p0);
+        uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1, q3 = q1;
+        if (plain && row_load) { const uint4* pa = reinterpret_cast<const uint4*>(p0); q1 = pa[1]; q2 = pa[2]; q3 = pa[3]; }
         bool back = false, search_over = false;
         if (lut_start) {
             cur = Cur{r0.x, r0.y, r0.z};
@@ -2470,6 +2475,16 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
             } else {
                 if (!resuming) {
                     lf1 = lf_known ? lf_val : (idx_t)r0.x;
+                    if (plain && row_load) {                        // the symbol that claims the row and its LF; a delimiter row: 0 (below C[1]: symbol 0, a dead end)
+                        const uint32_t dd[16] = {r0.x, r0.y, r0.z, r0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                        const uint32_t bit = (uint32_t)a & 63u;
+                        lf1 = 0;
+#pragma unroll
+                        for (uint32_t s_ = 1; s_ < 5u; ++s_) {
+                            const uint64_t bits = (uint64_t)dd[3 * s_ + 1] | ((uint64_t)dd[3 * s_ + 2] << 32);
+                            if ((bits >> bit) & 1ull) lf1 = dd[3 * s_] + popc64(bits & lowmask(bit));
+                        }
+                    }
                     if (report_slot != kNoResume) reinterpret_cast<uint32_t*>(frames + 2u * report_slot)[2] = lf1;
                 }
                 alive.clear(); alive.insert(symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, lf1));
@@ -3808,7 +3823,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     // 16-symbol walk: 2-bit symbols, queries staged in LDS as nibbles
     const bool have_lf = x->bwt.lf_table && x->rev.lf_table;
     const bool use_wj = !edit && !(sd.dev_flags & 32) && have_lf && x->bwt.walkj && x->rev.walkj && x->bwt.walk_bits == 2 && x->rev.walk_bits == 2 && qnib && qwords;
-    const bool fast_ok = scheme_mode && x->bwt.search_family() == FAM_A && (have_lf || (!edit && x->bwt.sigma == 5)) && x->bwt.sigma <= 32 && !(sd.dev_flags & 2);
+    const bool fast_ok = scheme_mode && x->bwt.search_family() == FAM_A && (have_lf || x->bwt.sigma == 5) && x->bwt.sigma <= 32 && !(sd.dev_flags & 2);   // (sigma = 5: the fast kernels also run on the plain index)
     const uint32_t lutL = (sd.dev_flags & 4) ? 0 : x->lut_len;
     // one launch of the table-driven kernel per query length: an equal-length batch is one bucket; a ragged batch is sorted by length on the
     // device (the kernel reads its queries through the sorted index) as long as the buckets stay large enough to be worth a launch each

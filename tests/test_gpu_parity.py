@@ -874,6 +874,49 @@ def test_edit_distance_equal_length_fast_path(k, length, sigma):
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)[0])
 
 
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+@pytest.mark.parametrize("length", [30, 101])
+def test_edit_distance_fast_kernel_on_the_plain_index(k, length):
+    """edit distance (search_ng26<true>, the reference's default) on a BiFMIndex<5> WITHOUT any table: equal-length batches take k_scheme_fast_edit, whose
+    one-row nodes read the row's symbol and LF off the row's block — cursors, errors, callback order and extension counts equal the CPU walk and
+    the general kernel (FMGPU_DEV_FLAGS bit 1); reads with delimiters inside; search_n clipping"""
+    rng = np.random.default_rng(300 + k + length)
+    seqs = repeat_text(40 + k, n=6000) + [np.tile(np.array([1, 1, 2], dtype=np.uint8), 200)]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
+    os.environ["FMGPU_LF_TABLE"] = "0"
+    try:
+        gx = gpu_index(ox)
+    finally:
+        del os.environ["FMGPU_LF_TABLE"]
+    queries = []
+    src = [q for q in seqs if len(q) > length + 8]
+    for i in range(600 if k < 3 else 120):
+        s_ = src[i % len(src)]
+        p = int(rng.integers(0, len(s_) - length - 8)); q = list(s_[p: p + length + 6])
+        for _ in range(int(rng.integers(0, k + 2))):
+            op = int(rng.integers(0, 3)); jj = int(rng.integers(0, len(q)))
+            if op == 0: q[jj] = int(rng.integers(1, 5))
+            elif op == 1: q.insert(jj, int(rng.integers(1, 5)))
+            else: del q[jj]
+        queries.append(np.array(q[:length], dtype=np.uint8))
+    queries[3][length // 2] = 0; queries[4][0] = 0
+    assert len({len(q) for q in queries}) == 1
+    qbuf, qoff = fm.flatten(queries)
+    for sch in (fm.search_scheme.h2(k + 2, 0, k), fm.search_scheme.pigeon_opt(0, k)):
+        ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 22)
+        assert len(ohits) > 0
+        for flags in ("0", "2"):
+            os.environ["FMGPU_DEV_FLAGS"] = flags
+            try:
+                hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 22)
+            finally:
+                del os.environ["FMGPU_DEV_FLAGS"]
+            assert same_hits(hits, ohits) and st.lf_steps == nodes, (k, length, flags)
+    sch = fm.search_scheme.h2(k + 2, 0, k)
+    for n in (1, 4):
+        assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=n, edit=True), ox.search_ng26(qbuf, qoff, sch, max_hits=n, edit=True)[0])
+
+
 def test_edit_distance_on_a_repeat_structured_text():
     """k = 2 edit distance on 4 Mbp of the genome-like text (repeat families, satellites, single-symbol runs): reads out of repeats visit 10^4 - 10^6
     nodes where the median read visits hundreds, so the lanes of a wave hand subtrees to each other all the time (k_scheme_fast_edit) and the
