@@ -709,7 +709,7 @@ def run_dna_text(c, name, primary):
             reads["k2"] = (qb[: n_e * 101], qo[: n_e + 1])
             out.append(k2_run("k2", 101, n_e, "plain", build_plain, edit=True))
             reads["k2"] = full
-        # the optional tables (LF, prefix, walk: 224 GB at this size).  N > 1 runs on the plain ~6 GB index north_star replicates, unless --multi-tables
+        # the optional tables (LF, prefix, walk: 224 GB at this size).  N > 1 runs on the plain index north_star replicates, unless --multi-tables
         want_tab = (not c.multi or args.multi_tables) and (any(wanted(c, "%s/%s/tables" % (name, w)) for w, _, _ in k2_legs) or
                                                             (args.with_edit and not c.multi and wanted(c, "%s/k2_edit/tables" % name)))
         if want_tab:
