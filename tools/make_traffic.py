@@ -7,7 +7,7 @@ RECORDS = {"genome/exact/plain": ("exact_plain", "k_exact_p"), "genome/exact/sin
            "genome/k2/plain": ("k2_plain", "k_scheme_lean"), "genome/k2_151/plain": ("k2_151_plain", "k_scheme_lean"), "genome/k2/tables": ("k2_tables", "k_scheme_fast"),
            "genome/locate/plain": ("locate_plain", "k_locate_fused"),
            "protein/exact/wavelet": ("protein_wavelet", "k_exact_s"), "protein/exact/tree": ("protein_tree", "k_exact_m"), "protein_wide/exact/wavelet": ("protein_wide", "k_exact_s"),
-           "genome/k2_edit/tables": ("edit_genome", "k_scheme_fast_edit"), "uniform/k2_edit/tables": ("edit_uniform", "k_scheme_fast_edit")}
+           "genome/k2_edit/tables": ("edit_genome", "k_scheme_fast_edit"), "genome/k2_edit/plain": ("edit_plain", "k_scheme_fast_edit"), "uniform/k2_edit/tables": ("edit_uniform", "k_scheme_fast_edit")}
 out = {}
 for rid, (tag, kernel) in RECORDS.items():
     path = os.path.join(ROOT, "profiles", "%s_%s_rocprof_summary.json" % (RND, tag))
