@@ -673,11 +673,13 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
         if ((rc = build_lf_table(x->bwt, stream))) return bail(rc);
         if (x->bidirectional && (rc = build_lf_table(x->rev, stream))) return bail(rc);
     }
+    if ((rc = auto_shadow(x.get(), stream))) return bail(rc);
     if (x->bidirectional) {
         for (DevString* t : {&x->bwt, &x->rev}) if ((rc = build_dense_dna(*t, stream))) return bail(rc);
         if (x->bwt.dense && !x->rev.dense) { (void)hipFree(x->bwt.dense); (void)hipFree(x->bwt.dense_ex); x->bwt.dense = nullptr; x->bwt.dense_ex = nullptr; x->bwt.dense_bytes = 0; x->bwt.dense_nex = 0; }
     }
     x->device_bytes += x->bwt.blk_bytes + x->bwt.aux_bytes + x->bwt.sup_bytes + x->rev.blk_bytes + x->rev.aux_bytes + x->rev.sup_bytes + x->bwt.dense_bytes + x->rev.dense_bytes +
+                       x->bwt.shadow_bytes + x->rev.shadow_bytes +
                        (x->bwt.lf_table ? n * sizeof(idx_t) : 0) + (x->rev.lf_table ? n * sizeof(idx_t) : 0);
     if ((rc = fuse_presence_bits(x.get(), stream))) return bail(rc);
     if ((rc = build_pair_table(x.get(), stream))) return bail(rc);

@@ -705,6 +705,10 @@ int build_dense_dna(DevString& s, hipStream_t stream);
 int fuse_presence_bits(Index* x, hipStream_t stream);
 // builds Format P beside the bwt of a sigma = 5 index with 32-bit rows (no-op where it does not apply; adds its bytes to device_bytes); defined in fmgpu_index.hip
 int build_pair_table(Index* x, hipStream_t stream);
+// sigma = 5 strings that arrived in another layout's own format (EPR / EPRV2 blocks read in place, the multi-ary wavelet tree) get the Format A expansion at once, so
+// that every search of the DNA path runs on the same kernels whatever layout the caller's index has (FMGPU_SHADOW=0: only on fmgpu_index_accelerate); adds nothing to
+// device_bytes itself; defined in fmgpu_index.hip
+int auto_shadow(Index* x, hipStream_t stream);
 // builds Format S beside the Wavelet bwt of an index with 6 <= sigma <= 29 (no-op where it does not apply; adds its bytes to device_bytes); defined in fmgpu_index.hip
 int build_flat_table(Index* x, hipStream_t stream);
 void free_string(DevString& s);

@@ -277,7 +277,13 @@ int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
             s.vm.super = (kWide && s.sup) ? reinterpret_cast<const uint64_t*>((const uint8_t*)s.sup + o.vm_super_off) : nullptr;
         }
     }
-    // Format D is derived data (a few ms): rebuilt rather than stored
+    // derived data is rebuilt rather than stored: the Format A expansion of a sigma = 5 string of another layout (unless the file carried it with its tables) ...
+    {
+        const size_t had = x->bwt.shadow_bytes + x->rev.shadow_bytes;
+        if ((rc = auto_shadow(x.get(), nullptr))) return bail(rc);
+        x->device_bytes += x->bwt.shadow_bytes + x->rev.shadow_bytes - had;
+    }
+    // ... Format D (a few ms)
     if (x->bidirectional) {
         for (DevString* t : {&x->bwt, &x->rev}) if ((rc = build_dense_dna(*t, nullptr))) return bail(rc);
         if (x->bwt.dense && !x->rev.dense) { (void)hipFree(x->bwt.dense); (void)hipFree(x->bwt.dense_ex); x->bwt.dense = nullptr; x->bwt.dense_ex = nullptr; x->bwt.dense_bytes = 0; x->bwt.dense_nex = 0; }

@@ -144,6 +144,17 @@ int fuse_presence_bits(Index* x, hipStream_t stream) {
     return 0;
 }
 
+int auto_shadow(Index* x, hipStream_t stream) {
+    const char* off = getenv("FMGPU_SHADOW");
+    if (x->bwt.sigma != 5 || (off && atoi(off) == 0)) return 0;
+    for (DevString* t : {&x->bwt, &x->rev}) {
+        if (t->n == 0 || t->family == FAM_A || t->shadow) continue;
+        int rc = build_format_a_shadow(*t, x->dC, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // ---- Format D (fmgpu_common.h): from the Format A blocks of a sigma = 5 string.  One thread per block; a delimiter row (no symbol >= 1 claims it) is appended to the list
 constexpr uint32_t kDenseMaxDelims = 256;
 __global__ __launch_bounds__(256) void k_dense_dna(const uint8_t* __restrict__ blk, uint64_t nblocks, uint64_t n, uint4* __restrict__ out, uint32_t* __restrict__ ex, uint32_t* __restrict__ nex) {
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256) void k_dense_dna(const uint8_t* __restrict__ b
 }
 int build_dense_dna(DevString& s, hipStream_t stream) {
     const char* off = getenv("FMGPU_DENSE_DNA");
-    if (kWide || s.sigma != 5 || s.family != FAM_A || s.shadow || s.va.bstride != 64u || s.n < 2 || s.dense || (off && atoi(off) == 0)) return 0;
+    if (kWide || s.sigma != 5 || s.search_family() != FAM_A || s.va.bstride != 64u || s.n < 2 || s.dense || (off && atoi(off) == 0)) return 0;   // (Format A blocks: the string's own or its expansion)
     // (reads the entries of symbols 1..4 only: entry 0's bitmap may already hold the presence bits)
     const uint64_t nblocks = s.n / 64 + 1;
     DBuf out, ex, cnt; int rc;
@@ -175,7 +186,7 @@ int build_dense_dna(DevString& s, hipStream_t stream) {
     FM_HIP(hipMemsetAsync(cnt.p, 0, 8, stream));
     FM_HIP(hipMemsetAsync(ex.p, 0xff, kDenseMaxDelims * 4, stream));
     FM_GRID(grid, nblocks);
-    k_dense_dna<<<grid, dim3(256), 0, stream>>>((const uint8_t*)s.blk, nblocks, s.n, out.as<uint4>(), ex.as<uint32_t>(), cnt.as<uint32_t>());
+    k_dense_dna<<<grid, dim3(256), 0, stream>>>(s.va.blk, nblocks, s.n, out.as<uint4>(), ex.as<uint32_t>(), cnt.as<uint32_t>());
     FM_LAUNCHED("k_dense_dna");
     uint32_t nex = 0;
     FM_HIP(hipMemcpyAsync(&nex, cnt.p, 4, hipMemcpyDeviceToHost, stream));
@@ -273,7 +284,7 @@ __global__ void k_pair_super(OccA<5> occ, const uint64_t* __restrict__ totals, u
 int build_pair_table(Index* x, hipStream_t stream) {
     DevString& s = x->bwt;
     const char* off = getenv("FMGPU_PAIRS");
-    if (s.sigma != 5 || s.family != FAM_A || s.shadow || s.va.bstride != 64u || s.n < 2 || s.n >= (1ull << 38) || s.pairs || (off && atoi(off) == 0)) return 0;
+    if (s.sigma != 5 || s.search_family() != FAM_A || s.va.bstride != 64u || s.n < 2 || s.n >= (1ull << 38) || s.pairs || (off && atoi(off) == 0)) return 0;
     const uint64_t nlines = s.n / 128 + 1;
     DBuf out, part, ex, cnt, tmp, totals, super; int rc;
     if ((rc = out.alloc(nlines * 128)) || (rc = part.alloc(nlines * 16 * 4)) || (rc = ex.alloc(kPairMaxRows * sizeof(idx_t))) || (rc = cnt.alloc(8))) return rc;
@@ -959,6 +970,7 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
     if (rc) return bail(rc);
     rc = create_string(desc->bwt, x->dC, x->bwt); if (rc) return bail(rc);
     if (desc->bwt_rev) { rc = create_string(*desc->bwt_rev, x->dC, x->rev); if (rc) return bail(rc); x->bidirectional = true; }
+    rc = auto_shadow(x.get(), nullptr); if (rc) return bail(rc);
     if (x->bidirectional) for (DevString* t : {&x->bwt, &x->rev}) { rc = build_dense_dna(*t, nullptr); if (rc) return bail(rc); }
     if (x->bwt.dense && !x->rev.dense) { (void)hipFree(x->bwt.dense); (void)hipFree(x->bwt.dense_ex); x->bwt.dense = nullptr; x->bwt.dense_ex = nullptr; x->bwt.dense_bytes = 0; x->bwt.dense_nex = 0; }
     if (lf_table_wanted()) {
@@ -966,6 +978,7 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
         if (x->bidirectional) { rc = build_lf_table(x->rev, nullptr); if (rc) return bail(rc); }
     }
     x->device_bytes = x->bwt.blk_bytes + x->bwt.aux_bytes + x->bwt.sup_bytes + x->rev.blk_bytes + x->rev.aux_bytes + x->rev.sup_bytes + x->bwt.dense_bytes + x->rev.dense_bytes +
+                      x->bwt.shadow_bytes + x->rev.shadow_bytes +
                       (x->bwt.lf_table ? x->bwt.n * sizeof(idx_t) : 0) + (x->rev.lf_table ? x->rev.n * sizeof(idx_t) : 0);
     rc = build_pair_table(x.get(), nullptr); if (rc) return bail(rc);
     rc = build_flat_table(x.get(), nullptr); if (rc) return bail(rc);

@@ -738,10 +738,29 @@ def test_occurrence_table_expansion(layout, sigma):
     base = rng.integers(1, sigma, size=1300, dtype=np.uint8)
     seqs = [np.concatenate([base, base[100:500]]), rng.integers(1, sigma, size=700, dtype=np.uint8)]
     ox = fo.OraIndex.build(layout, sigma, seqs, 4, True)
-    gx = gpu_index(ox)
+    os.environ["FMGPU_SHADOW"] = "0"                          # (sigma = 5 strings get the expansion at creation unless told otherwise: below)
+    try:
+        gx = gpu_index(ox)
+    finally:
+        del os.environ["FMGPU_SHADOW"]
     before = gx.device_bytes
     gx.accelerate(1)
     assert gx.device_bytes > before
+    if sigma == 5:
+        auto = gpu_index(ox)                                  # the same index as it is created by default: expanded (and with the formats derived from the expansion)
+        assert auto.device_bytes >= gx.device_bytes
+        qb_, qo_ = fm.flatten(mutated_queries(seqs, 400, 24, 25, 2, seed=3, sigma=sigma))
+        a_hits, a_st = fm.search_ng26.search(auto, (qb_, qo_), fm.search_scheme.h2(4, 0, 2), want_stats=True)
+        o_hits, _, o_nodes = ox.search_ng26(qb_, qo_, fm.search_scheme.h2(4, 0, 2))
+        assert same_hits(a_hits, o_hits) and a_st.lf_steps == o_nodes
+        a_lb, a_ln, a_st = fm.search_no_errors.search(auto, (qb_, qo_), want_stats=True)
+        o_lb, o_ln, o_steps = ox.search_exact(qb_, qo_, want_steps=True)
+        assert np.array_equal(a_lb, o_lb) and np.array_equal(a_ln, o_ln) and a_st.lf_steps == int(o_steps.sum())
+        rows_ = np.arange(0, ox.n, 11, dtype=np.uint64)
+        assert [tuple(int(v) for v in t) for t in zip(*auto.locate(rows_))] == [ox.locate(int(r)) for r in rows_]
+        auto.accelerate(0)                                     # dropping the expansion: the layout's own kernels again, same answers
+        assert np.array_equal(fm.search_no_errors.search(auto, (qb_, qo_))[1], o_ln)
+        assert same_hits(fm.search_ng26.search(auto, (qb_, qo_), fm.search_scheme.h2(4, 0, 2)), o_hits)
     same = [q for q in mutated_queries(seqs, 600, 24, 25, 2, seed=sigma, sigma=sigma)]
     ragged = mutated_queries(seqs, 300, 1, 60, 1, seed=sigma + 1, sigma=sigma)
     sch = fm.search_scheme.h2(3, 0, 1)
