@@ -43,7 +43,7 @@
 //     the counts and are listed (`pairs_ex`, ascending) behind a filter on the line number; built when there are at most 512 of them.
 //     64-bit rows (n < 2^38): the line's counts are relative to its super-block of 2^30 rows, `pairs_super[sb][16]` holds the interval start + the count before it.
 //
-//  Format S  ("symbol planes": the bwt of a Wavelet index with 6 <= sigma <= 29, beside Format M — what exact search reads there, one line per LF step and end):
+//  Format S  ("symbol planes": the bwt of an index with 6 <= sigma <= 29 that arrived as a Wavelet or as EPR / EPRV2 blocks, beside Format M / R — what exact search reads there, one line per LF step and end):
 //     one line of 128 bytes per 64 rows:  u64 plane[5] = bit k of each row's symbol;  then sigma 3-byte numbers = the rows before the line that hold
 //     symbol c, counted from the start of the line's super-block of 2^24 rows (read with one unaligned dword load);  flat_super[sb][c] = C[c] + the rows holding c before
 //     super-block sb (sigma * 3 + 40 <= 128 bytes: sigma <= 29).  LF(i, c) = flat_super[i >> 24][c] + count24[c] + popcount(rows of the line below i

@@ -330,7 +330,8 @@ int build_pair_table(Index* x, hipStream_t stream) {
 
 // ---- Format S (fmgpu_common.h): a flat one-line-per-64-rows occurrence table from the symbols of a Wavelet string.
 constexpr uint32_t kFlatSuperShift = 24;            // rows per super-block: the counts inside a line are 24 bits wide
-__global__ __launch_bounds__(256) void k_flat_planes(OccM occ, uint64_t n, uint32_t sigma, uint8_t* __restrict__ lines, uint8_t* __restrict__ cnt8, uint64_t nlines) {
+template <class Occ>
+__global__ __launch_bounds__(256) void k_flat_planes(Occ occ, uint64_t n, uint32_t sigma, uint8_t* __restrict__ lines, uint8_t* __restrict__ cnt8, uint64_t nlines) {
     const uint32_t lane = threadIdx.x & 63u;
     // (a grid-stride loop: a launch of more than 2^32 threads is not a thing HIP does)
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; (i >> 6) < nlines; i += (uint64_t)gridDim.x * 256u) {
@@ -379,14 +380,19 @@ __global__ void k_flat_super(const idx_t* __restrict__ C, const uint32_t* __rest
 int build_flat_table(Index* x, hipStream_t stream) {
     DevString& s = x->bwt;
     const char* off = getenv("FMGPU_FLAT");
-    if (s.family != FAM_WAVELET || s.sigma < 6 || s.sigma > 29 || s.n < 2 || s.n >= (1ull << 38) || s.flat || (off && atoi(off) == 0)) return 0;   // (n < 2^38: a line number fits 32 bits in k_exact_s)
+    // (beside a Wavelet, or EPR / EPRV2 blocks read in place: Format A reads one line per step and end already; n < 2^38: a line number fits 32 bits in k_exact_s)
+    if (s.family == FAM_A || s.sigma < 6 || s.sigma > 29 || s.n < 2 || s.n >= (1ull << 38) || s.flat || (off && atoi(off) == 0)) return 0;
     const uint64_t nlines = s.n / 64 + 1;
     const uint32_t nsb = (uint32_t)(s.n >> kFlatSuperShift) + 1u, sigma = (uint32_t)s.sigma;
     DBuf out, cnt8, totals, super; int rc;
     if ((rc = out.alloc(nlines * 128)) || (rc = cnt8.alloc(nlines * sigma)) || (rc = totals.alloc((size_t)nsb * sigma * 4)) || (rc = super.alloc((size_t)nsb * sigma * sizeof(idx_t)))) return rc;
     FM_HIP(hipMemsetAsync(out.p, 0, out.bytes, stream));
     dim3 grid; if ((rc = grid_of(nlines * 64, &grid, 1u << 22))) return rc;
-    k_flat_planes<<<grid, dim3(256), 0, stream>>>(OccM{s.vm}, s.n, sigma, out.as<uint8_t>(), cnt8.as<uint8_t>(), nlines);
+    rc = dispatch_native(s, [&](auto occ, auto) {
+        k_flat_planes<decltype(occ)><<<grid, dim3(256), 0, stream>>>(occ, s.n, sigma, out.as<uint8_t>(), cnt8.as<uint8_t>(), nlines);
+        return 0;
+    });
+    if (rc) return rc;
     FM_LAUNCHED("k_flat_planes");
     k_flat_counts<<<dim3(nsb, sigma), dim3(256), 0, stream>>>(cnt8.as<uint8_t>(), nlines, sigma, out.as<uint8_t>(), totals.as<uint32_t>());
     FM_LAUNCHED("k_flat_counts");

@@ -3601,7 +3601,7 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
             k_exact_p<<<grid, block, 4 * 8 * kCoopRegion + dev_extra_lds, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, x->bwt.pairs_super, qb, qo, nq, n, ol, on, dsteps);
         else if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
-    } else if (x->bwt.search_family() == FAM_WAVELET && x->bwt.flat && !(dev_flags_env() & (1 << 21))) {
+    } else if (x->bwt.flat && x->bwt.search_family() != FAM_A && !(dev_flags_env() & (1 << 21))) {
         const size_t super_bytes = (size_t)x->bwt.flat_nsb * x->bwt.sigma * sizeof(idx_t);
         const uint32_t super_lds = super_bytes <= 16 * 1024 ? x->bwt.flat_nsb * (uint32_t)x->bwt.sigma : 0u;      // (2 x 10^9 rows, sigma = 28: 13 KB)
         k_exact_s<<<grid, block, 4 * 8 * kCoopRegion + (super_lds ? super_bytes : 0) + dev_extra_lds, stream>>>(x->bwt.flat, x->bwt.flat_super, (uint32_t)x->bwt.sigma, (const uint8_t*)sbuf.dev,

@@ -29,7 +29,7 @@
  *   - derived occurrence tables: beside the layout it is handed, an index keeps what its kernels read fastest, built on the device at creation,
  *     construction and load and counted in device_bytes — sigma = 5: a symbol-pair table (1 byte per row; exact search takes two symbols per
  *     step; both row widths) and, for a BiFMIndex with 32-bit rows, dense DNA blocks (0.5 byte per row and direction; the equal-length k-mismatch kernel); a Wavelet
- *     bwt with 6 <= sigma <= 29: a symbol-plane table (2 bytes per row; exact search takes one memory line per step and interval end instead of
+ *     or EPR / EPRV2 bwt with 6 <= sigma <= 29: a symbol-plane table (2 bytes per row; exact search takes one memory line per step and interval end instead of
  *     one per tree level); a sigma = 5 string handed over as InterleavedEPR* / InterleavedEPRV2* blocks or as a Wavelet: the one-symbol block table every
  *     other DNA layout is held in (1 byte per row), and with it the two tables above — every layout searches at the same speed.
  *     Results do not depend on them (FMGPU_PAIRS=0 / FMGPU_DENSE_DNA=0 / FMGPU_FLAT=0 / FMGPU_SHADOW=0 in the environment keep them out).

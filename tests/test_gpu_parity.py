@@ -182,6 +182,35 @@ def test_exact_search_on_symbol_planes(sigma, built_on_gpu, monkeypatch):
     assert not a[1].any() and np.array_equal(a[0], b[0]) and a[2].lf_steps == b[2].lf_steps
 
 
+@pytest.mark.parametrize("layout", ["EPR16", "EPRV2_16", "EPR32"])
+@pytest.mark.parametrize("sigma", [6, 21, 28])
+def test_symbol_planes_beside_epr_blocks(layout, sigma):
+    """Format S is also derived beside InterleavedEPR* / InterleavedEPRV2* blocks that are read in place (6 <= sigma <= 29): exact search then takes
+    k_exact_s; intervals, miss rows and step counts equal the oracle's and the layout's own kernel's (bit 21 of FMGPU_DEV_FLAGS)"""
+    rng = np.random.default_rng(sigma * 7 + len(layout))
+    base = rng.integers(1, sigma, size=4000, dtype=np.uint8)
+    seqs = [np.concatenate([base, base[500:1500]]), rng.integers(1, min(sigma, 4), size=700, dtype=np.uint8), np.full(150, sigma - 1, dtype=np.uint8)]
+    ox = fo.OraIndex.build(layout, sigma, seqs, 8, False)
+    gx = gpu_index(ox)
+    os.environ["FMGPU_FLAT"] = "0"
+    try:
+        gx_own = gpu_index(ox)
+    finally:
+        del os.environ["FMGPU_FLAT"]
+    assert gx.device_bytes > gx_own.device_bytes
+    queries = mutated_queries([q for q in seqs if len(q) > 2], 1200, 1, 80, 1, seed=4, sigma=sigma) + [[], [1], [0], [sigma - 1] * 70, [1, 0, 1]]
+    qbuf, qoff = fm.flatten(queries)
+    olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
+    for flags in ("0", str(1 << 21)):
+        os.environ["FMGPU_DEV_FLAGS"] = flags
+        try:
+            for g in (gx, gx_own):
+                lb, ln, st = fm.search_no_errors.search(g, (qbuf, qoff), want_stats=True)
+                assert np.array_equal(ln, oln) and np.array_equal(lb, olb) and st.lf_steps == int(ost.sum()), (layout, sigma, flags)
+        finally:
+            del os.environ["FMGPU_DEV_FLAGS"]
+
+
 def test_exact_search_edge_cases():
     text = make_text(5000, 5, seed=9)
     ox = fo.OraIndex.build("IB16", 5, [text], 16, False)
