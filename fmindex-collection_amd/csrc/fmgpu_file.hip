@@ -282,6 +282,7 @@ int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
         const size_t had = x->bwt.shadow_bytes + x->rev.shadow_bytes;
         if ((rc = auto_shadow(x.get(), nullptr))) return bail(rc);
         x->device_bytes += x->bwt.shadow_bytes + x->rev.shadow_bytes - had;
+        if ((rc = fuse_presence_bits(x.get(), nullptr))) return bail(rc);          // (no-op where the saved blocks carry the bits already)
     }
     // ... Format D (a few ms)
     if (x->bidirectional) {

@@ -132,10 +132,10 @@ __global__ __launch_bounds__(256) void k_fuse_presence(uint8_t* __restrict__ blk
 int fuse_presence_bits(Index* x, hipStream_t stream) {
     DevString& s = x->bwt;
     const char* off = getenv("FMGPU_FUSED_LOCATE");
-    if (!x->has_sa || s.family != FAM_A || s.shadow || s.va.bstride != 64u || s.sigma < 2 || s.va.fused || (off && atoi(off) == 0)) return 0;
+    if (!x->has_sa || s.search_family() != FAM_A || s.va.bstride != 64u || s.sigma < 2 || s.va.fused || (off && atoi(off) == 0)) return 0;   // (the string's own Format A blocks, or its expansion)
     const uint64_t nblocks = s.n / 64 + 1;
     FM_GRID(grid, nblocks);
-    k_fuse_presence<<<grid, dim3(256), 0, stream>>>((uint8_t*)s.blk, x->vsa, nblocks);
+    k_fuse_presence<<<grid, dim3(256), 0, stream>>>(const_cast<uint8_t*>(s.va.blk), x->vsa, nblocks);
     FM_LAUNCHED("k_fuse_presence");
     FM_HIP(hipStreamSynchronize(stream));
     idx_t ksum = 0;

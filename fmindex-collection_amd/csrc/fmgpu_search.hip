@@ -4254,7 +4254,7 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
         k_locate_tab<<<grid, block, 0, stream>>>(x->loc_tab, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
     else
 #endif
-    if (x->bwt.va.fused && !x->bwt.shadow && x->bwt.family == FAM_A) {      // one line per step: presence bit, symbol and LF from the row's block (also ahead of the explicit LF table: that is two lines per step)
+    if (x->bwt.va.fused && x->bwt.search_family() == FAM_A) {      // one line per step: presence bit, symbol and LF from the row's block (also ahead of the explicit LF table: that is two lines per step)
         if (x->bwt.sigma == 5) k_locate_fused<5><<<grid, block, locate_lds, stream>>>(OccA<5>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
         else k_locate_fused<0><<<grid, block, locate_lds, stream>>>(OccA<0>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
     } else
