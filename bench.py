@@ -37,6 +37,7 @@ $FMGPU_BENCH_RECORDS) and, one short line per record, to stderr.  `cpu_baseline`
 cores over a bounded sample of the same reads, NUMA-spread and thread-bound; it is a reported baseline, not the target.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -50,10 +51,27 @@ GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 1708059
                   58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569]
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BLOCK_BYTES_IB16_S5 = 56       # sizeof(InterleavedBitvector16<5>::Block), SURVEY.md appendix B
-BYTES_PER_STEP_DNA = 2 * BLOCK_BYTES_IB16_S5          # both interval ends
-BYTES_PER_STEP_PAIRS = 68                             # Format P: 2 ends x (4-byte count + 64 bytes of planes) per two-symbol step = 68 B per symbol
-BYTES_PER_STEP_WAVELET28 = 2 * 5 * 17                 # 2 ends x 5 levels x (8 + 1 + 8) B
-BYTES_PER_STEP_FLAT28 = 2 * 44                        # Format S: 2 ends x (five 8-byte planes + a 3-byte count, 44 B counted) of one line per LF step
+# ---- the roofline rule, ONE for every plain-index record ------------------------------------------------------------------------
+# roofline.frac = frac_kernel_format: executed units (LF steps / visited nodes / locate steps — counted by the kernel, identical to the CPU walk) x the bytes the
+# kernel reads of the block(s) a unit touches in ITS OWN device format — both interval ends, one end for a one-row node or a locate step — / kernel time
+# (HIP events on the launch stream) / 8 TB/s.  Beside it, in every record: frac_sec8d = the same units x SURVEY 8d's bytes of the REFERENCE layout (null where
+# that exceeds the peak: the kernel touches fewer lines than the layout 8d prices; the one-symbol / tree records of the same run carry it), frac_loaded = the bytes
+# of the loads the kernel issued, counted in the kernel (two ends in one block count once, a node re-visited for its next sibling counts again) + the coalesced
+# query / result bytes, and traffic / frac_traffic = HBM bytes by the rocprofv3 counters (replayed from profiles/).
+RULE = ("frac = frac_kernel_format = executed units x bytes the kernel reads of the block(s) a unit touches in its own device format (both interval ends; one end for a one-row node "
+        "or a locate step) / kernel time (HIP events on the launch stream) / 8 TB/s; frac_sec8d = units x SURVEY 8d's bytes of the reference layout (null if > 1); "
+        "frac_loaded = bytes of the loads the kernel issued, counted in the kernel, + coalesced query / result bytes")
+SEC8D_STEP_DNA = 2 * BLOCK_BYTES_IB16_S5              # both interval ends x sizeof(InterleavedBitvector16<5>::Block) = 112 B per LF step / visited node
+SEC8D_STEP_WAVELET28 = 2 * 5 * 17                     # 2 ends x 5 levels x (8 + 1 + 8) B = 170 B per LF step
+SEC8D_STEP_LOCATE = BLOCK_BYTES_IB16_S5 + 64          # one block + one presence-bit line per locate step
+FMT_STEP_PAIRS = 68                                   # Format P: 2 ends x (4-byte count + 64 bytes of planes) per TWO symbols = 68 B per LF step
+FMT_STEP_BLOCKS = 2 * 12                              # Format A, one symbol per step: 2 ends x the 12-byte entry of the step's symbol
+FMT_STEP_PLANES28 = 2 * 44                            # Format S: 2 ends x (five 8-byte planes + the symbol's count: 44 B counted) of one line per LF step
+FMT_STEP_TREE28 = 2 * (4 + 24 + 4 + 16)               # Format M, sigma = 28: 2 ends x (8-ary level: count + three planes; 4-ary level: count + two planes) = 96 B per LF step
+FMT_NODE_DENSE = (64, 32)                             # Format D: a node of several rows reads 2 x 32 B, a one-row node 32 B
+FMT_NODE_BLOCKS = (96, 48)                            # Format A in the lean kernel: the entries of symbols 1..4 = 48 B per end
+FMT_NODE_EDIT = (128, 64)                             # the edit-distance kernel reads whole 64-byte blocks
+FMT_STEP_LOCATE = 64                                  # one fused 64-byte block per locate step (+ two 8-byte value words per located row)
 PROTEIN_SEQS, PROTEIN_SEQ_LEN = 4_000_000, 500        # UniRef50 stand-in (the release itself is not available offline): 2.0e9 residues
 PROTEIN_SEQS_WIDE = 9_000_000                         # ... and 4.5e9 residues: more than 2^32 rows, the 64-bit-row build of the kernels (UniRef50 itself is ~1e10)
 
@@ -79,6 +97,7 @@ def parse():
                     help="rehearsal only: gloo runs the N > 1 control flow where RCCL cannot (all ranks on one card); results travel through host memory")
     ap.add_argument("--all-ranks-device0", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--multi-tables", action="store_true", help="N > 1: also measure the table-augmented indices (136 / 224 GB per GPU); default at N > 1: the plain index only")
+    ap.add_argument("--opt", default="", help="library options for the whole run (fmgpu_set_option), e.g. pair_table=0,kernel_select=4194304 (A/B runs; the judged run sets none)")
     ap.add_argument("--total-k2-reads", type=int, default=100_000_000, help="N > 1: reads of the configs[3] leg in total (sharded over the ranks)")
     return ap.parse_args()
 
@@ -111,6 +130,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.gpus != world and not args.single_rank_collectives:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d — N > 1 is launched as python -m torch.distributed.run --nproc-per-node N bench.py --gpus N" % (args.gpus, world))
     if args.all_ranks_device0:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -129,7 +150,13 @@ def main():
             dist.init_process_group("nccl", device_id=c.dev)
         else:
             dist.init_process_group("gloo")
+        if dist.get_world_size() != (1 if args.single_rank_collectives and world == 1 else args.gpus):      # a group of another size would report the wrong n_gpus: refuse, loudly
+            raise SystemExit("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
     c.via_host = c.multi and args.dist_backend == "gloo"
+    for kv in (x for x in args.opt.split(",") if x):             # A/B runs: library options for the whole run
+        k, v = kv.split("=")
+        fm.options[k.strip()] = int(v, 0)
+    c.smi = Smi(local_rank)
     c.only = set(x for x in args.only.split(",") if x)
     c.traffic = {}
     for tf in ("r03_traffic.json", "r02_traffic.json"):           # per-launch HBM bytes from the committed rocprofv3 --pmc passes (replayed, labelled so)
@@ -187,9 +214,15 @@ def compact_line(records, multi, records_file):
             line[k] = _r4(head[k])
     rf = head.get("roofline")
     if rf:
-        line["roofline"] = {k: _r4(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "units_per_launch", "bytes_per_unit") if k in rf}
+        line["roofline"] = {k: _r4(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_kernel_format", "frac_sec8d", "frac_loaded", "traffic", "frac_traffic", "kernel", "kernel_ms",
+                                                    "units_per_launch", "bytes_per_unit") if k in rf}
+        if rf.get("frac_sec8d") is None and "sec8d" in rf:
+            line["roofline"]["sec8d_uncapped"] = _r4(rf["sec8d"]["frac_uncapped"])     # (> 1: SURVEY 8d's 112 B per step is more than this kernel's format makes it read)
+        line["roofline"]["rule"] = "frac = kernel-format bytes (2 interval ends x bytes read of the step's block) / kernel time / peak; sec8d = reference-layout bytes; loaded = counted in the kernel"
         if rf.get("traffic") is not None:
             line["roofline"]["traffic_source"] = "replayed from the committed rocprofv3 --pmc passes (profiles/), not measured in this run"
+    if head.get("clocks"):
+        line["clocks"] = head["clocks"]
     cb = head.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r4(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -203,7 +236,7 @@ def compact_line(records, multi, records_file):
     one = next((r for r in records if r["id"] == head["id"].replace("/plain", "/single")), None)
     if one is not None and one is not head:
         line["one_symbol_steps"] = {"record": one["id"], "value": _r4(one["value"]), "ms_per_step": _r4(one["ms_per_step"]), "kernel": one["roofline"]["kernel"],
-                                    "kernel_ms": _r4(one["roofline"]["kernel_ms"]), "bytes_per_unit": one["roofline"]["bytes_per_unit"], "frac": _r4(one["roofline"]["frac"]),
+                                    "kernel_ms": _r4(one["roofline"]["kernel_ms"]), "frac_sec8d": _r4(one["roofline"]["frac_sec8d"]),
                                     "what": "the same index and reads one symbol per step: SURVEY 8d's 112 B per LF step as written"}
     tab = next((r for r in records if r["id"] == head["id"].replace("/plain", "/tables")), None)
     if tab is not None and tab is not head:
@@ -220,12 +253,12 @@ def compact_line(records, multi, records_file):
         cb2 = k2["cpu_baseline"]
         line["k2_cpu_baseline"] = {"record": k2["id"], "value": _r4(cb2["value"]), "cores": cb2["cores"], "gpu_over_cpu": _r4(k2["value"] / cb2["value"]) if cb2["value"] else None,
                                    "gpu_results_match_on_sample": cb2["gpu_results_match_on_sample"]}
-    line["summary"] = {r["id"]: [_r4(r["ms_per_step"]), _r4(r["roofline"]["frac"])] for r in records}
-    line["summary_columns"] = ["ms_per_step", "roofline.frac"]
+    line["summary"] = {r["id"]: [_r4(r["ms_per_step"]), _r4(r["roofline"]["frac"]), _r4(r["roofline"].get("frac_sec8d")), _r4(r["roofline"].get("frac_loaded"))] for r in records}
+    line["summary_columns"] = ["ms_per_step", "roofline.frac (kernel format; table records: loaded)", "frac_sec8d", "frac_loaded"]
     line["records_file"] = records_file
     out = json.dumps(line, separators=(",", ":"))
     if len(out) > MAX_LINE:                                      # never let the headline be cut: drop the optional parts first
-        for k in ("summary_columns", "k2_cpu_baseline", "with_tables", "summary"):
+        for k in ("summary_columns", "clocks", "k2_cpu_baseline", "with_tables", "one_symbol_steps", "summary"):
             line.pop(k, None)
             out = json.dumps(line, separators=(",", ":"))
             if len(out) <= MAX_LINE:
@@ -243,7 +276,10 @@ def emit(records, multi, world):
         path = None
     for r in records:
         rf = r["roofline"]
-        print("bench.py: %-28s %10.3f ms/step  %-20s %9.3f ms  frac %.3f  value %.4g %s" % (r["id"], r["ms_per_step"], rf["kernel"], rf["kernel_ms"], rf["frac"], r["value"], r["unit"]),
+        f3 = lambda v: "  -  " if v is None else "%.3f" % v
+        ck = r.get("clocks") or {}
+        print("bench.py: %-30s %9.3f ms/step  %-18s %9.3f ms  frac %.3f  sec8d %s  loaded %s  sclk %s MHz  value %.4g %s"
+              % (r["id"], r["ms_per_step"], rf["kernel"], rf["kernel_ms"], rf["frac"], f3(rf.get("frac_sec8d")), f3(rf.get("frac_loaded")), ck.get("sclk_mhz_mean", "?"), r["value"], r["unit"]),
               file=sys.stderr, flush=True)
     print(compact_line(records, multi, os.path.basename(path) if path else None), flush=True)
 
@@ -328,6 +364,7 @@ def timed(c, step, drain=None):
     if c.multi:
         c.dist.barrier()
     torch.cuda.synchronize()
+    c.smi.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(log)
@@ -337,11 +374,81 @@ def timed(c, step, drain=None):
         c.dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    c.last_clocks = c.smi.stop()
     if c.multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if c.via_host else c.dev)
         c.dist.all_reduce(t, op=c.dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, log
+
+
+class Smi:
+    """clocks and power of the card WHILE the timed steps run (librocm_smi64 through ctypes, sampled every 2 ms by a thread): the figures that attribute a box-to-box
+    spread of the same kernel on the same input (10.8 vs 11.7 ms) to the clock the box ran at.  Reports nothing where the library is not usable."""
+
+    class _Freq(ctypes.Structure):                                # rsmi_frequencies_t (rocm_smi.h)
+        _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32), ("current", ctypes.c_uint32), ("frequency", ctypes.c_uint64 * 33)]
+
+    def __init__(self, dev):
+        import ctypes as C
+        self.dev, self.lib, self.samples, self.thread, self.stop_flag = dev, None, [], None, False
+        for path in ("/opt/rocm/lib/librocm_smi64.so", "librocm_smi64.so", "librocm_smi64.so.1"):
+            try:
+                L = C.CDLL(path)
+                if L.rsmi_init(C.c_uint64(0)) == 0:
+                    self.lib = L
+                    break
+            except OSError:
+                continue
+        self.cap_w = None
+        if self.lib is not None:
+            cap = C.c_uint64()
+            try:
+                if self.lib.rsmi_dev_power_cap_get(C.c_uint32(dev), C.c_uint32(0), C.byref(cap)) == 0:
+                    self.cap_w = cap.value / 1e6
+            except Exception:
+                pass
+
+    def _read(self):
+        import ctypes as C
+        out = []
+        for clk in (0, 4):                                        # RSMI_CLK_TYPE_SYS, RSMI_CLK_TYPE_MEM
+            f = Smi._Freq()
+            ok = self.lib.rsmi_dev_gpu_clk_freq_get(C.c_uint32(self.dev), C.c_int(clk), C.byref(f)) == 0 and f.current < 33
+            out.append(f.frequency[f.current] / 1e6 if ok else None)
+        pw = C.c_uint64()
+        out.append(pw.value / 1e6 if self.lib.rsmi_dev_current_socket_power_get(C.c_uint32(self.dev), C.byref(pw)) == 0 else None)
+        return out
+
+    def start(self):
+        if self.lib is None:
+            return
+        import threading
+        self.samples, self.stop_flag = [], False
+
+        def run():
+            while not self.stop_flag:
+                try:
+                    self.samples.append(self._read())
+                except Exception:
+                    return
+                time.sleep(0.002)
+        self.thread = threading.Thread(target=run, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        if self.lib is None or self.thread is None:
+            return None
+        self.stop_flag = True
+        self.thread.join(timeout=1.0)
+        self.thread = None
+        col = lambda k: [x[k] for x in self.samples if x[k] is not None]
+        sc, mc, pw = col(0), col(1), col(2)
+        if not sc:
+            return None
+        return {"sclk_mhz_mean": round(sum(sc) / len(sc)), "sclk_mhz_min": round(min(sc)), "sclk_mhz_max": round(max(sc)), "mclk_mhz": round(sum(mc) / len(mc)) if mc else None,
+                "socket_power_w_mean": round(sum(pw) / len(pw)) if pw else None, "power_cap_w": self.cap_w, "samples": len(sc),
+                "what": "rocm_smi readings of the card during the timed steps of this record (2 ms apart)"}
 
 
 class Exchange:
@@ -400,11 +507,27 @@ class Exchange:
         return ok
 
 
-def roofline_sec8d(units, bytes_per_unit, k_ms, kernel, what):
-    ach = units * bytes_per_unit / (k_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-            "kernel": kernel, "kernel_ms": k_ms, "units_per_launch": units, "bytes_per_unit": bytes_per_unit,
-            "accounting": "SURVEY 8d: executed " + what + " x bytes_per_unit of the reference layout / kernel time (HIP events on the launch stream)"}
+def roofline_plain(kernel, k_ms, units, unit_name, fmt_bytes, fmt_what, sec8d_per_unit, sec8d_what, loaded_bytes=None, loaded_what=None, loaded_accesses=None):
+    """the one rule of every plain-index record (RULE above): frac = kernel-format bytes / kernel time / peak, with the SURVEY 8d and in-kernel figures beside it"""
+    t = k_ms * 1e-3
+    ach = fmt_bytes / t / 1e9
+    sec = units * sec8d_per_unit / t / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+         "kernel": kernel, "kernel_ms": k_ms, "units_per_launch": units, "unit_name": unit_name, "bytes_per_unit": fmt_bytes / max(units, 1.0),
+         "frac_kernel_format": ach / HBM_PEAK_GBS, "kernel_format": {"bytes_per_launch": fmt_bytes, "what": fmt_what},
+         "frac_sec8d": sec / HBM_PEAK_GBS if sec <= HBM_PEAK_GBS else None,
+         "sec8d": {"bytes_per_unit": sec8d_per_unit, "achieved": sec, "frac_uncapped": sec / HBM_PEAK_GBS, "what": sec8d_what},
+         "frac_loaded": None, "rule": RULE}
+    if sec > HBM_PEAK_GBS:
+        r["sec8d"]["why_null"] = ("SURVEY 8d's bytes of the reference layout / kernel time exceed the 8 TB/s peak: this kernel reads a derived format that touches fewer lines per unit than the "
+                                  "layout 8d prices; 8d as written is measured on the one-symbol / tree record of the same run")
+    if loaded_bytes is not None:
+        r["frac_loaded"] = loaded_bytes / t / 1e9 / HBM_PEAK_GBS
+        r["loaded"] = {"bytes_per_launch": loaded_bytes, "what": loaded_what}
+        if loaded_accesses is not None:
+            r["loaded"]["accesses_per_launch"] = loaded_accesses
+            r["loaded"]["line_granular_frac"] = loaded_accesses * 128.0 / t / 1e9 / HBM_PEAK_GBS
+    return r
 
 
 def roofline_loaded(st, coalesced_bytes, k_ms, kernel, units, what):
@@ -414,6 +537,7 @@ def roofline_loaded(st, coalesced_bytes, k_ms, kernel, units, what):
     line = (ta * 128.0 + coalesced_bytes) / (k_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
             "kernel": kernel, "kernel_ms": k_ms, "units_per_launch": units,
+            "frac_kernel_format": None, "frac_sec8d": None, "frac_loaded": ach / HBM_PEAK_GBS,      # (a table entry serves several units: only the loaded bytes mean anything)
             "bytes_per_launch": {"table_entries": tb, "table_accesses": ta, "queries_and_results": coalesced_bytes},
             "line_granular": {"achieved": line, "frac": line / HBM_PEAK_GBS, "what": "every table access priced as one 128-byte line"},
             "accounting": "bytes of the loads the kernel issued (counted in the kernel: interval / context / walk / prefix table entries, blocks, frames, hit records) "
@@ -421,9 +545,11 @@ def roofline_loaded(st, coalesced_bytes, k_ms, kernel, units, what):
 
 
 def attach_traffic(c, rec):
+    rec["clocks"] = getattr(c, "last_clocks", None)           # (of the timed steps that made this record)
     t = c.traffic.get(rec["id"])
     if t and c.args.scale == 1.0:
         rec["roofline"]["traffic"] = t["bytes_per_launch"]
+        rec["roofline"]["frac_traffic"] = t["bytes_per_launch"] / (rec["roofline"]["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         rec["roofline"]["traffic_source"] = "%s (%s): separate rocprofv3 --pmc passes of this record, FETCH_SIZE x 2 + WRITE_SIZE; replayed, not measured in this run" % (c.traffic_file, t.get("source", ""))
 
 
@@ -451,11 +577,12 @@ def run_dna_text(c, name, primary):
         L = 101
         qbuf, qoff = sample_reads(c, text, lengths, L, nq, 1000 + c.rank, "exact")
         torch.cuda.synchronize()
-        os.environ["FMGPU_LF_TABLE"] = "0"
+        fm.options["lf_table"] = 0
         t0 = time.time()
         index = fm.FMIndex.from_sequences((_Dev(text), _Dev(seq_off)), 5, "IB16", 16, keep_host=want_cpu)
         build_plain = time.time() - t0
-        pairs = os.environ.get("FMGPU_PAIRS", "1") != "0" and not (int(os.environ.get("FMGPU_DEV_FLAGS", "0")) & (1 << 22)) and total < (1 << 32)
+        sel_base = fm.options["kernel_select"]
+        pairs = bool(index.formats & capi.FMT_PAIRS) and not (sel_base & capi.SEL_EXACT_ONE_SYMBOL)      # (what the library holds decides the kernel: the record is labelled from it)
         outs = [torch.empty(2 * nq, dtype=torch.int64, device=c.dev) for _ in range(2 if c.multi else 1)]
         packed = [torch.empty(nq, dtype=torch.int64, device=c.dev) for _ in range(2)] if c.multi else None
         stats = capi.Stats()
@@ -489,24 +616,22 @@ def run_dna_text(c, name, primary):
                    "config": {"workload": "grch38_exact", **base_cfg, "index": "FMIndex", "index_kind": index_kind, "queries_per_gpu": nq, "read_len": L,
                               "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2), **extra},
                    "gbp_per_s": qps * L / 1e9, "hits": int((out_len > 0).sum().item())}
+            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
+            coalesced = nq * (L + 8 + 16)
             if kernel == "k_exact_a":
-                rec["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_DNA, k_ms, kernel, "LF steps")
-            elif kernel == "k_exact_p":
-                # SURVEY 8d's form (both interval ends x the bytes of the block a step reads) for the two-symbol step: 2 ends x 68 B (a 4-byte count + four
-                # 16-byte plane words of one 128-byte line) per PAIR of symbols = 68 B per executed LF step (a one-symbol step is priced the same: less than its 112 B)
-                st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
-                rec["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_PAIRS, k_ms, kernel, "LF steps")
-                rec["roofline"]["accounting"] = ("k_exact_p takes two symbols per step from Format P (one 128-byte line per 128 rows: 16 pair counts + 4 bit planes): algorithmic bytes in "
-                                                 "SURVEY 8d's form = 2 interval ends x 68 B read of a line (4-byte count + four 16-byte plane words) per two-symbol step = 68 B per executed "
-                                                 "LF step, / kernel time (HIP events on the launch stream).  SURVEY 8d's own figure, 112 B per LF step of the reference's one-symbol layout, "
-                                                 "is record " + rid.rsplit("/", 1)[0] + "/single (k_exact_a, same index, same reads, same run)")
-                rec["roofline"]["loaded"] = {"bytes_per_launch": st["table_bytes"] + nq * (L + 8 + 16), "accesses_per_launch": st["table_accesses"],
-                                             "frac": (st["table_bytes"] + nq * (L + 8 + 16)) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                             "line_granular_frac": (st["table_accesses"] * 128.0 + nq * (L + 8 + 16)) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                             "what": "bytes the kernel's loads asked for, counted in the kernel (an interval end whose line is the other end's is one access), and the same with every access priced as one 128-byte line"}
+                rec["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", units * FMT_STEP_BLOCKS,
+                                                 "one symbol per step on the one-symbol blocks: 2 interval ends x the 12-byte entry {count, 64-bit bitmap} of the step's symbol = 24 B per LF step",
+                                                 SEC8D_STEP_DNA, "2 x sizeof(InterleavedBitvector16<5>::Block) = 112 B per executed LF step (this record IS SURVEY 8d as written)",
+                                                 st["table_bytes"] + coalesced, "12 B per entry the kernel loaded (an end in the other end's block: one load) + queries and results", st["table_accesses"])
+            elif kernel in ("k_exact_p", "k_exact_lp"):
+                rec["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", units * FMT_STEP_PAIRS,
+                                                 "two symbols per step on the pair lines (one 128-byte line per 128 rows: 16 pair counts + 4 bit planes): 2 interval ends x 68 B read of a "
+                                                 "line (4-byte count + four 16-byte plane words) per two-symbol step = 68 B per executed LF step",
+                                                 SEC8D_STEP_DNA, "2 x sizeof(InterleavedBitvector16<5>::Block) = 112 B per executed LF step: record " + rid.rsplit("/", 1)[0] + "/single (k_exact_a, same index, same reads, same run)",
+                                                 st["table_bytes"] + coalesced, "68 B per line the kernel fetched (an end in the other end's line: one fetch; 12 B per one-symbol entry; 8 B per "
+                                                 "interval-table entry) + queries and results", st["table_accesses"])
             else:
-                st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
-                rec["roofline"] = roofline_loaded(st, nq * (L + 8 + 16), k_ms, kernel, units, "LF steps")
+                rec["roofline"] = roofline_loaded(st, coalesced, k_ms, kernel, units, "LF steps")
             if xch:
                 rec["exchange"] = {"collective": xch.mode, "bytes_per_rank_and_step": nq * 8, "verified_on_rank0": xch.verify(), "record": "8 B per read (lb:32 | len:32)",
                                    "world_size_seen": c.dist.get_world_size()}
@@ -545,9 +670,17 @@ def run_dna_text(c, name, primary):
                               "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2)},
                    "lf_steps_per_row": units / nr, "located_positions_hold_their_reads": same}
             if index_kind == "plain":
-                rec["roofline"] = roofline_sec8d(units + nr, BLOCK_BYTES_IB16_S5 + 64, k_ms, "k_locate_fused" if os.environ.get("FMGPU_FUSED_LOCATE", "1") != "0" else "k_locate", "locate steps (LF steps + the final probe; one block + one presence-bit line each)")
+                fused = bool(index.formats & capi.FMT_FUSED)
+                lk = ("k_locate_fused" if (sel_base & capi.SEL_LOCATE_PER_LANE) else "k_locate_coop") if fused else "k_locate"
+                fmt = (units + nr) * (FMT_STEP_LOCATE if fused else 64 + 64) + nr * 16.0
+                rec["roofline"] = roofline_plain(lk, k_ms, units + nr, "locate steps (LF steps + the probe of the sampled row)", fmt,
+                                                 "one 64-byte block per step — presence bit, symbol and LF of the row; at the sampled row the value's rank from the same block — + two 8-byte value words per located row"
+                                                 if fused else "one block + one presence-bit line per step",
+                                                 SEC8D_STEP_LOCATE, "one 56-byte block + one 64-byte presence-bit line = 120 B per locate step",
+                                                 fmt + nr * 32.0, "the same blocks and value words (the kernel loads nothing else from the index) + rows and results")
             else:
                 rec["roofline"] = roofline_loaded({"table_bytes": 12.0 * nr, "table_accesses": float(nr)}, nr * 32, k_ms, "k_locate_tab", units, "LF steps of locate")
+            attach_traffic(c, rec)
             return rec
 
         plain_ms = None
@@ -576,11 +709,8 @@ def run_dna_text(c, name, primary):
                 step([])                                          # (the pair kernel's results, to compare with)
                 torch.cuda.synchronize()
             keep = outs[0].clone()
-            os.environ["FMGPU_DEV_FLAGS"] = str(1 << 22)
-            try:
+            with fm.options(kernel_select=sel_base | capi.SEL_EXACT_ONE_SYMBOL):
                 elapsed, log = timed(c, step, None)
-            finally:
-                os.environ.pop("FMGPU_DEV_FLAGS", None)
             r1 = finish(name + "/exact/single", "plain", "k_exact_a", elapsed, log, build_plain, {"tables": None, "occurrence_tables": "one-symbol blocks (Format A)"})
             r1["equal_to_the_pair_kernel"] = bool(torch.equal(keep, outs[0]))
             if not r1["equal_to_the_pair_kernel"]:
@@ -593,7 +723,7 @@ def run_dna_text(c, name, primary):
             out.append(locate_run(name + "/locate/plain", "plain", build_plain))
         if ((not c.multi or args.multi_tables) and wanted(c, name + "/exact/tables")) or (wanted(c, name + "/locate/tables") and not c.multi):
             t0 = time.time()
-            os.environ.pop("FMGPU_LF_TABLE", None)
+            del fm.options["lf_table"]
             index.accelerate(3, lut_len=args.lut_len, walk=2)
             build_tab = build_plain + time.time() - t0
             elapsed, log = timed(c, step, xch.drain if xch else None)
@@ -607,7 +737,7 @@ def run_dna_text(c, name, primary):
                 t0 = time.time()
                 index.accelerate_locate()
                 out.append(locate_run(name + "/locate/tables", "tables", build_tab + time.time() - t0))
-        os.environ.pop("FMGPU_LF_TABLE", None)
+        del fm.options["lf_table"]
         index.close()
         del index, qbuf, qoff, outs, packed
         torch.cuda.empty_cache()
@@ -618,12 +748,13 @@ def run_dna_text(c, name, primary):
     k2_legs = [(w, L, n_) for (w, L, n_) in k2_legs if n_ > 0 and (any(wanted(c, "%s/%s/%s" % (name, w, i)) for i in ("plain", "tables"))
                                                                     or (w == "k2" and args.with_edit and not c.multi and (wanted(c, "%s/k2_edit/tables" % name) or wanted(c, "%s/k2_edit/plain" % name))))]
     if k2_legs:
-        os.environ["FMGPU_LF_TABLE"] = "0"
+        fm.options["lf_table"] = 0
         t0 = time.time()
         keep = want_cpu and any(w == "k2" for w, _, _ in k2_legs)
         index = fm.BiFMIndex.from_sequences((_Dev(text), _Dev(seq_off)), 5, "IB16", 16, keep_host=keep)
         build_plain = time.time() - t0
-        os.environ.pop("FMGPU_LF_TABLE", None)
+        del fm.options["lf_table"]
+        sel_base = fm.options["kernel_select"]
         reads = {w: sample_reads(c, text, lengths, L, n_, 2000 + c.rank + 17 * L, "k2") for (w, L, n_) in k2_legs}
         torch.cuda.synchronize()
         if not keep:
@@ -673,7 +804,8 @@ def run_dna_text(c, name, primary):
             elapsed, log = timed(c, step, xch.drain if xch else None)
             k_ms = mean([x["kernel_ms"] for x in log]); units = mean([x["units"] for x in log]); nh = mean([x["hits"] for x in log])
             qps = c.world * n_ * args.steps / elapsed
-            lean_off = int(os.environ.get("FMGPU_DEV_FLAGS", "0")) & (1 << 30)
+            lean_off = sel_base & capi.SEL_NO_LEAN
+            dense = bool(index.formats & capi.FMT_DENSE) and not (sel_base & capi.SEL_LEAN_FORMAT_A)
             kernel = "k_scheme_fast_edit" if edit else ("k_scheme_lean" if index_kind == "plain" and not lean_off else "k_scheme_fast")
             part = [L // 4 + (1 if p < L % 4 else 0) for p in range(4)]
             rec = {"id": rid, "metric": "queries/sec (GRCh38-sized index, %s x %dbp, k=2 %s, h2(4,0,2))" % ("10M" if w == "k2" and not edit else ("%.1fM per GPU" % (n_ / 1e6)), L, "edit distance" if edit else "Hamming"),
@@ -685,10 +817,27 @@ def run_dna_text(c, name, primary):
                               "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2),
                               "tables": None if index_kind == "plain" else {"lf": True, "prefix_symbols": args.prefix_len, "walk": "LF,LF^2,LF^3 + LF^16"}},
                    "gbp_per_s": qps * L / 1e9, "hits": int(nh)}
-            if index_kind == "plain" or edit:                  # (the edit-distance kernels do not count their loads: SURVEY 8d's node accounting)
-                rec["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_DNA, k_ms, kernel, "visited nodes (cursor extensions)")
+            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
+            if kernel == "k_scheme_lean":
+                # fmgpu_stats of the lean kernel: table_accesses = blocks it fetched, table_bytes = visited nodes of several rows (the rest of the nodes stood on one row)
+                multi, single, blocks = st["table_bytes"], units - st["table_bytes"], st["table_accesses"]
+                per = FMT_NODE_DENSE if dense else FMT_NODE_BLOCKS
+                rec["roofline"] = roofline_plain(kernel, k_ms, units, "visited nodes (cursor extensions)", multi * per[0] + single * per[1],
+                                                 ("dense DNA blocks (32 B per 64 rows: four counts + two bit planes)" if dense else "the entries of symbols 1..4 of the one-symbol blocks (48 B)") +
+                                                 ": a node of several rows reads both interval ends' blocks (%d B), a one-row node its row's block (%d B); %.1f %% of the nodes hold several rows"
+                                                 % (per[0], per[1], 100.0 * multi / max(units, 1.0)),
+                                                 SEC8D_STEP_DNA, "2 x sizeof(InterleavedBitvector16<5>::Block) = 112 B per visited node",
+                                                 blocks * per[1] + nh * 40.0 + n_ * (L + 8.0), "%d B per block the kernel fetched (both ends in one block: one fetch; a node re-visited for its next sibling "
+                                                 "fetches again) + 40 B per hit record + the reads; its 16-byte stack frames (write-through, read back by LDS-DMA) are not counted" % per[1], blocks)
+                rec["roofline"]["nodes_of_several_rows"] = multi
+            elif index_kind == "plain" or edit:                # (the edit-distance kernel: whole 64-byte blocks; what it loads is counted in the kernel where it counts)
+                rec["roofline"] = roofline_plain(kernel, k_ms, units, "visited nodes (cursor extensions)", units * float(FMT_NODE_EDIT[0] if index_kind == "plain" else SEC8D_STEP_DNA),
+                                                 "both interval ends' 64-byte blocks per visited node (upper bound: a one-row node reads one block, or nothing where its LF is known)"
+                                                 if index_kind == "plain" else "SURVEY 8d's 112 B per visited node (the table-driven kernel serves one-row nodes from LF entries)",
+                                                 SEC8D_STEP_DNA, "2 x sizeof(InterleavedBitvector16<5>::Block) = 112 B per visited node",
+                                                 (st["table_bytes"] + n_ * (L + 8.0)) if st["table_bytes"] else None, "bytes of the loads the kernel issued (blocks, LF entries, frames, hit records), counted in the kernel, + the reads",
+                                                 st["table_accesses"] if st["table_bytes"] else None)
             else:
-                st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
                 rec["roofline"] = roofline_loaded(st, n_ * (L + 8), k_ms, kernel, units, "visited nodes")
             if xch:
                 rec["exchange"] = {"collective": xch.mode, "bytes_per_rank_and_step": int(xch.last[0].numel()), "verified_on_rank0": xch.verify(),
@@ -777,11 +926,12 @@ def run_protein(c, nseq, tag):
     seq_off = torch.arange(nseq + 1, device=c.dev, dtype=torch.int64) * PROTEIN_SEQ_LEN
     qbuf, qoff = sample_reads(c, text, None, L, nq, 1000, "exact", sigma=sigma, inside=(nseq, PROTEIN_SEQ_LEN))
     torch.cuda.synchronize()
-    os.environ["FMGPU_LF_TABLE"] = "0"
+    fm.options["lf_table"] = 0
     t0 = time.time()
     index = fm.FMIndex.from_sequences((_Dev(text), _Dev(seq_off)), sigma, "WAVELET", 16, keep_host=False)
     build_s = time.time() - t0
-    os.environ.pop("FMGPU_LF_TABLE", None)
+    del fm.options["lf_table"]
+    sel_base = fm.options["kernel_select"]
     del text
     torch.cuda.empty_cache()
     out_t = torch.empty(2 * nq, dtype=torch.int64, device=c.dev)
@@ -801,29 +951,25 @@ def run_protein(c, nseq, tag):
                         "index": "FMIndex", "index_kind": kind, "row_bits": index.row_bits, "queries_per_gpu": nq, "read_len": L, "index_device_bytes": index.device_bytes,
                         "index_build_s": round(b_s, 2), "tables": tables},
              "gres_per_s": qps * L / 1e9, "hits": int((out_t[nq:] > 0).sum().item())}
-        if kind == "wavelet":
-            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
-            if kernel == "k_exact_s":
-                r["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_FLAT28, k_ms, kernel, "LF steps")
-                r["roofline"]["accounting"] = ("k_exact_s reads Format S beside the tree (one 128-byte line per 64 rows: 5 symbol planes + sigma 24-bit counts): algorithmic bytes in SURVEY 8d's form = "
-                                               "2 interval ends x 44 B read of a line (40 B of planes + the symbol's count) per executed LF step, / kernel time (HIP events on the launch stream).  "
-                                               "SURVEY 8d's own figure, 170 useful bytes per LF step of the reference's binary wavelet tree, is applied to the search on the tree itself: record "
-                                               + tag + "/exact/tree (k_exact_m, same index, same reads, same run)")
-                r["roofline"]["loaded"] = {"bytes_per_launch": st["table_bytes"], "lines_per_launch": st["table_accesses"],
-                                           "line_granular_frac": st["table_accesses"] * 128.0 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           "what": "lines the kernel fetched (an interval end whose line is the other end's is one), counted in the kernel; every line priced at its 128 bytes"}
-            else:
-                r["roofline"] = roofline_sec8d(units, BYTES_PER_STEP_WAVELET28, k_ms, kernel, "LF steps")
-                r["roofline"]["loaded"] = {"bytes_per_launch": st["table_bytes"], "accesses_per_launch": st["table_accesses"],
-                                           "what": "bytes / blocks the kernel actually read from the two-level multi-ary tree (counted in the kernel)"}
+        st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
+        if kind == "wavelet" and kernel == "k_exact_s":
+            r["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", units * FMT_STEP_PLANES28,
+                                           "one line per step on the symbol planes beside the tree (one 128-byte line per 64 rows: 5 symbol planes + sigma bit-packed counts): 2 interval ends x "
+                                           "44 B read of a line (40 B of planes + the symbol's count) = 88 B per executed LF step",
+                                           SEC8D_STEP_WAVELET28, "2 ends x 5 levels x (8 + 1 + 8) useful bytes of the reference's binary wavelet tree = 170 B per LF step: record " + tag + "/exact/tree (k_exact_m, same index, same reads, same run)",
+                                           st["table_bytes"] + nq * (L + 8 + 16), "44 B per line the kernel fetched (an end in the other end's line: one fetch) + queries and results", st["table_accesses"])
+        elif kind == "wavelet":
+            r["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", units * FMT_STEP_TREE28,
+                                           "the two-level multi-ary tree: per interval end an 8-ary block (4-byte count + three 8-byte planes) and a 4-ary block (4-byte count + two planes) = 96 B per executed LF step",
+                                           SEC8D_STEP_WAVELET28, "2 ends x 5 levels x (8 + 1 + 8) useful bytes of the reference's binary wavelet tree = 170 B per LF step (this record IS SURVEY 8d as written)",
+                                           st["table_bytes"] + nq * (L + 8 + 16), "bytes the kernel read of the blocks (an end in the other end's block: one read) + queries and results", st["table_accesses"])
         else:
-            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
             r["roofline"] = roofline_loaded(st, nq * (L + 8 + 16), k_ms, kernel, units, "LF steps")
         attach_traffic(c, r)
         return r
 
     out = []
-    flat = os.environ.get("FMGPU_FLAT", "1") != "0" and not (int(os.environ.get("FMGPU_DEV_FLAGS", "0")) & (1 << 21))
+    flat = bool(index.formats & capi.FMT_PLANES) and not (sel_base & capi.SEL_EXACT_ON_TREE)
     flat_ms = None
     if wanted(c, ids[0]):
         elapsed, log = timed(c, step)
@@ -833,11 +979,8 @@ def run_protein(c, nseq, tag):
         if not wanted(c, ids[0]):
             step([]); torch.cuda.synchronize()
         keep = out_t.clone()
-        os.environ["FMGPU_DEV_FLAGS"] = str(1 << 21)
-        try:
+        with fm.options(kernel_select=sel_base | capi.SEL_EXACT_ON_TREE):
             elapsed, log = timed(c, step)
-        finally:
-            os.environ.pop("FMGPU_DEV_FLAGS", None)
         r1 = rec_of(ids[2], "wavelet", "k_exact_m", elapsed, log, build_s, None)
         r1["equal_to_the_line_kernel"] = bool(torch.equal(keep, out_t))
         if not r1["equal_to_the_line_kernel"]:

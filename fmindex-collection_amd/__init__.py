@@ -18,7 +18,42 @@ from .capi import FmgpuError, DeviceBuffer, LAYOUTS, UINT64_MAX, HIT_DTYPE
 from . import search_scheme  # noqa: F401
 
 __all__ = ["FMIndex", "BiFMIndex", "search_no_errors", "search_backtracking", "search_ng26", "search_ng21", "search", "search_n", "search_best", "LocateLinear",
-           "search_scheme", "FmgpuError", "DeviceBuffer", "flatten", "device_count", "Replicas"]
+           "search_scheme", "FmgpuError", "DeviceBuffer", "flatten", "device_count", "Replicas", "options"]
+
+
+class _Options:
+    """the library's process-wide options (fmgpu_set_option, include/fmgpu.h): `options["pair_table"] = 0`, `del options["pair_table"]` puts the default back,
+    `with options(pair_table=0, kernel_select=capi.SEL_GENERAL_DFS): ...` sets and restores"""
+
+    def __setitem__(self, name, value):
+        capi.set_option(name, value)
+
+    def __getitem__(self, name):
+        return capi.get_option(name)
+
+    def __delitem__(self, name):
+        capi.set_option(name, capi.OPTION_DEFAULTS[name])
+
+    def pop(self, name, default=None):
+        del self[name]
+
+    def __call__(self, **kw):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {k: self[k] for k in kw}
+            try:
+                for k, v in kw.items():
+                    self[k] = v
+                yield self
+            finally:
+                for k, v in old.items():
+                    self[k] = v
+        return scope()
+
+
+options = _Options()
 
 
 def device_count():
@@ -209,6 +244,13 @@ class FMIndex:
         b = C.c_int32()
         capi.check(capi.lib().fmgpu_index_row_bits(self._h, C.byref(b)))
         return b.value
+
+    @property
+    def formats(self):
+        """FMT_* bits (capi): what the bwt is held in at this moment — which kernel serves a search"""
+        m = C.c_uint32()
+        capi.check(capi.lib().fmgpu_index_formats(self._h, C.byref(m)))
+        return m.value
 
     def _refresh_bytes(self):
         dbytes = C.c_uint64()

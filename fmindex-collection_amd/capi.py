@@ -99,7 +99,19 @@ EXPORTS = [
     "fmgpu_index_save", "fmgpu_index_load",
     "fmgpu_replicas_load", "fmgpu_replicas_destroy", "fmgpu_replicas_info", "fmgpu_replicas_search_exact", "fmgpu_replicas_search_scheme",
     "fmgpu_replicas_search_ng21", "fmgpu_replicas_locate",
+    "fmgpu_set_option", "fmgpu_get_option", "fmgpu_index_formats",
 ]
+
+# fmgpu_option (include/fmgpu.h) and the defaults the library starts with
+OPTIONS = {"pair_table": 0, "dense_dna": 1, "symbol_planes": 2, "expand_dna": 3, "lf_table": 4, "fused_locate": 5, "heavy_first": 6,
+           "force_wide": 7, "kernel_select": 8, "fail_scratch": 9}
+OPTION_DEFAULTS = {"pair_table": 1, "dense_dna": 1, "symbol_planes": 1, "expand_dna": 1, "lf_table": 1, "fused_locate": 1, "heavy_first": 1,
+                   "force_wide": 0, "kernel_select": 0, "fail_scratch": 0}
+# FMGPU_SEL_* bits of the kernel_select option
+SEL_GENERAL_DFS, SEL_NO_PREFIX_TABLE, SEL_NO_LF3, SEL_NO_LF_GENERAL, SEL_NO_WALK_TABLE, SEL_NO_LENGTH_BUCKETS = 2, 4, 8, 16, 32, 64
+SEL_EXACT_ON_TREE, SEL_EXACT_ONE_SYMBOL, SEL_LOCATE_PER_LANE, SEL_NO_SHARING, SEL_NO_EXACT_LUT, SEL_LEAN_FORMAT_A, SEL_NO_LEAN = 1 << 21, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 29, 1 << 30
+# fmgpu_index_formats bits: what a handle holds beside (or as) the layout it was given
+FMT_BLOCKS, FMT_PAIRS, FMT_DENSE, FMT_PLANES, FMT_TREE, FMT_REFERENCE, FMT_LF, FMT_KSTEP, FMT_INTERVALS, FMT_WALK, FMT_PREFIX, FMT_LOCATE, FMT_FUSED = (1 << k for k in range(13))
 
 _lib = None
 
@@ -186,6 +198,9 @@ def lib():
         L.fmgpu_replicas_search_scheme.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Scheme), C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats)]
         L.fmgpu_replicas_search_ng21.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(ExpandedScheme), C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats)]
         L.fmgpu_replicas_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.fmgpu_set_option.argtypes = [C.c_int32, C.c_int64]
+    L.fmgpu_get_option.argtypes = [C.c_int32, C.POINTER(C.c_int64)]
+    L.fmgpu_index_formats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.fmgpu_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
     L.fmgpu_free.argtypes = [C.c_void_p]
     L.fmgpu_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
@@ -203,6 +218,17 @@ def lib():
 def check(rc):
     if rc != 0:
         raise FmgpuError(rc, lib().fmgpu_last_error().decode("utf-8", "replace"))
+
+
+def set_option(name, value):
+    """fmgpu_set_option by name (OPTIONS) or number"""
+    check(lib().fmgpu_set_option(OPTIONS[name] if isinstance(name, str) else int(name), int(value)))
+
+
+def get_option(name):
+    v = C.c_int64()
+    check(lib().fmgpu_get_option(OPTIONS[name] if isinstance(name, str) else int(name), C.byref(v)))
+    return int(v.value)
 
 
 def ptr(a):

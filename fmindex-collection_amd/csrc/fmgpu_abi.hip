@@ -5,8 +5,10 @@
 
 #include <cstdio>
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <new>
 
@@ -61,16 +63,36 @@ Staged::~Staged() {
     if (owned && dev) { (void)hipStreamSynchronize(stream); (void)hipFree(dev); }
 }
 
-bool want_wide(uint64_t n) {
-    if (n >= kNarrowLimit) return true;
-    const char* e = getenv("FMGPU_FORCE_WIDE");
-    return e && atoi(e) != 0;
+bool want_wide(uint64_t n) { return n >= kNarrowLimit || opt_on(FMGPU_OPT_FORCE_WIDE); }
+
+// ---- library options (fmgpu_set_option): process-wide, read when a call starts / a handle is made
+static const int64_t kOptionDefaults[FMGPU_OPT_COUNT_] = {1, 1, 1, 1, 1, 1, 1, 0, 0, 0};
+static std::atomic<int64_t> g_options[FMGPU_OPT_COUNT_];
+static std::once_flag g_options_once;
+static void options_init() {
+    for (int i = 0; i < FMGPU_OPT_COUNT_; ++i) g_options[i].store(kOptionDefaults[i], std::memory_order_relaxed);
+#ifdef FMGPU_DEV                                                     // (development builds only: the environment names the initial values)
+    static const char* const names[FMGPU_OPT_COUNT_] = {"FMGPU_PAIRS", "FMGPU_DENSE_DNA", "FMGPU_FLAT", "FMGPU_SHADOW", "FMGPU_LF_TABLE", "FMGPU_FUSED_LOCATE", "FMGPU_HEAVY_FIRST",
+                                                        "FMGPU_FORCE_WIDE", "FMGPU_DEV_FLAGS", "FMGPU_FAIL_SCRATCH"};
+    for (int i = 0; i < FMGPU_OPT_COUNT_; ++i) if (const char* e = getenv(names[i])) g_options[i].store(atoll(e), std::memory_order_relaxed);
+#endif
+}
+int64_t opt(int option) {
+    std::call_once(g_options_once, options_init);
+    return option >= 0 && option < FMGPU_OPT_COUNT_ ? g_options[option].load(std::memory_order_relaxed) : 0;
+}
+static int set_opt(int option, int64_t value) {
+    std::call_once(g_options_once, options_init);
+    if (option < 0 || option >= FMGPU_OPT_COUNT_) return fail(FMGPU_ERR_INVALID, "unknown option " + std::to_string(option));
+    if (option == FMGPU_OPT_KERNEL_SELECT && (value & ~(int64_t)FMGPU_SEL_ALL)) return fail(FMGPU_ERR_INVALID, "FMGPU_OPT_KERNEL_SELECT: bits outside FMGPU_SEL_ALL");
+    g_options[option].store(value, std::memory_order_relaxed);
+    return 0;
 }
 
 // ---- per-thread, per-device scratch -----------------------------------------------------------------------------------------------
 // Built into a local object and published only when every allocation has succeeded: a failed hipMalloc (plausible next to 224 GB of
 // tables) leaves nothing half-initialised behind, and the next call simply tries again.  Keyed by device: a host thread that alternates
-// between handles on two devices re-uses both sets.  FMGPU_FAIL_SCRATCH=k (test knob) fails the k-th allocation of the next creation.
+// between handles on two devices re-uses both sets.  FMGPU_OPT_FAIL_SCRATCH = k (test hook) fails the k-th allocation of the next creation.
 void CallScratch::drop() {
     for (void* p : {(void*)ctr, (void*)sink, (void*)len2, frames, dfs_ctr, order}) if (p) (void)hipFree(p);
     if (pinned) (void)hipHostFree(pinned);
@@ -89,8 +111,7 @@ int call_scratch(CallScratch** out) {
     auto it = set.by_dev.find(dev);
     if (it != set.by_dev.end()) { *out = &it->second; return 0; }
     CallScratch sc;
-    int inject = 0;
-    if (const char* e = getenv("FMGPU_FAIL_SCRATCH")) inject = atoi(e);
+    const int inject = (int)opt(FMGPU_OPT_FAIL_SCRATCH);
     int step = 0;
     auto guard = [&](hipError_t e, const char* what) -> int {
         ++step;
@@ -137,6 +158,13 @@ static inline const IndexHeader* header_of(fmgpu_index_t h) {
 extern "C" {
 
 int fmgpu_abi_version(void) { return FMGPU_ABI_VERSION; }
+int fmgpu_set_option(int32_t option, int64_t value) { return set_opt(option, value); }
+int fmgpu_get_option(int32_t option, int64_t* value) {
+    if (!value) return fail(FMGPU_ERR_INVALID, "value is null");
+    if (option < 0 || option >= FMGPU_OPT_COUNT_) return fail(FMGPU_ERR_INVALID, "unknown option " + std::to_string(option));
+    *value = opt(option);
+    return 0;
+}
 const char* fmgpu_last_error(void) { return last_error_cstr(); }
 
 int fmgpu_device_count(int* count) {
@@ -206,6 +234,7 @@ int fmgpu_index_destroy(fmgpu_index_t h) { if (!h) return 0; ROUTE(h, fmgpu_inde
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes) {
     ROUTE(h, fmgpu_index_info(h, n, sigma, layout, bidirectional, device_bytes));
 }
+int fmgpu_index_formats(fmgpu_index_t h, uint32_t* mask) { ROUTE(h, fmgpu_index_formats(h, mask)); }
 int fmgpu_index_row_bits(fmgpu_index_t h, int32_t* bits) {
     const IndexHeader* hd = header_of(h);
     if (!hd || !bits) return fail(FMGPU_ERR_INVALID, "index handle / bits is null");

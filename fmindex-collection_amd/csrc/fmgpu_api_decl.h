@@ -3,6 +3,7 @@
 int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out);
 int fmgpu_index_destroy(fmgpu_index_t h);
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes);
+int fmgpu_index_formats(fmgpu_index_t h, uint32_t* mask);
 int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep);
 int fmgpu_index_accelerate_exact(fmgpu_index_t h, int32_t kstep, int32_t lut_len, int32_t walk);
 int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t walk);

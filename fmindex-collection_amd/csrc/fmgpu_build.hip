@@ -668,8 +668,7 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return bail(hip_fail(e, "index construction"));
     text.release(); sa.release(); bwt.release();
-    const char* lfe = getenv("FMGPU_LF_TABLE");
-    if (!(lfe && atoi(lfe) == 0)) {
+    if (opt_on(FMGPU_OPT_LF_TABLE)) {
         if ((rc = build_lf_table(x->bwt, stream))) return bail(rc);
         if (x->bidirectional && (rc = build_lf_table(x->rev, stream))) return bail(rc);
     }

@@ -44,11 +44,11 @@
 //     64-bit rows (n < 2^38): the line's counts are relative to its super-block of 2^30 rows, `pairs_super[sb][16]` holds the interval start + the count before it.
 //
 //  Format S  ("symbol planes": the bwt of an index with 6 <= sigma <= 29 that arrived as a Wavelet or as EPR / EPRV2 blocks, beside Format M / R — what exact search reads there, one line per LF step and end):
-//     one line of 128 bytes per 64 rows:  u64 plane[5] = bit k of each row's symbol;  then sigma 3-byte numbers = the rows before the line that hold
-//     symbol c, counted from the start of the line's super-block of 2^24 rows (read with one unaligned dword load);  flat_super[sb][c] = C[c] + the rows holding c before
-//     super-block sb (sigma * 3 + 40 <= 128 bytes: sigma <= 29).  LF(i, c) = flat_super[i >> 24][c] + count24[c] + popcount(rows of the line below i
-//     whose five plane bits spell c).  The multi-ary wavelet tree takes two lines per step and end for sigma = 28 (two levels); the super table (13 KB at
-//     2 x 10^9 rows) stays in L2.  2 bytes per row.
+//     one line of 128 bytes per 64 rows:  u64 plane[5] = bit k of each row's symbol;  then, bit-packed into the 88 bytes behind them, sigma numbers of
+//     B = flat_count_bits(sigma) = min(28, 704 / sigma) bits (sigma = 28: 25, sigma = 29: 24) = the rows before the line that hold symbol c, counted from the start of the
+//     line's super-block of 2^B rows (two LDS words and one funnel shift);  flat_super[sb][c] = C[c] + the rows holding c before super-block sb (24 * sigma + 320 <= 1024
+//     bits: sigma <= 29).  LF(i, c) = flat_super[i >> B][c] + count[c] + popcount(rows of the line below i whose five plane bits spell c).  The multi-ary wavelet
+//     tree takes two lines per step and end for sigma = 28 (two levels); the super table (6.7 KB at 2 x 10^9 rows, 19 KB as 5-byte entries at 4.5 x 10^9) is staged in LDS.  2 bytes per row.
 //
 //  Format R  (reference layout as is — InterleavedEPR*, InterleavedEPRV2*): blocks + superBlocks copied verbatim.
 //
@@ -122,13 +122,13 @@ inline int grid_of(uint64_t threads, dim3* out, uint64_t cap_blocks = 0) {
 }
 #define FM_GRID(var, threads)       dim3 var; do { int rc_ = ::fmgpu::grid_of((threads), &var); if (rc_) return rc_; } while (0)
 
-// Environment switches.  The shipped library honours FMGPU_HEAVY_FIRST, FMGPU_LF_TABLE, FMGPU_FORCE_WIDE and FMGPU_FAIL_SCRATCH (test knobs) and the
-// kernel-SELECTION bits of FMGPU_DEV_FLAGS (which of several result-identical kernels / tables serves a call: the parity tests run every
-// kernel through them).  Everything else — count-only runs, per-read node dumps, tuning fields, residency overrides (FMGPU_DEV_*) — exists in
-// builds made with -DFMGPU_DEV only (make DEV=1; tools/k2_*_probe.py): a stray environment variable cannot make the shipped library drop records
+// Library options (fmgpu_set_option, include/fmgpu.h): which derived tables a new handle gets and which of several result-identical kernels serves a call.
+// The shipped library reads NO environment variable: tests, bench.py and the A/B tools set options through the ABI.  Builds made with -DFMGPU_DEV
+// (make DEV=1; tools/k2_*_probe.py) additionally honour the FMGPU_DEV_* environment knobs — count-only runs, per-read node dumps, tuning fields, residency
+// overrides — and take FMGPU_DEV_FLAGS as the initial kernel selection, so that a stray environment variable cannot make the shipped library drop records
 // or write outside a caller's buffer.
-constexpr int kSelectFlags = 2 | 4 | 8 | 16 | 32 | 64 | (1 << 21) | (1 << 22) | (1 << 24) | (1 << 29) | (1 << 30);   // (bit 22: exact search in one-symbol steps although Format P exists; bit 21: exact search on the wavelet levels although Format S exists)
-//   // general kernel | no prefix table | no LF^1..3 | no LF table in the general kernels | no walk table | no length buckets | no work sharing | k_scheme_lean on Format A although Format D exists | k_scheme_fast<PLAIN> instead of k_scheme_lean
+int64_t opt(int option);                      // current value of an fmgpu_option (fmgpu_abi.hip)
+inline bool opt_on(int option) { return opt(option) != 0; }
 inline const char* dev_env(const char* name) {
 #ifdef FMGPU_DEV
     return getenv(name);
@@ -136,11 +136,11 @@ inline const char* dev_env(const char* name) {
     (void)name; return nullptr;
 #endif
 }
-inline int dev_flags_env() {
-    const char* e = getenv("FMGPU_DEV_FLAGS");
-    int f = e ? atoi(e) : 0;
-#ifndef FMGPU_DEV
-    f &= kSelectFlags;
+// bits of FMGPU_OPT_KERNEL_SELECT (FMGPU_SEL_* in include/fmgpu.h); a DEV build ORs the non-selection bits of FMGPU_DEV_FLAGS in (1 = count hits only, ...)
+inline int kernel_flags() {
+    int f = (int)opt(FMGPU_OPT_KERNEL_SELECT) & FMGPU_SEL_ALL;
+#ifdef FMGPU_DEV
+    if (const char* e = getenv("FMGPU_DEV_FLAGS")) f |= atoi(e);
 #endif
     return f;
 }
@@ -709,6 +709,8 @@ int build_pair_table(Index* x, hipStream_t stream);
 // that every search of the DNA path runs on the same kernels whatever layout the caller's index has (FMGPU_SHADOW=0: only on fmgpu_index_accelerate); adds nothing to
 // device_bytes itself; defined in fmgpu_index.hip
 int auto_shadow(Index* x, hipStream_t stream);
+// Format S: bits of a count inside a line (= log2 of the rows per super-block); 28 at most, so that a super-block's scan stays short
+constexpr uint32_t flat_count_bits(uint32_t sigma) { return sigma == 0u ? 28u : ((704u / sigma) < 28u ? (704u / sigma) : 28u); }
 // builds Format S beside the Wavelet bwt of an index with 6 <= sigma <= 29 (no-op where it does not apply; adds its bytes to device_bytes); defined in fmgpu_index.hip
 int build_flat_table(Index* x, hipStream_t stream);
 void free_string(DevString& s);

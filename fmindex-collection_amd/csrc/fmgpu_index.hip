@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void k_fuse_presence(uint8_t* __restrict__ blk
 }
 int fuse_presence_bits(Index* x, hipStream_t stream) {
     DevString& s = x->bwt;
-    const char* off = getenv("FMGPU_FUSED_LOCATE");
-    if (!x->has_sa || s.search_family() != FAM_A || s.va.bstride != 64u || s.sigma < 2 || s.va.fused || (off && atoi(off) == 0)) return 0;   // (the string's own Format A blocks, or its expansion)
+    if (!x->has_sa || s.search_family() != FAM_A || s.va.bstride != 64u || s.sigma < 2 || s.va.fused || !opt_on(FMGPU_OPT_FUSED_LOCATE)) return 0;   // (the string's own Format A blocks, or its expansion)
     const uint64_t nblocks = s.n / 64 + 1;
     FM_GRID(grid, nblocks);
     k_fuse_presence<<<grid, dim3(256), 0, stream>>>(const_cast<uint8_t*>(s.va.blk), x->vsa, nblocks);
@@ -145,8 +144,7 @@ int fuse_presence_bits(Index* x, hipStream_t stream) {
 }
 
 int auto_shadow(Index* x, hipStream_t stream) {
-    const char* off = getenv("FMGPU_SHADOW");
-    if (x->bwt.sigma != 5 || (off && atoi(off) == 0)) return 0;
+    if (x->bwt.sigma != 5 || !opt_on(FMGPU_OPT_EXPAND_DNA)) return 0;
     for (DevString* t : {&x->bwt, &x->rev}) {
         if (t->n == 0 || t->family == FAM_A || t->shadow) continue;
         int rc = build_format_a_shadow(*t, x->dC, stream);
@@ -177,8 +175,7 @@ __global__ __launch_bounds__(256) void k_dense_dna(const uint8_t* __restrict__ b
     }
 }
 int build_dense_dna(DevString& s, hipStream_t stream) {
-    const char* off = getenv("FMGPU_DENSE_DNA");
-    if (kWide || s.sigma != 5 || s.search_family() != FAM_A || s.va.bstride != 64u || s.n < 2 || s.dense || (off && atoi(off) == 0)) return 0;   // (Format A blocks: the string's own or its expansion)
+    if (kWide || s.sigma != 5 || s.search_family() != FAM_A || s.va.bstride != 64u || s.n < 2 || s.dense || !opt_on(FMGPU_OPT_DENSE_DNA)) return 0;   // (Format A blocks: the string's own or its expansion)
     // (reads the entries of symbols 1..4 only: entry 0's bitmap may already hold the presence bits)
     const uint64_t nblocks = s.n / 64 + 1;
     DBuf out, ex, cnt; int rc;
@@ -283,8 +280,7 @@ __global__ void k_pair_super(OccA<5> occ, const uint64_t* __restrict__ totals, u
 }
 int build_pair_table(Index* x, hipStream_t stream) {
     DevString& s = x->bwt;
-    const char* off = getenv("FMGPU_PAIRS");
-    if (s.sigma != 5 || s.search_family() != FAM_A || s.va.bstride != 64u || s.n < 2 || s.n >= (1ull << 38) || s.pairs || (off && atoi(off) == 0)) return 0;
+    if (s.sigma != 5 || s.search_family() != FAM_A || s.va.bstride != 64u || s.n < 2 || s.n >= (1ull << 38) || s.pairs || !opt_on(FMGPU_OPT_PAIR_TABLE)) return 0;
     const uint64_t nlines = s.n / 128 + 1;
     DBuf out, part, ex, cnt, tmp, totals, super; int rc;
     if ((rc = out.alloc(nlines * 128)) || (rc = part.alloc(nlines * 16 * 4)) || (rc = ex.alloc(kPairMaxRows * sizeof(idx_t))) || (rc = cnt.alloc(8))) return rc;
@@ -329,7 +325,8 @@ int build_pair_table(Index* x, hipStream_t stream) {
 }
 
 // ---- Format S (fmgpu_common.h): a flat one-line-per-64-rows occurrence table from the symbols of a Wavelet string.
-constexpr uint32_t kFlatSuperShift = 24;            // rows per super-block: the counts inside a line are 24 bits wide
+// The counts inside a line are flat_count_bits(sigma) wide (as many as the 88 bytes behind the planes allow: sigma = 28: 25, sigma = 29: 24) and relative to the line's
+// super-block of 2^bits rows: the wider the counts, the smaller the super table k_exact_s keeps in LDS.
 template <class Occ>
 __global__ __launch_bounds__(256) void k_flat_planes(Occ occ, uint64_t n, uint32_t sigma, uint8_t* __restrict__ lines, uint8_t* __restrict__ cnt8, uint64_t nlines) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -349,13 +346,15 @@ __global__ __launch_bounds__(256) void k_flat_planes(Occ occ, uint64_t n, uint32
         }
     }
 }
-// workgroup (sb, c): the running count of symbol c through the lines of super-block sb, written into the lines; the super-block's total
-__global__ __launch_bounds__(256) void k_flat_counts(const uint8_t* __restrict__ cnt8, uint64_t nlines, uint32_t sigma, uint8_t* __restrict__ lines, uint32_t* __restrict__ totals) {
+// workgroup (sb, c): the running count of symbol c through the lines of super-block sb, written into the lines (bits [c * cbits, (c + 1) * cbits) of the 88 bytes
+// behind the planes; the lines start zeroed, workgroups of different symbols share dwords: atomicOr); the super-block's total
+__global__ __launch_bounds__(256) void k_flat_counts(const uint8_t* __restrict__ cnt8, uint64_t nlines, uint32_t sigma, uint32_t cbits, uint8_t* __restrict__ lines, unsigned long long* __restrict__ totals) {
     typedef hipcub::BlockScan<uint32_t, 256> Scan;
     __shared__ typename Scan::TempStorage tmp;
     const uint32_t sb = blockIdx.x, c = blockIdx.y;
-    const uint64_t first = (uint64_t)sb << (kFlatSuperShift - 6), last = min(nlines, first + (1ull << (kFlatSuperShift - 6)));
-    uint32_t run = 0;
+    const uint64_t first = (uint64_t)sb << (cbits - 6), last = min(nlines, first + (1ull << (cbits - 6)));
+    const uint32_t bitpos = c * cbits, w = 10u + (bitpos >> 5), sh = bitpos & 31u;
+    unsigned long long run = 0;
     for (uint64_t base = first; base < last; base += 256u) {
         const uint64_t L = base + threadIdx.x;
         const uint32_t v = L < last ? cnt8[(size_t)c * nlines + L] : 0u;
@@ -363,15 +362,16 @@ __global__ __launch_bounds__(256) void k_flat_counts(const uint8_t* __restrict__
         Scan(tmp).ExclusiveSum(v, before, sum);
         __syncthreads();
         if (L < last) {
-            const uint32_t t = run + before;
-            uint8_t* ln = lines + L * 128u;
-            ln[40u + 3u * c] = (uint8_t)t; ln[41u + 3u * c] = (uint8_t)(t >> 8); ln[42u + 3u * c] = (uint8_t)(t >> 16);
+            const uint32_t t = (uint32_t)run + before;              // (< 2^cbits: the rows of the super-block before the line)
+            uint32_t* ln = reinterpret_cast<uint32_t*>(lines + L * 128u);
+            if (t << sh) atomicOr(&ln[w], t << sh);
+            if (sh + cbits > 32u && (t >> (32u - sh))) atomicOr(&ln[w + 1u], t >> (32u - sh));
         }
         run += sum;
     }
     if (threadIdx.x == 0) totals[(size_t)sb * sigma + c] = run;
 }
-__global__ void k_flat_super(const idx_t* __restrict__ C, const uint32_t* __restrict__ totals, uint32_t nsb, uint32_t sigma, idx_t* __restrict__ super) {
+__global__ void k_flat_super(const idx_t* __restrict__ C, const unsigned long long* __restrict__ totals, uint32_t nsb, uint32_t sigma, idx_t* __restrict__ super) {
     const uint32_t c = threadIdx.x;
     if (c >= sigma) return;
     idx_t run = C[c];
@@ -379,13 +379,13 @@ __global__ void k_flat_super(const idx_t* __restrict__ C, const uint32_t* __rest
 }
 int build_flat_table(Index* x, hipStream_t stream) {
     DevString& s = x->bwt;
-    const char* off = getenv("FMGPU_FLAT");
     // (beside a Wavelet, or EPR / EPRV2 blocks read in place: Format A reads one line per step and end already; n < 2^38: a line number fits 32 bits in k_exact_s)
-    if (s.family == FAM_A || s.sigma < 6 || s.sigma > 29 || s.n < 2 || s.n >= (1ull << 38) || s.flat || (off && atoi(off) == 0)) return 0;
+    if (s.family == FAM_A || s.sigma < 6 || s.sigma > 29 || s.n < 2 || s.n >= (1ull << 38) || s.flat || !opt_on(FMGPU_OPT_SYMBOL_PLANES)) return 0;
     const uint64_t nlines = s.n / 64 + 1;
-    const uint32_t nsb = (uint32_t)(s.n >> kFlatSuperShift) + 1u, sigma = (uint32_t)s.sigma;
+    const uint32_t sigma = (uint32_t)s.sigma, cbits = flat_count_bits(sigma);
+    const uint32_t nsb = (uint32_t)(s.n >> cbits) + 1u;
     DBuf out, cnt8, totals, super; int rc;
-    if ((rc = out.alloc(nlines * 128)) || (rc = cnt8.alloc(nlines * sigma)) || (rc = totals.alloc((size_t)nsb * sigma * 4)) || (rc = super.alloc((size_t)nsb * sigma * sizeof(idx_t)))) return rc;
+    if ((rc = out.alloc(nlines * 128)) || (rc = cnt8.alloc(nlines * sigma)) || (rc = totals.alloc((size_t)nsb * sigma * 8)) || (rc = super.alloc((size_t)nsb * sigma * sizeof(idx_t)))) return rc;
     FM_HIP(hipMemsetAsync(out.p, 0, out.bytes, stream));
     dim3 grid; if ((rc = grid_of(nlines * 64, &grid, 1u << 22))) return rc;
     rc = dispatch_native(s, [&](auto occ, auto) {
@@ -394,9 +394,9 @@ int build_flat_table(Index* x, hipStream_t stream) {
     });
     if (rc) return rc;
     FM_LAUNCHED("k_flat_planes");
-    k_flat_counts<<<dim3(nsb, sigma), dim3(256), 0, stream>>>(cnt8.as<uint8_t>(), nlines, sigma, out.as<uint8_t>(), totals.as<uint32_t>());
+    k_flat_counts<<<dim3(nsb, sigma), dim3(256), 0, stream>>>(cnt8.as<uint8_t>(), nlines, sigma, cbits, out.as<uint8_t>(), totals.as<unsigned long long>());
     FM_LAUNCHED("k_flat_counts");
-    k_flat_super<<<1, 32, 0, stream>>>(x->dC, totals.as<uint32_t>(), nsb, sigma, super.as<idx_t>());
+    k_flat_super<<<1, 32, 0, stream>>>(x->dC, totals.as<unsigned long long>(), nsb, sigma, super.as<idx_t>());
     FM_LAUNCHED("k_flat_super");
     FM_HIP(hipStreamSynchronize(stream));
     s.flat_bytes = out.bytes + super.bytes; s.flat = (uint8_t*)out.take(); s.flat_super = (idx_t*)super.take(); s.flat_nsb = nsb;
@@ -951,7 +951,7 @@ int fmgpu_index_destroy(fmgpu_index_t h) {
     return 0;
 }
 
-static bool lf_table_wanted() { const char* e = getenv("FMGPU_LF_TABLE"); return !(e && atoi(e) == 0); }
+static bool lf_table_wanted() { return opt_on(FMGPU_OPT_LF_TABLE); }
 
 int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out) {
     if (!desc || !out) return fail(FMGPU_ERR_INVALID, "desc / out is null");
@@ -1223,6 +1223,28 @@ int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layo
     if (layout) *layout = x->bwt.layout;
     if (bidirectional) *bidirectional = x->bidirectional ? 1 : 0;
     if (device_bytes) *device_bytes = x->device_bytes;
+    return 0;
+}
+
+int fmgpu_index_formats(fmgpu_index_t h, uint32_t* mask) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x || !mask) return fail(FMGPU_ERR_INVALID, "index handle / mask is null");
+    const DevString& s = x->bwt;
+    uint32_t m = 0;
+    if (s.search_family() == FAM_A) m |= FMGPU_FMT_BLOCKS;
+    if (s.pairs) m |= FMGPU_FMT_PAIRS;
+    if (s.dense) m |= FMGPU_FMT_DENSE;
+    if (s.flat) m |= FMGPU_FMT_PLANES;
+    if (s.family == FAM_WAVELET) m |= FMGPU_FMT_TREE;
+    if (s.family == FAM_EPR || s.family == FAM_EPRV2) m |= FMGPU_FMT_REFERENCE;
+    if (s.lf_table) m |= FMGPU_FMT_LF;
+    if (s.kblk) m |= FMGPU_FMT_KSTEP;
+    if (s.slut) m |= FMGPU_FMT_INTERVALS;
+    if (s.walkj || s.walk3) m |= FMGPU_FMT_WALK;
+    if (x->lut) m |= FMGPU_FMT_PREFIX;
+    if (x->loc_tab) m |= FMGPU_FMT_LOCATE;
+    if (s.va.fused) m |= FMGPU_FMT_FUSED;
+    *mask = m;
     return 0;
 }
 

@@ -331,13 +331,14 @@ __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __r
 // LDS (LDS-DMA: piece j of lane 8o + k's line lands at region k, offset 128 o + 16 j), from where the owner reads its planes and count.  The loop is
 // wave-uniform (reads that are over ride along with a dummy line); waves do not synchronise with each other.
 // rows before row i that hold symbol c in the owner's line (now in LDS) + the line's count of c
-__device__ __forceinline__ uint32_t flat_rank_lds(const lds_word* own, uint32_t i, uint32_t c) {
+__device__ __forceinline__ uint32_t flat_rank_lds(const lds_word* own, uint32_t i, uint32_t c, uint32_t cbits) {
     const flat_u32x4 p01 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own);
     const flat_u32x4 p23 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 4);
     const uint32_t p4l = own[8], p4h = own[9];
-    const lds_word* g = own + 10u + 3u * (c >> 2);
-    const uint32_t d0 = g[0], d1 = g[1], d2 = g[2], k = c & 3u;
-    const uint32_t cnt = k == 0u ? (d0 & 0xffffffu) : (k == 1u ? ((d0 >> 24) | ((d1 & 0xffffu) << 8)) : (k == 2u ? ((d1 >> 16) | ((d2 & 0xffu) << 16)) : (d2 >> 8)));
+    // the symbol's count: cbits bits at bit c * cbits of the 88 bytes behind the planes (the word behind the last one may be the next line's first: masked away)
+    const uint32_t bitpos = c * cbits;
+    const lds_word* g = own + 10u + (bitpos >> 5);
+    const uint32_t cnt = __funnelshift_r(g[0], g[1], bitpos & 31u) & ((1u << cbits) - 1u);
     const uint32_t i0 = (c & 1u) ? 0u : ~0u, i1 = (c & 2u) ? 0u : ~0u, i2 = (c & 4u) ? 0u : ~0u, i3 = (c & 8u) ? 0u : ~0u, i4 = (c & 16u) ? 0u : ~0u;
     const uint32_t off = i & 63u;
     const uint32_t mlo = off >= 32u ? ~0u : (1u << off) - 1u, mhi = off > 32u ? (1u << (off - 32u)) - 1u : 0u;
@@ -345,15 +346,28 @@ __device__ __forceinline__ uint32_t flat_rank_lds(const lds_word* own, uint32_t 
     const uint32_t hi = (p01.y ^ i0) & (p01.w ^ i1) & (p23.y ^ i2) & (p23.w ^ i3) & (p4h ^ i4);
     return cnt + __popc(lo & mlo) + __popc(hi & mhi);
 }
-__global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ flat, const idx_t* __restrict__ super, uint32_t sigma,
+// the super table in LDS: 32-bit rows as they are; 64-bit rows as a low word + a high byte per entry (5 instead of 8 bytes: sigma = 28, 4.5 x 10^9 rows: 19 KB,
+// four resident blocks per CU; read through L2 instead the kernel took 13 % longer on the same text)
+constexpr size_t kFlatSuperLdsMax = 44 * 1024;      // (with the 16.6 KB of the regions: within the 64 KB a launch gets without asking)
+__host__ __device__ constexpr size_t flat_super_lds_bytes(uint32_t entries) { return kWide ? ((size_t)entries * 5u + 15u) / 16u * 16u : (size_t)entries * 4u; }
+__global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ flat, const idx_t* __restrict__ super, uint32_t sigma, uint32_t cbits,
                                                  const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                  unsigned long long* __restrict__ steps_total, uint32_t super_lds) {
-    extern __shared__ uint32_t s_flat[];                            // 4 waves x 8 regions | the super table, when it is small (super_lds entries)
-    idx_t* const s_super = reinterpret_cast<idx_t*>(s_flat + 4u * 8u * (kCoopRegion / 4u));
-    for (uint32_t t = threadIdx.x; t < super_lds; t += 256u) s_super[t] = super[t];
+    extern __shared__ uint32_t s_flat[];                            // 4 waves x 8 regions | 16 bytes | the super table, when it fits (super_lds entries)
+    uint32_t* const s_lo = s_flat + 4u * 8u * (kCoopRegion / 4u) + 4u;
+    uint8_t* const s_hi = reinterpret_cast<uint8_t*>(s_lo + super_lds);
+    for (uint32_t t = threadIdx.x; t < super_lds; t += 256u) {
+        const idx_t v = super[t];
+        s_lo[t] = (uint32_t)v;
+        if constexpr (kWide) s_hi[t] = (uint8_t)((uint64_t)v >> 32);
+    }
     __syncthreads();
-    const idx_t* sup = super_lds ? s_super : super;
+    auto sup = [&](size_t at) -> idx_t {
+        if (!super_lds) return super[at];
+        if constexpr (kWide) return (idx_t)s_lo[at] | ((idx_t)s_hi[at] << 32);
+        else return (idx_t)s_lo[at];
+    };
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     lds_word* const wave_lds = (lds_word*)(s_flat + wave * 8u * (kCoopRegion / 4u));
     const lds_word* const own = wave_lds + (lane & 7u) * (kCoopRegion / 4u) + (lane >> 3) * 32u;
@@ -385,17 +399,17 @@ __global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ fla
         coop_round(flat, la, lane, wave_lds);
         idx_t sa = 0, sb = 0;
         if (alive) {
-            sa = sup[(size_t)(a >> 24) * sigma + c];
+            sa = sup((size_t)(a >> cbits) * sigma + c);
             sb = sa;
-            if ((a >> 24) != (b >> 24)) sb = sup[(size_t)(b >> 24) * sigma + c];
+            if ((a >> cbits) != (b >> cbits)) sb = sup((size_t)(b >> cbits) * sigma + c);
             acc += far ? 2u : 1u;
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): the round's pieces are in LDS
         asm volatile("" ::: "memory");
         idx_t ra = 0, rb = 0;
         if (alive) {
-            ra = sa + flat_rank_lds(own, (uint32_t)a, c);
-            if (!far) rb = sb + flat_rank_lds(own, (uint32_t)b, c);
+            ra = sa + flat_rank_lds(own, (uint32_t)a, c, cbits);
+            if (!far) rb = sb + flat_rank_lds(own, (uint32_t)b, c, cbits);
         }
         if (__ballot(far)) {                                        // the other end's lines, where they are other lines (the first log_sigma(n) steps of a read)
             __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): every lane has read what it needs of the first round
@@ -403,7 +417,7 @@ __global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ fla
             coop_round(flat, far ? lbn : 0u, lane, wave_lds);
             __builtin_amdgcn_s_waitcnt(0x0f70);
             asm volatile("" ::: "memory");
-            if (far) rb = sb + flat_rank_lds(own, (uint32_t)b, c);
+            if (far) rb = sb + flat_rank_lds(own, (uint32_t)b, c, cbits);
         }
         if (alive) {
             lb = ra; len = rb - ra;
@@ -2785,6 +2799,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
 
     const uint32_t gid = blockIdx.x * 256u + tid;                   // frame d of this lane at frames[d * nlanes + gid]
     uint32_t nodes = 0, mark = 0, waste = 0, nodes0 = 0;            // nodes0: the lane's count when it took its current read (or subtree)
+    uint32_t blk_loads = 0, multi_nodes = 0;                        // blocks this lane fetched (a second end in another block counts) / visited nodes of several rows: fmgpu_stats::table_accesses, ::table_bytes
 #ifdef FMGPU_DEV_STAMPS
     unsigned long long st_top = 0, st_share = 0, st_refill = 0, st_sync = 0, st_issue = 0, st_wait = 0, st_node = 0, st_tail = 0, st_t = __builtin_amdgcn_s_memtime(), st_steps = 0;
 #define STAMP(acc) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - st_t; st_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -2901,6 +2916,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         // the second end's block only when it is another one (the ends of a short interval share their block)
         const bool far = multi && (a >> 6) != (b >> 6);
         if (far) { const Quad4* pb = reinterpret_cast<const Quad4*>(blk + (size_t)(b >> 6) * kBlk + kOff); b0 = pb[0]; b1 = pb[1]; if constexpr (!DENSE) b2 = pb[2]; }
+        blk_loads += far ? 2u : 1u;
         STAMP(st_issue);
 #ifdef FMGPU_DEV_STAMPS
         __builtin_amdgcn_s_waitcnt(0x0f70); STAMP(st_wait);
@@ -2974,7 +2990,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             const bool take_sub = !take_match && subs != 0u;
             uint32_t take = c;
             if (take_sub) { take = (uint32_t)__ffs((int)subs) - 1u; subs &= subs - 1u; }
-            nodes += (!resuming && (in_tail || xOK || mOK)) ? 1u : 0u;
+            { const uint32_t cnt_ = (!resuming && (in_tail || xOK || mOK)) ? 1u : 0u; nodes += cnt_; multi_nodes += cnt_; }
             if ((take_match || take_sub) && subs) {                 // (re-)push the parent: its remaining siblings start at the lowest of subs
                 uint64_t fw0, fw1;
                 lean_pack(lb, lbRev, len, j, e, (uint32_t)__ffs((int)subs) - 1u, fw0, fw1);
@@ -3072,6 +3088,12 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
 #ifdef FMGPU_DEV
     { const uint32_t a1 = wave_sum(dev_multi), a2 = wave_sum(dev_iter), a3 = wave_sum(dev_busy);
       if (lane == 0) { atomicAdd(&ctr->table_accesses, (unsigned long long)a1 | ((unsigned long long)a2 << 40)); atomicAdd(&ctr->table_bytes, (unsigned long long)a3); } }
+    (void)blk_loads; (void)multi_nodes;
+#else
+    // what the kernel asked of the occurrence tables: table_accesses = blocks fetched (both ends of a node whose ends lie in two blocks; a node re-visited for its next
+    // sibling fetches again), table_bytes = visited nodes of several rows (the rest of `nodes` stood on one row: one interval end) — bench.py prices both
+    { const uint32_t a1 = wave_sum(blk_loads), a2 = wave_sum(multi_nodes);
+      if (lane == 0 && (a1 | a2)) { atomicAdd(&ctr->table_accesses, (unsigned long long)a1); atomicAdd(&ctr->table_bytes, (unsigned long long)a2); } }
 #endif
 }
 
@@ -3234,6 +3256,111 @@ __global__ __launch_bounds__(256) void k_locate_fused(OccA<SIGMA> occ, ViewSA sa
         out_seq[t] = seq; out_pos[t] = pos; out_steps[t] = st;
     }
     add_counters(steps_total, steps, 0u, 0u);
+}
+
+// The same walk with the blocks fetched by the four lanes of a QUAD together and the rows of a wave handed out as lanes fall idle.  k_locate_fused keeps one
+// row per lane: the rows of a wave need 0..15 steps, so half of the lanes idle while the slowest walks, and every lane reads its 64-byte block with four
+// 16-byte loads of its own (four address translations and four passes through the texture path per block, on a table of 3-4 GB: fmgpu_common.h / DESIGN 4.3).
+// Here a wave owns kLocChunk rows, staged in LDS; a lane that reaches its sampled row parks the result in the row's LDS slot and takes the next unassigned row
+// (ballot + prefix count: no atomic); instruction k of a round has the four lanes of every quad load the four 16-byte pieces of the block of the quad's
+// lane k straight into LDS (one 64-byte request and one translation per block); the owner reads its block from there.  The value words (two DenseVector
+// reads per row) are fetched after the walk, by all lanes at once.  The loop is wave-uniform; waves never synchronise with each other.
+constexpr uint32_t kLocChunk = 512;                  // rows per wave
+constexpr uint32_t kLocRegion = 1024u + 16u;         // bytes per region of a round (64 pieces + padding that spreads the owners' reads over the LDS banks)
+constexpr uint32_t kLocSlotWords = kWide ? 4u : 2u;  // a row's LDS slot: the row, later {rank among the sampled rows (32-bit rows) or the sampled row itself, steps}
+constexpr uint32_t kLocWaveWords = 4u * (kLocRegion / 4u) + kLocChunk * kLocSlotWords;
+constexpr uint32_t kLocNoSteps = 0xffffffffu;
+template <int SIGMA>
+__global__ __launch_bounds__(256) void k_locate_coop(OccA<SIGMA> occ, ViewSA sa, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
+                                                     uint64_t* __restrict__ out_seq, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_steps,
+                                                     unsigned long long* __restrict__ steps_total) {
+    extern __shared__ uint32_t s_loc[];                             // per wave: 4 regions | kLocChunk slots
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* const wbase = s_loc + wave * kLocWaveWords;
+    lds_word* const wave_lds = (lds_word*)wbase;
+    uint32_t* const slots = wbase + 4u * (kLocRegion / 4u);
+    const lds_word* const own = wave_lds + (lane & 3u) * (kLocRegion / 4u) + (lane >> 2) * 16u;
+    const uint64_t base = ((uint64_t)blockIdx.x * 4u + wave) * kLocChunk;
+    const uint32_t cnt = base < count ? (uint32_t)min((uint64_t)kLocChunk, count - base) : 0u;
+    for (uint32_t t = lane; t < cnt; t += 64u) {
+        const uint64_t r = rows[base + t];
+        if constexpr (kWide) { slots[4u * t] = (uint32_t)r; slots[4u * t + 1u] = (uint32_t)(r >> 32); slots[4u * t + 2u] = r < n ? 0u : kLocNoSteps; }
+        else { slots[2u * t] = (uint32_t)r; slots[2u * t + 1u] = r < n ? 0u : kLocNoSteps; }
+    }
+    const uint32_t s = occ.sigma();
+    uint32_t next = 0, my = 0, steps = 0, total_steps = 0;
+    idx_t row = 0;
+    bool active = false;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (;;) {
+        const uint64_t idle = __ballot(!active);
+        if (idle && next < cnt) {                                   // the i-th idle lane takes row next + i of the chunk
+            const uint32_t at = next + (uint32_t)__popcll(idle & below);
+            if (!active && at < cnt) {
+                const uint32_t* e = slots + (size_t)at * kLocSlotWords;
+                if (e[kLocSlotWords - (kWide ? 2u : 1u)] != kLocNoSteps) {      // (a row beyond the index keeps its "no answer" mark)
+                    if constexpr (kWide) row = (idx_t)e[0] | ((idx_t)e[1] << 32); else row = (idx_t)e[0];
+                    my = at; steps = 0; active = true;
+                }
+            }
+            next = min(cnt, next + (uint32_t)__popcll(idle));
+        }
+        if (!__ballot(active)) { if (next >= cnt) break; continue; }
+        const uint32_t blk = active ? (uint32_t)(row >> 6) : 0u;    // (n < 2^38: a block number fits 32 bits; an idle lane rides along with block 0)
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t l = __shfl(blk, (int)((lane & ~3u) | k), 64);
+            const uint8_t* g = occ.v.blk + (size_t)l * 64u + (lane & 3u) * 16u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(wave_lds + k * (kLocRegion / 4u)), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): the round's pieces are in LDS
+        asm volatile("" ::: "memory");
+        if (active) {
+            const flat_u32x4 q0 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own), q1 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 4);
+            const flat_u32x4 q2 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 8), q3 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 12);
+            const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const uint32_t bit = (uint32_t)row & 63u;
+            const uint64_t present = (uint64_t)d[1] | ((uint64_t)d[2] << 32);
+            uint32_t* e = slots + (size_t)my * kLocSlotWords;
+            if ((present >> bit) & 1ull) {                          // the sampled row: park the answer's coordinates in the slot
+                if constexpr (kWide) { e[0] = (uint32_t)row; e[1] = (uint32_t)((uint64_t)row >> 32); e[2] = steps; }
+                else { e[0] = d[15] + popc64(present & lowmask(bit)); e[1] = steps; }      // sampled rows before this one: the block's own count + its presence bits
+                active = false;
+            } else {
+                idx_t nxt = row + occ.v.ksum;                       // the delimiter's LF unless a symbol >= 1 claims the row
+                bool claimed = false;
+#pragma unroll
+                for (uint32_t c = 1; c < (uint32_t)(SIGMA > 0 ? SIGMA : 5); ++c) {
+                    if (c < s) {
+                        const uint64_t bits = (uint64_t)d[3 * c + 1] | ((uint64_t)d[3 * c + 2] << 32);
+                        idx_t lfc = d[3 * c] + popc64(bits & lowmask(bit));
+                        if constexpr (kWide) lfc += occ.v.super[(size_t)(row >> kSuperShift) * s + c];
+                        if ((bits >> bit) & 1ull) { claimed = true; nxt = lfc; }
+                        else if (!claimed) nxt -= lfc;
+                    }
+                }
+                row = nxt;
+                ++steps; ++total_steps;
+                if (steps >= kLocateStepCap) { e[kLocSlotWords - (kWide ? 2u : 1u)] = kLocNoSteps; active = false; }     // (a corrupt index: no answer)
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): the next round overwrites the regions
+        asm volatile("" ::: "memory");
+    }
+    for (uint32_t t = lane; t < cnt; t += 64u) {                    // the values of the sampled rows (suffixarray/SparseArray.h:63-70), all lanes at once
+        const uint32_t* e = slots + (size_t)t * kLocSlotWords;
+        uint64_t seq = ~0ull, pos = ~0ull, st = ~0ull;
+        const uint32_t ns = e[kLocSlotWords - (kWide ? 2u : 1u)];
+        if (ns != kLocNoSteps) {
+            uint64_t k;
+            if constexpr (kWide) k = sa_rank(sa, (idx_t)e[0] | ((idx_t)e[1] << 32)); else k = e[0];
+            seq = dense_access(sa.f0, sa.bits0, sa.div0, k);
+            pos = dense_access(sa.f1, sa.bits1, sa.div1, k);
+            st = ns;
+        }
+        out_seq[base + t] = seq; out_pos[base + t] = pos; out_steps[base + t] = st;
+    }
+    add_counters(steps_total, total_steps, 0u, 0u);
 }
 
 template <class Occ>
@@ -3597,14 +3724,15 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         // k_exact_a runs best with 5 resident blocks per CU, not the 8 its 28 registers allow (measured on the 3.09 Gbp index, 10 M x 101 bp: 8 / 6 / 5 / 4 / 3
         // blocks = 19.53 / 19.23 / 18.92 / 19.10 / 18.95 ms — more waves only queue up at the memory system): 28 KB of unused dynamic LDS set the residency
         const size_t lds_a = dev_env("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)28 * 1024;
-        if (x->bwt.sigma == 5 && x->bwt.pairs && !(dev_flags_env() & (1 << 22)))
+        if (x->bwt.sigma == 5 && x->bwt.pairs && !(kernel_flags() & (1 << 22)))
             k_exact_p<<<grid, block, 4 * 8 * kCoopRegion + dev_extra_lds, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, x->bwt.pairs_super, qb, qo, nq, n, ol, on, dsteps);
         else if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
-    } else if (x->bwt.flat && x->bwt.search_family() != FAM_A && !(dev_flags_env() & (1 << 21))) {
-        const size_t super_bytes = (size_t)x->bwt.flat_nsb * x->bwt.sigma * sizeof(idx_t);
-        const uint32_t super_lds = super_bytes <= 16 * 1024 ? x->bwt.flat_nsb * (uint32_t)x->bwt.sigma : 0u;      // (2 x 10^9 rows, sigma = 28: 13 KB)
-        k_exact_s<<<grid, block, 4 * 8 * kCoopRegion + (super_lds ? super_bytes : 0) + dev_extra_lds, stream>>>(x->bwt.flat, x->bwt.flat_super, (uint32_t)x->bwt.sigma, (const uint8_t*)sbuf.dev,
+    } else if (x->bwt.flat && x->bwt.search_family() != FAM_A && !(kernel_flags() & (1 << 21))) {
+        const uint32_t entries = x->bwt.flat_nsb * (uint32_t)x->bwt.sigma;
+        const uint32_t super_lds = flat_super_lds_bytes(entries) <= kFlatSuperLdsMax ? entries : 0u;      // (sigma = 28: 6.7 KB at 2 x 10^9 rows, 19 KB at 4.5 x 10^9)
+        k_exact_s<<<grid, block, 4 * 8 * kCoopRegion + 16 + flat_super_lds_bytes(super_lds) + dev_extra_lds, stream>>>(x->bwt.flat, x->bwt.flat_super, (uint32_t)x->bwt.sigma,
+                                                           flat_count_bits((uint32_t)x->bwt.sigma), (const uint8_t*)sbuf.dev,
                                                            (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps, super_lds);
     } else if (x->bwt.search_family() == FAM_WAVELET) {
         uint32_t mx = shape_max, mn = 0;
@@ -3687,7 +3815,7 @@ static size_t lean_lds_bytes(uint32_t m, size_t step_words) {
 static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uint32_t m, size_t step_words, dim3 g, const uint8_t* dq, const uint64_t* doff, uint64_t count,
                         fmgpu_hit* dout, uint64_t capacity, const DfsWorkspace& ws, const uint32_t* qm, hipStream_t stream) {
     const idx_t n = (idx_t)x->bwt.n;
-    const bool dense = x->bwt.dense && x->rev.dense && !(dev_flags_env() & (1 << 29));      // (bit 29 of FMGPU_DEV_FLAGS: read Format A although Format D exists)
+    const bool dense = x->bwt.dense && x->rev.dense && !(kernel_flags() & (1 << 29));      // (bit 29 of FMGPU_DEV_FLAGS: read Format A although Format D exists)
     LeanArgs la{x->bwt.va.blk, x->rev.va.blk, d_steps, S, m, (idx_t)(x->hC[1] + x->hC[2] + x->hC[3] + x->hC[4]), x->bwt.va.super, x->rev.va.super,
                 kWide ? (uint32_t)((x->bwt.n >> kSuperShift) + 1) : 0u,
                 (const uint4*)x->bwt.dense, (const uint4*)x->rev.dense, x->bwt.dense_ex, x->rev.dense_ex, x->bwt.dense_nex, x->rev.dense_nex};
@@ -3722,7 +3850,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         if (max_hits == 0 || scheme->n_searches == 0) return 0;                       // SearchNg26.h:408-409
         sd.S = scheme->n_searches; sd.P = scheme->n_parts; sd.uniform = scheme->partition ? 0 : 1;
         edit = scheme->edit != 0;
-        sd.dev_flags = dev_flags_env();
+        sd.dev_flags = kernel_flags();
         sd.use_key = 0; sd.sharing = 0;                              // set below for the general Hamming kernel
         for (int s = 0; s < sd.S; ++s) {
             uint32_t seen = 0;
@@ -3804,8 +3932,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         lean_wide = build_step_table(sd, maxlen, 0, 0, wide_tab, lut_ok);
         if (lean_wide) {
             wide_tab.resize(wide_tab.size() / 3);                  // (the stretch words serve the walk tables)
-            const char* hf = getenv("FMGPU_HEAVY_FIRST");
-            if (maxlen >= 16 && nq >= (1u << 16) && nq < 0x7fffffffull && !(hf && atoi(hf) == 0)) {
+            if (maxlen >= 16 && nq >= (1u << 16) && nq < 0x7fffffffull && opt_on(FMGPU_OPT_HEAVY_FIRST)) {
                 uint32_t* order = nullptr;
                 const auto pre_t0 = std::chrono::steady_clock::now();
                 if ((rc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
@@ -3833,10 +3960,10 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         Bucket b{maxlen, 0, nq, {}, 0};
         fast = build_step_table(sd, maxlen, lutL, use_wj ? 16u : 0u, b.tab, b.lut_ok);
         if (fast) buckets.push_back(std::move(b));
-        const char* hf = getenv("FMGPU_HEAVY_FIRST");
+        const bool hf_on = opt_on(FMGPU_OPT_HEAVY_FIRST);
         const bool by_lut = fast && x->lut && lutL >= 8 && lutL <= 16 && (buckets[0].lut_ok & 1u);     // (no step table — m < P, a scheme too large for it: the general kernel below)
         const bool by_blocks = !have_lf && x->bwt.sigma == 5 && maxlen >= 16;     // (the plain-index instantiation)
-        if (fast && (by_lut || by_blocks) && nq >= (1u << 16) && nq < 0x7fffffffull && !(hf && atoi(hf) == 0)) {
+        if (fast && (by_lut || by_blocks) && nq >= (1u << 16) && nq < 0x7fffffffull && hf_on) {
             // hand the reads of high-copy repeats out first (k_heavy_flags; decided on a sample of the batch — a text without repeats has nothing to
             // reorder, and the pass would cost 5 % of a 7 ms batch)
             LutPositions lp{};
@@ -4016,8 +4143,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         // ... and the reads of high-copy repeats are handed out first here too (16 LF steps per read on whatever layout the index has)
         uint32_t* gen_order = nullptr;
         {
-            const char* hf = getenv("FMGPU_HEAVY_FIRST");
-            if (nq >= (1u << 16) && nq < 0x7fffffffull && minlen >= 1 && !(hf && atoi(hf) == 0)) {
+            if (nq >= (1u << 16) && nq < 0x7fffffffull && minlen >= 1 && opt_on(FMGPU_OPT_HEAVY_FIRST)) {
                 int orc = 0;
                 const auto pre_t0 = std::chrono::steady_clock::now();
                 rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
@@ -4170,7 +4296,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     // path keys (<= 3 errors, depth and child index within their bit fields) order the hits of a read; with them and no limit on the hits per read the
     // lanes that find the query queue empty take subtrees from the busy lanes of their wave
     const int use_key = S <= 16 && max_u <= 3 && M + max_u <= 250 && x->bwt.sigma <= 32 ? 1 : 0;
-    const int sharing = use_key && max_hits_per_query == ~0ull && !(dev_flags_env() & (1 << 24)) ? 1 : 0;
+    const int sharing = use_key && max_hits_per_query == ~0ull && !(kernel_flags() & (1 << 24)) ? 1 : 0;
     DfsWorkspace ws;
     if ((rc = ws.init((uint32_t)M + max_u + 2, nq, bpc, stream, kEditFramePlanes))) return rc;       // deletions lengthen the path beyond the query by at most the largest upper bound
     DBuf tab_buf;
@@ -4181,7 +4307,7 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     const idx_t n = (idx_t)x->bwt.n;
     const auto pre_t0 = std::chrono::steady_clock::now();
     uint32_t* order = nullptr;                                     // heavy reads first, as in search_ng26
-    if (le == hipSuccess && nq >= (1u << 16) && nq < 0x7fffffffull && !(getenv("FMGPU_HEAVY_FIRST") && atoi(getenv("FMGPU_HEAVY_FIRST")) == 0)) {
+    if (le == hipSuccess && nq >= (1u << 16) && nq < 0x7fffffffull && opt_on(FMGPU_OPT_HEAVY_FIRST)) {
         int orc = 0;
         rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
             orc = heavy_first_order(nq, stream, [&](uint64_t count_reads, uint8_t* flags, uint32_t* cnt) {
@@ -4255,6 +4381,13 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
     else
 #endif
     if (x->bwt.va.fused && x->bwt.search_family() == FAM_A) {      // one line per step: presence bit, symbol and LF from the row's block (also ahead of the explicit LF table: that is two lines per step)
+        const bool coop = (uint64_t)x->bwt.n < (1ull << 38) && !(kernel_flags() & (1 << 23));   // (bit 23: one row per lane, k_locate_fused)
+        const dim3 cgrid((unsigned)((count + 4u * kLocChunk - 1u) / (4u * kLocChunk)));
+        const size_t coop_lds = (size_t)4 * kLocWaveWords * 4 + (dev_env("FMGPU_DEV_LOCATE_LDS") ? locate_lds : 0);
+        if (coop && count / (4u * kLocChunk) < kMaxGridBlocks) {
+            if (x->bwt.sigma == 5) k_locate_coop<5><<<cgrid, block, coop_lds, stream>>>(OccA<5>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
+            else k_locate_coop<0><<<cgrid, block, coop_lds, stream>>>(OccA<0>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
+        } else
         if (x->bwt.sigma == 5) k_locate_fused<5><<<grid, block, locate_lds, stream>>>(OccA<5>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
         else k_locate_fused<0><<<grid, block, locate_lds, stream>>>(OccA<0>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
     } else

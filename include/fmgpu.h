@@ -32,7 +32,8 @@
  *     or EPR / EPRV2 bwt with 6 <= sigma <= 29: a symbol-plane table (2 bytes per row; exact search takes one memory line per step and interval end instead of
  *     one per tree level); a sigma = 5 string handed over as InterleavedEPR* / InterleavedEPRV2* blocks or as a Wavelet: the one-symbol block table every
  *     other DNA layout is held in (1 byte per row), and with it the two tables above — every layout searches at the same speed.
- *     Results do not depend on them (FMGPU_PAIRS=0 / FMGPU_DENSE_DNA=0 / FMGPU_FLAT=0 / FMGPU_SHADOW=0 in the environment keep them out).
+ *     Results do not depend on them (fmgpu_set_option: FMGPU_OPT_PAIR_TABLE / _DENSE_DNA / _SYMBOL_PLANES / _EXPAND_DNA = 0 keep them out).
+ *   - the library reads no environment variable: what used to be FMGPU_* switches are options set through fmgpu_set_option.
  */
 #ifndef FMGPU_H
 #define FMGPU_H
@@ -44,7 +45,7 @@
 extern "C" {
 #endif
 
-#define FMGPU_ABI_VERSION 5
+#define FMGPU_ABI_VERSION 6
 
 typedef enum fmgpu_status {
     FMGPU_OK = 0,
@@ -163,6 +164,40 @@ typedef struct fmgpu_stats {
     uint64_t table_accesses;
 } fmgpu_stats;
 
+/* Library options: process-wide, read when a handle is created / a call starts (set them before, not during, the calls they concern).
+ * The first seven choose what a handle holds or how a batch is prepared — results never depend on them; the last three are test hooks. */
+typedef enum fmgpu_option {
+    FMGPU_OPT_PAIR_TABLE = 0,      /* 1 (default): a sigma = 5 bwt gets the symbol-pair table (exact search takes two symbols per step) */
+    FMGPU_OPT_DENSE_DNA = 1,       /* 1: both strings of a sigma = 5 BiFMIndex with 32-bit rows get dense DNA blocks (equal-length k-mismatch kernel) */
+    FMGPU_OPT_SYMBOL_PLANES = 2,   /* 1: a Wavelet / EPR / EPRV2 bwt with 6 <= sigma <= 29 gets the symbol-plane table (one line per LF step and end) */
+    FMGPU_OPT_EXPAND_DNA = 3,      /* 1: sigma = 5 strings handed over as EPR / EPRV2 blocks or as a Wavelet are expanded into the one-symbol block table at creation */
+    FMGPU_OPT_LF_TABLE = 4,        /* 1: the explicit LF mapping is built at creation (fmgpu_index_accelerate_lf adds / drops it later) */
+    FMGPU_OPT_FUSED_LOCATE = 5,    /* 1: the sampled suffix array's presence bits are fused into the sigma <= 5 blocks (one line per locate step) */
+    FMGPU_OPT_HEAVY_FIRST = 6,     /* 1: k-mismatch batches are handed out with the reads of high-copy repeats first */
+    FMGPU_OPT_FORCE_WIDE = 7,      /* test hook, 0: 1 = every new handle is held in 64-bit-row tables whatever its size */
+    FMGPU_OPT_KERNEL_SELECT = 8,   /* test / A-B hook, 0: FMGPU_SEL_* bits — which of several result-identical kernels serves a call */
+    FMGPU_OPT_FAIL_SCRATCH = 9,    /* test hook, 0: k = the k-th allocation of the next per-thread call scratch fails */
+    FMGPU_OPT_COUNT_ = 10
+} fmgpu_option;
+/* bits of FMGPU_OPT_KERNEL_SELECT: each takes a call off the kernel the library would pick (the parity tests run every kernel through them) */
+#define FMGPU_SEL_GENERAL_DFS      (1 << 1)   /* search_ng26 / ng21: the general kernels (k_scheme, k_scheme_edit, k_ng21) */
+#define FMGPU_SEL_NO_PREFIX_TABLE  (1 << 2)
+#define FMGPU_SEL_NO_LF3           (1 << 3)   /* no LF^1..3 walk table */
+#define FMGPU_SEL_NO_LF_GENERAL    (1 << 4)   /* no LF table in the general kernels */
+#define FMGPU_SEL_NO_WALK_TABLE    (1 << 5)
+#define FMGPU_SEL_NO_LENGTH_BUCKETS (1 << 6)
+#define FMGPU_SEL_EXACT_ON_TREE    (1 << 21)  /* exact search on the wavelet levels although the symbol-plane table exists (k_exact_m) */
+#define FMGPU_SEL_EXACT_ONE_SYMBOL (1 << 22)  /* exact search in one-symbol steps although the pair table exists (k_exact_a) */
+#define FMGPU_SEL_LOCATE_PER_LANE  (1 << 23)  /* locate with one row per lane (k_locate_fused) instead of the quad-cooperative kernel */
+#define FMGPU_SEL_NO_SHARING       (1 << 24)  /* no work sharing between the lanes of a wave */
+#define FMGPU_SEL_NO_EXACT_LUT     (1 << 25)  /* exact search does not start from the interval table in front of the pair table */
+#define FMGPU_SEL_LEAN_FORMAT_A    (1 << 29)  /* k_scheme_lean on the one-symbol blocks although dense DNA blocks exist */
+#define FMGPU_SEL_NO_LEAN          (1 << 30)  /* k_scheme_fast<PLAIN> instead of k_scheme_lean */
+#define FMGPU_SEL_ALL (FMGPU_SEL_GENERAL_DFS | FMGPU_SEL_NO_PREFIX_TABLE | FMGPU_SEL_NO_LF3 | FMGPU_SEL_NO_LF_GENERAL | FMGPU_SEL_NO_WALK_TABLE | FMGPU_SEL_NO_LENGTH_BUCKETS | \
+                       FMGPU_SEL_EXACT_ON_TREE | FMGPU_SEL_EXACT_ONE_SYMBOL | FMGPU_SEL_LOCATE_PER_LANE | FMGPU_SEL_NO_SHARING | FMGPU_SEL_NO_EXACT_LUT | FMGPU_SEL_LEAN_FORMAT_A | FMGPU_SEL_NO_LEAN)
+int         fmgpu_set_option(int32_t option, int64_t value);
+int         fmgpu_get_option(int32_t option, int64_t* value);
+
 int         fmgpu_abi_version(void);
 const char* fmgpu_last_error(void);
 int         fmgpu_device_count(int* count);
@@ -175,6 +210,22 @@ int fmgpu_index_create(const fmgpu_index_desc* desc, fmgpu_index_t* out);
 int fmgpu_index_destroy(fmgpu_index_t h);
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes);
 int fmgpu_index_row_bits(fmgpu_index_t h, int32_t* bits);   /* 32 or 64: the width of the device tables this index is held in */
+/* what the handle's bwt is held in at this moment (FMGPU_FMT_* bits): tells which kernel serves a search — e.g. exact search takes the pair table when
+ * FMGPU_FMT_PAIRS is set, the symbol planes when FMGPU_FMT_PLANES is set and the handle has no one-symbol blocks, the interval / k-step / walk tables when any exists */
+#define FMGPU_FMT_BLOCKS     (1u << 0)   /* one-symbol block table (the InterleavedBitvector* layouts, or the expansion of another layout) */
+#define FMGPU_FMT_PAIRS      (1u << 1)   /* symbol-pair table */
+#define FMGPU_FMT_DENSE      (1u << 2)   /* dense DNA blocks */
+#define FMGPU_FMT_PLANES     (1u << 3)   /* symbol-plane table */
+#define FMGPU_FMT_TREE       (1u << 4)   /* multi-ary wavelet tree (a Wavelet string) */
+#define FMGPU_FMT_REFERENCE  (1u << 5)   /* EPR / EPRV2 blocks read in place */
+#define FMGPU_FMT_LF         (1u << 6)   /* explicit LF mapping */
+#define FMGPU_FMT_KSTEP      (1u << 7)   /* multi-symbol-step table */
+#define FMGPU_FMT_INTERVALS  (1u << 8)   /* interval table of fmgpu_index_accelerate_exact */
+#define FMGPU_FMT_WALK       (1u << 9)   /* walk tables */
+#define FMGPU_FMT_PREFIX     (1u << 10)  /* prefix table of fmgpu_index_accelerate_search */
+#define FMGPU_FMT_LOCATE     (1u << 11)  /* locate answer table */
+#define FMGPU_FMT_FUSED      (1u << 12)  /* presence bits of the sampled suffix array fused into the blocks */
+int fmgpu_index_formats(fmgpu_index_t h, uint32_t* mask);
 
 /* The library's own index file — replaces saveIndex / loadIndex (fmindex/diskStorage.h:12-27) for a handle of this library: a header, a description of
  * the handle and every device array as it sits in HBM, each with a checksum; include_tables != 0 also stores whatever optional tables the handle
@@ -186,8 +237,7 @@ int fmgpu_index_save(fmgpu_index_t h, const char* path, int32_t include_tables);
 int fmgpu_index_load(const char* path, fmgpu_index_t* out);
 
 /* The explicit LF mapping (one word per row and direction: LF(row) = C[s] + rank(row, s) of the row's own symbol s): one-load one-row
- * search nodes and locate steps, and what the walk tables are built from.  Built at creation unless FMGPU_LF_TABLE=0 is set in the
- * environment; enable = 0 drops it (the walk tables must have been dropped before), enable != 0 builds it.  Without it the index is the
+ * search nodes and locate steps, and what the walk tables are built from.  Built at creation unless FMGPU_OPT_LF_TABLE is 0; enable = 0 drops it (the walk tables must have been dropped before), enable != 0 builds it.  Without it the index is the
  * bit-packed occurrence table alone (GRCh38: 3.1 GB per direction).  Results are unchanged. */
 int fmgpu_index_accelerate_lf(fmgpu_index_t h, int32_t enable);
 

@@ -17,3 +17,15 @@ def _built_oracle():
     import fmoracle
     fmoracle.build(ref=True)
     yield
+
+
+@pytest.fixture(autouse=True)
+def _library_options_back_to_defaults():
+    """a test that sets a library option (fm.options[...]) and fails before it puts it back does not leak it into the next test"""
+    yield
+    try:
+        from fmindex_collection_amd import capi
+        for name, value in capi.OPTION_DEFAULTS.items():
+            capi.set_option(name, value)
+    except Exception:
+        pass

@@ -119,9 +119,9 @@ def test_exact_search_in_pair_steps(shape, monkeypatch):
         seqs = [np.array([1], dtype=np.uint8), np.array([2, 1], dtype=np.uint8)]
     ox = fo.OraIndex.build("IB16", 5, seqs, 4, False)
     gx = gpu_index(ox)
-    monkeypatch.setenv("FMGPU_PAIRS", "0")
+    fm.options["pair_table"] = "0"
     gx_single = gpu_index(ox)
-    monkeypatch.delenv("FMGPU_PAIRS")
+    del fm.options["pair_table"]
     has_table = gx.device_bytes > gx_single.device_bytes
     assert has_table == (shape != "too_many_sequences")
     long_enough = [q for q in seqs if len(q) > 2]
@@ -133,12 +133,12 @@ def test_exact_search_in_pair_steps(shape, monkeypatch):
     qbuf, qoff = fm.flatten(queries)
     olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
     for flags in ("0", str(1 << 22)):
-        monkeypatch.setenv("FMGPU_DEV_FLAGS", flags)
+        fm.options["kernel_select"] = flags
         for g in (gx, gx_single):
             lb, ln, st = fm.search_no_errors.search(g, (qbuf, qoff), want_stats=True)
             assert np.array_equal(ln, oln) and np.array_equal(lb, olb), (shape, flags)
             assert st.lf_steps == int(ost.sum())
-    monkeypatch.delenv("FMGPU_DEV_FLAGS")
+    del fm.options["kernel_select"]
     # the packed form (one word per read) goes through the same kernel
     packed = fm.search_no_errors.search_packed(gx, (qbuf, qoff))
     assert np.array_equal(packed, (olb << np.uint64(32)) | oln)
@@ -161,21 +161,21 @@ def test_exact_search_on_symbol_planes(sigma, built_on_gpu, monkeypatch):
     ox = fo.OraIndex.build("WAVELET", sigma, seqs, 8, False)
     make = (lambda: fm.FMIndex.from_sequences(seqs, sigma, "WAVELET", 8)) if built_on_gpu else (lambda: gpu_index(ox))
     gx = make()
-    monkeypatch.setenv("FMGPU_FLAT", "0")
+    fm.options["symbol_planes"] = "0"
     gx_tree = make()
-    monkeypatch.delenv("FMGPU_FLAT")
+    del fm.options["symbol_planes"]
     assert (gx.device_bytes > gx_tree.device_bytes) == (sigma <= 29)
     queries = mutated_queries([q for q in seqs if len(q) > 2], 1500, 1, 90, 1, seed=3, sigma=sigma)
     queries += [[], [1], [sigma - 1], [0], [1, 0], [0, 1], [sigma - 1] * 64, [sigma - 1] * 201, seqs[2], seqs[2][1:], np.concatenate([seqs[2][-5:], [0]])]
     qbuf, qoff = fm.flatten(queries)
     olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
     for flags in ("0", str(1 << 21)):
-        monkeypatch.setenv("FMGPU_DEV_FLAGS", flags)
+        fm.options["kernel_select"] = flags
         for g in (gx, gx_tree):
             lb, ln, st = fm.search_no_errors.search(g, (qbuf, qoff), want_stats=True)
             assert np.array_equal(ln, oln) and np.array_equal(lb, olb), (sigma, flags)
             assert st.lf_steps == int(ost.sum())
-    monkeypatch.delenv("FMGPU_DEV_FLAGS")
+    del fm.options["kernel_select"]
     odd = fm.flatten([[1, 2, sigma, 1], [sigma + 3, 1], [1, 255]])       # bytes outside the alphabet: an empty interval, at the same step in both kernels
     a = fm.search_no_errors.search(gx, odd, want_stats=True)
     b = fm.search_no_errors.search(gx_tree, odd, want_stats=True)
@@ -186,29 +186,29 @@ def test_exact_search_on_symbol_planes(sigma, built_on_gpu, monkeypatch):
 @pytest.mark.parametrize("sigma", [6, 21, 28])
 def test_symbol_planes_beside_epr_blocks(layout, sigma):
     """Format S is also derived beside InterleavedEPR* / InterleavedEPRV2* blocks that are read in place (6 <= sigma <= 29): exact search then takes
-    k_exact_s; intervals, miss rows and step counts equal the oracle's and the layout's own kernel's (bit 21 of FMGPU_DEV_FLAGS)"""
+    k_exact_s; intervals, miss rows and step counts equal the oracle's and the layout's own kernel's (FMGPU_SEL_EXACT_ON_TREE)"""
     rng = np.random.default_rng(sigma * 7 + len(layout))
     base = rng.integers(1, sigma, size=4000, dtype=np.uint8)
     seqs = [np.concatenate([base, base[500:1500]]), rng.integers(1, min(sigma, 4), size=700, dtype=np.uint8), np.full(150, sigma - 1, dtype=np.uint8)]
     ox = fo.OraIndex.build(layout, sigma, seqs, 8, False)
     gx = gpu_index(ox)
-    os.environ["FMGPU_FLAT"] = "0"
+    fm.options["symbol_planes"] = "0"
     try:
         gx_own = gpu_index(ox)
     finally:
-        del os.environ["FMGPU_FLAT"]
+        del fm.options["symbol_planes"]
     assert gx.device_bytes > gx_own.device_bytes
     queries = mutated_queries([q for q in seqs if len(q) > 2], 1200, 1, 80, 1, seed=4, sigma=sigma) + [[], [1], [0], [sigma - 1] * 70, [1, 0, 1]]
     qbuf, qoff = fm.flatten(queries)
     olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
     for flags in ("0", str(1 << 21)):
-        os.environ["FMGPU_DEV_FLAGS"] = flags
+        fm.options["kernel_select"] = flags
         try:
             for g in (gx, gx_own):
                 lb, ln, st = fm.search_no_errors.search(g, (qbuf, qoff), want_stats=True)
                 assert np.array_equal(ln, oln) and np.array_equal(lb, olb) and st.lf_steps == int(ost.sum()), (layout, sigma, flags)
         finally:
-            del os.environ["FMGPU_DEV_FLAGS"]
+            del fm.options["kernel_select"]
 
 
 def test_exact_search_edge_cases():
@@ -493,11 +493,11 @@ def test_scheme_search_equal_length_fast_path(k, length):
             assert same_hits(hits, ohits) and st.lf_steps == nodes, (accel, k, length)
         hits = fm.search_ng26.search(gx, (qbuf, qoff), fm.search_scheme.h2(k + 2, 0, k), n=2)
         assert same_hits(hits, ox.search_ng26(qbuf, qoff, fm.search_scheme.h2(k + 2, 0, k), max_hits=2)[0])
-    os.environ["FMGPU_DEV_FLAGS"] = "2"                       # force the generic kernel: both kernels agree
+    fm.options["kernel_select"] = "2"                       # force the generic kernel: both kernels agree
     try:
         hits2 = fm.search_ng26.search(gx, (qbuf, qoff), fm.search_scheme.h2(k + 2, 0, k))
     finally:
-        del os.environ["FMGPU_DEV_FLAGS"]
+        del fm.options["kernel_select"]
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, fm.search_scheme.h2(k + 2, 0, k))[0])
 
 
@@ -524,11 +524,11 @@ def test_heavy_reads_first_hand_out_order(mix):
     qbuf, qoff = reads.reshape(-1), np.arange(nq + 1, dtype=np.uint64) * L
     sch = fm.search_scheme.h2(3, 0, 1)
     want, _, wnodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 23)
-    os.environ["FMGPU_LF_TABLE"] = "0"
+    fm.options["lf_table"] = "0"
     try:
         gx = gpu_index(ox)                                    # plain index: the sample and the flags come from 16 LF steps on the blocks
     finally:
-        del os.environ["FMGPU_LF_TABLE"]
+        del fm.options["lf_table"]
     hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 23)
     assert same_hits(hits, want) and st.lf_steps == wnodes
     gx.accelerate_lf(True); gx.accelerate_search(8, 1)        # ... from the 8-symbol prefix table
@@ -537,18 +537,18 @@ def test_heavy_reads_first_hand_out_order(mix):
     ewant, _, enodes = ox.search_ng26(qbuf[: 66_000 * L], qoff[: 66_001], sch, edit=True, cap=1 << 23)
     ehits, est = fm.search_ng26.search(gx, (qbuf[: 66_000 * L], qoff[: 66_001]), sch, want_stats=True, edit=True, capacity=1 << 23)
     assert same_hits(ehits, ewant) and est.lf_steps == enodes
-    os.environ["FMGPU_HEAVY_FIRST"] = "0"
+    fm.options["heavy_first"] = "0"
     try:
         hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 23)
     finally:
-        del os.environ["FMGPU_HEAVY_FIRST"]
+        del fm.options["heavy_first"]
     assert same_hits(hits, want) and st.lf_steps == wnodes
-    os.environ["FMGPU_DEV_FLAGS"] = "2"                       # the general kernels order their hand-out too (16 LF steps per read on any layout)
+    fm.options["kernel_select"] = "2"                       # the general kernels order their hand-out too (16 LF steps per read on any layout)
     try:
         hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 23)
         ehits, est = fm.search_ng26.search(gx, (qbuf[: 66_000 * L], qoff[: 66_001]), sch, want_stats=True, edit=True, capacity=1 << 23)
     finally:
-        del os.environ["FMGPU_DEV_FLAGS"]
+        del fm.options["kernel_select"]
     assert same_hits(hits, want) and st.lf_steps == wnodes
     assert same_hits(ehits, ewant) and est.lf_steps == enodes
     ex = fm.search_scheme.expand(sch, L)                     # search_ng21 too
@@ -560,11 +560,11 @@ def test_heavy_reads_first_hand_out_order(mix):
         rq = np.concatenate([reads[i, : rl[i]] for i in range(nq)])
         ro = np.concatenate([[0], np.cumsum(rl)]).astype(np.uint64)
         rwant, _, rnodes = ox.search_ng26(rq, ro, sch, cap=1 << 23)
-        os.environ["FMGPU_FORCE_WIDE"] = "1"
+        fm.options["force_wide"] = "1"
         try:
             wx = gpu_index(ox)
         finally:
-            del os.environ["FMGPU_FORCE_WIDE"]
+            del fm.options["force_wide"]
         assert wx.row_bits == 64
         rhits, rst = fm.search_ng26.search(wx, (rq, ro), sch, want_stats=True, capacity=1 << 23)
         assert same_hits(rhits, rwant) and rst.lf_steps == rnodes
@@ -573,16 +573,16 @@ def test_heavy_reads_first_hand_out_order(mix):
 @pytest.mark.parametrize("k,length", [(1, 20), (2, 31), (2, 101), (2, 151), (2, 255), (3, 64), (0, 40)])
 def test_lean_kernel_on_the_plain_index(k, length):
     """equal-length batches on a BiFMIndex<5> WITHOUT any table take k_scheme_lean (top frame of the stack cached in LDS and refilled by LDS-DMA, hit ring
-    per wave, 2-bit staged reads): records in callback order and node counts equal the CPU walk and k_scheme_fast<PLAIN> (FMGPU_DEV_FLAGS bit 30) —
+    per wave, 2-bit staged reads): records in callback order and node counts equal the CPU walk and k_scheme_fast<PLAIN> (FMGPU_SEL_NO_LEAN) —
     on a repeat-rich text (deep stacks, thousands of hits per read: ring flushes, work sharing), with reads that hold delimiters and bytes outside
     the alphabet (read from global memory), and with more hits than the caller's buffer holds"""
     seqs = repeat_text(70 + k, n=9000) + [np.tile(np.array([1, 1, 1, 2], dtype=np.uint8), 300), np.full(700, 3, dtype=np.uint8)]
     ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
-    os.environ["FMGPU_LF_TABLE"] = "0"
+    fm.options["lf_table"] = "0"
     try:
         gx = gpu_index(ox)
     finally:
-        del os.environ["FMGPU_LF_TABLE"]
+        del fm.options["lf_table"]
     queries = mutated_queries([q for q in seqs if len(q) > length], 3000, length, length + 1, k + 1, seed=21 + k)
     rng = np.random.default_rng(k)
     for i in range(0, len(queries), 97):                      # delimiters inside reads, at the ends and inside: the lane reads such a read from global memory
@@ -596,11 +596,11 @@ def test_lean_kernel_on_the_plain_index(k, length):
         hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
         assert same_hits(hits, ohits) and st.lf_steps == nodes, (k, length)
         for flags in (1 << 30, 1 << 29):                           # k_scheme_fast<PLAIN>; k_scheme_lean on the Format A blocks (the default reads the dense Format D)
-            os.environ["FMGPU_DEV_FLAGS"] = str(flags)
+            fm.options["kernel_select"] = str(flags)
             try:
                 hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
             finally:
-                del os.environ["FMGPU_DEV_FLAGS"]
+                del fm.options["kernel_select"]
             assert same_hits(hits2, ohits) and st2.lf_steps == nodes, flags
         if len(ohits) > 10:                                       # a buffer that is too small: FMGPU_ERR_CAPACITY with the exact count (the wrapper then asks again with that capacity)
             assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, capacity=len(ohits) // 2), ohits)
@@ -613,11 +613,11 @@ def test_lean_kernel_on_the_plain_index(k, length):
     got = []
     for flags in (None, 1 << 30, 2):
         if flags is not None:
-            os.environ["FMGPU_DEV_FLAGS"] = str(flags)
+            fm.options["kernel_select"] = str(flags)
         try:
             got.append(fm.search_ng26.search(gx, (qb2, qo2), schemes[0], want_stats=True, capacity=1 << 22))
         finally:
-            os.environ.pop("FMGPU_DEV_FLAGS", None)
+            fm.options.pop("kernel_select")
     assert same_hits(got[0][0], got[1][0]) and same_hits(got[0][0], got[2][0]) and got[0][1].lf_steps == got[1][1].lf_steps == got[2][1].lf_steps
     # the poly-A / satellite reads alone: 64 lanes of a wave all deep in one repeat
     sat = [seqs[3][i: i + length] for i in range(0, 400)] + [seqs[4][:length]] * 200
@@ -678,11 +678,11 @@ def test_scheme_search_ragged_batch_in_length_buckets():
     ohits, _, nodes = ox.search_ng26(kb, ko, sch, cap=1 << 22)
     ohits = ohits.copy(); ohits["qidx"] = np.array(keep, dtype=np.uint64)[ohits["qidx"].astype(np.int64)]
     assert same_hits(hits, ohits) and st.lf_steps == nodes
-    os.environ["FMGPU_DEV_FLAGS"] = "64"                      # no length buckets: the general kernel
+    fm.options["kernel_select"] = "64"                      # no length buckets: the general kernel
     try:
         hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 22)
     finally:
-        del os.environ["FMGPU_DEV_FLAGS"]
+        del fm.options["kernel_select"]
     assert hits2.tobytes() == hits.tobytes() and st2.lf_steps == nodes
     assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=1, capacity=1 << 22), ox_n1(ox, kb, ko, sch, keep))
 
@@ -767,11 +767,11 @@ def test_occurrence_table_expansion(layout, sigma):
     base = rng.integers(1, sigma, size=1300, dtype=np.uint8)
     seqs = [np.concatenate([base, base[100:500]]), rng.integers(1, sigma, size=700, dtype=np.uint8)]
     ox = fo.OraIndex.build(layout, sigma, seqs, 4, True)
-    os.environ["FMGPU_SHADOW"] = "0"                          # (sigma = 5 strings get the expansion at creation unless told otherwise: below)
+    fm.options["expand_dna"] = "0"                          # (sigma = 5 strings get the expansion at creation unless told otherwise: below)
     try:
         gx = gpu_index(ox)
     finally:
-        del os.environ["FMGPU_SHADOW"]
+        del fm.options["expand_dna"]
     before = gx.device_bytes
     gx.accelerate(1)
     assert gx.device_bytes > before
@@ -914,11 +914,11 @@ def test_edit_distance_equal_length_fast_path(k, length, sigma):
         sch = fm.search_scheme.h2(k + 2, 0, k)
         for n in (1, 4):
             assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=n, edit=True), ox.search_ng26(qbuf, qoff, sch, max_hits=n, edit=True)[0])
-    os.environ["FMGPU_DEV_FLAGS"] = "2"                       # the general kernel
+    fm.options["kernel_select"] = "2"                       # the general kernel
     try:
         hits2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, edit=True, capacity=1 << 21)
     finally:
-        del os.environ["FMGPU_DEV_FLAGS"]
+        del fm.options["kernel_select"]
     assert same_hits(hits2, ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 21)[0])
 
 
@@ -927,15 +927,15 @@ def test_edit_distance_equal_length_fast_path(k, length, sigma):
 def test_edit_distance_fast_kernel_on_the_plain_index(k, length):
     """edit distance (search_ng26<true>, the reference's default) on a BiFMIndex<5> WITHOUT any table: equal-length batches take k_scheme_fast_edit, whose
     one-row nodes read the row's symbol and LF off the row's block — cursors, errors, callback order and extension counts equal the CPU walk and
-    the general kernel (FMGPU_DEV_FLAGS bit 1); reads with delimiters inside; search_n clipping"""
+    the general kernel (FMGPU_SEL_GENERAL_DFS); reads with delimiters inside; search_n clipping"""
     rng = np.random.default_rng(300 + k + length)
     seqs = repeat_text(40 + k, n=6000) + [np.tile(np.array([1, 1, 2], dtype=np.uint8), 200)]
     ox = fo.OraIndex.build("IB16", 5, seqs, 4, True)
-    os.environ["FMGPU_LF_TABLE"] = "0"
+    fm.options["lf_table"] = "0"
     try:
         gx = gpu_index(ox)
     finally:
-        del os.environ["FMGPU_LF_TABLE"]
+        del fm.options["lf_table"]
     queries = []
     src = [q for q in seqs if len(q) > length + 8]
     for i in range(600 if k < 3 else 120):
@@ -954,11 +954,11 @@ def test_edit_distance_fast_kernel_on_the_plain_index(k, length):
         ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch, edit=True, cap=1 << 22)
         assert len(ohits) > 0
         for flags in ("0", "2"):
-            os.environ["FMGPU_DEV_FLAGS"] = flags
+            fm.options["kernel_select"] = flags
             try:
                 hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 22)
             finally:
-                del os.environ["FMGPU_DEV_FLAGS"]
+                del fm.options["kernel_select"]
             assert same_hits(hits, ohits) and st.lf_steps == nodes, (k, length, flags)
     sch = fm.search_scheme.h2(k + 2, 0, k)
     for n in (1, 4):
@@ -996,21 +996,21 @@ def test_edit_distance_on_a_repeat_structured_text():
     assert per_read.max() > 50 * max(1, int(np.median(per_read)))           # the heavy tail this test is about
     hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 24)
     assert same_hits(hits, ohits) and st.lf_steps == nodes
-    os.environ["FMGPU_DEV_FLAGS"] = str(1 << 24)               # no work sharing: the callback index is counted, not derived from keys
+    fm.options["kernel_select"] = str(1 << 24)               # no work sharing: the callback index is counted, not derived from keys
     try:
         hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 24)
     finally:
-        del os.environ["FMGPU_DEV_FLAGS"]
+        del fm.options["kernel_select"]
     assert same_hits(hits2, ohits) and st2.lf_steps == nodes
     assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=3, edit=True), ox.search_ng26(qbuf, qoff, sch, max_hits=3, edit=True)[0])
     # the general kernels (ragged batches, other layouts, 64-bit rows) share work at the end of the batch, with the same keys; search_ng21 too
     hh, _, hnodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 24)
-    os.environ["FMGPU_DEV_FLAGS"] = "2"
+    fm.options["kernel_select"] = "2"
     try:
         hits3, st3 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 24)
         hits4, st4 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
     finally:
-        del os.environ["FMGPU_DEV_FLAGS"]
+        del fm.options["kernel_select"]
     assert same_hits(hits3, ohits) and st3.lf_steps == nodes
     assert same_hits(hits4, hh) and st4.lf_steps == hnodes
     ex = fm.search_scheme.expand(sch, L)
@@ -1467,6 +1467,15 @@ def test_locate_random(layout, rate):
     want = np.array([ox.locate(int(r)) for r in rows], dtype=np.uint64)
     assert np.array_equal(np.stack([seq, pos, steps], axis=1), want)
     assert st.lf_steps == int(want[:, 2].sum())
+    if bool(gx.formats & capi.FMT_FUSED):
+        # the quad-cooperative kernel (rows of a wave handed out as lanes fall idle) against the one-row-per-lane kernel: the same triples and step count, also for a batch
+        # that ends inside a wave's chunk, repeated rows, and rows beyond the index mixed in
+        mixed = np.concatenate([rows[::-1], rows[:777], np.array([ox.n, 2**40, ox.n - 1], dtype=np.uint64), rows[: 3 * 512 + 5]])
+        got = gx.locate(mixed, want_stats=True)
+        with fm.options(kernel_select=capi.SEL_LOCATE_PER_LANE):
+            ref = gx.locate(mixed, want_stats=True)
+            one, _, _, st1 = gx.locate(rows, want_stats=True)
+        assert all(np.array_equal(a, b) for a, b in zip(got[:3], ref[:3])) and got[3].lf_steps == ref[3].lf_steps and st1.lf_steps == st.lf_steps and np.array_equal(one, seq)
     # out-of-range rows are flagged, not walked
     seq, pos, steps = gx.locate(np.array([ox.n, ox.n + 5], dtype=np.uint64))
     assert np.all(steps == np.uint64(2**64 - 1))
@@ -1483,11 +1492,11 @@ def test_locate_random(layout, rate):
     lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
     olb, oln = ox.search_exact(qbuf, qoff)
     assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
-    os.environ["FMGPU_FUSED_LOCATE"] = "0"                    # the same index without the fusion: the two-line locate
+    fm.options["fused_locate"] = "0"                    # the same index without the fusion: the two-line locate
     try:
         gx0 = gpu_index(ox)
     finally:
-        del os.environ["FMGPU_FUSED_LOCATE"]
+        del fm.options["fused_locate"]
     assert all(np.array_equal(a, b) for a, b in zip(gx0.locate(rows), gx.locate(rows)))
 
 
@@ -1695,11 +1704,11 @@ def test_index_file_round_trip(layout, sigma, bidir, tmp_path):
             fm.FMIndex.load(bad)
         assert e.value.code == capi.FMGPU_ERR_INVALID, name
     if layout == "IB16" and sigma == 5 and bidir:                 # 64-bit rows: its own file, refused by nothing but read by the wide build
-        os.environ["FMGPU_FORCE_WIDE"] = "1"
+        fm.options["force_wide"] = "1"
         try:
             wx = gpu_index(ox)
         finally:
-            del os.environ["FMGPU_FORCE_WIDE"]
+            del fm.options["force_wide"]
         f3 = str(tmp_path / "wide.fmgpu")
         wx.save(f3)
         lw = fm.FMIndex.load(f3)
@@ -1894,11 +1903,11 @@ def test_full_size_k2_records_equal_the_cpu_walk():
             p = torch.randint(0, L, (sel.numel(),), generator=g, device=dev)
             reads[sel, p] = reads[sel, p] % 4 + 1
         batches[L] = (reads.reshape(-1).cpu().numpy(), (np.arange(nq + 1, dtype=np.uint64) * L))
-    os.environ["FMGPU_LF_TABLE"] = "0"
+    fm.options["lf_table"] = "0"
     try:
         gx = fm.BiFMIndex.from_sequences((_V(text), _V(seq_off)), 5, "IB16", 16, keep_host=True)
     finally:
-        del os.environ["FMGPU_LF_TABLE"]
+        del fm.options["lf_table"]
     del text
     ox = _oracle_from_built(gx, True)
     sch = fm.search_scheme.h2(4, 0, 2)
@@ -1940,13 +1949,13 @@ def test_full_size_k2_records_equal_the_cpu_walk():
     for accel in ((11, 1), (0, 2), (16, 3)):
         gx.accelerate_search(*accel)
         check(accel)
-    os.environ["FMGPU_DEV_FLAGS"] = "2"                        # the general kernel
+    fm.options["kernel_select"] = "2"                        # the general kernel
     try:
         check("general kernel")
     finally:
-        del os.environ["FMGPU_DEV_FLAGS"]
+        del fm.options["kernel_select"]
     # edit distance at full size (20 k reads, single-threaded CPU walk): the table-driven kernel with its path keys, work sharing and the
-    # heavy-reads-first hand-out order (the batch is below its 64 k threshold: FMGPU_DEV_FLAGS keeps the order on for a repeated batch)
+    # heavy-reads-first hand-out order (the batch is below its 64 k threshold: the kernel selection keeps the order on for a repeated batch)
     hq, ho = batches[101]
     eq, eo = hq[: 20_000 * 101], ho[: 20_001]
     oe, _, enodes = ox.search_ng26(eq, eo, sch, edit=True, cap=1 << 22)
@@ -2093,7 +2102,7 @@ def test_failed_table_requests_leave_the_handle_as_it_was():
 
 
 def test_call_scratch_allocation_failure_is_an_error_not_a_fault():
-    """FMGPU_FAIL_SCRATCH=k fails the k-th allocation of the per-thread call scratch: the call returns an error code, nothing half-initialised
+    """the option fail_scratch = k (FMGPU_OPT_FAIL_SCRATCH) fails the k-th allocation of the per-thread call scratch: the call returns an error code, nothing half-initialised
     stays behind, and the next call (on a fresh host thread, whose scratch is created anew) works"""
     import threading
     text = make_text(20_000, 5, seed=5)
@@ -2105,7 +2114,7 @@ def test_call_scratch_allocation_failure_is_an_error_not_a_fault():
 
     def worker(tag, env):
         if env:
-            os.environ["FMGPU_FAIL_SCRATCH"] = env
+            fm.options["fail_scratch"] = env
         try:
             capi.check(capi.lib().fmgpu_set_device(0))
             try:
@@ -2113,10 +2122,10 @@ def test_call_scratch_allocation_failure_is_an_error_not_a_fault():
             except fm.FmgpuError as ex:
                 out[tag] = ex
                 out[tag + "_retry"] = None
-                os.environ.pop("FMGPU_FAIL_SCRATCH", None)
+                fm.options.pop("fail_scratch")
                 out[tag + "_retry"] = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)[:2]    # same thread: the scratch is built now
         finally:
-            os.environ.pop("FMGPU_FAIL_SCRATCH", None)
+            fm.options.pop("fail_scratch")
     for k in ("1", "4", "6"):
         t = threading.Thread(target=worker, args=("fail" + k, k)); t.start(); t.join()
         assert isinstance(out["fail" + k], fm.FmgpuError) and out["fail" + k].code in (capi.FMGPU_ERR_NOMEM, capi.FMGPU_ERR_HIP)

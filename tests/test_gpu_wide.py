@@ -1,5 +1,5 @@
 """The 64-bit-row build of the kernels (indices of 2^32 rows or more; the reference switches to libsais64 at 2^31 rows, utils.h:243-247),
-exercised on small inputs: FMGPU_FORCE_WIDE=1 routes a new index to it whatever its size, so every kernel of that build is compared with
+exercised on small inputs: the option force_wide = 1 (FMGPU_OPT_FORCE_WIDE) routes a new index to it whatever its size, so every kernel of that build is compared with
 the oracle exactly like its 32-bit twin.  The test at real size (n > 2^32) is test_gpu_parity.py::test_rows_beyond_2_32."""
 import contextlib
 import os
@@ -18,15 +18,8 @@ pytestmark = pytest.mark.gpu
 
 @contextlib.contextmanager
 def force_wide():
-    old = os.environ.get("FMGPU_FORCE_WIDE")
-    os.environ["FMGPU_FORCE_WIDE"] = "1"
-    try:
+    with fm.options(force_wide=1):
         yield
-    finally:
-        if old is None:
-            os.environ.pop("FMGPU_FORCE_WIDE", None)
-        else:
-            os.environ["FMGPU_FORCE_WIDE"] = old
 
 
 def wide_index(ox):
@@ -136,11 +129,11 @@ def test_wide_lean_kernel(k, length):
         ohits, _, nodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 24)
         hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
         assert same_hits(hits, ohits) and st.lf_steps == nodes, (k, length)
-        os.environ["FMGPU_DEV_FLAGS"] = "2"                        # the general kernel
+        fm.options["kernel_select"] = "2"                        # the general kernel
         try:
             hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
         finally:
-            del os.environ["FMGPU_DEV_FLAGS"]
+            del fm.options["kernel_select"]
         assert same_hits(hits2, ohits) and st2.lf_steps == nodes
 
 
@@ -229,9 +222,9 @@ def test_wide_exact_search_in_pair_steps(shape, monkeypatch):
         seqs = [np.where(rng.random(int(rng.integers(2, 700))) < 0.85, 1, rng.integers(1, 5, size=1)[0]).astype(np.uint8) for _ in range(60)]
     ox = fo.OraIndex.build("IB16", 5, seqs, 4, False)
     gx = wide_index(ox)
-    monkeypatch.setenv("FMGPU_PAIRS", "0")
+    fm.options["pair_table"] = "0"
     gx_single = wide_index(ox)
-    monkeypatch.delenv("FMGPU_PAIRS")
+    del fm.options["pair_table"]
     assert gx.device_bytes > gx_single.device_bytes
     queries = mutated_queries([q for q in seqs if len(q) > 2], 1500, 1, 140, 2, seed=6)
     queries += [[], [1], [1, 1], [1, 1, 1], [4, 4, 4, 4], [0], [1, 0], [0, 1], [1, 0, 1, 1], [2, 1, 0], [1] * 64, [1] * 65, [1] * 129, [2, 1], [1, 2]]
@@ -240,7 +233,7 @@ def test_wide_exact_search_in_pair_steps(shape, monkeypatch):
     qbuf, qoff = fm.flatten(queries)
     olb, oln, ost = ox.search_exact(qbuf, qoff, want_steps=True)
     for flags in ("0", str(1 << 22)):
-        monkeypatch.setenv("FMGPU_DEV_FLAGS", flags)
+        fm.options["kernel_select"] = flags
         for g in (gx, gx_single):
             lb, ln, st = fm.search_no_errors.search(g, (qbuf, qoff), want_stats=True)
             assert np.array_equal(ln, oln) and np.array_equal(lb, olb), (shape, flags)

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for name in sorted(declared):
         assert hasattr(L, name), name
-    assert L.fmgpu_abi_version() == 5
+    assert L.fmgpu_abi_version() == 6
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -62,7 +62,7 @@ def test_index_file_errors_without_a_gpu(tmp_path):
     assert L.fmgpu_index_load(os.fsencode(tmp_path / "missing.idx"), C.byref(h)) == capi.FMGPU_ERR_INVALID and b"cannot open" in L.fmgpu_last_error()
     assert L.fmgpu_index_save(None, b"/tmp/x", 1) == capi.FMGPU_ERR_INVALID
     import struct
-    def header(magic=b"FMGPUIDX", version=1, abi=5, wide=0, probe=0x01020304):
+    def header(magic=b"FMGPUIDX", version=1, abi=L.fmgpu_abi_version(), wide=0, probe=0x01020304):
         return magic + struct.pack("<IIIIQQQQQ", version, abi, wide, probe, 0, 0, 0, 0, 0)
     cases = [(b"\x01\x00\x00\x00cereal-like bytes" * 8, capi.FMGPU_ERR_INVALID, b"not an index file"), (header()[:40], capi.FMGPU_ERR_INVALID, b"truncated"),
              (header(version=2), capi.FMGPU_ERR_UNSUPPORTED, b"format version"), (header(abi=4), capi.FMGPU_ERR_UNSUPPORTED, b"ABI version"),
@@ -217,7 +217,9 @@ def test_bench_line_is_compact():
                            "queries_per_gpu": 10_000_000, "read_len": 101, "index_device_bytes": 4_200_000_000, "tables": {"a": "y" * 200}},
                 "gbp_per_s": 53.5, "hits": 9_000_000,
                 "roofline": {"bound": "hbm", "achieved": 5600.123456, "peak": 8000.0, "unit": "GB/s", "frac": frac, "traffic": 1.349e11, "kernel": kernel, "kernel_ms": 18.9,
-                             "units_per_launch": 961847926.0, "bytes_per_unit": 112, "accounting": "z" * 400, "traffic_source": "w" * 300},
+                             "units_per_launch": 961847926.0, "bytes_per_unit": 112, "accounting": "z" * 400, "traffic_source": "w" * 300, "rule": "u" * 600,
+                             "frac_kernel_format": frac, "frac_sec8d": None, "frac_loaded": 0.4123456, "frac_traffic": 0.9, "sec8d": {"frac_uncapped": 1.2345678, "what": "v" * 300}},
+                "clocks": {"sclk_mhz_mean": 2100, "sclk_mhz_min": 2050, "sclk_mhz_max": 2400, "mclk_mhz": 2000, "socket_power_w_mean": 900, "power_cap_w": 1400.0, "samples": 40, "what": "q" * 100},
                 "exchange": {"collective": "gather", "bytes_per_rank_and_step": 80_000_000, "verified_on_rank0": True, "world_size_seen": 8, "record": "r" * 200}}
     ids = ["%s/%s/%s" % (t_, w, k) for t_ in ("genome", "uniform") for w in ("exact", "locate", "k2", "k2_151", "k2_edit") for k in ("plain", "tables")]
     ids += ["protein/exact/wavelet", "protein/exact/tables", "protein_wide/exact/wavelet", "protein_wide/exact/tables"]
@@ -235,8 +237,33 @@ def test_bench_line_is_compact():
         assert d["roofline"]["frac"] == pytest.approx(0.4712, rel=1e-3) and d["roofline"]["bytes_per_unit"] == 112 and d["roofline"]["kernel_ms"] == 18.9
         assert d["cpu_baseline"]["cores"] == 16 and d["cpu_baseline"]["gpu_results_match_on_sample"] is True
         assert set(d["summary"]) == set(ids) and d["with_tables"]["record"] == "genome/exact/tables"
+        # one rule, three figures: kernel format (= frac), SURVEY 8d (null where it exceeds the peak, the uncapped figure beside it), counted in the kernel; the clocks of the run
+        assert d["roofline"]["frac_kernel_format"] == d["roofline"]["frac"] and d["roofline"]["frac_sec8d"] is None and d["roofline"]["sec8d_uncapped"] == pytest.approx(1.235, rel=1e-3)
+        assert d["roofline"]["frac_loaded"] == pytest.approx(0.4123, rel=1e-3) and d["clocks"]["sclk_mhz_mean"] == 2100 and len(d["summary"]["genome/k2/plain"]) == 4
         assert ("secondary" in d) == multi
     # a run with absurdly many records still prints a parseable headline (the optional parts go first)
     many = records + [rec("x%d/exact/plain" % i, "k", 0.1) for i in range(400)]
     line = bench.compact_line(many, False, "bench_records.json")
     assert len(line) < bench.MAX_LINE and json.loads(line)["roofline"]["kernel"] == "k_scheme_fast_edit"
+
+
+def test_options_are_set_through_the_abi_not_the_environment(monkeypatch):
+    """fmgpu_set_option / fmgpu_get_option (include/fmgpu.h): defaults, round trip, unknown options and selection bits outside FMGPU_SEL_ALL are refused;
+    the shipped library reads no environment variable (an FMGPU_* variable in the environment changes nothing)"""
+    import fmindex_collection_amd as fm
+    L = capi.lib()
+    for name, value in capi.OPTION_DEFAULTS.items():
+        assert fm.options[name] == value, name
+    monkeypatch.setenv("FMGPU_PAIRS", "0")
+    monkeypatch.setenv("FMGPU_DEV_FLAGS", "2")
+    assert fm.options["pair_table"] == 1 and fm.options["kernel_select"] == 0
+    with fm.options(pair_table=0, kernel_select=capi.SEL_GENERAL_DFS | capi.SEL_NO_LEAN):
+        assert fm.options["pair_table"] == 0 and fm.options["kernel_select"] == capi.SEL_GENERAL_DFS | capi.SEL_NO_LEAN
+    assert fm.options["pair_table"] == 1 and fm.options["kernel_select"] == 0
+    v = C.c_int64()
+    assert L.fmgpu_set_option(99, 1) == capi.FMGPU_ERR_INVALID and L.fmgpu_get_option(-1, C.byref(v)) == capi.FMGPU_ERR_INVALID and L.fmgpu_get_option(0, None) == capi.FMGPU_ERR_INVALID
+    assert L.fmgpu_set_option(capi.OPTIONS["kernel_select"], 1) == capi.FMGPU_ERR_INVALID and b"FMGPU_SEL_ALL" in L.fmgpu_last_error()      # (bit 0 — count only — exists in development builds alone)
+    src = "".join(open(os.path.join(ROOT, "fmindex-collection_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "fmindex-collection_amd", "csrc")) if f.endswith((".hip", ".h")))
+    import re
+    outside_dev = re.sub(r"#ifdef FMGPU_DEV\b.*?#e(?:lse|ndif)", "", src, flags=re.S)
+    assert "getenv" not in outside_dev
