@@ -562,7 +562,7 @@ def run_dna_text(c, name, primary):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
     legs = ["exact", "k2", "k2_151"]
-    ids = ["%s/%s/%s" % (name, w, i) for w in legs + ["locate"] for i in ("plain", "tables")] + ["%s/k2_edit/tables" % name, "%s/k2_edit/plain" % name, "%s/exact/single" % name]
+    ids = ["%s/%s/%s" % (name, w, i) for w in legs + ["locate"] for i in ("plain", "tables")] + ["%s/k2_edit/tables" % name, "%s/k2_edit/plain" % name, "%s/exact/single" % name, "%s/exact/plain+lut12" % name]
     if c.only and not any(i in c.only for i in ids):
         return []
     text, seq_off, lengths, tinfo = make_text(c, name)
@@ -573,7 +573,7 @@ def run_dna_text(c, name, primary):
     base_cfg = {"text": tinfo, "sigma": 5, "layout": "InterleavedBitvector16", "scale": args.scale}
 
     # ------------------------------------------------------------------ exact search, configs[1]
-    if any(wanted(c, "%s/%s/%s" % (name, w_, i)) for w_ in ("exact", "locate") for i in ("plain", "tables")) or wanted(c, name + "/exact/single"):
+    if any(wanted(c, "%s/%s/%s" % (name, w_, i)) for w_ in ("exact", "locate") for i in ("plain", "tables")) or wanted(c, name + "/exact/single") or wanted(c, name + "/exact/plain+lut12"):
         L = 101
         qbuf, qoff = sample_reads(c, text, lengths, L, nq, 1000 + c.rank, "exact")
         torch.cuda.synchronize()
@@ -598,7 +598,7 @@ def run_dna_text(c, name, primary):
             else:
                 capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
                                                          C.c_void_p(outs[b][:nq].data_ptr()), C.c_void_p(outs[b][nq:].data_ptr()), C.byref(stats), None))
-            log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses})
+            log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses, "table_steps": stats.table_steps})
             if xch:
                 xch.send(packed[b].view(torch.uint8), b)
 
@@ -616,15 +616,18 @@ def run_dna_text(c, name, primary):
                    "config": {"workload": "grch38_exact", **base_cfg, "index": "FMIndex", "index_kind": index_kind, "queries_per_gpu": nq, "read_len": L,
                               "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2), **extra},
                    "gbp_per_s": qps * L / 1e9, "hits": int((out_len > 0).sum().item())}
-            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
+            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses", "table_steps")}
             coalesced = nq * (L + 8 + 16)
+            lut_len = extra.get("interval_table_symbols") or 1
+            fmt_pairs = (units - st["table_steps"]) * FMT_STEP_PAIRS + st["table_steps"] / lut_len * 8.0      # (an interval-table entry — 8 B — stands for lut_len steps)
             if kernel == "k_exact_a":
                 rec["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", units * FMT_STEP_BLOCKS,
                                                  "one symbol per step on the one-symbol blocks: 2 interval ends x the 12-byte entry {count, 64-bit bitmap} of the step's symbol = 24 B per LF step",
                                                  SEC8D_STEP_DNA, "2 x sizeof(InterleavedBitvector16<5>::Block) = 112 B per executed LF step (this record IS SURVEY 8d as written)",
                                                  st["table_bytes"] + coalesced, "12 B per entry the kernel loaded (an end in the other end's block: one load) + queries and results", st["table_accesses"])
             elif kernel in ("k_exact_p", "k_exact_lp"):
-                rec["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", units * FMT_STEP_PAIRS,
+                rec["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", fmt_pairs,
+                                                 ("the read's last %d symbols from one 8-byte interval-table entry, then " % lut_len if kernel == "k_exact_lp" else "") +
                                                  "two symbols per step on the pair lines (one 128-byte line per 128 rows: 16 pair counts + 4 bit planes): 2 interval ends x 68 B read of a "
                                                  "line (4-byte count + four 16-byte plane words) per two-symbol step = 68 B per executed LF step",
                                                  SEC8D_STEP_DNA, "2 x sizeof(InterleavedBitvector16<5>::Block) = 112 B per executed LF step: record " + rid.rsplit("/", 1)[0] + "/single (k_exact_a, same index, same reads, same run)",
@@ -721,6 +724,21 @@ def run_dna_text(c, name, primary):
             del keep
         if wanted(c, name + "/locate/plain") and not c.multi:
             out.append(locate_run(name + "/locate/plain", "plain", build_plain))
+        if pairs and not c.multi and wanted(c, name + "/exact/plain+lut12"):      # the same search behind a 12-symbol interval table (134 MB: 4^12 entries of 8 bytes), no other table
+            t0 = time.time()
+            index.accelerate(1, lut_len=12, walk=0)
+            keep = outs[0].clone() if plain_ms else None
+            elapsed, log = timed(c, step, None)
+            r2 = finish(name + "/exact/plain+lut12", "plain+lut12", "k_exact_lp", elapsed, log, build_plain + time.time() - t0,
+                        {"tables": {"suffix_interval_symbols": 12}, "interval_table_symbols": 12,
+                         "occurrence_tables": "one-symbol blocks (Format A) + symbol-pair lines (Format P) + the intervals of all 12-symbol strings (134 MB)"})
+            if keep is not None:
+                r2["equal_to_the_plain_index"] = bool(torch.equal(keep, outs[0]))
+                if not r2["equal_to_the_plain_index"]:
+                    raise SystemExit("bench.py: exact search with and without the interval table disagree")
+                r2["roofline"]["speedup_over_plain_index_kernel"] = plain_ms / r2["roofline"]["kernel_ms"]
+            out.append(r2)
+            del keep
         if ((not c.multi or args.multi_tables) and wanted(c, name + "/exact/tables")) or (wanted(c, name + "/locate/tables") and not c.multi):
             t0 = time.time()
             del fm.options["lf_table"]

@@ -210,6 +210,15 @@ class FMIndex:
             x.__class__ = BiFMIndex
         return x
 
+    def clone(self):
+        """a copy of the handle on the calling thread's current device, made device to device (fmgpu_index_clone): every array incl. the optional tables"""
+        h = C.c_void_p()
+        capi.check(capi.lib().fmgpu_index_clone(self._h, C.byref(h)))
+        x = FMIndex(h)
+        if x.bidirectional:
+            x.__class__ = BiFMIndex
+        return x
+
     def built_array(self, part, dtype=np.uint8):
         """host copy of a construction by-product (keep_host=True): 0 = BWT bytes, 1 = BWT of the reversed text, 2 = C"""
         if not self._built:
@@ -445,6 +454,9 @@ class Replicas:
         dev = (C.c_int32 * n.value)()
         capi.check(capi.lib().fmgpu_replicas_info(self._r, None, dev, n.value, None))
         self.devices = list(dev)
+        pc = C.c_int32()
+        capi.check(capi.lib().fmgpu_replicas_peer_copies(self._r, C.byref(pc)))
+        self.peer_copies = pc.value                 # replicas made by a device-to-device copy of the first one (the file was read once)
 
     @classmethod
     def load(cls, path, devices=None):

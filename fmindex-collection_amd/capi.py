@@ -84,7 +84,7 @@ class ExpandedScheme(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("lf_steps", C.c_uint64), ("hits", C.c_uint64), ("kernel_ms", C.c_float), ("prepass_ms", C.c_float),
-                ("table_bytes", C.c_uint64), ("table_accesses", C.c_uint64)]
+                ("table_bytes", C.c_uint64), ("table_accesses", C.c_uint64), ("table_steps", C.c_uint64)]
 
 
 # every symbol include/fmgpu.h declares (tests check that the library exports all of them)
@@ -99,7 +99,7 @@ EXPORTS = [
     "fmgpu_index_save", "fmgpu_index_load",
     "fmgpu_replicas_load", "fmgpu_replicas_destroy", "fmgpu_replicas_info", "fmgpu_replicas_search_exact", "fmgpu_replicas_search_scheme",
     "fmgpu_replicas_search_ng21", "fmgpu_replicas_locate",
-    "fmgpu_set_option", "fmgpu_get_option", "fmgpu_index_formats",
+    "fmgpu_set_option", "fmgpu_get_option", "fmgpu_index_formats", "fmgpu_index_clone", "fmgpu_replicas_peer_copies",
 ]
 
 # fmgpu_option (include/fmgpu.h) and the defaults the library starts with
@@ -190,9 +190,11 @@ def lib():
     L.fmgpu_cursor_extend.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.fmgpu_index_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.fmgpu_index_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.fmgpu_index_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     if hasattr(L, "fmgpu_replicas_load"):
         L.fmgpu_replicas_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
         L.fmgpu_replicas_destroy.argtypes = [C.c_void_p]
+        L.fmgpu_replicas_peer_copies.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.fmgpu_replicas_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
         L.fmgpu_replicas_search_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.fmgpu_replicas_search_scheme.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Scheme), C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.POINTER(Stats)]

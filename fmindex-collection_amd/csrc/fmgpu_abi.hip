@@ -231,6 +231,7 @@ int fmgpu_index_load(const char* path, fmgpu_index_t* out) {
     return rc;
 }
 int fmgpu_index_destroy(fmgpu_index_t h) { if (!h) return 0; ROUTE(h, fmgpu_index_destroy(h)); }
+int fmgpu_index_clone(fmgpu_index_t h, fmgpu_index_t* out) { ROUTE(h, fmgpu_index_clone(h, out)); }
 int fmgpu_index_info(fmgpu_index_t h, uint64_t* n, int32_t* sigma, int32_t* layout, int32_t* bidirectional, uint64_t* device_bytes) {
     ROUTE(h, fmgpu_index_info(h, n, sigma, layout, bidirectional, device_bytes));
 }

@@ -25,4 +25,5 @@ int fmgpu_cursor_extend(fmgpu_index_t h, int32_t direction, uint64_t count, cons
 int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nseq, int32_t sigma, int32_t layout, uint64_t sampling_rate, int32_t bidirectional,
                       int32_t keep_host, fmgpu_index_t* out, fmgpu_built_t* built);
 int fmgpu_index_save(fmgpu_index_t h, const char* path, int32_t include_tables);
+int fmgpu_index_clone(fmgpu_index_t h, fmgpu_index_t* out);
 int index_load(FILE* f, const void* file_header, fmgpu_index_t* out);      // (fmgpu_index_load has read and checked the 64-byte header: it names the row width)

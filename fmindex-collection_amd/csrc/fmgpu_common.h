@@ -194,7 +194,7 @@ bool want_wide(uint64_t n);
 // than the bookkeeping they serve — hipFree synchronises the device).  `ctr` serves calls that report stats (they synchronise before
 // returning, so it is idle between calls), `sink` the others (never read).
 constexpr uint32_t kCounterStripes = 64;      // step counters of the one-thread-per-query kernels are striped (a single word would serialise one atomic per wave)
-constexpr uint32_t kCounterKinds = 3;         // [0] steps, [1] table bytes, [2] table accesses — kCounterStripes words each
+constexpr uint32_t kCounterKinds = 4;         // [0] steps, [1] table bytes, [2] table accesses, [3] steps served by interval-table entries — kCounterStripes words each
 struct CallScratch {
     unsigned long long* ctr = nullptr; unsigned long long* sink = nullptr; unsigned long long* len2 = nullptr;
     unsigned long long* pinned = nullptr;                         // host side of the small read-backs (a pageable target costs a staging copy each)

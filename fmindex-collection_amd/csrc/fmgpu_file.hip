@@ -123,6 +123,21 @@ static void describe_string(const DevString& s, bool tables, SavedString& o, con
     }
 }
 
+static void describe_index(const Index* x, bool tables, SavedIndex& m, const void* sp[2][11]) {
+    std::memset(&m, 0, sizeof(SavedIndex));
+    m.n = x->bwt.n; m.sigma = x->bwt.sigma; m.bidirectional = x->bidirectional; m.has_sa = x->has_sa; m.wide = kWide ? 1 : 0;
+    std::memcpy(m.hC, x->hC, sizeof m.hC);
+    describe_string(x->bwt, tables, m.str[0], sp[0]);
+    describe_string(x->rev, tables, m.str[1], sp[1]);
+    m.dC_bytes = ((uint64_t)x->bwt.sigma + 1) * sizeof(idx_t);
+    if (x->has_sa) {
+        for (int k = 0; k < 5; ++k) m.sa_bytes[k] = x->sa_bytes[k];
+        m.vsa = x->vsa; m.vsa.l0 = nullptr; m.vsa.l1 = nullptr; m.vsa.bits = nullptr; m.vsa.f0 = nullptr; m.vsa.f1 = nullptr;
+    }
+    if (tables && x->loc_tab) m.loc_bytes = x->bwt.n * 12 + 16;
+    if (tables && x->lut) { m.lut_bytes = x->lut_entries * 16; m.lut_entries = x->lut_entries; m.lut_len = x->lut_len; }
+}
+
 namespace api {
 #include "fmgpu_api_decl.h"
 int fmgpu_index_save(fmgpu_index_t h, const char* path, int32_t include_tables) {
@@ -132,19 +147,8 @@ int fmgpu_index_save(fmgpu_index_t h, const char* path, int32_t include_tables) 
     FM_HIP(hipDeviceSynchronize());
     const bool tables = include_tables != 0;
     auto meta = std::make_unique<SavedIndex>();
-    std::memset(meta.get(), 0, sizeof(SavedIndex));
-    meta->n = x->bwt.n; meta->sigma = x->bwt.sigma; meta->bidirectional = x->bidirectional; meta->has_sa = x->has_sa; meta->wide = kWide ? 1 : 0;
-    std::memcpy(meta->hC, x->hC, sizeof meta->hC);
     const void* sp[2][11];
-    describe_string(x->bwt, tables, meta->str[0], sp[0]);
-    describe_string(x->rev, tables, meta->str[1], sp[1]);
-    meta->dC_bytes = ((uint64_t)x->bwt.sigma + 1) * sizeof(idx_t);
-    if (x->has_sa) {
-        for (int k = 0; k < 5; ++k) meta->sa_bytes[k] = x->sa_bytes[k];
-        meta->vsa = x->vsa; meta->vsa.l0 = nullptr; meta->vsa.l1 = nullptr; meta->vsa.bits = nullptr; meta->vsa.f0 = nullptr; meta->vsa.f1 = nullptr;
-    }
-    if (tables && x->loc_tab) meta->loc_bytes = x->bwt.n * 12 + 16;
-    if (tables && x->lut) { meta->lut_bytes = x->lut_entries * 16; meta->lut_entries = x->lut_entries; meta->lut_len = x->lut_len; }
+    describe_index(x, tables, *meta, sp);
 
     File f(fopen(path, "wb"));
     if (!f) return fail(FMGPU_ERR_INVALID, std::string("index file: cannot open for writing: ") + path);
@@ -171,56 +175,170 @@ int fmgpu_index_save(fmgpu_index_t h, const char* path, int32_t include_tables) 
     return 0;
 }
 
-// ---- load (called by the extern "C" entry point once the header says which row width the file holds)
+// ---- load (called by the extern "C" entry point once the header says which row width the file holds) and clone (another device of the same process)
 static int read_exact(FILE* f, void* p, size_t bytes, const char* what) {
     if (fread(p, 1, bytes, f) != bytes) return fail(FMGPU_ERR_INVALID, std::string("index file: truncated (") + what + ")");
     return 0;
 }
-static int read_section(FILE* f, uint32_t want_id, uint64_t want_bytes, void** dev, uint8_t* host, uint32_t* nsec) {
-    *dev = nullptr;
-    if (want_bytes == 0) return 0;
-    SectionHeader sh{};
-    int rc = read_exact(f, &sh, sizeof sh, "section header");
-    if (rc) return rc;
-    if (sh.id != want_id || sh.bytes != want_bytes)
-        return fail(FMGPU_ERR_INVALID, "index file: section " + std::to_string(want_id) + " expected with " + std::to_string(want_bytes) + " bytes, found section " +
-                                       std::to_string(sh.id) + " with " + std::to_string(sh.bytes));
-    DBuf d;
-    if ((rc = d.alloc(want_bytes))) return rc;
-    uint64_t sum = 0x243f6a8885a308d3ull ^ want_id;
-    for (uint64_t at = 0; at < want_bytes; at += kChunk) {
-        const size_t c = (size_t)std::min<uint64_t>(kChunk, want_bytes - at);
-        if ((rc = read_exact(f, host, c, "section payload"))) return rc;
-        sum = mix_words(sum, host, c);
-        FM_HIP(hipMemcpy((uint8_t*)d.p + at, host, c, hipMemcpyHostToDevice));
+
+// The description block is checked against n, sigma and the layouts BEFORE anything is allocated: its checksum is not keyed, so a stale file, a file of a build with the
+// same sizeof(SavedIndex) or a hand-edited one would otherwise yield a handle whose kernels read outside the uploaded arrays.  Every size must be what creation
+// would have allocated for (n, sigma, layout) — or at least that, where creation takes the caller's array as it is.
+static int bad_meta(const std::string& what) { return fail(FMGPU_ERR_INVALID, "index file: inconsistent description block (" + what + ")"); }
+static bool power_of(uint64_t base, uint32_t exp, uint64_t want, uint64_t cap) {
+    uint64_t v = 1;
+    for (uint32_t t = 0; t < exp; ++t) { v *= base; if (v > cap) return false; }
+    return v == want;
+}
+static int validate_string(const SavedString& o, const SavedIndex& m, int w) {
+    const std::string tag = w ? "bwtRev: " : "bwt: ";
+    const uint64_t n = m.n, nblocks = n / 64 + 1;
+    const uint32_t sigma = (uint32_t)m.sigma, R = sigma - 1;
+    if (o.sigma != m.sigma || o.n != n) return bad_meta(tag + "n / sigma differ from the index's");
+    if (o.layout < 0 || o.layout > FMGPU_FBV_2048_64K || o.family < FAM_A || o.family > FAM_WAVELET) return bad_meta(tag + "layout / family");
+    if (o.bytes[SEC_BLK] == 0) return bad_meta(tag + "no block array");
+    auto check_va = [&](uint64_t blk_bytes, uint64_t sup_bytes) -> int {
+        const uint32_t bstride = sigma <= 5 ? 64u : 12u * sigma;
+        if (o.va.bstride != bstride || o.va.sigma != sigma || o.va.fused > 1u || (o.va.fused && sigma > 5)) return bad_meta(tag + "block table view");
+        if (blk_bytes < nblocks * bstride) return bad_meta(tag + "block table shorter than n / 64 + 1 blocks");
+        if (kWide && sup_bytes < ((n >> kSuperShift) + 1) * sigma * 8) return bad_meta(tag + "super-block table too short");
+        return 0;
+    };
+    int rc;
+    if (o.family == FAM_A) { if ((rc = check_va(o.bytes[SEC_BLK], o.bytes[SEC_SUP]))) return rc; }
+    else if (o.has_shadow) { if ((rc = check_va(o.bytes[SEC_SHADOW], o.bytes[SEC_SHADOW_SUP]))) return rc; }
+    if (!o.has_shadow && (o.bytes[SEC_SHADOW] || o.bytes[SEC_SHADOW_SUP])) return bad_meta(tag + "expansion arrays without the expansion");
+    if (o.has_shadow && (o.family == FAM_A || !o.bytes[SEC_SHADOW])) return bad_meta(tag + "expansion flag");
+    if (o.family == FAM_EPR || o.family == FAM_EPRV2) {
+        const ViewR& v = o.vr;
+        const bool v2 = o.family == FAM_EPRV2;
+        if (v.sigma != sigma || v.bitct < 1 || v.bitct > 8 || (v.bt != 1 && v.bt != 2 && v.bt != 4) || v.rows < 1 || v.rows > 64 || v.stride < 8 || v.stride > 4096 ||
+            (uint64_t)sigma * v.bt > v.bits_off || (uint64_t)v.bits_off + 8ull * (v2 ? v.bitct : 1u) > v.stride || (!v2 && (v.period < 1 || v.rows != 64u / v.bitct)) ||
+            (v2 && (v.rows != 64 || v.period_shift != 8u * v.bt)))
+            return bad_meta(tag + "EPR block view");
+        if (o.bytes[SEC_BLK] < (n / v.rows + 1) * v.stride) return bad_meta(tag + "too few EPR blocks for n rows");
+        const uint64_t nsup = v2 ? ((v.period_shift >= 32 ? (n >> 32) : (n >> v.period_shift)) + 1) : n / v.period + 1;
+        if (o.bytes[SEC_AUX] < nsup * sigma * 8) return bad_meta(tag + "too few EPR super-blocks for n rows");
     }
-    uint64_t pad = (8 - want_bytes % 8) % 8, skip = 0;
-    if (pad && (rc = read_exact(f, &skip, pad, "padding"))) return rc;
-    if (sum != sh.sum) return fail(FMGPU_ERR_INVALID, "index file: checksum mismatch in section " + std::to_string(want_id));
-    *dev = d.take();
-    ++*nsec;
+    if (o.family == FAM_WAVELET) {
+        const ViewM& v = o.vm;
+        if (v.sigma != sigma || v.nlevels < 1 || v.nlevels > (uint32_t)kMaxLevelsM || v.nnodes < 1 || v.nnodes > (uint32_t)kMaxNodesM || v.bitct < 1 || v.bitct > 8) return bad_meta(tag + "wavelet tree view");
+        uint32_t nodes_seen = 0, bits_seen = 0;
+        for (uint32_t l = 0; l < v.nlevels; ++l) {
+            const LevelM& L = v.lv[l];
+            if (L.bits < 1 || L.bits > 3 || L.stride < (4u << L.bits) + 8u * L.bits || L.stride > 64 || L.first_node != nodes_seen || L.shift + L.bits + bits_seen != v.bitct) return bad_meta(tag + "wavelet level");
+            nodes_seen += 1u << bits_seen; bits_seen += L.bits;
+        }
+        if (nodes_seen != v.nnodes || bits_seen != v.bitct || o.bytes[SEC_AUX] < (uint64_t)v.nnodes * 8) return bad_meta(tag + "wavelet node table");
+        uint64_t least = 0;                                       // every level holds the n positions once, cut into blocks of 64 per node
+        for (uint32_t l = 0; l < v.nlevels; ++l) least += (n / 64) * v.lv[l].stride;
+        if (o.bytes[SEC_BLK] < least) return bad_meta(tag + "wavelet tree shorter than its levels");
+        if (kWide && (o.vm_super_off >= o.bytes[SEC_SUP] || o.vm_super_off < ((uint64_t)v.nnodes * 4 + 63) / 64 * 64 || (o.bytes[SEC_SUP] - o.vm_super_off) % 64)) return bad_meta(tag + "wavelet super-block table");
+    }
+    if (o.bytes[SEC_LF] && o.bytes[SEC_LF] != n * sizeof(idx_t) + 16) return bad_meta(tag + "LF table size");
+    if (o.bytes[SEC_WALK3] && (o.bytes[SEC_WALK3] != n * 12 + 16 || kWide)) return bad_meta(tag + "walk table size");
+    if (o.bytes[SEC_KBLK] && (kWide || o.kstep < 2 || !power_of(R, o.kstep, o.kcodes, 255) || o.bytes[SEC_KBLK] < nblocks * o.kcodes * 16)) return bad_meta(tag + "multi-symbol-step table");
+    if (!o.bytes[SEC_KBLK] && (o.kstep || o.kcodes)) return bad_meta(tag + "multi-symbol-step fields without the table");
+    if (o.bytes[SEC_SLUT] && (o.slut_len < 1 || o.slut_len > 32 || !power_of(R, o.slut_len, o.slut_entries, 1ull << 32) || o.bytes[SEC_SLUT] != o.slut_entries * kSlutEntryBytes)) return bad_meta(tag + "interval table");
+    if (!o.bytes[SEC_SLUT] && (o.slut_len || o.slut_entries)) return bad_meta(tag + "interval-table fields without the table");
+    if (o.bytes[SEC_WALKJ]) {
+        uint32_t bits = 1; while ((1u << bits) < R) ++bits;
+        if (o.bytes[SEC_WALKJ] != n * kWalkEntryBytes + 16 || o.walk_bits != bits || o.walk_J != 32u / bits) return bad_meta(tag + "LF^J walk table");
+    } else if (o.walk_J || o.walk_bits) return bad_meta(tag + "walk fields without the table");
+    if (o.bytes[SEC_WALK2J] && (o.bytes[SEC_WALK2J] != n * kWalk2EntryBytes + 16 || !o.bytes[SEC_WALKJ])) return bad_meta(tag + "LF^2J walk table");
+    return 0;
+}
+static int validate_meta(const SavedIndex& m) {
+    if ((m.wide != 0) != kWide || m.sigma < 2 || m.sigma > 256 || m.str[0].n != m.n || m.n >= kWideLimit || (!kWide && m.n >= kNarrowLimit)) return bad_meta("n / sigma / row width");
+    if ((m.bidirectional != 0 && m.bidirectional != 1) || (m.has_sa != 0 && m.has_sa != 1)) return bad_meta("flags");
+    const uint64_t n = m.n; const uint32_t sigma = (uint32_t)m.sigma;
+    for (uint32_t c = 0; c < sigma; ++c) if (m.hC[c] > m.hC[c + 1]) return bad_meta("C is not ascending");
+    if (m.hC[0] != 0 || m.hC[sigma] != n) return bad_meta("C does not end at n");
+    if (m.dC_bytes != ((uint64_t)sigma + 1) * sizeof(idx_t)) return bad_meta("size of C");
+    int rc;
+    if ((rc = validate_string(m.str[0], m, 0))) return rc;
+    if (m.bidirectional) { if ((rc = validate_string(m.str[1], m, 1))) return rc; }
+    else {
+        for (int k = 0; k < 11; ++k) if (m.str[1].bytes[k]) return bad_meta("arrays of a bwtRev the index does not have");
+        if (m.lut_bytes) return bad_meta("prefix table without a bwtRev");
+    }
+    if (m.has_sa) {
+        if (m.sa_bytes[0] < (n / 65536 + 1) * 8 || m.sa_bytes[1] < (n / 512 + 1) * 2 || m.sa_bytes[2] < (n / 512 + 1) * 64 || m.sa_bytes[3] < 8 || m.sa_bytes[4] < 8 || m.sa_bytes[3] % 8 || m.sa_bytes[4] % 8)
+            return bad_meta("sampled suffix array arrays too short");
+        if (m.vsa.bits0 < 1 || m.vsa.bits0 > 64 || m.vsa.bits1 < 1 || m.vsa.bits1 > 64 || m.vsa.div0 == 0 || m.vsa.div1 == 0) return bad_meta("sampled suffix array fields");
+    } else {
+        for (int k = 0; k < 5; ++k) if (m.sa_bytes[k]) return bad_meta("sampled suffix array arrays without the array");
+        if (m.loc_bytes) return bad_meta("locate table without a sampled suffix array");
+        if (m.str[0].va.fused) return bad_meta("fused presence bits without a sampled suffix array");
+    }
+    if (m.loc_bytes && (kWide || m.loc_bytes != n * 12 + 16)) return bad_meta("locate table size");
+    if (m.lut_bytes && (kWide || m.lut_len < 1 || m.lut_len > 16 || !power_of(sigma - 1, m.lut_len, m.lut_entries, 1ull << 32) || m.lut_bytes != m.lut_entries * 16)) return bad_meta("prefix table");
+    if (!m.lut_bytes && (m.lut_len || m.lut_entries)) return bad_meta("prefix-table fields without the table");
     return 0;
 }
 
-int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
-    const FileHeader& fh = *reinterpret_cast<const FileHeader*>(header);
-    if (fh.meta_bytes != sizeof(SavedIndex)) return fail(FMGPU_ERR_UNSUPPORTED, "index file: written by another build of the library (description block of " + std::to_string(fh.meta_bytes) + " bytes)");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); return fail(FMGPU_ERR_NO_DEVICE, "no HIP device visible — the product path has no CPU fallback"); }
-    auto meta = std::make_unique<SavedIndex>();
+// where the arrays of a new handle come from: the sections of a file (through a pinned buffer, checksummed), or the arrays of a handle on another device of this
+// process (hipMemcpyPeer: over xGMI, no host copy — SURVEY 8e: "upload once to GPU0 then hipMemcpyPeer")
+struct FileSource {
+    FILE* f; uint8_t* host; uint32_t nsec = 0;
+    int get(uint32_t want_id, uint64_t want_bytes, void** dev) {
+        *dev = nullptr;
+        if (want_bytes == 0) return 0;
+        SectionHeader sh{};
+        int rc = read_exact(f, &sh, sizeof sh, "section header");
+        if (rc) return rc;
+        if (sh.id != want_id || sh.bytes != want_bytes)
+            return fail(FMGPU_ERR_INVALID, "index file: section " + std::to_string(want_id) + " expected with " + std::to_string(want_bytes) + " bytes, found section " +
+                                           std::to_string(sh.id) + " with " + std::to_string(sh.bytes));
+        DBuf d;
+        if ((rc = d.alloc(want_bytes))) return rc;
+        uint64_t sum = 0x243f6a8885a308d3ull ^ want_id;
+        for (uint64_t at = 0; at < want_bytes; at += kChunk) {
+            const size_t c = (size_t)std::min<uint64_t>(kChunk, want_bytes - at);
+            if ((rc = read_exact(f, host, c, "section payload"))) return rc;
+            sum = mix_words(sum, host, c);
+            FM_HIP(hipMemcpy((uint8_t*)d.p + at, host, c, hipMemcpyHostToDevice));
+        }
+        uint64_t pad = (8 - want_bytes % 8) % 8, skip = 0;
+        if (pad && (rc = read_exact(f, &skip, pad, "padding"))) return rc;
+        if (sum != sh.sum) return fail(FMGPU_ERR_INVALID, "index file: checksum mismatch in section " + std::to_string(want_id));
+        *dev = d.take();
+        ++nsec;
+        return 0;
+    }
+    int finish() {
+        uint64_t trailer[2] = {0, 0};
+        int rc = read_exact(f, trailer, sizeof trailer, "trailer");
+        if (rc) return rc;
+        if (trailer[0] != kTrailerMagic || trailer[1] != nsec) return fail(FMGPU_ERR_INVALID, "index file: trailer does not match (truncated or not an index file)");
+        return 0;
+    }
+};
+struct PeerSource {
+    const void* ptr[2][11]; const void* other[8]; int src_device, dst_device;     // other: by SectionId - SEC_C
+    int get(uint32_t id, uint64_t bytes, void** dev) {
+        *dev = nullptr;
+        if (bytes == 0) return 0;
+        const void* from = id >= SEC_C ? other[id - SEC_C] : ptr[id / 32][id % 32];
+        if (!from) return fail(FMGPU_ERR_INVALID, "index clone: array " + std::to_string(id) + " is missing on the source handle");
+        DBuf d; int rc;
+        if ((rc = d.alloc(bytes))) return rc;
+        FM_HIP(hipMemcpyPeer(d.p, dst_device, from, src_device, bytes));
+        *dev = d.take();
+        return 0;
+    }
+    int finish() { return 0; }
+};
+
+// the handle from its description and its arrays (Source::get hands over one device array per call, in file order), then everything that is derived rather than stored
+template <class Source>
+static int index_assemble(const SavedIndex& m, Source& src, fmgpu_index_t* out) {
+    const SavedIndex* meta = &m;
     int rc;
-    if ((rc = read_exact(f, meta.get(), sizeof(SavedIndex), "description block"))) return rc;
-    if (mix_words(0x13198a2e03707344ull, (const uint8_t*)meta.get(), sizeof(SavedIndex)) != fh.meta_sum) return fail(FMGPU_ERR_INVALID, "index file: checksum mismatch in the description block");
-    if ((meta->wide != 0) != kWide || meta->sigma < 2 || meta->sigma > 256 || meta->str[0].n != meta->n || meta->n >= kWideLimit)
-        return fail(FMGPU_ERR_INVALID, "index file: inconsistent description block");
     std::unique_ptr<Index> x(new (std::nothrow) Index());
     if (!x) return fail(FMGPU_ERR_NOMEM, "host allocation");
     (void)hipGetDevice(&x->hdr.device);
     auto bail = [&](int code) { api::fmgpu_index_destroy(reinterpret_cast<fmgpu_index_t>(x.release())); return code; };
-    PinnedBuf pin;
-    if ((rc = pin.alloc(kChunk))) return bail(rc);
-    uint8_t* host = (uint8_t*)pin.p;
-    uint32_t nsec = 0;
     std::memcpy(x->hC, meta->hC, sizeof meta->hC);
     x->bidirectional = meta->bidirectional != 0;
     for (int w = 0; w < 2; ++w) {
@@ -229,7 +347,7 @@ int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
         s.layout = o.layout; s.family = o.family; s.sigma = o.sigma; s.bitct = o.bitct; s.n = o.n;
         void* p[11];
         for (uint32_t k = 0; k < 11; ++k) {
-            if ((rc = read_section(f, k + 32u * w, o.bytes[k], &p[k], host, &nsec))) { for (uint32_t q = 0; q < k; ++q) if (p[q]) (void)hipFree(p[q]); return bail(rc); }
+            if ((rc = src.get(k + 32u * w, o.bytes[k], &p[k]))) { for (uint32_t q = 0; q < k; ++q) if (p[q]) (void)hipFree(p[q]); return bail(rc); }
         }
         s.blk = p[SEC_BLK]; s.blk_bytes = o.bytes[SEC_BLK]; s.aux = p[SEC_AUX]; s.aux_bytes = o.bytes[SEC_AUX]; s.sup = p[SEC_SUP]; s.sup_bytes = o.bytes[SEC_SUP];
         s.lf_table = (idx_t*)p[SEC_LF]; s.kblk = (uint8_t*)p[SEC_KBLK]; s.kblk_bytes = o.bytes[SEC_KBLK]; s.kstep = o.kstep; s.kcodes = o.kcodes;
@@ -239,12 +357,12 @@ int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
         for (uint32_t k = 0; k < 11; ++k) x->device_bytes += o.bytes[k];
     }
     void* dC = nullptr;
-    if ((rc = read_section(f, SEC_C, meta->dC_bytes, &dC, host, &nsec))) return bail(rc);
+    if ((rc = src.get(SEC_C, meta->dC_bytes, &dC))) return bail(rc);
     x->dC = (idx_t*)dC;
     if (meta->has_sa) {
         void** dst[5] = {&x->sa_l0, &x->sa_l1, &x->sa_bits, &x->sa_f0, &x->sa_f1};
         for (uint32_t k = 0; k < 5; ++k) {
-            if ((rc = read_section(f, SEC_SA_L0 + k, meta->sa_bytes[k], dst[k], host, &nsec))) return bail(rc);
+            if ((rc = src.get(SEC_SA_L0 + k, meta->sa_bytes[k], dst[k]))) return bail(rc);
             x->sa_bytes[k] = meta->sa_bytes[k]; x->device_bytes += meta->sa_bytes[k];
         }
         x->vsa = meta->vsa;
@@ -253,13 +371,11 @@ int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
         x->has_sa = true;
     }
     void* q = nullptr;
-    if ((rc = read_section(f, SEC_LOC, meta->loc_bytes, &q, host, &nsec))) return bail(rc);
+    if ((rc = src.get(SEC_LOC, meta->loc_bytes, &q))) return bail(rc);
     x->loc_tab = (uint32_t*)q; x->device_bytes += meta->loc_bytes;
-    if ((rc = read_section(f, SEC_LUT, meta->lut_bytes, &q, host, &nsec))) return bail(rc);
+    if ((rc = src.get(SEC_LUT, meta->lut_bytes, &q))) return bail(rc);
     x->lut = (uint4*)q; x->lut_len = meta->lut_len; x->lut_entries = meta->lut_entries; x->device_bytes += meta->lut_bytes;
-    uint64_t trailer[2] = {0, 0};
-    if ((rc = read_exact(f, trailer, sizeof trailer, "trailer"))) return bail(rc);
-    if (trailer[0] != kTrailerMagic || trailer[1] != nsec) return bail(fail(FMGPU_ERR_INVALID, "index file: trailer does not match (truncated or not an index file)"));
+    if ((rc = src.finish())) return bail(rc);
     // the views: the saved scalars with this process's device pointers
     for (int w = 0; w < 2; ++w) {
         DevString& s = w ? x->rev : x->bwt;
@@ -275,6 +391,15 @@ int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
             s.vm = o.vm; s.vm.data = (const uint8_t*)s.blk; s.vm.node_off = (const uint64_t*)s.aux; s.vm.C = x->dC;
             s.vm.node_super = kWide ? (const uint32_t*)s.sup : nullptr;
             s.vm.super = (kWide && s.sup) ? reinterpret_cast<const uint64_t*>((const uint8_t*)s.sup + o.vm_super_off) : nullptr;
+            // the node offsets are data the kernels index the tree with: every node's block array must start inside the tree
+            std::vector<uint64_t> off(s.vm.nnodes);
+            hipError_t e = hipMemcpy(off.data(), s.aux, off.size() * 8, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return bail(hip_fail(e, "index load (node offsets)"));
+            for (uint32_t l = 0; l < s.vm.nlevels; ++l) {
+                const uint32_t first = s.vm.lv[l].first_node, last = l + 1 < s.vm.nlevels ? s.vm.lv[l + 1].first_node : s.vm.nnodes;
+                for (uint32_t k = first; k < last; ++k)
+                    if (off[k] + s.vm.lv[l].stride > s.blk_bytes || (k > 0 && off[k] < off[k - 1])) return bail(bad_meta("wavelet node offsets leave the tree"));
+            }
         }
     }
     // derived data is rebuilt rather than stored: the Format A expansion of a sigma = 5 string of another layout (unless the file carried it with its tables) ...
@@ -292,9 +417,52 @@ int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
     }
     if ((rc = build_pair_table(x.get(), nullptr))) return bail(rc);       // ... and so are Formats P and S
     if ((rc = build_flat_table(x.get(), nullptr))) return bail(rc);
-    FM_HIP(hipDeviceSynchronize());
+    { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) return bail(hip_fail(e, "index load")); }     // (an asynchronous fault of a builder surfaces here: nothing is handed out)
     *out = reinterpret_cast<fmgpu_index_t>(x.release());
     return 0;
+}
+
+int index_load(FILE* f, const void* header, fmgpu_index_t* out) {
+    const FileHeader& fh = *reinterpret_cast<const FileHeader*>(header);
+    if (fh.meta_bytes != sizeof(SavedIndex)) return fail(FMGPU_ERR_UNSUPPORTED, "index file: written by another build of the library (description block of " + std::to_string(fh.meta_bytes) + " bytes)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); return fail(FMGPU_ERR_NO_DEVICE, "no HIP device visible — the product path has no CPU fallback"); }
+    auto meta = std::make_unique<SavedIndex>();
+    int rc;
+    if ((rc = read_exact(f, meta.get(), sizeof(SavedIndex), "description block"))) return rc;
+    if (mix_words(0x13198a2e03707344ull, (const uint8_t*)meta.get(), sizeof(SavedIndex)) != fh.meta_sum) return fail(FMGPU_ERR_INVALID, "index file: checksum mismatch in the description block");
+    if ((rc = validate_meta(*meta))) return rc;
+    PinnedBuf pin;
+    if ((rc = pin.alloc(kChunk))) return rc;
+    FileSource src{f, (uint8_t*)pin.p};
+    return index_assemble(*meta, src, out);
+}
+
+// a copy of the handle on the calling thread's current device: every stored array travels device to device, the derived tables are rebuilt there
+int fmgpu_index_clone(fmgpu_index_t h, fmgpu_index_t* out) {
+    Index* x = reinterpret_cast<Index*>(h);
+    if (!x || !out) return fail(FMGPU_ERR_INVALID, "index handle / out is null");
+    *out = nullptr;
+    int dst = 0;
+    FM_HIP(hipGetDevice(&dst));
+    const int srcd = x->hdr.device;
+    if (dst != srcd) {
+        int can = 0;
+        hipError_t e = hipDeviceCanAccessPeer(&can, dst, srcd);
+        if (e != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        if (can) { e = hipDeviceEnablePeerAccess(srcd, 0); if (e != hipSuccess) (void)hipGetLastError(); }     // (already enabled is fine; hipMemcpyPeer stages through the host where it is not possible)
+    }
+    auto meta = std::make_unique<SavedIndex>();
+    PeerSource src{};
+    describe_index(x, true, *meta, src.ptr);
+    src.other[SEC_C - SEC_C] = x->dC;
+    src.other[SEC_SA_L0 - SEC_C] = x->sa_l0; src.other[SEC_SA_L1 - SEC_C] = x->sa_l1; src.other[SEC_SA_BITS - SEC_C] = x->sa_bits;
+    src.other[SEC_SA_F0 - SEC_C] = x->sa_f0; src.other[SEC_SA_F1 - SEC_C] = x->sa_f1;
+    src.other[SEC_LOC - SEC_C] = x->loc_tab; src.other[SEC_LUT - SEC_C] = x->lut;
+    src.src_device = srcd; src.dst_device = dst;
+    int rc;
+    if ((rc = validate_meta(*meta))) return rc;                   // (a handle describes itself consistently: a guard for the code above, not for the caller)
+    return index_assemble(*meta, src, out);
 }
 }  // namespace api
 }  // namespace FMGPU_NS

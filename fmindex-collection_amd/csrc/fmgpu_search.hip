@@ -45,15 +45,16 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
     return v;
 }
 
-// counters of the one-thread-per-query kernels: [0] executed steps, [1] table bytes consumed, [2] table accesses (fmgpu_stats), each striped
+// counters of the one-thread-per-query kernels: [0] executed steps, [1] table bytes consumed, [2] table accesses, [3] steps that an interval-table entry stood for (fmgpu_stats), each striped
 // over kCounterStripes words (a single word would serialise one atomic per wave — 156 k of them for 10 M queries — behind each other)
-__device__ __forceinline__ void add_counters(unsigned long long* __restrict__ ctr, uint32_t steps, uint32_t bytes, uint32_t accesses) {
-    const uint32_t ts = wave_sum(steps), tb = wave_sum(bytes), ta = wave_sum(accesses);
+__device__ __forceinline__ void add_counters(unsigned long long* __restrict__ ctr, uint32_t steps, uint32_t bytes, uint32_t accesses, uint32_t table_steps = 0u) {
+    const uint32_t ts = wave_sum(steps), tb = wave_sum(bytes), ta = wave_sum(accesses), tt = wave_sum(table_steps);
     if ((threadIdx.x & 63u) == 0 && ts) {
         const uint32_t stripe = blockIdx.x & (kCounterStripes - 1u);
         atomicAdd(&ctr[stripe], (unsigned long long)ts);
         atomicAdd(&ctr[kCounterStripes + stripe], (unsigned long long)tb);
         atomicAdd(&ctr[2u * kCounterStripes + stripe], (unsigned long long)ta);
+        if (tt) atomicAdd(&ctr[3u * kCounterStripes + stripe], (unsigned long long)tt);
     }
 }
 
@@ -214,7 +215,11 @@ __device__ __forceinline__ uint32_t pair_rank_lds(const lds_word* own, uint32_t 
     const uint32_t h2 = (w2.x ^ i0) & (w2.z ^ i1) & (w3.x ^ i2) & (w3.z ^ i3), h3 = (w2.y ^ i0) & (w2.w ^ i1) & (w3.y ^ i2) & (w3.w ^ i3);
     return cnt + __popc(h0 & m0) + __popc(h1 & m1) + __popc(h2 & m2) + __popc(h3 & m3);
 }
+// slut != null (fmgpu_index_accelerate_exact(h, 1, lutL, 0) on a handle with the pair table): a read whose last lutL symbols are all in 1..4 starts from the interval-table
+// entry of those symbols (one 8 / 16-byte load from a table of 4^lutL entries — 12 symbols: 134 MB, Infinity-Cache resident — instead of lutL / 2 pair steps whose two interval
+// ends lie in two lines each); an empty entry is walked from the start instead, so the miss row and the step count stay the one-symbol search's.
 __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __restrict__ pairs, const idx_t* __restrict__ ex, uint32_t nex, const idx_t* __restrict__ psuper,
+                                                 const void* __restrict__ slut, uint32_t lutL,
                                                  const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                  unsigned long long* __restrict__ steps_total) {
@@ -269,15 +274,26 @@ __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __r
         return len != 0;
     };
     bool alive = m != 0;
-    uint32_t mmax = m;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, (uint32_t)__shfl_xor(mmax, off, 64));
-    for (uint32_t i = 0; i < mmax; i += 2u) {                       // every lane of the wave stands at symbol i of its read (or is done)
-        if (i >= m) alive = false;
+    uint32_t done = 0, lut_steps = 0, acc3 = 0;                     // symbols of the read consumed so far; steps an interval-table entry stood for; such entries read
+    if (slut && alive && m >= lutL && n > 1) {
+        uint32_t code = 0; bool valid = true;
+        for (uint32_t t = 0; t < lutL; ++t) { const uint32_t c = qr.next(); valid = valid && c - 1u < 4u; code |= ((c - 1u) & 3u) << (2u * t); }
+        idx_t elb = 0, elen = 0;
+        if (valid) {
+            if constexpr (kWide) { const ulonglong2 en = reinterpret_cast<const ulonglong2*>(slut)[code]; elb = (idx_t)en.x; elen = (idx_t)en.y; }
+            else { const uint2 en = reinterpret_cast<const uint2*>(slut)[code]; elb = en.x; elen = en.y; }
+            ++acc3;
+        }
+        if (elen != 0) { lb = elb; len = elen; done = lutL; steps = lutL; lut_steps = lutL; }
+        else qr.init(qbuf, qoff[q], m);                             // (a foreign byte among the symbols, or a string the text does not hold: from the start, step by step)
+    }
+    for (;;) {                                                      // every lane of the wave takes its next two symbols (or is done)
+        if (done >= m) alive = false;
         if (!__ballot(alive)) break;
-        const bool two = alive && i + 2u <= m;
+        const bool two = alive && done + 2u <= m;
         uint32_t y = 0, x = 0;
         if (alive) { y = qr.next(); if (two) x = qr.next(); }
+        done += 2u;
         const bool pairable = two && y - 1u < 4u && x - 1u < 4u;
         bool stepped = false;
         if (__ballot(pairable)) {
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __r
         }
     }
     if (q < nq) store_interval(out_lb, out_len, q, lb, len);
-    add_counters(steps_total, steps, 12u * acc + 68u * acc2, acc + acc2);
+    add_counters(steps_total, steps, 12u * acc + 68u * acc2 + (uint32_t)kSlutEntryBytes * acc3, acc + acc2 + acc3, lut_steps);
 }
 
 // ---- exact search on Format S (fmgpu_common.h): ONE 128-byte line per LF step and interval end where the multi-ary wavelet tree of sigma = 28 takes two —
@@ -2808,6 +2824,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
 #endif
 #ifdef FMGPU_DEV
     uint32_t dev_multi = 0, dev_iter = 0, dev_busy = 0;             // dev build: lane-iterations on multi-row nodes / wave iterations / busy lane-iterations (reported through table_accesses, table_bytes)
+    uint32_t dev_slot_bad = 0;                                      // dev build: pops / hand-overs whose LDS slot did not hold the frame that is in HBM (reported through table_steps: must be 0)
 #endif
     bool have = false, exhausted = n == 0, need_start = false, is_task = false, odd = false, in_tail = false;
     uint32_t q = 0, si = 0, e = 0, j = 0, sp = 0, sbase = 0, resume = kLeanNoResume;
@@ -2836,6 +2853,12 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                         asm volatile("" ::: "memory");              // LDS-DMA issued a whole pass ago — the node steps in between consumed block loads issued after it)
                         const u32x4 t = *bos_slot;
                         w0 = (uint64_t)t.x | ((uint64_t)t.y << 32); w1 = (uint64_t)t.z | ((uint64_t)t.w << 32);
+#ifdef FMGPU_DEV
+                        {   // the invariant the slot rests on: it holds what the write-through stack holds at depth sbase
+                            const u32x4 hb = *reinterpret_cast<const u32x4*>(frames + ((uint64_t)sbase * nlanes + gid));
+                            if (hb.x != t.x || hb.y != t.y || hb.z != t.z || hb.w != t.w) ++dev_slot_bad;
+                        }
+#endif
                     }
                     { const uint32_t fe = lean_frame_errors(w1); w2 = ((uint64_t)(fe >= 1u ? k1 : 0u) << 32) | (fe >= 2u ? k2 : 0u); }      // the key of the frame's node: the fields of later substitutions cleared
                     ++sbase; mark = nodes;
@@ -3058,6 +3081,12 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 --sp;
                 asm volatile("" ::: "memory");                      // (the slot is read here, not ahead of the branch)
                 const u32x4 t = *tos_slot;                          // the cached top frame ...
+#ifdef FMGPU_DEV
+                {   // the ordering invariant above, checked: the LDS-DMA that refilled the slot has landed, so the slot holds the frame the stack holds at depth sp
+                    const u32x4 hb = *reinterpret_cast<const u32x4*>(frames + ((uint64_t)sp * nlanes + gid));
+                    if (hb.x != t.x || hb.y != t.y || hb.z != t.z || hb.w != t.w) ++dev_slot_bad;
+                }
+#endif
                 lean_unpack((uint64_t)t.x | ((uint64_t)t.y << 32), (uint64_t)t.z | ((uint64_t)t.w << 32), lb, lbRev, len, j, e, resume);
                 if (e == 0u) k1 = 0u;                                // the key of the popped node: the fields of later substitutions cleared
                 if (e <= 1u) k2 = 0u;
@@ -3087,7 +3116,9 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
 #endif
 #ifdef FMGPU_DEV
     { const uint32_t a1 = wave_sum(dev_multi), a2 = wave_sum(dev_iter), a3 = wave_sum(dev_busy);
-      if (lane == 0) { atomicAdd(&ctr->table_accesses, (unsigned long long)a1 | ((unsigned long long)a2 << 40)); atomicAdd(&ctr->table_bytes, (unsigned long long)a3); } }
+      if (lane == 0) { atomicAdd(&ctr->table_accesses, (unsigned long long)a1 | ((unsigned long long)a2 << 40)); atomicAdd(&ctr->table_bytes, (unsigned long long)a3); }
+      const uint32_t bad = wave_sum(dev_slot_bad);
+      if (lane == 0 && bad) atomicAdd(reinterpret_cast<unsigned long long*>(ctr) + 20, (unsigned long long)bad); }
     (void)blk_loads; (void)multi_nodes;
 #else
     // what the kernel asked of the occurrence tables: table_accesses = blocks fetched (both ends of a node whose ends lie in two blocks; a node re-visited for its next
@@ -3700,7 +3731,10 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
     const idx_t n = (idx_t)x->bwt.n;
     timer.start();
     uint32_t kq_words = 0, kq_max = 0, kq_nib = x->bwt.sigma <= 15 ? 1u : 0u;
-    const bool accel = x->bwt.kblk || x->bwt.slut || x->bwt.walkj;
+    // the pair table with an interval table in front of it (and no other table): k_exact_p starts from the entry of the read's last symbols
+    const bool pair_lut = x->bwt.sigma == 5 && x->bwt.pairs && x->bwt.slut && !x->bwt.kblk && !x->bwt.walkj && x->bwt.search_family() == FAM_A &&
+                          !(kernel_flags() & (FMGPU_SEL_EXACT_ONE_SYMBOL | FMGPU_SEL_NO_EXACT_LUT));
+    const bool accel = (x->bwt.kblk || x->bwt.slut || x->bwt.walkj) && !pair_lut;
     if (accel) {                                                 // LDS staging needs the longest query of the batch
         uint32_t mn = 0;
         if (have_shape) kq_max = shape_max;
@@ -3725,7 +3759,8 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         // blocks = 19.53 / 19.23 / 18.92 / 19.10 / 18.95 ms — more waves only queue up at the memory system): 28 KB of unused dynamic LDS set the residency
         const size_t lds_a = dev_env("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)28 * 1024;
         if (x->bwt.sigma == 5 && x->bwt.pairs && !(kernel_flags() & (1 << 22)))
-            k_exact_p<<<grid, block, 4 * 8 * kCoopRegion + dev_extra_lds, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, x->bwt.pairs_super, qb, qo, nq, n, ol, on, dsteps);
+            k_exact_p<<<grid, block, 4 * 8 * kCoopRegion + dev_extra_lds, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, x->bwt.pairs_super,
+                                                                                    pair_lut ? (const void*)x->bwt.slut : nullptr, x->bwt.slut_len, qb, qo, nq, n, ol, on, dsteps);
         else if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
         else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
     } else if (x->bwt.flat && x->bwt.search_family() != FAM_A && !(kernel_flags() & (1 << 21))) {
@@ -3765,10 +3800,10 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_exact launch");
     if (stats) {
-        unsigned long long hs[kCounterKinds] = {0, 0, 0};
+        unsigned long long hs[kCounterKinds] = {0, 0, 0, 0};
         if ((rc = read_step_counters(dsteps, stream, hs))) return rc;
         stats->lf_steps = hs[0]; stats->hits = nq; stats->kernel_ms = timer.ms();
-        stats->table_bytes = hs[1]; stats->table_accesses = hs[2];
+        stats->table_bytes = hs[1]; stats->table_accesses = hs[2]; stats->table_steps = hs[3];
     }
     if ((rc = slb.finish())) return rc;
     if (out_len && (rc = slen.finish())) return rc;
@@ -4199,6 +4234,9 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
 #endif
     *out_count = hc.hits;
     if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); stats->prepass_ms = prepass_ms; stats->table_bytes = hc.table_bytes; stats->table_accesses = hc.table_accesses; }
+#ifdef FMGPU_DEV
+    if (stats) { unsigned long long bad = 0; (void)hipMemcpy(&bad, reinterpret_cast<unsigned long long*>(ws.ctr) + 20, 8, hipMemcpyDeviceToHost); stats->table_steps = bad; }     // (k_scheme_lean: LDS frame slots that disagreed with the stack in HBM)
+#endif
     if (hc.hits > capacity) {
         if (sout.writeback) { sout.bytes = capacity * sizeof(fmgpu_hit); (void)sout.finish(); }
         return fail(FMGPU_ERR_CAPACITY, "result buffer holds " + std::to_string(capacity) + " records, " + std::to_string(hc.hits) + " produced");
@@ -4400,7 +4438,7 @@ int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "k_locate launch");
     if (stats) {
-        unsigned long long hs[kCounterKinds] = {0, 0, 0};
+        unsigned long long hs[kCounterKinds] = {0, 0, 0, 0};
         if ((rc = read_step_counters(dsteps, stream, hs))) return rc;
         stats->lf_steps = hs[0]; stats->hits = count; stats->kernel_ms = timer.ms();
     }

@@ -162,6 +162,7 @@ typedef struct fmgpu_stats {
      * memory line (two loads into the same 64-byte block count once).  Query and result traffic is coalesced and not included. */
     uint64_t table_bytes;
     uint64_t table_accesses;
+    uint64_t table_steps;    /* exact search from an interval table in front of the pair table: LF steps that the entries stood for (entries read x their symbols); else 0 */
 } fmgpu_stats;
 
 /* Library options: process-wide, read when a handle is created / a call starts (set them before, not during, the calls they concern).
@@ -231,10 +232,14 @@ int fmgpu_index_formats(fmgpu_index_t h, uint32_t* mask);
  * the handle and every device array as it sits in HBM, each with a checksum; include_tables != 0 also stores whatever optional tables the handle
  * holds at that moment (LF, k-step, interval, walk, prefix, locate tables, Format A expansion), so that a process start costs one read and one copy per
  * array instead of a suffix sort and the table construction.  fmgpu_index_load creates the handle on the calling thread's current device; a file
- * that is truncated, damaged (checksums), of another format / ABI version or byte order is refused with an error code and nothing is created.
+ * that is truncated, damaged (checksums), of another format / ABI version or byte order, or whose description does not fit its own n / sigma / layouts (every
+ * array size is checked against what creation would allocate, before anything is allocated) is refused with an error code and nothing is created.
  * NOT the reference's cereal format: its byte layout for the mmser members cannot be pinned without a reference-written file. */
 int fmgpu_index_save(fmgpu_index_t h, const char* path, int32_t include_tables);
 int fmgpu_index_load(const char* path, fmgpu_index_t* out);
+/* A copy of the handle on the calling thread's CURRENT device: every array the handle holds (optional tables included) travels device to device (hipMemcpyPeer: over
+ * xGMI, no host copy), the derived tables are rebuilt there.  SURVEY 8e: "upload once to GPU0 then hipMemcpyPeer rather than 8 PCIe uploads"; fmgpu_replicas_load uses it. */
+int fmgpu_index_clone(fmgpu_index_t h, fmgpu_index_t* out);
 
 /* The explicit LF mapping (one word per row and direction: LF(row) = C[s] + rank(row, s) of the row's own symbol s): one-load one-row
  * search nodes and locate steps, and what the walk tables are built from.  Built at creation unless FMGPU_OPT_LF_TABLE is 0; enable = 0 drops it (the walk tables must have been dropped before), enable != 0 builds it.  Without it the index is the
@@ -356,8 +361,9 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
 int fmgpu_built_get(fmgpu_built_t b, int32_t part, const void** ptr, uint64_t* bytes);
 int fmgpu_built_free(fmgpu_built_t b);
 
-/* ---- one index on several GPUs of a node, for a caller that is ONE process (SURVEY 8b `fmgpu_set_devices`, 8e): the index file is loaded once per listed
- * device (ndev <= 0: every visible device; a device may be listed twice), a batch is cut into contiguous ranges of queries, every replica searches its range
+/* ---- one index on several GPUs of a node, for a caller that is ONE process (SURVEY 8b `fmgpu_set_devices`, 8e): the index file is read ONCE, onto the first listed
+ * device, and copied from there to the others device to device (fmgpu_index_clone; the file is read again for a device the copy fails on;
+ * ndev <= 0: every visible device; a device may be listed twice), a batch is cut into contiguous ranges of queries, every replica searches its range
  * on its own device from its own host thread and writes into its range of the caller's HOST arrays (queries are independent and the index is read-only: there
  * is no exchange between replicas; ranks of a multi-process job gather with RCCL instead — bench.py).  Results equal the single-handle calls' on the same
  * batch (hit records: the same set, query numbers of the whole batch; fmgpu_hits_sort orders them).  stats: sums, kernel_ms / prepass_ms = the slowest replica's.
@@ -365,6 +371,7 @@ int fmgpu_built_free(fmgpu_built_t b);
 typedef struct fmgpu_replicas* fmgpu_replicas_t;
 int fmgpu_replicas_load(const char* path, const int32_t* devices, int32_t ndev, fmgpu_replicas_t* out);
 int fmgpu_replicas_destroy(fmgpu_replicas_t r);
+int fmgpu_replicas_peer_copies(fmgpu_replicas_t r, int32_t* count);   /* replicas that were made by a device-to-device copy of the first one (the others read the file) */
 int fmgpu_replicas_info(fmgpu_replicas_t r, int32_t* count, int32_t* devices, int32_t capacity, fmgpu_index_t* first);
 int fmgpu_replicas_search_exact(fmgpu_replicas_t r, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats);
 int fmgpu_replicas_search_scheme(fmgpu_replicas_t r, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme, uint64_t max_hits_per_query,

@@ -732,6 +732,28 @@ uint64_t ora_dense_access(const ora_dense_vector* v, uint64_t i) {   /* DenseVec
     return value * v->commonDivisor;
 }
 static uint64_t gcd_u64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; }
+/* DenseVector on its own (the reference tests it apart from the SparseArray, checkDenseVector.cpp:8-82):
+ * largest == 0 and divisor == 0: DenseVector{span} (DenseVector.h:84-99: largest value and gcd of the values); else DenseVector(largest, divisor) + push_back (:57-61) */
+ora_dense_vector* ora_dense_build(const uint64_t* values, uint64_t n, uint64_t largest, uint64_t divisor) {
+    ora_dense_vector* v = calloc(1, sizeof *v);
+    if (largest == 0 && divisor == 0) {
+        for (uint64_t i = 0; i < n; ++i) { if (values[i] > largest) largest = values[i]; divisor = gcd_u64(divisor, values[i]); }
+        if (divisor == 0) divisor = 1;
+    }
+    dense_init(v, largest, divisor, n);
+    for (uint64_t i = 0; i < n; ++i) dense_push(v, values[i]);
+    return v;
+}
+uint64_t ora_dense_size(const ora_dense_vector* v) { return v->bits ? v->bitCount / v->bits : 0; }   /* DenseVector.h: size() */
+ora_dense_vector* ora_dense_concat(const ora_dense_vector* a, const ora_dense_vector* b) {           /* DenseVector.h:38-50 */
+    ora_dense_vector* v = calloc(1, sizeof *v);
+    const uint64_t na = ora_dense_size(a), nb = ora_dense_size(b);
+    dense_init(v, a->largestValue > b->largestValue ? a->largestValue : b->largestValue, gcd_u64(a->commonDivisor, b->commonDivisor), na + nb);
+    for (uint64_t i = 0; i < na; ++i) dense_push(v, ora_dense_access(a, i));
+    for (uint64_t i = 0; i < nb; ++i) dense_push(v, ora_dense_access(b, i));
+    return v;
+}
+void ora_dense_free(ora_dense_vector* v) { if (v) { free(v->data); free(v); } }
 
 ora_sparse* ora_sparse_build(uint64_t n, const uint8_t* has, const uint64_t* seq, const uint64_t* pos) {
     ora_sparse* s = calloc(1, sizeof *s);
@@ -775,6 +797,7 @@ static uint64_t sparse_rank(const ora_sparse* s, uint64_t idx) {    /* Bitvector
     if (bitId % 64) cnt += POPC(w[bitId / 64] << (64 - bitId % 64));
     return s->l0[l0Id] + s->l1[l1Id] + cnt;
 }
+uint64_t ora_sparse_rank(const ora_sparse* s, uint64_t idx) { return sparse_rank(s, idx); }       /* (the presence bitvector's rank, for bitvector/unittest.cpp's vectors) */
 int ora_sparse_value(const ora_sparse* s, uint64_t idx, uint64_t* seq, uint64_t* pos) {   /* SparseArray.h:63-70 */
     if (!((s->bits[idx / 64] >> (idx % 64)) & 1)) return 0;
     uint64_t r = sparse_rank(s, idx);

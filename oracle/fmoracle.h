@@ -89,6 +89,11 @@ ora_sparse* ora_sparse_build(uint64_t n, const uint8_t* has, const uint64_t* seq
 void        ora_sparse_free(ora_sparse* s);
 int         ora_sparse_value(const ora_sparse* s, uint64_t idx, uint64_t* seq, uint64_t* pos);  /* 1 if present */
 uint64_t    ora_dense_access(const ora_dense_vector* v, uint64_t i);
+ora_dense_vector* ora_dense_build(const uint64_t* values, uint64_t n, uint64_t largest, uint64_t divisor);   /* DenseVector.h:57-61, :84-99 (largest = divisor = 0: from the values) */
+ora_dense_vector* ora_dense_concat(const ora_dense_vector* a, const ora_dense_vector* b);                     /* DenseVector.h:38-50 */
+uint64_t    ora_dense_size(const ora_dense_vector* v);
+void        ora_dense_free(ora_dense_vector* v);
+uint64_t    ora_sparse_rank(const ora_sparse* s, uint64_t idx);                                               /* bitvector/Bitvector2L.h:123-142 */
 
 /* ---------------------------------------------------------------- FMIndex / BiFMIndex */
 typedef struct ora_index {

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfmoracle.so")
+LIB_PATH = os.environ.get("FMORACLE_LIBRARY") or os.path.join(HERE, "libfmoracle.so")      # (FMORACLE_LIBRARY: the sanitizer build of `make -C oracle asan`)
 REF_PATH = os.path.join(HERE, "_ref", "libfmref.so")
 
 LAYOUTS = {
@@ -99,6 +99,17 @@ def lib():
         L.ora_sparse_build.argtypes = [C.c_uint64, u8p, u64p, u64p]
         L.ora_sparse_free.argtypes = [C.POINTER(Sparse)]
         L.ora_sparse_value.argtypes = [C.POINTER(Sparse), C.c_uint64, u64p, u64p]
+        L.ora_sparse_rank.restype = C.c_uint64
+        L.ora_sparse_rank.argtypes = [C.POINTER(Sparse), C.c_uint64]
+        L.ora_dense_build.restype = C.POINTER(DenseVector)
+        L.ora_dense_build.argtypes = [u64p, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.ora_dense_concat.restype = C.POINTER(DenseVector)
+        L.ora_dense_concat.argtypes = [C.POINTER(DenseVector), C.POINTER(DenseVector)]
+        L.ora_dense_free.argtypes = [C.POINTER(DenseVector)]
+        L.ora_dense_size.restype = C.c_uint64
+        L.ora_dense_size.argtypes = [C.POINTER(DenseVector)]
+        L.ora_dense_access.restype = C.c_uint64
+        L.ora_dense_access.argtypes = [C.POINTER(DenseVector), C.c_uint64]
         L.ora_suffix_array.argtypes = [u8p, C.c_uint64, u64p]
         L.ora_bwt_from_sa.argtypes = [u8p, C.c_uint64, u64p, u8p]
         L.ora_index_build.restype = C.POINTER(IndexStruct)
@@ -252,6 +263,62 @@ class OraString(_StringBase):
                 r[i, c] = L.ora_rank(self.h, i, c)
                 p[i, c] = L.ora_prefix_rank(self.h, i, c)
         return r, p
+
+
+class OraDenseVector:
+    """DenseVector (DenseVector.h:26-203): DenseVector{values}, or DenseVector(largest, divisor) followed by push_back of the values"""
+
+    def __init__(self, values=None, largest=0, divisor=0, _ptr=None):
+        if _ptr is None:
+            v = as_u64(values)
+            _ptr = lib().ora_dense_build(_p64(v), len(v), largest, divisor)
+        self.p = _ptr
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            lib().ora_dense_free(self.p)
+            self.p = None
+
+    @classmethod
+    def concat(cls, a, b):
+        return cls(_ptr=lib().ora_dense_concat(a.p, b.p))
+
+    def __len__(self):
+        return int(lib().ora_dense_size(self.p))
+
+    def __getitem__(self, i):
+        return int(lib().ora_dense_access(self.p, i))
+
+    @property
+    def common_divisor(self):
+        return int(self.p.contents.commonDivisor)
+
+    @property
+    def bits(self):
+        return int(self.p.contents.bits)
+
+
+class OraSparse:
+    """SparseArray<tuple, Bitvector2L<512, 65536>> (suffixarray/SparseArray.h:31-76) on its own: has[i] marks the rows that carry (seq[i], pos[i])"""
+
+    def __init__(self, has, seq=None, pos=None):
+        self.has = as_u8(has)
+        n = len(self.has)
+        self.seq = as_u64(seq if seq is not None else np.zeros(n))
+        self.pos = as_u64(pos if pos is not None else np.zeros(n))
+        self.p = lib().ora_sparse_build(n, _p8(self.has), _p64(self.seq), _p64(self.pos))
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            lib().ora_sparse_free(self.p)
+            self.p = None
+
+    def rank(self, i):
+        return int(lib().ora_sparse_rank(self.p, i))
+
+    def value(self, i):
+        a, b = C.c_uint64(), C.c_uint64()
+        return (int(a.value), int(b.value)) if lib().ora_sparse_value(self.p, i, C.byref(a), C.byref(b)) else None
 
 
 class OraIndex:

@@ -11,7 +11,7 @@
   ref_schemes.json       search-scheme tables produced by the real reference (h2, pigeon_opt, backtracking, expand,
                          limitToHamming, isValid, isComplete, nodeCount, createUniformPartition).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [--tests-only]
 """
 import json
 import os
@@ -154,6 +154,74 @@ def reference_tests():
         {"in": [[0, 1], [0, 0], [0, 1]], "len": 3, "out": [[0, 1, 2], [0, 0, 0], [0, 0, 1]]}]}
     out["h2_complete"] = {"source": "search_scheme/checkGeneratorsIsComplete.cpp:48-60",
                           "expect": "isComplete(h2(N, minK, maxK), minK, maxK) for N in 1..9, minK <= maxK < min(N, 5)"}
+    # --- DenseVector / DenseMultiVector (the value arrays of the sampled suffix array): inputs, how each vector is made, the divisor the tests assert
+    def dense_cases(path, lines):
+        src = open(path).read()
+        cases = []
+        for m in re.finditer(r'TEST_CASE\("([^"]+)"', src):
+            body = src[m.end(): (src.index("TEST_CASE(", m.end()) if "TEST_CASE(" in src[m.end():] else len(src))]
+            vecs = [[_tok(t) for t in re.findall(r"[^,\s{}]+", v)] for v in re.findall(r"std::vector<uint64_t>\{([^}]*)\}", body)]
+            case = {"name": m.group(1), "line": _line_of(src, m.start()), "inputs": vecs, "concat": "::concat(" in body}
+            ld = re.search(r"DenseVector\(/\*\.largestValue =\*/\s*(\d+),\s*/\*\.commonDivisor =\s*\*/\s*(\d+)\)", body)
+            if ld:
+                case["largest_divisor"] = [int(ld.group(1)), int(ld.group(2))]
+            cd = re.search(r"commonDivisor == (\d+)", body)
+            if cd:
+                case["common_divisor"] = int(cd.group(1))
+            cases.append(case)
+        return {"source": lines, "cases": cases, "expect": "vec[i] == input[i] for every i (concat: the left inputs followed by the right ones)"}
+    out["dense_vector"] = dense_cases(f"{TESTS}/checkDenseVector.cpp", "checkDenseVector.cpp:8-82")
+    out["dense_multi_vector"] = dense_cases(f"{TESTS}/checkDenseMultiVector.cpp", "checkDenseMultiVector.cpp:8-89")
+    # --- bitvector/unittest.cpp (runs over Bitvector2L_512_64k, bitvector/allBitVectors.h:45 — the presence bitvector of the sampled suffix array)
+    src = open(f"{TESTS}/bitvector/unittest.cpp").read()
+    short, p = _list_after(src, "auto text = std::vector<uint8_t>{")
+    sym = [[int(a), int(b)] for a, b in re.findall(r"CHECK\(vec\.symbol\(\s*(\d+)\) == (\d+)\);", src[p: src.index('SECTION("longer text")')])]
+    rk = [[int(a), int(b)] for a, b in re.findall(r"CHECK\(vec\.rank\(\s*(\d+)\) == (\d+)\);", src[p: src.index('SECTION("longer text")')])]
+    j = src.index('SECTION("longer text")')
+    long_bits, p2 = _list_after(src, "auto text = std::vector<uint8_t>{", j)
+    loop = re.search(r"for \(size_t i\{0\}; i < (\d+); i \+= (\d+)\)", src[p2:])
+    per = [[int(a), int(b)] for a, b in re.findall(r"CHECK\(vec\.rank\(i \+\s*(\d+)\) == (\d+) \+ i/16\*8\);", src[p2:])][:17]
+    long_rank = [[i + a, b + i // 16 * 8] for i in range(0, int(loop.group(1)), int(loop.group(2))) for a, b in per]
+    out["bitvector"] = {"source": "bitvector/unittest.cpp:14-140", "short": {"bits": short, "symbol": sym, "rank": rk},
+                        "long": {"bits": long_bits, "rank": long_rank, "expect": "symbol(i) == bits[i]; rank(i + j) == r_j + i / 16 * 8 for i = 0, 16, .. 496 (expanded here)"}}
+    # --- suffixarray/checkCSA.cpp: suffix array of "Hello$World$" and the (sequence, position) the sampled rows answer at sampling rates 3, 4, 5, 8
+    src = open(f"{TESTS}/suffixarray/checkCSA.cpp").read()
+    sa_col = [int(m.group(1)) for m in re.finditer(r"//\s+\S+\s+\d\s+\d\s+(\d+)\s*$", src, flags=re.M)]
+    csa = {"source": "suffixarray/checkCSA.cpp:9-81", "sequences": [[ord(c) for c in "Hello"], [ord(c) for c in "World"]], "sigma": 256, "sa": sa_col, "sampling": {}}
+    for m in re.finditer(r'SECTION\("sampling (\d+)"\)', src):
+        body = src[m.end(): src.index("check(csa, expected);", m.end())]
+        csa["sampling"][m.group(1)] = [[int(a), int(b), int(c)] for a, b, c in re.findall(r"expected\[(\d+)\] = \{(\d+), (\d+)\};", body)]     # row, sequence, position
+    out["csa"] = csa
+    # --- search_scheme: node counts, validity, completeness, the generators' validity ranges
+    src = open(f"{TESTS}/search_scheme/nodeCount.cpp").read()
+    known = [[int(a), int(b), int(c), int(d), int(e)] for a, b, c, d, e in
+             re.findall(r"CHECK\(\s*(\d+) == ss::nodeCount</\*Edit=\*/false>\(gen::backtracking\((\d+), (\d+), (\d+)\), (\d+)\)\);", src)]
+    out["node_count"] = {"source": "search_scheme/nodeCount.cpp:13-34", "sigma": 4, "zero_errors": {"n_from": 1, "n_to": 999, "expect": "nodeCount<false>(backtracking(n, 0, 0)) == n == nodeCount<false>(expand(backtracking(1, 0, 0), n))"},
+                         "known": known}                            # [count, N, minK, K, sigma]
+    src = open(f"{TESTS}/search_scheme/weightedNodeCount.cpp").read()
+    known = [[int(a), int(b), int(c), int(d), int(e), int(f.replace("'", ""))] for a, b, c, d, e, f in
+             re.findall(r"CHECK\(\s*(\d+) == ss::weightedNodeCount</\*Edit=\*/false>\(gen::backtracking\((\d+), (\d+), (\d+)\), (\d+), ([\d']+)\)\);", src)]
+    out["weighted_node_count"] = {"source": "search_scheme/weightedNodeCount.cpp:13-45", "sigma": 4, "N": 1_000_000_000,
+                                  "exact_below": 14, "bounded": {"n_from": 15, "n_to": 999, "below": 16}, "known": known}
+    def searches_of(path, call):
+        src = open(path).read()
+        res = []
+        for m in re.finditer(r"CHECK\((not )?ss::%s\(ss::S" % call, src):
+            nums, end = _list_after(src, "{", src.index("ss::Search", m.end() - 5) + len("ss::Search"))
+            tail = src[end: src.index(";", end)]
+            args = [int(x) for x in re.findall(r"\b(\d+)\b", tail)]
+            k = len(nums) // 3
+            res.append({"line": _line_of(src, m.start()), "expected": m.group(1) is None, "pi": nums[:k], "l": nums[k:2 * k], "u": nums[2 * k:], "args": args})
+        return res
+    src = open(f"{TESTS}/search_scheme/isValid.cpp").read()
+    first, _ = _list_after(src, "auto search = ss::Search{")
+    out["is_valid"] = {"source": "search_scheme/isValid.cpp:10-65", "cases": [{"line": 12, "expected": True, "pi": first[:1], "l": first[1:2], "u": first[2:], "args": []}] +
+                       searches_of(f"{TESTS}/search_scheme/isValid.cpp", "isValid")}
+    out["is_complete"] = {"source": "search_scheme/isComplete.cpp:10-35", "cases": searches_of(f"{TESTS}/search_scheme/isComplete.cpp", "isComplete")}     # args = [minK, maxK]
+    out["generators_valid"] = {"source": "search_scheme/checkGenerators.cpp:21-132",
+                               "backtracking": {"N": [1, 19], "minK": [0, 9], "maxK_below": 10}, "h2": {"N": [1, 19], "K_below": "min(N, 10)"},
+                               "pigeon_trivial": {"minK": [0, 19], "maxK_below": 20}, "pigeon_opt": {"minK": [0, 19], "maxK_below": 20},
+                               "expect": "isValid(generator(...)) over the ranges the reference's loops run (the generators this build restates)"}
     return out
 
 
@@ -277,6 +345,10 @@ def ref_search_intervals():
 
 
 def main():
+    if "--tests-only" in sys.argv:                               # only the data of the reference's own tests (needs /root/reference, not oracle/_ref)
+        with open(os.path.join(HERE, "reference_tests.json"), "w") as f:
+            json.dump(reference_tests(), f, separators=(",", ":"))
+        return
     ref_search_intervals()
     with open(os.path.join(HERE, "reference_tests.json"), "w") as f:
         json.dump(reference_tests(), f, separators=(",", ":"))

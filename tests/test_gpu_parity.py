@@ -147,6 +147,24 @@ def test_exact_search_in_pair_steps(shape, monkeypatch):
     a = fm.search_no_errors.search(gx, odd, want_stats=True)
     b = fm.search_no_errors.search(gx_single, odd, want_stats=True)
     assert not a[1].any() and np.array_equal(a[0], b[0]) and a[2].lf_steps == b[2].lf_steps
+    # an interval table in front of the pair table (fmgpu_index_accelerate_exact(h, 1, L, 0)): reads whose last L symbols are ordinary start from its entry — the
+    # intervals, the rows of misses and the step counts stay the one-symbol search's, also for reads shorter than L, strings the text does not hold (the
+    # entry is empty: walked from the start), delimiters and foreign bytes among the last L symbols
+    for lut_len in (1, 2, 5, 7):
+        gx.accelerate(1, lut_len=lut_len, walk=0)
+        assert bool(gx.formats & capi.FMT_INTERVALS)
+        for sel in (0, capi.SEL_NO_EXACT_LUT):               # k_exact_p behind the table, then the table-driven kernel on the same handle
+            with fm.options(kernel_select=sel):
+                lb, ln, st = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+                c = fm.search_no_errors.search(gx, odd, want_stats=True)
+            assert np.array_equal(ln, oln) and np.array_equal(lb, olb) and st.lf_steps == int(ost.sum()), (shape, lut_len, sel)
+            assert not c[1].any() and np.array_equal(c[0], b[0]) and c[2].lf_steps == b[2].lf_steps
+            if sel == 0 and has_table:
+                served = int(sum(lut_len for q_, l_ in zip(queries, oln) if len(q_) >= lut_len and all(1 <= int(v) <= 4 for v in list(q_)[-lut_len:]) and
+                                 ox.search_exact(*fm.flatten([list(q_)[-lut_len:]]))[1][0] > 0))
+                assert st.table_steps == served, (shape, lut_len)
+    gx.accelerate(1, lut_len=0, walk=0)
+    assert not (gx.formats & capi.FMT_INTERVALS)
 
 
 @pytest.mark.parametrize("sigma", [6, 21, 28, 29, 30])
@@ -1019,6 +1037,59 @@ def test_edit_distance_on_a_repeat_structured_text():
     assert same_hits(h21, o21) and st21.lf_steps == n21
 
 
+_SLOT_PROBE = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import fmindex_collection_amd as fm
+from fmindex_collection_amd import datasets
+dev = torch.device("cuda", 0)
+lengths = [2_500_000, 1_200_000, 300_000]
+text, _ = datasets.genome_like_text(lengths, seed=11, device=dev)
+n = int(text.numel())
+seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)).to(dev)
+g = torch.Generator(device=dev); g.manual_seed(5)
+class V:
+    def __init__(self, t): self.t, self.ptr, self.nbytes = t, t.data_ptr(), t.numel() * t.element_size()
+out = []
+for wide in (0, 1):
+    with fm.options(lf_table=0, force_wide=wide):
+        gx = fm.BiFMIndex.from_sequences((V(text), V(seq_off)), 5, "IB16", 16)
+    for L in (101, 151):
+        nq = 150_000
+        starts = torch.randint(0, n - L, (nq,), generator=g, device=dev, dtype=torch.int64)
+        reads = text[starts[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
+        rows = torch.arange(nq, device=dev)
+        for k in range(2):
+            sel = rows[rows %% 3 > k]
+            p = torch.randint(0, L, (sel.numel(),), generator=g, device=dev)
+            reads[sel, p] = reads[sel, p] %% 4 + 1
+        hits, st = fm.search_ng26.search(gx, (reads.reshape(-1).cpu().numpy(), np.arange(nq + 1, dtype=np.uint64) * L), fm.search_scheme.h2(4, 0, 2), want_stats=True, capacity=1 << 25)
+        out.append((wide, L, len(hits), int(st.lf_steps), int(st.table_steps)))
+    gx.close()
+print("SLOTS", out)
+"""
+
+
+def test_lean_kernel_lds_slots_hold_the_frames_of_the_stack():
+    """k_scheme_lean reads the top and the bottom frame of a lane's stack from LDS slots that an LDS-DMA load refills; that the load has landed when a slot is read
+    rests on an ordering argument the compiler does not know (fmgpu_search.hip, "Order of the top-frame slot's accesses").  The development build (make DEV=1:
+    libfmgpu_dev.so) compares every slot it reads with the frame the write-through stack holds in HBM and counts the differences: zero over 600 k reads of a
+    repeat-structured text (deep stacks, hand-overs between lanes), 101 and 151 bp, 32- and 64-bit rows."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev_lib = os.path.join(root, "fmindex-collection_amd", "libfmgpu_dev.so")
+    if not os.path.exists(dev_lib):
+        pytest.skip("libfmgpu_dev.so is not built (make -C fmindex-collection_amd/csrc DEV=1)")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FMGPU_")}
+    env["FMGPU_LIBRARY"] = dev_lib
+    r = subprocess.run([sys.executable, "-c", _SLOT_PROBE % root], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "SLOTS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    got = eval(r.stdout.split("SLOTS", 1)[1].strip())
+    assert len(got) == 4 and all(hits > 100_000 and nodes > 10_000_000 and bad == 0 for _, _, hits, nodes, bad in got), got
+
+
 @pytest.mark.parametrize("layout,sigma,tables", [("IB16", 5, False), ("IB16", 5, True), ("WAVELET", 28, False), ("EPR16", 5, False), ("IB16", 256, False)])
 def test_packed_exact_intervals(layout, sigma, tables):
     """fmgpu_search_exact_packed: one word lb << 32 | len per query, equal to the two-array form on every kernel variant"""
@@ -1456,6 +1527,41 @@ def test_locate_reference_fixtures(fixture, bidir):
                 assert (int(seq[i]), int(pos[i]), int(steps[i])) == ox.locate(i)
 
 
+@pytest.mark.parametrize("layout", ["IB16", "EPRV2_16", "WAVELET"])
+def test_locate_csa_and_dense_vector_reference_fixtures(layout):
+    """suffixarray/checkCSA.cpp:9-81 — Hello$World$ at sampling rates 3, 4, 5, 8: the rows the reference samples answer its (sequence, position) in zero steps and
+    every other row walks to the position its suffix-array entry names; checkDenseVector.cpp:8-82 / checkDenseMultiVector.cpp:8-89 — the value arrays of those tests
+    (greatest common divisors 1, 2 and 5: DenseVector.h:154-182's scaling) as the two fields of a SparseArray, read back by fmgpu_locate"""
+    g = REF["csa"]
+    seqs = [np.array(s_, dtype=np.uint8) for s_ in g["sequences"]]
+    text = np.concatenate([np.concatenate([s_, [0]]) for s_ in seqs]).astype(np.uint8)
+    sa = np.array(g["sa"], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum([len(s_) + 1 for s_ in seqs])])
+    seq_of = np.searchsorted(starts, sa, side="right") - 1
+    pos_of = sa - starts[seq_of]
+    bwt = text[(sa - 1) % len(text)]
+    rows = np.arange(len(sa), dtype=np.uint64)
+    for rate, expected in g["sampling"].items():
+        has = (pos_of % int(rate) == 0).astype(np.uint8)
+        ox = fo.OraIndex.from_bwt(layout, g["sigma"], bwt, None, has, seq_of.astype(np.uint64), pos_of.astype(np.uint64))
+        gx = gpu_index(ox)
+        for sel in (0, capi.SEL_LOCATE_PER_LANE):
+            with fm.options(kernel_select=sel):
+                seq, pos, steps = gx.locate(rows)
+            for r, s_, p_ in expected:
+                assert (int(seq[r]), int(pos[r]), int(steps[r])) == (s_, p_, 0), (rate, r)
+            assert np.array_equal(seq, seq_of.astype(np.uint64)) and np.array_equal(pos + steps, pos_of.astype(np.uint64)), rate
+            assert [(int(a), int(b), int(c)) for a, b, c in zip(seq, pos, steps)] == [ox.locate(int(r)) for r in rows]
+    for which in ("dense_vector", "dense_multi_vector"):
+        cases = REF[which]["cases"]
+        for a, b in ((cases[0]["inputs"][0], cases[1]["inputs"][0]), (cases[2]["inputs"][0], cases[1]["inputs"][0]), (cases[5]["inputs"][0], cases[5]["inputs"][1])):
+            assert len(a) == len(b) == len(sa)                    # 12 values each: one per row of the 12-row index above, every row sampled
+            ox = fo.OraIndex.from_bwt(layout, g["sigma"], bwt, None, np.ones(len(sa), dtype=np.uint8), np.array(a, dtype=np.uint64), np.array(b, dtype=np.uint64))
+            gx = gpu_index(ox)
+            seq, pos, steps = gx.locate(rows)
+            assert seq.tolist() == a and pos.tolist() == b and not steps.any(), which
+
+
 @pytest.mark.parametrize("layout", ["IB16", "IBP16", "EPR16", "EPRV2_16", "WAVELET"])
 @pytest.mark.parametrize("rate", [1, 3, 16, 64])
 def test_locate_random(layout, rate):
@@ -1703,6 +1809,39 @@ def test_index_file_round_trip(layout, sigma, bidir, tmp_path):
         with pytest.raises(fm.FmgpuError) as e:
             fm.FMIndex.load(bad)
         assert e.value.code == capi.FMGPU_ERR_INVALID, name
+    # a device-to-device copy of the handle with its tables (fmgpu_index_clone: what the replica set is made with) answers the same
+    cx = gx.clone()
+    assert abs(cx.device_bytes - gx.device_bytes) < 4096 and cx.formats == gx.formats and same(answers(cx), want)
+    cx.close()
+    # a description block that does not fit its own n / sigma / layouts — a stale or hand-edited file whose (unkeyed) checksum was recomputed — is refused before
+    # anything is allocated: one size field each of the block table, the sampled suffix array, C, the interval table, and n itself
+    import struct
+    M64 = (1 << 64) - 1
+
+    def mix(h, data):
+        for i in range(0, len(data), 8):
+            w = int.from_bytes(data[i:i + 8].ljust(8, b"\0"), "little")
+            h = ((h ^ w) * 0x9e3779b97f4a7c15) & M64
+            h ^= h >> 29
+        return h
+    tb = bytearray(open(f2, "rb").read())
+    meta_bytes, meta_sum = struct.unpack_from("<QQ", tb, 24)
+    assert mix(0x13198a2e03707344, bytes(tb[64:64 + meta_bytes])) == meta_sum      # (the test's restatement of the checksum is the library's)
+    str0 = 64 + 8 + 16 + 258 * 8 + 5 * 8 + 64 + 4 * 8 + 8                            # offset of SavedIndex::str[0] (n, 4 ints, hC, sa_bytes, ViewSA, 4 sizes, lut_len + reserved)
+    head0 = struct.unpack_from("<iiiiQ", tb, str0)                                   # layout, family, sigma, bitct, n of the bwt
+    assert (head0[2], head0[4]) == (sigma, gx.n)
+    edits = {"n": (64, lambda v: v + 64), "sa_bits_bytes": (64 + 8 + 16 + 258 * 8 + 2 * 8, lambda v: v // 2), "C_bytes": (64 + 8 + 16 + 258 * 8 + 5 * 8 + 64, lambda v: v + 8),
+             "blk_bytes": (str0 + 24, lambda v: v // 2), "slut_bytes": (str0 + 24 + 6 * 8, lambda v: v * 2)}
+    for name, (at, change) in edits.items():
+        t2 = bytearray(tb)
+        (v,) = struct.unpack_from("<Q", t2, at)
+        struct.pack_into("<Q", t2, at, change(v))
+        struct.pack_into("<Q", t2, 32, mix(0x13198a2e03707344, bytes(t2[64:64 + meta_bytes])))
+        bad = str(tmp_path / ("edited_" + name + ".fmgpu"))
+        open(bad, "wb").write(bytes(t2))
+        with pytest.raises(fm.FmgpuError) as e:
+            fm.FMIndex.load(bad)
+        assert e.value.code == capi.FMGPU_ERR_INVALID and "description block" in str(e.value), (name, str(e.value))
     if layout == "IB16" and sigma == 5 and bidir:                 # 64-bit rows: its own file, refused by nothing but read by the wide build
         fm.options["force_wide"] = "1"
         try:
@@ -1733,6 +1872,7 @@ def test_replicas_shard_a_batch_over_devices(tmp_path):
     for devices in ([0], [0, 0], [0, 0, 0], None):
         r = fm.Replicas.load(path, devices)
         assert r.devices == (devices if devices else list(range(fm.device_count())))
+        assert r.peer_copies == len(r.devices) - 1               # the file was read once: every other replica is a device-to-device copy of the first
         lb, ln, st = r.search_exact((qbuf, qoff), want_stats=True)
         assert np.array_equal(lb, olb) and np.array_equal(ln, oln) and st.lf_steps == int(ost.sum())
         hits, st = r.search_scheme((qbuf, qoff), sch, want_stats=True)
@@ -1876,6 +2016,69 @@ def _oracle_from_built(gx, bidir, sigma=5, layout="IB16", threads=None):
 
 def _sorted_records(hits):
     return hits[np.lexsort((hits["seq"], hits["qidx"]))]
+
+
+def test_full_size_exact_records_equal_the_cpu_walk():
+    """BASELINE.json configs[1] at full index size on the repeat-structured text (what bench.py's headline runs): 200 k reads of 101 bp cut from the text, every
+    tenth with one substitution — the interval, the row of a miss and the step count of every read from the two-symbol-step kernel (k_exact_p), from the same kernel
+    behind a 12-symbol interval table, from the one-symbol kernel (k_exact_a) and from the CPU walk over the GPU-built BWT are equal; and, an anchor that does not
+    pass through that BWT: every unchanged read that lies inside one sequence is found at the text offset it was cut from (locate of its interval)."""
+    torch = pytest.importorskip("torch")
+    from fmindex_collection_amd import datasets
+    import bench
+    dev = torch.device("cuda", 0)
+    lengths = list(bench.GRCH38_LENGTHS)
+    text, stats = datasets.genome_like_text(lengths, seed=42, device=dev)
+    n = int(text.numel())
+    seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64))])).to(dev)
+    g = torch.Generator(device=dev); g.manual_seed(23)
+    L, nq = 101, 200_000
+    starts = torch.randint(0, n - L, (nq,), generator=g, device=dev, dtype=torch.int64)
+    reads = text[starts[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
+    sel = torch.arange(0, nq, 10, device=dev)
+    p = torch.randint(0, L, (sel.numel(),), generator=g, device=dev)
+    reads[sel, p] = reads[sel, p] % 4 + 1
+    hq, ho = reads.reshape(-1).cpu().numpy(), np.arange(nq + 1, dtype=np.uint64) * L
+    org = starts.cpu().numpy()
+    with fm.options(lf_table=0):
+        gx = fm.FMIndex.from_sequences((_V(text), _V(seq_off)), 5, "IB16", 16, keep_host=True)
+    del text, reads
+    assert bool(gx.formats & capi.FMT_PAIRS) and bool(gx.formats & capi.FMT_FUSED)
+    ox = _oracle_from_built(gx, False)
+    olb, oln, ost = ox.search_exact(hq, ho, want_steps=True, nthreads=len(os.sched_getaffinity(0)))
+    assert int((oln == 0).sum()) > nq // 20                      # (most of the changed reads miss: the rows and step counts of misses are compared too)
+
+    def check(tag, sel_bits=0):
+        with fm.options(kernel_select=sel_bits):
+            lb, ln, st = fm.search_no_errors.search(gx, (hq, ho), want_stats=True)
+        assert np.array_equal(ln, oln) and np.array_equal(lb, olb) and st.lf_steps == int(ost.sum()), tag
+        return st
+    check("pair steps")
+    check("one-symbol steps", capi.SEL_EXACT_ONE_SYMBOL)
+    # the text-side anchor: unchanged reads inside one sequence, intervals of at most 4096 rows
+    seq_off_h = seq_off.cpu().numpy()
+    unchanged = np.ones(nq, dtype=bool); unchanged[::10] = False
+    inside = seq_off_h[np.searchsorted(seq_off_h, org, side="right")] >= org + L
+    use = np.nonzero(unchanged & inside & (oln > 0) & (oln <= 4096))[0][:30_000]
+    cnt = oln[use].astype(np.int64)
+    owner = np.repeat(np.arange(use.size), cnt)
+    rows = np.repeat(olb[use].astype(np.int64), cnt) + (np.arange(owner.size) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    seq, pos, steps = gx.locate(rows.astype(np.uint64))
+    tpos = seq_off_h[seq.astype(np.int64)] + pos.astype(np.int64) + steps.astype(np.int64)
+    found = np.zeros(use.size, dtype=bool)
+    np.logical_or.at(found, owner, tpos == org[use][owner])
+    assert use.size > 20_000 and bool(found.all()), (int(use.size), int((~found).sum()))
+    with fm.options(kernel_select=capi.SEL_LOCATE_PER_LANE):     # (the one-row-per-lane locate kernel agrees)
+        seq1, pos1, steps1 = gx.locate(rows[:200_000].astype(np.uint64))
+    assert np.array_equal(seq1, seq[:200_000]) and np.array_equal(pos1, pos[:200_000]) and np.array_equal(steps1, steps[:200_000])
+    # the same search behind the 12-symbol interval table (134 MB): results and step counts unchanged, 12 steps per read served by one entry
+    before = gx.device_bytes
+    gx.accelerate(1, lut_len=12, walk=0)
+    assert gx.device_bytes - before == 4 ** 12 * 8
+    st = check("interval table + pair steps")
+    assert st.table_steps > 0.95 * 12 * nq and st.table_steps % 12 == 0
+    check("interval table, table-driven kernel", capi.SEL_NO_EXACT_LUT)
+    gx.close()
 
 
 def test_full_size_k2_records_equal_the_cpu_walk():

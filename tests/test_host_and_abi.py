@@ -267,3 +267,39 @@ def test_options_are_set_through_the_abi_not_the_environment(monkeypatch):
     import re
     outside_dev = re.sub(r"#ifdef FMGPU_DEV\b.*?#e(?:lse|ndif)", "", src, flags=re.S)
     assert "getenv" not in outside_dev
+
+
+def test_scheme_mirror_against_the_reference_tests_own_values():
+    """search_scheme/nodeCount.cpp:13-34, weightedNodeCount.cpp:13-45, isValid.cpp:10-65, isComplete.cpp:10-35, checkGenerators.cpp:21-132 through the Python
+    mirror of the reference's search_scheme functions (the values are the reference tests' own: tests/golden/reference_tests.json)"""
+    import numpy as np
+    from fmindex_collection_amd import search_scheme as ss
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_tests.json")))
+    g = ref["node_count"]
+    for n in list(range(1, 40)) + list(range(40, g["zero_errors"]["n_to"] + 1, 37)):
+        assert ss.nodeCount(ss.backtracking(n, 0, 0), g["sigma"]) == n == ss.nodeCount(ss.expand(ss.backtracking(1, 0, 0), n), g["sigma"])
+    for count, N, minK, K, sigma in g["known"]:
+        assert ss.nodeCount(ss.backtracking(N, minK, K), sigma) == count
+    w = ref["weighted_node_count"]
+    for n in range(1, w["exact_below"]):
+        assert ss.weightedNodeCount(ss.backtracking(n, 0, 0), w["sigma"], w["N"]) == n == ss.weightedNodeCount(ss.expand(ss.backtracking(1, 0, 0), n), w["sigma"], w["N"])
+    for n in list(range(w["bounded"]["n_from"], 60)) + list(range(60, w["bounded"]["n_to"] + 1, 53)):
+        assert ss.weightedNodeCount(ss.backtracking(n, 0, 0), w["sigma"], w["N"]) < w["bounded"]["below"]
+        assert ss.weightedNodeCount(ss.expand(ss.backtracking(1, 0, 0), n), w["sigma"], w["N"]) < w["bounded"]["below"]
+    for count, N, minK, K, sigma, size in w["known"]:
+        assert ss.weightedNodeCount(ss.backtracking(N, minK, K), sigma, size) == count
+    as_scheme = lambda c: tuple(np.array([c[k]], dtype=np.uint64) for k in ("pi", "l", "u"))
+    for c in ref["is_valid"]["cases"]:
+        assert bool(ss.isValid(as_scheme(c))) == c["expected"], c
+    for c in ref["is_complete"]["cases"]:
+        assert bool(ss.isComplete(as_scheme(c), *c["args"])) == c["expected"], c
+    for N in range(1, 20):
+        for minK in range(0, 10):
+            for maxK in range(minK, 10):
+                assert ss.isValid(ss.backtracking(N, minK, maxK))
+        for minK in range(0, min(N, 10)):
+            for maxK in range(minK, min(N, 10)):
+                assert ss.isValid(ss.h2(N, minK, maxK))
+    for minK in range(0, 20):
+        for maxK in range(minK, 20):
+            assert ss.isValid(ss.pigeon_trivial(minK, maxK)) and ss.isValid(ss.pigeon_opt(minK, maxK))

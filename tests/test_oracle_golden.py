@@ -546,3 +546,99 @@ def test_suffix_array_and_bwt_small():
     assert fo.lib().ora_suffix_array(fo._p8(text), len(text), fo._p64(sa)) == 0
     naive = sorted(range(len(text)), key=lambda i: bytes(text[i:].tolist()))
     assert sa.tolist() == naive
+
+
+# ------------------------------------------------------------------------------------------------ the sampled suffix array's parts, from the reference's own tests
+@pytest.mark.parametrize("which", ["dense_vector", "dense_multi_vector"])
+def test_dense_vector_reference_cases(which):
+    """checkDenseVector.cpp:8-82, checkDenseMultiVector.cpp:8-89 — every value reads back, for vectors made from a list (largest value and gcd taken from the
+    values), with a given largest value and divisor + push_back, and by concat (divisor = gcd of both sides': 5 where the test asserts it)"""
+    for c in REF[which]["cases"]:
+        if c["concat"]:
+            left, right = fo.OraDenseVector(c["inputs"][0]), fo.OraDenseVector(c["inputs"][1])
+            v = fo.OraDenseVector.concat(left, right)
+            want = c["inputs"][0] + c["inputs"][1]
+        elif "largest_divisor" in c:
+            v = fo.OraDenseVector(c["inputs"][0], *c["largest_divisor"])
+            want = c["inputs"][0]
+            assert v.common_divisor == c["largest_divisor"][1] and v.bits == (c["largest_divisor"][0] // c["largest_divisor"][1]).bit_length()
+        else:
+            v = fo.OraDenseVector(c["inputs"][0])
+            want = c["inputs"][0]
+            assert v.common_divisor == int(np.gcd.reduce(np.array(want, dtype=np.int64))) and v.bits == (max(want) // v.common_divisor).bit_length()
+        assert len(v) == len(want) and [v[i] for i in range(len(want))] == want, c["name"]
+        if "common_divisor" in c:
+            assert v.common_divisor == c["common_divisor"], c["name"]
+    # the same values as the two fields of a SparseArray (what an index holds): every second row carries (a, b)
+    a, b = REF[which]["cases"][1]["inputs"][0], REF[which]["cases"][2]["inputs"][0]
+    has = np.zeros(2 * len(a), dtype=np.uint8); has[::2] = 1
+    sp = fo.OraSparse(has, np.repeat(a, 2), np.repeat(b, 2))
+    assert [sp.value(2 * i) for i in range(len(a))] == list(zip(a, b)) and all(sp.value(2 * i + 1) is None for i in range(len(a)))
+
+
+def test_bitvector2l_reference_vectors():
+    """bitvector/unittest.cpp:14-140 (run there over Bitvector2L_512_64k, the presence bitvector of the sampled suffix array): symbol and rank of the 14-bit text,
+    rank at every checked index of the 512-bit text (rank(512) is the first to read an L1 counter other than block 0's)"""
+    g = REF["bitvector"]
+    sp = fo.OraSparse(g["short"]["bits"])
+    for i, v in g["short"]["symbol"]:
+        assert (sp.value(i) is not None) == bool(v)
+    for i, v in g["short"]["rank"]:
+        assert sp.rank(i) == v, i
+    bits = g["long"]["bits"]
+    sp = fo.OraSparse(bits + [0] * 8)                               # (rank(512) needs a 513th position: the reference's Bitvector2L always holds one more block)
+    assert len(bits) == 512 and len(g["long"]["rank"]) == 32 * 17
+    for i, v in enumerate(bits):
+        assert (sp.value(i) is not None) == bool(v)
+    for i, v in g["long"]["rank"]:
+        assert sp.rank(i) == v, i
+
+
+def test_csa_reference_vectors():
+    """suffixarray/checkCSA.cpp:9-81: the suffix array of Hello$World$ and, for sampling rates 3, 4, 5 and 8, which rows carry a value and the (sequence,
+    position) they answer — through the oracle's suffix sorter, its SparseArray and the LF walk of locate for the rows in between"""
+    g = REF["csa"]
+    seqs = [np.array(s_, dtype=np.uint8) for s_ in g["sequences"]]
+    text = np.concatenate([np.concatenate([s_, [0]]) for s_ in seqs]).astype(np.uint8)
+    sa = np.zeros(len(text), dtype=np.uint64)
+    assert fo.lib().ora_suffix_array(fo._p8(text), len(text), fo._p64(sa)) == 0 and sa.tolist() == g["sa"]
+    starts = np.concatenate([[0], np.cumsum([len(s_) + 1 for s_ in seqs])])
+    seq_of = np.searchsorted(starts, sa, side="right") - 1
+    pos_of = sa - starts[seq_of]
+    bwt = text[(sa.astype(np.int64) - 1) % len(text)]
+    for rate, rows in g["sampling"].items():
+        has = (pos_of % int(rate) == 0).astype(np.uint8)
+        assert sorted(r for r, _, _ in rows) == np.nonzero(has)[0].tolist(), rate      # the reference samples exactly the rows whose position is a multiple of the rate
+        sp = fo.OraSparse(has, seq_of, pos_of)
+        for r, s_, p_ in rows:
+            assert sp.value(r) == (s_, p_), (rate, r)
+        x = fo.OraIndex.from_bwt("IB16", g["sigma"], bwt, None, has, seq_of.astype(np.uint64), pos_of.astype(np.uint64))
+        for r in range(len(sa)):
+            s_, p_, st = x.locate(r)
+            assert (s_, p_ + st) == (int(seq_of[r]), int(pos_of[r])), (rate, r)
+
+
+def test_scheme_counts_and_validity_reference_cases():
+    """search_scheme/nodeCount.cpp:13-34, isValid.cpp:10-65, isComplete.cpp:10-35, checkGenerators.cpp:21-132 through the oracle's restatements"""
+    g = REF["node_count"]
+    for n in range(g["zero_errors"]["n_from"], g["zero_errors"]["n_to"] + 1, 7):
+        assert fo.scheme_node_count_hamming(fo.scheme_backtracking(n, 0, 0), g["sigma"]) == n
+        assert fo.scheme_node_count_hamming(fo.scheme_expand(fo.scheme_backtracking(1, 0, 0), n), g["sigma"]) == n
+    for count, N, minK, K, sigma in g["known"]:
+        assert fo.scheme_node_count_hamming(fo.scheme_backtracking(N, minK, K), sigma) == count
+    as_scheme = lambda c: tuple(np.array([c[k]], dtype=np.uint64) for k in ("pi", "l", "u"))
+    for c in REF["is_valid"]["cases"]:
+        assert bool(fo.scheme_is_valid(as_scheme(c))) == c["expected"], c
+    for c in REF["is_complete"]["cases"]:
+        assert bool(fo.scheme_is_complete(as_scheme(c), *c["args"])) == c["expected"], c
+    gv = REF["generators_valid"]
+    for N in range(gv["backtracking"]["N"][0], gv["backtracking"]["N"][1] + 1):
+        for minK in range(0, 10):
+            for maxK in range(minK, 10):
+                assert fo.scheme_is_valid(fo.scheme_backtracking(N, minK, maxK))
+        for minK in range(0, min(N, 10)):
+            for maxK in range(minK, min(N, 10)):
+                assert fo.scheme_is_valid(fo.scheme_h2(N, minK, maxK)), (N, minK, maxK)
+    for minK in range(0, 20):
+        for maxK in range(minK, 20):
+            assert fo.scheme_is_valid(fo.scheme_pigeon_trivial(minK, maxK)) and fo.scheme_is_valid(fo.scheme_pigeon_opt(minK, maxK))
