@@ -159,7 +159,7 @@ def main():
     c.smi = Smi(local_rank)
     c.only = set(x for x in args.only.split(",") if x)
     c.traffic = {}
-    for tf in ("r03_traffic.json", "r02_traffic.json"):           # per-launch HBM bytes from the committed rocprofv3 --pmc passes (replayed, labelled so)
+    for tf in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):           # per-launch HBM bytes from the committed rocprofv3 --pmc passes (replayed, labelled so)
         try:
             c.traffic = json.load(open(os.path.join(ROOT, "profiles", tf)))
             c.traffic_file = "profiles/" + tf
@@ -356,6 +356,15 @@ def timed(c, step, drain=None):
     """W warm-up steps, then exactly K steps between barrier + synchronize on both sides; returns (seconds [max over ranks], per-step stats)"""
     torch, args = c.torch, c.args
     log = []
+    if not getattr(c, "spun_up", False):                          # the first measurement of the process: the card's clocks ramp up over the first few hundred ms of load
+        c.spun_up = True                                          # (r4: the first record ran at sclk 2243 MHz where later ones ran at 2350-2390) — untimed, before the W warm-up steps
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.5:
+            step(log)
+            torch.cuda.synchronize()
+        if drain:
+            drain()
+        log.clear()
     for _ in range(args.warmup):
         step(log)
     if drain:
@@ -400,8 +409,14 @@ class Smi:
                     break
             except OSError:
                 continue
-        self.cap_w = None
+        self.cap_w, self.card = None, None
         if self.lib is not None:
+            uid = C.c_uint64()
+            try:
+                if self.lib.rsmi_dev_unique_id_get(C.c_uint32(dev), C.byref(uid)) == 0:
+                    self.card = "%016x" % uid.value                # (which card of the pool ran this: the same kernel differs by a few percent between cards)
+            except Exception:
+                pass
             cap = C.c_uint64()
             try:
                 if self.lib.rsmi_dev_power_cap_get(C.c_uint32(dev), C.c_uint32(0), C.byref(cap)) == 0:
@@ -412,13 +427,13 @@ class Smi:
     def _read(self):
         import ctypes as C
         out = []
-        for clk in (0, 4):                                        # RSMI_CLK_TYPE_SYS, RSMI_CLK_TYPE_MEM
+        for clk in (0, 4, 1):                                     # RSMI_CLK_TYPE_SYS, RSMI_CLK_TYPE_MEM, RSMI_CLK_TYPE_DF (the fabric)
             f = Smi._Freq()
             ok = self.lib.rsmi_dev_gpu_clk_freq_get(C.c_uint32(self.dev), C.c_int(clk), C.byref(f)) == 0 and f.current < 33
             out.append(f.frequency[f.current] / 1e6 if ok else None)
         pw = C.c_uint64()
-        out.append(pw.value / 1e6 if self.lib.rsmi_dev_current_socket_power_get(C.c_uint32(self.dev), C.byref(pw)) == 0 else None)
-        return out
+        out.insert(2, pw.value / 1e6 if self.lib.rsmi_dev_current_socket_power_get(C.c_uint32(self.dev), C.byref(pw)) == 0 else None)
+        return out                                                # [sclk, mclk, power, fclk]
 
     def start(self):
         if self.lib is None:
@@ -443,11 +458,12 @@ class Smi:
         self.thread.join(timeout=1.0)
         self.thread = None
         col = lambda k: [x[k] for x in self.samples if x[k] is not None]
-        sc, mc, pw = col(0), col(1), col(2)
+        sc, mc, pw, fc = col(0), col(1), col(2), col(3)
         if not sc:
             return None
         return {"sclk_mhz_mean": round(sum(sc) / len(sc)), "sclk_mhz_min": round(min(sc)), "sclk_mhz_max": round(max(sc)), "mclk_mhz": round(sum(mc) / len(mc)) if mc else None,
-                "socket_power_w_mean": round(sum(pw) / len(pw)) if pw else None, "power_cap_w": self.cap_w, "samples": len(sc),
+                "fclk_mhz": round(sum(fc) / len(fc)) if fc else None, "socket_power_w_mean": round(sum(pw) / len(pw)) if pw else None, "power_cap_w": self.cap_w, "samples": len(sc),
+                "card": self.card,
                 "what": "rocm_smi readings of the card during the timed steps of this record (2 ms apart)"}
 
 

@@ -2331,7 +2331,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
 // further error" as 0x4000, an edge that follows the match child as (2, 255 - depth, child index): a deeper one is met earlier on the way
 // back up.  depth = query symbols consumed + deletions made.  Layout: search:4 | 3 x 16 bits; it travels like the Hamming key (the low
 // 32 bits in fmgpu_hit::seq, the rest in the upper 24 bits of fmgpu_hit::errors) until fmgpu_hits_sort turns it into the callback index.
-template <int SIGMA, int MAXSIG>
+template <int SIGMA, int MAXSIG, bool PLAIN = false>      // PLAIN: sigma = 5 and no LF table — known when the kernel is compiled, so that the table paths (and the scalar registers their pointers hold) are not in it
 __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
@@ -2340,6 +2340,15 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
     uint32_t* s_hb = s_steps + 2u * S * stride;                     // kWaveHitWords
+    // the TOP frame of every lane's stack lives in LDS (two 16-byte halves per lane) and reaches HBM only when another frame is pushed on top of it: a node with k
+    // viable children is popped and pushed back k - 1 times, and with write-through frames (round 3) these were 45 % of the kernel's memory requests.  A pop reads the
+    // slot and at once asks for the frame below it by LDS-DMA (global_load_lds: no register holds it), an iteration before it can be needed: the stack is off the
+    // dependent chain.  Invariants: the slot is valid iff sp > sbase; every frame below the top is in HBM; `tos_dirty`: the slot's frame is not (or is newer than) its HBM copy.
+    typedef uint32_t __attribute__((ext_vector_type(4))) e_u32x4;
+    typedef __attribute__((address_space(3))) e_u32x4 e_lds_u32x4;
+    e_lds_u32x4* const s_tos0 = (e_lds_u32x4*)(s_dyn + (((size_t)qwords * 256u + 2u * S * stride + kWaveHitWords + 3u) & ~(size_t)3));     // (16-byte aligned)
+    e_lds_u32x4* const s_tos1 = s_tos0 + 256;
+    e_lds_u32x4* const tos0 = s_tos0 + threadIdx.x; e_lds_u32x4* const tos1 = s_tos1 + threadIdx.x;
     wave_ring_init(s_hb);
     const QStage qst{s_dyn, qwords, qnib};
     for (uint32_t i = threadIdx.x; i < 2u * S * stride; i += blockDim.x) s_steps[i] = fa.steps[i];
@@ -2368,6 +2377,16 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     bool in_tail = false, lf_known = false;
     idx_t lf_val = 0, cached_lf = 0, cached_lf2 = 0xffffffffu;
     uint32_t report_slot = kNoResume;
+#ifdef FMGPU_DEV
+    uint32_t dev_slot_bad = 0;
+#endif
+    bool tos_dirty = false, tos_pending = false;                    // tos_pending: a refill of the slot by LDS-DMA may still be in flight (settle() before the slot is touched)
+    // the refill was issued at the end of an earlier iteration; by the places that touch the slot every load of the current iteration has been consumed, so this
+    // wait is for that one transfer (and for frame spills / record flushes of the previous iteration)
+    auto settle = [&]() {
+        if (__ballot(tos_pending)) { __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); }
+        tos_pending = false;
+    };
     for (;;) {
         // ---- wave-synchronous part: every lane passes here in every iteration
         if (sharing) {
@@ -2382,8 +2401,10 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
                 uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0;
                 uint64_t gk = 0;
+                if (__ballot(give && sbase + 1u == sp)) settle();   // (a bottom frame that is also the top frame is in the slot)
                 if (give) {
-                    g0 = frames[2u * sbase]; g1 = frames[2u * sbase + 1u];
+                    if (sbase + 1u == sp) { const e_u32x4 u0 = *tos0, u1 = *tos1; g0 = make_uint4(u0.x, u0.y, u0.z, u0.w); g1 = make_uint4(u1.x, u1.y, u1.z, u1.w); tos_dirty = false; }
+                    else { g0 = frames[2u * sbase]; g1 = frames[2u * sbase + 1u]; }
                     gk = ekey_prefix(pkey, (g0.w >> 16) & 0xffu);
                     ++sbase; mark = nodes;
                 }
@@ -2406,6 +2427,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                     for (uint32_t w = 0; w < qwords; ++w) s_dyn[w * 256u + threadIdx.x] = s_dyn[w * 256u + vt];     // the partner's staged read
                     have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
                     tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; lf_known = false; report_slot = kNoResume; mark = nodes; nodes0 = nodes;
+                    tos_dirty = false;
                 }
             }
         }
@@ -2437,7 +2459,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
             need_start = false;
             tab = s_steps + si * stride;
             cur = Cur{0, 0, n}; e = 0; j = 0; sp = 0; sbase = 0; resume = kNoResume; side = 0; info = 0; ndel = 0;
-            in_tail = false; lf_known = false; cached_lf = 0; cached_lf2 = 0xffffffffu; report_slot = kNoResume;
+            in_tail = false; lf_known = false; cached_lf = 0; cached_lf2 = 0xffffffffu; report_slot = kNoResume; tos_dirty = false;
             pkey = ((uint64_t)si << 48) | kEditKeyNone;
             if (fa.lut && ((fa.lut_ok >> si) & 1u) && n > 1) {      // the always-exact first part starts from the prefix table
                 uint32_t code = 0, mul = 1; bool valid = true;
@@ -2470,7 +2492,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
         constexpr bool kSplit = SIGMA > 0 && SIGMA <= 5;
         const uint8_t* blk = (right ? rv : fw).v.blk;
         // (the plain index — no LF table, sigma = 5: a one-row node reads its row's symbol and LF off the row's block, like a multi-row node reads its counts)
-        const bool plain = kSplit && fa.lf_fw == nullptr;
+        constexpr bool plain = PLAIN && kSplit;
         const uint8_t* p0 = lut_start ? reinterpret_cast<const uint8_t*>(fa.lut + lut_code)
                           : ((multi && kSplit) || plain) ? blk + (size_t)(a >> 6) * 64u
                           : reinterpret_cast<const uint8_t*>((right ? fa.lf_rv : fa.lf_fw) + a);
@@ -2515,7 +2537,9 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                             if ((bits >> bit) & 1ull) lf1 = dd[3 * s_] + popc64(bits & lowmask(bit));
                         }
                     }
-                    if (report_slot != kNoResume) reinterpret_cast<uint32_t*>(frames + 2u * report_slot)[2] = lf1;
+                    // (the parent that waits for this row's LF was pushed in the previous iteration: it is the top frame, in its slot)
+                    if (__ballot(report_slot != kNoResume)) settle();
+                    if (report_slot != kNoResume) { e_u32x4 u0 = *tos0; u0.z = (uint32_t)lf1; *tos0 = u0; }
                 }
                 alive.clear(); alive.insert(symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, lf1));
             }
@@ -2570,10 +2594,17 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 code = idx == kNoResume ? 0u : idx;
             }
             nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + (start_tail ? 1u : 0u))));
-            if (kind != 4u && nxt != kNoResume) {                   // keep the parent: its remaining children start at nxt
-                uint4* f = frames + 2u * sp;
-                f[0] = make_uint4(cur.lb, cur.lbRev, multi ? cur.len : 0xffffffffu, (j & 0xffffu) | ((e & 0xffu) << 16) | ((multi ? 0u : 1u) << 24) | (info << 25));
-                f[1] = make_uint4(nxt, side, lf1, ndel);
+            const bool keep = kind != 4u && nxt != kNoResume;
+            if (__ballot(keep || kind == 4u)) settle();             // (the slot is touched below: by a push, or by the pop of a lane that goes back)
+            if (keep) {                                             // keep the parent: its remaining children start at nxt
+                if (sp > sbase && tos_dirty) {                      // the frame the slot holds is buried now: to HBM
+                    const e_u32x4 u0 = *tos0, u1 = *tos1;
+                    uint4* f = frames + 2u * (sp - 1u);
+                    f[0] = make_uint4(u0.x, u0.y, u0.z, u0.w); f[1] = make_uint4(u1.x, u1.y, u1.z, u1.w);
+                }
+                const e_u32x4 n0 = {(uint32_t)cur.lb, (uint32_t)cur.lbRev, multi ? (uint32_t)cur.len : 0xffffffffu, (j & 0xffffu) | ((e & 0xffu) << 16) | ((multi ? 0u : 1u) << 24) | (info << 25)};
+                const e_u32x4 n1 = {nxt, side, (uint32_t)lf1, ndel};
+                *tos0 = n0; *tos1 = n1; tos_dirty = true;
                 if (!multi && nxt == 2u && (kind == 0u || kind == 1u)) report_slot = sp;
                 ++sp;
             }
@@ -2622,8 +2653,21 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 if (sp == sbase) search_over = true;
                 else {
                     --sp;
-                    const uint4* f = frames + 2u * sp;
-                    const uint4 a0 = f[0], a1 = f[1];
+                    asm volatile("" ::: "memory");                  // (the slot is read here, not ahead of the branch)
+                    const e_u32x4 a0 = *tos0, a1 = *tos1;           // the top frame, from its slot ...
+#ifdef FMGPU_DEV
+                    if (!tos_dirty) {                               // dev build: a clean slot holds what HBM holds
+                        const uint4 h0 = frames[2u * sp], h1 = frames[2u * sp + 1u];
+                        if (h0.x != a0.x || h0.y != a0.y || h0.z != a0.z || h0.w != a0.w || h1.x != a1.x || h1.y != a1.y || h1.z != a1.z || h1.w != a1.w) ++dev_slot_bad;
+                    }
+#endif
+                    if (sp > sbase) {                               // ... and the one below it, requested an iteration before it can be needed, straight into the slot
+                        const uint4* below = frames + 2u * (sp - 1u);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)below, (__attribute__((address_space(3))) void*)(s_tos0 + (threadIdx.x & ~63u)), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(below + 1), (__attribute__((address_space(3))) void*)(s_tos1 + (threadIdx.x & ~63u)), 16, 0, 0);
+                        tos_pending = true;
+                    }
+                    tos_dirty = false;
                     const bool one_row = (a0.w >> 24) & 1u;
                     cur.lb = a0.x; cur.lbRev = a0.y; cur.len = one_row ? 1u : a0.z; cached_lf2 = one_row ? a0.z : 0xffffffffu;
                     j = a0.w & 0xffffu; e = (a0.w >> 16) & 0xffu; info = (a0.w >> 25) & 15u;
@@ -2645,6 +2689,9 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
         atomicAdd(&ctr->nodes, (unsigned long long)tot);
         if (co) atomicAdd(&ctr->hits, (unsigned long long)co);
     }
+#ifdef FMGPU_DEV
+    { const uint32_t bad = wave_sum(dev_slot_bad); if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(reinterpret_cast<unsigned long long*>(ctr) + 20, (unsigned long long)bad); }
+#endif
 }
 
 #endif  // !FMGPU_WIDE (the table-driven kernels)
@@ -4059,7 +4106,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (fast && edit) {
         size_t max_tab = 0;
         for (const Bucket& b : buckets) max_tab = std::max(max_tab, b.tab.size());
-        const size_t lds_fast = lds_bytes + max_tab * 4 + (size_t)kWaveHitWords * 4;
+        const size_t lds_fast = lds_bytes + max_tab * 4 + (size_t)kWaveHitWords * 4 + 2 * 256 * 16 + 16;      // (+ the top frames of the edit kernel's stacks)
         const auto key = std::make_tuple(-1, x->bwt.sigma, 3, lds_fast);
         bool known = false;
         { std::lock_guard<std::mutex> g(occ_mu); auto it = occ_cache.find(key); if (it != occ_cache.end()) { bpc = it->second; known = true; } }
@@ -4145,15 +4192,17 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             if (use_wj) { fa.wj_fw = x->bwt.walkj; fa.wj_rv = x->rev.walkj; }
             fa.lut = b.lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = b.lut_ok;
             for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
-            const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (size_t)kWaveHitWords * 4;
+            const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (size_t)kWaveHitWords * 4 + (edit ? 2 * 256 * 16 + 16 : 0);     // (edit distance: + the top frames of the stacks)
             const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ws.grid, (b.count + 255) / 256)));
             FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));   // reads are handed out from 0
             const uint32_t* qm = d_qmap ? d_qmap + b.first : nullptr;
             if (edit) {
-                if (x->bwt.sigma == 5)
-                    k_scheme_fast_edit<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                if (x->bwt.sigma == 5) {
+                    if (!have_lf) k_scheme_fast_edit<5, 5, true><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                              b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
-                else
+                    else k_scheme_fast_edit<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
+                } else
                     k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                               b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
             } else if (lean) {

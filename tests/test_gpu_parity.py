@@ -1066,6 +1066,10 @@ for wide in (0, 1):
             reads[sel, p] = reads[sel, p] %% 4 + 1
         hits, st = fm.search_ng26.search(gx, (reads.reshape(-1).cpu().numpy(), np.arange(nq + 1, dtype=np.uint64) * L), fm.search_scheme.h2(4, 0, 2), want_stats=True, capacity=1 << 25)
         out.append((wide, L, len(hits), int(st.lf_steps), int(st.table_steps)))
+        if not wide and L == 101:                                 # the edit-distance kernel keeps its top frames in LDS slots too (write-back: a clean slot holds what HBM holds)
+            hq = reads[:60_000].reshape(-1).cpu().numpy()
+            ehits, est = fm.search_ng26.search(gx, (hq, np.arange(60_001, dtype=np.uint64) * L), fm.search_scheme.h2(4, 0, 2), want_stats=True, edit=True, capacity=1 << 25)
+            out.append((2, L, len(ehits), int(est.lf_steps), int(est.table_steps)))
     gx.close()
 print("SLOTS", out)
 """
@@ -1075,7 +1079,7 @@ def test_lean_kernel_lds_slots_hold_the_frames_of_the_stack():
     """k_scheme_lean reads the top and the bottom frame of a lane's stack from LDS slots that an LDS-DMA load refills; that the load has landed when a slot is read
     rests on an ordering argument the compiler does not know (fmgpu_search.hip, "Order of the top-frame slot's accesses").  The development build (make DEV=1:
     libfmgpu_dev.so) compares every slot it reads with the frame the write-through stack holds in HBM and counts the differences: zero over 600 k reads of a
-    repeat-structured text (deep stacks, hand-overs between lanes), 101 and 151 bp, 32- and 64-bit rows."""
+    repeat-structured text (deep stacks, hand-overs between lanes), 101 and 151 bp, 32- and 64-bit rows; k_scheme_fast_edit (edit distance, write-back slots) likewise."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1087,7 +1091,7 @@ def test_lean_kernel_lds_slots_hold_the_frames_of_the_stack():
     r = subprocess.run([sys.executable, "-c", _SLOT_PROBE % root], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "SLOTS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     got = eval(r.stdout.split("SLOTS", 1)[1].strip())
-    assert len(got) == 4 and all(hits > 100_000 and nodes > 10_000_000 and bad == 0 for _, _, hits, nodes, bad in got), got
+    assert len(got) == 5 and all(hits > 100_000 and nodes > 10_000_000 and bad == 0 for _, _, hits, nodes, bad in got), got
 
 
 @pytest.mark.parametrize("layout,sigma,tables", [("IB16", 5, False), ("IB16", 5, True), ("WAVELET", 28, False), ("EPR16", 5, False), ("IB16", 256, False)])

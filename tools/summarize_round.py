@@ -23,10 +23,16 @@ if "FETCH_SIZE" in c:
                                            "correction": "FETCH_SIZE x 2 (128-B requests tallied at 64 B on gfx950, confirmed by tools/membench.hip mode 1) + WRITE_SIZE"}
 try:
     res["bench_line"] = json.loads(open(d + "/bench_line.json").read())
+    if "hbm_traffic_bytes_per_launch" in res and "roofline" in res["bench_line"]:       # the line of the trace pass replayed an older figure: this profile's own counters replace it
+        rf = res["bench_line"]["roofline"]
+        rf["traffic"] = res["hbm_traffic_bytes_per_launch"]["corrected_bytes"]
+        rf["traffic_source"] = "this profile's own --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x 2 + WRITE_SIZE)"
+        if rf.get("kernel_ms"):
+            rf["frac_traffic"] = rf["traffic"] / (rf["kernel_ms"] * 1e-3) / 1e9 / rf.get("peak", 8000.0)
 except Exception:
     pass
 try:                                                             # the full records of the trace pass (bench.py writes them beside its compact line)
-    res["bench_records"] = [{k: r[k] for k in ("id", "value", "unit", "ms_per_step", "roofline", "hits") if k in r} for r in json.load(open(d + "/bench_records_trace.json"))["records"]]
+    res["bench_records"] = [{k: r[k] for k in ("id", "value", "unit", "ms_per_step", "roofline", "hits", "clocks") if k in r} for r in json.load(open(d + "/bench_records_trace.json"))["records"]]
 except Exception:
     pass
 json.dump(res, open(out, "w"), indent=1)
