@@ -358,10 +358,11 @@ def timed(c, step, drain=None):
     log = []
     if not getattr(c, "spun_up", False):                          # the first measurement of the process: the card's clocks ramp up over the first few hundred ms of load
         c.spun_up = True                                          # (r4: the first record ran at sclk 2243 MHz where later ones ran at 2350-2390) — untimed, before the W warm-up steps
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < 0.5:
+        t_spin, n_spin = time.perf_counter(), 0
+        while (n_spin < 8) if c.multi else (time.perf_counter() - t_spin < 0.5):      # (N > 1: the same number of steps on every rank — each step holds a collective)
             step(log)
             torch.cuda.synchronize()
+            n_spin += 1
         if drain:
             drain()
         log.clear()
@@ -578,7 +579,7 @@ def run_dna_text(c, name, primary):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
     legs = ["exact", "k2", "k2_151"]
-    ids = ["%s/%s/%s" % (name, w, i) for w in legs + ["locate"] for i in ("plain", "tables")] + ["%s/k2_edit/tables" % name, "%s/k2_edit/plain" % name, "%s/exact/single" % name, "%s/exact/plain+lut12" % name]
+    ids = ["%s/%s/%s" % (name, w, i) for w in legs + ["locate"] for i in ("plain", "tables")] + ["%s/%s/plain+lut12" % (name, w) for w in ("k2", "k2_151")] + ["%s/k2_edit/tables" % name, "%s/k2_edit/plain" % name, "%s/exact/single" % name, "%s/exact/plain+lut12" % name]
     if c.only and not any(i in c.only for i in ids):
         return []
     text, seq_off, lengths, tinfo = make_text(c, name)
@@ -779,7 +780,7 @@ def run_dna_text(c, name, primary):
     # ------------------------------------------------------------------ k = 2 Hamming, configs[2] (101 bp) and configs[3] (151 bp)
     scheme = fm.search_scheme.h2(4, 0, 2)
     k2_legs = [("k2", 101, nq if not c.multi else 0), ("k2_151", 151, (args.total_k2_reads // c.world) if c.multi else min(12_500_000, max(1, int(12_500_000 * min(1.0, nq / 10_000_000)))))]
-    k2_legs = [(w, L, n_) for (w, L, n_) in k2_legs if n_ > 0 and (any(wanted(c, "%s/%s/%s" % (name, w, i)) for i in ("plain", "tables"))
+    k2_legs = [(w, L, n_) for (w, L, n_) in k2_legs if n_ > 0 and (any(wanted(c, "%s/%s/%s" % (name, w, i)) for i in ("plain", "tables", "plain+lut12"))
                                                                     or (w == "k2" and args.with_edit and not c.multi and (wanted(c, "%s/k2_edit/tables" % name) or wanted(c, "%s/k2_edit/plain" % name))))]
     if k2_legs:
         fm.options["lf_table"] = 0
@@ -829,7 +830,7 @@ def run_dna_text(c, name, primary):
                 capi.check(capi.lib().fmgpu_search_scheme(index._h, C.c_void_p(qb.data_ptr()), C.c_void_p(qo.data_ptr()), n_, C.byref(sc[0]), capi.UINT64_MAX,
                                                           C.c_void_p(hits_bufs[b].data_ptr()), hit_cap, C.byref(cnt), C.byref(stats), None))
                 state["cnt"] = int(cnt.value)
-                log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses, "hits": stats.hits})
+                log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses, "hits": stats.hits, "table_steps": stats.table_steps})
                 if xch:                                           # 24 bytes per hit (qidx:32 | lb:32, len:32 | errors + key:32, lb_rev:32 | key:32); the rank's count rides in the last row
                     capi.check(capi.lib().fmgpu_hits_pack24(C.c_void_p(hits_bufs[b].data_ptr()), int(cnt.value), C.c_void_p(packed_hits[b].data_ptr()), None))
                     packed_hits[b][pk_cap, 0] = int(cnt.value)
@@ -840,7 +841,7 @@ def run_dna_text(c, name, primary):
             qps = c.world * n_ * args.steps / elapsed
             lean_off = sel_base & capi.SEL_NO_LEAN
             dense = bool(index.formats & capi.FMT_DENSE) and not (sel_base & capi.SEL_LEAN_FORMAT_A)
-            kernel = "k_scheme_fast_edit" if edit else ("k_scheme_lean" if index_kind == "plain" and not lean_off else "k_scheme_fast")
+            kernel = "k_scheme_fast_edit" if edit else ("k_scheme_lean" if index_kind.startswith("plain") and not lean_off else "k_scheme_fast")
             part = [L // 4 + (1 if p < L % 4 else 0) for p in range(4)]
             rec = {"id": rid, "metric": "queries/sec (GRCh38-sized index, %s x %dbp, k=2 %s, h2(4,0,2))" % ("10M" if w == "k2" and not edit else ("%.1fM per GPU" % (n_ / 1e6)), L, "edit distance" if edit else "Hamming"),
                    "value": qps, "unit": "queries/s", "n_gpus": c.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -849,14 +850,15 @@ def run_dna_text(c, name, primary):
                    "config": {"workload": "grch38_k2" if w == "k2" else "grch38_k2_151bp (configs[3]%s)" % ("" if c.multi else ": one GPU's share of 8"), **base_cfg,
                               "index": "BiFMIndex", "index_kind": index_kind, "queries_per_gpu": n_, "read_len": L, "scheme": "h2(4,0,2)", "partition": part,
                               "index_device_bytes": index.device_bytes, "index_build_s": round(build_s, 2),
-                              "tables": None if index_kind == "plain" else {"lf": True, "prefix_symbols": args.prefix_len, "walk": "LF,LF^2,LF^3 + LF^16"}},
+                              "tables": None if index_kind == "plain" else ({"prefix_symbols": 12} if index_kind == "plain+lut12" else {"lf": True, "prefix_symbols": args.prefix_len, "walk": "LF,LF^2,LF^3 + LF^16"})},
                    "gbp_per_s": qps * L / 1e9, "hits": int(nh)}
-            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
+            st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses", "table_steps")}
             if kernel == "k_scheme_lean":
-                # fmgpu_stats of the lean kernel: table_accesses = blocks it fetched, table_bytes = visited nodes of several rows (the rest of the nodes stood on one row)
-                multi, single, blocks = st["table_bytes"], units - st["table_bytes"], st["table_accesses"]
+                # fmgpu_stats of the lean kernel: table_accesses = blocks it fetched, table_bytes = visited nodes of several rows (the rest of the walked nodes stood on one row),
+                # table_steps = nodes that prefix-table entries stood for (one 16-byte entry per 12 of them)
+                multi, single, blocks = st["table_bytes"], units - st["table_bytes"] - st["table_steps"], st["table_accesses"]
                 per = FMT_NODE_DENSE if dense else FMT_NODE_BLOCKS
-                rec["roofline"] = roofline_plain(kernel, k_ms, units, "visited nodes (cursor extensions)", multi * per[0] + single * per[1],
+                rec["roofline"] = roofline_plain(kernel, k_ms, units, "visited nodes (cursor extensions)", multi * per[0] + single * per[1] + st["table_steps"] / 12.0 * 16.0,
                                                  ("dense DNA blocks (32 B per 64 rows: four counts + two bit planes)" if dense else "the entries of symbols 1..4 of the one-symbol blocks (48 B)") +
                                                  ": a node of several rows reads both interval ends' blocks (%d B), a one-row node its row's block (%d B); %.1f %% of the nodes hold several rows"
                                                  % (per[0], per[1], 100.0 * multi / max(units, 1.0)),
@@ -885,6 +887,12 @@ def run_dna_text(c, name, primary):
 
         for (w, L, n_) in k2_legs:
             out.append(k2_run(w, L, n_, "plain", build_plain))
+        if not c.multi and any(wanted(c, "%s/%s/plain+lut12" % (name, w)) for w, _, _ in k2_legs):      # the same searches behind a 12-symbol prefix table (268 MB), no other table
+            t0 = time.time()
+            index.accelerate_search(12, 0)
+            for (w, L, n_) in k2_legs:
+                out.append(k2_run(w, L, n_, "plain+lut12", build_plain + time.time() - t0))
+            index.accelerate_search(0, 0)
         if args.with_edit and not c.multi and any(w == "k2" for w, _, _ in k2_legs) and wanted(c, "%s/k2_edit/plain" % name):
             qb, qo = reads["k2"]                                    # edit distance (the reference's default, search_ng26<true>) on the plain index: one-row nodes read their row's block
             n_e = min(2_000_000, nq)
@@ -946,7 +954,7 @@ def _scheme_struct(capi, scheme):
 def run_protein(c, nseq, tag):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
-    ids = [tag + "/exact/wavelet", tag + "/exact/tables", tag + "/exact/tree"]
+    ids = [tag + "/exact/wavelet", tag + "/exact/tables", tag + "/exact/tree", tag + "/exact/wavelet+lut5"]
     if c.only and not any(i in c.only for i in ids):
         return []
     sigma, L, nq = 28, 40, args.nq
@@ -974,7 +982,7 @@ def run_protein(c, nseq, tag):
     def step(log):
         capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
                                                  C.c_void_p(out_t[:nq].data_ptr()), C.c_void_p(out_t[nq:].data_ptr()), C.byref(stats), None))
-        log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses})
+        log.append({"kernel_ms": stats.kernel_ms, "units": stats.lf_steps, "table_bytes": stats.table_bytes, "table_accesses": stats.table_accesses, "table_steps": stats.table_steps})
 
     def rec_of(rid, kind, kernel, elapsed, log, b_s, tables):
         k_ms = mean([x["kernel_ms"] for x in log]); units = mean([x["units"] for x in log])
@@ -985,10 +993,10 @@ def run_protein(c, nseq, tag):
                         "index": "FMIndex", "index_kind": kind, "row_bits": index.row_bits, "queries_per_gpu": nq, "read_len": L, "index_device_bytes": index.device_bytes,
                         "index_build_s": round(b_s, 2), "tables": tables},
              "gres_per_s": qps * L / 1e9, "hits": int((out_t[nq:] > 0).sum().item())}
-        st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses")}
-        if kind == "wavelet" and kernel == "k_exact_s":
-            r["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", units * FMT_STEP_PLANES28,
-                                           "one line per step on the symbol planes beside the tree (one 128-byte line per 64 rows: 5 symbol planes + sigma bit-packed counts): 2 interval ends x "
+        st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses", "table_steps")}
+        if kind.startswith("wavelet") and kernel in ("k_exact_s", "k_exact_ls"):
+            r["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", (units - st["table_steps"]) * FMT_STEP_PLANES28 + st["table_steps"] / 5.0 * 8.0,
+                                           ("the read's last 5 symbols from one interval-table entry, then " if kernel == "k_exact_ls" else "") + "one line per step on the symbol planes beside the tree (one 128-byte line per 64 rows: 5 symbol planes + sigma bit-packed counts): 2 interval ends x "
                                            "44 B read of a line (40 B of planes + the symbol's count) = 88 B per executed LF step",
                                            SEC8D_STEP_WAVELET28, "2 ends x 5 levels x (8 + 1 + 8) useful bytes of the reference's binary wavelet tree = 170 B per LF step: record " + tag + "/exact/tree (k_exact_m, same index, same reads, same run)",
                                            st["table_bytes"] + nq * (L + 8 + 16), "44 B per line the kernel fetched (an end in the other end's line: one fetch) + queries and results", st["table_accesses"])
@@ -1022,6 +1030,21 @@ def run_protein(c, nseq, tag):
         if flat_ms:
             r1["roofline"]["line_kernel_speedup"] = r1["roofline"]["kernel_ms"] / flat_ms
         out.append(r1)
+        del keep
+    if flat and wanted(c, tag + "/exact/wavelet+lut5"):           # the same search behind a 5-symbol interval table (27^5 entries: 115 MB with 32-bit rows), no other table
+        if not wanted(c, ids[0]):
+            step([]); torch.cuda.synchronize()
+        keep = out_t.clone()
+        t0 = time.time()
+        index.accelerate(0, lut_len=5, walk=0)
+        elapsed, log = timed(c, step)
+        r2 = rec_of(tag + "/exact/wavelet+lut5", "wavelet+lut5", "k_exact_ls", elapsed, log, build_s + time.time() - t0, {"suffix_interval_symbols": 5})
+        r2["equal_to_the_plain_index"] = bool(torch.equal(keep, out_t))
+        if not r2["equal_to_the_plain_index"]:
+            raise SystemExit("bench.py: protein exact search with and without the interval table disagree")
+        if flat_ms:
+            r2["roofline"]["speedup_over_plain_index_kernel"] = flat_ms / r2["roofline"]["kernel_ms"]
+        out.append(r2)
         del keep
     if len(ids) > 1 and wanted(c, ids[1]):
         t0 = time.time()

@@ -291,7 +291,7 @@ struct FileSource {
             return fail(FMGPU_ERR_INVALID, "index file: section " + std::to_string(want_id) + " expected with " + std::to_string(want_bytes) + " bytes, found section " +
                                            std::to_string(sh.id) + " with " + std::to_string(sh.bytes));
         DBuf d;
-        if ((rc = d.alloc(want_bytes))) return rc;
+        if ((rc = d.alloc(want_bytes + 64))) return rc;           // (+ the slack every table carries behind its last entry)
         uint64_t sum = 0x243f6a8885a308d3ull ^ want_id;
         for (uint64_t at = 0; at < want_bytes; at += kChunk) {
             const size_t c = (size_t)std::min<uint64_t>(kChunk, want_bytes - at);
@@ -322,7 +322,7 @@ struct PeerSource {
         const void* from = id >= SEC_C ? other[id - SEC_C] : ptr[id / 32][id % 32];
         if (!from) return fail(FMGPU_ERR_INVALID, "index clone: array " + std::to_string(id) + " is missing on the source handle");
         DBuf d; int rc;
-        if ((rc = d.alloc(bytes))) return rc;
+        if ((rc = d.alloc(bytes + 64))) return rc;
         FM_HIP(hipMemcpyPeer(d.p, dst_device, from, src_device, bytes));
         *dev = d.take();
         return 0;

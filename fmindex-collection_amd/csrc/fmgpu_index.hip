@@ -1041,6 +1041,28 @@ int fmgpu_index_accelerate_lf(fmgpu_index_t h, int32_t enable) {
     return 0;
 }
 
+// dropping the Format A expansion of a string takes the tables derived from it along (pair lines, dense DNA blocks: no kernel could reach them any more)
+static void drop_shadow(Index* x, DevString& t) {
+    if (!t.shadow) return;
+    (void)hipFree(t.shadow); if (t.shadow_sup) (void)hipFree(t.shadow_sup);
+    x->device_bytes -= t.shadow_bytes;
+    t.shadow = nullptr; t.shadow_sup = nullptr; t.shadow_bytes = 0; t.shadow_sup_bytes = 0; t.va = ViewA{};
+    if (t.pairs) { (void)hipFree(t.pairs); if (t.pairs_ex) (void)hipFree(t.pairs_ex); if (t.pairs_super) (void)hipFree(t.pairs_super);
+                   x->device_bytes -= t.pairs_bytes; t.pairs = nullptr; t.pairs_ex = nullptr; t.pairs_super = nullptr; t.pairs_bytes = 0; t.pairs_nex = 0; t.pairs_nsb = 0; }
+    if (t.dense) { (void)hipFree(t.dense); if (t.dense_ex) (void)hipFree(t.dense_ex);
+                   x->device_bytes -= t.dense_bytes; t.dense = nullptr; t.dense_ex = nullptr; t.dense_bytes = 0; t.dense_nex = 0; }
+}
+// ... and (re)building it brings them back, as at creation: presence bits fused into the blocks, dense DNA blocks, pair lines
+static int rebuild_derived(Index* x) {
+    int rc;
+    if ((rc = fuse_presence_bits(x, nullptr))) return rc;
+    if (x->bidirectional) {
+        for (DevString* t : {&x->bwt, &x->rev}) { const size_t had = t->dense_bytes; if ((rc = build_dense_dna(*t, nullptr))) return rc; x->device_bytes += t->dense_bytes - had; }
+        if (x->bwt.dense && !x->rev.dense) { (void)hipFree(x->bwt.dense); (void)hipFree(x->bwt.dense_ex); x->device_bytes -= x->bwt.dense_bytes; x->bwt.dense = nullptr; x->bwt.dense_ex = nullptr; x->bwt.dense_bytes = 0; x->bwt.dense_nex = 0; }
+    }
+    return build_pair_table(x, nullptr);
+}
+
 #if FMGPU_WIDE
 static int no_wide(const char* what) { return fail(FMGPU_ERR_UNSUPPORTED, std::string(what) + " is not available for indices of 2^32 rows or more (64-bit-row build): searches run on the plain occurrence tables"); }
 int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
@@ -1050,15 +1072,16 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
     if (kstep <= 1) {                                      // Format A expansion of EPR / Wavelet strings (kstep = 1), or dropping it (0): available
         if (int drc = on_handle_device(x)) return drc;
         if (kstep == 0) {
-            for (DevString* t : {&x->bwt, &x->rev}) if (t->shadow) { (void)hipFree(t->shadow); if (t->shadow_sup) (void)hipFree(t->shadow_sup); x->device_bytes -= t->shadow_bytes; t->shadow = t->shadow_sup = nullptr; t->shadow_bytes = 0; t->va = ViewA{}; }
+            for (DevString* t : {&x->bwt, &x->rev}) drop_shadow(x, *t);
             return 0;
         }
+        bool built = false;
         for (DevString* t : {&x->bwt, &x->rev}) {
             if (t->n == 0 || t->family == FAM_A || t->shadow) continue;
             int rc = build_format_a_shadow(*t, x->dC, nullptr); if (rc) return rc;
-            x->device_bytes += t->shadow_bytes;
+            x->device_bytes += t->shadow_bytes; built = true;
         }
-        return 0;
+        return built ? rebuild_derived(x) : 0;
     }
     return no_wide("the multi-symbol-step table");
 }
@@ -1078,16 +1101,18 @@ int fmgpu_index_accelerate(fmgpu_index_t h, int32_t kstep) {
     x->device_bytes -= s.kblk_bytes;
     if (s.kblk) { (void)hipFree(s.kblk); s.kblk = nullptr; s.kstep = s.kcodes = 0; s.kblk_bytes = 0; }
     if (kstep == 0) {                                  // drop the Format A shadows as well
-        for (DevString* t : {&x->bwt, &x->rev}) if (t->shadow) { (void)hipFree(t->shadow); x->device_bytes -= t->shadow_bytes; t->shadow = nullptr; t->shadow_bytes = 0; t->va = ViewA{}; }
+        for (DevString* t : {&x->bwt, &x->rev}) drop_shadow(x, *t);
         return 0;
     }
     if (s.n == 0) return 0;
     int rc = 0;
+    bool built = false;
     for (DevString* t : {&x->bwt, &x->rev}) {          // EPR / Wavelet strings: searches read a Format A expansion from here on
         if (t->n == 0 || t->family == FAM_A || t->shadow) continue;
         if ((rc = build_format_a_shadow(*t, x->dC, nullptr))) return rc;
-        x->device_bytes += t->shadow_bytes;
+        x->device_bytes += t->shadow_bytes; built = true;
     }
+    if (built && (rc = rebuild_derived(x))) return rc;
     if (kstep <= 1) return 0;
     rc = dispatch_occ(s, [&](auto occ, auto) { return accelerate_with(s, occ, (uint32_t)kstep); });
     if (rc == 0) x->device_bytes += s.kblk_bytes;
@@ -1139,7 +1164,7 @@ int fmgpu_index_accelerate_search(fmgpu_index_t h, int32_t prefix_len, int32_t w
         uint64_t entries = 1;
         for (int t = 0; t < prefix_len; ++t) { entries *= R; if (entries > (1ull << 32)) return fail(FMGPU_ERR_UNSUPPORTED, "prefix table would exceed 2^32 entries"); }
         DBuf lut;
-        if ((rc = lut.alloc(entries * 16))) return rc;
+        if ((rc = lut.alloc(entries * 16 + 64))) return rc;            // (+ slack: the lean kernel reads a block's worth behind an entry)
         dim3 grid;
         if ((rc = grid_of(entries, &grid, kTableGridCap))) return rc;
         rc = dispatch_native(x->rev, [&](auto occ, auto) {

@@ -1,818 +1,19 @@
-// fmgpu_search.hip — the hot path: one query per lane.
+// fmgpu_search.hip — the search-scheme searches (depth-first walks of the bidirectional index), one query per lane, and the hit-record helpers.
 //
-//  k_exact_kstep       search_no_errors::search, table-driven: interval table, k-symbol-step table, LF^J walk table (search/SearchNoErrors.h:12-86)
-//  k_exact_a / _w / k_exact   the same without tables: Format A blocks / wavelet lines / any layout
-//  k_scheme_fast       search_ng26::search<Edit=false> on equal-length (or length-bucketed) batches: per-step table, prefix table,
-//                      LF..LF^3 and LF^16 walk tables, searches of a scheme started wave-synchronously (search/SearchNg26.h:18-433)
-//  k_scheme_fast_edit  search_ng26::search<Edit=true>, the same frame with the insertion / deletion branches (:146-218, :286-362)
-//  k_scheme, k_scheme_edit   the general forms (ragged small batches, explicit partitions, every layout): flat state machines
+//  k_scheme_lean       search_ng26::search<Edit=false> on the plain sigma = 5 index (equal-length batches; top / bottom frames in LDS, hit ring per wave, 2-bit reads)
+//  k_scheme_fast       the same with tables: per-step table, prefix table, LF..LF^3 and LF^16 walk tables (search/SearchNg26.h:18-433)
+//  k_scheme_fast_edit  search_ng26::search<Edit=true>, the same frame with the insertion / deletion branches (:146-218, :286-362); top frame in LDS (write-back)
+//  k_scheme, k_scheme_edit, k_ng21   the general forms (ragged small batches, explicit partitions, every layout, search_ng21): flat state machines
 //  k_backtracking      search_backtracking::search         (search/Backtracking.h:42-102)
-//  k_locate, k_locate_tab    FMIndex::locate / BiFMIndex::locate (fmindex/FMIndex.h:113-124), LF walk or per-row answer table
+//  (exact search: fmgpu_exact.hip; locate: fmgpu_locate.hip; what they share: fmgpu_search_shared.h)
 //
 // The general DFS kernels are flat state machines: every loop iteration performs exactly one memory phase per lane (the occurrence-table
 // blocks at both interval ends, Occ::all2, or one LF-table load for a one-row cursor) followed by register-only control logic.  Pending
 // siblings of a branching node live in a per-lane stack in HBM and are re-derived from the parent cursor when popped; children with an empty
 // interval are never pushed (the reference returns from them at once).  Queries are handed out and hit records written by whole waves.
-#include "fmgpu_common.h"
-
-#include <algorithm>
-#include <chrono>
-#include <cstdlib>
-#include <map>
-#include <mutex>
-#include <tuple>
-#include <vector>
-
-#include <hipcub/hipcub.hpp>
+#include "fmgpu_search_shared.h"
 
 namespace FMGPU_NS {
-
-// the cursor of query q: two 64-bit arrays as the reference's cursor fields, or (out_len == nullptr) one word lb << 32 | len — the transport
-// form of fmgpu_search_exact_packed (32-bit rows only)
-__device__ __forceinline__ void store_interval(uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len, uint64_t q, idx_t lb, idx_t len) {
-    if (kWide || out_len) { out_lb[q] = lb; out_len[q] = len; }
-    else out_lb[q] = ((uint64_t)lb << 32) | (uint64_t)len;
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// counters of the one-thread-per-query kernels: [0] executed steps, [1] table bytes consumed, [2] table accesses, [3] steps that an interval-table entry stood for (fmgpu_stats), each striped
-// over kCounterStripes words (a single word would serialise one atomic per wave — 156 k of them for 10 M queries — behind each other)
-__device__ __forceinline__ void add_counters(unsigned long long* __restrict__ ctr, uint32_t steps, uint32_t bytes, uint32_t accesses, uint32_t table_steps = 0u) {
-    const uint32_t ts = wave_sum(steps), tb = wave_sum(bytes), ta = wave_sum(accesses), tt = wave_sum(table_steps);
-    if ((threadIdx.x & 63u) == 0 && ts) {
-        const uint32_t stripe = blockIdx.x & (kCounterStripes - 1u);
-        atomicAdd(&ctr[stripe], (unsigned long long)ts);
-        atomicAdd(&ctr[kCounterStripes + stripe], (unsigned long long)tb);
-        atomicAdd(&ctr[2u * kCounterStripes + stripe], (unsigned long long)ta);
-        if (tt) atomicAdd(&ctr[3u * kCounterStripes + stripe], (unsigned long long)tt);
-    }
-}
-
-// ------------------------------------------------------------------ exact search
-template <class Occ>
-__global__ __launch_bounds__(256) void k_exact(Occ occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
-                                               uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
-                                               unsigned long long* __restrict__ steps_total) {
-    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0;
-    if (q < nq) {
-        uint64_t o = qoff[q];
-        uint32_t m = (uint32_t)(qoff[q + 1] - o);
-        const uint8_t* s = qbuf + o;
-        const uint32_t sigma = occ.sigma();
-        idx_t lb = 0, len = n;
-        for (uint32_t i = m; i-- > 0;) {
-            uint32_t c = s[i];
-            ++steps;
-            if (c >= sigma) { lb = 0; len = 0; break; }      // not a rank of this alphabet: no occurrence
-            idx_t ra, rb;
-            occ.lf2(lb, lb + len, c, ra, rb);                 // fmindex/FMIndexCursor.h:33-37
-            lb = ra; len = rb - ra;
-            if (len == 0) break;
-        }
-        store_interval(out_lb, out_len, q, lb, len);
-    }
-    add_counters(steps_total, steps, 0u, 0u);
-}
-
-// symbols a query consumes until its interval is a single row (or empty): out[q] = that count, or its length + 1 if the interval still
-// holds several rows at the end — the quantity that decides how much of a read the one-row walk tables can serve (bench.py reports its distribution)
-template <class Occ>
-__global__ __launch_bounds__(256) void k_exact_depth(Occ occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
-                                                     uint32_t* __restrict__ out) {
-    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    uint64_t o = qoff[q];
-    uint32_t m = (uint32_t)(qoff[q + 1] - o);
-    const uint8_t* s = qbuf + o;
-    const uint32_t sigma = occ.sigma();
-    idx_t lb = 0, len = n;
-    uint32_t depth = m + 1, done = 0;
-    for (uint32_t i = m; i-- > 0 && len > 1;) {
-        uint32_t c = s[i];
-        ++done;
-        if (c >= sigma) { len = 0; break; }
-        idx_t ra, rb;
-        occ.lf2(lb, lb + len, c, ra, rb);
-        lb = ra; len = rb - ra;
-    }
-    if (len <= 1) depth = done;
-    out[q] = depth;
-}
-
-// ---- exact search on Format A without accelerator tables --------------------------------------------------------
-// The query symbols are fetched as aligned 64-bit words one word ahead of use, so that the only load on the
-// dependent chain of an LF step is the occurrence-table entry; the second interval end re-uses the first end's
-// entry when both fall into the same 64-row block (the common case once the interval is short).
-struct QueryReader {
-    const uint64_t* base;   // 8-byte aligned
-    uint64_t pos;           // absolute byte position (relative to base) of the next symbol to hand out (moving down)
-    uint64_t cw, nw;        // current word, next (lower) word
-    __device__ __forceinline__ void init(const uint8_t* qbuf, uint64_t off, uint32_t m) {
-        uint64_t mis = (uint64_t)qbuf & 7ull;
-        base = reinterpret_cast<const uint64_t*>((uint64_t)qbuf - mis);
-        pos = off + mis + m - 1;                       // m >= 1
-        uint64_t w = pos >> 3;
-        cw = base[w];
-        nw = w ? base[w - 1] : 0;
-    }
-    __device__ __forceinline__ uint32_t next() {
-        uint32_t c = (uint32_t)(cw >> ((pos & 7ull) * 8ull)) & 0xffu;
-        if ((pos & 7ull) == 0) {                       // crossing into the lower word: rotate and prefetch
-            uint64_t w = pos >> 3;
-            cw = nw;
-            nw = w >= 2 ? base[w - 2] : 0;
-        }
-        --pos;
-        return c;
-    }
-};
-
-template <int SIGMA>
-__device__ __noinline__ void lf0_pair(const OccA<SIGMA>& occ, idx_t a, idx_t b, idx_t& ra, idx_t& rb) { ra = occ.lf0_fused(a); rb = occ.lf0_fused(b); }
-template <int SIGMA>
-__global__ __launch_bounds__(256) void k_exact_a(OccA<SIGMA> occ, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
-                                                 uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
-                                                 unsigned long long* __restrict__ steps_total) {
-    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0, acc = 0;
-    if (q < nq) {
-        uint64_t o = qoff[q];
-        uint32_t m = (uint32_t)(qoff[q + 1] - o);
-        const uint32_t sigma = occ.sigma();
-        idx_t lb = 0, len = n;
-        if (m) {
-            QueryReader qr; qr.init(qbuf, o, m);
-            for (uint32_t i = 0; i < m; ++i) {
-                uint32_t c = qr.next();
-                ++steps;
-                if (c >= sigma) { lb = 0; len = 0; break; }
-                const idx_t a = lb, b = lb + len;
-                idx_t ra, rb;
-                if (c == 0 && occ.v.fused) { lf0_pair(occ, a, b, ra, rb); acc += 2; }   // a delimiter in the query on a table whose entry 0 carries presence bits (rare; out of line)
-                else {
-                    EntryA ea = load_entry_a(occ.v, a, c);
-                    EntryA eb = ea;
-                    ++acc;
-                    if ((a >> 6) != (b >> 6)) { eb = load_entry_a(occ.v, b, c); ++acc; }
-                    ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
-                    rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
-                }
-                lb = ra; len = rb - ra;
-                if (len == 0) break;
-            }
-        }
-        store_interval(out_lb, out_len, q, lb, len);
-    }
-    add_counters(steps_total, steps, 12u * acc, acc);
-}
-
-// ---- exact search in two-symbol steps on Format P (fmgpu_common.h): one 128-byte line per interval end and PAIR of symbols.  An exact search is bound
-// by the random line fills it causes (tools/membench.hip: 52-55 G dependent lines/s, whatever is read of a line), so halving the lines of a read halves
-// its time.  A pair whose interval comes out empty is taken again in one-symbol steps (Format A), which yields the row and the step count a
-// one-symbol search ends with; so is a pair that holds a delimiter or a byte outside the alphabet, and the last symbol of a read of odd length.
-constexpr uint32_t kPairFilterBits = 32768;          // line number mod this: the ~50 listed rows of a genome mark 0.15 % of the lines
-// ---- lines fetched by the eight lanes of an octet together (k_exact_p, k_exact_s).  A lane that reads 44-68 bytes of its own random line with four or five load
-// instructions pays as many address translations and passes through the texture path per line, and that — not the line fills — bounds such a kernel
-// (tools/membench.hip modes 8 / 9 / 4: 33 / 47 / 44 G lines/s on a 3.1 GB table, 24 / 22 / 25 on a 4.2 GB one, where one load per line keeps 51).  Here
-// instruction k of a round has the eight lanes of every octet load the eight 16-byte pieces of the line of the octet's lane k — one coalesced 128-byte
-// request and one translation per line — straight into LDS (LDS-DMA: piece j of lane 8o + k's line lands at region k, offset 128 o + 16 j), from where the
-// owner reads what it needs.  The loops are wave-uniform (reads that are over ride along with a dummy line); waves do not synchronise with each other.
-constexpr uint32_t kCoopRegion = 1024u + 16u;        // bytes per region (64 pieces + padding that spreads the owners' reads over the LDS banks)
-typedef __attribute__((address_space(3))) uint32_t lds_word;
-typedef uint32_t __attribute__((ext_vector_type(4))) flat_u32x4;
-__device__ __forceinline__ void coop_round(const uint8_t* __restrict__ flat, uint32_t line, uint32_t lane, lds_word* wave_lds) {
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; ++k) {
-        const uint32_t l = __shfl(line, (int)((lane & ~7u) | k), 64);
-        const uint8_t* g = flat + (size_t)l * 128u + (lane & 7u) * 16u;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(wave_lds + k * (kCoopRegion / 4u)), 16, 0, 0);
-    }
-}
-// rows of the pair before row i in the owner's line (now in LDS) + the pair's count
-__device__ __forceinline__ uint32_t pair_rank_lds(const lds_word* own, uint32_t i, uint32_t pc) {
-    const uint32_t cnt = own[pc];
-    const flat_u32x4 w0 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 16), w1 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 20);
-    const flat_u32x4 w2 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 24), w3 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 28);
-    const uint32_t i0 = (pc & 1u) ? 0u : ~0u, i1 = (pc & 2u) ? 0u : ~0u, i2 = (pc & 4u) ? 0u : ~0u, i3 = (pc & 8u) ? 0u : ~0u;
-    const uint32_t off = i & 127u;
-    const uint32_t m0 = off >= 32u ? ~0u : (1u << off) - 1u;
-    const uint32_t m1 = off >= 64u ? ~0u : (off > 32u ? (1u << (off - 32u)) - 1u : 0u);
-    const uint32_t m2 = off >= 96u ? ~0u : (off > 64u ? (1u << (off - 64u)) - 1u : 0u);
-    const uint32_t m3 = off > 96u ? (1u << (off - 96u)) - 1u : 0u;
-    // rows 0..63: w0 = planes 0, 1 (lo, hi words each), w1 = planes 2, 3; rows 64..127: w2, w3
-    const uint32_t h0 = (w0.x ^ i0) & (w0.z ^ i1) & (w1.x ^ i2) & (w1.z ^ i3), h1 = (w0.y ^ i0) & (w0.w ^ i1) & (w1.y ^ i2) & (w1.w ^ i3);
-    const uint32_t h2 = (w2.x ^ i0) & (w2.z ^ i1) & (w3.x ^ i2) & (w3.z ^ i3), h3 = (w2.y ^ i0) & (w2.w ^ i1) & (w3.y ^ i2) & (w3.w ^ i3);
-    return cnt + __popc(h0 & m0) + __popc(h1 & m1) + __popc(h2 & m2) + __popc(h3 & m3);
-}
-// slut != null (fmgpu_index_accelerate_exact(h, 1, lutL, 0) on a handle with the pair table): a read whose last lutL symbols are all in 1..4 starts from the interval-table
-// entry of those symbols (one 8 / 16-byte load from a table of 4^lutL entries — 12 symbols: 134 MB, Infinity-Cache resident — instead of lutL / 2 pair steps whose two interval
-// ends lie in two lines each); an empty entry is walked from the start instead, so the miss row and the step count stay the one-symbol search's.
-__global__ __launch_bounds__(256) void k_exact_p(OccA<5> occ, const uint8_t* __restrict__ pairs, const idx_t* __restrict__ ex, uint32_t nex, const idx_t* __restrict__ psuper,
-                                                 const void* __restrict__ slut, uint32_t lutL,
-                                                 const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
-                                                 uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
-                                                 unsigned long long* __restrict__ steps_total) {
-    extern __shared__ uint32_t s_coop[];                            // 4 waves x 8 regions
-    __shared__ uint32_t s_filt[kPairFilterBits / 32u];
-    __shared__ idx_t s_ex[512];
-    for (uint32_t t = threadIdx.x; t < kPairFilterBits / 32u; t += 256u) s_filt[t] = 0u;
-    for (uint32_t t = threadIdx.x; t < 512u; t += 256u) s_ex[t] = t < nex ? ex[t] : ~(idx_t)0;
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < 512u; t += 256u) {
-        const idx_t r = s_ex[t];
-        if (r != ~(idx_t)0) { const uint32_t bk = (uint32_t)(r >> 7) & (kPairFilterBits - 1u); atomicOr(&s_filt[bk >> 5], 1u << (bk & 31u)); }
-    }
-    __syncthreads();
-    // listed rows in [first row of i's line, i): they sit in the planes as code 0 and are in no count
-    auto listed_before = [&](idx_t i) -> uint32_t {
-        const uint32_t bk = (uint32_t)(i >> 7) & (kPairFilterBits - 1u);
-        if (!((s_filt[bk >> 5] >> (bk & 31u)) & 1u)) return 0u;
-        const idx_t first = i & ~(idx_t)127;
-        uint32_t c = 0;
-        for (uint32_t t = 0; t < 512u && s_ex[t] < i; ++t) if (s_ex[t] >= first) ++c;
-        return c;
-    };
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    lds_word* const wave_lds = (lds_word*)(s_coop + wave * 8u * (kCoopRegion / 4u));
-    const lds_word* const own = wave_lds + (lane & 7u) * (kCoopRegion / 4u) + (lane >> 3) * 32u;
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0, acc = 0, acc2 = 0, m = 0;
-    idx_t lb = 0, len = n;
-    QueryReader qr;
-    if (q < nq) {
-        const uint64_t o = qoff[q];
-        m = (uint32_t)(qoff[q + 1] - o);
-        if (m) qr.init(qbuf, o, m);
-    }
-    // one symbol, as k_exact_a does it; false once the search is over
-    auto single = [&](uint32_t c) -> bool {
-        ++steps;
-        if (c >= 5u) { lb = 0; len = 0; return false; }
-        const idx_t a = lb, b = lb + len;
-        idx_t ra, rb;
-        if (c == 0 && occ.v.fused) { lf0_pair(occ, a, b, ra, rb); acc += 2; }
-        else {
-            EntryA ea = load_entry_a(occ.v, a, c);
-            EntryA eb = ea;
-            ++acc;
-            if ((a >> 6) != (b >> 6)) { eb = load_entry_a(occ.v, b, c); ++acc; }
-            ra = ea.cnt + popc64(ea.bits & lowmask((uint32_t)a & 63u));
-            rb = eb.cnt + popc64(eb.bits & lowmask((uint32_t)b & 63u));
-        }
-        lb = ra; len = rb - ra;
-        return len != 0;
-    };
-    bool alive = m != 0;
-    uint32_t done = 0, lut_steps = 0, acc3 = 0;                     // symbols of the read consumed so far; steps an interval-table entry stood for; such entries read
-    if (slut && alive && m >= lutL && n > 1) {
-        uint32_t code = 0; bool valid = true;
-        for (uint32_t t = 0; t < lutL; ++t) { const uint32_t c = qr.next(); valid = valid && c - 1u < 4u; code |= ((c - 1u) & 3u) << (2u * t); }
-        idx_t elb = 0, elen = 0;
-        if (valid) {
-            if constexpr (kWide) { const ulonglong2 en = reinterpret_cast<const ulonglong2*>(slut)[code]; elb = (idx_t)en.x; elen = (idx_t)en.y; }
-            else { const uint2 en = reinterpret_cast<const uint2*>(slut)[code]; elb = en.x; elen = en.y; }
-            ++acc3;
-        }
-        if (elen != 0) { lb = elb; len = elen; done = lutL; steps = lutL; lut_steps = lutL; }
-        else qr.init(qbuf, qoff[q], m);                             // (a foreign byte among the symbols, or a string the text does not hold: from the start, step by step)
-    }
-    for (;;) {                                                      // every lane of the wave takes its next two symbols (or is done)
-        if (done >= m) alive = false;
-        if (!__ballot(alive)) break;
-        const bool two = alive && done + 2u <= m;
-        uint32_t y = 0, x = 0;
-        if (alive) { y = qr.next(); if (two) x = qr.next(); }
-        done += 2u;
-        const bool pairable = two && y - 1u < 4u && x - 1u < 4u;
-        bool stepped = false;
-        if (__ballot(pairable)) {
-            const uint32_t pc = pairable ? (x - 1u) * 4u + (y - 1u) : 0u;
-            const idx_t a = lb, b = lb + len;
-            const uint32_t la = pairable ? (uint32_t)(a >> 7) : 0u, lbn = pairable ? (uint32_t)(b >> 7) : 0u;      // (n < 2^38: a line number fits 31 bits)
-            const bool far = pairable && la != lbn;
-            coop_round(pairs, la, lane, wave_lds);
-            __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0): the round's pieces are in LDS
-            asm volatile("" ::: "memory");
-            idx_t ra = 0, rb = 0;
-            if (pairable) {
-                acc2 += far ? 2u : 1u;
-                ra = pair_rank_lds(own, (uint32_t)a, pc);
-                if (!far) rb = pair_rank_lds(own, (uint32_t)b, pc);
-            }
-            if (__ballot(far)) {                                    // the other end's lines, where they are other lines (the first ~14 symbols of a read)
-                __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): every lane has read what it needs of the first round
-                asm volatile("" ::: "memory");
-                coop_round(pairs, far ? lbn : 0u, lane, wave_lds);
-                __builtin_amdgcn_s_waitcnt(0x0f70);
-                asm volatile("" ::: "memory");
-                if (far) rb = pair_rank_lds(own, (uint32_t)b, pc);
-            }
-            if (pairable) {
-                if constexpr (kWide) {                              // the line's counts are relative to its super-block of 2^30 rows
-                    const idx_t sa = psuper[(size_t)(a >> kSuperShift) * 16u + pc];
-                    ra += sa; rb += (a >> kSuperShift) == (b >> kSuperShift) ? sa : psuper[(size_t)(b >> kSuperShift) * 16u + pc];
-                }
-                if (pc == 0u) { ra -= listed_before(a); rb -= listed_before(b); }
-                if (rb > ra) { lb = ra; len = rb - ra; steps += 2u; stepped = true; }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                     // the next round overwrites the regions
-            asm volatile("" ::: "memory");
-        }
-        if (alive && !stepped) {                                    // rare: a pair that came out empty or cannot be a pair, the last symbol of an odd read
-            alive = single(y);
-            if (alive && two) alive = single(x);
-        }
-    }
-    if (q < nq) store_interval(out_lb, out_len, q, lb, len);
-    add_counters(steps_total, steps, 12u * acc + 68u * acc2 + (uint32_t)kSlutEntryBytes * acc3, acc + acc2 + acc3, lut_steps);
-}
-
-// ---- exact search on Format S (fmgpu_common.h): ONE 128-byte line per LF step and interval end where the multi-ary wavelet tree of sigma = 28 takes two —
-// the five symbol planes of the line's 64 rows, the symbol's 24-bit count before the line and the super-block's count (a small table, LDS or L2).
-// The lines are fetched by the lanes of an OCTET together: a lane that reads 44 bytes of its own random line with four load instructions pays four address
-// translations and four passes through the texture path per line, and that — not the line fills — bounds the kernel (tools/membench.hip modes 8 / 9 / 4:
-// 33 / 47 / 44 G lines/s on a 3.1 GB table, 24 / 22 / 25 on a 4.2 GB one, where one load per line keeps 51).  Here instruction k of a round has the eight lanes of
-// every octet load the eight 16-byte pieces of the line of the octet's lane k — one coalesced 128-byte request and one translation per line — straight into
-// LDS (LDS-DMA: piece j of lane 8o + k's line lands at region k, offset 128 o + 16 j), from where the owner reads its planes and count.  The loop is
-// wave-uniform (reads that are over ride along with a dummy line); waves do not synchronise with each other.
-// rows before row i that hold symbol c in the owner's line (now in LDS) + the line's count of c
-__device__ __forceinline__ uint32_t flat_rank_lds(const lds_word* own, uint32_t i, uint32_t c, uint32_t cbits) {
-    const flat_u32x4 p01 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own);
-    const flat_u32x4 p23 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 4);
-    const uint32_t p4l = own[8], p4h = own[9];
-    // the symbol's count: cbits bits at bit c * cbits of the 88 bytes behind the planes (the word behind the last one may be the next line's first: masked away)
-    const uint32_t bitpos = c * cbits;
-    const lds_word* g = own + 10u + (bitpos >> 5);
-    const uint32_t cnt = __funnelshift_r(g[0], g[1], bitpos & 31u) & ((1u << cbits) - 1u);
-    const uint32_t i0 = (c & 1u) ? 0u : ~0u, i1 = (c & 2u) ? 0u : ~0u, i2 = (c & 4u) ? 0u : ~0u, i3 = (c & 8u) ? 0u : ~0u, i4 = (c & 16u) ? 0u : ~0u;
-    const uint32_t off = i & 63u;
-    const uint32_t mlo = off >= 32u ? ~0u : (1u << off) - 1u, mhi = off > 32u ? (1u << (off - 32u)) - 1u : 0u;
-    const uint32_t lo = (p01.x ^ i0) & (p01.z ^ i1) & (p23.x ^ i2) & (p23.z ^ i3) & (p4l ^ i4);
-    const uint32_t hi = (p01.y ^ i0) & (p01.w ^ i1) & (p23.y ^ i2) & (p23.w ^ i3) & (p4h ^ i4);
-    return cnt + __popc(lo & mlo) + __popc(hi & mhi);
-}
-// the super table in LDS: 32-bit rows as they are; 64-bit rows as a low word + a high byte per entry (5 instead of 8 bytes: sigma = 28, 4.5 x 10^9 rows: 19 KB,
-// four resident blocks per CU; read through L2 instead the kernel took 13 % longer on the same text)
-constexpr size_t kFlatSuperLdsMax = 44 * 1024;      // (with the 16.6 KB of the regions: within the 64 KB a launch gets without asking)
-__host__ __device__ constexpr size_t flat_super_lds_bytes(uint32_t entries) { return kWide ? ((size_t)entries * 5u + 15u) / 16u * 16u : (size_t)entries * 4u; }
-__global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ flat, const idx_t* __restrict__ super, uint32_t sigma, uint32_t cbits,
-                                                 const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
-                                                 uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
-                                                 unsigned long long* __restrict__ steps_total, uint32_t super_lds) {
-    extern __shared__ uint32_t s_flat[];                            // 4 waves x 8 regions | 16 bytes | the super table, when it fits (super_lds entries)
-    uint32_t* const s_lo = s_flat + 4u * 8u * (kCoopRegion / 4u) + 4u;
-    uint8_t* const s_hi = reinterpret_cast<uint8_t*>(s_lo + super_lds);
-    for (uint32_t t = threadIdx.x; t < super_lds; t += 256u) {
-        const idx_t v = super[t];
-        s_lo[t] = (uint32_t)v;
-        if constexpr (kWide) s_hi[t] = (uint8_t)((uint64_t)v >> 32);
-    }
-    __syncthreads();
-    auto sup = [&](size_t at) -> idx_t {
-        if (!super_lds) return super[at];
-        if constexpr (kWide) return (idx_t)s_lo[at] | ((idx_t)s_hi[at] << 32);
-        else return (idx_t)s_lo[at];
-    };
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    lds_word* const wave_lds = (lds_word*)(s_flat + wave * 8u * (kCoopRegion / 4u));
-    const lds_word* const own = wave_lds + (lane & 7u) * (kCoopRegion / 4u) + (lane >> 3) * 32u;
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0, acc = 0, m = 0;
-    idx_t lb = 0, len = n;
-    QueryReader qr;
-    if (q < nq) {
-        const uint64_t o = qoff[q];
-        m = (uint32_t)(qoff[q + 1] - o);
-        if (m) qr.init(qbuf, o, m);
-    }
-    bool alive = m != 0;
-    uint32_t mmax = m;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, (uint32_t)__shfl_xor(mmax, off, 64));
-    for (uint32_t i = 0; i < mmax; ++i) {
-        if (i >= m) alive = false;                                  // (a shorter read of the wave is done)
-        if (!__ballot(alive)) break;
-        uint32_t c = 0;
-        if (alive) {
-            c = qr.next();
-            ++steps;
-            if (c >= sigma) { lb = 0; len = 0; alive = false; }
-        }
-        const idx_t a = lb, b = lb + len;
-        const uint32_t la = alive ? (uint32_t)(a >> 6) : 0u, lbn = alive ? (uint32_t)(b >> 6) : 0u;
-        const bool far = alive && la != lbn;
-        coop_round(flat, la, lane, wave_lds);
-        idx_t sa = 0, sb = 0;
-        if (alive) {
-            sa = sup((size_t)(a >> cbits) * sigma + c);
-            sb = sa;
-            if ((a >> cbits) != (b >> cbits)) sb = sup((size_t)(b >> cbits) * sigma + c);
-            acc += far ? 2u : 1u;
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): the round's pieces are in LDS
-        asm volatile("" ::: "memory");
-        idx_t ra = 0, rb = 0;
-        if (alive) {
-            ra = sa + flat_rank_lds(own, (uint32_t)a, c, cbits);
-            if (!far) rb = sb + flat_rank_lds(own, (uint32_t)b, c, cbits);
-        }
-        if (__ballot(far)) {                                        // the other end's lines, where they are other lines (the first log_sigma(n) steps of a read)
-            __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): every lane has read what it needs of the first round
-            asm volatile("" ::: "memory");
-            coop_round(flat, far ? lbn : 0u, lane, wave_lds);
-            __builtin_amdgcn_s_waitcnt(0x0f70);
-            asm volatile("" ::: "memory");
-            if (far) rb = sb + flat_rank_lds(own, (uint32_t)b, c, cbits);
-        }
-        if (alive) {
-            lb = ra; len = rb - ra;
-            if (len == 0) alive = false;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                         // the next round overwrites the regions
-        asm volatile("" ::: "memory");
-    }
-    if (q < nq) store_interval(out_lb, out_len, q, lb, len);
-    add_counters(steps_total, steps, 44u * acc, acc);
-}
-
-// ------------------------------------------------------------------ DFS machinery
-constexpr int kMaxParts = 16;
-constexpr int kMaxSearches = 16;
-
-struct SchemeDev {             // flattened [search][part]; values fit a byte (errors <= 255, parts <= 16)
-    int S, P;
-    uint8_t pi[kMaxSearches * kMaxParts], l[kMaxSearches * kMaxParts], u[kMaxSearches * kMaxParts];
-    uint32_t partition[kMaxParts];   // used when uniform == 0
-    uint32_t psum;                   // sum of partition[] (queries of another length are skipped)
-    int uniform;
-    int dev_flags;                   // dev knobs: 1 = count hits per lane only (no records)
-    int use_key, sharing;            // k_scheme: hit records carry path keys / idle lanes take subtrees from the busy lanes of their wave
-};
-
-struct Counters { unsigned long long hits, nodes, next, table_bytes, table_accesses; };
-
-// ---- work sharing between the lanes of a wave in k_scheme_fast -------------------------------------------------------------------------
-// The work of a k-mismatch search is heavy-tailed on a repeat-rich text: the median read visits ~200 nodes, a read from a satellite array
-// half a million (measured on the genome-like text: 0.02 % of the reads hold 13 % of all nodes), and a depth-first walk of one read by one
-// lane takes as long as its node count.  A lane that has spent kShareNodes nodes on its current read therefore offers the BOTTOM frame of its
-// stack — the untried siblings of its shallowest branching node, the largest piece of work it still owns — to the lanes of its wave that
-// are out of work: the frame travels by lane shuffles, the staged read by an LDS column copy, no atomic and no global traffic beyond the
-// three frame words.  (A device-wide task queue was tried first: one queue head for thousands of waiting waves serialised the hand-over at
-// ~1.3 us per task — 2 M tasks, 8 s — and was dropped.)  This needs an order of the hit records that does not depend on who found them:
-constexpr uint32_t kShareNodes = 2;
-// ... and only from a read that has proven heavy: with offers from every read the hand-over ran in nearly every iteration of a wave (some lane is always
-// out of work) and cost more than it returned (uniform text, plain index: 56.8 -> 39.8 ms once reads of fewer than 64 nodes stopped offering)
-[[maybe_unused]] constexpr uint32_t kShareHeavy = 64;
-
-// Path key: the callback order of the reference is the depth-first order in which every node tries its match child first and its substitution
-// children in ascending symbol order (SearchNg26.h:171-218).  For hits of one read that is the lexicographic order of
-//   (search, [m - step of the 1st substitution, its symbol], [m - step of the 2nd substitution, its symbol])   with "no substitution" = 0:
-// a later first substitution is met earlier on the way back up.  24 bits per substitution; the key travels in fmgpu_hit::seq (low 32 bits) and
-// the upper 24 bits of fmgpu_hit::errors until fmgpu_hits_sort orders the records by (qidx, key) and turns it into the dense callback index.
-// the key of an ancestor that had made `e` substitutions: the fields of the later ones cleared (so frames need not carry keys)
-__device__ __forceinline__ uint64_t key_prefix(uint64_t key, uint32_t e) {
-    return e == 0u ? key & (0xffull << 48) : (e == 1u ? key & ~0xffffffull : key);
-}
-__device__ __forceinline__ uint64_t key_with(uint64_t key, uint32_t e_before, uint32_t m, uint32_t step, uint32_t symb) {
-    if (e_before >= 2u) return key;
-    return key | ((uint64_t)(((m - step) << 8) | symb) << (24u * (1u - e_before)));
-}
-
-
-
-// lane-interleaved frame stack: frame d of lane g at word (d * nlanes + g) of three u64 planes
-struct StackView { uint64_t *p0, *p1, *p2, *p3; uint64_t nlanes; uint32_t depth; };   // frame planes (the edit-distance kernels use the block as 32-byte records)
-
-struct Cur { idx_t lb, lbRev, len; };
-
-__device__ __forceinline__ void emit_hit(fmgpu_hit* out, uint64_t cap, Counters* ctr, uint64_t qidx, Cur c, uint32_t e, uint32_t seq) {
-    unsigned long long k = atomicAdd(&ctr->hits, 1ull);
-    if (k < cap) {
-        fmgpu_hit h;
-        h.qidx = qidx; h.lb = c.lb; h.lb_rev = c.lbRev; h.len = c.len; h.errors = e; h.seq = seq;
-        out[k] = h;
-    }
-}
-
-// ---- symbol sets and children ----------------------------------------------------------------------------------
-// MAXSIG <= 32: one register word, arrays stay in registers (fully unrolled selects).  MAXSIG = 256: eight words, the
-// LF arrays live in scratch and are indexed dynamically (the reference itself does O(sigma) work per extend-all).
-template <int MAXSIG>
-struct SymSet {
-    static constexpr int W = (MAXSIG + 31) / 32;
-    uint32_t w[W];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int i = 0; i < W; ++i) w[i] = 0;
-    }
-    __device__ __forceinline__ bool test(uint32_t s) const {
-        if (s >= (uint32_t)MAXSIG) return false;
-        if (W == 1) return (w[0] >> s) & 1u;
-        uint32_t r = 0;
-#pragma unroll
-        for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) r = w[i];
-        return (r >> (s & 31u)) & 1u;
-    }
-    __device__ __forceinline__ void remove(uint32_t s) {
-        if (s >= (uint32_t)MAXSIG) return;
-#pragma unroll
-        for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) w[i] &= ~(1u << (s & 31u));
-    }
-    __device__ __forceinline__ void insert(uint32_t s) {
-        if (s >= (uint32_t)MAXSIG) return;
-#pragma unroll
-        for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) w[i] |= 1u << (s & 31u);
-    }
-    __device__ __forceinline__ bool any() const {
-        uint32_t r = 0;
-#pragma unroll
-        for (int i = 0; i < W; ++i) r |= w[i];
-        return r != 0;
-    }
-    __device__ __forceinline__ uint32_t first() const {     // lowest member; caller checks any()
-        uint32_t r = 0xffffffffu;
-#pragma unroll
-        for (int i = W - 1; i >= 0; --i) if (w[i]) r = (uint32_t)i * 32u + (uint32_t)__ffs((int)w[i]) - 1u;
-        return r;
-    }
-    __device__ __forceinline__ void clear_below(uint32_t s) {   // drop members < s
-#pragma unroll
-        for (int i = 0; i < W; ++i) {
-            uint32_t lo = (uint32_t)i * 32u;
-            if (s >= lo + 32u) w[i] = 0;
-            else if (s > lo) w[i] &= ~((1u << (s - lo)) - 1u);
-        }
-    }
-};
-
-template <int MAXSIG>
-__device__ __forceinline__ SymSet<MAXSIG> alive_set(const idx_t* lfa, const idx_t* lfb, uint32_t sigma) {
-    SymSet<MAXSIG> m; m.clear();
-    if (MAXSIG <= 32) {
-#pragma unroll
-        for (uint32_t d = 0; d < (uint32_t)MAXSIG; ++d) if (d < sigma && lfb[d] != lfa[d]) m.w[0] |= 1u << d;
-    } else {
-        for (uint32_t d = 0; d < sigma; ++d) if (lfb[d] != lfa[d]) m.w[d >> 5] |= 1u << (d & 31u);
-    }
-    return m;
-}
-
-// kid cursor of symbol s from the LF values at both ends; `right` mirrors the roles (fmindex/BiFMIndexCursor.h:58-82)
-template <int MAXSIG>
-__device__ __forceinline__ Cur kid_of(const idx_t* lfa, const idx_t* lfb, Cur cur, uint32_t s, bool right, uint32_t sigma) {
-    idx_t pre = 0, la = 0, lb = 0;
-    if (MAXSIG <= 32) {
-#pragma unroll
-        for (uint32_t d = 0; d < (uint32_t)MAXSIG; ++d) {
-            if (d < s && d < sigma) pre += lfb[d] - lfa[d];
-            if (d == s) { la = lfa[d]; lb = lfb[d]; }
-        }
-    } else {
-        for (uint32_t d = 0; d < s; ++d) pre += lfb[d] - lfa[d];
-        la = lfa[s]; lb = lfb[s];
-    }
-    Cur k;
-    k.len = lb - la;
-    if (right) { k.lbRev = la; k.lb = cur.lb + pre; }
-    else       { k.lb = la; k.lbRev = cur.lbRev + pre; }
-    return k;
-}
-
-constexpr uint32_t kNoResume = 0xffffffffu;
-
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
-    uint32_t x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off, 64); if (lane >= (uint32_t)off) x += y; }
-    return x - v;
-}
-
-// ---- wave-level reservations for the DFS kernels ----------------------------------------------------------------------------------
-// One atomicAdd per hit (or per query handed out) queues millions of atomics behind each other on one address: ~9 ns each, more than the
-// searches themselves.  Instead every lane of a wave passes a synchronous section in each loop iteration (a lane without work idles until
-// the whole wave is done): queries are handed out with one reservation for all lanes that want one, and hit records go to a ring per WAVE in
-// LDS — the slot from an LDS atomic on the ring's fill count — that the whole wave writes out with ONE reservation once it holds kWaveRingFlush
-// records.  (Round 2 kept two slots per LANE and flushed when one lane's were full: a lane in a repeat fills its two while the other 63 are
-// empty — one reservation per ~6 records, 8.8 M returning atomics on one word per 10 M reads, near the ~88 M/s a single word sustains.)
-constexpr uint32_t kWaveHitBuf = 2;                               // (sizes the LDS area: 2 x 64 record slots per wave)
-constexpr uint32_t kHitWords = kWide ? 10u : 7u;                  // [qidx lo, qidx hi, lb, lbRev, len, e, seq (, high words of lb, lbRev, len)]
-constexpr uint32_t kWaveHitWords = kWaveHitBuf * kHitWords * 256u;   // per block: 4 waves x [word][128 slots]; slot 0 of word 0 is the ring's fill count
-constexpr uint32_t kWaveRingSlots = kWaveHitBuf * 64u - 1u;       // 127 records per wave
-constexpr uint32_t kWaveRingFlush = 64u;                          // written out once this many are waiting: 63 more fit (one per lane and iteration), a surplus goes out one by one
-typedef __attribute__((address_space(3))) uint32_t lds_word;
-
-__device__ __forceinline__ uint64_t wave_hand_out(bool want, Counters* ctr, uint32_t lane) {     // all lanes call; valid for lanes with `want`
-    const uint64_t wm = __ballot(want);
-    if (!wm) return 0;
-    const uint32_t leader = (uint32_t)__ffsll((unsigned long long)wm) - 1u;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(&ctr->next, (unsigned long long)__popcll(wm));
-    base = ((unsigned long long)__shfl((uint32_t)(base >> 32), leader, 64) << 32) | __shfl((uint32_t)base, leader, 64);
-    return base + (uint64_t)__popcll(wm & ((1ull << lane) - 1ull));
-}
-__device__ __forceinline__ uint32_t* wave_ring(uint32_t* s_hb) { return s_hb + (threadIdx.x >> 6) * (kWaveHitBuf * kHitWords * 64u); }
-__device__ __forceinline__ void wave_ring_init(uint32_t* s_hb) {  // every wave, before its first record (LDS operations of one wave execute in order)
-    if ((threadIdx.x & 63u) == 0) __hip_atomic_store((lds_word*)wave_ring(s_hb), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-__device__ __forceinline__ uint32_t wave_ring_fill(uint32_t* s_hb) {   // wave-uniform
-    return __hip_atomic_load((lds_word*)wave_ring(s_hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
-__device__ __forceinline__ void wave_keep_hit(uint32_t* s_hb, uint32_t& nh, fmgpu_hit* out, uint64_t cap, Counters* ctr, uint64_t q, Cur r, uint32_t e, uint32_t seq) {
-    uint32_t* ring = wave_ring(s_hb);
-    const uint32_t slot = 1u + __hip_atomic_fetch_add((lds_word*)ring, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    constexpr uint32_t W = kWaveHitBuf * 64u;                      // slots per word plane
-    if (slot <= kWaveRingSlots) {
-        uint32_t* h = ring + slot;
-        h[0] = (uint32_t)q; h[W] = (uint32_t)(q >> 32); h[2 * W] = (uint32_t)r.lb; h[3 * W] = (uint32_t)r.lbRev; h[4 * W] = (uint32_t)r.len; h[5 * W] = e; h[6 * W] = seq;
-        if constexpr (kWide) { h[7 * W] = (uint32_t)((uint64_t)r.lb >> 32); h[8 * W] = (uint32_t)((uint64_t)r.lbRev >> 32); h[9 * W] = (uint32_t)((uint64_t)r.len >> 32); }
-    } else emit_hit(out, cap, ctr, q, r, e, seq);                  // the ring is full (more than 63 records since the wave last looked): this one goes out alone
-    (void)nh;
-}
-__device__ __forceinline__ void wave_flush_hits(uint32_t* s_hb, uint32_t& nh, uint32_t lane, fmgpu_hit* out, uint64_t cap, Counters* ctr) {   // all lanes call
-    uint32_t* ring = wave_ring(s_hb);
-    const uint32_t total = min(wave_ring_fill(s_hb), kWaveRingSlots);
-    constexpr uint32_t W = kWaveHitBuf * 64u;
-    if (total) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->hits, (unsigned long long)total);
-        base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0, 64) << 32) | __shfl((uint32_t)base, 0, 64);
-        for (uint32_t k = 1u + lane; k <= total; k += 64u) {
-            const uint32_t* h = ring + k;
-            const unsigned long long at = base + (k - 1u);
-            if (at < cap) {
-                fmgpu_hit rec;
-                rec.qidx = (uint64_t)h[0] | ((uint64_t)h[W] << 32); rec.lb = h[2 * W]; rec.lb_rev = h[3 * W]; rec.len = h[4 * W];
-                if constexpr (kWide) { rec.lb |= (uint64_t)h[7 * W] << 32; rec.lb_rev |= (uint64_t)h[8 * W] << 32; rec.len |= (uint64_t)h[9 * W] << 32; }
-                rec.errors = h[5 * W]; rec.seq = h[6 * W];
-                out[at] = rec;
-            }
-        }
-        if (lane == 0) __hip_atomic_store((lds_word*)ring, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-    nh = 0;
-}
-
-
-// one-row cursors with the explicit LF table (DevString::lf_table): LF(row) in one 4-byte load; the row's symbol is the k with
-// C[k] <= LF(row) < C[k+1] (C staged in LDS)
-struct LfView { const idx_t* fw; const idx_t* rv; const idx_t* C; };
-__device__ __forceinline__ uint32_t symbol_of_lf_lds(const idx_t* sC, uint32_t sigma, idx_t t) {
-    uint32_t lo = 0, hi = sigma;                    // invariant: sC[lo] <= t < sC[hi]   (sC[sigma] = n > t)
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sC[mid] <= t) lo = mid; else hi = mid; }
-    return lo;
-}
-
-// eight query bytes -> eight nibbles (a byte >= sigma, sigma <= 15, becomes 15 = "not a symbol"), with word operations
-__device__ __forceinline__ uint32_t pack_nibbles8(uint64_t x, uint32_t sigma) {
-    const uint64_t k1 = 0x0101010101010101ull;
-    const uint64_t t = (((x & (0x7full * k1)) + (uint64_t)(0x80u - sigma) * k1) | x) & (0x80ull * k1);   // bit 7 of a byte set <=> byte >= sigma
-    uint64_t y = (x | ((t >> 7) * 0xffull)) & (0x0full * k1);
-    y = (y | (y >> 4)) & 0x00ff00ff00ff00ffull;
-    y = (y | (y >> 8)) & 0x0000ffff0000ffffull;
-    y = (y | (y >> 16)) & 0x00000000ffffffffull;
-    return (uint32_t)y;
-}
-// ---- per-lane query staging in LDS ------------------------------------------------------------------------------
-// A DFS visits a few hundred nodes per query; reading the query symbol of every node from global memory costs a
-// second random line per node (half a million lanes' query lines do not survive in L2).  Each lane therefore copies
-// its query once into LDS: word w of lane t at  lds[w * 256 + t]  (bank = t mod 32/64: conflict-free), 8 symbols per
-// word as nibbles (sigma <= 15; 15 = "not a symbol") or 4 symbols per word as bytes.
-struct QStage {
-    uint32_t* lds;          // this block's staging area
-    uint32_t words;         // words per query (0 = staging disabled: read global memory)
-    uint32_t nib;           // 1 = 4-bit symbols
-};
-__device__ __forceinline__ void qstage_load(const QStage& st, const uint8_t* qbuf, uint64_t off, uint32_t m, uint32_t sigma) {
-    if (!st.words) return;
-    const uint64_t addr = (uint64_t)qbuf + off;
-    const uint32_t mis = (uint32_t)(addr & 7ull);
-    const uint64_t* base = reinterpret_cast<const uint64_t*>(addr - mis);
-    const uint32_t last = (mis + m - 1u) >> 3;                     // last aligned word that holds query bytes (m >= 1)
-    uint64_t lo = base[0];
-    const uint32_t per = st.nib ? 8u : 4u;
-    uint32_t wi = 0;
-    for (uint32_t k = 0; k * 8u < m; ++k) {
-        uint64_t hi = (k + 1 <= last) ? base[k + 1] : 0ull;
-        uint64_t x = mis ? ((lo >> (8u * mis)) | (hi << (64u - 8u * mis))) : lo;   // query bytes 8k .. 8k+7
-        lo = hi;
-        if (st.nib) {
-            st.lds[wi * 256u + threadIdx.x] = pack_nibbles8(x, sigma); ++wi;
-        } else {
-            st.lds[wi * 256u + threadIdx.x] = (uint32_t)x; ++wi;
-            if ((k * 8u + 4u) < m) { st.lds[wi * 256u + threadIdx.x] = (uint32_t)(x >> 32); ++wi; }
-        }
-    }
-    (void)per;
-}
-__device__ __forceinline__ uint32_t qstage_get(const QStage& st, const uint8_t* qs, uint32_t p) {
-    if (!st.words) return qs[p];
-    if (st.nib) { uint32_t v = (st.lds[(p >> 3) * 256u + threadIdx.x] >> ((p & 7u) * 4u)) & 15u; return v == 15u ? 255u : v; }
-    return (st.lds[(p >> 2) * 256u + threadIdx.x] >> ((p & 3u) * 8u)) & 255u;
-}
-
-// ---- exact search over Format M (multi-ary wavelet tree) -----------------------------------------------------------
-// One LF step = one node rank per level (string/Wavelet.h:104-119 with the levels fused into digits of 3 / 2 bits): per level and interval end one
-// block of 64 positions = one memory line — the count of the digit value before the block and the digit's bit planes.  Both ends walk the same
-// node path; once the interval is short they sit in the same block and the second end re-uses the first end's loads.  The query is staged in
-// LDS, the node offsets and C[] too, so that the only global loads of a step are the block reads on the dependent chain.
-template <int D>
-__device__ __forceinline__ void load_block_m(const uint8_t* blk, uint32_t val, uint32_t& cnt, uint64_t (&pl)[3]) {
-    cnt = reinterpret_cast<const uint32_t*>(blk)[val];
-    if constexpr (D == 3) {
-        const uint4 x = *reinterpret_cast<const uint4*>(blk + 32); const uint2 y = *reinterpret_cast<const uint2*>(blk + 48);
-        pl[0] = (uint64_t)x.x | ((uint64_t)x.y << 32); pl[1] = (uint64_t)x.z | ((uint64_t)x.w << 32); pl[2] = (uint64_t)y.x | ((uint64_t)y.y << 32);
-    } else if constexpr (D == 2) {
-        const uint4 x = *reinterpret_cast<const uint4*>(blk + 16);
-        pl[0] = (uint64_t)x.x | ((uint64_t)x.y << 32); pl[1] = (uint64_t)x.z | ((uint64_t)x.w << 32); pl[2] = 0;
-    } else {
-        const uint2 x = *reinterpret_cast<const uint2*>(blk + 8);
-        pl[0] = (uint64_t)x.x | ((uint64_t)x.y << 32); pl[1] = 0; pl[2] = 0;
-    }
-}
-template <int D>
-__device__ __forceinline__ uint64_t match_m(const uint64_t (&pl)[3], uint32_t val) {
-    uint64_t m = pl[0] ^ (0ull - (uint64_t)(~val & 1u));
-    if constexpr (D >= 2) m &= pl[1] ^ (0ull - (uint64_t)((~val >> 1) & 1u));
-    if constexpr (D >= 3) m &= pl[2] ^ (0ull - (uint64_t)((~val >> 2) & 1u));
-    return m;
-}
-// one level of the descent for both interval ends
-template <int D, int SHIFT, int FIRST>
-__device__ __forceinline__ void level_m(const ViewM& v, const uint64_t* s_off, const uint32_t* nsup, const uint64_t* sup, uint32_t c, idx_t& a, idx_t& b, uint32_t& bytes, uint32_t& acc) {
-    constexpr uint32_t stride = D == 3 ? 64u : (D == 2 ? 32u : 16u);
-    const uint32_t val = (c >> SHIFT) & ((1u << D) - 1u), node = (uint32_t)FIRST + (c >> (SHIFT + D));
-    const uint8_t* nb = v.data + s_off[node];
-    uint32_t ca, cb; uint64_t pa[3], pb[3];
-    load_block_m<D>(nb + (size_t)(a >> 6) * stride, val, ca, pa);
-    bytes += 4u + 8u * D; ++acc;
-    if ((a >> 6) != (b >> 6)) { load_block_m<D>(nb + (size_t)(b >> 6) * stride, val, cb, pb); bytes += 4u + 8u * D; ++acc; }
-    else { cb = ca; pb[0] = pa[0]; pb[1] = pa[1]; pb[2] = pa[2]; }
-    idx_t xa = ca + popc64(match_m<D>(pa, val) & lowmask((uint32_t)a & 63u));
-    idx_t xb = cb + popc64(match_m<D>(pb, val) & lowmask((uint32_t)b & 63u));
-    if constexpr (kWide) {                                          // counts are relative to super-blocks of 2^30 positions: the rest from the super table (LDS when it is small)
-        const size_t row = nsup[node];
-        xa += (idx_t)sup[(row + (size_t)(a >> kSuperShift)) * 8u + val];
-        xb += (idx_t)sup[(row + (size_t)(b >> kSuperShift)) * 8u + val];
-    }
-    a = xa; b = xb;
-}
-template <int D0, int D1, int D2>
-__global__ __launch_bounds__(256) void k_exact_m(ViewM v, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
-                                                 uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len, unsigned long long* __restrict__ steps_total,
-                                                 uint32_t qwords, uint32_t super_rows) {
-    extern __shared__ uint32_t s_query[];
-    __shared__ uint64_t s_off[kMaxNodesM];
-    __shared__ idx_t s_C[257];
-    // 64-bit rows: the super table (a few rows of 8 counts per node: 13 rows for 4.5 x 10^9 residues) and the nodes' first rows staged in LDS — from global
-    // memory they were two more dependent loads per level and interval end on the chain of every LF step (protein_wide 0.41-0.46 of the roofline vs 0.56 with 32-bit rows)
-    constexpr uint32_t kSuperLds = kWide ? 96u : 1u;
-    __shared__ uint64_t s_sup[kSuperLds * 8u];
-    __shared__ uint32_t s_nsup[kWide ? kMaxNodesM : 1];
-    const uint32_t sigma = v.sigma;
-    for (uint32_t i = threadIdx.x; i < v.nnodes; i += blockDim.x) s_off[i] = v.node_off[i];
-    for (uint32_t i = threadIdx.x; i <= sigma; i += blockDim.x) s_C[i] = v.C[i];
-    const uint64_t* sup = nullptr; const uint32_t* nsup = nullptr;
-    if constexpr (kWide) {
-        for (uint32_t i = threadIdx.x; i < v.nnodes; i += blockDim.x) s_nsup[i] = v.node_super[i];
-        nsup = s_nsup; sup = v.super;
-        if (super_rows <= kSuperLds) { for (uint32_t i = threadIdx.x; i < super_rows * 8u; i += blockDim.x) s_sup[i] = v.super[i]; sup = s_sup; }
-    }
-    __syncthreads();
-    constexpr int BITCT = D0 + D1 + D2;
-    const QStage qst{s_query, qwords, 0u};
-    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0, bytes = 0, acc = 0;
-    if (q < nq) {
-        uint64_t o = qoff[q];
-        uint32_t m = (uint32_t)(qoff[q + 1] - o);
-        const uint8_t* qs = qbuf + o;
-        if (m) qstage_load(qst, qbuf, o, m, sigma);
-        idx_t a = 0, b = n;
-        for (uint32_t i = m; i-- > 0;) {
-            uint32_t c = qstage_get(qst, qs, i);
-            ++steps;
-            if (c >= sigma) { a = b = 0; break; }
-            level_m<D0, BITCT - D0, 0>(v, s_off, nsup, sup, c, a, b, bytes, acc);
-            if constexpr (D1 > 0) level_m<D1, BITCT - D0 - D1, 1>(v, s_off, nsup, sup, c, a, b, bytes, acc);
-            if constexpr (D2 > 0) level_m<D2, 0, 1 + (1 << D0)>(v, s_off, nsup, sup, c, a, b, bytes, acc);
-            a += s_C[c]; b += s_C[c];
-            if (a == b) break;
-        }
-        store_interval(out_lb, out_len, q, a, b - a);
-    }
-    add_counters(steps_total, steps, bytes, acc);
-}
 
 // ---- search_ng26 Hamming --------------------------------------------------------------------------------------
 template <class Occ, int MAXSIG>
@@ -1660,206 +861,6 @@ __device__ __forceinline__ uint32_t symbol_of_lf(const FastArgs& fa, const idx_t
     return b;
 }
 
-// wave-synchronous staging of one query per lane: all loads of a chunk are issued before the first is consumed
-__device__ __forceinline__ void qstage_load_sync(const QStage& st, const uint8_t* qbuf, uint64_t off, uint32_t m, uint32_t sigma, bool active, uint32_t maxm) {
-    if (!st.words) return;                                         // staging disabled (very long queries): qstage_get reads global memory
-    const uint64_t addr = (uint64_t)qbuf + off;
-    const uint32_t mis = (uint32_t)(addr & 7ull);
-    const uint64_t* base = reinterpret_cast<const uint64_t*>(addr - mis);
-    const uint32_t nw = active ? ((mis + m + 7u) >> 3) : 0u;        // aligned 64-bit words that hold query bytes
-    uint64_t carry = 0;
-    uint32_t wi = 0;
-    for (uint32_t k0 = 0; k0 <= ((maxm + 14u) >> 3); k0 += 8) {     // uniform trip count (maxm >= every lane's m); word nw flushes the last bytes
-        uint64_t r[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) r[k] = (k0 + k < nw) ? base[k0 + k] : 0ull;
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            // query bytes 8(k0+k-1) .. +7 are completed by word k0+k:  x = (carry >> 8mis) | (r[k] << (64 - 8mis))
-            const uint32_t widx = k0 + k;
-            if (widx == 0) { carry = r[k]; continue; }
-            uint64_t x = mis ? ((carry >> (8u * mis)) | (r[k] << (64u - 8u * mis))) : carry;
-            carry = r[k];
-            const uint32_t p0 = (widx - 1u) * 8u;                   // first query position in x
-            if (active && p0 < m) {
-                if (st.nib) {
-                    st.lds[wi * 256u + threadIdx.x] = pack_nibbles8(x, sigma); ++wi;
-                } else {
-                    st.lds[wi * 256u + threadIdx.x] = (uint32_t)x; ++wi;
-                    if (p0 + 4u < m) { st.lds[wi * 256u + threadIdx.x] = (uint32_t)(x >> 32); ++wi; }
-                }
-            }
-        }
-    }
-}
-
-
-// ---- exact search over the multi-symbol-step table (fmgpu_index_accelerate) ---------------------------------------
-// One table entry advances the cursor by K query symbols, so a query touches 1/K as many lines.  A chunk that holds a
-// symbol outside [1, sigma), or that empties the interval, is (re-)walked with single steps so that the reported cursor
-// and step count are exactly those of search/SearchNoErrors.h:12-26.  The query is staged in LDS up front (one query per
-// lane: the staging is wave-synchronous by construction); the next chunk's context code is fetched from LDS while the
-// table entries of the current chunk are in flight, and both interval ends are loaded together.
-// the 16 query symbols of a stretch as a 32-bit code (2 bits per symbol, the symbol consumed first in the low bits), from the nibble staging:
-// pos = query position of the stretch's first step, right = positions ascend.  valid = all 16 symbols are in 1 .. 4.
-__device__ __forceinline__ uint32_t query_code16(const QStage& qst, uint32_t pos, bool right, bool& valid) {
-    const uint32_t p0 = right ? pos : pos - 15u;                 // lowest query position of the stretch
-    const uint32_t w0 = qst.lds[(p0 >> 3) * 256u + threadIdx.x], w1 = qst.lds[((p0 >> 3) + 1u) * 256u + threadIdx.x];
-    const uint32_t w2 = (p0 & 7u) ? qst.lds[((p0 >> 3) + 2u) * 256u + threadIdx.x] : 0u;
-    const uint32_t sh = 4u * (p0 & 7u);
-    uint64_t x = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh;
-    if (sh) x |= (uint64_t)w2 << (64u - sh);
-    const uint64_t v = x - 0x1111111111111111ull;                // nibbles 1..4 -> 0..3
-    valid = ((v & ~x & 0x8888888888888888ull) == 0ull) && ((v & 0xccccccccccccccccull) == 0ull);
-    uint64_t t = v & 0x3333333333333333ull;
-    t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full; t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
-    t = (t | (t >> 8)) & 0x0000ffff0000ffffull; t = (t | (t >> 16)) & 0x00000000ffffffffull;
-    uint32_t qc = (uint32_t)t;                                   // symbol at position p0 + k in bits 2k
-    if (!right) { qc = __brev(qc); qc = ((qc >> 1) & 0x55555555u) | ((qc & 0x55555555u) << 1); }   // ... at position pos - k
-    return qc;
-}
-
-struct ExactAccel {                                 // (entry shapes by row width: fmgpu_common.h)
-    const uint8_t* kblk; uint32_t K, ncodes;        // k-symbol-step table (or null; 32-bit rows only)
-    const void* slut; uint32_t lutL;                // interval of the query's last lutL symbols (or null)
-    const void* walk; uint32_t J, wbits;            // per row LF^J + the J symbols met (or null)
-    const void* walk2;                              // per row LF^(2J) + the 2J symbols met as two codes (or null)
-};
-
-template <class Occ>
-__global__ __launch_bounds__(256) void k_exact_kstep(Occ occ, ExactAccel ac, uint32_t R,
-                                                     const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
-                                                     uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
-                                                     unsigned long long* __restrict__ steps_total, uint32_t qwords, uint32_t qnib, uint32_t maxm) {
-    extern __shared__ uint32_t s_dyn[];
-    const QStage qst{s_dyn, qwords, qnib};
-    uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = q < nq;
-    const uint64_t o = active ? qoff[q] : 0;
-    const uint32_t m = active ? (uint32_t)(qoff[q + 1] - o) : 0;
-    const uint8_t* sq = qbuf + o;
-    const uint32_t sigma = occ.sigma();
-    const uint32_t K = ac.K, ncodes = ac.ncodes;
-    qstage_load_sync(qst, qbuf, o, m, sigma, active && m != 0, maxm);
-    uint32_t steps = 0, tbytes = 0, tacc = 0;          // executed extensions; table bytes consumed / table accesses issued (fmgpu_stats)
-    if (active) {
-        idx_t lb = 0, len = n;
-        uint32_t done = 0;                                       // symbols consumed (from the right end)
-        // code of the `cnt` symbols ending at position m-1-from, radix R (tables indexed by contexts) or `shift` bits per symbol (walk table)
-        auto code_of = [&](uint32_t from, uint32_t cnt, uint32_t shift, bool& valid) -> uint32_t {
-            uint32_t code = 0, mul = 1; valid = m - from >= cnt;
-            if (valid) for (uint32_t t = 0; t < cnt; ++t) {
-                uint32_t c = qstage_get(qst, sq, m - 1 - from - t);
-                valid = valid && c >= 1 && c < sigma;
-                if (shift) code |= (c - 1) << (shift * t); else { code += (c - 1) * mul; mul *= R; }
-            }
-            return code;
-        };
-        if (ac.slut && n > 1) {                                  // the last lutL symbols at once; an empty entry is walked step by step instead
-            bool v = false;                                      // (the reference's cursor and step count at the failing step are part of the result)
-            uint32_t code;
-            if (qst.words && qst.nib && R == 4u && ac.lutL <= 16u && m >= 16u) {       // radix 4 = 2 bits per symbol: the word-level code, cut to lutL symbols
-                code = query_code16(qst, m - 1u, false, v);
-                if (ac.lutL < 16u) code &= (1u << (2u * ac.lutL)) - 1u;
-                if (!v) code = code_of(0, ac.lutL, 0, v);       // (an odd symbol among the 16: decide on the lutL symbols alone)
-            } else code = code_of(0, ac.lutL, 0, v);
-            if (v) {
-                idx_t elb, elen;
-                if constexpr (kWide) { const ulonglong2 en = reinterpret_cast<const ulonglong2*>(ac.slut)[code]; elb = (idx_t)en.x; elen = (idx_t)en.y; }
-                else { const uint2 en = reinterpret_cast<const uint2*>(ac.slut)[code]; elb = en.x; elen = en.y; }
-                tbytes += (uint32_t)kSlutEntryBytes; ++tacc;
-                if (elen != 0) { lb = elb; len = elen; done = ac.lutL; steps = ac.lutL; }
-            }
-        }
-        // main phase: one table load per iteration.  One row left: J (or 2J) symbols per load from the walk tables; otherwise K symbols from the
-        // context table.  A step that would empty the interval (or meets an odd symbol) ends the phase WITHOUT touching the cursor:
-        // its single-step walk is left to the tail phase, where the lanes of the wave are convergent again.
-        // The lanes of a wave sit in different kinds of steps, so an iteration first decides every lane's kind and address (registers and LDS
-        // only), then issues ONE 16-byte load for all of them (every table entry is dword-aligned and the tables carry 16 bytes of slack),
-        // and only then looks at what came back: one memory round trip per iteration instead of one per kind of step present in the wave.
-        const bool nib16 = qst.words && qst.nib && ac.wbits == 2u && ac.J == 16u;         // DNA: 16 staged nibbles -> one 32-bit code with a few word operations
-        // A walk entry whose symbols differ from the query's tells where: the symbols before that place are matches and still go K at a time
-        // through the context table (walks switched off up to `limit`); only the differing step itself and < K symbols before it are single steps.
-        bool walks = true; uint32_t limit = 0;
-        for (;;) {
-            uint32_t kind = 0, q0 = 0, q1 = 0;                  // 1: 2J symbols, 2: J symbols, 3: K symbols from the context table
-            const uint8_t* p0 = nullptr;
-            const idx_t a = lb, b = lb + len;
-            if (!walks) {
-                bool valid = false;
-                if (!ac.kblk || done + K > limit) break;
-                const uint32_t code = code_of(done, K, 0, valid);
-                if (!valid) break;
-                kind = 3; p0 = ac.kblk + (size_t)code * 16u + (size_t)(a >> 6) * ((size_t)ncodes * 16u);
-            } else if (ac.walk2 && len == 1 && m - done >= 2u * ac.J) {
-                bool v0 = false, v1 = false;
-                q0 = nib16 ? query_code16(qst, m - 1u - done, false, v0) : code_of(done, ac.J, ac.wbits, v0);
-                q1 = nib16 ? query_code16(qst, m - 17u - done, false, v1) : code_of(done + ac.J, ac.J, ac.wbits, v1);
-                if (!(v0 && v1)) break;
-                kind = 1; p0 = reinterpret_cast<const uint8_t*>(ac.walk2) + (size_t)lb * kWalk2EntryBytes;
-            } else if (ac.walk && len == 1 && m - done >= ac.J) {
-                bool v = false;
-                q0 = nib16 ? query_code16(qst, m - 1u - done, false, v) : code_of(done, ac.J, ac.wbits, v);
-                if (!v) break;
-                kind = 2; p0 = reinterpret_cast<const uint8_t*>(ac.walk) + (size_t)lb * kWalkEntryBytes;
-            } else if (ac.kblk) {
-                bool valid = false;
-                const uint32_t code = code_of(done, K, 0, valid);
-                if (!valid) break;
-                kind = 3; p0 = ac.kblk + (size_t)code * 16u + (size_t)(a >> 6) * ((size_t)ncodes * 16u);      // same 12-byte entry shape as Format A
-            } else {                                             // no context table: one symbol per iteration from the occurrence table itself
-                if (done >= m) break;
-                const uint32_t c = qstage_get(qst, sq, m - 1 - done);
-                if (c >= sigma) break;
-                idx_t ra, rb;
-                occ.lf2(lb, lb + len, c, ra, rb);
-                tbytes += 24u; tacc += 2u;
-                if (rb == ra) break;
-                lb = ra; len = rb - ra; ++steps; ++done;
-                continue;
-            }
-            const uint4 r0 = *reinterpret_cast<const uint4*>(p0);
-            uint4 r1 = r0;
-            tbytes += kind == 2u ? (uint32_t)kWalkEntryBytes : (kind == 1u ? (uint32_t)kWalk2EntryBytes : 12u); ++tacc;
-            // the entry's fields by row width: the row reached (all ones: a delimiter on the way) and the code(s) of the symbols met
-            const bool w_none = kWide ? (r0.x == 0xffffffffu && r0.y == 0xffffffffu) : r0.x == 0xffffffffu;
-            const idx_t w_row = kWide ? (idx_t)((uint64_t)r0.x | ((uint64_t)r0.y << 32)) : (idx_t)r0.x;
-            const uint32_t w_c0 = kWide ? r0.z : r0.y, w_c1 = kWide ? r0.w : r0.z;
-            if (kind == 3u && (a >> 6) != (b >> 6)) { r1 = *reinterpret_cast<const uint4*>(p0 + ((size_t)(b >> 6) - (size_t)(a >> 6)) * ((size_t)ncodes * 16u)); tbytes += 12u; ++tacc; }
-            if (kind == 1u) {
-                if (w_none) break;
-                if (w_c0 != q0 || w_c1 != q1) {                  // symbols matching before the first differing one
-                    const uint32_t same = w_c0 != q0 ? ((uint32_t)__ffs((int)(w_c0 ^ q0)) - 1u) / ac.wbits : ac.J + ((uint32_t)__ffs((int)(w_c1 ^ q1)) - 1u) / ac.wbits;
-                    walks = false; limit = done + same;
-                    continue;
-                }
-                lb = w_row; done += 2u * ac.J; steps += 2u * ac.J;
-            } else if (kind == 2u) {
-                if (w_none) break;
-                if (w_c0 != q0) { walks = false; limit = done + ((uint32_t)__ffs((int)(w_c0 ^ q0)) - 1u) / ac.wbits; continue; }
-                lb = w_row; done += ac.J; steps += ac.J;
-            } else {
-                const idx_t ra = r0.x + popc64(((uint64_t)r0.y | ((uint64_t)r0.z << 32)) & lowmask(a & 63u));
-                const idx_t rb = r1.x + popc64(((uint64_t)r1.y | ((uint64_t)r1.z << 32)) & lowmask(b & 63u));
-                if (rb == ra) break;
-                lb = ra; len = rb - ra; steps += K; done += K;
-            }
-        }
-        // tail phase: single steps — the step that failed in a table (until the interval is empty), the symbols after an odd one,
-        // or the left-over symbols
-        while (len != 0 && done < m) {
-            uint32_t c = qstage_get(qst, sq, m - 1 - done);
-            ++steps; ++done;
-            if (c >= sigma) { lb = 0; len = 0; break; }
-            idx_t ra, rb;
-            occ.lf2(lb, lb + len, c, ra, rb);
-            tbytes += 24u; tacc += 2u;
-            lb = ra; len = rb - ra;
-        }
-        store_interval(out_lb, out_len, q, lb, len);
-    }
-    add_counters(steps_total, steps, tbytes, tacc);
-}
 
 #if !FMGPU_WIDE   // ======== 32-bit rows only: the table-driven k-mismatch kernels (LF / walk / prefix tables, their frames and transport words hold 32-bit rows)
 // when a wave fetches and stages new queries (a wave-synchronous phase of ~15 loads and LDS stores per lane, paid by all 64 lanes): when the
@@ -2730,6 +1731,7 @@ struct LeanArgs {
     uint32_t super_rows;
     const uint4* dfw; const uint4* drv;               // Format D blocks (DENSE instantiation), two uint4 per 64 rows
     const uint32_t* ex_fw; const uint32_t* ex_rv; uint32_t nex_fw, nex_rv;   // ... and their delimiter rows, ascending
+    const uint4* lut; uint32_t lutL, lut_ok;          // prefix table (fmgpu_index_accelerate_search(h, L <= 16, 0): the bidirectional interval of every string of lutL symbols, or null); bit s: search s may start from it
 };
 // a frame as two 64-bit words (what travels between lanes when a subtree is handed over) <-> its fields
 __device__ __forceinline__ void lean_pack(idx_t lb, idx_t lbRev, idx_t len, uint32_t j, uint32_t e, uint32_t next, uint64_t& w0, uint64_t& w1) {
@@ -2862,6 +1864,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
 
     const uint32_t gid = blockIdx.x * 256u + tid;                   // frame d of this lane at frames[d * nlanes + gid]
     uint32_t nodes = 0, mark = 0, waste = 0, nodes0 = 0;            // nodes0: the lane's count when it took its current read (or subtree)
+    uint32_t lut_nodes = 0;                                         // nodes that prefix-table entries stood for (fmgpu_stats::table_steps)
     uint32_t blk_loads = 0, multi_nodes = 0;                        // blocks this lane fetched (a second end in another block counts) / visited nodes of several rows: fmgpu_stats::table_accesses, ::table_bytes
 #ifdef FMGPU_DEV_STAMPS
     unsigned long long st_top = 0, st_share = 0, st_refill = 0, st_sync = 0, st_issue = 0, st_wait = 0, st_node = 0, st_tail = 0, st_t = __builtin_amdgcn_s_memtime(), st_steps = 0;
@@ -2964,13 +1967,21 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         ++st_steps;
 #endif
         // ---- one node per lane
+        bool lut_start = false; uint32_t lut_code = 0;
         if (need_start) {                                           // search_impl (SearchNg26.h:385-390) -> run(): :62-79
             need_start = false;
             lb = 0; lbRev = 0; len = n; e = 0; j = 0; sp = 0; sbase = 0; resume = kLeanNoResume; in_tail = false;
             k1 = 0; k2 = 0;
+            // the always-exact first part of the search (u[0] = 0; it extends to the right, so its first lutL symbols are consecutive in the read) starts from its entry of
+            // the prefix table: this iteration's ONE load is that entry instead of a block, and lutL nodes — the ones whose interval ends lie furthest apart — are not walked
+            if (la.lut && ((la.lut_ok >> si) & 1u) && !odd) {
+                const uint32_t p0 = s_steps[si * stride] & 0xffffu, w = p0 >> 4;
+                lut_code = __funnelshift_r(s_dyn[w * 256u + tid], s_dyn[(w + 1u) * 256u + tid], (p0 & 15u) * 2u) & (la.lutL >= 16u ? 0xffffffffu : (1u << (2u * la.lutL)) - 1u);
+                lut_start = true;
+            }
         }
         const uint32_t ent = s_steps[si * stride + j];
-        const bool right = (ent >> 16) & 1u, multi = len > 1u;
+        const bool right = (ent >> 16) & 1u, multi = !lut_start && len > 1u;
 #ifdef FMGPU_DEV
         dev_multi += multi ? 1u : 0u; ++dev_busy; if (lane == (uint32_t)__ffsll((unsigned long long)__ballot(true)) - 1u) ++dev_iter;
 #endif
@@ -2979,14 +1990,14 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         // memory phase: the entries of symbols 1..4 of the block(s) of both interval ends (one end for a one-row node) — Format A: 48 bytes, 12 into the 64-byte
         // block; Format D: the whole 32-byte block
         constexpr uint32_t kBlk = DENSE ? 32u : 64u, kOff = DENSE ? 0u : 12u;
-        const Quad4* pa = reinterpret_cast<const Quad4*>(blk + (size_t)(a >> 6) * kBlk + kOff);
-        const Quad4 a0 = pa[0], a1 = pa[1];
+        const Quad4* pa = lut_start ? reinterpret_cast<const Quad4*>(la.lut + lut_code) : reinterpret_cast<const Quad4*>(blk + (size_t)(a >> 6) * kBlk + kOff);
+        const Quad4 a0 = pa[0], a1 = pa[1];                         // (a table entry is 16 bytes: what follows it is read and ignored — the tables carry that much slack)
         Quad4 a2, b0, b1, b2;                                       // (only a multi-row node reads b: no default, or the compiler waits for A before it asks for B)
         if constexpr (!DENSE) a2 = pa[2];
         // the second end's block only when it is another one (the ends of a short interval share their block)
         const bool far = multi && (a >> 6) != (b >> 6);
         if (far) { const Quad4* pb = reinterpret_cast<const Quad4*>(blk + (size_t)(b >> 6) * kBlk + kOff); b0 = pb[0]; b1 = pb[1]; if constexpr (!DENSE) b2 = pb[2]; }
-        blk_loads += far ? 2u : 1u;
+        blk_loads += lut_start ? 0u : (far ? 2u : 1u);
         STAMP(st_issue);
 #ifdef FMGPU_DEV_STAMPS
         __builtin_amdgcn_s_waitcnt(0x0f70); STAMP(st_wait);
@@ -3030,6 +2041,11 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         }
         bool back = false, search_over = false;
         const bool mOK = minE <= e && e <= maxE, sOK = minE <= e + 1u && e + 1u <= maxE, xOK = e + 1u <= maxE;
+        if (lut_start) {                                            // {lb, lbRev, len, nodes the walk of these symbols visits (fewer than lutL where the interval empties on the way)}
+            lb = (idx_t)a0.x; lbRev = (idx_t)a0.y; len = (idx_t)a0.z; nodes += a0.w; lut_nodes += a0.w;
+            j = la.lutL; in_tail = true;                            // (the first part is longer than lutL: the rest of it is exact too)
+            if (len == 0u) back = true;
+        } else
         if (multi) {
             // ---- extend-all node (search_next_dir, :143-224) or exact-tail step over several rows
             if (!far) { b0 = a0; b1 = a1; if constexpr (!DENSE) b2 = a2; }   // (after the loads have been waited for: selects, no copy ahead of the second end's loads)
@@ -3173,6 +2189,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     { const uint32_t a1 = wave_sum(blk_loads), a2 = wave_sum(multi_nodes);
       if (lane == 0 && (a1 | a2)) { atomicAdd(&ctr->table_accesses, (unsigned long long)a1); atomicAdd(&ctr->table_bytes, (unsigned long long)a2); } }
 #endif
+    { const uint32_t a3 = wave_sum(lut_nodes); if (lane == 0 && a3) atomicAdd(reinterpret_cast<unsigned long long*>(ctr) + 21, (unsigned long long)a3); }
 }
 
 
@@ -3258,296 +2275,6 @@ __global__ __launch_bounds__(256) void k_backtracking(Occ fw, bool bidir, const 
     if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(&ctr->nodes, (unsigned long long)tot);
 }
 
-// ------------------------------------------------------------------ locate
-#if !FMGPU_WIDE
-// with the per-row answer table (fmgpu_index_accelerate_locate): one 12-byte load per row
-__global__ __launch_bounds__(256) void k_locate_tab(const uint32_t* __restrict__ tab, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
-                                                    uint64_t* __restrict__ out_seq, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_steps,
-                                                    unsigned long long* __restrict__ steps_total) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0;
-    if (t < count) {
-        uint64_t r = rows[t], seq = ~0ull, pos = ~0ull, st = ~0ull;
-        if (r < n) {
-            const uint32_t* p = tab + 3u * (size_t)r;
-            const uint32_t a = p[0], b = p[1], c = p[2];
-            if (c != 0xffffffffu) { seq = a; pos = b; st = c; steps = c; }
-        }
-        out_seq[t] = seq; out_pos[t] = pos; out_steps[t] = st;
-    }
-    add_counters(steps_total, steps, 0u, 0u);
-}
-
-#endif
-constexpr uint32_t kLocateStepCap = 1u << 24;   // a valid index reaches a sampled row long before; bounds a corrupt one
-
-// FMIndex::locate on a Format A table with fused presence bits (sigma <= 5; fmgpu_common.h): ONE 64-byte block per step answers "is this row
-// sampled", "which symbol precedes it" and "where does that lead" (fmindex/FMIndex.h:113-124 with suffixarray/SparseArray.h:63-70's presence test
-// read from the block); the Bitvector2L rank and the two DenseVector reads happen once, at the sampled row.
-template <int SIGMA>
-__global__ __launch_bounds__(256) void k_locate_fused(OccA<SIGMA> occ, ViewSA sa, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
-                                                      uint64_t* __restrict__ out_seq, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_steps,
-                                                      unsigned long long* __restrict__ steps_total) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0;
-    if (t < count) {
-        uint64_t r64 = rows[t];
-        uint64_t seq = ~0ull, pos = ~0ull, st = ~0ull;
-        if (r64 < n) {
-            idx_t row = (idx_t)r64;
-            bool found = false;
-            uint64_t k = 0;
-            const uint32_t s = occ.sigma();
-            while (steps < kLocateStepCap) {
-                const uint4* p = reinterpret_cast<const uint4*>(occ.v.blk + (size_t)(row >> 6) * 64u);
-                const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];             // the whole block: one line
-                const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-                const uint32_t bit = (uint32_t)row & 63u;
-                const uint64_t present = (uint64_t)d[1] | ((uint64_t)d[2] << 32);
-                if ((present >> bit) & 1ull) {
-                    found = true;
-                    if constexpr (!kWide) k = (uint64_t)d[15] + popc64(present & lowmask(bit));      // sampled rows before this one: the block's own count + its presence bits
-                    break;
-                }
-                idx_t next = row + occ.v.ksum;                                   // the delimiter's LF unless a symbol >= 1 claims the row
-                bool claimed = false;
-#pragma unroll
-                for (uint32_t c = 1; c < (uint32_t)(SIGMA > 0 ? SIGMA : 5); ++c) {
-                    if (c < s) {
-                        const uint64_t bits = (uint64_t)d[3 * c + 1] | ((uint64_t)d[3 * c + 2] << 32);
-                        idx_t lfc = d[3 * c] + popc64(bits & lowmask(bit));
-                        if constexpr (kWide) lfc += occ.v.super[(size_t)(row >> kSuperShift) * s + c];
-                        if ((bits >> bit) & 1ull) { claimed = true; next = lfc; }
-                        else if (!claimed) next -= lfc;
-                    }
-                }
-                row = next;
-                ++steps;
-            }
-            if (found) {
-                if constexpr (kWide) k = sa_rank(sa, row);
-                seq = dense_access(sa.f0, sa.bits0, sa.div0, k);
-                pos = dense_access(sa.f1, sa.bits1, sa.div1, k);
-                st = steps;
-            }
-        }
-        out_seq[t] = seq; out_pos[t] = pos; out_steps[t] = st;
-    }
-    add_counters(steps_total, steps, 0u, 0u);
-}
-
-// The same walk with the blocks fetched by the four lanes of a QUAD together and the rows of a wave handed out as lanes fall idle.  k_locate_fused keeps one
-// row per lane: the rows of a wave need 0..15 steps, so half of the lanes idle while the slowest walks, and every lane reads its 64-byte block with four
-// 16-byte loads of its own (four address translations and four passes through the texture path per block, on a table of 3-4 GB: fmgpu_common.h / DESIGN 4.3).
-// Here a wave owns kLocChunk rows, staged in LDS; a lane that reaches its sampled row parks the result in the row's LDS slot and takes the next unassigned row
-// (ballot + prefix count: no atomic); instruction k of a round has the four lanes of every quad load the four 16-byte pieces of the block of the quad's
-// lane k straight into LDS (one 64-byte request and one translation per block); the owner reads its block from there.  The value words (two DenseVector
-// reads per row) are fetched after the walk, by all lanes at once.  The loop is wave-uniform; waves never synchronise with each other.
-constexpr uint32_t kLocChunk = 512;                  // rows per wave
-constexpr uint32_t kLocRegion = 1024u + 16u;         // bytes per region of a round (64 pieces + padding that spreads the owners' reads over the LDS banks)
-constexpr uint32_t kLocSlotWords = kWide ? 4u : 2u;  // a row's LDS slot: the row, later {rank among the sampled rows (32-bit rows) or the sampled row itself, steps}
-constexpr uint32_t kLocWaveWords = 4u * (kLocRegion / 4u) + kLocChunk * kLocSlotWords;
-constexpr uint32_t kLocNoSteps = 0xffffffffu;
-template <int SIGMA>
-__global__ __launch_bounds__(256) void k_locate_coop(OccA<SIGMA> occ, ViewSA sa, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
-                                                     uint64_t* __restrict__ out_seq, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_steps,
-                                                     unsigned long long* __restrict__ steps_total) {
-    extern __shared__ uint32_t s_loc[];                             // per wave: 4 regions | kLocChunk slots
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* const wbase = s_loc + wave * kLocWaveWords;
-    lds_word* const wave_lds = (lds_word*)wbase;
-    uint32_t* const slots = wbase + 4u * (kLocRegion / 4u);
-    const lds_word* const own = wave_lds + (lane & 3u) * (kLocRegion / 4u) + (lane >> 2) * 16u;
-    const uint64_t base = ((uint64_t)blockIdx.x * 4u + wave) * kLocChunk;
-    const uint32_t cnt = base < count ? (uint32_t)min((uint64_t)kLocChunk, count - base) : 0u;
-    for (uint32_t t = lane; t < cnt; t += 64u) {
-        const uint64_t r = rows[base + t];
-        if constexpr (kWide) { slots[4u * t] = (uint32_t)r; slots[4u * t + 1u] = (uint32_t)(r >> 32); slots[4u * t + 2u] = r < n ? 0u : kLocNoSteps; }
-        else { slots[2u * t] = (uint32_t)r; slots[2u * t + 1u] = r < n ? 0u : kLocNoSteps; }
-    }
-    const uint32_t s = occ.sigma();
-    uint32_t next = 0, my = 0, steps = 0, total_steps = 0;
-    idx_t row = 0;
-    bool active = false;
-    const uint64_t below = (1ull << lane) - 1ull;
-    for (;;) {
-        const uint64_t idle = __ballot(!active);
-        if (idle && next < cnt) {                                   // the i-th idle lane takes row next + i of the chunk
-            const uint32_t at = next + (uint32_t)__popcll(idle & below);
-            if (!active && at < cnt) {
-                const uint32_t* e = slots + (size_t)at * kLocSlotWords;
-                if (e[kLocSlotWords - (kWide ? 2u : 1u)] != kLocNoSteps) {      // (a row beyond the index keeps its "no answer" mark)
-                    if constexpr (kWide) row = (idx_t)e[0] | ((idx_t)e[1] << 32); else row = (idx_t)e[0];
-                    my = at; steps = 0; active = true;
-                }
-            }
-            next = min(cnt, next + (uint32_t)__popcll(idle));
-        }
-        if (!__ballot(active)) { if (next >= cnt) break; continue; }
-        const uint32_t blk = active ? (uint32_t)(row >> 6) : 0u;    // (n < 2^38: a block number fits 32 bits; an idle lane rides along with block 0)
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t l = __shfl(blk, (int)((lane & ~3u) | k), 64);
-            const uint8_t* g = occ.v.blk + (size_t)l * 64u + (lane & 3u) * 16u;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(wave_lds + k * (kLocRegion / 4u)), 16, 0, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): the round's pieces are in LDS
-        asm volatile("" ::: "memory");
-        if (active) {
-            const flat_u32x4 q0 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own), q1 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 4);
-            const flat_u32x4 q2 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 8), q3 = *reinterpret_cast<const __attribute__((address_space(3))) flat_u32x4*>(own + 12);
-            const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-            const uint32_t bit = (uint32_t)row & 63u;
-            const uint64_t present = (uint64_t)d[1] | ((uint64_t)d[2] << 32);
-            uint32_t* e = slots + (size_t)my * kLocSlotWords;
-            if ((present >> bit) & 1ull) {                          // the sampled row: park the answer's coordinates in the slot
-                if constexpr (kWide) { e[0] = (uint32_t)row; e[1] = (uint32_t)((uint64_t)row >> 32); e[2] = steps; }
-                else { e[0] = d[15] + popc64(present & lowmask(bit)); e[1] = steps; }      // sampled rows before this one: the block's own count + its presence bits
-                active = false;
-            } else {
-                idx_t nxt = row + occ.v.ksum;                       // the delimiter's LF unless a symbol >= 1 claims the row
-                bool claimed = false;
-#pragma unroll
-                for (uint32_t c = 1; c < (uint32_t)(SIGMA > 0 ? SIGMA : 5); ++c) {
-                    if (c < s) {
-                        const uint64_t bits = (uint64_t)d[3 * c + 1] | ((uint64_t)d[3 * c + 2] << 32);
-                        idx_t lfc = d[3 * c] + popc64(bits & lowmask(bit));
-                        if constexpr (kWide) lfc += occ.v.super[(size_t)(row >> kSuperShift) * s + c];
-                        if ((bits >> bit) & 1ull) { claimed = true; nxt = lfc; }
-                        else if (!claimed) nxt -= lfc;
-                    }
-                }
-                row = nxt;
-                ++steps; ++total_steps;
-                if (steps >= kLocateStepCap) { e[kLocSlotWords - (kWide ? 2u : 1u)] = kLocNoSteps; active = false; }     // (a corrupt index: no answer)
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): the next round overwrites the regions
-        asm volatile("" ::: "memory");
-    }
-    for (uint32_t t = lane; t < cnt; t += 64u) {                    // the values of the sampled rows (suffixarray/SparseArray.h:63-70), all lanes at once
-        const uint32_t* e = slots + (size_t)t * kLocSlotWords;
-        uint64_t seq = ~0ull, pos = ~0ull, st = ~0ull;
-        const uint32_t ns = e[kLocSlotWords - (kWide ? 2u : 1u)];
-        if (ns != kLocNoSteps) {
-            uint64_t k;
-            if constexpr (kWide) k = sa_rank(sa, (idx_t)e[0] | ((idx_t)e[1] << 32)); else k = e[0];
-            seq = dense_access(sa.f0, sa.bits0, sa.div0, k);
-            pos = dense_access(sa.f1, sa.bits1, sa.div1, k);
-            st = ns;
-        }
-        out_seq[base + t] = seq; out_pos[base + t] = pos; out_steps[base + t] = st;
-    }
-    add_counters(steps_total, total_steps, 0u, 0u);
-}
-
-template <class Occ>
-__global__ __launch_bounds__(256) void k_locate(Occ occ, const idx_t* __restrict__ lf_table, ViewSA sa, const uint64_t* __restrict__ rows, uint64_t count, idx_t n,
-                                                uint64_t* __restrict__ out_seq, uint64_t* __restrict__ out_pos, uint64_t* __restrict__ out_steps,
-                                                unsigned long long* __restrict__ steps_total) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t steps = 0;
-    if (t < count) {
-        uint64_t r64 = rows[t];
-        uint64_t seq = ~0ull, pos = ~0ull, st = ~0ull;
-        if (r64 < n) {
-            idx_t row = (idx_t)r64;
-            while (!sa_present(sa, row) && steps < kLocateStepCap) {    // fmindex/FMIndex.h:116-121
-                if (lf_table) row = lf_table[row];                      // one load per LF step when the explicit table exists
-                else { uint32_t c; row = occ.lf_symbol(row, c); }
-                ++steps;
-            }
-            if (sa_present(sa, row)) {
-                uint64_t k = sa_rank(sa, row);                          // suffixarray/SparseArray.h:63-70
-                seq = dense_access(sa.f0, sa.bits0, sa.div0, k);
-                pos = dense_access(sa.f1, sa.bits1, sa.div1, k);
-                st = steps;
-            }
-        }
-        out_seq[t] = seq; out_pos[t] = pos; out_steps[t] = st;
-    }
-    add_counters(steps_total, steps, 0u, 0u);
-}
-
-// ------------------------------------------------------------------ host launchers
-static int step_counters(bool want, hipStream_t stream, unsigned long long** out) {
-    CallScratch* sc = nullptr;
-    int rc = call_scratch(&sc); if (rc) return rc;
-    if (want) FM_HIP(hipMemsetAsync(sc->ctr, 0, (size_t)kCounterStripes * kCounterKinds * 8, stream));
-    *out = want ? sc->ctr : sc->sink;
-    return 0;
-}
-// totals[0] executed steps, [1] table bytes, [2] table accesses
-static int read_step_counters(const unsigned long long* dev, hipStream_t stream, unsigned long long* totals) {
-    CallScratch* sc = nullptr;
-    int rc = call_scratch(&sc); if (rc) return rc;
-    unsigned long long* h = sc->pinned;
-    FM_HIP(hipMemcpyAsync(h, dev, (size_t)kCounterStripes * kCounterKinds * 8, hipMemcpyDeviceToHost, stream));
-    FM_HIP(hipStreamSynchronize(stream));
-    for (unsigned kind = 0; kind < kCounterKinds; ++kind) {
-        unsigned long long t = 0;
-        for (unsigned k = 0; k < kCounterStripes; ++k) t += h[kind * kCounterStripes + k];
-        totals[kind] = t;
-    }
-    return 0;
-}
-
-struct EventTimer {       // the thread's cached event pair (one timed call at a time per host thread)
-    hipEvent_t a = nullptr, b = nullptr; hipStream_t s; bool on;
-    EventTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
-        CallScratch* sc = nullptr;
-        if (on && call_scratch(&sc) == 0) { a = sc->ev_a; b = sc->ev_b; } else on = false;
-    }
-    void start() { if (on) (void)hipEventRecord(a, s); }
-    void stop() { if (on) (void)hipEventRecord(b, s); }
-    float ms() { float v = 0; if (on) { (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&v, a, b); } return v; }
-};
-
-// longest and shortest query and the total symbol count of a batch whose offsets live in HBM: one reduction kernel, one small copy,
-// one synchronisation (per-block partial results reduced on the host: no atomics, nothing to initialise)
-constexpr unsigned kLenBlocks = 1024;
-__global__ __launch_bounds__(256) void k_len_range(const uint64_t* __restrict__ qoff, uint64_t nq, unsigned long long* __restrict__ out) {
-    __shared__ unsigned long long s_v[4], s_w[4];
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long v = 0, w = ~0ull;
-    for (uint64_t q = t; q < nq; q += (uint64_t)gridDim.x * blockDim.x) { unsigned long long l = qoff[q + 1] - qoff[q]; v = l > v ? l : v; w = l < w ? l : w; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v;
-        unsigned long long p = __shfl_xor(w, off, 64); w = p < w ? p : w;
-    }
-    if ((threadIdx.x & 63u) == 0) { s_v[threadIdx.x >> 6] = v; s_w[threadIdx.x >> 6] = w; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 4; ++i) { v = s_v[i] > v ? s_v[i] : v; w = s_w[i] < w ? s_w[i] : w; }
-        out[2 * blockIdx.x] = v; out[2 * blockIdx.x + 1] = w;
-        if (blockIdx.x == 0) out[2 * gridDim.x] = qoff[nq];
-    }
-}
-
-static int query_shape(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out_max, uint32_t* out_min, uint64_t* out_total) {
-    CallScratch* sc = nullptr;
-    int rc = call_scratch(&sc); if (rc) return rc;
-    unsigned long long* d = sc->len2;
-    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + 255) / 256, kLenBlocks));
-    k_len_range<<<dim3(blocks), dim3(256), 0, stream>>>(dqoff, nq, d);
-    unsigned long long* h = sc->pinned;
-    hipError_t e = hipMemcpyAsync(h, d, ((size_t)2 * blocks + 1) * 8, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return hip_fail(e, "k_len_range");
-    unsigned long long mx = 0, mn = ~0ull;
-    for (unsigned b = 0; b < blocks; ++b) { mx = std::max(mx, h[2 * b]); mn = std::min(mn, h[2 * b + 1]); }
-    *out_max = (uint32_t)std::min<unsigned long long>(mx, 0xffffffffull);
-    *out_min = (uint32_t)std::min<unsigned long long>(mn, 0xffffffffull);
-    if (out_total) *out_total = h[2 * blocks];
-    return 0;
-}
-static int query_len_range(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out_max, uint32_t* out_min) {
-    return query_shape(dqoff, nq, stream, out_max, out_min, nullptr);
-}
-
-// expands a scheme for queries of length m into the fast kernel's per-step table (see k_scheme_fast); false if it does not fit.
-// lut_ok: bit s set if search s may start from a prefix table of lutL symbols (first part longer than lutL and error free)
 static bool build_step_table(const SchemeDev& sd, uint32_t m, uint32_t lutL, uint32_t J, std::vector<uint32_t>& tab, uint32_t& lut_ok) {
     const uint32_t S = (uint32_t)sd.S, P = (uint32_t)sd.P;
     lut_ok = 0;
@@ -3747,160 +2474,17 @@ int fmgpu_hits_pack16(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void
 int fmgpu_hits_pack24(const fmgpu_hit* hits, uint64_t count, uint64_t* out, void* stream);
 int fmgpu_hits_sort(fmgpu_hit* hits, uint64_t count, void* stream);
 
-static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
-                        uint64_t* out_lb, uint64_t* out_len, bool packed, fmgpu_stats* stats, void* stream_) {
-    size_t dev_extra_lds = 0;                                      // dev knob: unused dynamic LDS per block, to limit the resident blocks per CU
-    { const char* ev = dev_env("FMGPU_DEV_EXACT_LDS"); if (ev) dev_extra_lds = (size_t)atoi(ev); }
-    Index* x = reinterpret_cast<Index*>(h);
-    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
-    if (int drc = on_handle_device(x)) return drc;
-    if (stats) *stats = fmgpu_stats{};
-    if (nq == 0) return 0;
-    if (!qbuf || !qoff || !out_lb || (!out_len && !packed)) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out_lb / out_len is null");
-    if (kWide && packed) return fail(FMGPU_ERR_UNSUPPORTED, "the one-word interval form (lb << 32 | len) needs rows below 2^32; use fmgpu_search_exact");
-    hipStream_t stream = (hipStream_t)stream_;
-    Staged soff, sbuf, slb, slen;
-    int rc;
-    if ((rc = soff.in(qoff, (nq + 1) * 8, stream))) return rc;
-    uint64_t total = 0;
-    uint32_t shape_max = 0, shape_min = 0;
-    bool have_shape = false;                                     // offsets in HBM: total and length range come back in one copy
-    if (is_device_pointer(qoff)) { if ((rc = query_shape((const uint64_t*)soff.dev, nq, stream, &shape_max, &shape_min, &total))) return rc; have_shape = true; }
-    else total = qoff[nq];
-    if ((rc = sbuf.in(qbuf, total, stream))) return rc;
-    if ((rc = slb.out(out_lb, nq * 8, stream))) return rc;
-    if (out_len && (rc = slen.out(out_len, nq * 8, stream))) return rc;   // (packed form: slen.dev stays null and the kernels write one word per query)
-    unsigned long long* dsteps = nullptr;
-    if ((rc = step_counters(stats != nullptr, stream, &dsteps))) return rc;
-    EventTimer timer(stream, stats != nullptr);
-    FM_GRID(grid, nq);
-    const dim3 block(256);
-    const idx_t n = (idx_t)x->bwt.n;
-    timer.start();
-    uint32_t kq_words = 0, kq_max = 0, kq_nib = x->bwt.sigma <= 15 ? 1u : 0u;
-    // the pair table with an interval table in front of it (and no other table): k_exact_p starts from the entry of the read's last symbols
-    const bool pair_lut = x->bwt.sigma == 5 && x->bwt.pairs && x->bwt.slut && !x->bwt.kblk && !x->bwt.walkj && x->bwt.search_family() == FAM_A &&
-                          !(kernel_flags() & (FMGPU_SEL_EXACT_ONE_SYMBOL | FMGPU_SEL_NO_EXACT_LUT));
-    const bool accel = (x->bwt.kblk || x->bwt.slut || x->bwt.walkj) && !pair_lut;
-    if (accel) {                                                 // LDS staging needs the longest query of the batch
-        uint32_t mn = 0;
-        if (have_shape) kq_max = shape_max;
-        else if ((rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &kq_max, &mn))) return rc;
-        kq_words = kq_nib ? (kq_max + 7) / 8 : (kq_max + 3) / 4;
-        if ((size_t)kq_words * 1024 > 48 * 1024) kq_words = 0;  // very long queries: read them from global memory
-        timer.start();
-    }
-    if (accel) {
-        const DevString& bs = x->bwt;
-        ExactAccel ac{bs.kblk, bs.kstep, bs.kcodes, bs.slut, bs.slut_len, bs.walkj, bs.walk_J, bs.walk_bits, bs.walk2j};
-        rc = dispatch_occ(bs, [&](auto occ, auto) {
-            k_exact_kstep<decltype(occ)><<<grid, block, (size_t)kq_words * 1024 + dev_extra_lds, stream>>>(occ, ac, (uint32_t)bs.sigma - 1,
-                                                                    (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev,
-                                                                    (uint64_t*)slen.dev, dsteps, kq_words, kq_nib, kq_max);
-            return 0;
-        });
-    } else
-    if (x->bwt.search_family() == FAM_A) {
-        auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
-        // k_exact_a runs best with 5 resident blocks per CU, not the 8 its 28 registers allow (measured on the 3.09 Gbp index, 10 M x 101 bp: 8 / 6 / 5 / 4 / 3
-        // blocks = 19.53 / 19.23 / 18.92 / 19.10 / 18.95 ms — more waves only queue up at the memory system): 28 KB of unused dynamic LDS set the residency
-        const size_t lds_a = dev_env("FMGPU_DEV_EXACT_LDS") ? dev_extra_lds : (size_t)28 * 1024;
-        if (x->bwt.sigma == 5 && x->bwt.pairs && !(kernel_flags() & (1 << 22)))
-            k_exact_p<<<grid, block, 4 * 8 * kCoopRegion + dev_extra_lds, stream>>>(OccA<5>{x->bwt.va}, x->bwt.pairs, x->bwt.pairs_ex, x->bwt.pairs_nex, x->bwt.pairs_super,
-                                                                                    pair_lut ? (const void*)x->bwt.slut : nullptr, x->bwt.slut_len, qb, qo, nq, n, ol, on, dsteps);
-        else if (x->bwt.sigma == 5) k_exact_a<5><<<grid, block, lds_a, stream>>>(OccA<5>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
-        else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
-    } else if (x->bwt.flat && x->bwt.search_family() != FAM_A && !(kernel_flags() & (1 << 21))) {
-        const uint32_t entries = x->bwt.flat_nsb * (uint32_t)x->bwt.sigma;
-        const uint32_t super_lds = flat_super_lds_bytes(entries) <= kFlatSuperLdsMax ? entries : 0u;      // (sigma = 28: 6.7 KB at 2 x 10^9 rows, 19 KB at 4.5 x 10^9)
-        k_exact_s<<<grid, block, 4 * 8 * kCoopRegion + 16 + flat_super_lds_bytes(super_lds) + dev_extra_lds, stream>>>(x->bwt.flat, x->bwt.flat_super, (uint32_t)x->bwt.sigma,
-                                                           flat_count_bits((uint32_t)x->bwt.sigma), (const uint8_t*)sbuf.dev,
-                                                           (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps, super_lds);
-    } else if (x->bwt.search_family() == FAM_WAVELET) {
-        uint32_t mx = shape_max, mn = 0;
-        if (!have_shape && (rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) return rc;
-        uint32_t qw = (mx + 3) / 4;
-        if ((size_t)qw * 1024 > 48 * 1024) qw = 0;
-        timer.start();
-        const ViewM& vm = x->bwt.vm;
-        const uint32_t m_super_rows = kWide && x->bwt.sup_bytes ? (uint32_t)std::min<uint64_t>(0xffffffffu, (x->bwt.sup_bytes - ((uint64_t)vm.nnodes * 4 + 63) / 64 * 64) / 64) : 0u;
-        auto qb = (const uint8_t*)sbuf.dev; auto qo = (const uint64_t*)soff.dev; auto ol = (uint64_t*)slb.dev; auto on = (uint64_t*)slen.dev;
-        const size_t lds = (size_t)qw * 1024;
-        switch (vm.bitct) {                                      // the digits of digits_of() as template arguments
-        case 1: k_exact_m<1, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
-        case 2: k_exact_m<2, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
-        case 3: k_exact_m<3, 0, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
-        case 4: k_exact_m<2, 2, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
-        case 5: k_exact_m<3, 2, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
-        case 6: k_exact_m<3, 3, 0><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
-        case 7: k_exact_m<3, 2, 2><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
-        default: k_exact_m<3, 3, 2><<<grid, block, lds + dev_extra_lds, stream>>>(vm, qb, qo, nq, n, ol, on, dsteps, qw, m_super_rows); break;
-        }
-    } else {
-        rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
-            k_exact<decltype(occ)><<<grid, block, 0, stream>>>(occ, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, n,
-                                                              (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps);
-            return 0;
-        });
-    }
-    timer.stop();
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "k_exact launch");
-    if (stats) {
-        unsigned long long hs[kCounterKinds] = {0, 0, 0, 0};
-        if ((rc = read_step_counters(dsteps, stream, hs))) return rc;
-        stats->lf_steps = hs[0]; stats->hits = nq; stats->kernel_ms = timer.ms();
-        stats->table_bytes = hs[1]; stats->table_accesses = hs[2]; stats->table_steps = hs[3];
-    }
-    if ((rc = slb.finish())) return rc;
-    if (out_len && (rc = slen.finish())) return rc;
-    if (stats || slb.owned || slen.owned) (void)hipStreamSynchronize(stream);
-    return 0;
-}
-
-int fmgpu_search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
-                       uint64_t* out_lb, uint64_t* out_len, fmgpu_stats* stats, void* stream) {
-    return search_exact(h, qbuf, qoff, nq, out_lb, out_len, false, stats, stream);
-}
-
-int fmgpu_search_exact_packed(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq,
-                              uint64_t* out_interval, fmgpu_stats* stats, void* stream) {
-    return search_exact(h, qbuf, qoff, nq, out_interval, nullptr, true, stats, stream);
-}
-
-int fmgpu_search_exact_depth(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, uint32_t* out_depth, void* stream_) {
-    Index* x = reinterpret_cast<Index*>(h);
-    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
-    if (int drc = on_handle_device(x)) return drc;
-    if (nq == 0) return 0;
-    if (!qbuf || !qoff || !out_depth) return fail(FMGPU_ERR_INVALID, "qbuf / qoff / out_depth is null");
-    hipStream_t stream = (hipStream_t)stream_;
-    Staged soff, sbuf, sout;
-    int rc;
-    if ((rc = soff.in(qoff, (nq + 1) * 8, stream))) return rc;
-    uint64_t total = 0;
-    if (is_device_pointer(qoff)) { FM_HIP(hipMemcpyAsync(&total, qoff + nq, 8, hipMemcpyDeviceToHost, stream)); FM_HIP(hipStreamSynchronize(stream)); }
-    else total = qoff[nq];
-    if ((rc = sbuf.in(qbuf, total, stream)) || (rc = sout.out(out_depth, nq * 4, stream))) return rc;
-    FM_GRID(grid, nq);
-    rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
-        k_exact_depth<decltype(occ)><<<grid, dim3(256), 0, stream>>>(occ, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, (idx_t)x->bwt.n, (uint32_t*)sout.dev);
-        return 0;
-    });
-    FM_LAUNCHED("k_exact_depth");
-    return sout.finish();
-}
-
 static size_t lean_lds_bytes(uint32_t m, size_t step_words) {
     return (size_t)((m + 15) / 16) * 1024 + 8192 + step_words * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;      // staged reads | top and bottom frame slots | steps | ring fill | rings
 }
 static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uint32_t m, size_t step_words, dim3 g, const uint8_t* dq, const uint64_t* doff, uint64_t count,
-                        fmgpu_hit* dout, uint64_t capacity, const DfsWorkspace& ws, const uint32_t* qm, hipStream_t stream) {
+                        fmgpu_hit* dout, uint64_t capacity, const DfsWorkspace& ws, const uint32_t* qm, hipStream_t stream, uint32_t lut_ok = 0) {
     const idx_t n = (idx_t)x->bwt.n;
     const bool dense = x->bwt.dense && x->rev.dense && !(kernel_flags() & (1 << 29));      // (bit 29 of FMGPU_DEV_FLAGS: read Format A although Format D exists)
     LeanArgs la{x->bwt.va.blk, x->rev.va.blk, d_steps, S, m, (idx_t)(x->hC[1] + x->hC[2] + x->hC[3] + x->hC[4]), x->bwt.va.super, x->rev.va.super,
                 kWide ? (uint32_t)((x->bwt.n >> kSuperShift) + 1) : 0u,
-                (const uint4*)x->bwt.dense, (const uint4*)x->rev.dense, x->bwt.dense_ex, x->rev.dense_ex, x->bwt.dense_nex, x->rev.dense_nex};
+                (const uint4*)x->bwt.dense, (const uint4*)x->rev.dense, x->bwt.dense_ex, x->rev.dense_ex, x->bwt.dense_nex, x->rev.dense_nex, nullptr, 0u, 0u};
+    if (!kWide && x->lut && x->lut_len >= 1 && x->lut_len <= 16 && lut_ok && !(kernel_flags() & FMGPU_SEL_NO_PREFIX_TABLE)) { la.lut = x->lut; la.lutL = x->lut_len; la.lut_ok = lut_ok; }
     const size_t lds = lean_lds_bytes(m, step_words);
     uint32_t waste = kLeanRefillWaste, heavy = kLeanShareHeavy; [[maybe_unused]] int steps = kLeanSteps;
     if (const char* ev = dev_env("FMGPU_DEV_LEAN_WASTE")) waste = (uint32_t)std::max(1, atoi(ev));
@@ -4206,7 +2790,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
                     k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                               b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
             } else if (lean) {
-                launch_lean(x, fa.steps, (uint32_t)sd.S, b.m, b.tab.size() / 3, g, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (fmgpu_hit*)sout.dev, capacity, ws, qm, stream);
+                launch_lean(x, fa.steps, (uint32_t)sd.S, b.m, b.tab.size() / 3, g, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (fmgpu_hit*)sout.dev, capacity, ws, qm, stream, b.lut_ok);
             } else if (x->bwt.sigma == 5 && !have_lf)
                 k_scheme_fast<5, 5, true><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
                                                                           b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
@@ -4283,8 +2867,9 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
 #endif
     *out_count = hc.hits;
     if (stats) { stats->lf_steps = hc.nodes; stats->hits = hc.hits; stats->kernel_ms = timer.ms(); stats->prepass_ms = prepass_ms; stats->table_bytes = hc.table_bytes; stats->table_accesses = hc.table_accesses; }
+    if (stats) { unsigned long long served = 0; (void)hipMemcpy(&served, reinterpret_cast<unsigned long long*>(ws.ctr) + 21, 8, hipMemcpyDeviceToHost); stats->table_steps = served; }   // (k_scheme_lean: nodes that prefix-table entries stood for)
 #ifdef FMGPU_DEV
-    if (stats) { unsigned long long bad = 0; (void)hipMemcpy(&bad, reinterpret_cast<unsigned long long*>(ws.ctr) + 20, 8, hipMemcpyDeviceToHost); stats->table_steps = bad; }     // (k_scheme_lean: LDS frame slots that disagreed with the stack in HBM)
+    if (stats) { unsigned long long bad = 0; (void)hipMemcpy(&bad, reinterpret_cast<unsigned long long*>(ws.ctr) + 20, 8, hipMemcpyDeviceToHost); stats->hits |= bad << 48; }     // (dev build: LDS frame slots that disagreed with the stack in HBM, in the top bits of `hits`)
 #endif
     if (hc.hits > capacity) {
         if (sout.writeback) { sout.bytes = capacity * sizeof(fmgpu_hit); (void)sout.finish(); }
@@ -4434,116 +3019,6 @@ int fmgpu_search_ng21(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qoff
     if (sout.writeback) sout.bytes = hc.hits * sizeof(fmgpu_hit);
     return sout.finish();
 }
-
-int fmgpu_locate(fmgpu_index_t h, const uint64_t* rows, uint64_t count, uint64_t* out_seq, uint64_t* out_pos, uint64_t* out_steps,
-                 fmgpu_stats* stats, void* stream_) {
-    // k_locate runs best with 4 resident blocks per CU (9 M rows of the 3.09 Gbp index: 8 / 5 / 4 / 3 blocks = 4.73 / 4.20 / 3.99 / 4.03 ms — its lanes
-    // leave after 0 .. 15 LF steps and more waves only queue up at the memory system): 36 KB of unused dynamic LDS set the residency
-    size_t locate_lds = (size_t)36 * 1024;
-    { const char* ev = dev_env("FMGPU_DEV_LOCATE_LDS"); if (ev) locate_lds = (size_t)atoi(ev); }
-    Index* x = reinterpret_cast<Index*>(h);
-    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
-    if (int drc = on_handle_device(x)) return drc;
-    if (!x->has_sa) return fail(FMGPU_ERR_INVALID, "index was created without an annotated (sampled suffix) array");
-    if (stats) *stats = fmgpu_stats{};
-    if (count == 0) return 0;
-    if (!rows || !out_seq || !out_pos || !out_steps) return fail(FMGPU_ERR_INVALID, "rows / outputs is null");
-    hipStream_t stream = (hipStream_t)stream_;
-    Staged srows, sseq, spos, sst;
-    int rc;
-    if ((rc = srows.in(rows, count * 8, stream))) return rc;
-    if ((rc = sseq.out(out_seq, count * 8, stream))) return rc;
-    if ((rc = spos.out(out_pos, count * 8, stream))) return rc;
-    if ((rc = sst.out(out_steps, count * 8, stream))) return rc;
-    unsigned long long* dsteps = nullptr;
-    if ((rc = step_counters(stats != nullptr, stream, &dsteps))) return rc;
-    EventTimer timer(stream, stats != nullptr);
-    FM_GRID(grid, count);
-    const dim3 block(256);
-    const idx_t n = (idx_t)x->bwt.n;
-    timer.start();
-#if !FMGPU_WIDE
-    if (x->loc_tab)
-        k_locate_tab<<<grid, block, 0, stream>>>(x->loc_tab, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
-    else
-#endif
-    if (x->bwt.va.fused && x->bwt.search_family() == FAM_A) {      // one line per step: presence bit, symbol and LF from the row's block (also ahead of the explicit LF table: that is two lines per step)
-        const bool coop = (uint64_t)x->bwt.n < (1ull << 38) && !(kernel_flags() & (1 << 23));   // (bit 23: one row per lane, k_locate_fused)
-        const dim3 cgrid((unsigned)((count + 4u * kLocChunk - 1u) / (4u * kLocChunk)));
-        const size_t coop_lds = (size_t)4 * kLocWaveWords * 4 + (dev_env("FMGPU_DEV_LOCATE_LDS") ? locate_lds : 0);
-        if (coop && count / (4u * kLocChunk) < kMaxGridBlocks) {
-            if (x->bwt.sigma == 5) k_locate_coop<5><<<cgrid, block, coop_lds, stream>>>(OccA<5>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
-            else k_locate_coop<0><<<cgrid, block, coop_lds, stream>>>(OccA<0>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
-        } else
-        if (x->bwt.sigma == 5) k_locate_fused<5><<<grid, block, locate_lds, stream>>>(OccA<5>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
-        else k_locate_fused<0><<<grid, block, locate_lds, stream>>>(OccA<0>{x->bwt.va}, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev, (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
-    } else
-    rc = dispatch_occ(x->bwt, [&](auto occ, auto) {
-        k_locate<decltype(occ)><<<grid, block, locate_lds, stream>>>(occ, x->bwt.lf_table, x->vsa, (const uint64_t*)srows.dev, count, n, (uint64_t*)sseq.dev,
-                                                           (uint64_t*)spos.dev, (uint64_t*)sst.dev, dsteps);
-        return 0;
-    });
-    timer.stop();
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "k_locate launch");
-    if (stats) {
-        unsigned long long hs[kCounterKinds] = {0, 0, 0, 0};
-        if ((rc = read_step_counters(dsteps, stream, hs))) return rc;
-        stats->lf_steps = hs[0]; stats->hits = count; stats->kernel_ms = timer.ms();
-    }
-    rc = sseq.finish(); if (!rc) rc = spos.finish(); if (!rc) rc = sst.finish();
-    if (stats || sseq.owned || spos.owned || sst.owned) (void)hipStreamSynchronize(stream);
-    return rc;
-}
-
-#if FMGPU_WIDE
-int fmgpu_index_accelerate_locate(fmgpu_index_t h, int32_t enable) {
-    if (!h) return fail(FMGPU_ERR_INVALID, "index handle is null");
-    if (!enable) return 0;
-    return fail(FMGPU_ERR_UNSUPPORTED, "the locate answer table is not available for indices of 2^32 rows or more (64-bit-row build)");
-}
-#else
-// answer table for locate: every row is located once, the triples are kept (12 bytes per row)
-__global__ __launch_bounds__(256) void k_pack_locate(const uint64_t* __restrict__ seq, const uint64_t* __restrict__ pos, const uint64_t* __restrict__ st, uint64_t first,
-                                                     uint64_t count, uint32_t* __restrict__ tab) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    uint32_t* p = tab + 3u * (size_t)(first + t);
-    const bool ok = st[t] != ~0ull && seq[t] <= 0xfffffffeull && pos[t] <= 0xffffffffull;
-    p[0] = ok ? (uint32_t)seq[t] : 0u; p[1] = ok ? (uint32_t)pos[t] : 0u; p[2] = ok ? (uint32_t)st[t] : 0xffffffffu;
-}
-__global__ __launch_bounds__(256) void k_iota64(uint64_t* __restrict__ out, uint64_t first, uint64_t count) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < count) out[t] = first + t;
-}
-
-int fmgpu_index_accelerate_locate(fmgpu_index_t h, int32_t enable) {
-    Index* x = reinterpret_cast<Index*>(h);
-    if (!x) return fail(FMGPU_ERR_INVALID, "index handle is null");
-    if (int drc = on_handle_device(x)) return drc;
-    const uint64_t n = x->bwt.n;
-    if (x->loc_tab) { (void)hipFree(x->loc_tab); x->loc_tab = nullptr; x->device_bytes -= n * 12; }
-    if (!enable || n == 0) return 0;
-    if (!x->has_sa) return fail(FMGPU_ERR_INVALID, "index was created without an annotated (sampled suffix) array");
-    DBuf tab, staging;
-    int rc;
-    const uint64_t chunk = 1ull << 26;
-    if ((rc = tab.alloc(n * 12 + 16)) || (rc = staging.alloc(chunk * 8 * 4))) return rc;
-    uint64_t* buf = staging.as<uint64_t>();                        // rows | seq | pos | steps of one chunk
-    for (uint64_t first = 0; first < n; first += chunk) {
-        const uint64_t cnt = std::min(chunk, n - first);
-        k_iota64<<<dim3((unsigned)((cnt + 255) / 256)), 256>>>(buf, first, cnt);
-        FM_LAUNCHED("k_iota64");
-        if ((rc = api::fmgpu_locate(h, buf, cnt, buf + chunk, buf + 2 * chunk, buf + 3 * chunk, nullptr, nullptr))) return rc;
-        k_pack_locate<<<dim3((unsigned)((cnt + 255) / 256)), 256>>>(buf + chunk, buf + 2 * chunk, buf + 3 * chunk, first, cnt, tab.as<uint32_t>());
-        FM_LAUNCHED("k_pack_locate");
-    }
-    FM_HIP(hipDeviceSynchronize());
-    x->loc_tab = (uint32_t*)tab.take();
-    x->device_bytes += n * 12;
-    return 0;
-}
-#endif  // FMGPU_WIDE
 
 #if !FMGPU_WIDE   // (fmgpu_hit holds 64-bit fields: the record helpers are width-independent and live in the 32-bit-row build)
 // ---- hit records in the reference's callback order -----------------------------------------------------------------------------------

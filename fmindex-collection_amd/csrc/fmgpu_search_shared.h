@@ -1,0 +1,487 @@
+// fmgpu_search_shared.h — what the search translation units (fmgpu_exact.hip, fmgpu_search.hip, fmgpu_locate.hip) share: wave-level helpers, the step counters
+// of the one-thread-per-query kernels, query readers and LDS staging, the DFS kernels' machinery (scheme tables, path keys, symbol sets, hit rings), and the host
+// helpers of the launchers.  Internal to libfmgpu.so; included once per row width like fmgpu_common.h.
+#pragma once
+#include "fmgpu_common.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include <hipcub/hipcub.hpp>
+
+namespace FMGPU_NS {
+
+typedef __attribute__((address_space(3))) uint32_t lds_word;
+typedef uint32_t __attribute__((ext_vector_type(4))) flat_u32x4;
+
+// the cursor of query q: two 64-bit arrays as the reference's cursor fields, or (out_len == nullptr) one word lb << 32 | len — the transport
+// form of fmgpu_search_exact_packed (32-bit rows only)
+__device__ __forceinline__ void store_interval(uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len, uint64_t q, idx_t lb, idx_t len) {
+    if (kWide || out_len) { out_lb[q] = lb; out_len[q] = len; }
+    else out_lb[q] = ((uint64_t)lb << 32) | (uint64_t)len;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// counters of the one-thread-per-query kernels: [0] executed steps, [1] table bytes consumed, [2] table accesses, [3] steps that an interval-table entry stood for (fmgpu_stats), each striped
+// over kCounterStripes words (a single word would serialise one atomic per wave — 156 k of them for 10 M queries — behind each other)
+__device__ __forceinline__ void add_counters(unsigned long long* __restrict__ ctr, uint32_t steps, uint32_t bytes, uint32_t accesses, uint32_t table_steps = 0u) {
+    const uint32_t ts = wave_sum(steps), tb = wave_sum(bytes), ta = wave_sum(accesses), tt = wave_sum(table_steps);
+    if ((threadIdx.x & 63u) == 0 && ts) {
+        const uint32_t stripe = blockIdx.x & (kCounterStripes - 1u);
+        atomicAdd(&ctr[stripe], (unsigned long long)ts);
+        atomicAdd(&ctr[kCounterStripes + stripe], (unsigned long long)tb);
+        atomicAdd(&ctr[2u * kCounterStripes + stripe], (unsigned long long)ta);
+        if (tt) atomicAdd(&ctr[3u * kCounterStripes + stripe], (unsigned long long)tt);
+    }
+}
+
+// ---- exact search on Format A without accelerator tables --------------------------------------------------------
+// The query symbols are fetched as aligned 64-bit words one word ahead of use, so that the only load on the
+// dependent chain of an LF step is the occurrence-table entry; the second interval end re-uses the first end's
+// entry when both fall into the same 64-row block (the common case once the interval is short).
+struct QueryReader {
+    const uint64_t* base;   // 8-byte aligned
+    uint64_t pos;           // absolute byte position (relative to base) of the next symbol to hand out (moving down)
+    uint64_t cw, nw;        // current word, next (lower) word
+    __device__ __forceinline__ void init(const uint8_t* qbuf, uint64_t off, uint32_t m) {
+        uint64_t mis = (uint64_t)qbuf & 7ull;
+        base = reinterpret_cast<const uint64_t*>((uint64_t)qbuf - mis);
+        pos = off + mis + m - 1;                       // m >= 1
+        uint64_t w = pos >> 3;
+        cw = base[w];
+        nw = w ? base[w - 1] : 0;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        uint32_t c = (uint32_t)(cw >> ((pos & 7ull) * 8ull)) & 0xffu;
+        if ((pos & 7ull) == 0) {                       // crossing into the lower word: rotate and prefetch
+            uint64_t w = pos >> 3;
+            cw = nw;
+            nw = w >= 2 ? base[w - 2] : 0;
+        }
+        --pos;
+        return c;
+    }
+};
+
+// ------------------------------------------------------------------ DFS machinery
+constexpr int kMaxParts = 16;
+constexpr int kMaxSearches = 16;
+
+struct SchemeDev {             // flattened [search][part]; values fit a byte (errors <= 255, parts <= 16)
+    int S, P;
+    uint8_t pi[kMaxSearches * kMaxParts], l[kMaxSearches * kMaxParts], u[kMaxSearches * kMaxParts];
+    uint32_t partition[kMaxParts];   // used when uniform == 0
+    uint32_t psum;                   // sum of partition[] (queries of another length are skipped)
+    int uniform;
+    int dev_flags;                   // dev knobs: 1 = count hits per lane only (no records)
+    int use_key, sharing;            // k_scheme: hit records carry path keys / idle lanes take subtrees from the busy lanes of their wave
+};
+
+struct Counters { unsigned long long hits, nodes, next, table_bytes, table_accesses; };
+
+// ---- work sharing between the lanes of a wave in k_scheme_fast -------------------------------------------------------------------------
+// The work of a k-mismatch search is heavy-tailed on a repeat-rich text: the median read visits ~200 nodes, a read from a satellite array
+// half a million (measured on the genome-like text: 0.02 % of the reads hold 13 % of all nodes), and a depth-first walk of one read by one
+// lane takes as long as its node count.  A lane that has spent kShareNodes nodes on its current read therefore offers the BOTTOM frame of its
+// stack — the untried siblings of its shallowest branching node, the largest piece of work it still owns — to the lanes of its wave that
+// are out of work: the frame travels by lane shuffles, the staged read by an LDS column copy, no atomic and no global traffic beyond the
+// three frame words.  (A device-wide task queue was tried first: one queue head for thousands of waiting waves serialised the hand-over at
+// ~1.3 us per task — 2 M tasks, 8 s — and was dropped.)  This needs an order of the hit records that does not depend on who found them:
+constexpr uint32_t kShareNodes = 2;
+// ... and only from a read that has proven heavy: with offers from every read the hand-over ran in nearly every iteration of a wave (some lane is always
+// out of work) and cost more than it returned (uniform text, plain index: 56.8 -> 39.8 ms once reads of fewer than 64 nodes stopped offering)
+[[maybe_unused]] constexpr uint32_t kShareHeavy = 64;
+
+// Path key: the callback order of the reference is the depth-first order in which every node tries its match child first and its substitution
+// children in ascending symbol order (SearchNg26.h:171-218).  For hits of one read that is the lexicographic order of
+//   (search, [m - step of the 1st substitution, its symbol], [m - step of the 2nd substitution, its symbol])   with "no substitution" = 0:
+// a later first substitution is met earlier on the way back up.  24 bits per substitution; the key travels in fmgpu_hit::seq (low 32 bits) and
+// the upper 24 bits of fmgpu_hit::errors until fmgpu_hits_sort orders the records by (qidx, key) and turns it into the dense callback index.
+// the key of an ancestor that had made `e` substitutions: the fields of the later ones cleared (so frames need not carry keys)
+__device__ __forceinline__ uint64_t key_prefix(uint64_t key, uint32_t e) {
+    return e == 0u ? key & (0xffull << 48) : (e == 1u ? key & ~0xffffffull : key);
+}
+__device__ __forceinline__ uint64_t key_with(uint64_t key, uint32_t e_before, uint32_t m, uint32_t step, uint32_t symb) {
+    if (e_before >= 2u) return key;
+    return key | ((uint64_t)(((m - step) << 8) | symb) << (24u * (1u - e_before)));
+}
+
+
+
+// lane-interleaved frame stack: frame d of lane g at word (d * nlanes + g) of three u64 planes
+struct StackView { uint64_t *p0, *p1, *p2, *p3; uint64_t nlanes; uint32_t depth; };   // frame planes (the edit-distance kernels use the block as 32-byte records)
+
+struct Cur { idx_t lb, lbRev, len; };
+
+__device__ __forceinline__ void emit_hit(fmgpu_hit* out, uint64_t cap, Counters* ctr, uint64_t qidx, Cur c, uint32_t e, uint32_t seq) {
+    unsigned long long k = atomicAdd(&ctr->hits, 1ull);
+    if (k < cap) {
+        fmgpu_hit h;
+        h.qidx = qidx; h.lb = c.lb; h.lb_rev = c.lbRev; h.len = c.len; h.errors = e; h.seq = seq;
+        out[k] = h;
+    }
+}
+
+// ---- symbol sets and children ----------------------------------------------------------------------------------
+// MAXSIG <= 32: one register word, arrays stay in registers (fully unrolled selects).  MAXSIG = 256: eight words, the
+// LF arrays live in scratch and are indexed dynamically (the reference itself does O(sigma) work per extend-all).
+template <int MAXSIG>
+struct SymSet {
+    static constexpr int W = (MAXSIG + 31) / 32;
+    uint32_t w[W];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < W; ++i) w[i] = 0;
+    }
+    __device__ __forceinline__ bool test(uint32_t s) const {
+        if (s >= (uint32_t)MAXSIG) return false;
+        if (W == 1) return (w[0] >> s) & 1u;
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) r = w[i];
+        return (r >> (s & 31u)) & 1u;
+    }
+    __device__ __forceinline__ void remove(uint32_t s) {
+        if (s >= (uint32_t)MAXSIG) return;
+#pragma unroll
+        for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) w[i] &= ~(1u << (s & 31u));
+    }
+    __device__ __forceinline__ void insert(uint32_t s) {
+        if (s >= (uint32_t)MAXSIG) return;
+#pragma unroll
+        for (int i = 0; i < W; ++i) if ((s >> 5) == (uint32_t)i) w[i] |= 1u << (s & 31u);
+    }
+    __device__ __forceinline__ bool any() const {
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) r |= w[i];
+        return r != 0;
+    }
+    __device__ __forceinline__ uint32_t first() const {     // lowest member; caller checks any()
+        uint32_t r = 0xffffffffu;
+#pragma unroll
+        for (int i = W - 1; i >= 0; --i) if (w[i]) r = (uint32_t)i * 32u + (uint32_t)__ffs((int)w[i]) - 1u;
+        return r;
+    }
+    __device__ __forceinline__ void clear_below(uint32_t s) {   // drop members < s
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            uint32_t lo = (uint32_t)i * 32u;
+            if (s >= lo + 32u) w[i] = 0;
+            else if (s > lo) w[i] &= ~((1u << (s - lo)) - 1u);
+        }
+    }
+};
+
+template <int MAXSIG>
+__device__ __forceinline__ SymSet<MAXSIG> alive_set(const idx_t* lfa, const idx_t* lfb, uint32_t sigma) {
+    SymSet<MAXSIG> m; m.clear();
+    if (MAXSIG <= 32) {
+#pragma unroll
+        for (uint32_t d = 0; d < (uint32_t)MAXSIG; ++d) if (d < sigma && lfb[d] != lfa[d]) m.w[0] |= 1u << d;
+    } else {
+        for (uint32_t d = 0; d < sigma; ++d) if (lfb[d] != lfa[d]) m.w[d >> 5] |= 1u << (d & 31u);
+    }
+    return m;
+}
+
+// kid cursor of symbol s from the LF values at both ends; `right` mirrors the roles (fmindex/BiFMIndexCursor.h:58-82)
+template <int MAXSIG>
+__device__ __forceinline__ Cur kid_of(const idx_t* lfa, const idx_t* lfb, Cur cur, uint32_t s, bool right, uint32_t sigma) {
+    idx_t pre = 0, la = 0, lb = 0;
+    if (MAXSIG <= 32) {
+#pragma unroll
+        for (uint32_t d = 0; d < (uint32_t)MAXSIG; ++d) {
+            if (d < s && d < sigma) pre += lfb[d] - lfa[d];
+            if (d == s) { la = lfa[d]; lb = lfb[d]; }
+        }
+    } else {
+        for (uint32_t d = 0; d < s; ++d) pre += lfb[d] - lfa[d];
+        la = lfa[s]; lb = lfb[s];
+    }
+    Cur k;
+    k.len = lb - la;
+    if (right) { k.lbRev = la; k.lb = cur.lb + pre; }
+    else       { k.lb = la; k.lbRev = cur.lbRev + pre; }
+    return k;
+}
+
+constexpr uint32_t kNoResume = 0xffffffffu;
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t y = __shfl_up(x, off, 64); if (lane >= (uint32_t)off) x += y; }
+    return x - v;
+}
+
+// ---- wave-level reservations for the DFS kernels ----------------------------------------------------------------------------------
+// One atomicAdd per hit (or per query handed out) queues millions of atomics behind each other on one address: ~9 ns each, more than the
+// searches themselves.  Instead every lane of a wave passes a synchronous section in each loop iteration (a lane without work idles until
+// the whole wave is done): queries are handed out with one reservation for all lanes that want one, and hit records go to a ring per WAVE in
+// LDS — the slot from an LDS atomic on the ring's fill count — that the whole wave writes out with ONE reservation once it holds kWaveRingFlush
+// records.  (Round 2 kept two slots per LANE and flushed when one lane's were full: a lane in a repeat fills its two while the other 63 are
+// empty — one reservation per ~6 records, 8.8 M returning atomics on one word per 10 M reads, near the ~88 M/s a single word sustains.)
+constexpr uint32_t kWaveHitBuf = 2;                               // (sizes the LDS area: 2 x 64 record slots per wave)
+constexpr uint32_t kHitWords = kWide ? 10u : 7u;                  // [qidx lo, qidx hi, lb, lbRev, len, e, seq (, high words of lb, lbRev, len)]
+constexpr uint32_t kWaveHitWords = kWaveHitBuf * kHitWords * 256u;   // per block: 4 waves x [word][128 slots]; slot 0 of word 0 is the ring's fill count
+constexpr uint32_t kWaveRingSlots = kWaveHitBuf * 64u - 1u;       // 127 records per wave
+constexpr uint32_t kWaveRingFlush = 64u;                          // written out once this many are waiting: 63 more fit (one per lane and iteration), a surplus goes out one by one
+
+__device__ __forceinline__ uint64_t wave_hand_out(bool want, Counters* ctr, uint32_t lane) {     // all lanes call; valid for lanes with `want`
+    const uint64_t wm = __ballot(want);
+    if (!wm) return 0;
+    const uint32_t leader = (uint32_t)__ffsll((unsigned long long)wm) - 1u;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(&ctr->next, (unsigned long long)__popcll(wm));
+    base = ((unsigned long long)__shfl((uint32_t)(base >> 32), leader, 64) << 32) | __shfl((uint32_t)base, leader, 64);
+    return base + (uint64_t)__popcll(wm & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ uint32_t* wave_ring(uint32_t* s_hb) { return s_hb + (threadIdx.x >> 6) * (kWaveHitBuf * kHitWords * 64u); }
+__device__ __forceinline__ void wave_ring_init(uint32_t* s_hb) {  // every wave, before its first record (LDS operations of one wave execute in order)
+    if ((threadIdx.x & 63u) == 0) __hip_atomic_store((lds_word*)wave_ring(s_hb), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ uint32_t wave_ring_fill(uint32_t* s_hb) {   // wave-uniform
+    return __hip_atomic_load((lds_word*)wave_ring(s_hb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void wave_keep_hit(uint32_t* s_hb, uint32_t& nh, fmgpu_hit* out, uint64_t cap, Counters* ctr, uint64_t q, Cur r, uint32_t e, uint32_t seq) {
+    uint32_t* ring = wave_ring(s_hb);
+    const uint32_t slot = 1u + __hip_atomic_fetch_add((lds_word*)ring, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    constexpr uint32_t W = kWaveHitBuf * 64u;                      // slots per word plane
+    if (slot <= kWaveRingSlots) {
+        uint32_t* h = ring + slot;
+        h[0] = (uint32_t)q; h[W] = (uint32_t)(q >> 32); h[2 * W] = (uint32_t)r.lb; h[3 * W] = (uint32_t)r.lbRev; h[4 * W] = (uint32_t)r.len; h[5 * W] = e; h[6 * W] = seq;
+        if constexpr (kWide) { h[7 * W] = (uint32_t)((uint64_t)r.lb >> 32); h[8 * W] = (uint32_t)((uint64_t)r.lbRev >> 32); h[9 * W] = (uint32_t)((uint64_t)r.len >> 32); }
+    } else emit_hit(out, cap, ctr, q, r, e, seq);                  // the ring is full (more than 63 records since the wave last looked): this one goes out alone
+    (void)nh;
+}
+__device__ __forceinline__ void wave_flush_hits(uint32_t* s_hb, uint32_t& nh, uint32_t lane, fmgpu_hit* out, uint64_t cap, Counters* ctr) {   // all lanes call
+    uint32_t* ring = wave_ring(s_hb);
+    const uint32_t total = min(wave_ring_fill(s_hb), kWaveRingSlots);
+    constexpr uint32_t W = kWaveHitBuf * 64u;
+    if (total) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->hits, (unsigned long long)total);
+        base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0, 64) << 32) | __shfl((uint32_t)base, 0, 64);
+        for (uint32_t k = 1u + lane; k <= total; k += 64u) {
+            const uint32_t* h = ring + k;
+            const unsigned long long at = base + (k - 1u);
+            if (at < cap) {
+                fmgpu_hit rec;
+                rec.qidx = (uint64_t)h[0] | ((uint64_t)h[W] << 32); rec.lb = h[2 * W]; rec.lb_rev = h[3 * W]; rec.len = h[4 * W];
+                if constexpr (kWide) { rec.lb |= (uint64_t)h[7 * W] << 32; rec.lb_rev |= (uint64_t)h[8 * W] << 32; rec.len |= (uint64_t)h[9 * W] << 32; }
+                rec.errors = h[5 * W]; rec.seq = h[6 * W];
+                out[at] = rec;
+            }
+        }
+        if (lane == 0) __hip_atomic_store((lds_word*)ring, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    nh = 0;
+}
+
+
+// one-row cursors with the explicit LF table (DevString::lf_table): LF(row) in one 4-byte load; the row's symbol is the k with
+// C[k] <= LF(row) < C[k+1] (C staged in LDS)
+struct LfView { const idx_t* fw; const idx_t* rv; const idx_t* C; };
+__device__ __forceinline__ uint32_t symbol_of_lf_lds(const idx_t* sC, uint32_t sigma, idx_t t) {
+    uint32_t lo = 0, hi = sigma;                    // invariant: sC[lo] <= t < sC[hi]   (sC[sigma] = n > t)
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (sC[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// eight query bytes -> eight nibbles (a byte >= sigma, sigma <= 15, becomes 15 = "not a symbol"), with word operations
+__device__ __forceinline__ uint32_t pack_nibbles8(uint64_t x, uint32_t sigma) {
+    const uint64_t k1 = 0x0101010101010101ull;
+    const uint64_t t = (((x & (0x7full * k1)) + (uint64_t)(0x80u - sigma) * k1) | x) & (0x80ull * k1);   // bit 7 of a byte set <=> byte >= sigma
+    uint64_t y = (x | ((t >> 7) * 0xffull)) & (0x0full * k1);
+    y = (y | (y >> 4)) & 0x00ff00ff00ff00ffull;
+    y = (y | (y >> 8)) & 0x0000ffff0000ffffull;
+    y = (y | (y >> 16)) & 0x00000000ffffffffull;
+    return (uint32_t)y;
+}
+// ---- per-lane query staging in LDS ------------------------------------------------------------------------------
+// A DFS visits a few hundred nodes per query; reading the query symbol of every node from global memory costs a
+// second random line per node (half a million lanes' query lines do not survive in L2).  Each lane therefore copies
+// its query once into LDS: word w of lane t at  lds[w * 256 + t]  (bank = t mod 32/64: conflict-free), 8 symbols per
+// word as nibbles (sigma <= 15; 15 = "not a symbol") or 4 symbols per word as bytes.
+struct QStage {
+    uint32_t* lds;          // this block's staging area
+    uint32_t words;         // words per query (0 = staging disabled: read global memory)
+    uint32_t nib;           // 1 = 4-bit symbols
+};
+__device__ __forceinline__ void qstage_load(const QStage& st, const uint8_t* qbuf, uint64_t off, uint32_t m, uint32_t sigma) {
+    if (!st.words) return;
+    const uint64_t addr = (uint64_t)qbuf + off;
+    const uint32_t mis = (uint32_t)(addr & 7ull);
+    const uint64_t* base = reinterpret_cast<const uint64_t*>(addr - mis);
+    const uint32_t last = (mis + m - 1u) >> 3;                     // last aligned word that holds query bytes (m >= 1)
+    uint64_t lo = base[0];
+    const uint32_t per = st.nib ? 8u : 4u;
+    uint32_t wi = 0;
+    for (uint32_t k = 0; k * 8u < m; ++k) {
+        uint64_t hi = (k + 1 <= last) ? base[k + 1] : 0ull;
+        uint64_t x = mis ? ((lo >> (8u * mis)) | (hi << (64u - 8u * mis))) : lo;   // query bytes 8k .. 8k+7
+        lo = hi;
+        if (st.nib) {
+            st.lds[wi * 256u + threadIdx.x] = pack_nibbles8(x, sigma); ++wi;
+        } else {
+            st.lds[wi * 256u + threadIdx.x] = (uint32_t)x; ++wi;
+            if ((k * 8u + 4u) < m) { st.lds[wi * 256u + threadIdx.x] = (uint32_t)(x >> 32); ++wi; }
+        }
+    }
+    (void)per;
+}
+__device__ __forceinline__ uint32_t qstage_get(const QStage& st, const uint8_t* qs, uint32_t p) {
+    if (!st.words) return qs[p];
+    if (st.nib) { uint32_t v = (st.lds[(p >> 3) * 256u + threadIdx.x] >> ((p & 7u) * 4u)) & 15u; return v == 15u ? 255u : v; }
+    return (st.lds[(p >> 2) * 256u + threadIdx.x] >> ((p & 3u) * 8u)) & 255u;
+}
+
+// wave-synchronous staging of one query per lane: all loads of a chunk are issued before the first is consumed
+__device__ __forceinline__ void qstage_load_sync(const QStage& st, const uint8_t* qbuf, uint64_t off, uint32_t m, uint32_t sigma, bool active, uint32_t maxm) {
+    if (!st.words) return;                                         // staging disabled (very long queries): qstage_get reads global memory
+    const uint64_t addr = (uint64_t)qbuf + off;
+    const uint32_t mis = (uint32_t)(addr & 7ull);
+    const uint64_t* base = reinterpret_cast<const uint64_t*>(addr - mis);
+    const uint32_t nw = active ? ((mis + m + 7u) >> 3) : 0u;        // aligned 64-bit words that hold query bytes
+    uint64_t carry = 0;
+    uint32_t wi = 0;
+    for (uint32_t k0 = 0; k0 <= ((maxm + 14u) >> 3); k0 += 8) {     // uniform trip count (maxm >= every lane's m); word nw flushes the last bytes
+        uint64_t r[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) r[k] = (k0 + k < nw) ? base[k0 + k] : 0ull;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            // query bytes 8(k0+k-1) .. +7 are completed by word k0+k:  x = (carry >> 8mis) | (r[k] << (64 - 8mis))
+            const uint32_t widx = k0 + k;
+            if (widx == 0) { carry = r[k]; continue; }
+            uint64_t x = mis ? ((carry >> (8u * mis)) | (r[k] << (64u - 8u * mis))) : carry;
+            carry = r[k];
+            const uint32_t p0 = (widx - 1u) * 8u;                   // first query position in x
+            if (active && p0 < m) {
+                if (st.nib) {
+                    st.lds[wi * 256u + threadIdx.x] = pack_nibbles8(x, sigma); ++wi;
+                } else {
+                    st.lds[wi * 256u + threadIdx.x] = (uint32_t)x; ++wi;
+                    if (p0 + 4u < m) { st.lds[wi * 256u + threadIdx.x] = (uint32_t)(x >> 32); ++wi; }
+                }
+            }
+        }
+    }
+}
+
+
+// the 16 query symbols of a stretch as a 32-bit code (2 bits per symbol, the symbol consumed first in the low bits), from the nibble staging:
+// pos = query position of the stretch's first step, right = positions ascend.  valid = all 16 symbols are in 1 .. 4.
+__device__ __forceinline__ uint32_t query_code16(const QStage& qst, uint32_t pos, bool right, bool& valid) {
+    const uint32_t p0 = right ? pos : pos - 15u;                 // lowest query position of the stretch
+    const uint32_t w0 = qst.lds[(p0 >> 3) * 256u + threadIdx.x], w1 = qst.lds[((p0 >> 3) + 1u) * 256u + threadIdx.x];
+    const uint32_t w2 = (p0 & 7u) ? qst.lds[((p0 >> 3) + 2u) * 256u + threadIdx.x] : 0u;
+    const uint32_t sh = 4u * (p0 & 7u);
+    uint64_t x = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh;
+    if (sh) x |= (uint64_t)w2 << (64u - sh);
+    const uint64_t v = x - 0x1111111111111111ull;                // nibbles 1..4 -> 0..3
+    valid = ((v & ~x & 0x8888888888888888ull) == 0ull) && ((v & 0xccccccccccccccccull) == 0ull);
+    uint64_t t = v & 0x3333333333333333ull;
+    t = (t | (t >> 2)) & 0x0f0f0f0f0f0f0f0full; t = (t | (t >> 4)) & 0x00ff00ff00ff00ffull;
+    t = (t | (t >> 8)) & 0x0000ffff0000ffffull; t = (t | (t >> 16)) & 0x00000000ffffffffull;
+    uint32_t qc = (uint32_t)t;                                   // symbol at position p0 + k in bits 2k
+    if (!right) { qc = __brev(qc); qc = ((qc >> 1) & 0x55555555u) | ((qc & 0x55555555u) << 1); }   // ... at position pos - k
+    return qc;
+}
+
+// ------------------------------------------------------------------ host launchers
+static int step_counters(bool want, hipStream_t stream, unsigned long long** out) {
+    CallScratch* sc = nullptr;
+    int rc = call_scratch(&sc); if (rc) return rc;
+    if (want) FM_HIP(hipMemsetAsync(sc->ctr, 0, (size_t)kCounterStripes * kCounterKinds * 8, stream));
+    *out = want ? sc->ctr : sc->sink;
+    return 0;
+}
+// totals[0] executed steps, [1] table bytes, [2] table accesses
+static int read_step_counters(const unsigned long long* dev, hipStream_t stream, unsigned long long* totals) {
+    CallScratch* sc = nullptr;
+    int rc = call_scratch(&sc); if (rc) return rc;
+    unsigned long long* h = sc->pinned;
+    FM_HIP(hipMemcpyAsync(h, dev, (size_t)kCounterStripes * kCounterKinds * 8, hipMemcpyDeviceToHost, stream));
+    FM_HIP(hipStreamSynchronize(stream));
+    for (unsigned kind = 0; kind < kCounterKinds; ++kind) {
+        unsigned long long t = 0;
+        for (unsigned k = 0; k < kCounterStripes; ++k) t += h[kind * kCounterStripes + k];
+        totals[kind] = t;
+    }
+    return 0;
+}
+
+struct EventTimer {       // the thread's cached event pair (one timed call at a time per host thread)
+    hipEvent_t a = nullptr, b = nullptr; hipStream_t s; bool on;
+    EventTimer(hipStream_t s_, bool on_) : s(s_), on(on_) {
+        CallScratch* sc = nullptr;
+        if (on && call_scratch(&sc) == 0) { a = sc->ev_a; b = sc->ev_b; } else on = false;
+    }
+    void start() { if (on) (void)hipEventRecord(a, s); }
+    void stop() { if (on) (void)hipEventRecord(b, s); }
+    float ms() { float v = 0; if (on) { (void)hipEventSynchronize(b); (void)hipEventElapsedTime(&v, a, b); } return v; }
+};
+
+// longest and shortest query and the total symbol count of a batch whose offsets live in HBM: one reduction kernel, one small copy,
+// one synchronisation (per-block partial results reduced on the host: no atomics, nothing to initialise)
+constexpr unsigned kLenBlocks = 1024;
+static __global__ __launch_bounds__(256) void k_len_range(const uint64_t* __restrict__ qoff, uint64_t nq, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long s_v[4], s_w[4];
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0, w = ~0ull;
+    for (uint64_t q = t; q < nq; q += (uint64_t)gridDim.x * blockDim.x) { unsigned long long l = qoff[q + 1] - qoff[q]; v = l > v ? l : v; w = l < w ? l : w; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v;
+        unsigned long long p = __shfl_xor(w, off, 64); w = p < w ? p : w;
+    }
+    if ((threadIdx.x & 63u) == 0) { s_v[threadIdx.x >> 6] = v; s_w[threadIdx.x >> 6] = w; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { v = s_v[i] > v ? s_v[i] : v; w = s_w[i] < w ? s_w[i] : w; }
+        out[2 * blockIdx.x] = v; out[2 * blockIdx.x + 1] = w;
+        if (blockIdx.x == 0) out[2 * gridDim.x] = qoff[nq];
+    }
+}
+
+static int query_shape(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out_max, uint32_t* out_min, uint64_t* out_total) {
+    CallScratch* sc = nullptr;
+    int rc = call_scratch(&sc); if (rc) return rc;
+    unsigned long long* d = sc->len2;
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((nq + 255) / 256, kLenBlocks));
+    k_len_range<<<dim3(blocks), dim3(256), 0, stream>>>(dqoff, nq, d);
+    unsigned long long* h = sc->pinned;
+    hipError_t e = hipMemcpyAsync(h, d, ((size_t)2 * blocks + 1) * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return hip_fail(e, "k_len_range");
+    unsigned long long mx = 0, mn = ~0ull;
+    for (unsigned b = 0; b < blocks; ++b) { mx = std::max(mx, h[2 * b]); mn = std::min(mn, h[2 * b + 1]); }
+    *out_max = (uint32_t)std::min<unsigned long long>(mx, 0xffffffffull);
+    *out_min = (uint32_t)std::min<unsigned long long>(mn, 0xffffffffull);
+    if (out_total) *out_total = h[2 * blocks];
+    return 0;
+}
+static int query_len_range(const uint64_t* dqoff, uint64_t nq, hipStream_t stream, uint32_t* out_max, uint32_t* out_min) {
+    return query_shape(dqoff, nq, stream, out_max, out_min, nullptr);
+}
+
+// expands a scheme for queries of length m into the fast kernel's per-step table (see k_scheme_fast); false if it does not fit.
+
+}  // namespace FMGPU_NS

@@ -198,6 +198,19 @@ def test_exact_search_on_symbol_planes(sigma, built_on_gpu, monkeypatch):
     a = fm.search_no_errors.search(gx, odd, want_stats=True)
     b = fm.search_no_errors.search(gx_tree, odd, want_stats=True)
     assert not a[1].any() and np.array_equal(a[0], b[0]) and a[2].lf_steps == b[2].lf_steps
+    if sigma <= 29:
+        # an interval table in front of the symbol planes (fmgpu_index_accelerate_exact(h, 0, L, 0)): k_exact_s starts from the entry of a read's last L symbols —
+        # intervals, miss rows and step counts unchanged; switched off by selection, the table-driven kernel serves the same handle
+        for lut_len in (1, 2, 3):
+            gx.accelerate(0, lut_len=lut_len, walk=0)
+            for sel in (0, capi.SEL_NO_EXACT_LUT):
+                with fm.options(kernel_select=sel):
+                    lb, ln, st = fm.search_no_errors.search(gx, (qbuf, qoff), want_stats=True)
+                    c = fm.search_no_errors.search(gx, odd, want_stats=True)
+                assert np.array_equal(ln, oln) and np.array_equal(lb, olb) and st.lf_steps == int(ost.sum()), (sigma, lut_len, sel)
+                assert not c[1].any() and np.array_equal(c[0], b[0]) and c[2].lf_steps == b[2].lf_steps
+                assert (st.table_steps > 0) == (sel == 0) and st.table_steps % lut_len == 0
+        gx.accelerate(0, lut_len=0, walk=0)
 
 
 @pytest.mark.parametrize("layout", ["EPR16", "EPRV2_16", "EPR32"])
@@ -637,6 +650,24 @@ def test_lean_kernel_on_the_plain_index(k, length):
         finally:
             fm.options.pop("kernel_select")
     assert same_hits(got[0][0], got[1][0]) and same_hits(got[0][0], got[2][0]) and got[0][1].lf_steps == got[1][1].lf_steps == got[2][1].lf_steps
+    # a prefix table in front of the blocks (fmgpu_index_accelerate_search(h, L, 0): no LF table, so the lean kernel still serves the batch): a search whose first part is
+    # exact and longer than L symbols starts from the entry of its first L symbols — records, callback order and node counts unchanged (reads with a delimiter
+    # or a foreign byte walk from the start); the table switched off by selection gives the same
+    for lut_len in ((2, 5, 9) if length >= 50 else (2, 5)):
+        gx.accelerate_search(lut_len, 0)
+        assert bool(gx.formats & capi.FMT_PREFIX) and not (gx.formats & capi.FMT_LF)
+        for sch in schemes:
+            ohits, qc, nodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 24)
+            hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
+            assert same_hits(hits, ohits) and st.lf_steps == nodes, (k, length, lut_len)
+            if k <= 2:                                              # (the lean kernel serves these; it reports the nodes its table entries stood for)
+                assert 0 < st.table_steps <= nodes and st.table_steps <= lut_len * len(queries) * int(np.asarray(sch[0]).shape[0]), (k, length, lut_len, st.table_steps)
+            with fm.options(kernel_select=capi.SEL_NO_PREFIX_TABLE):
+                hits2, st2 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 24)
+            assert same_hits(hits2, ohits) and st2.lf_steps == nodes and st2.table_steps == 0
+        g0 = fm.search_ng26.search(gx, (qb2, qo2), schemes[0], want_stats=True, capacity=1 << 22)
+        assert same_hits(g0[0], got[0][0]) and g0[1].lf_steps == got[0][1].lf_steps
+    gx.accelerate_search(0, 0)
     # the poly-A / satellite reads alone: 64 lanes of a wave all deep in one repeat
     sat = [seqs[3][i: i + length] for i in range(0, 400)] + [seqs[4][:length]] * 200
     if all(len(q) == length for q in sat):
@@ -1065,11 +1096,11 @@ for wide in (0, 1):
             p = torch.randint(0, L, (sel.numel(),), generator=g, device=dev)
             reads[sel, p] = reads[sel, p] %% 4 + 1
         hits, st = fm.search_ng26.search(gx, (reads.reshape(-1).cpu().numpy(), np.arange(nq + 1, dtype=np.uint64) * L), fm.search_scheme.h2(4, 0, 2), want_stats=True, capacity=1 << 25)
-        out.append((wide, L, len(hits), int(st.lf_steps), int(st.table_steps)))
+        out.append((wide, L, len(hits), int(st.lf_steps), int(st.hits) >> 48))      # (the development build reports slots that disagreed with the stack in the top bits of stats.hits)
         if not wide and L == 101:                                 # the edit-distance kernel keeps its top frames in LDS slots too (write-back: a clean slot holds what HBM holds)
             hq = reads[:60_000].reshape(-1).cpu().numpy()
             ehits, est = fm.search_ng26.search(gx, (hq, np.arange(60_001, dtype=np.uint64) * L), fm.search_scheme.h2(4, 0, 2), want_stats=True, edit=True, capacity=1 << 25)
-            out.append((2, L, len(ehits), int(est.lf_steps), int(est.table_steps)))
+            out.append((2, L, len(ehits), int(est.lf_steps), int(est.hits) >> 48))
     gx.close()
 print("SLOTS", out)
 """
