@@ -100,10 +100,9 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? (kWide ? 4 : 5) : 1) void k_sche
             const bool offer = !idle && !need_search && sp > sbase && nodes - mark >= kShareNodes;
             const uint64_t idlem = __ballot(idle), offerm = __ballot(offer);
             if (idlem && offerm) {
-                const uint64_t below = (1ull << lane) - 1ull;
-                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
-                const bool give = offer && (uint32_t)__popcll(offerm & below) < pairs;
-                const bool take = idle && (uint32_t)__popcll(idlem & below) < pairs;
+                const WavePairs wp(idlem, offerm, lane);
+                const bool give = wp.gives(offer);
+                const bool take = wp.takes(idle);
                 uint64_t w0 = 0, w1 = 0, w2 = 0, wk = 0;
                 if (give) {
                     const uint64_t o = (uint64_t)sbase * stk.nlanes + gid;
@@ -111,9 +110,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? (kWide ? 4 : 5) : 1) void k_sche
                     wk = key_prefix(pkey, kWide ? ((uint32_t)(w0 >> 56) & 0xffu) : ((uint32_t)(w2 >> 32) & 0xffu));
                     ++sbase; mark = nodes; tbytes += 24u; ++tacc;
                 }
-                uint64_t om = offerm;                               // my partner: the (rank + 1)-th offering lane
-                for (uint32_t t = take ? (uint32_t)__popcll(idlem & below) : 0u; t > 0; --t) om &= om - 1ull;
-                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const int vl = wp.partner(take);                       // my partner: the lane whose frame this lane takes
                 const uint64_t t0 = __shfl(w0, vl, 64), t1 = __shfl(w1, vl, 64), t2 = __shfl(w2, vl, 64), tk = __shfl(wk, vl, 64);
                 const uint64_t tq = __shfl(q, vl, 64), tqs = __shfl((uint64_t)qs, vl, 64);
                 const uint32_t tsi = __shfl(si, vl, 64), tm = __shfl(m, vl, 64);
@@ -376,19 +373,16 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
             const bool offer = !idle && !need_search && sp > sbase && nodes - mark >= kShareNodes && report_slot != sbase;
             const uint64_t idlem = __ballot(idle), offerm = __ballot(offer);
             if (idlem && offerm) {
-                const uint64_t below = (1ull << lane) - 1ull;
-                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
-                const bool give = offer && (uint32_t)__popcll(offerm & below) < pairs;
-                const bool take = idle && (uint32_t)__popcll(idlem & below) < pairs;
+                const WavePairs wp(idlem, offerm, lane);
+                const bool give = wp.gives(offer);
+                const bool take = wp.takes(idle);
                 idx_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; uint32_t ga = 0, gb = 0, gc = 0, gd = 0; uint64_t gk = 0;
                 if (give) {
                     edit_frame_get(edit_frame(stk, gid, sbase), g0, g1, g2, g3, ga, gb, gc, gd);
                     gk = ekey_prefix(pkey, gc & 0xffu);             // (e sits in the low byte of the frame's third word)
                     ++sbase; mark = nodes;
                 }
-                uint64_t om = offerm;                               // my partner: the (rank + 1)-th offering lane
-                for (uint32_t t = take ? (uint32_t)__popcll(idlem & below) : 0u; t > 0; --t) om &= om - 1ull;
-                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const int vl = wp.partner(take);                       // my partner: the lane whose frame this lane takes
                 const uint64_t t0 = __shfl((uint64_t)g0, vl, 64), t1 = __shfl((uint64_t)g1, vl, 64), t2 = __shfl((uint64_t)g2, vl, 64), t3 = __shfl((uint64_t)g3, vl, 64);
                 const uint32_t ta = __shfl(ga, vl, 64), tb = __shfl(gb, vl, 64), tc = __shfl(gc, vl, 64), td = __shfl(gd, vl, 64);
                 const uint64_t tk = __shfl(gk, vl, 64), tq = __shfl(q, vl, 64), tqs = __shfl((uint64_t)qs, vl, 64);
@@ -658,19 +652,16 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? 5 : 1) void k_ng21(Occ fw, Occ r
             const bool offer = !idle && !need_search && sp > sbase && nodes - mark >= kShareNodes;
             const uint64_t idlem = __ballot(idle), offerm = __ballot(offer);
             if (idlem && offerm) {
-                const uint64_t below = (1ull << lane) - 1ull;
-                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
-                const bool give = offer && (uint32_t)__popcll(offerm & below) < pairs;
-                const bool take = idle && (uint32_t)__popcll(idlem & below) < pairs;
+                const WavePairs wp(idlem, offerm, lane);
+                const bool give = wp.gives(offer);
+                const bool take = wp.takes(idle);
                 idx_t g0 = 0, g1 = 0, g2 = 0, g3 = 0; uint32_t ga = 0, gb = 0, gc = 0, gd = 0; uint64_t gk = 0;
                 if (give) {
                     edit_frame_get(edit_frame(stk, gid, sbase), g0, g1, g2, g3, ga, gb, gc, gd);
                     gk = ekey_prefix(pkey, gc & 255u);
                     ++sbase; mark = nodes;
                 }
-                uint64_t om = offerm;
-                for (uint32_t t = take ? (uint32_t)__popcll(idlem & below) : 0u; t > 0; --t) om &= om - 1ull;
-                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const int vl = wp.partner(take);                       // my partner: the lane whose frame this lane takes
                 const uint64_t t0 = __shfl((uint64_t)g0, vl, 64), t1 = __shfl((uint64_t)g1, vl, 64), t2 = __shfl((uint64_t)g2, vl, 64), t3 = __shfl((uint64_t)g3, vl, 64);
                 const uint32_t ta = __shfl(ga, vl, 64), tb = __shfl(gb, vl, 64), tc = __shfl(gc, vl, 64), td = __shfl(gd, vl, 64);
                 const uint64_t tk = __shfl(gk, vl, 64), tq = __shfl(q, vl, 64), tqs = __shfl((uint64_t)qs, vl, 64);
@@ -944,19 +935,16 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
             const uint64_t idlem = __ballot(!have), offerm = __ballot(have && sp > sbase && nodes - mark >= share_nodes && nodes - nodes0 >= share_heavy);
             if (idlem && offerm) {
                 // the i-th idle lane takes the bottom frame of the i-th offering lane
-                const uint64_t below = (1ull << lane) - 1ull;
-                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
-                const bool give = have && sp > sbase && nodes - mark >= share_nodes && nodes - nodes0 >= share_heavy && (uint32_t)__popcll(offerm & below) < pairs;
-                const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
+                const WavePairs wp(idlem, offerm, lane);
+                const bool give = wp.gives(have && sp > sbase && nodes - mark >= share_nodes && nodes - nodes0 >= share_heavy);
+                const bool take = wp.takes(!have);
                 uint64_t w0 = 0, w1 = 0, w2 = 0;
                 if (give) {
                     const ulonglong2 fr = frames[(uint64_t)sbase * stk.nlanes + gid];
                     w0 = fr.x; w1 = fr.y; w2 = key_prefix(pkey, (uint32_t)(w1 >> 48) & 0xffu);
                     ++sbase; mark = nodes; tbytes += 16u; ++tacc;
                 }
-                uint64_t om = offerm;                               // the lane of my partner: the (rank + 1)-th offering lane
-                for (uint32_t k = take ? (uint32_t)__popcll(idlem & below) : 0u; k > 0; --k) om &= om - 1ull;
-                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const int vl = wp.partner(take);                       // my partner: the lane whose frame this lane takes
                 const uint64_t tw0 = __shfl(w0, vl, 64), tw1 = __shfl(w1, vl, 64), tw2 = __shfl(w2, vl, 64), tq_ = __shfl(q, vl, 64);
                 const uint64_t tqs = __shfl((uint64_t)qs, vl, 64);
                 const uint32_t tsi = __shfl(si, vl, 64);
@@ -1396,10 +1384,9 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
             const uint64_t idlem = __ballot(!have), offerm = __ballot(offer);
             if (idlem && offerm) {
                 // the i-th idle lane takes the bottom frame of the i-th offering lane
-                const uint64_t below = (1ull << lane) - 1ull;
-                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
-                const bool give = offer && (uint32_t)__popcll(offerm & below) < pairs;
-                const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
+                const WavePairs wp(idlem, offerm, lane);
+                const bool give = wp.gives(offer);
+                const bool take = wp.takes(!have);
                 uint4 g0 = make_uint4(0, 0, 0, 0), g1 = g0;
                 uint64_t gk = 0;
                 if (__ballot(give && sbase + 1u == sp)) settle();   // (a bottom frame that is also the top frame is in the slot)
@@ -1409,9 +1396,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                     gk = ekey_prefix(pkey, (g0.w >> 16) & 0xffu);
                     ++sbase; mark = nodes;
                 }
-                uint64_t om = offerm;                               // the lane of my partner: the (rank + 1)-th offering lane
-                for (uint32_t k = take ? (uint32_t)__popcll(idlem & below) : 0u; k > 0; --k) om &= om - 1ull;
-                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const int vl = wp.partner(take);                       // my partner: the lane whose frame this lane takes
                 uint4 t0, t1;
                 t0.x = __shfl(g0.x, vl, 64); t0.y = __shfl(g0.y, vl, 64); t0.z = __shfl(g0.z, vl, 64); t0.w = __shfl(g0.w, vl, 64);
                 t1.x = __shfl(g1.x, vl, 64); t1.y = __shfl(g1.y, vl, 64); t1.z = __shfl(g1.z, vl, 64); t1.w = __shfl(g1.w, vl, 64);
@@ -1824,7 +1809,9 @@ __device__ __forceinline__ void ring_flush(lds_u32* s_cnt_w, const uint32_t* rin
 // DENSE: the blocks are Format D (fmgpu_common.h; 32 bytes per 64 rows: two vector-memory instructions per interval end instead of three — the loop is bound
 // by their number); the delimiter rows, written as 'A' there, are corrected from a list behind a filter, both staged in LDS.
 constexpr uint32_t kDenseFilterBits = 32768;      // block number mod this: 25 delimiter rows mark 0.08 % of the blocks, ~7 % of the iterations of a wave meet one
-template <int WAVES, int NSTEP, bool DENSE>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
+// LUT: searches may start from the prefix table (la.lut): an instantiation of its own, so that the kernel of the plain index carries none of it (with the start
+// path compiled into the one kernel the genome text went from 95.7 to 106.8 ms although no table was there to be used)
+template <int WAVES, int NSTEP, bool DENSE, bool LUT = false>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
 __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
                                                              fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, ulonglong2* __restrict__ frames, uint64_t nlanes,
                                                              uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste, uint32_t share_heavy) {
@@ -1893,10 +1880,9 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             const bool can_give = have && sp > sbase && nodes - mark >= kShareNodes && nodes - nodes0 >= share_heavy;
             const uint64_t idlem = __ballot(!have), offerm = __ballot(can_give);
             if (idlem && offerm) {                                  // the i-th idle lane takes the bottom frame of the i-th offering lane
-                const uint64_t below = (1ull << lane) - 1ull;
-                const uint32_t pairs = (uint32_t)min(__popcll(idlem), __popcll(offerm));
-                const bool give = can_give && (uint32_t)__popcll(offerm & below) < pairs;
-                const bool take = !have && (uint32_t)__popcll(idlem & below) < pairs;
+                const WavePairs wp(idlem, offerm, lane);
+                const bool give = wp.gives(can_give);
+                const bool take = wp.takes(!have);
                 uint64_t w0 = 0, w1 = 0, w2 = 0;
                 if (give) {
                     {                                               // the bottom frame from its LDS slot (written by the push onto an empty stack, or refilled below: an
@@ -1918,9 +1904,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                                                          (__attribute__((address_space(3))) void*)(s_bos + wave * 64u), 16, 0, 0);
                     }
                 }
-                uint64_t om = offerm;
-                for (uint32_t k = take ? (uint32_t)__popcll(idlem & below) : 0u; k > 0; --k) om &= om - 1ull;
-                const int vl = (int)__ffsll((unsigned long long)om) - 1;
+                const int vl = wp.partner(take);                       // my partner: the lane whose frame this lane takes
                 const uint64_t tw0 = __shfl(w0, vl, 64), tw1 = __shfl(w1, vl, 64), tw2 = __shfl(w2, vl, 64);
                 const uint32_t tq = __shfl(q, vl, 64), tsi = __shfl(si, vl, 64), todd = __shfl((uint32_t)odd, vl, 64);
                 if (take) {
@@ -1974,14 +1958,14 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             k1 = 0; k2 = 0;
             // the always-exact first part of the search (u[0] = 0; it extends to the right, so its first lutL symbols are consecutive in the read) starts from its entry of
             // the prefix table: this iteration's ONE load is that entry instead of a block, and lutL nodes — the ones whose interval ends lie furthest apart — are not walked
-            if (la.lut && ((la.lut_ok >> si) & 1u) && !odd) {
+            if (LUT && ((la.lut_ok >> si) & 1u) && !odd) {
                 const uint32_t p0 = s_steps[si * stride] & 0xffffu, w = p0 >> 4;
                 lut_code = __funnelshift_r(s_dyn[w * 256u + tid], s_dyn[(w + 1u) * 256u + tid], (p0 & 15u) * 2u) & (la.lutL >= 16u ? 0xffffffffu : (1u << (2u * la.lutL)) - 1u);
                 lut_start = true;
             }
         }
         const uint32_t ent = s_steps[si * stride + j];
-        const bool right = (ent >> 16) & 1u, multi = !lut_start && len > 1u;
+        const bool right = (ent >> 16) & 1u, multi = !(LUT && lut_start) && len > 1u;
 #ifdef FMGPU_DEV
         dev_multi += multi ? 1u : 0u; ++dev_busy; if (lane == (uint32_t)__ffsll((unsigned long long)__ballot(true)) - 1u) ++dev_iter;
 #endif
@@ -1990,14 +1974,14 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         // memory phase: the entries of symbols 1..4 of the block(s) of both interval ends (one end for a one-row node) — Format A: 48 bytes, 12 into the 64-byte
         // block; Format D: the whole 32-byte block
         constexpr uint32_t kBlk = DENSE ? 32u : 64u, kOff = DENSE ? 0u : 12u;
-        const Quad4* pa = lut_start ? reinterpret_cast<const Quad4*>(la.lut + lut_code) : reinterpret_cast<const Quad4*>(blk + (size_t)(a >> 6) * kBlk + kOff);
+        const Quad4* pa = (LUT && lut_start) ? reinterpret_cast<const Quad4*>(la.lut + lut_code) : reinterpret_cast<const Quad4*>(blk + (size_t)(a >> 6) * kBlk + kOff);
         const Quad4 a0 = pa[0], a1 = pa[1];                         // (a table entry is 16 bytes: what follows it is read and ignored — the tables carry that much slack)
         Quad4 a2, b0, b1, b2;                                       // (only a multi-row node reads b: no default, or the compiler waits for A before it asks for B)
         if constexpr (!DENSE) a2 = pa[2];
         // the second end's block only when it is another one (the ends of a short interval share their block)
         const bool far = multi && (a >> 6) != (b >> 6);
         if (far) { const Quad4* pb = reinterpret_cast<const Quad4*>(blk + (size_t)(b >> 6) * kBlk + kOff); b0 = pb[0]; b1 = pb[1]; if constexpr (!DENSE) b2 = pb[2]; }
-        blk_loads += lut_start ? 0u : (far ? 2u : 1u);
+        blk_loads += (LUT && lut_start) ? 0u : (far ? 2u : 1u);
         STAMP(st_issue);
 #ifdef FMGPU_DEV_STAMPS
         __builtin_amdgcn_s_waitcnt(0x0f70); STAMP(st_wait);
@@ -2041,7 +2025,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         }
         bool back = false, search_over = false;
         const bool mOK = minE <= e && e <= maxE, sOK = minE <= e + 1u && e + 1u <= maxE, xOK = e + 1u <= maxE;
-        if (lut_start) {                                            // {lb, lbRev, len, nodes the walk of these symbols visits (fewer than lutL where the interval empties on the way)}
+        if (LUT && lut_start) {                                     // {lb, lbRev, len, nodes the walk of these symbols visits (fewer than lutL where the interval empties on the way)}
             lb = (idx_t)a0.x; lbRev = (idx_t)a0.y; len = (idx_t)a0.z; nodes += a0.w; lut_nodes += a0.w;
             j = la.lutL; in_tail = true;                            // (the first part is longer than lutL: the rest of it is exact too)
             if (len == 0u) back = true;
@@ -2495,7 +2479,10 @@ static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uin
 #ifdef FMGPU_DEV
     if (steps == 1) launch(k_scheme_lean<kLeanWaves, 1, false>); else if (steps == 2) launch(k_scheme_lean<kLeanWaves, 2, false>); else if (steps == 8) launch(k_scheme_lean<kLeanWaves, 8, false>); else
 #endif
-    if constexpr (!kWide) { if (dense) { launch(k_scheme_lean<kLeanWaves, kLeanSteps, true>); return; } }
+    if constexpr (!kWide) {
+        if (la.lut) { if (dense) launch(k_scheme_lean<kLeanWaves, kLeanSteps, true, true>); else launch(k_scheme_lean<kLeanWaves, kLeanSteps, false, true>); return; }
+        if (dense) { launch(k_scheme_lean<kLeanWaves, kLeanSteps, true>); return; }
+    }
     launch(k_scheme_lean<kLeanWaves, kLeanSteps, false>);
 }
 
@@ -2627,7 +2614,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         fast = build_step_table(sd, maxlen, lutL, use_wj ? 16u : 0u, b.tab, b.lut_ok);
         if (fast) buckets.push_back(std::move(b));
         const bool hf_on = opt_on(FMGPU_OPT_HEAVY_FIRST);
-        const bool by_lut = fast && x->lut && lutL >= 8 && lutL <= 16 && (buckets[0].lut_ok & 1u);     // (no step table — m < P, a scheme too large for it: the general kernel below)
+        const bool by_lut = fast && x->lut && lutL >= 15 && lutL <= 16 && (buckets[0].lut_ok & 1u);     // (no step table — m < P, a scheme too large for it: the general kernel below)
         const bool by_blocks = !have_lf && x->bwt.sigma == 5 && maxlen >= 16;     // (the plain-index instantiation)
         if (fast && (by_lut || by_blocks) && nq >= (1u << 16) && nq < 0x7fffffffull && hf_on) {
             // hand the reads of high-copy repeats out first (k_heavy_flags; decided on a sample of the batch — a text without repeats has nothing to

@@ -221,6 +221,21 @@ __device__ __forceinline__ Cur kid_of(const idx_t* lfa, const idx_t* lfb, Cur cu
     return k;
 }
 
+// ---- work sharing inside a wave: who hands a subtree to whom (used by every depth-first kernel).  idlem / offerm = ballots of the lanes that are out of work / that
+// offer the bottom frame of their stack; the i-th idle lane is paired with the i-th offering lane.
+struct WavePairs {
+    uint64_t idlem, offerm, below; uint32_t pairs;
+    __device__ __forceinline__ WavePairs(uint64_t idle_mask, uint64_t offer_mask, uint32_t lane)
+        : idlem(idle_mask), offerm(offer_mask), below((1ull << lane) - 1ull), pairs((uint32_t)min(__popcll(idle_mask), __popcll(offer_mask))) {}
+    __device__ __forceinline__ bool gives(bool offer) const { return offer && (uint32_t)__popcll(offerm & below) < pairs; }
+    __device__ __forceinline__ bool takes(bool idle) const { return idle && (uint32_t)__popcll(idlem & below) < pairs; }
+    __device__ __forceinline__ int partner(bool take) const {       // the (rank + 1)-th offering lane, for the idle lane of that rank (lane 0's for everyone else)
+        uint64_t om = offerm;
+        for (uint32_t t = take ? (uint32_t)__popcll(idlem & below) : 0u; t > 0; --t) om &= om - 1ull;
+        return (int)__ffsll((unsigned long long)om) - 1;
+    }
+};
+
 constexpr uint32_t kNoResume = 0xffffffffu;
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
