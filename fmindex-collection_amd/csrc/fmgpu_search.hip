@@ -1705,7 +1705,7 @@ constexpr uint32_t kLeanShareHeavy = 64;           // nodes a lane spends on a r
 constexpr uint32_t kLeanSuperRows = kWide ? 64u : 1u;   // super-block rows per direction staged in LDS (64 x 2^30 rows: more than HBM holds)
 constexpr uint32_t kLeanNoResume = 7u;
 constexpr int kLeanWaves = 4;            // resident blocks per CU the register allocation allows (the grid asks for 3: the loop is bound by the L1 access rate, not by latency)
-constexpr int kLeanSteps = 4;            // node steps per pass through the wave-synchronous part (genome text, kernel ms at 101 / 151 bp: 1 step 119 / 213, 2: 114 / 195, 4: 112 / 183)
+constexpr int kLeanSteps = 4;            // node steps per pass through the wave-synchronous part (genome text, kernel ms at 101 / 151 bp: 1 step 119 / 213, 2: 114 / 195, 4: 112 / 183; round 4, 8 steps for 101 bp on Format D: 99.3 against ~96 ms)
 
 struct LeanArgs {
     const uint8_t* fw; const uint8_t* rv;    // Format A blocks of bwt / bwtRev (64 bytes per 64 rows)

@@ -720,8 +720,14 @@ struct Search {
 };
 template <typename I, typename Q, typename D> Search(I const&, Q const&, bool, size_t, std::optional<size_t>, D const&) -> Search<I, Q, D>;
 
-// One index file on several GPUs of this process (include/fmgpu.h: fmgpu_replicas_*): loadReplicas<Index>(file, {0, 1, 2, 3}) loads the file once per listed
-// device (empty list: every visible device); searches cut the batch into contiguous ranges, one per replica, run them concurrently and report in batch order.
+// Library options (include/fmgpu.h: fmgpu_option) — what a new handle is given, which of several result-identical kernels serves a call; the library reads no
+// environment variable.  setOption(FMGPU_OPT_LF_TABLE, 0) before an index is made keeps it the plain configuration (occurrence tables + sampled suffix array).
+inline void setOption(fmgpu_option option, int64_t value) { detail::check(fmgpu_set_option(static_cast<int32_t>(option), value)); }
+inline auto getOption(fmgpu_option option) -> int64_t { int64_t v{}; detail::check(fmgpu_get_option(static_cast<int32_t>(option), &v)); return v; }
+
+// One index file on several GPUs of this process (include/fmgpu.h: fmgpu_replicas_*): loadReplicas<Index>(file, {0, 1, 2, 3}) reads the file ONCE, onto the first
+// listed device, and copies the handle to the others device to device (peerCopies() tells how many replicas were made that way; empty list: every visible device);
+// searches cut the batch into contiguous ranges, one per replica, run them concurrently and report in batch order.
 // `front()` is the first replica as an Index (locate and cursor steps go through it with its device current).
 template <typename Index>
 struct Replicas {
@@ -734,6 +740,7 @@ struct Replicas {
     ~Replicas() { first.handle = nullptr; if (handle) fmgpu_replicas_destroy(handle); }       // (the first replica's handle is borrowed from the set)
     auto size() const -> size_t { int32_t n{}; detail::check(fmgpu_replicas_info(handle, &n, nullptr, 0, nullptr)); return static_cast<size_t>(n); }
     auto front() const -> Index const& { return first; }
+    auto peerCopies() const -> size_t { int32_t n{}; detail::check(fmgpu_replicas_peer_copies(handle, &n)); return static_cast<size_t>(n); }
     // search_no_errors::search over the replicas: delegate(qidx, cursor) for every non-empty cursor, in batch order
     template <typename Queries, typename Delegate>
     void searchNoErrors(Queries const& queries, Delegate&& delegate) const {

@@ -274,6 +274,11 @@ int main(int argc, char** argv) {
         auto replicas = fmc::loadReplicas<fmc::BiFMIndex<5>>(file, {0, 0});
         auto sharded = run([&](auto&& d) { replicas.searchNoErrors(reads, d); });
         CHECK(!direct.empty() && direct == loaded && direct == sharded && replicas.size() == 2);
+        CHECK(replicas.peerCopies() == 1);                          // the file was read once: the second replica is a device-to-device copy of the first
+        fmc::setOption(FMGPU_OPT_KERNEL_SELECT, FMGPU_SEL_EXACT_ONE_SYMBOL);      // library options go through the ABI: the same search on the one-symbol kernel
+        auto single = run([&](auto&& d) { fmc::search_no_errors::search(index, reads, d); });
+        fmc::setOption(FMGPU_OPT_KERNEL_SELECT, 0);
+        CHECK(single == direct && fmc::getOption(FMGPU_OPT_KERNEL_SELECT) == 0 && fmc::getOption(FMGPU_OPT_PAIR_TABLE) == 1);
         size_t located = 0;
         replicas.searchNoErrors(reads, [&](size_t qidx, auto cursor) {
             for (auto [sid, spos, offset] : fmc::LocateLinear{replicas.front(), cursor}) if (sid == 0 && spos + offset == qidx * 37) ++located;
