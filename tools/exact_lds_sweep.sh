@@ -1,6 +1,7 @@
 #!/bin/bash
 # dev tool (library built with `make DEV=1`): exact-search kernels for several residencies (unused dynamic LDS per block).  usage (through gpurun): tools/exact_lds_sweep.sh <tag> <record> [lds values]
 TAG=$1; REC=$2; shift; shift
+export FMGPU_LIBRARY=${GRAFT_REPO_ROOT:-/root/repo}/fmindex-collection_amd/libfmgpu_dev.so   # the development build (make -C fmindex-collection_amd/csrc DEV=1): the shipped library reads no environment variable
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/ldssweep_$TAG.log
 : > $OUT

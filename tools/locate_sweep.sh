@@ -1,6 +1,7 @@
 #!/bin/bash
 # dev tool (library built with `make DEV=1`): locate on the plain index for several residencies (unused dynamic LDS).  usage (through gpurun): tools/locate_sweep.sh <tag>
 TAG=$1; shift
+export FMGPU_LIBRARY=${GRAFT_REPO_ROOT:-/root/repo}/fmindex-collection_amd/libfmgpu_dev.so   # the development build (make -C fmindex-collection_amd/csrc DEV=1): the shipped library reads no environment variable
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/locsweep_$TAG.log
 : > $OUT
