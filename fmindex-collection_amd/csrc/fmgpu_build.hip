@@ -321,6 +321,47 @@ __global__ __launch_bounds__(256) void k_sa_values(const idx_t* __restrict__ sa,
     }
 }
 
+// ---- the same outputs from a bucket of the bucketed sorter (fmgpu_bucketsort.hip): rows first .. first + count - 1 with their text positions, the suffix array itself is never held
+// pass 1: BWT symbols; flag[j] = row first + j is sampled
+__global__ __launch_bounds__(256) void k_bucket_bwt(const uint8_t* __restrict__ text, const idx_t* __restrict__ pos, uint64_t count, uint64_t first, uint64_t n, uint8_t* __restrict__ bwt,
+                                                    const uint64_t* __restrict__ sstart, uint64_t nseq, uint64_t rate, uint32_t* __restrict__ flag) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = pos[j];
+        bwt[first + j] = text[p ? p - 1 : n - 1];
+        if (flag) { uint64_t s, o; seq_of(sstart, nseq, p, s, o); flag[j] = o % rate == 0 ? 1u : 0u; }
+    }
+}
+// pass 2: presence bits and values; at[j] = sampled rows of the bucket before row j, *base = sampled rows of the buckets before this one
+__global__ __launch_bounds__(256) void k_bucket_samples(const idx_t* __restrict__ pos, uint64_t count, uint64_t first, const uint64_t* __restrict__ sstart, uint64_t nseq,
+                                                        const uint32_t* __restrict__ flag, const uint32_t* __restrict__ at, const unsigned long long* __restrict__ base,
+                                                        unsigned long long* __restrict__ bits, unsigned long long* __restrict__ f0, unsigned long long* __restrict__ f1,
+                                                        uint32_t w0, uint32_t w1, uint64_t d0, uint64_t d1) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) {
+        if (!flag[j]) continue;
+        uint64_t s, o; seq_of(sstart, nseq, pos[j], s, o);
+        const uint64_t i = first + j, r = *base + at[j];
+        atomicOr(&bits[i >> 6], 1ull << (i & 63u));
+        auto put = [](unsigned long long* data, uint32_t width, uint64_t idx, uint64_t v) {   // DenseVector::push_back layout, DenseVector.h:124-144
+            uint64_t begin = idx * width; uint32_t off = (uint32_t)(begin & 63u);
+            atomicOr(&data[begin >> 6], (unsigned long long)(v << off));
+            if (off + width > 64) atomicOr(&data[(begin >> 6) + 1], (unsigned long long)(v >> (64u - off)));
+        };
+        put(f0, w0, r, s / d0);
+        put(f1, w1, r, o / d1);
+    }
+}
+__global__ void k_bucket_advance(unsigned long long* __restrict__ base, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ at, uint64_t count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count) *base += (unsigned long long)at[count - 1] + flag[count - 1];
+}
+// sampled rows per 512 rows, from the finished presence bits (what k_sa_bits counts on the way)
+__global__ __launch_bounds__(256) void k_count_presence(const uint64_t* __restrict__ bits, uint64_t nl1, cnt_t* __restrict__ g) {
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nl1; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < 8; ++k) c += (uint32_t)__popcll(bits[b * 8 + k]);
+        g[b] = (cnt_t)c;
+    }
+}
+
 static int make_format_a(const uint8_t* bwt, uint64_t n, uint32_t sigma, const idx_t* dC, DevString& s, int layout, hipStream_t stream) {
     uint64_t nblocks = n / 64 + 1;
     uint32_t bstride = sigma <= 5 ? 64u : 12u * sigma;
@@ -545,8 +586,16 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
     auto bail = [&](int code) { api::fmgpu_index_destroy(reinterpret_cast<fmgpu_index_t>(x.release())); return code; };
     (void)hipGetDevice(&x->hdr.device);
 
+    // the suffix sorter: all suffixes at once (suffix array, rank array, key buffers: 30 / 42 bytes per row beside the text) where that fits the free memory, bucket by
+    // bucket without ever holding the array (fmgpu_bucketsort.hip) where it does not — or where FMGPU_OPT_BUCKET_ROWS asks for it
+    const uint64_t bucket_rows = (uint64_t)opt(FMGPU_OPT_BUCKET_ROWS);
+    bool bucketed = bucket_rows > 0;
+    if (!bucketed) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)n * (kWide ? 44.0 : 32.0) > (double)free_b) bucketed = true;
+    }
     DBuf text, sa, bwt;
-    if ((rc = text.alloc(n)) || (rc = sa.alloc(n * sizeof(idx_t))) || (rc = bwt.alloc(n))) return bail(rc);
+    if ((rc = text.alloc(n)) || (rc = bwt.alloc(n)) || (!bucketed && (rc = sa.alloc(n * sizeof(idx_t))))) return bail(rc);
     k_assemble_text<<<grid_for(n), 256, 0, stream>>>((const uint8_t*)sseq.dev, (const uint64_t*)soff.dev, nseq, text.as<uint8_t>(), n);
     {
         hipError_t le = hipGetLastError();
@@ -560,8 +609,91 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
         if (e != hipSuccess) return bail(hip_fail(e, "k_check_symbols"));
         if (hb) return bail(fail(FMGPU_ERR_INVALID, "a sequence holds a symbol >= sigma"));
     }
-    if ((rc = build_suffix_array(text.as<uint8_t>(), n, (uint32_t)sigma, sa.as<idx_t>(), stream))) return bail(rc);
-    k_bwt<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), sa.as<idx_t>(), n, bwt.as<uint8_t>());
+
+    // ---- sampled suffix array in the reference's SparseArray layout (suffixarray/SparseArray.h:31-76): sizes and arrays
+    std::vector<uint64_t> sstart(nseq + 1);
+    uint64_t maxlen = 0, nsampled = 0;
+    for (uint64_t s = 0; s <= nseq; ++s) sstart[s] = hoff[s] - hoff[0] + s;
+    for (uint64_t s = 0; s < nseq; ++s) {
+        const uint64_t len = hoff[s + 1] - hoff[s];                  // positions 0..len (delimiter slot included)
+        maxlen = std::max(maxlen, len);
+        nsampled += len / sampling_rate + 1;                        // the sampled ones among them
+    }
+    // DenseMultiVector ctor (DenseMultiVector.h:65-103): largest value and gcd per field
+    uint64_t largest0 = nseq - 1, div0 = nseq >= 2 ? 1 : 0;
+    uint64_t largest1 = (maxlen / sampling_rate) * sampling_rate, div1 = largest1 ? sampling_rate : 0;
+    if (div0 == 0) div0 = 1; if (largest0 == 0) largest0 = 1;
+    if (div1 == 0) div1 = 1; if (largest1 == 0) largest1 = 1;
+    const uint32_t w0 = bit_width64(largest0 / div0), w1 = bit_width64(largest1 / div1);
+    const uint64_t nl0 = n / 65536 + 1, nl1 = n / 512 + 1, nwords = nl1 * 8;
+    DBuf dstart, g;
+    if ((rc = dstart.alloc((nseq + 1) * 8)) || (rc = g.alloc((nl1 + 1) * sizeof(cnt_t)))) return bail(rc);
+    {
+        hipError_t e = hipMemcpy(dstart.p, sstart.data(), (nseq + 1) * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bail(hip_fail(e, "copy sstart"));
+        if ((e = hipMalloc(&x->sa_bits, nwords * 8)) != hipSuccess || (e = hipMalloc(&x->sa_l0, nl0 * 8)) != hipSuccess || (e = hipMalloc(&x->sa_l1, nl1 * 2)) != hipSuccess)
+            return bail(hip_fail(e, "hipMalloc(sa)"));
+        (void)hipMemsetAsync(x->sa_bits, 0, nwords * 8, stream);
+        (void)hipMemsetAsync(g.p, 0, (nl1 + 1) * sizeof(cnt_t), stream);
+    }
+    uint64_t f0words = 0, f1words = 0;
+    auto alloc_fields = [&](uint64_t nvalues) -> int {
+        f0words = (nvalues * w0 + 63) / 64; f1words = (nvalues * w1 + 63) / 64;
+        hipError_t e;
+        if ((e = hipMalloc(&x->sa_f0, (f0words + 1) * 8)) != hipSuccess || (e = hipMalloc(&x->sa_f1, (f1words + 1) * 8)) != hipSuccess) return hip_fail(e, "hipMalloc(sa fields)");
+        (void)hipMemsetAsync(x->sa_f0, 0, (f0words + 1) * 8, stream);
+        (void)hipMemsetAsync(x->sa_f1, 0, (f1words + 1) * 8, stream);
+        return 0;
+    };
+    // g = sampled rows per 512 rows -> running counts, the two counter levels; returns the number of sampled rows
+    auto finish_levels = [&](uint64_t* nvalues_out) -> int {
+        Temp tmp;
+        int r = cub_call(tmp, [&](void* t, size_t& bytes) { return hipcub::DeviceScan::ExclusiveSum(t, bytes, g.as<cnt_t>(), g.as<cnt_t>(), (size_t)(nl1 + 1), stream); });
+        if (r) return r;
+        cnt_t nvalues_c = 0;
+        hipError_t e = hipMemcpy(&nvalues_c, g.as<cnt_t>() + nl1, sizeof(cnt_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return hip_fail(e, "sample count");
+        *nvalues_out = nvalues_c;
+        k_sa_levels<<<grid_for(nl1), 256, 0, stream>>>(g.as<cnt_t>(), nl1, nl0, (uint64_t*)x->sa_l0, (uint16_t*)x->sa_l1);
+        FM_LAUNCHED("k_sa_levels");
+        return 0;
+    };
+
+    // bwt (and, forward text only, the sampled entries) of `text` through the bucketed sorter
+    auto bucketed_pass = [&](bool with_samples) -> int {
+        DBuf base; int r;
+        if ((r = base.alloc(8))) return r;
+        FM_HIP(hipMemsetAsync(base.p, 0, 8, stream));
+        Temp tmp;
+        return sort_suffixes_bucketed(text.as<uint8_t>(), n, (uint32_t)sigma, bucket_rows, [&](uint64_t first, const idx_t* pos, uint64_t count, void* scratch, size_t scratch_bytes) -> int {
+            if (with_samples && scratch_bytes < count * 8) return fail(FMGPU_ERR_HIP, "bucket scratch too small");
+            uint32_t* flag = with_samples ? reinterpret_cast<uint32_t*>(scratch) : nullptr;
+            uint32_t* at = with_samples ? flag + count : nullptr;
+            k_bucket_bwt<<<grid_for(count), 256, 0, stream>>>(text.as<uint8_t>(), pos, count, first, n, bwt.as<uint8_t>(), dstart.as<uint64_t>(), nseq, sampling_rate, flag);
+            FM_LAUNCHED("k_bucket_bwt");
+            if (!with_samples) return 0;
+            int r2 = cub_call(tmp, [&](void* t, size_t& bytes) { return hipcub::DeviceScan::ExclusiveSum(t, bytes, flag, at, (size_t)count, stream); });
+            if (r2) return r2;
+            k_bucket_samples<<<grid_for(count), 256, 0, stream>>>(pos, count, first, dstart.as<uint64_t>(), nseq, flag, at, base.as<unsigned long long>(), (unsigned long long*)x->sa_bits,
+                                                                   (unsigned long long*)x->sa_f0, (unsigned long long*)x->sa_f1, w0, w1, div0, div1);
+            FM_LAUNCHED("k_bucket_samples");
+            k_bucket_advance<<<1, 64, 0, stream>>>(base.as<unsigned long long>(), flag, at, count);
+            FM_LAUNCHED("k_bucket_advance");
+            return 0;
+        }, stream);
+    };
+
+    uint64_t nvalues = 0;
+    if (bucketed) {
+        if ((rc = alloc_fields(nsampled))) return bail(rc);
+        if ((rc = bucketed_pass(true))) return bail(rc);
+        k_count_presence<<<grid_for(nl1), 256, 0, stream>>>((const uint64_t*)x->sa_bits, nl1, g.as<cnt_t>());
+        if ((rc = finish_levels(&nvalues))) return bail(rc);
+        if (nvalues != nsampled) return bail(fail(FMGPU_ERR_HIP, "the bucketed sorter marked " + std::to_string(nvalues) + " sampled rows, the text holds " + std::to_string(nsampled)));
+    } else {
+        if ((rc = build_suffix_array(text.as<uint8_t>(), n, (uint32_t)sigma, sa.as<idx_t>(), stream))) return bail(rc);
+        k_bwt<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), sa.as<idx_t>(), n, bwt.as<uint8_t>());
+    }
 
     // C[c] = #symbols < c  (utils.h:199-206)
     {
@@ -589,48 +721,21 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
         std::memcpy(built->part[2].data(), x->hC, (sigma + 1) * 8);
     }
 
-    // ---- sampled suffix array in the reference's SparseArray layout (suffixarray/SparseArray.h:31-76)
     {
-        std::vector<uint64_t> sstart(nseq + 1);
-        uint64_t maxlen = 0;
-        for (uint64_t s = 0; s <= nseq; ++s) sstart[s] = hoff[s] - hoff[0] + s;
-        for (uint64_t s = 0; s < nseq; ++s) maxlen = std::max(maxlen, hoff[s + 1] - hoff[s]);     // positions 0..len (delimiter slot included)
-        // DenseMultiVector ctor (DenseMultiVector.h:65-103): largest value and gcd per field
-        uint64_t largest0 = nseq - 1, div0 = nseq >= 2 ? 1 : 0;
-        uint64_t largest1 = (maxlen / sampling_rate) * sampling_rate, div1 = largest1 ? sampling_rate : 0;
-        if (div0 == 0) div0 = 1; if (largest0 == 0) largest0 = 1;
-        if (div1 == 0) div1 = 1; if (largest1 == 0) largest1 = 1;
-        uint32_t w0 = bit_width64(largest0 / div0), w1 = bit_width64(largest1 / div1);
-        uint64_t nl0 = n / 65536 + 1, nl1 = n / 512 + 1, nwords = nl1 * 8;
-        DBuf dstart, g;
-        if ((rc = dstart.alloc((nseq + 1) * 8)) || (rc = g.alloc((nl1 + 1) * sizeof(cnt_t)))) return bail(rc);
-        hipError_t e = hipMemcpy(dstart.p, sstart.data(), (nseq + 1) * 8, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return bail(hip_fail(e, "copy sstart"));
-        if ((e = hipMalloc(&x->sa_bits, nwords * 8)) != hipSuccess || (e = hipMalloc(&x->sa_l0, nl0 * 8)) != hipSuccess || (e = hipMalloc(&x->sa_l1, nl1 * 2)) != hipSuccess)
-            return bail(hip_fail(e, "hipMalloc(sa)"));
-        (void)hipMemsetAsync(x->sa_bits, 0, nwords * 8, stream);
-        (void)hipMemsetAsync(g.p, 0, (nl1 + 1) * sizeof(cnt_t), stream);
-        for (uint64_t first = 0; first < n; first += kSliceRows) {
-            const uint64_t rows = std::min(kSliceRows, n - first);
-            k_sa_bits<<<dim3((unsigned)(((rows + 63) / 64 * 64 + 255) / 256)), 256, 0, stream>>>(sa.as<idx_t>(), n, dstart.as<uint64_t>(), nseq, sampling_rate, (uint64_t*)x->sa_bits,
-                                                                                               g.as<cnt_t>(), first);
+        if (!bucketed) {
+            for (uint64_t first = 0; first < n; first += kSliceRows) {
+                const uint64_t rows = std::min(kSliceRows, n - first);
+                k_sa_bits<<<dim3((unsigned)(((rows + 63) / 64 * 64 + 255) / 256)), 256, 0, stream>>>(sa.as<idx_t>(), n, dstart.as<uint64_t>(), nseq, sampling_rate, (uint64_t*)x->sa_bits,
+                                                                                                   g.as<cnt_t>(), first);
+            }
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return bail(hip_fail(le, "k_sa_bits"));
+            if ((rc = finish_levels(&nvalues))) return bail(rc);
+            if ((rc = alloc_fields(nvalues))) return bail(rc);
+            k_sa_values<<<grid_for(n), 256, 0, stream>>>(sa.as<idx_t>(), n, dstart.as<uint64_t>(), nseq, sampling_rate, (const uint64_t*)x->sa_bits, g.as<cnt_t>(),
+                                                         (unsigned long long*)x->sa_f0, (unsigned long long*)x->sa_f1, w0, w1, div0, div1);
         }
-        if ((e = hipGetLastError()) != hipSuccess) return bail(hip_fail(e, "k_sa_bits"));
-        Temp tmp;
-        rc = cub_call(tmp, [&](void* t, size_t& bytes) { return hipcub::DeviceScan::ExclusiveSum(t, bytes, g.as<cnt_t>(), g.as<cnt_t>(), (size_t)(nl1 + 1), stream); });
-        if (rc) return bail(rc);
-        cnt_t nvalues_c = 0;
-        e = hipMemcpy(&nvalues_c, g.as<cnt_t>() + nl1, sizeof(cnt_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return bail(hip_fail(e, "sample count"));
-        const uint64_t nvalues = nvalues_c;
-        k_sa_levels<<<grid_for(nl1), 256, 0, stream>>>(g.as<cnt_t>(), nl1, nl0, (uint64_t*)x->sa_l0, (uint16_t*)x->sa_l1);
-        uint64_t f0words = (nvalues * w0 + 63) / 64, f1words = (nvalues * w1 + 63) / 64;
-        if ((e = hipMalloc(&x->sa_f0, (f0words + 1) * 8)) != hipSuccess || (e = hipMalloc(&x->sa_f1, (f1words + 1) * 8)) != hipSuccess) return bail(hip_fail(e, "hipMalloc(sa fields)"));
-        (void)hipMemsetAsync(x->sa_f0, 0, (f0words + 1) * 8, stream);
-        (void)hipMemsetAsync(x->sa_f1, 0, (f1words + 1) * 8, stream);
-        k_sa_values<<<grid_for(n), 256, 0, stream>>>(sa.as<idx_t>(), n, dstart.as<uint64_t>(), nseq, sampling_rate, (const uint64_t*)x->sa_bits, g.as<cnt_t>(),
-                                                     (unsigned long long*)x->sa_f0, (unsigned long long*)x->sa_f1, w0, w1, div0, div1);
-        e = hipGetLastError();
+        hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return bail(hip_fail(e, "sampled suffix array kernels"));
         x->vsa = ViewSA{(const uint64_t*)x->sa_l0, (const uint16_t*)x->sa_l1, (const uint64_t*)x->sa_bits, (const uint64_t*)x->sa_f0, (const uint64_t*)x->sa_f1, w0, w1, div0, div1};
@@ -654,8 +759,11 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
         // BiFMIndex.h:78-92: reverse the whole concatenation (delimiters included), second suffix sort
         k_reverse<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), bwt.as<uint8_t>(), n);
         FM_HIP(hipMemcpyAsync(text.p, bwt.p, n, hipMemcpyDeviceToDevice, stream));
-        if ((rc = build_suffix_array(text.as<uint8_t>(), n, (uint32_t)sigma, sa.as<idx_t>(), stream))) return bail(rc);
-        k_bwt<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), sa.as<idx_t>(), n, bwt.as<uint8_t>());
+        if (bucketed) { if ((rc = bucketed_pass(false))) return bail(rc); }
+        else {
+            if ((rc = build_suffix_array(text.as<uint8_t>(), n, (uint32_t)sigma, sa.as<idx_t>(), stream))) return bail(rc);
+            k_bwt<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), sa.as<idx_t>(), n, bwt.as<uint8_t>());
+        }
         if ((rc = make_string(bwt.as<uint8_t>(), n, (uint32_t)sigma, x->dC, x->rev, layout, stream))) return bail(rc);
         x->bidirectional = true;
         if (built) {

@@ -70,6 +70,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -692,6 +693,11 @@ struct DevString {
 int build_format_a_shadow(DevString& s, const idx_t* dC, hipStream_t stream);
 // Format M from a device array of symbols (string/Wavelet.h:61-71 restated as bulk passes); defined in fmgpu_build.hip
 int make_format_m(const uint8_t* symbols, uint64_t n, uint32_t sigma, const idx_t* dC, DevString& s, int layout, hipStream_t stream);
+
+// Suffix sorting without the suffix array (fmgpu_bucketsort.hip): the suffixes are sorted bucket by bucket (a bucket = a range of rows) and every bucket's text positions are handed to
+// `sink`, in ascending row order: sink(first_row, pos, count, scratch, scratch_bytes) — scratch: device memory the sink may use until it returns (8 bytes per row of the largest bucket)
+using SuffixSink = std::function<int(uint64_t first_row, const idx_t* pos, uint64_t count, void* scratch, size_t scratch_bytes)>;
+int sort_suffixes_bucketed(const uint8_t* text, uint64_t n, uint32_t sigma, uint64_t bucket_rows, const SuffixSink& sink, hipStream_t stream);
 
 struct Index;
 // 0 if the calling thread's current device is the one the handle lives on; defined in fmgpu_index.hip

@@ -166,7 +166,7 @@ typedef struct fmgpu_stats {
 } fmgpu_stats;
 
 /* Library options: process-wide, read when a handle is created / a call starts (set them before, not during, the calls they concern).
- * The first seven choose what a handle holds or how a batch is prepared — results never depend on them; the last three are test hooks. */
+ * The first seven and FMGPU_OPT_BUCKET_ROWS choose what a handle holds or how a batch / a construction is prepared — results never depend on them; FORCE_WIDE, KERNEL_SELECT and FAIL_SCRATCH are test hooks. */
 typedef enum fmgpu_option {
     FMGPU_OPT_PAIR_TABLE = 0,      /* 1 (default): a sigma = 5 bwt gets the symbol-pair table (exact search takes two symbols per step) */
     FMGPU_OPT_DENSE_DNA = 1,       /* 1: both strings of a sigma = 5 BiFMIndex with 32-bit rows get dense DNA blocks (equal-length k-mismatch kernel) */
@@ -178,7 +178,10 @@ typedef enum fmgpu_option {
     FMGPU_OPT_FORCE_WIDE = 7,      /* test hook, 0: 1 = every new handle is held in 64-bit-row tables whatever its size */
     FMGPU_OPT_KERNEL_SELECT = 8,   /* test / A-B hook, 0: FMGPU_SEL_* bits — which of several result-identical kernels serves a call */
     FMGPU_OPT_FAIL_SCRATCH = 9,    /* test hook, 0: k = the k-th allocation of the next per-thread call scratch fails */
-    FMGPU_OPT_COUNT_ = 10
+    FMGPU_OPT_BUCKET_ROWS = 10,    /* 0 (default): fmgpu_build_index sorts all suffixes at once where the suffix array and its buffers fit the free device memory (30 / 42 bytes
+                                    * per row with 32- / 64-bit rows) and bucket by bucket, without ever holding the suffix array, where they do not;
+                                    * k > 0: always bucket by bucket, k rows per bucket at most (results do not depend on it) */
+    FMGPU_OPT_COUNT_ = 11
 } fmgpu_option;
 /* bits of FMGPU_OPT_KERNEL_SELECT: each takes a call off the kernel the library would pick (the parity tests run every kernel through them) */
 #define FMGPU_SEL_GENERAL_DFS      (1 << 1)   /* search_ng26 / ng21: the general kernels (k_scheme, k_scheme_edit, k_ng21) */

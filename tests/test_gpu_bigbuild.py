@@ -1,0 +1,125 @@
+"""Construction bucket by bucket (csrc/fmgpu_bucketsort.hip) — the suffix sorter that never holds the suffix array, for texts beyond the ~6e9 rows the doubling sorter's
+buffers fit (UniRef50-sized protein databases: BASELINE.json configs[4]).  FMIndex(Sequences, samplingRate) / BiFMIndex(...) (fmindex/FMIndex.h:58-104, BiFMIndex.h:107-167,
+utils.h:97-163) as restated by the oracle, and the library's own all-at-once sorter (pinned against the oracle in test_gpu_parity.py), are what it is compared with:
+every built array byte for byte — BWT, bwtRev, C, the SparseArray's presence bits, both counter levels, both bit-packed fields and their parameters."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import fmindex_collection_amd as fm  # noqa: E402
+from fmindex_collection_amd import capi  # noqa: E402
+from tests.util import make_text, sample_reads  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _built(gx, bidir):
+    parts = [gx.built_array(0).copy(), gx.built_array(2, np.uint64).copy()] + [gx.built_array(k, np.uint64 if k != 4 else np.uint16).copy() for k in range(3, 9)]
+    if bidir:
+        parts.append(gx.built_array(1).copy())
+    return parts
+
+
+def _same(a, b):
+    return len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def _collection(seed):
+    """1 to 30 sequences over alphabets 2 .. 28: random ones, runs of one symbol, tandem repeats, exact and truncated copies of earlier sequences (ties that only a delimiter resolves)"""
+    rng = np.random.default_rng(9000 + seed)
+    sigma = int(rng.choice([2, 3, 5, 5, 6, 21, 28]))
+    seqs = []
+    for _ in range(int(rng.integers(1, 31))):
+        kind = int(rng.integers(0, 6))
+        m = int(rng.integers(0, 600))
+        if kind == 0 or sigma == 2: q = np.ones(m, dtype=np.uint8)
+        elif kind == 1: q = np.tile(rng.integers(1, sigma, size=int(rng.integers(1, 9)), dtype=np.uint8), m // 2 + 1)[:m]
+        elif kind == 2 and seqs: q = seqs[int(rng.integers(0, len(seqs)))].copy()
+        elif kind == 3 and seqs: base = seqs[int(rng.integers(0, len(seqs)))]; q = base[len(base) // 3:].copy()
+        else: q = rng.integers(1, sigma, size=m, dtype=np.uint8)
+        seqs.append(q.astype(np.uint8))
+    return sigma, seqs, int(rng.choice([1, 3, 16, 64])), bool(rng.integers(0, 2))
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("wide", [False, True])
+def test_bucketed_construction_equals_the_all_at_once_sorter(seed, wide):
+    """the same collection built with the doubling sorter and bucket by bucket — buckets of 1, 61 and 4000 rows and one bucket for everything — in both row widths"""
+    sigma, seqs, rate, bidir = _collection(seed)
+    cls = fm.BiFMIndex if bidir else fm.FMIndex
+    layout = "WAVELET" if sigma > 5 else "IB16"
+    with fm.options(force_wide=1 if wide else 0):
+        want = _built(cls.from_sequences(seqs, sigma, layout, rate, keep_host=True), bidir)
+        for rows in ((1,) if seed % 4 == 0 else ()) + (61, 4000, 1 << 40):
+            with fm.options(bucket_rows=rows):
+                gx = cls.from_sequences(seqs, sigma, layout, rate, keep_host=True)
+            assert gx.row_bits == (64 if wide else 32)
+            assert _same(_built(gx, bidir), want), (seed, wide, rows, sigma, len(seqs), rate, bidir)
+
+
+def test_bucketed_construction_against_the_oracle():
+    """... and directly against the CPU restatement of the reference's construction (BWT, C, SparseArray arrays, locate), 200 kbp in 23 buckets"""
+    import fmoracle as fo
+    seqs = [make_text(120_000, 5, 31), make_text(7, 5, 32), make_text(80_000, 5, 33)]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 16, True)
+    with fm.options(bucket_rows=9000):
+        gx = fm.BiFMIndex.from_sequences(seqs, 5, "IB16", 16, keep_host=True)
+    n = ox.n
+    assert gx.n == n
+    assert np.array_equal(gx.built_array(2, np.uint64), ox.C)
+    sp = ox.sparse()
+    assert np.array_equal(gx.built_array(3, np.uint64), sp["l0"]) and np.array_equal(gx.built_array(4, np.uint16), sp["l1"]) and np.array_equal(gx.built_array(5, np.uint64), sp["bits"])
+    assert np.array_equal(gx.built_array(6, np.uint64), sp["fields"][0]["data"]) and np.array_equal(gx.built_array(7, np.uint64), sp["fields"][1]["data"])
+    bw = gx.built_array(0); bwr = gx.built_array(1)
+    st, sr = ox.bwt_string(), ox.bwt_string(rev=True)
+    for i in range(0, n, 37):
+        assert bw[i] == st.symbol(i) and bwr[i] == sr.symbol(i)
+    reads = sample_reads(np.concatenate(seqs[::2]), 3000, 40, seed=5, mutate=1)
+    qbuf, qoff = fm.flatten(reads)
+    lb, ln = fm.search_no_errors.search(gx, (qbuf, qoff))
+    olb, oln = ox.search_exact(qbuf, qoff)
+    assert np.array_equal(lb, olb) and np.array_equal(ln, oln)
+    rows = np.arange(0, n, 211, dtype=np.uint64)
+    seq, pos, steps = gx.locate(rows)
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(seq, pos, steps)] == [ox.locate(int(r)) for r in rows]
+
+
+def test_bucketed_construction_of_a_protein_text_with_shared_domains():
+    """sigma = 28, 3 M residues in 6 000 sequences, a fifth of them carrying one of 40 'domains' of 30 .. 300 residues verbatim (ties of hundreds of symbols between distant
+    sequences: several tie rounds), 40 buckets: every array equals the all-at-once sorter's; exact search of 40-residue reads finds every read where it was cut"""
+    rng = np.random.default_rng(77)
+    domains = [rng.integers(1, 28, size=int(rng.integers(30, 301)), dtype=np.uint8) for _ in range(40)]
+    seqs = []
+    for i in range(6000):
+        q = rng.integers(1, 28, size=500, dtype=np.uint8)
+        if i % 5 == 0:
+            d = domains[int(rng.integers(0, 40))]; at = int(rng.integers(0, 500 - len(d) + 1)); q[at:at + len(d)] = d
+        seqs.append(q)
+    want = _built(fm.FMIndex.from_sequences(seqs, 28, "WAVELET", 16, keep_host=True), False)
+    with fm.options(bucket_rows=80_000):
+        gx = fm.FMIndex.from_sequences(seqs, 28, "WAVELET", 16, keep_host=True)
+    assert _same(_built(gx, False), want)
+    pick = rng.integers(0, 6000, size=2000); off = rng.integers(0, 460, size=2000)
+    reads = [seqs[int(s)][int(o):int(o) + 40] for s, o in zip(pick, off)]
+    lb, ln = fm.search_no_errors.search(gx, fm.flatten(reads))
+    assert (ln >= 1).all()
+    seq, pos, steps = gx.locate(lb)                                 # (the first row of each interval — SOME occurrence of the read: the sampled entry + the LF steps that led to it, FMIndex.h:113-124)
+    for s, p, k, r in zip(seq, pos, steps, reads):
+        assert np.array_equal(seqs[int(s)][int(p) + int(k):int(p) + int(k) + 40], r)
+
+
+def test_a_megabase_run_is_refused_not_ground_through():
+    """the bucketed sorter breaks ties by reading further symbols of the text, not by doubling: a run of 3 M equal symbols would cost ~2e5 rounds over the run's rows.
+    Its work is bounded and the text is refused with an error that says so; the all-at-once sorter builds the same text"""
+    seqs = [np.concatenate([make_text(2000, 5, 3), np.ones(3_000_000, dtype=np.uint8), make_text(2000, 5, 4)])]
+    with fm.options(bucket_rows=1 << 40):
+        with pytest.raises(fm.FmgpuError) as e:
+            fm.FMIndex.from_sequences(seqs, 5, "IB16", 16)
+    assert e.value.code == capi.FMGPU_ERR_UNSUPPORTED and "doubling" in str(e.value)
+    assert fm.FMIndex.from_sequences(seqs, 5, "IB16", 16).n == 3_004_001
