@@ -73,7 +73,9 @@ FMT_NODE_BLOCKS = (96, 48)                            # Format A in the lean ker
 FMT_NODE_EDIT = (128, 64)                             # the edit-distance kernel reads whole 64-byte blocks
 FMT_STEP_LOCATE = 64                                  # one fused 64-byte block per locate step (+ two 8-byte value words per located row)
 PROTEIN_SEQS, PROTEIN_SEQ_LEN = 4_000_000, 500        # UniRef50 stand-in (the release itself is not available offline): 2.0e9 residues
-PROTEIN_SEQS_WIDE = 9_000_000                         # ... and 4.5e9 residues: more than 2^32 rows, the 64-bit-row build of the kernels (UniRef50 itself is ~1e10)
+PROTEIN_SEQS_WIDE = 9_000_000                         # ... and 4.5e9 residues: more than 2^32 rows, the 64-bit-row build of the kernels
+PROTEIN_SEQS_XL = 20_000_000                          # ... and 1.0e10 residues, UniRef50's own order of magnitude (BASELINE.json configs[4]): the suffix array and its sort buffers (42 bytes per row) do not fit
+                                                      # beside the text; construction sorts the suffixes bucket by bucket without ever holding the array (csrc/fmgpu_bucketsort.hip)
 
 
 def parse():
@@ -91,6 +93,7 @@ def parse():
     ap.add_argument("--with-edit", action="store_true", help="also measure k = 2 EDIT distance (search_ng26<Edit = true>, the reference's default) on 2 M of the 101-bp reads, with the tables")
     ap.add_argument("--no-protein", action="store_true")
     ap.add_argument("--no-protein-wide", action="store_true", help="skip the 4.5e9-residue protein record (64-bit rows)")
+    ap.add_argument("--no-protein-xl", action="store_true", help="skip the 1.0e10-residue protein record (UniRef50-sized: construction bucket by bucket)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads in the CPU baseline sample (0 = auto, ~15 s of CPU work)")
     ap.add_argument("--single-rank-collectives", action="store_true", help="rehearsal only: run the N > 1 code path (process group, asynchronous gather, barrier) with one rank")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -188,6 +191,8 @@ def main():
         records += run_protein(c, PROTEIN_SEQS, "protein")
         if not args.no_protein_wide:
             records += run_protein(c, PROTEIN_SEQS_WIDE, "protein_wide")
+        if not args.no_protein_xl:
+            records += run_protein(c, PROTEIN_SEQS_XL, "protein_xl", plain_only=True)
     if rank != 0:
         if c.multi:
             c.dist.destroy_process_group()
@@ -228,9 +233,9 @@ def compact_line(records, multi, records_file):
                                                     "units_per_launch", "bytes_per_unit") if k in rf}
         if rf.get("frac_sec8d") is None and "sec8d" in rf:
             line["roofline"]["sec8d_uncapped"] = _r4(rf["sec8d"]["frac_uncapped"])     # (> 1: SURVEY 8d's 112 B per step is more than this kernel's format makes it read)
-        line["roofline"]["rule"] = "frac = kernel-format bytes (2 interval ends x bytes read of the step's block) / kernel time / peak; sec8d = reference-layout bytes; loaded = counted in the kernel"
+        line["roofline"]["rule"] = "frac = kernel-format bytes (2 interval ends x bytes read of a step's block) / kernel time / peak; sec8d: reference-layout bytes; loaded: counted in the kernel"
         if rf.get("traffic") is not None:
-            line["roofline"]["traffic_source"] = "replayed from the committed rocprofv3 --pmc passes (profiles/), not measured in this run"
+            line["roofline"]["traffic_source"] = "replayed: rocprofv3 --pmc passes in profiles/, not this run"
     if head.get("clocks"):
         line["clocks"] = head["clocks"]
     cb = head.get("cpu_baseline")
@@ -271,8 +276,8 @@ def compact_line(records, multi, records_file):
     line["records_file"] = records_file
     out = json.dumps(line, separators=(",", ":"))
     if len(out) > MAX_LINE - 300:                                # keep room to spare: the comparison text's records first go to the records file alone ...
-        line["summary"] = {r["id"]: row(r) for r in records if r["id"].split("/")[0] in (first_text, "protein", "protein_wide")}
-        line["summary_also_in_records_file"] = sorted({r["id"].split("/")[0] for r in records} - {first_text, "protein", "protein_wide"})
+        line["summary"] = {r["id"]: row(r) for r in records if r["id"].split("/")[0] in (first_text, "protein", "protein_wide", "protein_xl")}
+        line["summary_also_in_records_file"] = sorted({r["id"].split("/")[0] for r in records} - {first_text, "protein", "protein_wide", "protein_xl"})
         out = json.dumps(line, separators=(",", ":"))
     if len(out) > MAX_LINE:                                      # ... and never let the headline be cut: drop the optional parts
         for k in ("summary_also_in_records_file", "summary_columns", "k2_cpu_baseline", "with_tables", "one_symbol_steps", "summary", "clocks"):
@@ -968,11 +973,13 @@ def _scheme_struct(capi, scheme):
 
 
 # ---------------------------------------------------------------------------------------------------------------- protein, configs[4]
-def run_protein(c, nseq, tag):
+def run_protein(c, nseq, tag, plain_only=False):
     torch, np, fm, capi, args = c.torch, c.np, c.fm, c.capi, c.args
     import ctypes as C
     ids = [tag + "/exact/wavelet", tag + "/exact/tables", tag + "/exact/tree", tag + "/exact/wavelet+lut5"]
-    if c.only and not any(i in c.only for i in ids):
+    if plain_only:                                            # (the optional tables of a 1e10-row index — 16 bytes per row and table — are not this record's subject)
+        ids[1] = ids[3] = None
+    if c.only and not any(i in c.only for i in ids if i):
         return []
     sigma, L, nq = 28, 40, args.nq
     total = nseq * PROTEIN_SEQ_LEN
@@ -986,6 +993,9 @@ def run_protein(c, nseq, tag):
     qbuf, qoff = sample_reads(c, text, None, L, nq, 1000, "exact", sigma=sigma, inside=(nseq, PROTEIN_SEQ_LEN))
     torch.cuda.synchronize()
     fm.options["lf_table"] = 0
+    # (fmgpu_build_index's own rule, csrc/fmgpu_build.hip: all suffixes at once where 44 bytes per row with 64-bit rows / 32 with 32-bit rows fit the free memory)
+    sorter = "bucket by bucket (the suffix array is never held)" if fm.options["bucket_rows"] or (total + nseq) * (44 if total + nseq >= (1 << 32) - 64 else 32) > torch.cuda.mem_get_info()[0] \
+        else "all suffixes at once (prefix doubling)"
     t0 = time.time()
     index = fm.FMIndex.from_sequences((_Dev(text), _Dev(seq_off)), sigma, "WAVELET", 16, keep_host=False)
     build_s = time.time() - t0
@@ -1008,8 +1018,12 @@ def run_protein(c, nseq, tag):
              "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
              "config": {"workload": "protein_exact", "text": {"text": "uniform residues in {1..27}", "symbols": total, "sequences": nseq}, "sigma": sigma, "layout": "Wavelet",
                         "index": "FMIndex", "index_kind": kind, "row_bits": index.row_bits, "queries_per_gpu": nq, "read_len": L, "index_device_bytes": index.device_bytes,
-                        "index_build_s": round(b_s, 2), "tables": tables},
+                        "index_build_s": round(b_s, 2), "suffix_sorter": sorter, "tables": tables},
              "gres_per_s": qps * L / 1e9, "hits": int((out_t[nq:] > 0).sum().item())}
+        # every read was cut from the text; every 10th then got one substitution (27^40 strings of its length: such a read is not in the text): exactly the others are found
+        r["hits_expected"] = nq - (nq + 9) // 10
+        if r["hits"] != r["hits_expected"]:
+            raise SystemExit("bench.py: %s found %d of the %d reads that were cut from the text" % (rid, r["hits"], r["hits_expected"]))
         st = {k: mean([x[k] for x in log]) for k in ("table_bytes", "table_accesses", "table_steps")}
         if kind.startswith("wavelet") and kernel in ("k_exact_s", "k_exact_ls"):
             r["roofline"] = roofline_plain(kernel, k_ms, units, "executed LF steps", (units - st["table_steps"]) * FMT_STEP_PLANES28 + st["table_steps"] / 5.0 * 8.0,
@@ -1048,7 +1062,7 @@ def run_protein(c, nseq, tag):
             r1["roofline"]["line_kernel_speedup"] = r1["roofline"]["kernel_ms"] / flat_ms
         out.append(r1)
         del keep
-    if flat and wanted(c, tag + "/exact/wavelet+lut5"):           # the same search behind a 5-symbol interval table (27^5 entries: 115 MB with 32-bit rows), no other table
+    if flat and ids[3] and wanted(c, ids[3]):                     # the same search behind a 5-symbol interval table (27^5 entries: 115 MB with 32-bit rows), no other table
         if not wanted(c, ids[0]):
             step([]); torch.cuda.synchronize()
         keep = out_t.clone()
@@ -1063,7 +1077,7 @@ def run_protein(c, nseq, tag):
             r2["roofline"]["speedup_over_plain_index_kernel"] = flat_ms / r2["roofline"]["kernel_ms"]
         out.append(r2)
         del keep
-    if len(ids) > 1 and wanted(c, ids[1]):
+    if ids[1] and wanted(c, ids[1]):
         t0 = time.time()
         wide = index.row_bits == 64                            # 64-bit rows: 16-byte entries — the 6-symbol walk alone (72 GB at 4.5e9 rows), no 12-symbol one
         index.accelerate(1, lut_len=6, walk=1 if wide else 2)

@@ -285,19 +285,36 @@ __device__ __forceinline__ uint32_t flat_rank_lds(const lds_word* own, uint32_t 
 }
 // the super table in LDS: 32-bit rows as they are; 64-bit rows as a low word + a high byte per entry (5 instead of 8 bytes: sigma = 28, 4.5 x 10^9 rows: 19 KB,
 // four resident blocks per CU; read through L2 instead the kernel took 13 % longer on the same text)
-constexpr size_t kFlatSuperLdsMax = 44 * 1024;      // (with the 16.6 KB of the regions: within the 64 KB a launch gets without asking)
+// Every workgroup stages its own copy, so a large table costs residency: 42 KB (sigma = 28, 10^10 rows) beside the 16.6 KB of four waves' regions leaves two 256-lane workgroups per CU —
+// 8 waves where the kernel wants 16 and more.  The kernel is therefore instantiated for workgroups of 256, 512 and 1024 lanes (4 / 8 / 16 waves share one copy; a CU has 160 KB of LDS and
+// one workgroup may take all of it), and the launch takes the size that keeps the most waves resident: 10^10 rows: two workgroups of 512 lanes = 16 waves per CU.
+constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr size_t kFlatSuperLdsMax = 88 * 1024;      // (with the 66 KB of sixteen waves' regions: one workgroup of 1024 lanes per CU; sigma = 28: 2.1 x 10^10 rows)
 __host__ __device__ constexpr size_t flat_super_lds_bytes(uint32_t entries) { return kWide ? ((size_t)entries * 5u + 15u) / 16u * 16u : (size_t)entries * 4u; }
-// slut != null: a read starts from the interval-table entry of its last lutL symbols (fmgpu_index_accelerate_exact(h, 1, lutL, 0); sigma = 28, 5 symbols: 27^5 entries,
-// 115 MB), as k_exact_p does; an empty entry, or a foreign byte among those symbols, is walked from the start.
-__global__ __launch_bounds__(256) void k_exact_s(const uint8_t* __restrict__ flat, const idx_t* __restrict__ super, uint32_t sigma, uint32_t cbits,
+__host__ constexpr size_t flat_lds_bytes(uint32_t block, uint32_t super_entries) { return (size_t)(block / 64u) * 8u * (1024u + 16u) + 16u + flat_super_lds_bytes(super_entries); }
+// lanes per workgroup: the smallest workgroup that keeps 16 waves resident on a CU (the kernel's 74 registers allow 24; more than 16 gain nothing — they queue up at the memory
+// system), else the one that keeps the most.  Measured, 10 M x 40 aa, kernel ms with 256 / 512 / 1024 lanes: 2.0 x 10^9 rows (6.7 KB table) 7.98 / 7.53 / 7.66; 4.5 x 10^9 rows (19 KB)
+// 7.95 / 8.38 / 8.02; 10^10 rows (42 KB: 8 / 16 / 16 resident waves) 8.85 / 8.62 / 8.86
+inline uint32_t flat_block_lanes(uint32_t super_entries) {
+    uint32_t best = 256, best_waves = 0;
+    for (uint32_t blk : {256u, 512u, 1024u}) {
+        const size_t lds = flat_lds_bytes(blk, super_entries);
+        if (lds > kLdsPerCu) continue;
+        const uint32_t waves = (uint32_t)std::min<size_t>(16u, (kLdsPerCu / lds) * (blk / 64u));
+        if (waves > best_waves) { best_waves = waves; best = blk; }
+    }
+    return best;
+}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_exact_s(const uint8_t* __restrict__ flat, const idx_t* __restrict__ super, uint32_t sigma, uint32_t cbits,
                                                  const void* __restrict__ slut, uint32_t lutL,
                                                  const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff,
                                                  uint64_t nq, idx_t n, uint64_t* __restrict__ out_lb, uint64_t* __restrict__ out_len,
                                                  unsigned long long* __restrict__ steps_total, uint32_t super_lds) {
-    extern __shared__ uint32_t s_flat[];                            // 4 waves x 8 regions | 16 bytes | the super table, when it fits (super_lds entries)
-    uint32_t* const s_lo = s_flat + 4u * 8u * (kCoopRegion / 4u) + 4u;
+    extern __shared__ uint32_t s_flat[];                            // BLOCK / 64 waves x 8 regions | 16 bytes | the super table, when it fits (super_lds entries)
+    uint32_t* const s_lo = s_flat + (uint32_t)(BLOCK / 64) * 8u * (kCoopRegion / 4u) + 4u;
     uint8_t* const s_hi = reinterpret_cast<uint8_t*>(s_lo + super_lds);
-    for (uint32_t t = threadIdx.x; t < super_lds; t += 256u) {
+    for (uint32_t t = threadIdx.x; t < super_lds; t += (uint32_t)BLOCK) {
         const idx_t v = super[t];
         s_lo[t] = (uint32_t)v;
         if constexpr (kWide) s_hi[t] = (uint8_t)((uint64_t)v >> 32);
@@ -691,10 +708,19 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
     } else if (x->bwt.flat && x->bwt.search_family() != FAM_A && !(kernel_flags() & (1 << 21))) {
         const uint32_t entries = x->bwt.flat_nsb * (uint32_t)x->bwt.sigma;
-        const uint32_t super_lds = flat_super_lds_bytes(entries) <= kFlatSuperLdsMax ? entries : 0u;      // (sigma = 28: 6.7 KB at 2 x 10^9 rows, 19 KB at 4.5 x 10^9)
-        k_exact_s<<<grid, block, 4 * 8 * kCoopRegion + 16 + flat_super_lds_bytes(super_lds) + dev_extra_lds, stream>>>(x->bwt.flat, x->bwt.flat_super, (uint32_t)x->bwt.sigma,
-                                                           flat_count_bits((uint32_t)x->bwt.sigma), flat_lut ? (const void*)x->bwt.slut : nullptr, x->bwt.slut_len, (const uint8_t*)sbuf.dev,
-                                                           (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps, super_lds);
+        const uint32_t super_lds = flat_super_lds_bytes(entries) <= kFlatSuperLdsMax ? entries : 0u;      // (sigma = 28: 6.7 KB at 2 x 10^9 rows, 19 KB at 4.5 x 10^9, 42 KB at 10^10)
+        uint32_t lanes = flat_block_lanes(super_lds);
+        if (const char* ev = dev_env("FMGPU_DEV_FLAT_LANES")) { const uint32_t v = (uint32_t)atoi(ev); if ((v == 256 || v == 512 || v == 1024) && flat_lds_bytes(v, super_lds) <= kLdsPerCu) lanes = v; }     // (dev knob)
+        const size_t lds = flat_lds_bytes(lanes, super_lds) + dev_extra_lds;
+        auto launch = [&](auto kernel) -> int {
+            if (lds > 64 * 1024) FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     // (more than a launch gets without asking)
+            dim3 g; if (int grc = grid_of((nq + lanes - 1) / lanes * 256u, &g)) return grc;
+            kernel<<<g, dim3(lanes), lds, stream>>>(x->bwt.flat, x->bwt.flat_super, (uint32_t)x->bwt.sigma, flat_count_bits((uint32_t)x->bwt.sigma),
+                                                     flat_lut ? (const void*)x->bwt.slut : nullptr, x->bwt.slut_len, (const uint8_t*)sbuf.dev,
+                                                     (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps, super_lds);
+            return 0;
+        };
+        if ((rc = lanes == 256 ? launch(k_exact_s<256>) : lanes == 512 ? launch(k_exact_s<512>) : launch(k_exact_s<1024>))) return rc;
     } else if (x->bwt.search_family() == FAM_WAVELET) {
         uint32_t mx = shape_max, mn = 0;
         if (!have_shape && (rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) return rc;

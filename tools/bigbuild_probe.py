@@ -1,0 +1,78 @@
+"""tools/bigbuild_probe.py NSEQ [BUCKET_ROWS] — builds FMIndex<28, Wavelet> over NSEQ x 500 uniform residues on the GPU (beyond ~6e9 rows the library sorts the suffixes bucket by
+bucket), then checks it through properties that do not need a CPU walk of that size: every one of 2 M reads cut from the text is found, the located origin of a read's first row
+spells the read, a read with one substitution that the text does not hold is not found, the line kernel and the tree kernel agree; prints build time, sizes and the search time."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import fmindex_collection_amd as fm  # noqa: E402
+from fmindex_collection_amd import capi  # noqa: E402
+
+
+class Dev:
+    def __init__(self, t):
+        self.t, self.ptr, self.nbytes = t, t.data_ptr(), t.numel() * t.element_size()
+
+
+def main():
+    nseq = int(sys.argv[1]); slen = 500; sigma = 28; L = 40; nq = 2_000_000
+    if len(sys.argv) > 2:
+        fm.options["bucket_rows"] = int(sys.argv[2])
+    dev = torch.device("cuda:0")
+    total = nseq * slen
+    g = torch.Generator(device=dev); g.manual_seed(42)
+    text = torch.empty(total, dtype=torch.uint8, device=dev)
+    for lo in range(0, total, 1 << 28):
+        hi = min(total, lo + (1 << 28))
+        text[lo:hi] = torch.randint(1, sigma, (hi - lo,), generator=g, device=dev, dtype=torch.uint8)
+    seq_off = torch.arange(nseq + 1, device=dev, dtype=torch.int64) * slen
+    starts = torch.randint(0, nseq, (nq,), generator=g, device=dev, dtype=torch.int64) * slen + torch.randint(0, slen - L + 1, (nq,), generator=g, device=dev, dtype=torch.int64)
+    reads = text[starts[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
+    bad = torch.arange(0, nq, 10, device=dev)                      # every 10th read gets one substitution
+    pos = torch.randint(0, L, (bad.numel(),), generator=g, device=dev)
+    reads[bad, pos] = (reads[bad, pos] - 1 + 7) % (sigma - 1) + 1
+    qoff = torch.arange(nq + 1, device=dev, dtype=torch.int64) * L
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    fm.options["lf_table"] = 0
+    t0 = time.time()
+    index = fm.FMIndex.from_sequences((Dev(text), Dev(seq_off)), sigma, "WAVELET", 16)
+    build_s = time.time() - t0
+    out = torch.empty(2 * nq, dtype=torch.int64, device=dev)
+    stats = capi.Stats()
+
+    def search():
+        capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(reads.data_ptr()), C.c_void_p(qoff.data_ptr()), nq, C.c_void_p(out[:nq].data_ptr()), C.c_void_p(out[nq:].data_ptr()),
+                                                 C.byref(stats), None))
+        torch.cuda.synchronize()
+        return stats.kernel_ms
+    search(); ms = min(search() for _ in range(3))
+    lb, ln = out[:nq].clone(), out[nq:].clone()
+    with fm.options(kernel_select=capi.SEL_EXACT_ON_TREE):
+        tree_ms = min(search() for _ in range(2))
+    same = bool(torch.equal(lb, out[:nq]) and torch.equal(ln, out[nq:]))
+    good = torch.ones(nq, dtype=torch.bool, device=dev); good[bad] = False
+    found_all = bool((ln[good] >= 1).all().item())
+    n_bad_found = int((ln[bad] >= 1).sum().item())                 # (a substituted read occurs elsewhere with probability ~1e10 / 27^40: none)
+    rows = lb[good][:200_000].to(torch.uint64)
+    seq = torch.empty(rows.numel(), dtype=torch.int64, device=dev); p = torch.empty_like(seq); st = torch.empty_like(seq)
+    capi.check(capi.lib().fmgpu_locate(index._h, C.c_void_p(rows.data_ptr()), rows.numel(), C.c_void_p(seq.data_ptr()), C.c_void_p(p.data_ptr()), C.c_void_p(st.data_ptr()), None, None))
+    torch.cuda.synchronize()
+    at = seq * slen + p + st
+    got = text[at[:, None] + torch.arange(L, device=dev)[None, :]]
+    located_ok = bool(torch.equal(got, reads[good][:200_000]))
+    print(json.dumps({"residues": total, "rows": index.n, "row_bits": index.row_bits, "build_s": round(build_s, 1), "index_device_bytes": index.device_bytes,
+                      "free_before_build": free0, "exact_kernel_ms_2M": round(ms, 3), "tree_kernel_ms_2M": round(tree_ms, 3), "line_equals_tree": same,
+                      "every_cut_read_found": found_all, "substituted_reads_found": n_bad_found, "located_origins_spell_the_reads": located_ok}))
+    if not (same and found_all and located_ok and n_bad_found == 0):
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
