@@ -104,9 +104,9 @@ EXPORTS = [
 
 # fmgpu_option (include/fmgpu.h) and the defaults the library starts with
 OPTIONS = {"pair_table": 0, "dense_dna": 1, "symbol_planes": 2, "expand_dna": 3, "lf_table": 4, "fused_locate": 5, "heavy_first": 6,
-           "force_wide": 7, "kernel_select": 8, "fail_scratch": 9, "bucket_rows": 10}
+           "force_wide": 7, "kernel_select": 8, "fail_scratch": 9, "bucket_rows": 10, "suffix_sorter": 11}
 OPTION_DEFAULTS = {"pair_table": 1, "dense_dna": 1, "symbol_planes": 1, "expand_dna": 1, "lf_table": 1, "fused_locate": 1, "heavy_first": 1,
-                   "force_wide": 0, "kernel_select": 0, "fail_scratch": 0, "bucket_rows": 0}
+                   "force_wide": 0, "kernel_select": 0, "fail_scratch": 0, "bucket_rows": 0, "suffix_sorter": 0}
 # FMGPU_SEL_* bits of the kernel_select option
 SEL_GENERAL_DFS, SEL_NO_PREFIX_TABLE, SEL_NO_LF3, SEL_NO_LF_GENERAL, SEL_NO_WALK_TABLE, SEL_NO_LENGTH_BUCKETS = 2, 4, 8, 16, 32, 64
 SEL_EXACT_ON_TREE, SEL_EXACT_ONE_SYMBOL, SEL_LOCATE_PER_LANE, SEL_NO_SHARING, SEL_NO_EXACT_LUT, SEL_LEAN_FORMAT_A, SEL_NO_LEAN = 1 << 21, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 29, 1 << 30

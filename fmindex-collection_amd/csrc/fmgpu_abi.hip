@@ -66,14 +66,14 @@ Staged::~Staged() {
 bool want_wide(uint64_t n) { return n >= kNarrowLimit || opt_on(FMGPU_OPT_FORCE_WIDE); }
 
 // ---- library options (fmgpu_set_option): process-wide, read when a call starts / a handle is made
-static const int64_t kOptionDefaults[FMGPU_OPT_COUNT_] = {1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0};
+static const int64_t kOptionDefaults[FMGPU_OPT_COUNT_] = {1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
 static std::atomic<int64_t> g_options[FMGPU_OPT_COUNT_];
 static std::once_flag g_options_once;
 static void options_init() {
     for (int i = 0; i < FMGPU_OPT_COUNT_; ++i) g_options[i].store(kOptionDefaults[i], std::memory_order_relaxed);
 #ifdef FMGPU_DEV                                                     // (development builds only: the environment names the initial values)
     static const char* const names[FMGPU_OPT_COUNT_] = {"FMGPU_PAIRS", "FMGPU_DENSE_DNA", "FMGPU_FLAT", "FMGPU_SHADOW", "FMGPU_LF_TABLE", "FMGPU_FUSED_LOCATE", "FMGPU_HEAVY_FIRST",
-                                                        "FMGPU_FORCE_WIDE", "FMGPU_DEV_FLAGS", "FMGPU_FAIL_SCRATCH", "FMGPU_BUCKET_ROWS"};
+                                                        "FMGPU_FORCE_WIDE", "FMGPU_DEV_FLAGS", "FMGPU_FAIL_SCRATCH", "FMGPU_BUCKET_ROWS", "FMGPU_SUFFIX_SORTER"};
     for (int i = 0; i < FMGPU_OPT_COUNT_; ++i) if (const char* e = getenv(names[i])) g_options[i].store(atoll(e), std::memory_order_relaxed);
 #endif
 }
@@ -86,6 +86,7 @@ static int set_opt(int option, int64_t value) {
     if (option < 0 || option >= FMGPU_OPT_COUNT_) return fail(FMGPU_ERR_INVALID, "unknown option " + std::to_string(option));
     if (option == FMGPU_OPT_KERNEL_SELECT && (value & ~(int64_t)FMGPU_SEL_ALL)) return fail(FMGPU_ERR_INVALID, "FMGPU_OPT_KERNEL_SELECT: bits outside FMGPU_SEL_ALL");
     if (option == FMGPU_OPT_BUCKET_ROWS && value < 0) return fail(FMGPU_ERR_INVALID, "FMGPU_OPT_BUCKET_ROWS: a number of rows");
+    if (option == FMGPU_OPT_SUFFIX_SORTER && (value < 0 || value > 3)) return fail(FMGPU_ERR_INVALID, "FMGPU_OPT_SUFFIX_SORTER: 0 .. 3");
     g_options[option].store(value, std::memory_order_relaxed);
     return 0;
 }

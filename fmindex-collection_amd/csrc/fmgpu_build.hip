@@ -353,6 +353,44 @@ __global__ __launch_bounds__(256) void k_bucket_samples(const idx_t* __restrict_
 __global__ void k_bucket_advance(unsigned long long* __restrict__ base, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ at, uint64_t count) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && count) *base += (unsigned long long)at[count - 1] + flag[count - 1];
 }
+// ---- ... and from the inverse suffix array (sort_suffixes_isa): rank[p] = the row of suffix p
+__global__ __launch_bounds__(256) void k_isa_bwt(const uint8_t* __restrict__ text, const idx_t* __restrict__ rank, uint64_t n, uint8_t* __restrict__ bwt) {
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) bwt[rank[p]] = text[p ? p - 1 : n - 1];
+}
+// the i-th sampled position of the text: sequence s = the last one with sbase[s] <= i, offset (i - sbase[s]) * rate
+__device__ __forceinline__ void sampled_position(const uint64_t* __restrict__ sstart, const uint64_t* __restrict__ sbase, uint64_t nseq, uint64_t rate, uint64_t i, uint64_t& s, uint64_t& o) {
+    uint64_t lo = 0, hi = nseq;
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (sbase[mid] <= i) lo = mid; else hi = mid; }
+    s = lo; o = (i - sbase[lo]) * rate;
+}
+__global__ __launch_bounds__(256) void k_isa_presence(const idx_t* __restrict__ rank, const uint64_t* __restrict__ sstart, const uint64_t* __restrict__ sbase, uint64_t nseq, uint64_t rate,
+                                                      uint64_t nsampled, unsigned long long* __restrict__ bits) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nsampled; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s, o; sampled_position(sstart, sbase, nseq, rate, i, s, o);
+        const uint64_t r = rank[sstart[s] + o];
+        atomicOr(&bits[r >> 6], 1ull << (r & 63u));
+    }
+}
+__global__ __launch_bounds__(256) void k_isa_values(const idx_t* __restrict__ rank, const uint64_t* __restrict__ sstart, const uint64_t* __restrict__ sbase, uint64_t nseq, uint64_t rate,
+                                                    uint64_t nsampled, const uint64_t* __restrict__ bits, const cnt_t* __restrict__ g,
+                                                    unsigned long long* __restrict__ f0, unsigned long long* __restrict__ f1, uint32_t w0, uint32_t w1, uint64_t d0, uint64_t d1) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nsampled; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s, o; sampled_position(sstart, sbase, nseq, rate, i, s, o);
+        const uint64_t row = rank[sstart[s] + o];
+        uint64_t r = g[row >> 9];                                   // sampled rows before this one
+        const uint64_t* w = bits + (row >> 9) * 8;
+        const uint32_t bit = (uint32_t)(row & 511u);
+        for (uint32_t k = 0; k < (bit >> 6); ++k) r += (uint64_t)__popcll(w[k]);
+        if (bit & 63u) r += (uint64_t)__popcll(w[bit >> 6] & ((1ull << (bit & 63u)) - 1ull));
+        auto put = [](unsigned long long* data, uint32_t width, uint64_t idx, uint64_t v) {   // DenseVector::push_back layout, DenseVector.h:124-144
+            uint64_t begin = idx * width; uint32_t off = (uint32_t)(begin & 63u);
+            atomicOr(&data[begin >> 6], (unsigned long long)(v << off));
+            if (off + width > 64) atomicOr(&data[(begin >> 6) + 1], (unsigned long long)(v >> (64u - off)));
+        };
+        put(f0, w0, r, s / d0);
+        put(f1, w1, r, o / d1);
+    }
+}
 // sampled rows per 512 rows, from the finished presence bits (what k_sa_bits counts on the way)
 __global__ __launch_bounds__(256) void k_count_presence(const uint64_t* __restrict__ bits, uint64_t nl1, cnt_t* __restrict__ g) {
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nl1; b += (uint64_t)gridDim.x * blockDim.x) {
@@ -586,14 +624,21 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
     auto bail = [&](int code) { api::fmgpu_index_destroy(reinterpret_cast<fmgpu_index_t>(x.release())); return code; };
     (void)hipGetDevice(&x->hdr.device);
 
-    // the suffix sorter: all suffixes at once (suffix array, rank array, key buffers: 30 / 42 bytes per row beside the text) where that fits the free memory, bucket by
-    // bucket without ever holding the array (fmgpu_bucketsort.hip) where it does not — or where FMGPU_OPT_BUCKET_ROWS asks for it
+    // the suffix sorter (FMGPU_OPT_SUFFIX_SORTER; 0: by the memory each needs, in this order):
+    //   1 all suffixes at once — suffix array, rank array, key buffers of all rows: 30 / 42 bytes per row beside the text (build_suffix_array);
+    //   2 bucket by bucket with the inverse suffix array as the rank array of the doubling rounds: 6 / 10 bytes per row + one bucket + the tied rows (sort_suffixes_isa);
+    //   3 bucket by bucket with no array of n entries: 2 bytes per row + one bucket, ties broken by further symbols of the text (sort_suffixes_bucketed)
     const uint64_t bucket_rows = (uint64_t)opt(FMGPU_OPT_BUCKET_ROWS);
-    bool bucketed = bucket_rows > 0;
-    if (!bucketed) {
+    int sorter = (int)opt(FMGPU_OPT_SUFFIX_SORTER);
+    if (sorter == 0) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)n * (kWide ? 44.0 : 32.0) > (double)free_b) bucketed = true;
+        sorter = 1;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            if ((double)n * (kWide ? 44.0 : 32.0) > (double)free_b) sorter = 2;
+            if (sorter == 2 && (double)n * (2.0 + sizeof(idx_t)) * 1.5 > (double)free_b) sorter = 3;
+        }
     }
+    const bool bucketed = sorter != 1;
     DBuf text, sa, bwt;
     if ((rc = text.alloc(n)) || (rc = bwt.alloc(n)) || (!bucketed && (rc = sa.alloc(n * sizeof(idx_t))))) return bail(rc);
     k_assemble_text<<<grid_for(n), 256, 0, stream>>>((const uint8_t*)sseq.dev, (const uint64_t*)soff.dev, nseq, text.as<uint8_t>(), n);
@@ -683,13 +728,47 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
         }, stream);
     };
 
+    // ... and through the sorter that leaves the inverse suffix array: bwt[rank[p]] = text[p - 1]; the sampled entries are the text's positions at multiples of the rate
+    // within their sequence — enumerated directly (sequence s holds len_s / rate + 1 of them), their rows read off the array
+    DBuf sbase;                                                     // sbase[s] = sampled positions of the sequences before s
+    auto isa_pass = [&](bool with_samples) -> int {
+        DBuf rank; int r;
+        if ((r = rank.alloc(n * sizeof(idx_t)))) return r;
+        if ((r = sort_suffixes_isa(text.as<uint8_t>(), n, (uint32_t)sigma, bucket_rows, rank.as<idx_t>(), stream))) return r;
+        k_isa_bwt<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), rank.as<idx_t>(), n, bwt.as<uint8_t>());
+        FM_LAUNCHED("k_isa_bwt");
+        if (with_samples) {
+            std::vector<uint64_t> hb(nseq + 1);
+            hb[0] = 0;
+            for (uint64_t s = 0; s < nseq; ++s) hb[s + 1] = hb[s] + (hoff[s + 1] - hoff[s]) / sampling_rate + 1;
+            if ((r = sbase.alloc((nseq + 1) * 8))) return r;
+            FM_HIP(hipMemcpy(sbase.p, hb.data(), (nseq + 1) * 8, hipMemcpyHostToDevice));
+            k_isa_presence<<<grid_for(nsampled), 256, 0, stream>>>(rank.as<idx_t>(), dstart.as<uint64_t>(), sbase.as<uint64_t>(), nseq, sampling_rate, nsampled, (unsigned long long*)x->sa_bits);
+            FM_LAUNCHED("k_isa_presence");
+            k_count_presence<<<grid_for(nl1), 256, 0, stream>>>((const uint64_t*)x->sa_bits, nl1, g.as<cnt_t>());
+            FM_LAUNCHED("k_count_presence");
+            uint64_t got = 0;
+            if ((r = finish_levels(&got))) return r;
+            if (got != nsampled) return fail(FMGPU_ERR_HIP, "the suffix sorter marked " + std::to_string(got) + " sampled rows, the text holds " + std::to_string(nsampled));
+            k_isa_values<<<grid_for(nsampled), 256, 0, stream>>>(rank.as<idx_t>(), dstart.as<uint64_t>(), sbase.as<uint64_t>(), nseq, sampling_rate, nsampled, (const uint64_t*)x->sa_bits,
+                                                                 g.as<cnt_t>(), (unsigned long long*)x->sa_f0, (unsigned long long*)x->sa_f1, w0, w1, div0, div1);
+            FM_LAUNCHED("k_isa_values");
+        }
+        FM_HIP(hipStreamSynchronize(stream));
+        return 0;
+    };
+
     uint64_t nvalues = 0;
-    if (bucketed) {
+    if (sorter == 3) {
         if ((rc = alloc_fields(nsampled))) return bail(rc);
         if ((rc = bucketed_pass(true))) return bail(rc);
         k_count_presence<<<grid_for(nl1), 256, 0, stream>>>((const uint64_t*)x->sa_bits, nl1, g.as<cnt_t>());
         if ((rc = finish_levels(&nvalues))) return bail(rc);
         if (nvalues != nsampled) return bail(fail(FMGPU_ERR_HIP, "the bucketed sorter marked " + std::to_string(nvalues) + " sampled rows, the text holds " + std::to_string(nsampled)));
+    } else if (sorter == 2) {
+        if ((rc = alloc_fields(nsampled))) return bail(rc);
+        if ((rc = isa_pass(true))) return bail(rc);
+        nvalues = nsampled;
     } else {
         if ((rc = build_suffix_array(text.as<uint8_t>(), n, (uint32_t)sigma, sa.as<idx_t>(), stream))) return bail(rc);
         k_bwt<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), sa.as<idx_t>(), n, bwt.as<uint8_t>());
@@ -722,7 +801,7 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
     }
 
     {
-        if (!bucketed) {
+        if (sorter == 1) {
             for (uint64_t first = 0; first < n; first += kSliceRows) {
                 const uint64_t rows = std::min(kSliceRows, n - first);
                 k_sa_bits<<<dim3((unsigned)(((rows + 63) / 64 * 64 + 255) / 256)), 256, 0, stream>>>(sa.as<idx_t>(), n, dstart.as<uint64_t>(), nseq, sampling_rate, (uint64_t*)x->sa_bits,
@@ -759,7 +838,8 @@ int fmgpu_build_index(const uint8_t* seqs, const uint64_t* seq_off, uint64_t nse
         // BiFMIndex.h:78-92: reverse the whole concatenation (delimiters included), second suffix sort
         k_reverse<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), bwt.as<uint8_t>(), n);
         FM_HIP(hipMemcpyAsync(text.p, bwt.p, n, hipMemcpyDeviceToDevice, stream));
-        if (bucketed) { if ((rc = bucketed_pass(false))) return bail(rc); }
+        if (sorter == 3) { if ((rc = bucketed_pass(false))) return bail(rc); }
+        else if (sorter == 2) { if ((rc = isa_pass(false))) return bail(rc); }
         else {
             if ((rc = build_suffix_array(text.as<uint8_t>(), n, (uint32_t)sigma, sa.as<idx_t>(), stream))) return bail(rc);
             k_bwt<<<grid_for(n), 256, 0, stream>>>(text.as<uint8_t>(), sa.as<idx_t>(), n, bwt.as<uint8_t>());

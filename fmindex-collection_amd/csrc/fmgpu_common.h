@@ -698,6 +698,8 @@ int make_format_m(const uint8_t* symbols, uint64_t n, uint32_t sigma, const idx_
 // `sink`, in ascending row order: sink(first_row, pos, count, scratch, scratch_bytes) — scratch: device memory the sink may use until it returns (8 bytes per row of the largest bucket)
 using SuffixSink = std::function<int(uint64_t first_row, const idx_t* pos, uint64_t count, void* scratch, size_t scratch_bytes)>;
 int sort_suffixes_bucketed(const uint8_t* text, uint64_t n, uint32_t sigma, uint64_t bucket_rows, const SuffixSink& sink, hipStream_t stream);
+// ... with the inverse suffix array as the rank array of a prefix doubling on the ties: rank[p] (n entries, device) = the row of suffix p
+int sort_suffixes_isa(const uint8_t* text, uint64_t n, uint32_t sigma, uint64_t bucket_rows, idx_t* rank, hipStream_t stream);
 
 struct Index;
 // 0 if the calling thread's current device is the one the handle lives on; defined in fmgpu_index.hip

@@ -178,10 +178,14 @@ typedef enum fmgpu_option {
     FMGPU_OPT_FORCE_WIDE = 7,      /* test hook, 0: 1 = every new handle is held in 64-bit-row tables whatever its size */
     FMGPU_OPT_KERNEL_SELECT = 8,   /* test / A-B hook, 0: FMGPU_SEL_* bits — which of several result-identical kernels serves a call */
     FMGPU_OPT_FAIL_SCRATCH = 9,    /* test hook, 0: k = the k-th allocation of the next per-thread call scratch fails */
-    FMGPU_OPT_BUCKET_ROWS = 10,    /* 0 (default): fmgpu_build_index sorts all suffixes at once where the suffix array and its buffers fit the free device memory (30 / 42 bytes
-                                    * per row with 32- / 64-bit rows) and bucket by bucket, without ever holding the suffix array, where they do not;
-                                    * k > 0: always bucket by bucket, k rows per bucket at most (results do not depend on it) */
-    FMGPU_OPT_COUNT_ = 11
+    FMGPU_OPT_BUCKET_ROWS = 10,    /* 0 (default): the bucketed suffix sorters cut their buckets as large as the free device memory allows; k > 0: k rows per bucket at most */
+    FMGPU_OPT_SUFFIX_SORTER = 11,  /* which suffix sorter fmgpu_build_index uses (results do not depend on it).  0 (default): by the memory each needs —
+                                    * 1: all suffixes at once: suffix array + rank array + keys of all rows (30 / 42 bytes per row with 32- / 64-bit rows beside the text);
+                                    * 2: bucket by bucket with the inverse suffix array as rank array (6 / 10 bytes per row beside the text + one bucket + ~60 bytes per row that shares
+                                    *    its first 12-21 symbols with another): prefix doubling on the ties, the suffix array itself is never held;
+                                    * 3: bucket by bucket without any array of n entries (2 bytes per row + one bucket): ties are broken by reading further symbols, a text with
+                                    *    very long exact repeats is refused (FMGPU_ERR_UNSUPPORTED) */
+    FMGPU_OPT_COUNT_ = 12
 } fmgpu_option;
 /* bits of FMGPU_OPT_KERNEL_SELECT: each takes a call off the kernel the library would pick (the parity tests run every kernel through them) */
 #define FMGPU_SEL_GENERAL_DFS      (1 << 1)   /* search_ng26 / ng21: the general kernels (k_scheme, k_scheme_edit, k_ng21) */

@@ -1,4 +1,5 @@
-"""Construction bucket by bucket (csrc/fmgpu_bucketsort.hip) — the suffix sorter that never holds the suffix array, for texts beyond the ~6e9 rows the doubling sorter's
+"""Construction bucket by bucket (csrc/fmgpu_bucketsort.hip) — the two suffix sorters that never hold the suffix array (suffix_sorter = 2: prefix doubling on the ties with the
+inverse suffix array as rank array; 3: no array of n entries at all, ties broken by further symbols of the text), for texts beyond the ~6e9 rows the all-at-once sorter's
 buffers fit (UniRef50-sized protein databases: BASELINE.json configs[4]).  FMIndex(Sequences, samplingRate) / BiFMIndex(...) (fmindex/FMIndex.h:58-104, BiFMIndex.h:107-167,
 utils.h:97-163) as restated by the oracle, and the library's own all-at-once sorter (pinned against the oracle in test_gpu_parity.py), are what it is compared with:
 every built array byte for byte — BWT, bwtRev, C, the SparseArray's presence bits, both counter levels, both bit-packed fields and their parameters."""
@@ -50,25 +51,29 @@ def _collection(seed):
 @pytest.mark.parametrize("seed", list(range(12)))
 @pytest.mark.parametrize("wide", [False, True])
 def test_bucketed_construction_equals_the_all_at_once_sorter(seed, wide):
-    """the same collection built with the doubling sorter and bucket by bucket — buckets of 1, 61 and 4000 rows and one bucket for everything — in both row widths"""
+    """the same collection built with the all-at-once sorter and bucket by bucket, by both bucketed sorters — buckets of 1, 61 and 4000 rows and one bucket for everything
+    (the bucket size also caps the groups a doubling round sorts together: 61 makes every round run through several segments) — in both row widths"""
     sigma, seqs, rate, bidir = _collection(seed)
     cls = fm.BiFMIndex if bidir else fm.FMIndex
     layout = "WAVELET" if sigma > 5 else "IB16"
     with fm.options(force_wide=1 if wide else 0):
-        want = _built(cls.from_sequences(seqs, sigma, layout, rate, keep_host=True), bidir)
-        for rows in ((1,) if seed % 4 == 0 else ()) + (61, 4000, 1 << 40):
-            with fm.options(bucket_rows=rows):
-                gx = cls.from_sequences(seqs, sigma, layout, rate, keep_host=True)
-            assert gx.row_bits == (64 if wide else 32)
-            assert _same(_built(gx, bidir), want), (seed, wide, rows, sigma, len(seqs), rate, bidir)
+        with fm.options(suffix_sorter=1):
+            want = _built(cls.from_sequences(seqs, sigma, layout, rate, keep_host=True), bidir)
+        for sorter in (2, 3):
+            for rows in ((1,) if seed % 4 == 0 else ()) + (61, 4000, 1 << 40):
+                with fm.options(bucket_rows=rows, suffix_sorter=sorter):
+                    gx = cls.from_sequences(seqs, sigma, layout, rate, keep_host=True)
+                assert gx.row_bits == (64 if wide else 32)
+                assert _same(_built(gx, bidir), want), (seed, wide, sorter, rows, sigma, len(seqs), rate, bidir)
 
 
-def test_bucketed_construction_against_the_oracle():
+@pytest.mark.parametrize("sorter", [2, 3])
+def test_bucketed_construction_against_the_oracle(sorter):
     """... and directly against the CPU restatement of the reference's construction (BWT, C, SparseArray arrays, locate), 200 kbp in 23 buckets"""
     import fmoracle as fo
     seqs = [make_text(120_000, 5, 31), make_text(7, 5, 32), make_text(80_000, 5, 33)]
     ox = fo.OraIndex.build("IB16", 5, seqs, 16, True)
-    with fm.options(bucket_rows=9000):
+    with fm.options(bucket_rows=9000, suffix_sorter=sorter):
         gx = fm.BiFMIndex.from_sequences(seqs, 5, "IB16", 16, keep_host=True)
     n = ox.n
     assert gx.n == n
@@ -90,7 +95,8 @@ def test_bucketed_construction_against_the_oracle():
     assert [(int(a), int(b), int(c)) for a, b, c in zip(seq, pos, steps)] == [ox.locate(int(r)) for r in rows]
 
 
-def test_bucketed_construction_of_a_protein_text_with_shared_domains():
+@pytest.mark.parametrize("sorter", [2, 3])
+def test_bucketed_construction_of_a_protein_text_with_shared_domains(sorter):
     """sigma = 28, 3 M residues in 6 000 sequences, a fifth of them carrying one of 40 'domains' of 30 .. 300 residues verbatim (ties of hundreds of symbols between distant
     sequences: several tie rounds), 40 buckets: every array equals the all-at-once sorter's; exact search of 40-residue reads finds every read where it was cut"""
     rng = np.random.default_rng(77)
@@ -101,8 +107,9 @@ def test_bucketed_construction_of_a_protein_text_with_shared_domains():
         if i % 5 == 0:
             d = domains[int(rng.integers(0, 40))]; at = int(rng.integers(0, 500 - len(d) + 1)); q[at:at + len(d)] = d
         seqs.append(q)
-    want = _built(fm.FMIndex.from_sequences(seqs, 28, "WAVELET", 16, keep_host=True), False)
-    with fm.options(bucket_rows=80_000):
+    with fm.options(suffix_sorter=1):
+        want = _built(fm.FMIndex.from_sequences(seqs, 28, "WAVELET", 16, keep_host=True), False)
+    with fm.options(bucket_rows=80_000, suffix_sorter=sorter):
         gx = fm.FMIndex.from_sequences(seqs, 28, "WAVELET", 16, keep_host=True)
     assert _same(_built(gx, False), want)
     pick = rng.integers(0, 6000, size=2000); off = rng.integers(0, 460, size=2000)
@@ -114,12 +121,31 @@ def test_bucketed_construction_of_a_protein_text_with_shared_domains():
         assert np.array_equal(seqs[int(s)][int(p) + int(k):int(p) + int(k) + 40], r)
 
 
-def test_a_megabase_run_is_refused_not_ground_through():
-    """the bucketed sorter breaks ties by reading further symbols of the text, not by doubling: a run of 3 M equal symbols would cost ~2e5 rounds over the run's rows.
-    Its work is bounded and the text is refused with an error that says so; the all-at-once sorter builds the same text"""
+def test_a_megabase_run():
+    """a run of 3 M equal symbols.  The sorter without a rank array breaks ties by reading further symbols of the text — ~2e5 rounds over the run's rows: its work is bounded and
+    the text is refused with an error that says so.  The sorter that keeps the inverse suffix array doubles (18 rounds) and builds what the all-at-once sorter builds"""
     seqs = [np.concatenate([make_text(2000, 5, 3), np.ones(3_000_000, dtype=np.uint8), make_text(2000, 5, 4)])]
-    with fm.options(bucket_rows=1 << 40):
+    with fm.options(bucket_rows=1 << 40, suffix_sorter=3):
         with pytest.raises(fm.FmgpuError) as e:
             fm.FMIndex.from_sequences(seqs, 5, "IB16", 16)
     assert e.value.code == capi.FMGPU_ERR_UNSUPPORTED and "doubling" in str(e.value)
-    assert fm.FMIndex.from_sequences(seqs, 5, "IB16", 16).n == 3_004_001
+    with fm.options(suffix_sorter=1):
+        want = _built(fm.BiFMIndex.from_sequences(seqs, 5, "IB16", 16, keep_host=True), True)
+    with fm.options(bucket_rows=700_000, suffix_sorter=2):
+        gx = fm.BiFMIndex.from_sequences(seqs, 5, "IB16", 16, keep_host=True)
+    assert gx.n == 3_004_001 and _same(_built(gx, True), want)
+
+
+def test_repeat_structured_text_through_the_rank_array_sorter():
+    """20 Mbp of the repeat-structured genome stand-in (interspersed repeat families, satellite arrays, runs of one symbol: ties thousands of symbols deep over a large share of the
+    rows), BiFMIndex, 7 buckets: every built array equals the all-at-once sorter's"""
+    from fmindex_collection_amd import datasets
+    lengths = [6_000_000, 9_000_000, 5_000_000]
+    text, _ = datasets.genome_like_text(lengths, seed=11, device="cuda:0")
+    flat = text.cpu().numpy(); off = np.concatenate([[0], np.cumsum(lengths)])
+    seqs = [flat[off[i]:off[i + 1]] for i in range(len(lengths))]
+    with fm.options(suffix_sorter=1):
+        want = _built(fm.BiFMIndex.from_sequences(seqs, 5, "IB16", 16, keep_host=True), True)
+    with fm.options(bucket_rows=3_000_000, suffix_sorter=2):
+        gx = fm.BiFMIndex.from_sequences(seqs, 5, "IB16", 16, keep_host=True)
+    assert _same(_built(gx, True), want)
