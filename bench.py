@@ -993,18 +993,32 @@ def run_protein(c, nseq, tag, plain_only=False):
     qbuf, qoff = sample_reads(c, text, None, L, nq, 1000, "exact", sigma=sigma, inside=(nseq, PROTEIN_SEQ_LEN))
     torch.cuda.synchronize()
     fm.options["lf_table"] = 0
-    # (fmgpu_build_index's own rule, csrc/fmgpu_build.hip: all suffixes at once where 44 bytes per row with 64-bit rows / 32 with 32-bit rows fit the free memory)
-    sorter = "bucket by bucket (the suffix array is never held)" if fm.options["bucket_rows"] or (total + nseq) * (44 if total + nseq >= (1 << 32) - 64 else 32) > torch.cuda.mem_get_info()[0] \
-        else "all suffixes at once (prefix doubling)"
+    # (fmgpu_build_index's own rule, csrc/fmgpu_build.hip: all suffixes at once where 44 bytes per row with 64-bit rows / 32 with 32-bit rows fit the free memory, else bucket by bucket
+    # with the inverse suffix array as rank array, 10 / 6 bytes per row)
+    rows_ = total + nseq
+    srt = fm.options["suffix_sorter"] or (1 if rows_ * (44 if rows_ >= (1 << 32) - 64 else 32) <= torch.cuda.mem_get_info()[0] else 2)
+    sorter = {1: "all suffixes at once (suffix array + rank array + keys of all rows)", 2: "bucket by bucket, prefix doubling on the ties with the inverse suffix array as rank array (no suffix array)",
+              3: "bucket by bucket, no array of n entries"}[srt]
     t0 = time.time()
     index = fm.FMIndex.from_sequences((_Dev(text), _Dev(seq_off)), sigma, "WAVELET", 16, keep_host=False)
     build_s = time.time() - t0
     del fm.options["lf_table"]
     sel_base = fm.options["kernel_select"]
-    del text
-    torch.cuda.empty_cache()
     out_t = torch.empty(2 * nq, dtype=torch.int64, device=c.dev)
     stats = capi.Stats()
+    # text-side check of the built index, before the text goes: the first row of 200 k found reads, located, must spell the read where the sampled entry + LF steps point
+    capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq, C.c_void_p(out_t[:nq].data_ptr()), C.c_void_p(out_t[nq:].data_ptr()), None, None))
+    pick = torch.nonzero(out_t[nq:] > 0)[:200_000, 0]
+    rows = out_t[:nq][pick].contiguous()
+    loc = torch.empty(3 * rows.numel(), dtype=torch.int64, device=c.dev)
+    k = rows.numel()
+    capi.check(capi.lib().fmgpu_locate(index._h, C.c_void_p(rows.data_ptr()), k, C.c_void_p(loc[:k].data_ptr()), C.c_void_p(loc[k:2 * k].data_ptr()), C.c_void_p(loc[2 * k:].data_ptr()), None, None))
+    at = loc[:k] * PROTEIN_SEQ_LEN + loc[k:2 * k] + loc[2 * k:]
+    located_ok = bool(torch.equal(text[at[:, None] + torch.arange(L, device=c.dev)[None, :]], qbuf.reshape(nq, L)[pick])) and int(loc[2 * k:].max().item()) < 16
+    if not located_ok:
+        raise SystemExit("bench.py: %s — located rows do not spell their reads (or a row needs 16 LF steps and more at sampling rate 16)" % tag)
+    del text, loc, at, rows, pick
+    torch.cuda.empty_cache()
 
     def step(log):
         capi.check(capi.lib().fmgpu_search_exact(index._h, C.c_void_p(qbuf.data_ptr()), C.c_void_p(qoff.data_ptr()), nq,
@@ -1021,6 +1035,7 @@ def run_protein(c, nseq, tag, plain_only=False):
                         "index_build_s": round(b_s, 2), "suffix_sorter": sorter, "tables": tables},
              "gres_per_s": qps * L / 1e9, "hits": int((out_t[nq:] > 0).sum().item())}
         # every read was cut from the text; every 10th then got one substitution (27^40 strings of its length: such a read is not in the text): exactly the others are found
+        r["located_origins_checked"] = 200_000                    # (against the text, right after construction)
         r["hits_expected"] = nq - (nq + 9) // 10
         if r["hits"] != r["hits_expected"]:
             raise SystemExit("bench.py: %s found %d of the %d reads that were cut from the text" % (rid, r["hits"], r["hits_expected"]))

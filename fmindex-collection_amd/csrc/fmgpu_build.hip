@@ -280,8 +280,10 @@ __device__ __forceinline__ void seq_of(const uint64_t* __restrict__ sstart, uint
     while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (sstart[mid] <= p) lo = mid; else hi = mid; }
     s = lo; o = p - sstart[lo];
 }
-// one thread per row, launched in slices of at most kSliceRows rows (a wave's ballot is the presence word of its 64 rows)
-constexpr uint64_t kSliceRows = 1ull << 36;
+// one thread per row, launched in slices of at most kSliceRows rows (a wave's ballot is the presence word of its 64 rows).  A launch holds fewer than 2^32 threads: the
+// dispatch packet's grid size is a 32-bit number, and a larger launch is cut to its low 32 bits WITHOUT an error (round 4: with 2^36 here, an index of 4.5 x 10^9 rows got
+// presence bits for its first 2.1 x 10^8 rows only — found by comparing against the bucketed sorters, whose writers stride)
+constexpr uint64_t kSliceRows = 1ull << 31;
 __global__ __launch_bounds__(256) void k_sa_bits(const idx_t* __restrict__ sa, uint64_t n, const uint64_t* __restrict__ sstart, uint64_t nseq, uint64_t rate,
                                                  uint64_t* __restrict__ bits, cnt_t* __restrict__ blockcnt, uint64_t first) {
     uint64_t i = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

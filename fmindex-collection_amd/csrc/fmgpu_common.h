@@ -117,7 +117,8 @@ inline int grid_of(uint64_t threads, dim3* out, uint64_t cap_blocks = 0) {
     uint64_t blocks = (threads + 255) / 256;
     if (blocks == 0) blocks = 1;
     if (cap_blocks) blocks = blocks < cap_blocks ? blocks : cap_blocks;
-    if (blocks > kMaxGridBlocks) return fail(FMGPU_ERR_UNSUPPORTED, "a launch of " + std::to_string(threads) + " threads exceeds the grid limit");
+    // (2^32 threads and more: the dispatch packet holds the grid size in 32 bits and the runtime cuts a larger launch short without an error)
+    if (blocks > kMaxGridBlocks || blocks * 256 > 0xffffffffull) return fail(FMGPU_ERR_UNSUPPORTED, "a launch of " + std::to_string(threads) + " threads exceeds the grid limit");
     *out = dim3((unsigned)blocks);
     return 0;
 }

@@ -2272,6 +2272,7 @@ def test_rows_beyond_2_32():
     st_host = starts.cpu().numpy()
     want_seq = (st_host[hit] >= lengths[0]).astype(np.uint64)
     assert np.array_equal(seq, want_seq) and np.array_equal(pos + steps, (st_host[hit] - want_seq.astype(np.int64) * lengths[0]).astype(np.uint64))
+    assert int(steps.max()) < 16                               # every 16th position is sampled — in ALL rows (a launch of 2^32 threads and more is cut short without an error)
     sch = fm.search_scheme.h2(3, 0, 1)
     hits, st = fm.search_ng26.search(gx, (hq, ho), sch, want_stats=True)
     oh, _, onodes = ox.search_ng26(hq, ho, sch, nthreads=8, records=True)

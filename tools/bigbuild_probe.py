@@ -1,4 +1,4 @@
-"""tools/bigbuild_probe.py NSEQ [BUCKET_ROWS] — builds FMIndex<28, Wavelet> over NSEQ x 500 uniform residues on the GPU (beyond ~6e9 rows the library sorts the suffixes bucket by
+"""tools/bigbuild_probe.py NSEQ [BUCKET_ROWS [SUFFIX_SORTER]] — builds FMIndex<28, Wavelet> over NSEQ x 500 uniform residues on the GPU (beyond ~6e9 rows the library sorts the suffixes bucket by
 bucket), then checks it through properties that do not need a CPU walk of that size: every one of 2 M reads cut from the text is found, the located origin of a read's first row
 spells the read, a read with one substitution that the text does not hold is not found, the line kernel and the tree kernel agree; prints build time, sizes and the search time."""
 import ctypes as C
@@ -24,6 +24,8 @@ def main():
     nseq = int(sys.argv[1]); slen = 500; sigma = 28; L = 40; nq = 2_000_000
     if len(sys.argv) > 2:
         fm.options["bucket_rows"] = int(sys.argv[2])
+    if len(sys.argv) > 3:
+        fm.options["suffix_sorter"] = int(sys.argv[3])
     dev = torch.device("cuda:0")
     total = nseq * slen
     g = torch.Generator(device=dev); g.manual_seed(42)
