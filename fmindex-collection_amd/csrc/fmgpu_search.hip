@@ -309,6 +309,78 @@ __device__ __forceinline__ void edit_frame_set_r2(uint4* f, idx_t v) {     // th
 // recomputed when the frame is resumed.  State beyond the Hamming kernel's: the last index / query symbol per side (:36-39) and
 // the last operation per side (LInfo / RInfo: 0 M, 1 S, 2 I, 3 D).
 constexpr int kEditWaves = 4;         // waves per SIMD the register allocation aims at (6 or 8 spill and measure the same)
+// ---- the node step of search_ng26<Edit = true> (search/SearchNg26.h:143-365), shared by k_scheme_edit and k_scheme_fast_edit ------------------------------------------
+// Which child of a node the walk takes next, the reference's call order written as child numbers.  A node of several rows (:143-224): 0 the match child, 2i - 1 the deletion
+// of symbol i, 2i the substitution by i (i = 1 .. sigma - 1, != the query symbol), 2 sigma - 1 the insertion.  A node of ONE row (:251-365): 0 the insertion, 1 the match or
+// the substitution by the row's symbol, 2 its deletion.  In an exact tail (:225-250) only the match child exists.  `start` = the first number still to try (a resumed node).
+// kind: 0 match, 1 substitution, 2 deletion, 3 insertion, 4 nothing left; take = the index symbol of the child; nxt = the number of the following child (kNoResume: none — the
+// parent need not be kept); code = the child's number (its component of the path key); start_tail: a match child that cannot afford an error any more starts the exact tail.
+struct EditStep { uint32_t kind, take, nxt, code; bool start_tail; };
+template <int MAXSIG>
+__device__ __forceinline__ EditStep edit_next_child(const SymSet<MAXSIG>& alive, uint32_t c, bool in_tail, bool multi, bool resuming, uint32_t start, bool mOK, bool iOK, bool xOK,
+                                                    bool Deletion, bool Insertion, uint32_t INS) {
+    EditStep r{4u, c, kNoResume, 0u, false};
+    const bool c_alive = alive.test(c);
+    if (in_tail) { if (c_alive) r.kind = 0u; }
+    else if (multi) {
+        if (!xOK) { if (!resuming && mOK && c_alive) { r.kind = 0u; r.start_tail = true; } }
+        else {
+            SymSet<MAXSIG> dels = alive; dels.remove(0); if (!Deletion) dels.clear();
+            SymSet<MAXSIG> subs = alive; subs.remove(0); subs.remove(c); if (!iOK) subs.clear();
+            const bool insOK = Insertion && iOK;
+            auto child_from = [&](uint32_t s0) -> uint32_t {                // number of the first existing child >= s0
+                if (s0 == 0u && mOK && c_alive) return 0u;
+                SymSet<MAXSIG> dd = dels, ss = subs;
+                dd.clear_below(s0 <= 1u ? 1u : (s0 + 2u) >> 1);              // 2i - 1 >= s0
+                ss.clear_below(s0 <= 2u ? 1u : (s0 + 1u) >> 1);              // 2i     >= s0
+                uint32_t best = kNoResume;
+                if (dd.any()) best = 2u * dd.first() - 1u;
+                if (ss.any()) { uint32_t v = 2u * ss.first(); if (v < best) best = v; }
+                if (best == kNoResume && insOK && s0 <= INS) best = INS;
+                return best;
+            };
+            const uint32_t idx = child_from(start);
+            if (idx != kNoResume) {
+                if (idx == 0u) r.kind = 0u;
+                else if (idx == INS) r.kind = 3u;
+                else { r.kind = (idx & 1u) ? 2u : 1u; r.take = (idx + 1u) >> 1; }
+                if (idx != INS) r.nxt = child_from(idx + 1u);
+                r.code = idx;
+            }
+        }
+    } else {
+        const uint32_t b = alive.first();                           // the row's symbol (symbolLeft / symbolRight, :267-277)
+        const bool valid = alive.any() && b >= 1u;                  // :298-301 only insertions below FirstSymb
+        const bool same = valid && b == c;
+        const bool en0 = Insertion && iOK;
+        const bool en1 = same ? mOK : (valid && xOK && iOK);
+        const bool en2 = Deletion && valid && xOK;
+        uint32_t idx = kNoResume;
+        if (start <= 0u && en0) idx = 0u; else if (start <= 1u && en1) idx = 1u; else if (start <= 2u && en2) idx = 2u;
+        if (idx == 0u) { r.kind = 3u; r.nxt = en1 ? 1u : (en2 ? 2u : kNoResume); }
+        else if (idx == 1u) {
+            r.take = b;
+            if (same) { r.kind = 0u; r.start_tail = !xOK; r.nxt = (en2 && xOK) ? 2u : kNoResume; }   // :310-314: the exact tail's result is returned as is
+            else { r.kind = 1u; r.nxt = en2 ? 2u : kNoResume; }
+        } else if (idx == 2u) { r.kind = 2u; r.take = b; }
+        r.code = idx == kNoResume ? 0u : idx;
+    }
+    return r;
+}
+// nodes the reference counts for this visit (a resumed node was counted when it was first met; a one-row match child that starts the exact tail counts the tail's first node too)
+__device__ __forceinline__ uint32_t edit_nodes_visited(bool in_tail, bool resuming, bool multi, bool xOK, bool mOK, bool start_tail) {
+    return in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + (start_tail ? 1u : 0u))));
+}
+// the edge taken, noted for the next node's rules (:146-163): side = lastRank | lastQRank per direction (8 bits each), info = the edge's kind per direction (2 bits: 0 match,
+// 1 substitution, 2 insertion, 3 deletion); d = 0 left, 1 right
+__device__ __forceinline__ void edit_note_edge(uint32_t kind, uint32_t take, uint32_t c, uint32_t d, uint32_t& side, uint32_t& info) {
+    const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
+    if (kind == 0u) { side = (side & rmask & qmask) | (c << (8u * d)) | (c << (16u + 8u * d)); info = info & imask; }      // (in the exact tail the values written last survive, :236-237)
+    else if (kind == 1u) { side = (side & rmask & qmask) | (take << (8u * d)) | (c << (16u + 8u * d)); info = (info & imask) | (1u << (2u * d)); }
+    else if (kind == 2u) { side = (side & rmask) | (take << (8u * d)); info = (info & imask) | (3u << (2u * d)); }
+    else { side = (side & qmask) | (c << (16u + 8u * d)); info = (info & imask) | (2u << (2u * d)); }
+}
+
 template <class Occ, int MAXSIG>
 __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_edit(Occ fw, Occ rv, SchemeDev sch, const uint8_t* __restrict__ qbuf,
                                                      const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
@@ -469,7 +541,6 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
         SymSet<MAXSIG> alive;
         if (via_lf) { alive.clear(); alive.insert(symbol_of_lf_lds(s_C, sigma, lf1)); }
         else alive = alive_set<MAXSIG>(lfa, lfb, sigma);
-        const bool c_alive = alive.test(c);
         const uint32_t d = right ? 1u : 0u;
         const uint32_t T = (info >> (2u * d)) & 3u;
         const uint32_t lastR = (side >> (8u * d)) & 255u, lastQ = (side >> (16u + 8u * d)) & 255u;
@@ -481,53 +552,10 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
         const bool xOK = e + 1 <= Up;
         const uint32_t start = resuming ? resume : 0u;
         // kind: 0 match, 1 substitution, 2 deletion, 3 insertion, 4 nothing left; `take` = index symbol of the child; `nxt` = number of the following child
-        uint32_t kind = 4u, take = c, nxt = kNoResume, code = 0;   // code: the child's index among the error children of its node (path key)
-        bool start_tail = false;
-        if (in_tail) { if (c_alive) kind = 0u; }
-        else if (multi) {
-            if (!xOK) { if (!resuming && mOK && c_alive) { kind = 0u; start_tail = true; } }
-            else {
-                SymSet<MAXSIG> dels = alive; dels.remove(0); if (!Deletion) dels.clear();
-                SymSet<MAXSIG> subs = alive; subs.remove(0); subs.remove(c); if (!iOK) subs.clear();
-                const bool insOK = Insertion && iOK;
-                auto child_from = [&](uint32_t s0) -> uint32_t {                // number of the first existing child >= s0
-                    if (s0 == 0u && mOK && c_alive) return 0u;
-                    SymSet<MAXSIG> dd = dels, ss = subs;
-                    dd.clear_below(s0 <= 1u ? 1u : (s0 + 2u) >> 1);              // 2i - 1 >= s0
-                    ss.clear_below(s0 <= 2u ? 1u : (s0 + 1u) >> 1);              // 2i     >= s0
-                    uint32_t best = kNoResume;
-                    if (dd.any()) best = 2u * dd.first() - 1u;
-                    if (ss.any()) { uint32_t v = 2u * ss.first(); if (v < best) best = v; }
-                    if (best == kNoResume && insOK && s0 <= INS) best = INS;
-                    return best;
-                };
-                const uint32_t idx = child_from(start);
-                if (idx != kNoResume) {
-                    if (idx == 0u) kind = 0u;
-                    else if (idx == INS) kind = 3u;
-                    else { kind = (idx & 1u) ? 2u : 1u; take = (idx + 1u) >> 1; }
-                    if (idx != INS) nxt = child_from(idx + 1u);
-                    code = idx;
-                }
-            }
-        } else {
-            const uint32_t b = alive.first();                       // the row's symbol (symbolLeft / symbolRight, :267-277)
-            const bool valid = alive.any() && b >= 1u;              // :298-301 only insertions below FirstSymb
-            const bool same = valid && b == c;
-            const bool en0 = Insertion && iOK;
-            const bool en1 = same ? mOK : (valid && xOK && iOK);
-            const bool en2 = Deletion && valid && xOK;
-            uint32_t idx = kNoResume;
-            if (start <= 0u && en0) idx = 0u; else if (start <= 1u && en1) idx = 1u; else if (start <= 2u && en2) idx = 2u;
-            if (idx == 0u) { kind = 3u; nxt = en1 ? 1u : (en2 ? 2u : kNoResume); }
-            else if (idx == 1u) {
-                take = b;
-                if (same) { kind = 0u; start_tail = !xOK; nxt = (en2 && xOK) ? 2u : kNoResume; }   // :310-314: the exact tail's result is returned as is
-                else { kind = 1u; nxt = en2 ? 2u : kNoResume; }
-            } else if (idx == 2u) { kind = 2u; take = b; }
-            code = idx == kNoResume ? 0u : idx;
-        }
-        nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + ((start_tail) ? 1u : 0u))));
+        const EditStep es = edit_next_child<MAXSIG>(alive, c, in_tail, multi, resuming, start, mOK, iOK, xOK, Deletion, Insertion, INS);
+        const uint32_t kind = es.kind, take = es.take, nxt = es.nxt, code = es.code;
+        const bool start_tail = es.start_tail;
+        nodes += edit_nodes_visited(in_tail, resuming, multi, xOK, mOK, start_tail);
         if (kind != 4u && nxt != kNoResume) {                       // keep the parent: its remaining children start at nxt
             const uint64_t w2 = (uint64_t)(nxt | (info << 16) | ((via_lf ? 1u : 0u) << 20) | ((ndel & 0xffu) << 21)) | ((uint64_t)(e & 0xffu) << 32) | ((uint64_t)(part & 0x7fu) << 40) |
                                 ((uint64_t)(right ? 1u : 0u) << 47) | ((uint64_t)((qL + 1u) & 0xffffu) << 48);
@@ -550,20 +578,7 @@ __global__ __launch_bounds__(256, MAXSIG <= 5 ? kEditWaves : 1) void k_scheme_ed
                 e += 1;
                 if (kind == 2u) ++ndel;
             }
-            const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
-            if (kind == 0u) {                                       // in the exact tail the values written last survive (:236-237)
-                side = (side & rmask & qmask) | (c << (8u * d)) | (c << (16u + 8u * d));
-                info = info & imask;
-            } else if (kind == 1u) {
-                side = (side & rmask & qmask) | (take << (8u * d)) | (c << (16u + 8u * d));
-                info = (info & imask) | (1u << (2u * d));
-            } else if (kind == 2u) {
-                side = (side & rmask) | (take << (8u * d));
-                info = (info & imask) | (3u << (2u * d));
-            } else {
-                side = (side & qmask) | (c << (16u + 8u * d));
-                info = (info & imask) | (2u << (2u * d));
-            }
+            edit_note_edge(kind, take, c, d, side, info);
             if (kind != 2u) {                                       // NextPos: one query symbol consumed (:122-133)
                 if (right) ++qR; else --qL;
                 if (in_tail) { to_next = --tail == 0; if (to_next) { ++part; pev = part != P ? part_len(pi[part]) : 0; } }
@@ -1530,56 +1545,12 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 alive.clear(); alive.insert(symbol_of_lf<SIGMA>(fa, fw.v.C, sigma, lf1));
             }
             lf_known = false; report_slot = kNoResume;
-            const bool c_alive = alive.test(c);
-            // ---- child selection (numbering as in k_scheme_edit)
+            // ---- child selection (edit_next_child: one definition for this kernel and k_scheme_edit)
             const uint32_t start = resuming ? resume : 0u;
-            uint32_t kind = 4u, take = c, nxt = kNoResume, code = 0;   // code: the child's index among the error children of its node (path key)
-            bool start_tail = false;
-            if (in_tail) { if (c_alive) kind = 0u; }
-            else if (multi) {
-                if (!xOK) { if (!resuming && mOK && c_alive) { kind = 0u; start_tail = true; } }
-                else {
-                    SymSet<MAXSIG> dels = alive; dels.remove(0); if (!Deletion) dels.clear();
-                    SymSet<MAXSIG> subs = alive; subs.remove(0); subs.remove(c); if (!iOK) subs.clear();
-                    const bool insOK = Insertion && iOK;
-                    auto child_from = [&](uint32_t s0) -> uint32_t {
-                        if (s0 == 0u && mOK && c_alive) return 0u;
-                        SymSet<MAXSIG> dd = dels, ss = subs;
-                        dd.clear_below(s0 <= 1u ? 1u : (s0 + 2u) >> 1);
-                        ss.clear_below(s0 <= 2u ? 1u : (s0 + 1u) >> 1);
-                        uint32_t best = kNoResume;
-                        if (dd.any()) best = 2u * dd.first() - 1u;
-                        if (ss.any()) { uint32_t v = 2u * ss.first(); if (v < best) best = v; }
-                        if (best == kNoResume && insOK && s0 <= INS) best = INS;
-                        return best;
-                    };
-                    const uint32_t idx = child_from(start);
-                    if (idx != kNoResume) {
-                        if (idx == 0u) kind = 0u;
-                        else if (idx == INS) kind = 3u;
-                        else { kind = (idx & 1u) ? 2u : 1u; take = (idx + 1u) >> 1; }
-                        if (idx != INS) nxt = child_from(idx + 1u);
-                        code = idx;
-                    }
-                }
-            } else {
-                const uint32_t b = alive.first();
-                const bool valid = b >= 1u;
-                const bool same = valid && b == c;
-                const bool en0 = Insertion && iOK;
-                const bool en1 = same ? mOK : (valid && xOK && iOK);
-                const bool en2 = Deletion && valid && xOK;
-                uint32_t idx = kNoResume;
-                if (start <= 0u && en0) idx = 0u; else if (start <= 1u && en1) idx = 1u; else if (start <= 2u && en2) idx = 2u;
-                if (idx == 0u) { kind = 3u; nxt = en1 ? 1u : (en2 ? 2u : kNoResume); }
-                else if (idx == 1u) {
-                    take = b;
-                    if (same) { kind = 0u; start_tail = !xOK; nxt = (en2 && xOK) ? 2u : kNoResume; }
-                    else { kind = 1u; nxt = en2 ? 2u : kNoResume; }
-                } else if (idx == 2u) { kind = 2u; take = b; }
-                code = idx == kNoResume ? 0u : idx;
-            }
-            nodes += in_tail ? 1u : (resuming ? 0u : (multi ? ((xOK || mOK) ? 1u : 0u) : (1u + (start_tail ? 1u : 0u))));
+            const EditStep es = edit_next_child<MAXSIG>(alive, c, in_tail, multi, resuming, start, mOK, iOK, xOK, Deletion, Insertion, INS);
+            const uint32_t kind = es.kind, take = es.take, nxt = es.nxt, code = es.code;   // code: the child's index among the error children of its node (path key)
+            const bool start_tail = es.start_tail;
+            nodes += edit_nodes_visited(in_tail, resuming, multi, xOK, mOK, start_tail);
             const bool keep = kind != 4u && nxt != kNoResume;
             if (__ballot(keep || kind == 4u)) settle();             // (the slot is touched below: by a push, or by the pop of a lane that goes back)
             if (keep) {                                             // keep the parent: its remaining children start at nxt
@@ -1609,11 +1580,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                     e += 1;
                     if (kind == 2u) ++ndel;
                 }
-                const uint32_t rmask = ~(255u << (8u * d)), qmask = ~(255u << (16u + 8u * d)), imask = ~(3u << (2u * d));
-                if (kind == 0u) { side = (side & rmask & qmask) | (c << (8u * d)) | (c << (16u + 8u * d)); info = info & imask; }
-                else if (kind == 1u) { side = (side & rmask & qmask) | (take << (8u * d)) | (c << (16u + 8u * d)); info = (info & imask) | (1u << (2u * d)); }
-                else if (kind == 2u) { side = (side & rmask) | (take << (8u * d)); info = (info & imask) | (3u << (2u * d)); }
-                else { side = (side & qmask) | (c << (16u + 8u * d)); info = (info & imask) | (2u << (2u * d)); }
+                edit_note_edge(kind, take, c, d, side, info);
                 if (kind != 2u) {                                   // one query symbol consumed: the next step of the table
                     in_tail = !lastp && (in_tail || start_tail);
                     ++j;
