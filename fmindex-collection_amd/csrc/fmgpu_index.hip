@@ -54,8 +54,7 @@ __global__ __launch_bounds__(256) void k_convert_ib(const uint8_t* __restrict__ 
                                                     const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t* __restrict__ out_super,
                                                     uint64_t nblocks, uint32_t sigma, uint32_t bt, uint32_t bits_off,
                                                     uint32_t stride, uint64_t period, uint32_t bstride, int prefix) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblocks * sigma) return;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblocks * sigma; t += (uint64_t)gridDim.x * blockDim.x) {      // (strided: a launch holds fewer than 2^32 threads)
     uint64_t B = t / sigma;
     uint32_t c = (uint32_t)(t % sigma);
     auto count_of = [&](uint64_t b, uint32_t s) -> uint64_t {
@@ -85,6 +84,7 @@ __global__ __launch_bounds__(256) void k_convert_ib(const uint8_t* __restrict__ 
     const uint64_t total = eval(B, &bits);
     const uint64_t base = kWide ? eval(super_first_block(B), nullptr) : 0;
     put_entry_a(out, out_super, B, c, sigma, bstride, total, base, bits);
+    }
 }
 
 static int upload(const void* host, size_t bytes, void** dev) {
@@ -414,8 +414,7 @@ struct HierView {
 };
 __global__ __launch_bounds__(256) void k_convert_hier(HierView v, const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t* __restrict__ out_super,
                                                       uint64_t nblocks, uint64_t n, uint32_t sigma, uint32_t bitct, uint32_t bstride) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblocks * sigma) return;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblocks * sigma; t += (uint64_t)gridDim.x * blockDim.x) {      // (strided: a launch holds fewer than 2^32 threads)
     const uint64_t B = t / sigma;
     uint32_t c = (uint32_t)(t % sigma);
     auto eval = [&](uint64_t b) -> uint64_t {
@@ -437,6 +436,7 @@ __global__ __launch_bounds__(256) void k_convert_hier(HierView v, const idx_t* _
     }
     if (n - row < 64) m &= (1ull << (n - row)) - 1ull;                                 // rows past the end read as symbol 0 in the planes
     put_entry_a(out, out_super, B, c, sigma, bstride, eval(B), kWide ? eval(super_first_block(B)) : 0, m);
+    }
 }
 
 static int create_hier(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
@@ -472,7 +472,7 @@ static int create_hier(const fmgpu_string_desc& d, const idx_t* dC, DevString& s
     }
     if ((rc = alloc_format_a(s, d.n, sigma, dC))) { drop(); return rc; }
     dim3 grid;
-    if ((rc = grid_of(nblocks * sigma, &grid))) { drop(); return rc; }
+    if ((rc = grid_of(nblocks * sigma, &grid, 1u << 22))) { drop(); return rc; }
     k_convert_hier<<<grid, dim3(256)>>>(v, dC, (uint8_t*)s.blk, (uint64_t*)s.sup, nblocks, d.n, sigma, bitct, s.va.bstride);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -486,8 +486,7 @@ static int create_hier(const fmgpu_string_desc& d, const idx_t* dC, DevString& s
 __global__ __launch_bounds__(256) void k_convert_fbv(const uint8_t* __restrict__ bits, const uint64_t* __restrict__ l0, const uint16_t* __restrict__ l1,
                                                      const idx_t* __restrict__ C, uint8_t* __restrict__ out, uint64_t* __restrict__ out_super, uint64_t nblocks, uint64_t n,
                                                      uint32_t sigma, uint32_t bitct, uint32_t l1_bits, uint32_t bstride) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblocks * sigma) return;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblocks * sigma; t += (uint64_t)gridDim.x * blockDim.x) {      // (strided: a launch holds fewer than 2^32 threads)
     const uint64_t B = t / sigma;
     const uint32_t c = (uint32_t)(t % sigma), sig1 = sigma + 1;
     auto eval = [&](uint64_t b, uint64_t* bits_out) -> uint64_t {
@@ -514,6 +513,7 @@ __global__ __launch_bounds__(256) void k_convert_fbv(const uint8_t* __restrict__
     uint64_t m = 0;
     const uint64_t total = eval(B, &m);
     put_entry_a(out, out_super, B, c, sigma, bstride, total, kWide ? eval(super_first_block(B), nullptr) : 0, m);
+    }
 }
 
 static int create_fbv(const fmgpu_string_desc& d, const idx_t* dC, DevString& s) {
@@ -531,7 +531,7 @@ static int create_fbv(const fmgpu_string_desc& d, const idx_t* dC, DevString& s)
     rc = upload(d.levels[0], nl1 * (sigma + 1) * 2, &d1); if (rc) { drop(); return rc; }
     if ((rc = alloc_format_a(s, d.n, sigma, dC))) { drop(); return rc; }
     dim3 grid;
-    if ((rc = grid_of(nblocks * sigma, &grid))) { drop(); return rc; }
+    if ((rc = grid_of(nblocks * sigma, &grid, 1u << 22))) { drop(); return rc; }
     k_convert_fbv<<<grid, dim3(256)>>>((const uint8_t*)db, (const uint64_t*)d0, (const uint16_t*)d1, dC, (uint8_t*)s.blk, (uint64_t*)s.sup,
                                        nblocks, d.n, sigma, bitct, l1_bits, s.va.bstride);
     hipError_t e = hipGetLastError();
@@ -611,7 +611,7 @@ static int create_string(const fmgpu_string_desc& d, const idx_t* dC, DevString&
         auto drop = [&] { (void)hipFree(raw); (void)hipFree(sup); };
         if ((rc = alloc_format_a(s, d.n, sigma, dC))) { drop(); return rc; }
         dim3 grid;
-        if ((rc = grid_of(nblocks * sigma, &grid))) { drop(); return rc; }
+        if ((rc = grid_of(nblocks * sigma, &grid, 1u << 22))) { drop(); return rc; }
         k_convert_ib<<<grid, dim3(256)>>>((const uint8_t*)raw, (const uint64_t*)sup, dC, (uint8_t*)s.blk, (uint64_t*)s.sup, nblocks, sigma, L.bt, L.bits_off, L.stride,
                                           L.period, s.va.bstride, L.family == 1 ? 1 : 0);
         hipError_t e = hipGetLastError();
