@@ -110,6 +110,7 @@ OPTION_DEFAULTS = {"pair_table": 1, "dense_dna": 1, "symbol_planes": 1, "expand_
 # FMGPU_SEL_* bits of the kernel_select option
 SEL_GENERAL_DFS, SEL_NO_PREFIX_TABLE, SEL_NO_LF3, SEL_NO_LF_GENERAL, SEL_NO_WALK_TABLE, SEL_NO_LENGTH_BUCKETS = 2, 4, 8, 16, 32, 64
 SEL_EXACT_ON_TREE, SEL_EXACT_ONE_SYMBOL, SEL_LOCATE_PER_LANE, SEL_NO_SHARING, SEL_NO_EXACT_LUT, SEL_LEAN_FORMAT_A, SEL_NO_LEAN = 1 << 21, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 29, 1 << 30
+SEL_NO_BOARD = 1 << 26
 # fmgpu_index_formats bits: what a handle holds beside (or as) the layout it was given
 FMT_BLOCKS, FMT_PAIRS, FMT_DENSE, FMT_PLANES, FMT_TREE, FMT_REFERENCE, FMT_LF, FMT_KSTEP, FMT_INTERVALS, FMT_WALK, FMT_PREFIX, FMT_LOCATE, FMT_FUSED = (1 << k for k in range(13))
 

@@ -96,7 +96,7 @@ static int set_opt(int option, int64_t value) {
 // tables) leaves nothing half-initialised behind, and the next call simply tries again.  Keyed by device: a host thread that alternates
 // between handles on two devices re-uses both sets.  FMGPU_OPT_FAIL_SCRATCH = k (test hook) fails the k-th allocation of the next creation.
 void CallScratch::drop() {
-    for (void* p : {(void*)ctr, (void*)sink, (void*)len2, frames, dfs_ctr, order}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)ctr, (void*)sink, (void*)len2, frames, dfs_ctr, order, board}) if (p) (void)hipFree(p);
     if (pinned) (void)hipHostFree(pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);

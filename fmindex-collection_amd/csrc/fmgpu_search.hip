@@ -1339,7 +1339,7 @@ template <int SIGMA, int MAXSIG, bool PLAIN = false>      // PLAIN: sigma = 5 an
 __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
-                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, int sharing, int use_key) {
+                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, int sharing, int use_key, WorkBoard* board) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
@@ -1362,6 +1362,15 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sigma = fw.sigma(), R = sigma - 1;
     const uint32_t INS = 2u * sigma - 1u;
+    if (board) board_enter(board, lane);                            // (work sharing between the waves of the launch: fmgpu_search_shared.h)
+    uint32_t pass = 0;
+    const uint32_t board_heavy = board ? board->heavy : 0u, board_period = board ? board->period : 1u;
+#ifdef FMGPU_DEV
+    unsigned long long bt_wait = 0, bt_give = 0, bt_look = 0, bn_wait = 0, bn_give = 0, bn_look = 0; const unsigned long long bt_start = __builtin_amdgcn_s_memtime();
+#define BSTAMP() __builtin_amdgcn_s_memtime()
+#else
+#define BSTAMP() 0ull
+#endif
     uint4* const frames = reinterpret_cast<uint4*>(stk.p0) + 2u * (gid * ((uint64_t)stk.depth + 1u));   // this lane's frames, 32 bytes each
     uint32_t nodes = 0, nh = 0, count_only = 0;
     const uint32_t refill_waste = ((uint32_t)dev_flags >> 8) & 0xffffu ? (((uint32_t)dev_flags >> 8) & 0xffffu) : kRefillWaste;   // (dev knob: bits 8..23)
@@ -1383,6 +1392,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     uint32_t report_slot = kNoResume;
 #ifdef FMGPU_DEV
     uint32_t dev_slot_bad = 0;
+    uint32_t dev_multi = 0, dev_revisit = 0, dev_busy = 0, dev_iter = 0, dev_noload = 0;   // dev build: lane-iterations on nodes of several rows / of those, re-visits for the next child / all / wave iterations / one-row iterations that load nothing
 #endif
     bool tos_dirty = false, tos_pending = false;                    // tos_pending: a refill of the slot by LDS-DMA may still be in flight (settle() before the slot is touched)
     // the refill was issued at the end of an earlier iteration; by the places that touch the slot every load of the current iteration has been consumed, so this
@@ -1432,6 +1442,36 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 }
             }
         }
+        // ---- ... and with the other waves of the launch: every kBoardPeriod-th pass a wave with subtrees to give looks whether a wave waits for work, and hands it the bottom
+        // frames of ALL its offering lanes (the same frames, keys and thresholds as above; the taker stages the reads itself)
+        if (board && (++pass % board_period) == 0u) {
+            const bool cand = have && sp > sbase && nodes - mark >= share_nodes && nodes - nodes0 >= board_heavy && report_slot != sbase;
+            const uint64_t cm = __ballot(cand);
+            uint32_t bslot = 0, bidx = 0;
+            [[maybe_unused]] const unsigned long long t0_ = BSTAMP();
+            const bool got_ = cm && board_reserve(board, lane, &bslot, &bidx);
+#ifdef FMGPU_DEV
+            if (cm) { bt_look += BSTAMP() - t0_; ++bn_look; }
+#endif
+            if (got_) {
+                if (__ballot(cand && sbase + 1u == sp)) settle();
+                if (cand) {
+                    uint4 g0, g1;
+                    if (sbase + 1u == sp) { const e_u32x4 u0 = *tos0, u1 = *tos1; g0 = make_uint4(u0.x, u0.y, u0.z, u0.w); g1 = make_uint4(u1.x, u1.y, u1.z, u1.w); tos_dirty = false; }
+                    else { g0 = frames[2u * sbase]; g1 = frames[2u * sbase + 1u]; }
+                    const uint64_t gk = ekey_prefix(pkey, (g0.w >> 16) & 0xffu);
+                    ++sbase; mark = nodes;
+                    const uint32_t r = (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+                    const uint32_t w[kBoardWords] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, (uint32_t)gk, (uint32_t)(gk >> 32), (uint32_t)q, (uint32_t)(q >> 32), si, 0u};
+#pragma unroll
+                    for (uint32_t d_ = 0; d_ < kBoardWords; ++d_) board_put(board, bslot, d_, r, w[d_]);
+                }
+                board_publish(board, lane, bslot, bidx, (uint32_t)__popcll(cm));
+#ifdef FMGPU_DEV
+                bt_give += BSTAMP() - t0_; ++bn_give;
+#endif
+            }
+        }
         const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
         waste += (uint32_t)__popcll(needm);
         if (needm && (waste >= refill_waste || !busym)) {
@@ -1452,7 +1492,37 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
         {
             const bool full = wave_ring_fill(s_hb) >= kWaveRingFlush; const uint64_t busy = __ballot(have);
             if (full || !busy) wave_flush_hits(s_hb, nh, lane, out, cap, ctr);
-            if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
+            if (!busy) {
+                if (__ballot(!exhausted) != 0ull) continue;
+                if (!board) break;
+                // the wave is out of work and the batch is handed out: it waits for subtrees of the reads other waves still walk, or for the end of the launch
+                uint32_t bslot = 0;
+                [[maybe_unused]] const unsigned long long t0_ = BSTAMP();
+                const uint32_t k = board_wait(board, lane, &bslot);
+#ifdef FMGPU_DEV
+                bt_wait += BSTAMP() - t0_; ++bn_wait;
+#endif
+                if (k == 0u) break;
+                const bool fresh = lane < k; uint64_t qo = 0;
+                if (fresh) {
+                    uint32_t w[kBoardWords];
+#pragma unroll
+                    for (uint32_t d_ = 0; d_ < kBoardWords; ++d_) w[d_] = board_word(board, bslot, d_, lane);
+                    q = (uint64_t)w[10] | ((uint64_t)w[11] << 32); si = w[12];
+                    qo = qoff[q]; qs = qbuf + qo;
+                    const bool one_row = (w[3] >> 24) & 1u;
+                    cur.lb = w[0]; cur.lbRev = w[1]; cur.len = one_row ? 1u : w[2]; cached_lf2 = one_row ? w[2] : 0xffffffffu;
+                    j = w[3] & 0xffffu; e = (w[3] >> 16) & 0xffu; info = (w[3] >> 25) & 15u;
+                    resume = w[4]; side = w[5]; cached_lf = w[6]; ndel = w[7];
+                    pkey = (uint64_t)w[8] | ((uint64_t)w[9] << 32);
+                    have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
+                    tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; lf_known = false; report_slot = kNoResume; mark = nodes; nodes0 = nodes;
+                    tos_dirty = false;
+                }
+                qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                continue;
+            }
         }
         if (!have) continue;
         bool lut_start = false; uint32_t lut_code = 0;
@@ -1499,6 +1569,10 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                           : reinterpret_cast<const uint8_t*>((right ? fa.lf_rv : fa.lf_fw) + a);
         uint4 r0 = make_uint4(0, 0, 0, 0);
         const bool row_load = !lut_start && !multi && !resuming && !lf_known;
+#ifdef FMGPU_DEV
+        ++dev_busy; dev_multi += multi ? 1u : 0u; dev_revisit += (multi && resuming) ? 1u : 0u; dev_noload += (!lut_start && !multi && !row_load) ? 1u : 0u;
+        if (lane == (uint32_t)__ffsll((unsigned long long)__ballot(true)) - 1u) ++dev_iter;
+#endif
         if (lut_start || multi || row_load) r0 = *reinterpret_cast<const uint4*>(p0);
         uint4 q1 = make_uint4(0, 0, 0, 0), q2 = q1, q3 = q1;
         if (plain && row_load) { const uint4* pa = reinterpret_cast<const uint4*>(p0); q1 = pa[1]; q2 = pa[2]; q3 = pa[3]; }
@@ -1644,6 +1718,17 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     }
 #ifdef FMGPU_DEV
     { const uint32_t bad = wave_sum(dev_slot_bad); if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(reinterpret_cast<unsigned long long*>(ctr) + 20, (unsigned long long)bad); }
+    if (board && lane == 0) {
+        atomicAdd(&board->dev[0], bt_wait); atomicAdd(&board->dev[1], bt_give); atomicAdd(&board->dev[2], bt_look); atomicAdd(&board->dev[3], bn_wait); atomicAdd(&board->dev[4], bn_give);
+        atomicAdd(&board->dev[5], bn_look); atomicAdd(&board->dev[6], BSTAMP() - bt_start);
+    }
+    {   // (tools/edit_mix_probe.py: table_accesses = multi | wave iterations << 40, table_bytes = busy | load-free << 40, table_steps = re-visits)
+        const uint32_t a1 = wave_sum(dev_multi), a2 = wave_sum(dev_iter), a3 = wave_sum(dev_busy), a4 = wave_sum(dev_revisit), a5 = wave_sum(dev_noload);
+        if ((threadIdx.x & 63u) == 0) {
+            atomicAdd(&ctr->table_accesses, (unsigned long long)a1 | ((unsigned long long)a2 << 40)); atomicAdd(&ctr->table_bytes, (unsigned long long)a3 | ((unsigned long long)a5 << 40));
+            atomicAdd(reinterpret_cast<unsigned long long*>(ctr) + 21, (unsigned long long)a4);
+        }
+    }
 #endif
 }
 
@@ -2356,12 +2441,14 @@ struct DfsWorkspace {
     // every block must be resident from the start or the late ones form a tail).
     // The frame stacks (~1 GB for a full-chip launch over 101-symbol reads) stay with the calling host thread between calls: allocating and
     // freeing them per call costs ~0.2 ms (hipFree synchronises the device), 2-3 % of a 10 M-read k = 2 call.
-    int init(uint32_t depth, uint64_t nq, int blocks_per_cu, hipStream_t stream, int nplanes = 3) {
+    WorkBoard* board = nullptr;                                    // (with_board) sharing between the waves of a launch
+    // with_board: every resident block is launched however small the batch — a block without reads of its own waits at the board for subtrees of the heavy reads
+    int init(uint32_t depth, uint64_t nq, int blocks_per_cu, hipStream_t stream, int nplanes = 3, bool with_board = false) {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         uint64_t want = (uint64_t)cus * (uint64_t)std::max(1, std::min(8, blocks_per_cu));
-        grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (nq + 255) / 256));
+        grid = (unsigned)std::max<uint64_t>(1, with_board ? want : std::min<uint64_t>(want, (nq + 255) / 256));
         view.nlanes = (uint64_t)grid * 256; view.depth = depth;
         uint64_t words = view.nlanes * ((uint64_t)depth + 1);
         const size_t need = words * 8 * (size_t)nplanes;
@@ -2381,7 +2468,38 @@ struct DfsWorkspace {
         view.p0 = planes; view.p1 = planes + words; view.p2 = planes + 2 * words; view.p3 = nplanes > 3 ? planes + 3 * words : nullptr;
         ctr = (Counters*)sc->dfs_ctr;
         FM_HIP(hipMemsetAsync(ctr, 0, 256, stream));                         // next: the query hand-out counter of the scheme kernels (+ a debug area)
+        if (with_board) {
+            if (!sc->board) FM_HIP(hipMalloc(&sc->board, sizeof(WorkBoard)));
+            board = (WorkBoard*)sc->board;
+        }
         return 0;
+    }
+    int reset_board(hipStream_t stream) {                          // before every launch that uses it
+        if (!board) return 0;
+        FM_HIP(hipMemsetAsync(board, 0, kBoardResetBytes, stream));
+        uint32_t cfg[3] = {kBoardHeavy, kBoardPeriod, kBoardWaiters};
+        if (const char* e = dev_env("FMGPU_DEV_BOARD_HEAVY")) cfg[0] = (uint32_t)atoi(e);
+        if (const char* e = dev_env("FMGPU_DEV_BOARD_PERIOD")) cfg[1] = (uint32_t)std::max(1, atoi(e));
+        if (const char* e = dev_env("FMGPU_DEV_BOARD_WAITERS")) cfg[2] = (uint32_t)std::max(1, atoi(e));
+        FM_HIP(hipMemcpyAsync(&board->heavy, cfg, 12, hipMemcpyHostToDevice, stream));
+        return 0;
+    }
+    // after the launch has been synchronised: a waiting wave that gave up means results may be missing
+    int check_board() {
+        if (!board) return 0;
+        unsigned long long f = 0;
+        FM_HIP(hipMemcpy(&f, &board->failed, 8, hipMemcpyDeviceToHost));
+        if (dev_env("FMGPU_DEV_BOARD_LOG")) {                        // (development build: what went over the board in the last launch)
+            unsigned long long v[2] = {0, 0}, t = 0;
+            (void)hipMemcpy(&v[0], &board->ht, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&t, &board->tasks, 8, hipMemcpyDeviceToHost);
+            unsigned long long d[7] = {0}; uint32_t tries = 0;
+            (void)hipMemcpy(d, &board->dev[0], sizeof d, hipMemcpyDeviceToHost); (void)hipMemcpy(&tries, &board->cas_tries, 4, hipMemcpyDeviceToHost);
+            const double clk = 2.4e3;                              // (s_memtime counts the shader clock here: ~2.4 GHz — cycles per microsecond)
+            fprintf(stderr, "board: %llu batches asked for, %llu published, %llu subtrees, %u compare-and-swaps; wave-time: waiting %.1f %% (%llu waits), giving %.2f %% (%llu, %.1f us each), looking %.2f %% (%llu, %.1f us each)\n",
+                    v[0] >> 32, v[0] & 0xffffffffull, t, tries, d[6] ? 100.0 * d[0] / d[6] : 0.0, d[3], d[6] ? 100.0 * d[1] / d[6] : 0.0, d[4], d[4] ? d[1] / (double)d[4] / clk : 0.0,
+                    d[6] ? 100.0 * d[2] / d[6] : 0.0, d[5], d[5] ? d[2] / (double)d[5] / clk : 0.0);
+        }
+        return f ? fail(FMGPU_ERR_HIP, "work sharing between waves: " + std::to_string(f) + " waiting wave(s) gave up") : 0;
     }
     ~DfsWorkspace() { if (planes && own_planes) (void)hipFree(planes); }
 };
@@ -2692,7 +2810,12 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
 #endif
     { const char* ev = dev_env("FMGPU_DEV_BPC"); if (ev && atoi(ev) > 0) bpc = atoi(ev); }   // dev knob: resident blocks per CU the grid is sized for
     // frames: one per node of the current path; deletions lengthen the path beyond the query by at most the largest upper bound
-    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3))) return rc;
+    // sharing between the waves of a launch (the board, fmgpu_search_shared.h): the table-driven edit-distance kernel, wherever its lanes share inside a wave
+    bool with_board = false;
+#if !FMGPU_WIDE
+    with_board = fast && edit && sharing && !(kernel_flags() & FMGPU_SEL_NO_BOARD);
+#endif
+    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3, with_board))) return rc;
     const dim3 grid(ws.grid);
 #if !FMGPU_WIDE
     size_t steps_words = 0;
@@ -2731,18 +2854,19 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             fa.lut = b.lut_ok ? x->lut : nullptr; fa.lutL = x->lut_len; fa.lut_ok = b.lut_ok;
             for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
             const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (size_t)kWaveHitWords * 4 + (edit ? 2 * 256 * 16 + 16 : 0);     // (edit distance: + the top frames of the stacks)
-            const dim3 g((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(ws.grid, (b.count + 255) / 256)));
+            const dim3 g((unsigned)std::max<uint64_t>(1, with_board ? (uint64_t)ws.grid : std::min<uint64_t>(ws.grid, (b.count + 255) / 256)));
             FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));   // reads are handed out from 0
+            if ((rc = ws.reset_board(stream))) return rc;
             const uint32_t* qm = d_qmap ? d_qmap + b.first : nullptr;
             if (edit) {
                 if (x->bwt.sigma == 5) {
                     if (!have_lf) k_scheme_fast_edit<5, 5, true><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
+                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key, ws.board);
                     else k_scheme_fast_edit<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
+                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key, ws.board);
                 } else
                     k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                              b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
+                                                                              b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key, ws.board);
             } else if (lean) {
                 launch_lean(x, fa.steps, (uint32_t)sd.S, b.m, b.tab.size() / 3, g, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (fmgpu_hit*)sout.dev, capacity, ws, qm, stream, b.lut_ok);
             } else if (x->bwt.sigma == 5 && !have_lf)
@@ -2814,6 +2938,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     if (le == hipSuccess) le = hipMemcpyAsync(&hc, ws.ctr, sizeof hc, hipMemcpyDeviceToHost, stream);
     if (le == hipSuccess) le = hipStreamSynchronize(stream);
     if (le != hipSuccess) return hip_fail(le, "search kernel");
+    if ((rc = ws.check_board())) return rc;
 #ifdef FMGPU_DEV_STAMPS
     { unsigned long long dbg[12]; (void)hipMemcpy(dbg, reinterpret_cast<unsigned long long*>(ws.ctr) + 8, sizeof dbg, hipMemcpyDeviceToHost);
       if (dbg[6]) fprintf(stderr, "stamps: waves %llu, wave node-steps %llu; cycles per node-step: top %.0f share %.0f refill %.0f flush+rest %.0f issue %.0f wait %.0f node %.0f tail %.0f\n", dbg[6], dbg[5],

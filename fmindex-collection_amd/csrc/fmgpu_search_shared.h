@@ -238,6 +238,125 @@ struct WavePairs {
 
 constexpr uint32_t kNoResume = 0xffffffffu;
 
+// ---- work sharing between the WAVES of a launch: the board ---------------------------------------------------------------------------------
+// Sharing inside a wave spreads a heavy read over 64 lanes.  On a repeat-rich text that is not enough for the heaviest reads: 125 k reads of the genome text took the
+// edit-distance kernel 85 ms and 2 M reads 147 ms (tools/batch_scaling_probe.py) — the launch ended when the ONE wave that held a read of a satellite array (millions of
+// nodes) was done, thousands of waves having left long before.  Round 2's device-wide task queue failed on its queue head: every heavy lane pushed, every idle lane popped, one
+// address served millions of atomics at ~1.3 us each.  The board is driven by DEMAND instead, so that nothing touches it while every wave has work:
+//   * a wave that is out of work once the batch is handed out leaves the count of working waves, asks for a batch (one fetch-add: its index) and sleeps on THAT batch's
+//     header word — a line of its own — until the batch is published or the launch is over (`state` = 0: no working wave, no untaken batch; it cannot rise again).  At most
+//     kBoardWaiters waves wait; the others leave (a poll is a read of memory);
+//   * a working wave looks at the board every kBoardPeriod-th pass — one load — and only if some lane of it has a subtree to give; if batches are asked for it takes the
+//     next index (one fetch-add), writes the bottom frames of ALL its offering lanes into that batch — one task per lane, up to 64 — and publishes the header; the sleeper
+//     wakes with that many lanes of work, which prove heavy in turn and give again.
+// Hit records carry path keys (fmgpu_hits_sort orders them whoever found them), as for the sharing inside a wave: the board is on exactly when that sharing is.
+// No co-residency is assumed: a wave that starts late finds the batch handed out, asks, sees state = 0 and leaves.
+// What it took (tools/board_sweep.sh, development build): (1) polls are RELAXED loads — an acquire load invalidates the CU's L1 at every poll; (2) no fence anywhere (below);
+// (3) a giver reserves with ONE fetch-add — a compare-and-swap loop cost (givers)^2 atomics once thousands of waves gave at once (7.5 x 10^7 attempts for 1.7 x 10^5 batches;
+// a reservation took milliseconds, the launch 1.1 s instead of 0.11); with these, a hand-over costs the giver 2.4 us and a look 0.6 us, and a low threshold is best.
+constexpr uint32_t kBoardBatches = 8192;      // ring of batches (a batch is taken at once by the wave that asked for it: one per waiting wave is ever in use)
+constexpr uint32_t kBoardWords = 14;          // dwords of a task (edit distance: two 16-byte frame halves, the path key, read number, search number)
+constexpr uint32_t kBoardPeriod = 8;          // passes of a working wave between two looks at the board (a look: one load; a hand-over: ~2.4 us of the giving wave)
+constexpr uint32_t kBoardHeavy = 256;         // nodes a lane must have spent on its read (or subtree) before it gives to another WAVE.  Measured on the genome text, k = 2 edit distance,
+                                              // kernel ms for 125 k / 1 M / 2 M reads (development build; without the board 85 / 110 / 147): heavy 8192: 92 / 101 / 124, 2048: 44 / 79 / 127,
+                                              // 512: 30 / 78 / 123, 256 and 64: 25 / 77 / 121 (period 4-8; period 64: 55 / 90 / 135)
+constexpr uint32_t kBoardSpinCap = 1u << 21;  // a waiting wave gives up after this many polls (~30 s) and flags the launch as failed: a bug must not hang the card
+constexpr uint32_t kBoardWaiters = 1024;      // waves that wait at the board at most: a poll is a read of memory (sc1), and 4096 waves polling every 3 us took the channels their headers
+                                              // live on — a giver's compare-and-swap on the same pages then took milliseconds (tools/board_sweep.sh); the other idle waves leave
+struct WorkBoard {
+    unsigned long long state;                 // low 32 bits: waves that hold work; high 32: published batches nobody has taken yet
+    unsigned long long failed;                // a waiting wave gave up (kBoardSpinCap)
+    unsigned long long tasks;                 // subtrees handed over (a count for the development build's log)
+    uint32_t heavy, period;                   // kBoardHeavy / kBoardPeriod of this launch (written by the host: development builds can vary them)
+    uint32_t waiters, cas_tries;              // kBoardWaiters of this launch; development build: compare-and-swap attempts of the givers
+    unsigned long long dev[7];                // development build: wave-cycles (s_memtime) waiting / giving / looking, their counts, waves, cycles of all waves
+    unsigned long long pad0[4];
+    unsigned long long ht;                    // (a line of its own) high 32 bits: batches asked for; low 32: batches published (never more than asked for)
+    unsigned long long pad1[15];
+    unsigned long long hdr[kBoardBatches][8]; // [.][0]: (index + 1) << 8 | tasks of the batch with that index, written last; 64 bytes apart: the waiting waves' polls spread over the memory channels
+    uint32_t task[kBoardBatches][kBoardWords][64];
+};
+constexpr size_t kBoardResetBytes = 256 + sizeof(unsigned long long) * 8 * kBoardBatches;     // what a launch starts from zero
+
+__device__ __forceinline__ unsigned long long wave_bcast64(unsigned long long v, int src) {
+    return ((unsigned long long)__shfl((uint32_t)(v >> 32), src, 64) << 32) | __shfl((uint32_t)v, src, 64);
+}
+// Visibility between waves on different CUs / XCDs without a fence: every word of the board is written by an agent-scope atomic or an `sc1` (write-through) store and read by an
+// agent-scope atomic or an `sc1` load; a giver drains its stores (s_waitcnt vmcnt(0)) before it stores the header, a taker loads the tasks only after its poll has matched the header
+// (MI355X_MICROARCH.md, "hand-offs measured with sc1 loads in place of the acquire").  A release / acquire fence here would write back and invalidate the XCD's L2 at every hand-over:
+// the first version did (__threadfence) and made the launch up to eight times SLOWER — thousands of hand-overs each flushed the cache every other wave of the XCD walks its index through.
+// every wave of the launch, before it asks for its first reads (the count has arrived before the hand-out counter moves: the add returns, and is waited for)
+__device__ __forceinline__ void board_enter(WorkBoard* b, uint32_t lane) {
+    unsigned long long old = 0;
+    if (lane == 0) old = atomicAdd(&b->state, 1ull);
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"((uint32_t)old) : "memory");
+}
+// a wave without work, the batch handed out: returns the number of tasks of the batch it was given (their dwords at task[*slot][.][0 .. k - 1]), or 0 = the launch is over
+__device__ __forceinline__ uint32_t board_wait(WorkBoard* b, uint32_t lane, uint32_t* slot) {
+    unsigned long long asked = 0; uint32_t stay = 0;
+    if (lane == 0) {
+        atomicAdd(&b->state, ~0ull);
+        const unsigned long long v = __hip_atomic_load(&b->ht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stay = (int32_t)((uint32_t)(v >> 32) - (uint32_t)v) < (int32_t)b->waiters ? 1u : 0u;      // (enough waves wait already: this one is not needed; published > asked: a batch waits for THIS wave)
+        if (stay) asked = atomicAdd(&b->ht, 1ull << 32) >> 32;
+    }
+    if (!__shfl(stay, 0, 64)) return 0;
+    const uint32_t idx = (uint32_t)wave_bcast64(asked, 0);
+    *slot = idx % kBoardBatches;
+    for (uint32_t spin = 0;; ++spin) {
+        unsigned long long h = 0, st = 1;
+        if (lane == 0) {
+            // (relaxed, never acquire: an acquire load invalidates the CU's L1 at every poll — with fifteen waiting waves beside it, the one wave that still walks the heaviest read
+            // then takes every block from L2)
+            h = __hip_atomic_load(&b->hdr[*slot][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((spin & 7u) == 7u) st = __hip_atomic_load(&b->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (spin == kBoardSpinCap) { atomicAdd(&b->failed, 1ull); st = 0; }
+        }
+        h = wave_bcast64(h, 0); st = wave_bcast64(st, 0);
+        if ((h >> 8) == (unsigned long long)idx + 1ull) {
+            if (lane == 0) atomicAdd(&b->state, 1ull - (1ull << 32));      // one more working wave, one batch fewer on the board — in one step
+            return (uint32_t)(h & 0xffu);
+        }
+        if (st == 0) return 0;
+        __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);      // ~14 us between polls
+    }
+}
+// a working wave with subtrees to give: the index of the batch it may fill, if a wave waits (wave-uniform).  ONE fetch-add, no compare-and-swap loop: in the tail of a launch
+// thousands of waves give at once, and a loop that retries until it wins costs (givers)^2 atomics on one word (measured: 7.5 x 10^7 compare-and-swaps for 1.7 x 10^5 batches,
+// a reservation took milliseconds).  Two givers that both saw the last request may both publish: the second batch has no waiting wave yet — the next wave that runs out of
+// work asks, gets exactly that index, and finds it published (every working wave asks when it is done, and a wave never leaves while a published batch is untaken)
+__device__ __forceinline__ bool board_reserve(WorkBoard* b, uint32_t lane, uint32_t* slot, uint32_t* index) {
+    unsigned long long v = 0; uint32_t ok = 0;
+    if (lane == 0) {
+        v = __hip_atomic_load(&b->ht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)((uint32_t)(v >> 32) - (uint32_t)v) > 0) {    // asked > published
+            atomicAdd(&b->state, 1ull << 32);                      // (counted as published before its header can be seen)
+            v = atomicAdd(&b->ht, 1ull);
+            ok = 1;
+#ifdef FMGPU_DEV
+            atomicAdd(&b->cas_tries, 1u);
+#endif
+        }
+    }
+    ok = __shfl(ok, 0, 64);
+    *index = (uint32_t)wave_bcast64(v, 0);
+    *slot = *index % kBoardBatches;
+    return ok != 0;
+}
+__device__ __forceinline__ void board_put(WorkBoard* b, uint32_t slot, uint32_t word, uint32_t task, uint32_t value) {      // a giver's lane: one dword of its task, written through
+    __hip_atomic_store(&b->task[slot][word][task], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void board_publish(WorkBoard* b, uint32_t lane, uint32_t slot, uint32_t index, uint32_t tasks) {      // all lanes, after the givers wrote their tasks
+#ifdef FMGPU_DEV
+    if (lane == 0) atomicAdd(&b->tasks, (unsigned long long)tasks);
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the wave's task stores (and the count above) have been written through
+    if (lane == 0) __hip_atomic_store(&b->hdr[slot][0], ((unsigned long long)(index + 1u) << 8) | tasks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t board_word(const WorkBoard* b, uint32_t slot, uint32_t word, uint32_t task) {      // (past the reader's L1: the slot may have been read before)
+    return __hip_atomic_load(&b->task[slot][word][task], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
     uint32_t x = v;
 #pragma unroll

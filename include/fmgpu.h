@@ -199,10 +199,11 @@ typedef enum fmgpu_option {
 #define FMGPU_SEL_LOCATE_PER_LANE  (1 << 23)  /* locate with one row per lane (k_locate_fused) instead of the quad-cooperative kernel */
 #define FMGPU_SEL_NO_SHARING       (1 << 24)  /* no work sharing between the lanes of a wave */
 #define FMGPU_SEL_NO_EXACT_LUT     (1 << 25)  /* exact search does not start from the interval table in front of the pair table */
+#define FMGPU_SEL_NO_BOARD         (1 << 26)  /* no work sharing between the waves of a launch (the lanes of a wave still share) */
 #define FMGPU_SEL_LEAN_FORMAT_A    (1 << 29)  /* k_scheme_lean on the one-symbol blocks although dense DNA blocks exist */
 #define FMGPU_SEL_NO_LEAN          (1 << 30)  /* k_scheme_fast<PLAIN> instead of k_scheme_lean */
 #define FMGPU_SEL_ALL (FMGPU_SEL_GENERAL_DFS | FMGPU_SEL_NO_PREFIX_TABLE | FMGPU_SEL_NO_LF3 | FMGPU_SEL_NO_LF_GENERAL | FMGPU_SEL_NO_WALK_TABLE | FMGPU_SEL_NO_LENGTH_BUCKETS | \
-                       FMGPU_SEL_EXACT_ON_TREE | FMGPU_SEL_EXACT_ONE_SYMBOL | FMGPU_SEL_LOCATE_PER_LANE | FMGPU_SEL_NO_SHARING | FMGPU_SEL_NO_EXACT_LUT | FMGPU_SEL_LEAN_FORMAT_A | FMGPU_SEL_NO_LEAN)
+                       FMGPU_SEL_EXACT_ON_TREE | FMGPU_SEL_EXACT_ONE_SYMBOL | FMGPU_SEL_LOCATE_PER_LANE | FMGPU_SEL_NO_SHARING | FMGPU_SEL_NO_EXACT_LUT | FMGPU_SEL_NO_BOARD | FMGPU_SEL_LEAN_FORMAT_A | FMGPU_SEL_NO_LEAN)
 int         fmgpu_set_option(int32_t option, int64_t value);
 int         fmgpu_get_option(int32_t option, int64_t* value);
 

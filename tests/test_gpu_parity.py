@@ -1051,6 +1051,17 @@ def test_edit_distance_on_a_repeat_structured_text():
     finally:
         del fm.options["kernel_select"]
     assert same_hits(hits2, ohits) and st2.lf_steps == nodes
+    # ... and between the WAVES of the launch (the board, csrc/fmgpu_search_shared.h): 6 000 reads leave most of the chip's waves without reads of their own — they wait at the
+    # board and take subtrees of the heavy reads; switched off, and on the plain index (no LF table: the PLAIN instantiation), the records are the same
+    with fm.options(kernel_select=capi.SEL_NO_BOARD):
+        hits5, st5 = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 24)
+    assert same_hits(hits5, ohits) and st5.lf_steps == nodes
+    with fm.options(lf_table=0):
+        px = gpu_index(ox)
+    for sel in (0, capi.SEL_NO_BOARD):
+        with fm.options(kernel_select=sel):
+            hits6, st6 = fm.search_ng26.search(px, (qbuf, qoff), sch, want_stats=True, edit=True, capacity=1 << 24)
+        assert same_hits(hits6, ohits) and st6.lf_steps == nodes
     assert same_hits(fm.search_ng26.search(gx, (qbuf, qoff), sch, n=3, edit=True), ox.search_ng26(qbuf, qoff, sch, max_hits=3, edit=True)[0])
     # the general kernels (ragged batches, other layouts, 64-bit rows) share work at the end of the batch, with the same keys; search_ng21 too
     hh, _, hnodes = ox.search_ng26(qbuf, qoff, sch, cap=1 << 24)
