@@ -1757,6 +1757,7 @@ constexpr uint32_t kLeanShareHeavy = 64;           // nodes a lane spends on a r
 constexpr uint32_t kLeanSuperRows = kWide ? 64u : 1u;   // super-block rows per direction staged in LDS (64 x 2^30 rows: more than HBM holds)
 constexpr uint32_t kLeanNoResume = 7u;
 constexpr int kLeanWaves = 4;            // resident blocks per CU the register allocation allows (the grid asks for 3: the loop is bound by the L1 access rate, not by latency)
+constexpr uint64_t kLeanBoardReads = ~0ull;   // batches of at most this many reads run the BOARD instantiation of the lean kernel
 constexpr int kLeanSteps = 4;            // node steps per pass through the wave-synchronous part (genome text, kernel ms at 101 / 151 bp: 1 step 119 / 213, 2: 114 / 195, 4: 112 / 183; round 4, 8 steps for 101 bp on Format D: 99.3 against ~96 ms)
 
 struct LeanArgs {
@@ -1863,10 +1864,11 @@ __device__ __forceinline__ void ring_flush(lds_u32* s_cnt_w, const uint32_t* rin
 constexpr uint32_t kDenseFilterBits = 32768;      // block number mod this: 25 delimiter rows mark 0.08 % of the blocks, ~7 % of the iterations of a wave meet one
 // LUT: searches may start from the prefix table (la.lut): an instantiation of its own, so that the kernel of the plain index carries none of it (with the start
 // path compiled into the one kernel the genome text went from 95.7 to 106.8 ms although no table was there to be used)
-template <int WAVES, int NSTEP, bool DENSE, bool LUT = false>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
+// BOARD: the waves of the launch share work too (the board, fmgpu_search_shared.h) — an instantiation of its own, taken for the batches whose end it shortens (launch_lean)
+template <int WAVES, int NSTEP, bool DENSE, bool LUT = false, bool BOARD = false>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
 __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
                                                              fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, ulonglong2* __restrict__ frames, uint64_t nlanes,
-                                                             uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste, uint32_t share_heavy) {
+                                                             uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste, uint32_t share_heavy, WorkBoard* board) {
     extern __shared__ uint32_t s_dyn[];                             // [qwords][256] staged reads | [256] top frames (16 B) | [S][m + 1] steps | [4] ring fill | 4 x [kRingWords][kRingCap] rings
     __shared__ uint64_t s_sup[2u * kLeanSuperRows * 5u];            // 64-bit rows: the super tables of bwt and bwtRev
     __shared__ uint32_t s_filt[DENSE ? 2u * kDenseFilterBits / 32u : 1u];   // Format D: which blocks (mod kDenseFilterBits) may hold a delimiter row, per direction
@@ -1919,6 +1921,8 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     uint32_t q = 0, si = 0, e = 0, j = 0, sp = 0, sbase = 0, resume = kLeanNoResume;
     idx_t lb = 0, lbRev = 0, len = 0;
     uint32_t k1 = 0, k2 = 0;                                        // path key fields of the 1st / 2nd substitution on the lane's path: (m - step) << 8 | symbol, 0 = none (key_with / key_prefix)
+    [[maybe_unused]] uint32_t pass = 0, board_heavy = 0, board_period = 1;
+    if constexpr (BOARD) { board_enter(board, lane); board_heavy = board->heavy; board_period = board->period; }
     // Order of the top-frame slot's accesses.  The slot is refilled by an LDS-DMA load issued at the END of an iteration (after a pop); every other
     // access of the slot in the node phase (push, pop) comes after the lane has consumed its block loads of that iteration, which were issued after the
     // DMA: vector-memory operations of a wave complete in order, so the DMA has landed.  The one access outside the node phase (handing the only
@@ -1969,6 +1973,33 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 }
             }
         }
+        if constexpr (BOARD) {
+            // ... and with the other waves of the launch: every board_period-th pass a wave with subtrees to give looks whether a wave waits for work, and hands it the bottom
+            // frames of ALL its offering lanes.  (A lane that gave inside the wave in this pass is no candidate — its mark is fresh —, so the slot read here was refilled a pass ago.)
+            if ((++pass % board_period) == 0u) {
+                const bool cand = have && sp > sbase && nodes - mark >= kShareNodes && nodes - nodes0 >= board_heavy;
+                const uint64_t cm = __ballot(cand);
+                uint32_t bslot = 0, bidx = 0;
+                if (cm && board_reserve(board, lane, &bslot, &bidx)) {
+                    if (cand) {
+                        asm volatile("" ::: "memory");
+                        const u32x4 t = *bos_slot;
+                        const uint32_t fe = lean_frame_errors((uint64_t)t.z | ((uint64_t)t.w << 32));
+                        ++sbase; mark = nodes;
+                        if (sp > sbase) {                           // the new bottom frame, straight into the slot
+                            uint32_t g = gid; asm volatile("" : "+v"(g));
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(frames + ((uint64_t)sbase * nlanes + g)),
+                                                             (__attribute__((address_space(3))) void*)(s_bos + wave * 64u), 16, 0, 0);
+                        }
+                        const uint32_t r = (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
+                        const uint32_t w[8] = {t.x, t.y, t.z, t.w, fe >= 1u ? k1 : 0u, fe >= 2u ? k2 : 0u, q, si};
+#pragma unroll
+                        for (uint32_t d_ = 0; d_ < 8u; ++d_) board_put(board, bslot, d_, r, w[d_]);
+                    }
+                    board_publish(board, lane, bslot, bidx, (uint32_t)__popcll(cm));
+                }
+            }
+        }
         STAMP(st_share);
         {
             const uint64_t needm = __ballot(!have && !exhausted), busym = __ballot(have);
@@ -1993,7 +2024,30 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
             const uint32_t filled = __hip_atomic_load(s_cnt_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             const uint64_t busy = __ballot(have);
             if (filled >= kRingFlush || (!busy && filled)) ring_flush(s_cnt_w, ring, lane, out, cap, ctr);
-            if (!busy) { if (__ballot(!exhausted) == 0ull) break; continue; }
+            if (!busy) {
+                if (__ballot(!exhausted) != 0ull) continue;
+                if constexpr (!BOARD) break;
+                else {
+                    // the wave is out of work and the batch is handed out: it waits for subtrees of the reads other waves still walk, or for the end of the launch
+                    uint32_t bslot = 0;
+                    const uint32_t k = board_wait(board, lane, &bslot);
+                    if (k == 0u) break;
+                    const bool fresh = lane < k; uint64_t qo = 0;
+                    if (fresh) {
+                        uint32_t w[8];
+#pragma unroll
+                        for (uint32_t d_ = 0; d_ < 8u; ++d_) w[d_] = board_word(board, bslot, d_, lane);
+                        lean_unpack((uint64_t)w[0] | ((uint64_t)w[1] << 32), (uint64_t)w[2] | ((uint64_t)w[3] << 32), lb, lbRev, len, j, e, resume);
+                        k1 = w[4]; k2 = w[5]; q = w[6]; si = w[7];
+                        qo = qoff[q];
+                        have = true; is_task = true; need_start = false; sp = 0; sbase = 0; in_tail = false; mark = nodes; nodes0 = nodes;
+                    }
+                    const bool ok = stage2_sync(s_dyn, qbuf, qo, m, fresh);
+                    if (fresh) odd = !ok;
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                    continue;
+                }
+            }
         }
         STAMP(st_sync);
 #pragma unroll 1
@@ -2560,15 +2614,15 @@ static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uin
     if (const char* ev = dev_env("FMGPU_DEV_LEAN_HEAVY")) heavy = (uint32_t)std::max(0, atoi(ev));
     if (const char* ev = dev_env("FMGPU_DEV_LEAN_STEPS")) steps = atoi(ev);
     auto launch = [&](auto kern) { kern<<<g, dim3(256), lds, stream>>>(la, dq, doff, count, n, dout, capacity, ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes,
-                                                                    (m + 15) / 16, qm, waste, heavy); };
+                                                                    (m + 15) / 16, qm, waste, heavy, ws.board); };
 #ifdef FMGPU_DEV
     if (steps == 1) launch(k_scheme_lean<kLeanWaves, 1, false>); else if (steps == 2) launch(k_scheme_lean<kLeanWaves, 2, false>); else if (steps == 8) launch(k_scheme_lean<kLeanWaves, 8, false>); else
 #endif
     if constexpr (!kWide) {
         if (la.lut) { if (dense) launch(k_scheme_lean<kLeanWaves, kLeanSteps, true, true>); else launch(k_scheme_lean<kLeanWaves, kLeanSteps, false, true>); return; }
-        if (dense) { launch(k_scheme_lean<kLeanWaves, kLeanSteps, true>); return; }
+        if (dense) { if (ws.board) launch(k_scheme_lean<kLeanWaves, kLeanSteps, true, false, true>); else launch(k_scheme_lean<kLeanWaves, kLeanSteps, true>); return; }
     }
-    launch(k_scheme_lean<kLeanWaves, kLeanSteps, false>);
+    if (ws.board) launch(k_scheme_lean<kLeanWaves, kLeanSteps, false, false, true>); else launch(k_scheme_lean<kLeanWaves, kLeanSteps, false>);
 }
 
 static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme,
@@ -2814,7 +2868,15 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
     bool with_board = false;
 #if !FMGPU_WIDE
     with_board = fast && edit && sharing && !(kernel_flags() & FMGPU_SEL_NO_BOARD);
+    const bool lean_any = lean;
+#else
+    const bool lean_any = lean_wide;
 #endif
+    {   // the lean kernel: its BOARD instantiation for the batches whose end it shortens (kLeanBoardReads)
+        uint64_t lim = kLeanBoardReads;
+        if (const char* ev = dev_env("FMGPU_DEV_LEAN_BOARD_READS")) lim = (uint64_t)atoll(ev);
+        if (lean_any && nq <= lim && !(kernel_flags() & FMGPU_SEL_NO_BOARD)) with_board = true;
+    }
     if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3, with_board))) return rc;
     const dim3 grid(ws.grid);
 #if !FMGPU_WIDE
@@ -2838,6 +2900,7 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
 #if FMGPU_WIDE
     if (lean_wide) {
         FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));
+        if ((rc = ws.reset_board(stream))) return rc;
         launch_lean(x, d_steps, (uint32_t)sd.S, maxlen, wide_tab.size(), grid, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, nq, (fmgpu_hit*)sout.dev, capacity, ws, d_qmap, stream);
     } else
 #endif

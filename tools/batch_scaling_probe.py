@@ -13,6 +13,8 @@ lengths = list(bench.GRCH38_LENGTHS)
 text, _ = datasets.genome_like_text(lengths, seed=42, device=dev)
 seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64))])).to(dev)
 fm.options["lf_table"] = 0
+if os.environ.get("PROBE_NO_BOARD"):
+    fm.options["kernel_select"] = capi.SEL_NO_BOARD
 gx = fm.BiFMIndex.from_sequences((_V(text), _V(seq_off)), 5, "IB16", 16)
 c = bench.Ctx(); c.torch, c.dev = torch, dev
 qb, qo = bench.sample_reads(c, text, lengths, 101, 10_000_000, 2017 + 17 * 101, "k2")
@@ -21,6 +23,8 @@ out = torch.empty(400_000_000 * 6, dtype=torch.int64, device=dev)       # room f
 modes = ((1, (125_000, 250_000, 500_000, 1_000_000, 2_000_000)), (0, (500_000, 1_000_000, 2_000_000, 5_000_000, 10_000_000)))
 if os.environ.get("PROBE_EDIT_ONLY"):
     modes = modes[:1]
+if os.environ.get("PROBE_HAMMING_ONLY"):
+    modes = modes[1:]
 for edit, sizes in modes:
     sc, keep = bench._scheme_struct(capi, fm.search_scheme.h2(4, 0, 2))
     sc.edit = edit
