@@ -285,23 +285,22 @@ __device__ __forceinline__ uint32_t flat_rank_lds(const lds_word* own, uint32_t 
 }
 // the super table in LDS: 32-bit rows as they are; 64-bit rows as a low word + a high byte per entry (5 instead of 8 bytes: sigma = 28, 4.5 x 10^9 rows: 19 KB,
 // four resident blocks per CU; read through L2 instead the kernel took 13 % longer on the same text)
-// Every workgroup stages its own copy, so a large table costs residency: 42 KB (sigma = 28, 10^10 rows) beside the 16.6 KB of four waves' regions leaves two 256-lane workgroups per CU —
-// 8 waves where the kernel wants 16 and more.  The kernel is therefore instantiated for workgroups of 256, 512 and 1024 lanes (4 / 8 / 16 waves share one copy; a CU has 160 KB of LDS and
-// one workgroup may take all of it), and the launch takes the size that keeps the most waves resident: 10^10 rows: two workgroups of 512 lanes = 16 waves per CU.
+// Every workgroup stages its own copy of the table, beside the 33 KB of four waves' regions: 6.7 KB at 2 x 10^9 rows, 19 KB at 4.5 x 10^9, 42 KB at 10^10 (sigma = 28) — three, three and
+// two 256-lane workgroups per CU.  The kernel is instantiated for workgroups of 256 and 512 lanes (a CU has 160 KB of LDS and one workgroup may take all of it); the launch takes the size
+// that keeps the most waves resident (more than 16 gain nothing: they queue up at the memory system), and on a tie the LARGER one — half as many copies of the table are staged and held.
+// Measured, 10 M x 40 aa, kernel ms with 256 / 512 lanes: 2.0 x 10^9 rows 7.98 / 7.53 (16 / 16 waves); 4.5 x 10^9 rows 7.95 / 8.38 (12 / 8); 10^10 rows 9.72 / 9.11 (8 / 8; the
+// table read through L2 instead, 16 waves: 9.85 — at that size the random lines miss the translation caches, and residency is not what bounds the kernel).
 constexpr size_t kLdsPerCu = 160 * 1024;
-constexpr size_t kFlatSuperLdsMax = 88 * 1024;      // (with the 66 KB of sixteen waves' regions: one workgroup of 1024 lanes per CU; sigma = 28: 2.1 x 10^10 rows)
+constexpr size_t kFlatSuperLdsMax = 88 * 1024;      // (with the 66.6 KB of eight waves' regions: one workgroup of 512 lanes per CU; sigma = 28: 2.1 x 10^10 rows)
 __host__ __device__ constexpr size_t flat_super_lds_bytes(uint32_t entries) { return kWide ? ((size_t)entries * 5u + 15u) / 16u * 16u : (size_t)entries * 4u; }
 __host__ constexpr size_t flat_lds_bytes(uint32_t block, uint32_t super_entries) { return (size_t)(block / 64u) * 8u * (1024u + 16u) + 16u + flat_super_lds_bytes(super_entries); }
-// lanes per workgroup: the smallest workgroup that keeps 16 waves resident on a CU (the kernel's 74 registers allow 24; more than 16 gain nothing — they queue up at the memory
-// system), else the one that keeps the most.  Measured, 10 M x 40 aa, kernel ms with 256 / 512 / 1024 lanes: 2.0 x 10^9 rows (6.7 KB table) 7.98 / 7.53 / 7.66; 4.5 x 10^9 rows (19 KB)
-// 7.95 / 8.38 / 8.02; 10^10 rows (42 KB: 8 / 16 / 16 resident waves) 8.85 / 8.62 / 8.86
 inline uint32_t flat_block_lanes(uint32_t super_entries) {
     uint32_t best = 256, best_waves = 0;
-    for (uint32_t blk : {256u, 512u, 1024u}) {
+    for (uint32_t blk : {256u, 512u}) {
         const size_t lds = flat_lds_bytes(blk, super_entries);
         if (lds > kLdsPerCu) continue;
         const uint32_t waves = (uint32_t)std::min<size_t>(16u, (kLdsPerCu / lds) * (blk / 64u));
-        if (waves > best_waves) { best_waves = waves; best = blk; }
+        if (waves >= best_waves) { best_waves = waves; best = blk; }
     }
     return best;
 }
@@ -708,9 +707,11 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
         else k_exact_a<0><<<grid, block, lds_a, stream>>>(OccA<0>{x->bwt.va}, qb, qo, nq, n, ol, on, dsteps);
     } else if (x->bwt.flat && x->bwt.search_family() != FAM_A && !(kernel_flags() & (1 << 21))) {
         const uint32_t entries = x->bwt.flat_nsb * (uint32_t)x->bwt.sigma;
-        const uint32_t super_lds = flat_super_lds_bytes(entries) <= kFlatSuperLdsMax ? entries : 0u;      // (sigma = 28: 6.7 KB at 2 x 10^9 rows, 19 KB at 4.5 x 10^9, 42 KB at 10^10)
+        size_t lds_max = kFlatSuperLdsMax;
+        if (const char* ev = dev_env("FMGPU_DEV_FLAT_SUPER_MAX")) lds_max = (size_t)atoll(ev);      // (dev knob: 0 = the super table is read through L2)
+        const uint32_t super_lds = flat_super_lds_bytes(entries) <= lds_max ? entries : 0u;      // (sigma = 28: 6.7 KB at 2 x 10^9 rows, 19 KB at 4.5 x 10^9, 42 KB at 10^10)
         uint32_t lanes = flat_block_lanes(super_lds);
-        if (const char* ev = dev_env("FMGPU_DEV_FLAT_LANES")) { const uint32_t v = (uint32_t)atoi(ev); if ((v == 256 || v == 512 || v == 1024) && flat_lds_bytes(v, super_lds) <= kLdsPerCu) lanes = v; }     // (dev knob)
+        if (const char* ev = dev_env("FMGPU_DEV_FLAT_LANES")) { const uint32_t v = (uint32_t)atoi(ev); if ((v == 256 || v == 512) && flat_lds_bytes(v, super_lds) <= kLdsPerCu) lanes = v; }     // (dev knob)
         const size_t lds = flat_lds_bytes(lanes, super_lds) + dev_extra_lds;
         auto launch = [&](auto kernel) -> int {
             if (lds > 64 * 1024) FM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     // (more than a launch gets without asking)
@@ -720,7 +721,7 @@ static int search_exact(fmgpu_index_t h, const uint8_t* qbuf, const uint64_t* qo
                                                      (const uint64_t*)soff.dev, nq, n, (uint64_t*)slb.dev, (uint64_t*)slen.dev, dsteps, super_lds);
             return 0;
         };
-        if ((rc = lanes == 256 ? launch(k_exact_s<256>) : lanes == 512 ? launch(k_exact_s<512>) : launch(k_exact_s<1024>))) return rc;
+        if ((rc = lanes == 256 ? launch(k_exact_s<256>) : launch(k_exact_s<512>))) return rc;
     } else if (x->bwt.search_family() == FAM_WAVELET) {
         uint32_t mx = shape_max, mn = 0;
         if (!have_shape && (rc = query_len_range((const uint64_t*)soff.dev, nq, stream, &mx, &mn))) return rc;

@@ -6,7 +6,7 @@ RND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 RECORDS = {"genome/exact/plain": ("exact_plain", "k_exact_p"), "genome/exact/single": ("exact_single", "k_exact_a"), "genome/exact/tables": ("exact_tables", "k_exact_kstep"),
            "genome/k2/plain": ("k2_plain", "k_scheme_lean"), "genome/k2_151/plain": ("k2_151_plain", "k_scheme_lean"), "genome/k2/tables": ("k2_tables", "k_scheme_fast"),
            "genome/locate/plain": ("locate_plain", "k_locate_coop" if RND >= "r04" else "k_locate_fused"), "genome/exact/plain+lut12": ("exact_lut12", "k_exact_p"),
-           "protein/exact/wavelet": ("protein_wavelet", "k_exact_s"), "protein/exact/tree": ("protein_tree", "k_exact_m"), "protein_wide/exact/wavelet": ("protein_wide", "k_exact_s"),
+           "protein/exact/wavelet": ("protein_wavelet", "k_exact_s"), "protein/exact/tree": ("protein_tree", "k_exact_m"), "protein_wide/exact/wavelet": ("protein_wide", "k_exact_s"), "protein_xl/exact/wavelet": ("protein_xl", "k_exact_s"),
            "genome/k2_edit/tables": ("edit_genome", "k_scheme_fast_edit"), "genome/k2_edit/plain": ("edit_plain", "k_scheme_fast_edit"), "uniform/k2_edit/tables": ("edit_uniform", "k_scheme_fast_edit")}
 out = {}
 for rid, (tag, kernel) in RECORDS.items():
