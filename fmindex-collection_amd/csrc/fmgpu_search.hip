@@ -2535,7 +2535,9 @@ struct DfsWorkspace {
         if (const char* e = dev_env("FMGPU_DEV_BOARD_HEAVY")) cfg[0] = (uint32_t)atoi(e);
         if (const char* e = dev_env("FMGPU_DEV_BOARD_PERIOD")) cfg[1] = (uint32_t)std::max(1, atoi(e));
         if (const char* e = dev_env("FMGPU_DEV_BOARD_WAITERS")) cfg[2] = (uint32_t)std::max(1, atoi(e));
-        FM_HIP(hipMemcpyAsync(&board->heavy, cfg, 12, hipMemcpyHostToDevice, stream));
+        FM_HIP(hipMemsetD32Async((hipDeviceptr_t)&board->heavy, (int)cfg[0], 1, stream));      // (fills, not copies: no host buffer has to outlive the call)
+        FM_HIP(hipMemsetD32Async((hipDeviceptr_t)&board->period, (int)cfg[1], 1, stream));
+        FM_HIP(hipMemsetD32Async((hipDeviceptr_t)&board->waiters, (int)cfg[2], 1, stream));
         return 0;
     }
     // after the launch has been synchronised: a waiting wave that gave up means results may be missing
