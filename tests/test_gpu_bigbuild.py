@@ -149,3 +149,46 @@ def test_repeat_structured_text_through_the_rank_array_sorter():
     with fm.options(bucket_rows=3_000_000, suffix_sorter=2):
         gx = fm.BiFMIndex.from_sequences(seqs, 5, "IB16", 16, keep_host=True)
     assert _same(_built(gx, True), want)
+
+
+def test_beyond_2_32_rows_both_ways():
+    """FMIndex<28, Wavelet> over 4.5e9 residues (9 M sequences; 64-bit rows at their real size), built by the all-at-once sorter and bucket by bucket with the inverse suffix array as
+    rank array: the same device bytes, the same intervals for 1 M reads cut from the text (every tenth with a substitution: not found), and — the check that found the launch of 2^32
+    threads cut short — every located row spells its read within 15 LF steps of a sampled entry"""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    dev = torch.device("cuda", 0)
+    nseq, slen, sigma, L, nq = 9_000_000, 500, 28, 40, 1_000_000
+    g = torch.Generator(device=dev); g.manual_seed(42)
+    text = torch.empty(nseq * slen, dtype=torch.uint8, device=dev)
+    for lo in range(0, text.numel(), 1 << 28):
+        hi = min(text.numel(), lo + (1 << 28))
+        text[lo:hi] = torch.randint(1, sigma, (hi - lo,), generator=g, device=dev, dtype=torch.uint8)
+    seq_off = torch.arange(nseq + 1, device=dev, dtype=torch.int64) * slen
+    starts = torch.randint(0, nseq, (nq,), generator=g, device=dev, dtype=torch.int64) * slen + torch.randint(0, slen - L + 1, (nq,), generator=g, device=dev, dtype=torch.int64)
+    reads = text[starts[:, None] + torch.arange(L, device=dev)[None, :]].contiguous()
+    bad = torch.arange(0, nq, 10, device=dev)
+    reads[bad, 7] = reads[bad, 7] % (sigma - 1) + 1
+    qoff = torch.arange(nq + 1, device=dev, dtype=torch.int64) * L
+
+    class V:
+        def __init__(self, t): self.t, self.ptr, self.nbytes = t, t.data_ptr(), t.numel() * t.element_size()
+    seen = []
+    for sorter in (1, 2):
+        with fm.options(suffix_sorter=sorter, lf_table=0):
+            gx = fm.FMIndex.from_sequences((V(text), V(seq_off)), sigma, "WAVELET", 16)
+        assert gx.row_bits == 64 and gx.n == nseq * (slen + 1)
+        out = torch.empty(2 * nq, dtype=torch.int64, device=dev)
+        capi.check(capi.lib().fmgpu_search_exact(gx._h, C.c_void_p(reads.data_ptr()), C.c_void_p(qoff.data_ptr()), nq, C.c_void_p(out[:nq].data_ptr()), C.c_void_p(out[nq:].data_ptr()), None, None))
+        found = out[nq:] > 0
+        assert int(found.sum().item()) == nq - bad.numel() and not bool(found[bad].any().item())
+        rows = out[:nq][found][:100_000].contiguous(); k = rows.numel()
+        loc = torch.empty(3 * k, dtype=torch.int64, device=dev)
+        capi.check(capi.lib().fmgpu_locate(gx._h, C.c_void_p(rows.data_ptr()), k, C.c_void_p(loc[:k].data_ptr()), C.c_void_p(loc[k:2 * k].data_ptr()), C.c_void_p(loc[2 * k:].data_ptr()), None, None))
+        at = loc[:k] * slen + loc[k:2 * k] + loc[2 * k:]
+        assert bool(torch.equal(text[at[:, None] + torch.arange(L, device=dev)[None, :]], reads[found][:100_000]))
+        assert int(loc[2 * k:].max().item()) < 16
+        seen.append((gx.device_bytes, out.clone(), loc.clone()))
+        gx.close(); del gx, out, loc
+        torch.cuda.empty_cache()
+    assert seen[0][0] == seen[1][0] and torch.equal(seen[0][1], seen[1][1]) and torch.equal(seen[0][2], seen[1][2])

@@ -265,6 +265,9 @@ def test_options_are_set_through_the_abi_not_the_environment(monkeypatch):
     v = C.c_int64()
     assert L.fmgpu_set_option(99, 1) == capi.FMGPU_ERR_INVALID and L.fmgpu_get_option(-1, C.byref(v)) == capi.FMGPU_ERR_INVALID and L.fmgpu_get_option(0, None) == capi.FMGPU_ERR_INVALID
     assert L.fmgpu_set_option(capi.OPTIONS["kernel_select"], 1) == capi.FMGPU_ERR_INVALID and b"FMGPU_SEL_ALL" in L.fmgpu_last_error()      # (bit 0 — count only — exists in development builds alone)
+    assert L.fmgpu_set_option(capi.OPTIONS["suffix_sorter"], 4) == capi.FMGPU_ERR_INVALID and L.fmgpu_set_option(capi.OPTIONS["suffix_sorter"], -1) == capi.FMGPU_ERR_INVALID
+    assert L.fmgpu_set_option(capi.OPTIONS["bucket_rows"], -5) == capi.FMGPU_ERR_INVALID
+    assert L.fmgpu_set_option(capi.OPTIONS["kernel_select"], capi.SEL_NO_BOARD) == 0 and L.fmgpu_set_option(capi.OPTIONS["kernel_select"], 0) == 0
     src = "".join(open(os.path.join(ROOT, "fmindex-collection_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "fmindex-collection_amd", "csrc")) if f.endswith((".hip", ".h")))
     import re
     outside_dev = re.sub(r"#ifdef FMGPU_DEV\b.*?#e(?:lse|ndif)", "", src, flags=re.S)
