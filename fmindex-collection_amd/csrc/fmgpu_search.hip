@@ -1496,9 +1496,9 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 if (__ballot(!exhausted) != 0ull) continue;
                 if (!board) break;
                 // the wave is out of work and the batch is handed out: it waits for subtrees of the reads other waves still walk, or for the end of the launch
-                uint32_t bslot = 0;
+                uint32_t bslot = 0, bidx = 0;
                 [[maybe_unused]] const unsigned long long t0_ = BSTAMP();
-                const uint32_t k = board_wait(board, lane, &bslot);
+                const uint32_t k = board_wait(board, lane, &bslot, &bidx);
 #ifdef FMGPU_DEV
                 bt_wait += BSTAMP() - t0_; ++bn_wait;
 #endif
@@ -1519,6 +1519,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                     tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; lf_known = false; report_slot = kNoResume; mark = nodes; nodes0 = nodes;
                     tos_dirty = false;
                 }
+                board_release(board, lane, bslot, bidx);
                 qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 continue;
@@ -2029,8 +2030,8 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 if constexpr (!BOARD) break;
                 else {
                     // the wave is out of work and the batch is handed out: it waits for subtrees of the reads other waves still walk, or for the end of the launch
-                    uint32_t bslot = 0;
-                    const uint32_t k = board_wait(board, lane, &bslot);
+                    uint32_t bslot = 0, bidx = 0;
+                    const uint32_t k = board_wait(board, lane, &bslot, &bidx);
                     if (k == 0u) break;
                     const bool fresh = lane < k; uint64_t qo = 0;
                     if (fresh) {
@@ -2042,6 +2043,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                         qo = qoff[q];
                         have = true; is_task = true; need_start = false; sp = 0; sbase = 0; in_tail = false; mark = nodes; nodes0 = nodes;
                     }
+                    board_release(board, lane, bslot, bidx);
                     const bool ok = stage2_sync(s_dyn, qbuf, qo, m, fresh);
                     if (fresh) odd = !ok;
                     __builtin_amdgcn_s_waitcnt(0x0f70);

@@ -273,7 +273,8 @@ struct WorkBoard {
     unsigned long long pad0[4];
     unsigned long long ht;                    // (a line of its own) high 32 bits: batches asked for; low 32: batches published (never more than asked for)
     unsigned long long pad1[15];
-    unsigned long long hdr[kBoardBatches][8]; // [.][0]: (index + 1) << 8 | tasks of the batch with that index, written last; 64 bytes apart: the waiting waves' polls spread over the memory channels
+    unsigned long long hdr[kBoardBatches][8]; // [.][0]: (index + 1) << 8 | tasks of the batch with that index, written last by its giver; (index + 1) << 8 | 0xff once its taker has read it;
+                                              // 64 bytes apart: the waiting waves' polls spread over the memory channels
     uint32_t task[kBoardBatches][kBoardWords][64];
 };
 constexpr size_t kBoardResetBytes = 256 + sizeof(unsigned long long) * 8 * kBoardBatches;     // what a launch starts from zero
@@ -292,7 +293,7 @@ __device__ __forceinline__ void board_enter(WorkBoard* b, uint32_t lane) {
     asm volatile("s_waitcnt vmcnt(0)" :: "v"((uint32_t)old) : "memory");
 }
 // a wave without work, the batch handed out: returns the number of tasks of the batch it was given (their dwords at task[*slot][.][0 .. k - 1]), or 0 = the launch is over
-__device__ __forceinline__ uint32_t board_wait(WorkBoard* b, uint32_t lane, uint32_t* slot) {
+__device__ __forceinline__ uint32_t board_wait(WorkBoard* b, uint32_t lane, uint32_t* slot, uint32_t* index) {
     unsigned long long asked = 0; uint32_t stay = 0;
     if (lane == 0) {
         atomicAdd(&b->state, ~0ull);
@@ -302,7 +303,7 @@ __device__ __forceinline__ uint32_t board_wait(WorkBoard* b, uint32_t lane, uint
     }
     if (!__shfl(stay, 0, 64)) return 0;
     const uint32_t idx = (uint32_t)wave_bcast64(asked, 0);
-    *slot = idx % kBoardBatches;
+    *slot = idx % kBoardBatches; *index = idx;
     for (uint32_t spin = 0;; ++spin) {
         unsigned long long h = 0, st = 1;
         if (lane == 0) {
@@ -341,7 +342,22 @@ __device__ __forceinline__ bool board_reserve(WorkBoard* b, uint32_t lane, uint3
     ok = __shfl(ok, 0, 64);
     *index = (uint32_t)wave_bcast64(v, 0);
     *slot = *index % kBoardBatches;
+    if (ok && lane == 0) {
+        // the slot is this batch's once the batch that used it a ring earlier has been TAKEN (its taker says so in the header).  Normally long past: a wave between its reservation and
+        // its header spends microseconds, a ring is thousands of reservations — but a wave can be held up (two processes on one card), and a batch written over an untaken one would
+        // lose subtrees silently.  The wait is for another wave's progress, never for this one's.
+        const unsigned long long free_mark = *index >= kBoardBatches ? (((unsigned long long)(*index - kBoardBatches + 1u) << 8) | 0xffull) : 0ull;
+        for (uint32_t spin = 0; __hip_atomic_load(&b->hdr[*slot][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != free_mark; ++spin) {
+            if (spin == kBoardSpinCap) { atomicAdd(&b->failed, 1ull); break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
     return ok != 0;
+}
+// a taker, after its lanes have read their tasks: the slot may be written again
+__device__ __forceinline__ void board_release(WorkBoard* b, uint32_t lane, uint32_t slot, uint32_t index) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&b->hdr[slot][0], ((unsigned long long)(index + 1u) << 8) | 0xffull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void board_put(WorkBoard* b, uint32_t slot, uint32_t word, uint32_t task, uint32_t value) {      // a giver's lane: one dword of its task, written through
     __hip_atomic_store(&b->task[slot][word][task], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
