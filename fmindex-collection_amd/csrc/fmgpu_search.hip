@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
     const uint32_t INS = 2u * sigma - 1u;
     if (board) board_enter(board, lane);                            // (work sharing between the waves of the launch: fmgpu_search_shared.h)
     uint32_t pass = 0;
-    const uint32_t board_heavy = board ? board->heavy : 0u, board_period = board ? board->period : 1u;
+    const uint32_t board_heavy = board ? board->heavy : 0u, board_period = board ? board->period - 1u : 0u;      // (the period is a power of two: its mask)
 #ifdef FMGPU_DEV
     unsigned long long bt_wait = 0, bt_give = 0, bt_look = 0, bn_wait = 0, bn_give = 0, bn_look = 0; const unsigned long long bt_start = __builtin_amdgcn_s_memtime();
 #define BSTAMP() __builtin_amdgcn_s_memtime()
@@ -1444,7 +1444,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
         }
         // ---- ... and with the other waves of the launch: every kBoardPeriod-th pass a wave with subtrees to give looks whether a wave waits for work, and hands it the bottom
         // frames of ALL its offering lanes (the same frames, keys and thresholds as above; the taker stages the reads itself)
-        if (board && (++pass % board_period) == 0u) {
+        if (board && (++pass & board_period) == 0u) {
             const bool cand = have && sp > sbase && nodes - mark >= share_nodes && nodes - nodes0 >= board_heavy && report_slot != sbase;
             const uint64_t cm = __ballot(cand);
             uint32_t bslot = 0, bidx = 0;
@@ -1923,7 +1923,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
     idx_t lb = 0, lbRev = 0, len = 0;
     uint32_t k1 = 0, k2 = 0;                                        // path key fields of the 1st / 2nd substitution on the lane's path: (m - step) << 8 | symbol, 0 = none (key_with / key_prefix)
     [[maybe_unused]] uint32_t pass = 0, board_heavy = 0, board_period = 1;
-    if constexpr (BOARD) { board_enter(board, lane); board_heavy = board->heavy; board_period = board->period; }
+    if constexpr (BOARD) { board_enter(board, lane); board_heavy = board->heavy; board_period = board->period - 1u; }      // (the period is a power of two: its mask)
     // Order of the top-frame slot's accesses.  The slot is refilled by an LDS-DMA load issued at the END of an iteration (after a pop); every other
     // access of the slot in the node phase (push, pop) comes after the lane has consumed its block loads of that iteration, which were issued after the
     // DMA: vector-memory operations of a wave complete in order, so the DMA has landed.  The one access outside the node phase (handing the only
@@ -1977,7 +1977,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
         if constexpr (BOARD) {
             // ... and with the other waves of the launch: every board_period-th pass a wave with subtrees to give looks whether a wave waits for work, and hands it the bottom
             // frames of ALL its offering lanes.  (A lane that gave inside the wave in this pass is no candidate — its mark is fresh —, so the slot read here was refilled a pass ago.)
-            if ((++pass % board_period) == 0u) {
+            if ((++pass & board_period) == 0u) {
                 const bool cand = have && sp > sbase && nodes - mark >= kShareNodes && nodes - nodes0 >= board_heavy;
                 const uint64_t cm = __ballot(cand);
                 uint32_t bslot = 0, bidx = 0;
@@ -2535,7 +2535,7 @@ struct DfsWorkspace {
         FM_HIP(hipMemsetAsync(board, 0, kBoardResetBytes, stream));
         uint32_t cfg[3] = {kBoardHeavy, kBoardPeriod, kBoardWaiters};
         if (const char* e = dev_env("FMGPU_DEV_BOARD_HEAVY")) cfg[0] = (uint32_t)atoi(e);
-        if (const char* e = dev_env("FMGPU_DEV_BOARD_PERIOD")) cfg[1] = (uint32_t)std::max(1, atoi(e));
+        if (const char* e = dev_env("FMGPU_DEV_BOARD_PERIOD")) { cfg[1] = 1; while (cfg[1] * 2 <= (uint32_t)std::max(1, atoi(e))) cfg[1] *= 2; }      // (a power of two: the kernels test pass & (period - 1))
         if (const char* e = dev_env("FMGPU_DEV_BOARD_WAITERS")) cfg[2] = (uint32_t)std::max(1, atoi(e));
         FM_HIP(hipMemsetD32Async((hipDeviceptr_t)&board->heavy, (int)cfg[0], 1, stream));      // (fills, not copies: no host buffer has to outlive the call)
         FM_HIP(hipMemsetD32Async((hipDeviceptr_t)&board->period, (int)cfg[1], 1, stream));
