@@ -1401,6 +1401,17 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
         if (__ballot(tos_pending)) { __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); }
         tos_pending = false;
     };
+    // a lane takes over a subtree (a frame handed over inside the wave, or through the board): the frame's node becomes the lane's, as a task of its own
+    auto adopt = [&](const uint4& t0, const uint4& t1, uint64_t key) {
+        const bool one_row = (t0.w >> 24) & 1u;
+        cur.lb = t0.x; cur.lbRev = t0.y; cur.len = one_row ? 1u : t0.z; cached_lf2 = one_row ? t0.z : 0xffffffffu;
+        j = t0.w & 0xffffu; e = (t0.w >> 16) & 0xffu; info = (t0.w >> 25) & 15u;
+        resume = t1.x; side = t1.y; cached_lf = t1.z; ndel = t1.w;
+        pkey = key;
+        have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
+        tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; lf_known = false; report_slot = kNoResume; mark = nodes; nodes0 = nodes;
+        tos_dirty = false;
+    };
     for (;;) {
         // ---- wave-synchronous part: every lane passes here in every iteration
         if (sharing) {
@@ -1429,16 +1440,9 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 const uint32_t tsi = __shfl(si, vl, 64);
                 if (take) {
                     q = tq_; si = tsi; qs = reinterpret_cast<const uint8_t*>(tqs);
-                    const bool one_row = (t0.w >> 24) & 1u;
-                    cur.lb = t0.x; cur.lbRev = t0.y; cur.len = one_row ? 1u : t0.z; cached_lf2 = one_row ? t0.z : 0xffffffffu;
-                    j = t0.w & 0xffffu; e = (t0.w >> 16) & 0xffu; info = (t0.w >> 25) & 15u;
-                    resume = t1.x; side = t1.y; cached_lf = t1.z; ndel = t1.w;
-                    pkey = tk;
+                    adopt(t0, t1, tk);
                     const uint32_t vt = (threadIdx.x & ~63u) | (uint32_t)vl;
                     for (uint32_t w = 0; w < qwords; ++w) s_dyn[w * 256u + threadIdx.x] = s_dyn[w * 256u + vt];     // the partner's staged read
-                    have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
-                    tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; lf_known = false; report_slot = kNoResume; mark = nodes; nodes0 = nodes;
-                    tos_dirty = false;
                 }
             }
         }
@@ -1510,14 +1514,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                     for (uint32_t d_ = 0; d_ < kBoardWords; ++d_) w[d_] = board_word(board, bslot, d_, lane);
                     q = (uint64_t)w[10] | ((uint64_t)w[11] << 32); si = w[12];
                     qo = qoff[q]; qs = qbuf + qo;
-                    const bool one_row = (w[3] >> 24) & 1u;
-                    cur.lb = w[0]; cur.lbRev = w[1]; cur.len = one_row ? 1u : w[2]; cached_lf2 = one_row ? w[2] : 0xffffffffu;
-                    j = w[3] & 0xffffu; e = (w[3] >> 16) & 0xffu; info = (w[3] >> 25) & 15u;
-                    resume = w[4]; side = w[5]; cached_lf = w[6]; ndel = w[7];
-                    pkey = (uint64_t)w[8] | ((uint64_t)w[9] << 32);
-                    have = true; is_task = true; need_start = false; query_over = false; quota = max_hits; seq = 0;
-                    tab = s_steps + si * stride; sp = 0; sbase = 0; in_tail = false; lf_known = false; report_slot = kNoResume; mark = nodes; nodes0 = nodes;
-                    tos_dirty = false;
+                    adopt(make_uint4(w[0], w[1], w[2], w[3]), make_uint4(w[4], w[5], w[6], w[7]), (uint64_t)w[8] | ((uint64_t)w[9] << 32));
                 }
                 board_release(board, lane, bslot, bidx);
                 qstage_load_sync(qst, qbuf, qo, m, sigma, fresh, m);
