@@ -1659,6 +1659,9 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                     if (j < m && (((tab[j] >> 16) & 1u) != (right ? 1u : 0u))) { lf_known = false; report_slot = kNoResume; }   // the other index from here on
                 }
             }
+            // (Tried and dropped, round 4: a one-row node that is popped for its next child taking that child in the SAME iteration — its LF comes with the frame, nothing is loaded; such
+            // re-visits are 16 % of the lane-iterations on the genome text.  Parity held; genome text 112.9 -> 119.2 ms per 2 M reads (with tables 103.5 -> 114.1), uniform text 49.9 -> 49.0:
+            // the child selection a second time in every iteration of the wave costs more than the iterations it saves)
             if (!back && j == m) {                                  // search_next at part == P (:101-108)
                 const uint32_t fin = tab[m];
                 const uint32_t li = info & 3u, ri = (info >> 2) & 3u;
