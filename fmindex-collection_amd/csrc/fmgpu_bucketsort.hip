@@ -2,17 +2,21 @@
 //
 // The sorter of fmgpu_build.hip (radix sort of every suffix's K-symbol prefix, prefix doubling on the ties) holds the text, the suffix array, the rank array, two key
 // buffers and a value buffer: 30 bytes per row with 32-bit suffix indices, 42 with 64-bit ones — ~6 x 10^9 rows in 288 GB.  The reference switches to libsais64 there
-// (utils.h:243-247) and has the host's memory to do it in.  What construction needs of the suffix array is its ORDER, once, front to back: bwt[i] = text[sa[i] - 1]
-// (utils.h:145-163) and the sampled entries (FMIndex.h:79-101).  So this sorter never holds the array: it cuts the suffixes into buckets by their first symbols
-// (a bucket = a range of rows), sorts one bucket at a time and hands its rows to the caller, in row order:
+// (utils.h:243-247) and has the host's memory to do it in.  What construction needs of the suffix array is its ORDER, once: bwt[i] = text[sa[i] - 1] (utils.h:145-163)
+// and the sampled entries (FMIndex.h:79-101).  The two sorters here never hold the array.  Both cut the suffixes into buckets by their first symbols (a bucket = a range of
+// rows of the final order) and sort one bucket at a time:
 //   1. one pass over the text counts the suffixes per bin (the top kBinBits bits of the packed K-symbol key); the host cuts the bins into buckets of <= bucket_rows rows;
-//   2. per bucket: a pass over the text collects (key, position) of its suffixes; one radix sort orders them by their K-symbol prefix;
-//   3. ties only: rows whose K-prefix is shared are compacted and re-sorted by (group, the next symbols of the suffix) — as many symbols as fit 64 bits beside the
-//      dense group number — until every group is a single row.  Not doubling (there is no rank array to double with): a repeat of length L costs L / symbols-per-round
-//      rounds over ITS rows, which is nothing for a protein database or a text without long exact repeats, and would be hours for megabase runs of one symbol —
-//      the work is bounded (kMaxRefineWork passes over a bucket's rows) and such a text is refused with an error instead (the doubling sorter handles it, up to its size);
-//   4. the bucket's positions, now in suffix order, go to the caller's sink (BWT symbols, sampled suffix array entries).
-// Memory: the text + ~40 bytes per row of ONE bucket (+ the tie buffers), whatever n is.
+//   2. per bucket: a pass over the text collects (key, position) of its suffixes; one radix sort orders them by their K-symbol prefix; a flag pass finds the groups of equal prefixes.
+// sort_suffixes_isa (FMGPU_OPT_SUFFIX_SORTER 2, the default beyond the all-at-once sorter's size) then doubles: every suffix gets the first row of its group as rank[position], the
+// rows of groups of two and more join ONE list of tied rows, and rounds with step h = K, 2K, 4K ... sort that list by (group, rank[position + h]) until it is empty — rank is the
+// inverse suffix array then, and the caller writes the BWT and the sampled entries from it.  Memory: the text, 4 / 8 bytes per row of rank array, one bucket, ~60 bytes per tied row.
+// sort_suffixes_bucketed (sorter 3, where even the rank array does not fit) holds NO array of n entries: it breaks a bucket's ties by reading further symbols of the text —
+//   3. rows whose K-prefix is shared are compacted and re-sorted by (group, the next symbols of the suffix) — as many symbols as fit 64 bits beside the dense group number —
+//      until every group is a single row.  Not doubling: a repeat of length L costs L / symbols-per-round rounds over ITS rows, which is nothing for a protein database or a
+//      text without long exact repeats, and would be hours for megabase runs of one symbol — the work is bounded (kMaxRefineWork passes over a bucket's rows) and such a text is
+//      refused with an error instead;
+//   4. the bucket's positions, now in suffix order, go to the caller's sink (BWT symbols, sampled suffix array entries) —
+// the text + ~40 bytes per row of ONE bucket (+ the tie buffers), whatever n is.
 #include "fmgpu_common.h"
 
 #include <hipcub/hipcub.hpp>
