@@ -260,7 +260,8 @@ constexpr uint32_t kBoardPeriod = 8;          // passes of a working wave betwee
 constexpr uint32_t kBoardHeavy = 256;         // nodes a lane must have spent on its read (or subtree) before it gives to another WAVE.  Measured on the genome text, k = 2 edit distance,
                                               // kernel ms for 125 k / 1 M / 2 M reads (development build; without the board 85 / 110 / 147): heavy 8192: 92 / 101 / 124, 2048: 44 / 79 / 127,
                                               // 512: 30 / 78 / 123, 256 and 64: 25 / 77 / 121 (period 4-8; period 64: 55 / 90 / 135)
-constexpr uint32_t kBoardSpinCap = 1u << 21;  // a waiting wave gives up after this many polls (~30 s) and flags the launch as failed: a bug must not hang the card
+constexpr uint32_t kBoardSpinCap = 1u << 21;  // polls (~30 s) of a waiting wave per give-up period: after eight periods in which NO wave published a batch it leaves and flags the launch as
+                                              // failed — a bug must not hang the card, and a long healthy launch must not be failed
 constexpr uint32_t kBoardWaiters = 1024;      // waves that wait at the board at most: a poll is a read of memory (sc1), and 4096 waves polling every 3 us took the channels their headers
                                               // live on — a giver's compare-and-swap on the same pages then took milliseconds (tools/board_sweep.sh); the other idle waves leave
 struct WorkBoard {
@@ -304,6 +305,7 @@ __device__ __forceinline__ uint32_t board_wait(WorkBoard* b, uint32_t lane, uint
     if (!__shfl(stay, 0, 64)) return 0;
     const uint32_t idx = (uint32_t)wave_bcast64(asked, 0);
     *slot = idx % kBoardBatches; *index = idx;
+    uint32_t quiet = 0, seen_published = 0;                        // (lane 0) give-up bookkeeping: periods of kBoardSpinCap polls in which no wave published anything
     for (uint32_t spin = 0;; ++spin) {
         unsigned long long h = 0, st = 1;
         if (lane == 0) {
@@ -311,7 +313,12 @@ __device__ __forceinline__ uint32_t board_wait(WorkBoard* b, uint32_t lane, uint
             // then takes every block from L2)
             h = __hip_atomic_load(&b->hdr[*slot][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((spin & 7u) == 7u) st = __hip_atomic_load(&b->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (spin == kBoardSpinCap) { atomicAdd(&b->failed, 1ull); st = 0; }
+            if (spin == kBoardSpinCap) {                            // ~30 s of waiting: a long launch whose waves still publish is healthy; eight such periods without ANY batch published are not
+                const uint32_t pub = (uint32_t)__hip_atomic_load(&b->ht, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pub != seen_published) { seen_published = pub; quiet = 0; } else ++quiet;
+                spin = 0;
+                if (quiet == 8u) { atomicAdd(&b->failed, 1ull); st = 0; }
+            }
         }
         h = wave_bcast64(h, 0); st = wave_bcast64(st, 0);
         if ((h >> 8) == (unsigned long long)idx + 1ull) {
