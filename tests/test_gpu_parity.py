@@ -2173,6 +2173,17 @@ def test_full_size_k2_records_equal_the_cpu_walk():
             assert st.lf_steps == onodes, (tag, L, st.lf_steps, onodes)
             assert same_hits(hits, oh), (tag, L)
     check("plain index")
+    # The same batches again and again, in slices small enough that most waves of the chip wait at the board (work sharing between the waves of a launch) in every
+    # launch, Hamming and edit distance, with the board and without: always the same records (a lost or doubled subtree would change their number; a waiting wave that gave up is an error)
+    for L, (hq, ho) in batches.items():
+        for edit in (False, True):
+            nq_s = 30_000 if edit else 100_000
+            sl = (hq[: nq_s * L], ho[: nq_s + 1])
+            with fm.options(kernel_select=capi.SEL_NO_BOARD):
+                ref_hits, ref_st = fm.search_ng26.search(gx, sl, sch, want_stats=True, edit=edit, capacity=1 << 23)
+            for _ in range(12):
+                h, st = fm.search_ng26.search(gx, sl, sch, want_stats=True, edit=edit, capacity=1 << 23)
+                assert st.lf_steps == ref_st.lf_steps and same_hits(h, ref_hits), (L, edit)
     # An anchor that does not pass through the GPU-built BWT the oracle was fed: every read was cut from the TEXT at a known offset with <= 2
     # substitutions, so that offset must be among the located positions of its e <= 2 hits (reads that straddle two sequences, and the few
     # reads of high-copy repeats whose hits cover more than 4096 rows, are left out)
