@@ -100,6 +100,8 @@ void CallScratch::drop() {
     if (pinned) (void)hipHostFree(pinned);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
+    for (hipStream_t st : dfs_streams) if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : dfs_events) if (ev) (void)hipEventDestroy(ev);
     *this = CallScratch{};
 }
 struct ScratchSet {

@@ -203,7 +203,9 @@ struct CallScratch {
     void* frames = nullptr; size_t frames_bytes = 0;              // frame stacks of the DFS kernels, kept between calls up to kFrameCache bytes
     void* dfs_ctr = nullptr;                                      // their Counters (a DFS call synchronises before it returns: one at a time per thread)
     void* order = nullptr; size_t order_bytes = 0;                // hand-out order of a batch and the workspace that makes it (heavy reads first), kept between calls
-    void* board = nullptr;                                        // the work board of the depth-first kernels (sharing between the waves of a launch), made on first use
+    void* board = nullptr; uint32_t board_slots = 0;              // the work boards of the depth-first kernels (sharing between the waves of a launch), made on first use: one per concurrent launch
+    hipStream_t dfs_streams[8] = {};                              // a ragged batch: the launches of its read lengths run side by side on these (made on first use)
+    hipEvent_t dfs_events[9] = {};
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     void drop();
 };

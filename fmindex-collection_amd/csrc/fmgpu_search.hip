@@ -896,7 +896,7 @@ template <int SIGMA, int MAXSIG, bool PLAIN>
 __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
-                                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, int sharing, int use_key) {
+                                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, int sharing, int use_key, unsigned long long* next_ctr) {
     // One flat loop per lane over (query, search, node) with every slow path wave-synchronous.  A wave pays for every slow path any of its 64
     // lanes takes, so nothing with a dependent memory round trip is lane-private: queries are fetched and staged TOGETHER — as soon as
     // kRefillLanes lanes of the wave are out of work (one atomicAdd per refill, query words issued back to back) — and hits are kept in LDS
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(256, SIGMA == 5 ? 5 : 1) void k_scheme_fast(OccA<SI
             waste = 0;
             const bool want = !have && !exhausted;
             bool fresh = false; uint64_t qo = 0;
-            const uint64_t got = wave_hand_out(want, ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
+            const uint64_t got = wave_hand_out_at(want, next_ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
             if (want) {
                 if (got >= nq) exhausted = true;
                 else {
@@ -1339,7 +1339,7 @@ template <int SIGMA, int MAXSIG, bool PLAIN = false>      // PLAIN: sigma = 5 an
 __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<SIGMA> rv, FastArgs fa, const uint8_t* __restrict__ qbuf,
                                                           const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n, uint64_t max_hits,
                                                           fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, StackView stk,
-                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, int sharing, int use_key, WorkBoard* board) {
+                                                          uint32_t qwords, uint32_t qnib, int dev_flags, const uint32_t* __restrict__ qmap, int sharing, int use_key, WorkBoard* board, unsigned long long* next_ctr) {
     extern __shared__ uint32_t s_dyn[];
     uint32_t* s_steps = s_dyn + (size_t)qwords * 256u;
     const uint32_t S = fa.S, m = fa.m, stride = fa.m + 1;
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
             waste = 0;
             const bool want = !have && !exhausted;
             bool fresh = false; uint64_t qo = 0;
-            const uint64_t got = wave_hand_out(want, ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
+            const uint64_t got = wave_hand_out_at(want, next_ctr, lane);    // nq = queries of this launch; qmap (if any) names them within the batch
             if (want) {
                 if (got >= nq) exhausted = true;
                 else {
@@ -1869,7 +1869,7 @@ constexpr uint32_t kDenseFilterBits = 32768;      // block number mod this: 25 d
 template <int WAVES, int NSTEP, bool DENSE, bool LUT = false, bool BOARD = false>      // WAVES: waves per SIMD the register allocation must allow (= resident 256-lane blocks per CU)
 __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const uint8_t* __restrict__ qbuf, const uint64_t* __restrict__ qoff, uint64_t nq, idx_t n,
                                                              fmgpu_hit* __restrict__ out, uint64_t cap, Counters* ctr, ulonglong2* __restrict__ frames, uint64_t nlanes,
-                                                             uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste, uint32_t share_heavy, WorkBoard* board) {
+                                                             uint32_t qwords, const uint32_t* __restrict__ qmap, uint32_t refill_waste, uint32_t share_heavy, WorkBoard* board, unsigned long long* next_ctr) {
     extern __shared__ uint32_t s_dyn[];                             // [qwords][256] staged reads | [256] top frames (16 B) | [S][m + 1] steps | [4] ring fill | 4 x [kRingWords][kRingCap] rings
     __shared__ uint64_t s_sup[2u * kLeanSuperRows * 5u];            // 64-bit rows: the super tables of bwt and bwtRev
     __shared__ uint32_t s_filt[DENSE ? 2u * kDenseFilterBits / 32u : 1u];   // Format D: which blocks (mod kDenseFilterBits) may hold a delimiter row, per direction
@@ -2009,7 +2009,7 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 waste = 0;
                 const bool want = !have && !exhausted;
                 bool fresh = false; uint64_t qo = 0;
-                const uint64_t got = wave_hand_out(want, ctr, lane);
+                const uint64_t got = wave_hand_out_at(want, next_ctr, lane);
                 if (want) {
                     if (got >= nq) exhausted = true;
                     else { q = qmap ? qmap[got] : (uint32_t)got; qo = qoff[q]; fresh = true; have = true; is_task = false; si = 0; need_start = true; mark = nodes; nodes0 = nodes; }
@@ -2489,6 +2489,7 @@ __global__ __launch_bounds__(256) void k_len_pairs(const uint64_t* __restrict__ 
 }
 
 constexpr size_t kFrameCache = (size_t)2 << 30;
+constexpr uint32_t kDfsSlots = 8;            // launches of a ragged batch that run side by side at most (CallScratch holds that many streams)
 struct DfsWorkspace {
     uint64_t* planes = nullptr; Counters* ctr = nullptr; StackView view{};
     unsigned grid = 0;
@@ -2498,15 +2499,22 @@ struct DfsWorkspace {
     // The frame stacks (~1 GB for a full-chip launch over 101-symbol reads) stay with the calling host thread between calls: allocating and
     // freeing them per call costs ~0.2 ms (hipFree synchronises the device), 2-3 % of a 10 M-read k = 2 call.
     WorkBoard* board = nullptr;                                    // (with_board) sharing between the waves of a launch
+    // slots > 1 (a ragged batch: one launch per read length): that many launches run side by side, each on a stream, a share of the grid, a stretch of the frame stacks, a hand-out counter
+    // and a board of its own — `grid` is then ONE launch's grid, `view` the first launch's stretch
+    uint32_t slots = 1;
+    CallScratch* scratch = nullptr;
+    size_t slot_bytes = 0;                                         // bytes of the frame stacks per concurrent launch
     // with_board: every resident block is launched however small the batch — a block without reads of its own waits at the board for subtrees of the heavy reads
-    int init(uint32_t depth, uint64_t nq, int blocks_per_cu, hipStream_t stream, int nplanes = 3, bool with_board = false) {
+    int init(uint32_t depth, uint64_t nq, int blocks_per_cu, hipStream_t stream, int nplanes = 3, bool with_board = false, uint32_t want_slots = 1) {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         uint64_t want = (uint64_t)cus * (uint64_t)std::max(1, std::min(8, blocks_per_cu));
+        slots = std::max(1u, std::min(kDfsSlots, want_slots));
+        if (slots > 1) want = std::max<uint64_t>(1, want / slots);
         grid = (unsigned)std::max<uint64_t>(1, with_board ? want : std::min<uint64_t>(want, (nq + 255) / 256));
         view.nlanes = (uint64_t)grid * 256; view.depth = depth;
-        uint64_t words = view.nlanes * ((uint64_t)depth + 1);
+        uint64_t words = view.nlanes * ((uint64_t)depth + 1) * slots;
         const size_t need = words * 8 * (size_t)nplanes;
         CallScratch* sc = nullptr;
         int rc = call_scratch(&sc); if (rc) return rc;
@@ -2522,16 +2530,48 @@ struct DfsWorkspace {
             own_planes = true;
         }
         view.p0 = planes; view.p1 = planes + words; view.p2 = planes + 2 * words; view.p3 = nplanes > 3 ? planes + 3 * words : nullptr;
+        slot_bytes = (need / slots) & ~(size_t)15;
+        scratch = sc;
         ctr = (Counters*)sc->dfs_ctr;
         FM_HIP(hipMemsetAsync(ctr, 0, 256, stream));                         // next: the query hand-out counter of the scheme kernels (+ a debug area)
         if (with_board) {
-            if (!sc->board) FM_HIP(hipMalloc(&sc->board, sizeof(WorkBoard)));
+            if (sc->board_slots < slots) {
+                if (sc->board) { (void)hipFree(sc->board); sc->board = nullptr; sc->board_slots = 0; }
+                FM_HIP(hipMalloc(&sc->board, sizeof(WorkBoard) * slots));
+                sc->board_slots = slots;
+            }
             board = (WorkBoard*)sc->board;
+        }
+        if (slots > 1) {
+            for (uint32_t k = 0; k < slots; ++k) if (!sc->dfs_streams[k]) FM_HIP(hipStreamCreateWithFlags(&sc->dfs_streams[k], hipStreamNonBlocking));
+            for (uint32_t k = 0; k <= slots; ++k) if (!sc->dfs_events[k]) FM_HIP(hipEventCreateWithFlags(&sc->dfs_events[k], hipEventDisableTiming));
         }
         return 0;
     }
-    int reset_board(hipStream_t stream) {                          // before every launch that uses it
+    // what the k-th concurrent launch works with
+    hipStream_t stream_of(uint32_t k, hipStream_t caller) const { return slots > 1 ? scratch->dfs_streams[k] : caller; }
+    unsigned long long* next_of(uint32_t k) const { return slots > 1 ? reinterpret_cast<unsigned long long*>(ctr) + 24 + k : &ctr->next; }      // (the hand-out counters of side-by-side launches: words 24..31 of the counter area)
+    WorkBoard* board_of(uint32_t k) const { return board ? board + (slots > 1 ? k : 0) : nullptr; }
+    StackView view_of(uint32_t k) const {                          // (the fast kernels address their frames from p0 alone: a stretch of the whole area per launch)
+        StackView v = view;
+        v.p0 = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(planes) + (size_t)k * slot_bytes);
+        return v;
+    }
+    // side-by-side launches start after everything the caller's stream holds, and the caller's stream goes on after all of them
+    int fork(hipStream_t caller) {
+        if (slots <= 1) return 0;
+        FM_HIP(hipEventRecord(scratch->dfs_events[slots], caller));
+        for (uint32_t k = 0; k < slots; ++k) FM_HIP(hipStreamWaitEvent(scratch->dfs_streams[k], scratch->dfs_events[slots], 0));
+        return 0;
+    }
+    int join(hipStream_t caller) {
+        if (slots <= 1) return 0;
+        for (uint32_t k = 0; k < slots; ++k) { FM_HIP(hipEventRecord(scratch->dfs_events[k], scratch->dfs_streams[k])); FM_HIP(hipStreamWaitEvent(caller, scratch->dfs_events[k], 0)); }
+        return 0;
+    }
+    int reset_board(hipStream_t stream, uint32_t k = 0) {          // before every launch that uses it (k: which of the side-by-side launches)
         if (!board) return 0;
+        WorkBoard* const board = board_of(k);
         FM_HIP(hipMemsetAsync(board, 0, kBoardResetBytes, stream));
         uint32_t cfg[3] = {kBoardHeavy, kBoardPeriod, kBoardWaiters};
         if (const char* e = dev_env("FMGPU_DEV_BOARD_HEAVY")) cfg[0] = (uint32_t)atoi(e);
@@ -2546,7 +2586,7 @@ struct DfsWorkspace {
     int check_board() {
         if (!board) return 0;
         unsigned long long f = 0;
-        FM_HIP(hipMemcpy(&f, &board->failed, 8, hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < slots; ++k) { unsigned long long fk = 0; FM_HIP(hipMemcpy(&fk, &board_of(k)->failed, 8, hipMemcpyDeviceToHost)); f += fk; }
         if (dev_env("FMGPU_DEV_BOARD_LOG")) {                        // (development build: what went over the board in the last launch)
             unsigned long long v[2] = {0, 0}, t = 0;
             (void)hipMemcpy(&v[0], &board->ht, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&t, &board->tasks, 8, hipMemcpyDeviceToHost);
@@ -2605,7 +2645,7 @@ static size_t lean_lds_bytes(uint32_t m, size_t step_words) {
     return (size_t)((m + 15) / 16) * 1024 + 8192 + step_words * 4 + 16 + (size_t)4 * kRingWords * kRingCap * 4;      // staged reads | top and bottom frame slots | steps | ring fill | rings
 }
 static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uint32_t m, size_t step_words, dim3 g, const uint8_t* dq, const uint64_t* doff, uint64_t count,
-                        fmgpu_hit* dout, uint64_t capacity, const DfsWorkspace& ws, const uint32_t* qm, hipStream_t stream, uint32_t lut_ok = 0) {
+                        fmgpu_hit* dout, uint64_t capacity, const DfsWorkspace& ws, const uint32_t* qm, hipStream_t stream, uint32_t lut_ok = 0, uint32_t slot = 0) {
     const idx_t n = (idx_t)x->bwt.n;
     const bool dense = x->bwt.dense && x->rev.dense && !(kernel_flags() & (1 << 29));      // (bit 29 of FMGPU_DEV_FLAGS: read Format A although Format D exists)
     LeanArgs la{x->bwt.va.blk, x->rev.va.blk, d_steps, S, m, (idx_t)(x->hC[1] + x->hC[2] + x->hC[3] + x->hC[4]), x->bwt.va.super, x->rev.va.super,
@@ -2617,16 +2657,17 @@ static void launch_lean(const Index* x, const uint32_t* d_steps, uint32_t S, uin
     if (const char* ev = dev_env("FMGPU_DEV_LEAN_WASTE")) waste = (uint32_t)std::max(1, atoi(ev));
     if (const char* ev = dev_env("FMGPU_DEV_LEAN_HEAVY")) heavy = (uint32_t)std::max(0, atoi(ev));
     if (const char* ev = dev_env("FMGPU_DEV_LEAN_STEPS")) steps = atoi(ev);
-    auto launch = [&](auto kern) { kern<<<g, dim3(256), lds, stream>>>(la, dq, doff, count, n, dout, capacity, ws.ctr, reinterpret_cast<ulonglong2*>(ws.view.p0), ws.view.nlanes,
-                                                                    (m + 15) / 16, qm, waste, heavy, ws.board); };
+    WorkBoard* const board = ws.board_of(slot);
+    auto launch = [&](auto kern) { kern<<<g, dim3(256), lds, stream>>>(la, dq, doff, count, n, dout, capacity, ws.ctr, reinterpret_cast<ulonglong2*>(ws.view_of(slot).p0), ws.view.nlanes,
+                                                                    (m + 15) / 16, qm, waste, heavy, board, ws.next_of(slot)); };
 #ifdef FMGPU_DEV
     if (steps == 1) launch(k_scheme_lean<kLeanWaves, 1, false>); else if (steps == 2) launch(k_scheme_lean<kLeanWaves, 2, false>); else if (steps == 8) launch(k_scheme_lean<kLeanWaves, 8, false>); else
 #endif
     if constexpr (!kWide) {
         if (la.lut) { if (dense) launch(k_scheme_lean<kLeanWaves, kLeanSteps, true, true>); else launch(k_scheme_lean<kLeanWaves, kLeanSteps, false, true>); return; }
-        if (dense) { if (ws.board) launch(k_scheme_lean<kLeanWaves, kLeanSteps, true, false, true>); else launch(k_scheme_lean<kLeanWaves, kLeanSteps, true>); return; }
+        if (dense) { if (board) launch(k_scheme_lean<kLeanWaves, kLeanSteps, true, false, true>); else launch(k_scheme_lean<kLeanWaves, kLeanSteps, true>); return; }
     }
-    if (ws.board) launch(k_scheme_lean<kLeanWaves, kLeanSteps, false, false, true>); else launch(k_scheme_lean<kLeanWaves, kLeanSteps, false>);
+    if (board) launch(k_scheme_lean<kLeanWaves, kLeanSteps, false, false, true>); else launch(k_scheme_lean<kLeanWaves, kLeanSteps, false>);
 }
 
 static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64_t* qoff, uint64_t nq, const fmgpu_scheme* scheme,
@@ -2881,7 +2922,16 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
         if (const char* ev = dev_env("FMGPU_DEV_LEAN_BOARD_READS")) lim = (uint64_t)atoll(ev);
         if (lean_any && nq <= lim && !(kernel_flags() & FMGPU_SEL_NO_BOARD)) with_board = true;
     }
-    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3, with_board))) return rc;
+    // a ragged batch through the equal-length kernels is one launch per read length: up to four of them run side by side (each on a quarter of the grid), so that the end of one
+    // launch — the waves that hold its heaviest reads — overlaps the bulk of the next ones
+    uint32_t dfs_slots = 1;
+#if !FMGPU_WIDE
+    if (fast && buckets.size() > 1 && !(kernel_flags() & FMGPU_SEL_NO_BOARD)) {
+        dfs_slots = (uint32_t)std::min<size_t>(kDfsSlots, buckets.size());
+        if (const char* ev = dev_env("FMGPU_DEV_DFS_SLOTS")) dfs_slots = (uint32_t)std::max(1, std::min((int)kDfsSlots, atoi(ev)));
+    }
+#endif
+    if ((rc = ws.init(edit ? maxlen + max_u + 2 : maxlen, nq, bpc, stream, edit ? kEditFramePlanes : 3, with_board, dfs_slots))) return rc;
     const dim3 grid(ws.grid);
 #if !FMGPU_WIDE
     size_t steps_words = 0;
@@ -2911,7 +2961,13 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
 #if !FMGPU_WIDE
     if (fast) {
         size_t at = 0;
+        if ((rc = ws.fork(stream))) return rc;
+        uint32_t turn = 0;
         for (const Bucket& b : buckets) {
+            const uint32_t slot = turn++ % ws.slots;                // (one launch after the other per slot: its stream orders them)
+            hipStream_t lstream = ws.stream_of(slot, stream);
+            const StackView lview = ws.view_of(slot);
+            unsigned long long* const lnext = ws.next_of(slot);
             FastArgs fa{};
             if (have_lf) { fa.lf_fw = x->bwt.lf_table; fa.lf_rv = x->rev.lf_table; }
             fa.steps = d_steps + at; fa.S = (uint32_t)sd.S; fa.m = b.m;
@@ -2922,30 +2978,31 @@ static int run_dfs(Index* x, bool scheme_mode, const uint8_t* qbuf, const uint64
             for (int k = 1; k < x->bwt.sigma && k <= 8; ++k) fa.C1[k - 1] = (idx_t)x->hC[k];
             const size_t lds_fast = lds_bytes + b.tab.size() * 4 + (size_t)kWaveHitWords * 4 + (edit ? 2 * 256 * 16 + 16 : 0);     // (edit distance: + the top frames of the stacks)
             const dim3 g((unsigned)std::max<uint64_t>(1, with_board ? (uint64_t)ws.grid : std::min<uint64_t>(ws.grid, (b.count + 255) / 256)));
-            FM_HIP(hipMemsetAsync(&ws.ctr->next, 0, 8, stream));   // reads are handed out from 0
-            if ((rc = ws.reset_board(stream))) return rc;
+            FM_HIP(hipMemsetAsync(lnext, 0, 8, lstream));          // reads are handed out from 0
+            if ((rc = ws.reset_board(lstream, slot))) return rc;
             const uint32_t* qm = d_qmap ? d_qmap + b.first : nullptr;
             if (edit) {
                 if (x->bwt.sigma == 5) {
-                    if (!have_lf) k_scheme_fast_edit<5, 5, true><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key, ws.board);
-                    else k_scheme_fast_edit<5, 5><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key, ws.board);
+                    if (!have_lf) k_scheme_fast_edit<5, 5, true><<<g, block, lds_fast, lstream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, lview, qwords, qnib, sd.dev_flags, qm, sharing, use_key, ws.board_of(slot), lnext);
+                    else k_scheme_fast_edit<5, 5><<<g, block, lds_fast, lstream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                             b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, lview, qwords, qnib, sd.dev_flags, qm, sharing, use_key, ws.board_of(slot), lnext);
                 } else
-                    k_scheme_fast_edit<0, 32><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                              b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key, ws.board);
+                    k_scheme_fast_edit<0, 32><<<g, block, lds_fast, lstream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                              b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, lview, qwords, qnib, sd.dev_flags, qm, sharing, use_key, ws.board_of(slot), lnext);
             } else if (lean) {
-                launch_lean(x, fa.steps, (uint32_t)sd.S, b.m, b.tab.size() / 3, g, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (fmgpu_hit*)sout.dev, capacity, ws, qm, stream, b.lut_ok);
+                launch_lean(x, fa.steps, (uint32_t)sd.S, b.m, b.tab.size() / 3, g, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev, b.count, (fmgpu_hit*)sout.dev, capacity, ws, qm, lstream, b.lut_ok, slot);
             } else if (x->bwt.sigma == 5 && !have_lf)
-                k_scheme_fast<5, 5, true><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                          b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
+                k_scheme_fast<5, 5, true><<<g, block, lds_fast, lstream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                          b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, lview, qwords, qnib, sd.dev_flags, qm, sharing, use_key, lnext);
             else if (x->bwt.sigma == 5)
-                k_scheme_fast<5, 5, false><<<g, block, lds_fast, stream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                    b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
+                k_scheme_fast<5, 5, false><<<g, block, lds_fast, lstream>>>(OccA<5>{x->bwt.va}, OccA<5>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                    b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, lview, qwords, qnib, sd.dev_flags, qm, sharing, use_key, lnext);
             else
-                k_scheme_fast<0, 32, false><<<g, block, lds_fast, stream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
-                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, ws.view, qwords, qnib, sd.dev_flags, qm, sharing, use_key);
+                k_scheme_fast<0, 32, false><<<g, block, lds_fast, lstream>>>(OccA<0>{x->bwt.va}, OccA<0>{x->rev.va}, fa, (const uint8_t*)sbuf.dev, (const uint64_t*)soff.dev,
+                                                                     b.count, n, max_hits, (fmgpu_hit*)sout.dev, capacity, ws.ctr, lview, qwords, qnib, sd.dev_flags, qm, sharing, use_key, lnext);
         }
+        if ((rc = ws.join(stream))) return rc;
     } else
 #endif
     if (scheme_mode) {

@@ -400,15 +400,16 @@ constexpr uint32_t kWaveHitWords = kWaveHitBuf * kHitWords * 256u;   // per bloc
 constexpr uint32_t kWaveRingSlots = kWaveHitBuf * 64u - 1u;       // 127 records per wave
 constexpr uint32_t kWaveRingFlush = 64u;                          // written out once this many are waiting: 63 more fit (one per lane and iteration), a surplus goes out one by one
 
-__device__ __forceinline__ uint64_t wave_hand_out(bool want, Counters* ctr, uint32_t lane) {     // all lanes call; valid for lanes with `want`
+__device__ __forceinline__ uint64_t wave_hand_out_at(bool want, unsigned long long* next, uint32_t lane) {     // all lanes call; valid for lanes with `want`
     const uint64_t wm = __ballot(want);
     if (!wm) return 0;
     const uint32_t leader = (uint32_t)__ffsll((unsigned long long)wm) - 1u;
     unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(&ctr->next, (unsigned long long)__popcll(wm));
+    if (lane == leader) base = atomicAdd(next, (unsigned long long)__popcll(wm));
     base = ((unsigned long long)__shfl((uint32_t)(base >> 32), leader, 64) << 32) | __shfl((uint32_t)base, leader, 64);
     return base + (uint64_t)__popcll(wm & ((1ull << lane) - 1ull));
 }
+__device__ __forceinline__ uint64_t wave_hand_out(bool want, Counters* ctr, uint32_t lane) { return wave_hand_out_at(want, &ctr->next, lane); }
 __device__ __forceinline__ uint32_t* wave_ring(uint32_t* s_hb) { return s_hb + (threadIdx.x >> 6) * (kWaveHitBuf * kHitWords * 64u); }
 __device__ __forceinline__ void wave_ring_init(uint32_t* s_hb) {  // every wave, before its first record (LDS operations of one wave execute in order)
     if ((threadIdx.x & 63u) == 0) __hip_atomic_store((lds_word*)wave_ring(s_hb), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
