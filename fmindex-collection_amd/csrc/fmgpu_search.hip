@@ -1677,6 +1677,10 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
                 }
                 back = !search_over;
             }
+            // A lane that pops now and popped an iteration ago may not have loaded anything in between (a one-row node that knows its LF; a child that completes the read): nothing it
+            // consumed orders the refill of its slot before this read of it.  Tests passed without this wait for half a round; with the board keeping the memory system busy to the end of a
+            // launch, one run of the full-size edit test counted 82 nodes too many (a stale slot = a frame walked twice).
+            if (__ballot(back && sp > sbase && tos_pending)) settle();
             if (back) {
                 if (sp == sbase) search_over = true;
                 else {
@@ -1982,22 +1986,29 @@ __global__ __launch_bounds__(256, WAVES) void k_scheme_lean(LeanArgs la, const u
                 const uint64_t cm = __ballot(cand);
                 uint32_t bslot = 0, bidx = 0;
                 if (cm && board_reserve(board, lane, &bslot, &bidx)) {
-                    if (cand) {
-                        asm volatile("" ::: "memory");
-                        const u32x4 t = *bos_slot;
+                    // a batch holds 64 subtrees: few offering lanes give SEVERAL frames each, from the bottom of their stacks up (a heavy read walks down its match path and leaves a
+                    // frame of untried substitutions per symbol: given one per look, a hundred of them were a chain of a hundred looks)
+                    const uint32_t per = min(kBoardFramesPerLane, 64u / (uint32_t)__popcll(cm));
+                    const uint32_t mine = cand ? min(per, sp - sbase) : 0u;
+                    const uint32_t r0 = wave_excl_scan(mine, lane), total = __shfl(r0 + mine, 63, 64);
+                    for (uint32_t i = 0; i < mine; ++i) {
+                        u32x4 t;
+                        if (i == 0u) { asm volatile("" ::: "memory"); t = *bos_slot; }
+                        else t = *reinterpret_cast<const u32x4*>(frames + ((uint64_t)(sbase + i) * nlanes + gid));      // (pushes write through: the stack in HBM is complete)
                         const uint32_t fe = lean_frame_errors((uint64_t)t.z | ((uint64_t)t.w << 32));
-                        ++sbase; mark = nodes;
+                        const uint32_t w[8] = {t.x, t.y, t.z, t.w, fe >= 1u ? k1 : 0u, fe >= 2u ? k2 : 0u, q, si};
+#pragma unroll
+                        for (uint32_t d_ = 0; d_ < 8u; ++d_) board_put(board, bslot, d_, r0 + i, w[d_]);
+                    }
+                    if (mine) {
+                        sbase += mine; mark = nodes;
                         if (sp > sbase) {                           // the new bottom frame, straight into the slot
                             uint32_t g = gid; asm volatile("" : "+v"(g));
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(frames + ((uint64_t)sbase * nlanes + g)),
                                                              (__attribute__((address_space(3))) void*)(s_bos + wave * 64u), 16, 0, 0);
                         }
-                        const uint32_t r = (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
-                        const uint32_t w[8] = {t.x, t.y, t.z, t.w, fe >= 1u ? k1 : 0u, fe >= 2u ? k2 : 0u, q, si};
-#pragma unroll
-                        for (uint32_t d_ = 0; d_ < 8u; ++d_) board_put(board, bslot, d_, r, w[d_]);
                     }
-                    board_publish(board, lane, bslot, bidx, (uint32_t)__popcll(cm));
+                    board_publish(board, lane, bslot, bidx, total);
                 }
             }
         }

@@ -260,6 +260,7 @@ constexpr uint32_t kBoardPeriod = 8;          // passes of a working wave betwee
 constexpr uint32_t kBoardHeavy = 256;         // nodes a lane must have spent on its read (or subtree) before it gives to another WAVE.  Measured on the genome text, k = 2 edit distance,
                                               // kernel ms for 125 k / 1 M / 2 M reads (development build; without the board 85 / 110 / 147): heavy 8192: 92 / 101 / 124, 2048: 44 / 79 / 127,
                                               // 512: 30 / 78 / 123, 256 and 64: 25 / 77 / 121 (period 4-8; period 64: 55 / 90 / 135)
+constexpr uint32_t kBoardFramesPerLane = 8;  // frames one lane gives per hand-over at most (a batch holds 64 subtrees; few offering lanes fill it from the bottoms of their stacks)
 constexpr uint32_t kBoardSpinCap = 1u << 21;  // polls (~30 s) of a waiting wave per give-up period: after eight periods in which NO wave published a batch it leaves and flags the launch as
                                               // failed — a bug must not hang the card, and a long healthy launch must not be failed
 constexpr uint32_t kBoardWaiters = 1024;      // waves that wait at the board at most: a poll is a read of memory (sc1), and 4096 waves polling every 3 us took the channels their headers
