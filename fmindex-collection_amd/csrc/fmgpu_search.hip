@@ -1459,18 +1459,22 @@ __global__ __launch_bounds__(256) void k_scheme_fast_edit(OccA<SIGMA> fw, OccA<S
 #endif
             if (got_) {
                 if (__ballot(cand && sbase + 1u == sp)) settle();
-                if (cand) {
+                // a batch holds 64 subtrees: few offering lanes give SEVERAL frames each, from the bottom of their stacks up — the frames below the top are complete in HBM; the top
+                // frame (in its slot, possibly waiting for a child's LF) goes only when it is the lane's one frame, as inside the wave
+                const uint32_t per = min(kBoardFramesPerLane, 64u / (uint32_t)__popcll(cm));
+                const uint32_t mine = !cand ? 0u : (sbase + 1u == sp ? 1u : min(per, sp - 1u - sbase));
+                const uint32_t r0 = wave_excl_scan(mine, lane), total = __shfl(r0 + mine, 63, 64);
+                for (uint32_t i = 0; i < mine; ++i) {
                     uint4 g0, g1;
                     if (sbase + 1u == sp) { const e_u32x4 u0 = *tos0, u1 = *tos1; g0 = make_uint4(u0.x, u0.y, u0.z, u0.w); g1 = make_uint4(u1.x, u1.y, u1.z, u1.w); tos_dirty = false; }
-                    else { g0 = frames[2u * sbase]; g1 = frames[2u * sbase + 1u]; }
+                    else { g0 = frames[2u * (sbase + i)]; g1 = frames[2u * (sbase + i) + 1u]; }
                     const uint64_t gk = ekey_prefix(pkey, (g0.w >> 16) & 0xffu);
-                    ++sbase; mark = nodes;
-                    const uint32_t r = (uint32_t)__popcll(cm & ((1ull << lane) - 1ull));
                     const uint32_t w[kBoardWords] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, (uint32_t)gk, (uint32_t)(gk >> 32), (uint32_t)q, (uint32_t)(q >> 32), si, 0u};
 #pragma unroll
-                    for (uint32_t d_ = 0; d_ < kBoardWords; ++d_) board_put(board, bslot, d_, r, w[d_]);
+                    for (uint32_t d_ = 0; d_ < kBoardWords; ++d_) board_put(board, bslot, d_, r0 + i, w[d_]);
                 }
-                board_publish(board, lane, bslot, bidx, (uint32_t)__popcll(cm));
+                if (mine) { sbase += mine; mark = nodes; }
+                board_publish(board, lane, bslot, bidx, total);
 #ifdef FMGPU_DEV
                 bt_give += BSTAMP() - t0_; ++bn_give;
 #endif
