@@ -29,6 +29,7 @@ for edit, sizes in ((1, (20_000, 61_000, 125_000)), (0, (50_000, 200_000, 600_00
         capi.check(capi.lib().fmgpu_search_scheme(gx._h, C.c_void_p(qb.data_ptr()), C.c_void_p(qo.data_ptr()), nq, C.byref(sc), capi.UINT64_MAX, C.c_void_p(out.data_ptr()), 60_000_000,
                                                   C.byref(cnt), C.byref(st), None))
         got = (cnt.value, st.lf_steps)
+        assert (st.hits >> 48) == 0, ("development build: LDS frame slots that disagreed with the stack in HBM", st.hits >> 48)
         if nq not in want: want[nq] = got
         assert got == want[nq], (edit, nq, r, got, want[nq])
     print("%s: %d launches, records / nodes per batch size %s, %.1f s so far" % ("edit distance" if edit else "hamming", rounds, want, time.time() - t0), flush=True)
