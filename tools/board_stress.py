@@ -12,7 +12,7 @@ class _V:
 lengths = list(bench.GRCH38_LENGTHS)
 text, _ = datasets.genome_like_text(lengths, seed=42, device=dev)
 seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64))])).to(dev)
-fm.options["lf_table"] = 0
+fm.options["lf_table"] = int(os.environ.get("STRESS_LF_TABLE", "0"))      # 1: the table-driven instantiations (k_scheme_fast, k_scheme_fast_edit<5, 5>)
 gx = fm.BiFMIndex.from_sequences((_V(text), _V(seq_off)), 5, "IB16", 16)
 c = bench.Ctx(); c.torch, c.dev = torch, dev
 qb, qo = bench.sample_reads(c, text, lengths, 101, 600_000, 2017 + 17 * 101, "k2")
