@@ -2577,11 +2577,13 @@ struct DfsWorkspace {
         if (slots <= 1) return 0;
         FM_HIP(hipEventRecord(scratch->dfs_events[slots], caller));
         for (uint32_t k = 0; k < slots; ++k) FM_HIP(hipStreamWaitEvent(scratch->dfs_streams[k], scratch->dfs_events[slots], 0));
+        forked = true;
         return 0;
     }
     int join(hipStream_t caller) {
         if (slots <= 1) return 0;
         for (uint32_t k = 0; k < slots; ++k) { FM_HIP(hipEventRecord(scratch->dfs_events[k], scratch->dfs_streams[k])); FM_HIP(hipStreamWaitEvent(caller, scratch->dfs_events[k], 0)); }
+        forked = false;
         return 0;
     }
     int reset_board(hipStream_t stream, uint32_t k = 0) {          // before every launch that uses it (k: which of the side-by-side launches)
@@ -2614,7 +2616,11 @@ struct DfsWorkspace {
         }
         return f ? fail(FMGPU_ERR_HIP, "work sharing between waves: " + std::to_string(f) + " waiting wave(s) gave up") : 0;
     }
-    ~DfsWorkspace() { if (planes && own_planes) (void)hipFree(planes); }
+    bool forked = false;                                           // side-by-side launches are out and have not been joined
+    ~DfsWorkspace() {
+        if (forked) for (uint32_t k = 0; k < slots; ++k) (void)hipStreamSynchronize(scratch->dfs_streams[k]);      // (an error path left between fork and join: nothing of this call may outlive it)
+        if (planes && own_planes) (void)hipFree(planes);
+    }
 };
 
 // the hand-out order of a batch with the reads of high-copy repeats in front (see k_heavy_flags): flag_pass(count, flags, counter) launches the
