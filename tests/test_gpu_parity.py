@@ -601,6 +601,37 @@ def test_heavy_reads_first_hand_out_order(mix):
         assert same_hits(rhits, rwant) and rst.lf_steps == rnodes
 
 
+
+def test_ragged_batch_in_launches_side_by_side():
+    """A ragged batch through the equal-length kernels is one launch per read length, and up to eight of them run side by side — each on a stream, a share of the grid, a stretch of
+    the frame stacks, a hand-out counter and a board of its own (DfsWorkspace::fork / join).  45 000 reads of nine lengths in the caller's (mixed) order, on a repeat-rich text: records in
+    callback order and node counts equal the CPU walk — Hamming on the plain index (k_scheme_lean) and with LF tables (k_scheme_fast), edit distance (k_scheme_fast_edit) —, and the
+    same one launch after the other (FMGPU_SEL_NO_BOARD)"""
+    seqs = repeat_text(91, n=12000) + [np.tile(np.array([1, 1, 2, 3], dtype=np.uint8), 400)]
+    ox = fo.OraIndex.build("IB16", 5, seqs, 8, True)
+    rng = np.random.default_rng(5)
+    lengths = [24, 25, 31, 40, 41, 42, 57, 64, 80]
+    queries = []
+    for L in lengths:
+        queries += mutated_queries([q for q in seqs if len(q) > L], 5000, L, L + 1, 3, seed=100 + L)
+    order = rng.permutation(len(queries))
+    queries = [queries[int(t)] for t in order]
+    qbuf, qoff = fm.flatten(queries)
+    sch = fm.search_scheme.h2(4, 0, 2)
+    want = {False: ox.search_ng26(qbuf, qoff, sch, cap=1 << 25, nthreads=8, records=True), True: None}
+    eq, eo = fm.flatten([q for q in queries if len(q) in (31, 40)])       # (edit distance: two lengths, two launches side by side; the CPU walk of it runs on one thread)
+    want[True] = ox.search_ng26(eq, eo, sch, edit=True, cap=1 << 25)
+    for lf in (0, 1):
+        with fm.options(lf_table=lf):
+            gx = gpu_index(ox)
+        for sel in (0, capi.SEL_NO_BOARD):
+            with fm.options(kernel_select=sel):
+                hits, st = fm.search_ng26.search(gx, (qbuf, qoff), sch, want_stats=True, capacity=1 << 25)
+                ehits, est = fm.search_ng26.search(gx, (eq, eo), sch, want_stats=True, edit=True, capacity=1 << 25)
+            assert same_hits(hits, want[False][0]) and st.lf_steps == want[False][2], (lf, sel)
+            assert same_hits(ehits, want[True][0]) and est.lf_steps == want[True][2], (lf, sel)
+
+
 @pytest.mark.parametrize("k,length", [(1, 20), (2, 31), (2, 101), (2, 151), (2, 255), (3, 64), (0, 40)])
 def test_lean_kernel_on_the_plain_index(k, length):
     """equal-length batches on a BiFMIndex<5> WITHOUT any table take k_scheme_lean (top frame of the stack cached in LDS and refilled by LDS-DMA, hit ring
