@@ -283,8 +283,8 @@ __device__ __forceinline__ uint32_t flat_rank_lds(const lds_word* own, uint32_t 
     const uint32_t hi = (p01.y ^ i0) & (p01.w ^ i1) & (p23.y ^ i2) & (p23.w ^ i3) & (p4h ^ i4);
     return cnt + __popc(lo & mlo) + __popc(hi & mhi);
 }
-// the super table in LDS: 32-bit rows as they are; 64-bit rows as a low word + a high byte per entry (5 instead of 8 bytes: sigma = 28, 4.5 x 10^9 rows: 19 KB,
-// four resident blocks per CU; read through L2 instead the kernel took 13 % longer on the same text)
+// the super table in LDS: 32-bit rows as they are; 64-bit rows as a low word + a high byte per entry (5 instead of 8 bytes: sigma = 28, 4.5 x 10^9 rows: 19 KB;
+// read through L2 instead the kernel took 13 % longer on the same text)
 // Every workgroup stages its own copy of the table, beside the 33 KB of four waves' regions: 6.7 KB at 2 x 10^9 rows, 19 KB at 4.5 x 10^9, 42 KB at 10^10 (sigma = 28) — three, three and
 // two 256-lane workgroups per CU.  The kernel is instantiated for workgroups of 256 and 512 lanes (a CU has 160 KB of LDS and one workgroup may take all of it); the launch takes the size
 // that keeps the most waves resident (more than 16 gain nothing: they queue up at the memory system), and on a tie the LARGER one — half as many copies of the table are staged and held.

@@ -247,8 +247,8 @@ constexpr uint32_t kNoResume = 0xffffffffu;
 //     header word — a line of its own — until the batch is published or the launch is over (`state` = 0: no working wave, no untaken batch; it cannot rise again).  At most
 //     kBoardWaiters waves wait; the others leave (a poll is a read of memory);
 //   * a working wave looks at the board every kBoardPeriod-th pass — one load — and only if some lane of it has a subtree to give; if batches are asked for it takes the
-//     next index (one fetch-add), writes the bottom frames of ALL its offering lanes into that batch — one task per lane, up to 64 — and publishes the header; the sleeper
-//     wakes with that many lanes of work, which prove heavy in turn and give again.
+//     next index (one fetch-add), writes the bottom frames of ALL its offering lanes into that batch — up to kBoardFramesPerLane per lane, 64 subtrees in all — and publishes
+//     the header; the sleeper wakes with that many lanes of work, which prove heavy in turn and give again.
 // Hit records carry path keys (fmgpu_hits_sort orders them whoever found them), as for the sharing inside a wave: the board is on exactly when that sharing is.
 // No co-residency is assumed: a wave that starts late finds the batch handed out, asks, sees state = 0 and leaves.
 // What it took (tools/board_sweep.sh, development build): (1) polls are RELAXED loads — an acquire load invalidates the CU's L1 at every poll; (2) no fence anywhere (below);
